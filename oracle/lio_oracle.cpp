@@ -1,0 +1,1320 @@
+// =============================================================================
+// oracle/lio_oracle.cpp -- CPU ORACLE (TEST INFRASTRUCTURE ONLY)
+//
+// A plain C++17 restatement of the reference's FastLIO scan-matching hot path.
+// It is the *checker* for the HIP path and the `cpu_baseline` of bench.py.
+// Nothing under lidar-slam-detection_amd/ (the product) may include, link or
+// call this file; only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg do.
+//
+// PARITY STATUS: the reference ships no tests, fixtures or golden vectors for
+// this path and cannot be built as a whole here
+// (PCL, Boost, OpenCV absent).  The pieces of the reference that *can* be
+// compiled from where they lie (iVox, esti_plane, the MTK manifold math and the
+// IKFoM iterated update) are compiled into oracle/_ref by oracle/Makefile and
+// this restatement is checked against them in tests/test_oracle_vs_ref.py (the
+// committed fixtures under tests/golden/ come from that build).  PCL VoxelGrid
+// is third-party source that is not in the tree: that one stage stays
+// "parity unpinned" (restated from PCL 1.9.1 voxel_grid.hpp semantics).
+//
+// Reference lines followed (paths relative to /root/reference/slam/mapping/fastlio):
+//   voxel downsample ........ PCL 1.9.1 VoxelGrid::applyFilter, called at
+//                             src/laserMapping.cpp:1206-1207
+//   iVox map ................ include/ivox3d/ivox3d.h:139-171,179-210,231-261
+//                             include/ivox3d/ivox3d_node.hpp:87-127
+//                             include/ivox3d/eigen_types.h:73-76
+//   esti_plane .............. include/common_lib.h:236-268
+//   measurement model ....... src/laserMapping.cpp:813-982 (h_share_model_geometric)
+//                             src/laserMapping.cpp:984-1023 (h_share_model)
+//   map update .............. src/laserMapping.cpp:523-576 (map_incremental)
+//   per-scan driver ......... src/laserMapping.cpp:1126-1345 (fastlio_main)
+//   constants ............... src/laserMapping.cpp:1025-1124 (fastlio_init)
+//   iterated ESKF ........... include/IKFoM_toolkit/esekfom/esekfom.hpp:1619-1931
+//   manifold math ........... include/IKFoM_toolkit/mtk/src/mtkmath.hpp:142-174,235-288
+//                             include/IKFoM_toolkit/mtk/types/SOn.hpp:233-245,284-297
+//                             include/IKFoM_toolkit/mtk/types/S2.hpp:136-167,179-197,259-280
+//   state layout ............ include/use-ikfom.hpp:12-21
+//
+// Floating-point contract (shared with the HIP kernels so that per-point
+// results can be compared bit-for-bit): all per-point f32 arithmetic is written
+// as explicit, sequential IEEE operations and this file is compiled with
+// -ffp-contract=off (no FMA fusion); sqrt and division are correctly rounded.
+// Neighbour sets are put in a canonical total order (d2, x, y, z): the
+// reference only guarantees "element 0 is the nearest, the rest unordered"
+// (ivox3d.h:160-165), of which the canonical order is one valid instance.
+// =============================================================================
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <unordered_map>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct P4 {
+    float x, y, z, w;  // w = intensity
+};
+
+// ----------------------------------------------------------------------------
+// PCL 1.9.1 VoxelGrid<PointT>::applyFilter (third-party, source not in tree).
+// leaf -> inverse leaf in f32; bbox over finite points; int32 overflow guard
+// returns the input unchanged; idx = (floor(p*inv) - min_b) . (1, dx, dx*dy);
+// sort by idx; per-voxel centroid of all fields in f32 running sums, divided by
+// (float)count; output in ascending idx.  std::sort is unstable in PCL, so the
+// in-voxel summation order is unspecified there; this oracle fixes it to
+// ascending input index (one valid realisation).
+// ----------------------------------------------------------------------------
+int voxel_downsample(const P4* in, int n, float leaf, std::vector<P4>& out) {
+    out.clear();
+    if (n <= 0) return 0;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool any = false;
+    for (int i = 0; i < n; i++) {
+        if (!std::isfinite(in[i].x) || !std::isfinite(in[i].y) || !std::isfinite(in[i].z)) continue;
+        any = true;
+        mn[0] = std::min(mn[0], in[i].x); mx[0] = std::max(mx[0], in[i].x);
+        mn[1] = std::min(mn[1], in[i].y); mx[1] = std::max(mx[1], in[i].y);
+        mn[2] = std::min(mn[2], in[i].z); mx[2] = std::max(mx[2], in[i].z);
+    }
+    if (!any) return 0;
+    int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1;
+    int64_t dy = (int64_t)((mx[1] - mn[1]) * inv) + 1;
+    int64_t dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT32_MAX) {  // PCL: warn and output = input
+        out.assign(in, in + n);
+        return n;
+    }
+    int minb[3], maxb[3], divb[3];
+    for (int a = 0; a < 3; a++) {
+        minb[a] = (int)std::floor(mn[a] * inv);
+        maxb[a] = (int)std::floor(mx[a] * inv);
+        divb[a] = maxb[a] - minb[a] + 1;
+    }
+    const int mul1 = divb[0], mul2 = divb[0] * divb[1];
+    std::vector<std::pair<int, int>> iv;  // (voxel idx, point idx)
+    iv.reserve(n);
+    for (int i = 0; i < n; i++) {
+        if (!std::isfinite(in[i].x) || !std::isfinite(in[i].y) || !std::isfinite(in[i].z)) continue;
+        int i0 = (int)(std::floor(in[i].x * inv) - (float)minb[0]);
+        int i1 = (int)(std::floor(in[i].y * inv) - (float)minb[1]);
+        int i2 = (int)(std::floor(in[i].z * inv) - (float)minb[2]);
+        iv.emplace_back(i0 + i1 * mul1 + i2 * mul2, i);
+    }
+    std::sort(iv.begin(), iv.end());  // (idx, point index): in-voxel order = input order
+    size_t a = 0;
+    while (a < iv.size()) {
+        size_t b = a;
+        float sx = 0, sy = 0, sz = 0, sw = 0;
+        while (b < iv.size() && iv[b].first == iv[a].first) {
+            const P4& p = in[iv[b].second];
+            sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; sw = sw + p.w;
+            b++;
+        }
+        const float cnt = (float)(b - a);
+        out.push_back({sx / cnt, sy / cnt, sz / cnt, sw / cnt});
+        a = b;
+    }
+    return (int)out.size();
+}
+
+// ----------------------------------------------------------------------------
+// iVox (Faster-LIO linear iVox): ivox3d.h / ivox3d_node.hpp
+// ----------------------------------------------------------------------------
+struct Key3 {
+    int x, y, z;
+    bool operator==(const Key3& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct Key3Hash {  // eigen_types.h:73-76
+    size_t operator()(const Key3& v) const {
+        return size_t(((v.x) * 73856093) ^ ((v.y) * 471943) ^ ((v.z) * 83492791)) % 10000000;
+    }
+};
+struct Cand {
+    float d2;
+    P4 p;
+};
+inline bool cand_less(const Cand& a, const Cand& b) {  // canonical total order
+    if (a.d2 != b.d2) return a.d2 < b.d2;
+    if (a.p.x != b.p.x) return a.p.x < b.p.x;
+    if (a.p.y != b.p.y) return a.p.y < b.p.y;
+    return a.p.z < b.p.z;
+}
+inline float dist2(const P4& a, const P4& b) {  // ivox3d_node.hpp:12-15
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+struct IVoxNode {
+    double created;  // travel distance stamped at creation (ivox3d.h:240)
+    std::vector<P4> pts;
+};
+
+class IVox {
+   public:
+    using Cache = std::list<std::pair<Key3, IVoxNode>>;
+    float res, inv_res;
+    size_t capacity;
+    double max_distance;
+    std::vector<Key3> nearby;
+    std::unordered_map<Key3, Cache::iterator, Key3Hash> grids;
+    Cache cache;
+    int stencil_id = 0;
+
+    IVox(float r, int stencil, size_t cap, double maxd) : res(r), inv_res(1.0f / r), capacity(cap), max_distance(maxd) {
+        set_stencil(stencil);
+    }
+    // ivox3d.h:179-210
+    void set_stencil(int s) {
+        stencil_id = s;
+        nearby.clear();
+        static const int n18[19][3] = {{0, 0, 0},  {-1, 0, 0}, {1, 0, 0},   {0, 1, 0},  {0, -1, 0}, {0, 0, -1}, {0, 0, 1},
+                                       {1, 1, 0},  {-1, 1, 0}, {1, -1, 0},  {-1, -1, 0}, {1, 0, 1},  {-1, 0, 1}, {1, 0, -1},
+                                       {-1, 0, -1}, {0, 1, 1},  {0, -1, 1},  {0, 1, -1}, {0, -1, -1}};
+        static const int n26x[8][3] = {{1, 1, 1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1}, {-1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, -1, -1}};
+        if (s == 1) {
+            nearby.push_back({0, 0, 0});
+        } else if (s == 7) {
+            for (int i = 0; i < 7; i++) nearby.push_back({n18[i][0], n18[i][1], n18[i][2]});
+        } else if (s == 19) {
+            for (int i = 0; i < 19; i++) nearby.push_back({n18[i][0], n18[i][1], n18[i][2]});
+        } else if (s == 27) {
+            for (int i = 0; i < 19; i++) nearby.push_back({n18[i][0], n18[i][1], n18[i][2]});
+            for (int i = 0; i < 8; i++) nearby.push_back({n26x[i][0], n26x[i][1], n26x[i][2]});
+        } else if (s == 75) {  // "NEARBY74" generates 5x5x3 = 75 offsets incl. centre
+            for (int i = -2; i <= 2; i++)
+                for (int j = -2; j <= 2; j++)
+                    for (int k = -1; k <= 1; k++) nearby.push_back({i, j, k});
+        }
+    }
+    Key3 pos2grid(const P4& p) const {  // ivox3d.h:258-261 (round half away from zero)
+        return {(int)std::round(p.x * inv_res), (int)std::round(p.y * inv_res), (int)std::round(p.z * inv_res)};
+    }
+    // ivox3d.h:231-256
+    void add_points(const P4* pts, int n, double distance) {
+        for (int i = 0; i < n; i++) {
+            Key3 key = pos2grid(pts[i]);
+            auto it = grids.find(key);
+            if (it == grids.end()) {
+                cache.push_front({key, IVoxNode{distance, {}}});
+                grids.insert({key, cache.begin()});
+                cache.front().second.pts.push_back(pts[i]);
+            } else {
+                it->second->second.pts.push_back(pts[i]);
+                cache.splice(cache.begin(), cache, it->second);
+                grids[key] = cache.begin();
+            }
+            if (grids.size() > capacity && (distance - cache.back().second.created) > max_distance) {
+                grids.erase(cache.back().first);
+                cache.pop_back();
+            }
+        }
+    }
+    // ivox3d.h:139-171.  Returns false and leaves `closest` UNTOUCHED when no
+    // candidate lies inside the stencil within the range (ivox3d.h:152-154):
+    // the caller's stale content survives, as in the reference.
+    bool closest(const P4& q, std::vector<P4>& closest_pt, int max_num, double max_sq, std::vector<Cand>& scratch) const {
+        scratch.clear();
+        Key3 key = pos2grid(q);
+        for (const Key3& d : nearby) {
+            auto it = grids.find(Key3{key.x + d.x, key.y + d.y, key.z + d.z});
+            if (it == grids.end()) continue;
+            for (const P4& p : it->second->second.pts) {
+                float d2 = dist2(p, q);
+                if ((double)d2 < max_sq) scratch.push_back({d2, p});
+            }
+        }
+        if (scratch.empty()) return false;
+        size_t k = std::min((size_t)max_num, scratch.size());
+        std::partial_sort(scratch.begin(), scratch.begin() + k, scratch.end(), cand_less);
+        closest_pt.clear();
+        for (size_t i = 0; i < k; i++) closest_pt.push_back(scratch[i].p);
+        return true;
+    }
+    size_t num_points() const {
+        size_t s = 0;
+        for (auto& kv : cache) s += kv.second.pts.size();
+        return s;
+    }
+};
+
+// ----------------------------------------------------------------------------
+// esti_plane (common_lib.h:236-268): solve A n = -1 (5x3, f32) by column-pivoted
+// Householder QR, normalise, reject if any |n.q + d| > threshold.
+// The QR follows Eigen's ColPivHouseholderQR algorithm (pivot on the largest
+// remaining column norm with LAPACK-style norm down-dating, Householder
+// reflector H = I - tau v v^T with v0 = 1, rank from the pivot threshold) written
+// as explicit sequential f32 operations.
+// ----------------------------------------------------------------------------
+bool esti_plane(float pabcd[4], const P4* pt, float threshold) {
+    const int R = 5, C = 3;
+    float A[R][C];
+    float b[R];
+    for (int j = 0; j < R; j++) {
+        A[j][0] = pt[j].x; A[j][1] = pt[j].y; A[j][2] = pt[j].z;
+        b[j] = -1.0f;
+    }
+    const float eps = 1.1920929e-07f;  // FLT_EPSILON
+    float normUpd[C], normDir[C];
+    int perm[C] = {0, 1, 2};
+    float hcoef[C];
+    float maxnorm = 0.f;
+    for (int k = 0; k < C; k++) {
+        float s = 0.f;
+        for (int r = 0; r < R; r++) s = s + A[r][k] * A[r][k];
+        normDir[k] = sqrtf(s);
+        normUpd[k] = normDir[k];
+        maxnorm = fmaxf(maxnorm, normDir[k]);
+    }
+    const float thr_helper = ((maxnorm * eps) * (maxnorm * eps)) / (float)R;
+    const float downdate_thr = sqrtf(eps);
+    int nonzero = C;
+    float maxpivot = 0.f;
+    for (int k = 0; k < C; k++) {
+        int big = k;
+        float bigv = normUpd[k];
+        for (int j = k + 1; j < C; j++)
+            if (normUpd[j] > bigv) { bigv = normUpd[j]; big = j; }
+        const float big_sq = bigv * bigv;
+        if (nonzero == C && big_sq < thr_helper * (float)(R - k)) nonzero = k;
+        if (big != k) {
+            for (int r = 0; r < R; r++) { float t = A[r][k]; A[r][k] = A[r][big]; A[r][big] = t; }
+            { float t = normUpd[k]; normUpd[k] = normUpd[big]; normUpd[big] = t; }
+            { float t = normDir[k]; normDir[k] = normDir[big]; normDir[big] = t; }
+            { int t = perm[k]; perm[k] = perm[big]; perm[big] = t; }
+        }
+        // Householder on A[k..R-1][k]
+        const float c0 = A[k][k];
+        float tail = 0.f;
+        for (int r = k + 1; r < R; r++) tail = tail + A[r][k] * A[r][k];
+        float tau, beta;
+        if (tail <= 1.17549435e-38f) {
+            tau = 0.f; beta = c0;
+            for (int r = k + 1; r < R; r++) A[r][k] = 0.f;
+        } else {
+            beta = sqrtf(c0 * c0 + tail);
+            if (c0 >= 0.f) beta = -beta;
+            const float den = c0 - beta;
+            for (int r = k + 1; r < R; r++) A[r][k] = A[r][k] / den;
+            tau = (beta - c0) / beta;
+        }
+        A[k][k] = beta;
+        hcoef[k] = tau;
+        if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
+        // apply H to trailing columns and to b later
+        if (tau != 0.f) {
+            for (int j = k + 1; j < C; j++) {
+                float t = 0.f;  // tmp = essential^T * bottom; tmp += row0  (Eigen Householder.h order)
+                for (int r = k + 1; r < R; r++) t = t + A[r][k] * A[r][j];
+                t = t + A[k][j];
+                A[k][j] = A[k][j] - tau * t;
+                for (int r = k + 1; r < R; r++) A[r][j] = A[r][j] - (tau * A[r][k]) * t;
+            }
+        }
+        for (int j = k + 1; j < C; j++) {
+            if (normUpd[j] != 0.f) {
+                float t = fabsf(A[k][j]) / normUpd[j];
+                t = (1.f + t) * (1.f - t);
+                if (t < 0.f) t = 0.f;
+                const float ratio = normUpd[j] / normDir[j];
+                const float t2 = t * (ratio * ratio);
+                if (t2 <= downdate_thr) {
+                    float s = 0.f;
+                    for (int r = k + 1; r < R; r++) s = s + A[r][j] * A[r][j];
+                    normDir[j] = sqrtf(s);
+                    normUpd[j] = normDir[j];
+                } else {
+                    normUpd[j] = normUpd[j] * sqrtf(t);
+                }
+            }
+        }
+    }
+    (void)maxpivot;
+    // c = Q^T b
+    for (int k = 0; k < nonzero; k++) {
+        const float tau = hcoef[k];
+        if (tau != 0.f) {
+            float t = 0.f;
+            for (int r = k + 1; r < R; r++) t = t + A[r][k] * b[r];
+            t = t + b[k];
+            b[k] = b[k] - tau * t;
+            for (int r = k + 1; r < R; r++) b[r] = b[r] - (tau * A[r][k]) * t;
+        }
+    }
+    float xs[C] = {0.f, 0.f, 0.f};
+    for (int i = nonzero - 1; i >= 0; i--) {
+        float s = b[i];
+        for (int j = i + 1; j < nonzero; j++) s = s - A[i][j] * xs[j];
+        xs[i] = s / A[i][i];
+    }
+    float nv[C] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < nonzero; i++) nv[perm[i]] = xs[i];
+    const float n = sqrtf((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
+    pabcd[0] = nv[0] / n;
+    pabcd[1] = nv[1] / n;
+    pabcd[2] = nv[2] / n;
+    pabcd[3] = 1.0f / n;
+    for (int j = 0; j < R; j++) {
+        const float v = ((pabcd[0] * pt[j].x + pabcd[1] * pt[j].y) + pabcd[2] * pt[j].z) + pabcd[3];
+        if (fabsf(v) > threshold) return false;
+    }
+    return true;
+}
+
+// ----------------------------------------------------------------------------
+// small dense f64 matrix helper (row-major)
+// ----------------------------------------------------------------------------
+struct Mat {
+    int r = 0, c = 0;
+    std::vector<double> a;
+    Mat() {}
+    Mat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
+    double& operator()(int i, int j) { return a[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+    static Mat eye(int n) { Mat m(n, n); for (int i = 0; i < n; i++) m(i, i) = 1; return m; }
+};
+Mat mul(const Mat& A, const Mat& B) {
+    Mat C(A.r, B.c);
+    for (int i = 0; i < A.r; i++)
+        for (int k = 0; k < A.c; k++) {
+            const double v = A(i, k);
+            if (v == 0.0) continue;
+            for (int j = 0; j < B.c; j++) C(i, j) += v * B(k, j);
+        }
+    return C;
+}
+Mat transpose(const Mat& A) {
+    Mat T(A.c, A.r);
+    for (int i = 0; i < A.r; i++) for (int j = 0; j < A.c; j++) T(j, i) = A(i, j);
+    return T;
+}
+// inverse by LU with partial pivoting (what Eigen's inverse() does for n > 4)
+Mat inverse(const Mat& A) {
+    const int n = A.r;
+    Mat LU = A;
+    std::vector<int> piv(n);
+    for (int i = 0; i < n; i++) piv[i] = i;
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        double best = std::fabs(LU(k, k));
+        for (int i = k + 1; i < n; i++) if (std::fabs(LU(i, k)) > best) { best = std::fabs(LU(i, k)); p = i; }
+        if (p != k) { for (int j = 0; j < n; j++) std::swap(LU(k, j), LU(p, j)); std::swap(piv[k], piv[p]); }
+        for (int i = k + 1; i < n; i++) {
+            LU(i, k) /= LU(k, k);
+            const double f = LU(i, k);
+            for (int j = k + 1; j < n; j++) LU(i, j) -= f * LU(k, j);
+        }
+    }
+    Mat X(n, n);
+    for (int col = 0; col < n; col++) {
+        std::vector<double> y(n);
+        for (int i = 0; i < n; i++) {
+            double s = (piv[i] == col) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) s -= LU(i, j) * y[j];
+            y[i] = s;
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = y[i];
+            for (int j = i + 1; j < n; j++) s -= LU(i, j) * X(j, col);
+            X(i, col) = s / LU(i, i);
+        }
+    }
+    return X;
+}
+
+// 3x3 helpers
+struct V3 { double v[3]; double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } };
+inline V3 cross(const V3& a, const V3& b) { return {{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}}; }
+struct Quat { double x, y, z, w; };  // Eigen coeffs order
+inline Quat qmul(const Quat& a, const Quat& b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+            a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+inline Quat qconj(const Quat& q) { return {-q.x, -q.y, -q.z, q.w}; }
+// Eigen QuaternionBase::_transformVector: uv = 2 (q.vec x v); v + w uv + q.vec x uv
+inline V3 qrot(const Quat& q, const V3& v) {
+    V3 qv{{q.x, q.y, q.z}};
+    V3 uv = cross(qv, v);
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    V3 c2 = cross(qv, uv);
+    return {{(v[0] + q.w * uv[0]) + c2[0], (v[1] + q.w * uv[1]) + c2[1], (v[2] + q.w * uv[2]) + c2[2]}};
+}
+// Eigen QuaternionBase::toRotationMatrix
+inline void qtoR(const Quat& q, double R[9]) {
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+inline void hat(const V3& v, double H[9]) {
+    H[0] = 0; H[1] = -v[2]; H[2] = v[1];
+    H[3] = v[2]; H[4] = 0; H[5] = -v[0];
+    H[6] = -v[1]; H[7] = v[0]; H[8] = 0;
+}
+inline void mm3(const double A[9], const double B[9], double C[9]) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[i * 3 + k] * B[k * 3 + j]; C[i * 3 + j] = s; }
+}
+
+const double kTol = 1e-11;  // MTK::tolerance<double>()
+
+// mtkmath.hpp:142-174
+inline void cos_sinc_sqrt(double x2, double& c, double& s) {
+    const double t0 = 2.220446049250313e-16;  // epsilon<double>
+    const double t2 = std::sqrt(t0);
+    const double tn = std::sqrt(t2);
+    if (x2 >= tn) { double x = std::sqrt(x2); c = std::cos(x); s = std::sin(x) / x; return; }
+    static const double inv[] = {1 / 3., 1 / 4., 1 / 5., 1 / 6., 1 / 7., 1 / 8., 1 / 9.};
+    double cosi = 1., sinc = 1.;
+    double term = -1 / 2. * x2;
+    for (int i = 0; i < 3; ++i) {
+        cosi += term; term *= inv[2 * i];
+        sinc += term; term *= -inv[2 * i + 1] * x2;
+    }
+    c = cosi; s = sinc;
+}
+// mtkmath.hpp:249-256: returns w, writes vec part
+inline Quat mtk_exp(const V3& v, double scale) {
+    const double n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    double c, s;
+    cos_sinc_sqrt(scale * scale * n2, c, s);
+    const double m = s * scale;
+    return {m * v[0], m * v[1], m * v[2], c};
+}
+// mtkmath.hpp:268-288 with plus_minus_periodicity = true, scale 2 (SOn.hpp:293-297)
+inline V3 so3_log(const Quat& q) {
+    double nv = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+    if (nv < kTol) nv = kTol;
+    const double s = 2.0 / nv * std::atan(nv / q.w);
+    return {{s * q.x, s * q.y, s * q.z}};
+}
+// mtkmath.hpp:235-247
+inline void A_matrix(const V3& v, double A[9]) {
+    const double sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const double n = std::sqrt(sq);
+    for (int i = 0; i < 9; i++) A[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (n < kTol) return;
+    double H[9], HH[9];
+    hat(v, H);
+    mm3(H, H, HH);
+    const double a = (1 - std::cos(n)) / sq, b = (1 - std::sin(n) / n) / sq;
+    for (int i = 0; i < 9; i++) A[i] += a * H[i] + b * HH[i];
+}
+
+// S2<double, 98090, 10000, 1> (use-ikfom.hpp:8): length 9.809, S2_typ = 1
+const double kS2Len = 98090.0 / 10000.0;
+inline void S2_Bx(const V3& vec, double Bx[6]) {  // 3x2 row-major; S2.hpp:179-245 (typ 1 branch)
+    const double L = kS2Len;
+    if (vec[0] + L > kTol) {
+        Bx[0] = -vec[1]; Bx[1] = -vec[2];
+        Bx[2] = L - vec[1] * vec[1] / (L + vec[0]); Bx[3] = -vec[2] * vec[1] / (L + vec[0]);
+        Bx[4] = -vec[2] * vec[1] / (L + vec[0]); Bx[5] = L - vec[2] * vec[2] / (L + vec[0]);
+        for (int i = 0; i < 6; i++) Bx[i] /= L;
+    } else {
+        for (int i = 0; i < 6; i++) Bx[i] = 0;
+        Bx[3] = -1;  // res(1,1)
+        Bx[4] = 1;   // res(2,0)
+    }
+}
+inline void S2_boxplus(V3& vec, const double d[2]) {  // S2.hpp:136-142
+    double Bx[6];
+    S2_Bx(vec, Bx);
+    V3 Bu{{Bx[0] * d[0] + Bx[1] * d[1], Bx[2] * d[0] + Bx[3] * d[1], Bx[4] * d[0] + Bx[5] * d[1]}};
+    Quat e = mtk_exp(Bu, 0.5);
+    double R[9];
+    qtoR(e, R);
+    V3 o;
+    for (int i = 0; i < 3; i++) o[i] = R[i * 3] * vec[0] + R[i * 3 + 1] * vec[1] + R[i * 3 + 2] * vec[2];
+    vec = o;
+}
+inline void S2_boxminus(const V3& vec, const V3& other, double res[2]) {  // S2.hpp:144-167
+    double H[9];
+    hat(vec, H);
+    V3 hv{{H[0] * other[0] + H[1] * other[1] + H[2] * other[2], H[3] * other[0] + H[4] * other[1] + H[5] * other[2],
+           H[6] * other[0] + H[7] * other[1] + H[8] * other[2]}};
+    const double v_sin = std::sqrt(hv[0] * hv[0] + hv[1] * hv[1] + hv[2] * hv[2]);
+    const double v_cos = vec[0] * other[0] + vec[1] * other[1] + vec[2] * other[2];
+    const double theta = std::atan2(v_sin, v_cos);
+    if (v_sin < kTol) {
+        if (std::fabs(theta) > kTol) { res[0] = 3.1415926; res[1] = 0; }
+        else { res[0] = 0; res[1] = 0; }
+    } else {
+        double Bx[6];
+        S2_Bx(other, Bx);
+        double Ho[9];
+        hat(other, Ho);
+        V3 t{{Ho[0] * vec[0] + Ho[1] * vec[1] + Ho[2] * vec[2], Ho[3] * vec[0] + Ho[4] * vec[1] + Ho[5] * vec[2],
+              Ho[6] * vec[0] + Ho[7] * vec[1] + Ho[8] * vec[2]}};
+        const double f = theta / v_sin;
+        res[0] = f * (Bx[0] * t[0] + Bx[2] * t[1] + Bx[4] * t[2]);
+        res[1] = f * (Bx[1] * t[0] + Bx[3] * t[1] + Bx[5] * t[2]);
+    }
+}
+inline void S2_Nx_yy(const V3& vec, double N[6]) {  // 2x3; S2.hpp:259-264
+    double Bx[6], H[9];
+    S2_Bx(vec, Bx);
+    hat(vec, H);
+    const double f = 1 / kS2Len / kS2Len;
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += Bx[k * 2 + i] * H[k * 3 + j];
+            N[i * 3 + j] = f * s;
+        }
+}
+inline void S2_Mx(const V3& vec, const double delta[2], double M[6]) {  // 3x2; S2.hpp:266-280
+    double Bx[6], H[9];
+    S2_Bx(vec, Bx);
+    hat(vec, H);
+    const double dn = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1]);
+    if (dn < kTol) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 2; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += H[i * 3 + k] * Bx[k * 2 + j];
+                M[i * 2 + j] = -s;
+            }
+    } else {
+        V3 Bu{{Bx[0] * delta[0] + Bx[1] * delta[1], Bx[2] * delta[0] + Bx[3] * delta[1], Bx[4] * delta[0] + Bx[5] * delta[1]}};
+        // exp_delta built with scale scalar(1/2) == 0 (integer division, S2.hpp:277) -> identity rotation
+        Quat e = mtk_exp(Bu, 0.0);
+        double E[9], A[9], T1[9], T2[9];
+        qtoR(e, E);
+        A_matrix(Bu, A);
+        double At[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[i * 3 + j] = A[j * 3 + i];
+        mm3(E, H, T1);
+        mm3(T1, At, T2);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 2; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += T2[i * 3 + k] * Bx[k * 2 + j];
+                M[i * 2 + j] = -s;
+            }
+    }
+}
+
+// state_ikfom (use-ikfom.hpp:12-21); 23 DoF: pos0 rot3 R_il6 t_il9 vel12 bg15 ba18 grav21
+struct State {
+    V3 pos;
+    Quat rot;
+    Quat ril;
+    V3 til;
+    V3 vel, bg, ba;
+    V3 grav;
+};
+void state_from(const double* s, State& x) {
+    for (int i = 0; i < 3; i++) x.pos[i] = s[i];
+    x.rot = {s[3], s[4], s[5], s[6]};
+    x.ril = {s[7], s[8], s[9], s[10]};
+    for (int i = 0; i < 3; i++) { x.til[i] = s[11 + i]; x.vel[i] = s[14 + i]; x.bg[i] = s[17 + i]; x.ba[i] = s[20 + i]; x.grav[i] = s[23 + i]; }
+}
+void state_to(const State& x, double* s) {
+    for (int i = 0; i < 3; i++) s[i] = x.pos[i];
+    s[3] = x.rot.x; s[4] = x.rot.y; s[5] = x.rot.z; s[6] = x.rot.w;
+    s[7] = x.ril.x; s[8] = x.ril.y; s[9] = x.ril.z; s[10] = x.ril.w;
+    for (int i = 0; i < 3; i++) { s[11 + i] = x.til[i]; s[14 + i] = x.vel[i]; s[17 + i] = x.bg[i]; s[20 + i] = x.ba[i]; s[23 + i] = x.grav[i]; }
+}
+void state_boxplus(State& x, const double* d) {
+    for (int i = 0; i < 3; i++) x.pos[i] += d[i];
+    x.rot = qmul(x.rot, mtk_exp(V3{{d[3], d[4], d[5]}}, 0.5));
+    x.ril = qmul(x.ril, mtk_exp(V3{{d[6], d[7], d[8]}}, 0.5));
+    for (int i = 0; i < 3; i++) { x.til[i] += d[9 + i]; x.vel[i] += d[12 + i]; x.bg[i] += d[15 + i]; x.ba[i] += d[18 + i]; }
+    S2_boxplus(x.grav, d + 21);
+}
+void state_boxminus(const State& x, const State& o, double* d) {
+    for (int i = 0; i < 3; i++) d[i] = x.pos[i] - o.pos[i];
+    V3 r = so3_log(qmul(qconj(o.rot), x.rot));
+    V3 r2 = so3_log(qmul(qconj(o.ril), x.ril));
+    for (int i = 0; i < 3; i++) { d[3 + i] = r[i]; d[6 + i] = r2[i]; }
+    for (int i = 0; i < 3; i++) { d[9 + i] = x.til[i] - o.til[i]; d[12 + i] = x.vel[i] - o.vel[i]; d[15 + i] = x.bg[i] - o.bg[i]; d[18 + i] = x.ba[i] - o.ba[i]; }
+    S2_boxminus(x.grav, o.grav, d + 21);
+}
+
+// symmetric 3x3 eigen decomposition (cyclic Jacobi, f64); columns of V are eigenvectors.
+void eig3(const double Ain[9], double w[3], double V[9]) {
+    double A[9];
+    std::memcpy(A, Ain, sizeof(A));
+    for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                const double apq = A[p * 3 + q];
+                if (apq == 0.0) continue;
+                const double app = A[p * 3 + p], aqq = A[q * 3 + q];
+                const double theta = (aqq - app) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+                    A[k * 3 + p] = c * akp - s * akq;
+                    A[k * 3 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+                    A[p * 3 + k] = c * apk - s * aqk;
+                    A[q * 3 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                    V[k * 3 + p] = c * vkp - s * vkq;
+                    V[k * 3 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
+    // ascending order like SelfAdjointEigenSolver
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (w[j] < w[i]) {
+                std::swap(w[i], w[j]);
+                for (int k = 0; k < 3; k++) std::swap(V[k * 3 + i], V[k * 3 + j]);
+            }
+}
+
+// ----------------------------------------------------------------------------
+// The LIO engine: file-scope globals of laserMapping.cpp gathered in a struct.
+// ----------------------------------------------------------------------------
+struct DynShare {  // esekfom.hpp:80-90
+    bool valid = true, converge = true;
+    Mat h_x;  // N x 15
+    std::vector<double> h;
+};
+
+struct PassLog {
+    int knn;          // this pass redid the neighbour search
+    int n_eff;        // effct_feat_num
+    int valid;        // dyn_share.valid after h_share_model
+    int degenerate;
+    double sum_abs_res;
+    double JtJ[36];   // top-left 6x6 of HTH (after degeneracy projection)
+    double Jtr[6];    // first 6 of h_x^T h
+    double dx[23];
+};
+
+const int kMaxPts = 100000;  // fixed arrays, laserMapping.cpp:86,103,122-124
+
+struct Lio {
+    // constants (fastlio_init, laserMapping.cpp:1025-1124)
+    int max_iter = 4;
+    float leaf_surf = 0.5f, leaf_map = 0.5f;
+    double init_time = 0.1;       // INIT_TIME
+    double laser_cov = 0.001;     // LASER_POINT_COV
+    bool degenerate_detect_en = true, extrinsic_est_en = false;
+    double limit[23];
+    int threads = 1;
+
+    IVox ivox;
+    State x;
+    Mat P;
+    double travel = 0, first_lidar_time = 0;
+    V3 last_pos_lid{{0, 0, 0}};
+    bool flg_first_scan = true, flg_EKF_inited = false, is_degenerate = false;
+    double res_mean_last = 0.05, total_residual = 0;
+    int effct_feat_num = 0;
+
+    std::vector<P4> ds_body, ds_world;
+    std::vector<std::vector<P4>> nearest;  // Nearest_Points: persists across scans
+    std::vector<uint8_t> selected;         // point_selected_surf (init true)
+    std::vector<P4> normvec;
+    std::vector<float> res_last;
+    std::vector<PassLog> log;
+    int n_ds = 0;
+
+    Lio(float res, int stencil, size_t cap, double maxd) : ivox(res, stencil, cap, maxd), P(Mat::eye(23)) {
+        for (int i = 0; i < 23; i++) limit[i] = 0.001;
+        selected.assign(kMaxPts, 1);
+        normvec.assign(kMaxPts, P4{0, 0, 0, 0});
+        res_last.assign(kMaxPts, 0.f);
+        x.pos = {{0, 0, 0}}; x.rot = {0, 0, 0, 1}; x.ril = {0, 0, 0, 1};
+        x.til = x.vel = x.bg = x.ba = {{0, 0, 0}};
+        x.grav = {{kS2Len, 0, 0}};
+    }
+
+    P4 body_to_world(const State& s, const P4& pb) const {  // laserMapping.cpp:189-198 / 831-836
+        V3 p{{(double)pb.x, (double)pb.y, (double)pb.z}};
+        V3 pi = qrot(s.ril, p);
+        pi[0] += s.til[0]; pi[1] += s.til[1]; pi[2] += s.til[2];
+        V3 pw = qrot(s.rot, pi);
+        return {(float)(pw[0] + s.pos[0]), (float)(pw[1] + s.pos[1]), (float)(pw[2] + s.pos[2]), pb.w};
+    }
+
+    // laserMapping.cpp:813-982
+    void h_share_model_geometric(const State& s, DynShare& d) {
+        total_residual = 0.0;
+        const int n = n_ds;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+        {
+            std::vector<Cand> scratch;
+            scratch.reserve(512);
+#ifdef _OPENMP
+#pragma omp for
+#endif
+            for (int i = 0; i < n; i++) {
+                const P4& pb = ds_body[i];
+                P4 pw = body_to_world(s, pb);
+                ds_world[i] = pw;
+                auto& near = nearest[i];
+                if (d.converge) {
+                    ivox.closest(pw, near, 5, 5.0, scratch);
+                    selected[i] = near.size() < 5 ? 0 : 1;
+                }
+                if (!selected[i]) continue;
+                float pabcd[4];
+                selected[i] = 0;
+                if (esti_plane(pabcd, near.data(), 0.1f)) {
+                    const float pd2 = ((pabcd[0] * pw.x + pabcd[1] * pw.y) + pabcd[2] * pw.z) + pabcd[3];
+                    const double pbn = std::sqrt(((double)pb.x * pb.x + (double)pb.y * pb.y) + (double)pb.z * pb.z);
+                    // float s = 1 - 0.9 * fabs(pd2) / sqrt(p_body.norm());  (evaluated in double, stored float)
+                    const float sc = (float)(1 - 0.9 * std::fabs((double)pd2) / std::sqrt(pbn));
+                    if ((double)sc > 0.9) {
+                        selected[i] = 1;
+                        normvec[i] = {pabcd[0], pabcd[1], pabcd[2], pd2};
+                        res_last[i] = std::fabs(pd2);
+                    }
+                }
+            }
+        }
+        effct_feat_num = 0;
+        std::vector<int> sel;
+        for (int i = 0; i < n; i++)
+            if (selected[i]) { sel.push_back(i); total_residual += res_last[i]; effct_feat_num++; }
+        if (effct_feat_num < 1) { d.valid = false; return; }
+        res_mean_last = total_residual / effct_feat_num;
+
+        d.h_x = Mat(effct_feat_num, 15);
+        d.h.assign(effct_feat_num, 0.0);
+        for (int r = 0; r < effct_feat_num; r++) {
+            const P4& lp = ds_body[sel[r]];
+            const P4& np = normvec[sel[r]];
+            V3 pbe{{(double)lp.x, (double)lp.y, (double)lp.z}};
+            V3 pthis = qrot(s.ril, pbe);
+            pthis[0] += s.til[0]; pthis[1] += s.til[1]; pthis[2] += s.til[2];
+            V3 nv{{(double)np.x, (double)np.y, (double)np.z}};
+            V3 Cv = qrot(qconj(s.rot), nv);
+            V3 Av = cross(pthis, Cv);  // point_crossmat * C
+            d.h_x(r, 0) = np.x; d.h_x(r, 1) = np.y; d.h_x(r, 2) = np.z;
+            d.h_x(r, 3) = Av[0]; d.h_x(r, 4) = Av[1]; d.h_x(r, 5) = Av[2];
+            if (extrinsic_est_en) {
+                V3 t = qrot(qconj(s.ril), Cv);
+                V3 Bv = cross(pbe, t);
+                for (int k = 0; k < 3; k++) { d.h_x(r, 6 + k) = Bv[k]; d.h_x(r, 9 + k) = Cv[k]; }
+            }
+            d.h[r] = -(double)np.w;
+        }
+        if (degenerate_detect_en) {
+            is_degenerate = false;
+            double HTH[9] = {0};
+            for (int r = 0; r < effct_feat_num; r++)
+                for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) HTH[a * 3 + b] += d.h_x(r, a) * d.h_x(r, b);
+            double w[3], V[9];
+            eig3(HTH, w, V);
+            double V2[9];  // mat_v2 = V^T
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) V2[a * 3 + b] = V[b * 3 + a];
+            for (int i = 0; i < 3; i++) {
+                float contri = 0, strong = 0;
+                for (int r = 0; r < effct_feat_num; r++) {
+                    double f0 = d.h_x(r, 0), f1 = d.h_x(r, 1), f2 = d.h_x(r, 2);
+                    const double nn = std::sqrt(f0 * f0 + f1 * f1 + f2 * f2);
+                    if (nn > 0) { f0 /= nn; f1 /= nn; f2 /= nn; }
+                    const float dotp = (float)std::fabs(f0 * V[0 * 3 + i] + f1 * V[1 * 3 + i] + f2 * V[2 * 3 + i]);
+                    if (dotp > 0.1736f) contri += dotp;
+                    if (dotp > 0.7070f) strong += dotp;
+                }
+                if (contri < 250.0f && strong < 50.0f) {
+                    for (int j = 0; j < 3; j++) V2[i * 3 + j] = 0;
+                    is_degenerate = true;
+                }
+            }
+            if (is_degenerate) {
+                // mat_p = (V^T)^-1 * V2 ; h_x[:, :3] = (mat_p * h_x[:, :3]^T)^T
+                Mat Vt(3, 3), V2m(3, 3);
+                for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { Vt(a, b) = V[b * 3 + a]; V2m(a, b) = V2[a * 3 + b]; }
+                Mat Pm = mul(inverse(Vt), V2m);
+                for (int r = 0; r < effct_feat_num; r++) {
+                    double o[3] = {d.h_x(r, 0), d.h_x(r, 1), d.h_x(r, 2)};
+                    for (int a = 0; a < 3; a++) d.h_x(r, a) = Pm(a, 0) * o[0] + Pm(a, 1) * o[1] + Pm(a, 2) * o[2];
+                }
+            }
+        }
+    }
+
+    // laserMapping.cpp:984-1023 (wheelspeed_en == false -> wheel block never valid)
+    void h_share_model(const State& s, DynShare& d) {
+        DynShare geo = d;  // copy: stale h_x / h of the previous pass survive an early return
+        h_share_model_geometric(s, geo);
+        const int n_terms = (int)geo.h.size();
+        d.h_x = geo.h_x;
+        d.h = geo.h;
+        if (n_terms == 0) d.valid = false;
+    }
+
+    // esekfom.hpp:1619-1931
+    void update_iterated(double R) {
+        DynShare dyn;
+        dyn.valid = true;
+        dyn.converge = true;
+        int t = 0;
+        const State x_prop = x;
+        const Mat P_prop = P;
+        const int n = 23;
+        Mat K_x(n, n);
+        std::vector<double> K_h(n, 0.0);
+        double dx_new[23] = {0};
+        log.clear();
+        for (int i = -1; i < max_iter; i++) {
+            dyn.valid = true;
+            PassLog pl;
+            std::memset(&pl, 0, sizeof(pl));
+            pl.knn = dyn.converge ? 1 : 0;
+            h_share_model(x, dyn);
+            pl.valid = dyn.valid;
+            pl.n_eff = effct_feat_num;
+            pl.degenerate = is_degenerate;
+            pl.sum_abs_res = total_residual;
+            if (!dyn.valid) { log.push_back(pl); continue; }
+            const Mat& hx = dyn.h_x;
+            const int dof = hx.r;
+            double dx[23];
+            state_boxminus(x, x_prop, dx);
+            for (int k = 0; k < 23; k++) dx_new[k] = dx[k];
+            P = P_prop;
+            const int so3_idx[2] = {3, 6};
+            for (int si = 0; si < 2; si++) {
+                const int idx = so3_idx[si];
+                double A[9], J[9];
+                A_matrix(V3{{dx[idx], dx[idx + 1], dx[idx + 2]}}, A);
+                for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) J[a * 3 + b] = A[b * 3 + a];
+                apply_left3(J, dx_new + idx);
+                apply_rows3(P, idx, J);
+                apply_cols3(P, idx, J);
+            }
+            {
+                const int idx = 21;
+                double Nx[6], Mx[6], J[4];
+                double seg[2] = {dx[idx], dx[idx + 1]};
+                S2_Nx_yy(x.grav, Nx);
+                S2_Mx(x_prop.grav, seg, Mx);
+                for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { double s = 0; for (int k = 0; k < 3; k++) s += Nx[a * 3 + k] * Mx[k * 2 + b]; J[a * 2 + b] = s; }
+                double t0 = J[0] * dx_new[idx] + J[1] * dx_new[idx + 1], t1 = J[2] * dx_new[idx] + J[3] * dx_new[idx + 1];
+                dx_new[idx] = t0; dx_new[idx + 1] = t1;
+                apply_rows2(P, idx, J);
+                apply_cols2(P, idx, J);
+            }
+            if (n > dof) {  // esekfom.hpp:1715-1744
+                Mat hc(dof, n);
+                for (int r = 0; r < dof; r++) for (int c = 0; c < 15; c++) hc(r, c) = hx(r, c);
+                Mat hct = transpose(hc);
+                Mat S = mul(mul(hc, P), hct);
+                for (int a = 0; a < dof; a++) for (int b = 0; b < dof; b++) S(a, b) = S(a, b) / R + (a == b ? 1.0 : 0.0);
+                Mat K = mul(mul(P, hct), inverse(S));
+                for (auto& v : K.a) v /= R;
+                for (int a = 0; a < n; a++) { double s = 0; for (int r = 0; r < dof; r++) s += K(a, r) * dyn.h[r]; K_h[a] = s; }
+                K_x = mul(K, hc);
+            } else {  // esekfom.hpp:1782-1809
+                Mat Pt = P;
+                for (auto& v : Pt.a) v /= R;
+                Mat P_temp = inverse(Pt);
+                Mat hxt = transpose(hx);
+                Mat HTH = mul(hxt, hx);  // 15x15
+                for (int a = 0; a < 15; a++) for (int b = 0; b < 15; b++) P_temp(a, b) += HTH(a, b);
+                Mat P_inv = inverse(P_temp);
+                Mat Pi15(n, 15);
+                for (int a = 0; a < n; a++) for (int b = 0; b < 15; b++) Pi15(a, b) = P_inv(a, b);
+                Mat T = mul(Pi15, hxt);  // 23 x N
+                for (int a = 0; a < n; a++) { double s = 0; for (int r = 0; r < dof; r++) s += T(a, r) * dyn.h[r]; K_h[a] = s; }
+                Mat Kx15 = mul(Pi15, HTH);
+                K_x = Mat(n, n);
+                for (int a = 0; a < n; a++) for (int b = 0; b < 15; b++) K_x(a, b) = Kx15(a, b);
+                for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) pl.JtJ[a * 6 + b] = HTH(a, b);
+                for (int a = 0; a < 6; a++) { double s = 0; for (int r = 0; r < dof; r++) s += hx(r, a) * dyn.h[r]; pl.Jtr[a] = s; }
+            }
+            double dx_[23];
+            for (int a = 0; a < n; a++) {
+                double s = K_h[a];
+                for (int b = 0; b < n; b++) s += (K_x(a, b) - (a == b ? 1.0 : 0.0)) * dx_new[b];
+                dx_[a] = s;
+            }
+            for (int a = 0; a < n; a++) pl.dx[a] = dx_[a];
+            log.push_back(pl);
+            state_boxplus(x, dx_);
+            dyn.converge = true;
+            for (int a = 0; a < n; a++)
+                if (std::fabs(dx_[a]) > limit[a]) { dyn.converge = false; break; }
+            if (dyn.converge) t++;
+            if (!t && i == max_iter - 2) dyn.converge = true;
+            if (t > 1 || i == max_iter - 1) {
+                Mat L = P;
+                for (int si = 0; si < 2; si++) {
+                    const int idx = so3_idx[si];
+                    double A[9], J[9];
+                    A_matrix(V3{{dx_[idx], dx_[idx + 1], dx_[idx + 2]}}, A);
+                    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) J[a * 3 + b] = A[b * 3 + a];
+                    // L rows from P rows (esekfom.hpp:1847-1849)
+                    for (int c = 0; c < n; c++) {
+                        double v[3] = {P(idx, c), P(idx + 1, c), P(idx + 2, c)};
+                        for (int a = 0; a < 3; a++) L(idx + a, c) = J[a * 3] * v[0] + J[a * 3 + 1] * v[1] + J[a * 3 + 2] * v[2];
+                    }
+                    for (int c = 0; c < 15; c++) {
+                        double v[3] = {K_x(idx, c), K_x(idx + 1, c), K_x(idx + 2, c)};
+                        for (int a = 0; a < 3; a++) K_x(idx + a, c) = J[a * 3] * v[0] + J[a * 3 + 1] * v[1] + J[a * 3 + 2] * v[2];
+                    }
+                    apply_cols3(L, idx, J);
+                    apply_cols3(P, idx, J);
+                }
+                {
+                    const int idx = 21;
+                    double Nx[6], Mx[6], J[4];
+                    double seg[2] = {dx_[idx], dx_[idx + 1]};
+                    S2_Nx_yy(x.grav, Nx);
+                    S2_Mx(x_prop.grav, seg, Mx);
+                    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { double s = 0; for (int k = 0; k < 3; k++) s += Nx[a * 3 + k] * Mx[k * 2 + b]; J[a * 2 + b] = s; }
+                    for (int c = 0; c < n; c++) {
+                        double v[2] = {P(idx, c), P(idx + 1, c)};
+                        L(idx, c) = J[0] * v[0] + J[1] * v[1];
+                        L(idx + 1, c) = J[2] * v[0] + J[3] * v[1];
+                    }
+                    for (int c = 0; c < 15; c++) {
+                        double v[2] = {K_x(idx, c), K_x(idx + 1, c)};
+                        K_x(idx, c) = J[0] * v[0] + J[1] * v[1];
+                        K_x(idx + 1, c) = J[2] * v[0] + J[3] * v[1];
+                    }
+                    apply_cols2(L, idx, J);
+                    apply_cols2(P, idx, J);
+                }
+                Mat Pn(n, n);
+                for (int a = 0; a < n; a++)
+                    for (int b = 0; b < n; b++) {
+                        double s = 0;
+                        for (int k = 0; k < 15; k++) s += K_x(a, k) * P(k, b);
+                        Pn(a, b) = L(a, b) - s;
+                    }
+                P = Pn;
+                return;
+            }
+        }
+    }
+    static void apply_left3(const double J[9], double* v) {
+        double t[3] = {v[0], v[1], v[2]};
+        for (int a = 0; a < 3; a++) v[a] = J[a * 3] * t[0] + J[a * 3 + 1] * t[1] + J[a * 3 + 2] * t[2];
+    }
+    static void apply_rows3(Mat& M, int idx, const double J[9]) {  // M[idx:idx+3, :] = J M[idx:idx+3, :]
+        for (int c = 0; c < M.c; c++) {
+            double v[3] = {M(idx, c), M(idx + 1, c), M(idx + 2, c)};
+            for (int a = 0; a < 3; a++) M(idx + a, c) = J[a * 3] * v[0] + J[a * 3 + 1] * v[1] + J[a * 3 + 2] * v[2];
+        }
+    }
+    static void apply_cols3(Mat& M, int idx, const double J[9]) {  // M[:, idx:idx+3] = M[:, idx:idx+3] J^T
+        for (int r = 0; r < M.r; r++) {
+            double v[3] = {M(r, idx), M(r, idx + 1), M(r, idx + 2)};
+            for (int a = 0; a < 3; a++) M(r, idx + a) = v[0] * J[a * 3] + v[1] * J[a * 3 + 1] + v[2] * J[a * 3 + 2];
+        }
+    }
+    static void apply_rows2(Mat& M, int idx, const double J[4]) {
+        for (int c = 0; c < M.c; c++) {
+            double v[2] = {M(idx, c), M(idx + 1, c)};
+            M(idx, c) = J[0] * v[0] + J[1] * v[1];
+            M(idx + 1, c) = J[2] * v[0] + J[3] * v[1];
+        }
+    }
+    static void apply_cols2(Mat& M, int idx, const double J[4]) {
+        for (int r = 0; r < M.r; r++) {
+            double v[2] = {M(r, idx), M(r, idx + 1)};
+            M(r, idx) = v[0] * J[0] + v[1] * J[1];
+            M(r, idx + 1) = v[0] * J[2] + v[1] * J[3];
+        }
+    }
+
+    // laserMapping.cpp:523-576
+    int map_incremental() {
+        std::vector<P4> to_add, no_ds;
+        to_add.reserve(n_ds);
+        no_ds.reserve(n_ds);
+        const float fs = leaf_map;
+        for (int i = 0; i < n_ds; i++) {
+            ds_world[i] = body_to_world(x, ds_body[i]);
+            const P4& pw = ds_world[i];
+            if (!nearest[i].empty() && flg_EKF_inited) {
+                const auto& near = nearest[i];
+                bool need_add = true;
+                P4 mid;
+                // floor(x / 0.5) * 0.5 + 0.5 * 0.5 evaluated in double (filter_size_map_min is double), stored float
+                mid.x = (float)(std::floor((double)pw.x / (double)fs) * (double)fs + 0.5 * (double)fs);
+                mid.y = (float)(std::floor((double)pw.y / (double)fs) * (double)fs + 0.5 * (double)fs);
+                mid.z = (float)(std::floor((double)pw.z / (double)fs) * (double)fs + 0.5 * (double)fs);
+                mid.w = 0;
+                const float dist = calc_dist(pw, mid);
+                const double half = 0.5 * (double)fs;
+                if (std::fabs((double)(near[0].x - mid.x)) > half && std::fabs((double)(near[0].y - mid.y)) > half &&
+                    std::fabs((double)(near[0].z - mid.z)) > half) {
+                    no_ds.push_back(pw);
+                    continue;
+                }
+                for (int k = 0; k < 5; k++) {
+                    if (near.size() < 5) break;
+                    if (calc_dist(near[k], mid) < dist) { need_add = false; break; }
+                }
+                if (need_add) to_add.push_back(pw);
+            } else {
+                to_add.push_back(pw);
+            }
+        }
+        ivox.add_points(to_add.data(), (int)to_add.size(), travel);
+        ivox.add_points(no_ds.data(), (int)no_ds.size(), travel);
+        return (int)(to_add.size() + no_ds.size());
+    }
+    static float calc_dist(const P4& a, const P4& b) {  // common_lib.h:231-234
+        return ((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)) + (a.z - b.z) * (a.z - b.z);
+    }
+
+    void set_ds(const P4* pts, int n) {
+        n_ds = n;
+        ds_body.assign(pts, pts + n);
+        ds_world.resize(n);
+        nearest.resize(n);  // Nearest_Points.resize: surviving entries keep their content (laserMapping.cpp:1274)
+    }
+
+    // fastlio_main after p_imu->Process (laserMapping.cpp:1189-1304).  `raw` plays
+    // feats_undistort; the caller has already put the propagated state/covariance in x/P.
+    // returns: 0 first-scan latch, 1 seeded map, 2 too few points, 3 updated, <0 error
+    int process_scan(const P4* raw, int n_raw, double lidar_beg_time) {
+        if (flg_first_scan) {
+            first_lidar_time = lidar_beg_time;
+            flg_first_scan = false;
+            return 0;
+        }
+        if (n_raw <= 0) return 2;
+        flg_EKF_inited = (lidar_beg_time - first_lidar_time) < init_time ? false : true;
+        std::vector<P4> ds;
+        voxel_downsample(raw, n_raw, leaf_surf, ds);
+        if ((int)ds.size() > kMaxPts) return -1;
+        n_ds = (int)ds.size();
+        ds_body = ds;
+        if (ivox.grids.empty()) {
+            if (n_ds > 5) {
+                ds_world.resize(n_ds);
+                for (int i = 0; i < n_ds; i++) ds_world[i] = body_to_world(x, ds_body[i]);
+                ivox.add_points(ds_world.data(), n_ds, travel);
+            }
+            return 1;
+        }
+        if (ivox.stencil_id != 19 && (lidar_beg_time - first_lidar_time) > 10 * init_time) ivox.set_stencil(19);
+        if (n_ds < 5) return 2;
+        ds_world.resize(n_ds);
+        nearest.resize(n_ds);
+        update_iterated(laser_cov);
+        V3 off = qrot(x.rot, x.til);
+        V3 pos_lid{{x.pos[0] + off[0], x.pos[1] + off[1], x.pos[2] + off[2]}};
+        const double dxp = pos_lid[0] - last_pos_lid[0], dyp = pos_lid[1] - last_pos_lid[1], dzp = pos_lid[2] - last_pos_lid[2];
+        travel = travel + std::sqrt(dxp * dxp + dyp * dyp + dzp * dzp);
+        last_pos_lid = pos_lid;
+        map_incremental();
+        return 3;
+    }
+};
+
+}  // namespace
+
+// =============================================================================
+// C ABI (ctypes)
+// =============================================================================
+extern "C" {
+
+int orc_voxel_downsample(const float* in_xyzi, int n, float leaf, float* out_xyzi, int cap) {
+    std::vector<P4> out;
+    int m = voxel_downsample(reinterpret_cast<const P4*>(in_xyzi), n, leaf, out);
+    if (m > cap) return -m;
+    std::memcpy(out_xyzi, out.data(), sizeof(P4) * (size_t)m);
+    return m;
+}
+
+int orc_esti_plane(const float* five_xyzi, float threshold, float* pabcd) {
+    return esti_plane(pabcd, reinterpret_cast<const P4*>(five_xyzi), threshold) ? 1 : 0;
+}
+
+void* orc_ivox_create(float res, int stencil, uint64_t capacity, double max_distance) { return new IVox(res, stencil, (size_t)capacity, max_distance); }
+void orc_ivox_destroy(void* h) { delete static_cast<IVox*>(h); }
+void orc_ivox_set_stencil(void* h, int stencil) { static_cast<IVox*>(h)->set_stencil(stencil); }
+void orc_ivox_add(void* h, const float* pts, int n, double travel) { static_cast<IVox*>(h)->add_points(reinterpret_cast<const P4*>(pts), n, travel); }
+uint64_t orc_ivox_num_voxels(void* h) { return static_cast<IVox*>(h)->grids.size(); }
+uint64_t orc_ivox_num_points(void* h) { return static_cast<IVox*>(h)->num_points(); }
+// pure kNN (no stale-content semantics): out_pts is n x 5 x 4 floats, out_cnt n ints.
+// returns the total number of in-range candidates visited (for the C-bar statistic of SURVEY 8d)
+uint64_t orc_ivox_knn(void* h, const float* q_xyzi, int n, float* out_pts, int* out_cnt, int threads) {
+    IVox* iv = static_cast<IVox*>(h);
+    const P4* q = reinterpret_cast<const P4*>(q_xyzi);
+    uint64_t visited = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads > 0 ? threads : 1) reduction(+ : visited)
+#endif
+    {
+        std::vector<Cand> scratch;
+        std::vector<P4> near;
+#ifdef _OPENMP
+#pragma omp for
+#endif
+        for (int i = 0; i < n; i++) {
+            near.clear();
+            bool ok = iv->closest(q[i], near, 5, 5.0, scratch);
+            visited += scratch.size();
+            out_cnt[i] = ok ? (int)near.size() : 0;
+            for (int k = 0; k < 5; k++) {
+                P4 p = (k < (int)near.size()) ? near[k] : P4{0, 0, 0, 0};
+                std::memcpy(out_pts + ((size_t)i * 5 + k) * 4, &p, sizeof(P4));
+            }
+        }
+    }
+    return visited;
+}
+// number of map points resident in the stencil voxels of each query (no range test): C-bar of SURVEY 8d
+uint64_t orc_ivox_stencil_points(void* h, const float* q_xyzi, int n) {
+    IVox* iv = static_cast<IVox*>(h);
+    const P4* q = reinterpret_cast<const P4*>(q_xyzi);
+    uint64_t tot = 0;
+    for (int i = 0; i < n; i++) {
+        Key3 key = iv->pos2grid(q[i]);
+        for (const Key3& d : iv->nearby) {
+            auto it = iv->grids.find(Key3{key.x + d.x, key.y + d.y, key.z + d.z});
+            if (it != iv->grids.end()) tot += it->second->second.pts.size();
+        }
+    }
+    return tot;
+}
+
+void* orc_lio_create(float res, int stencil, uint64_t capacity, double max_distance, int threads) {
+    Lio* l = new Lio(res, stencil, (size_t)capacity, max_distance);
+    l->threads = threads > 0 ? threads : 1;
+    return l;
+}
+void orc_lio_destroy(void* h) { delete static_cast<Lio*>(h); }
+void orc_lio_set_state(void* h, const double* s26) { state_from(s26, static_cast<Lio*>(h)->x); }
+void orc_lio_get_state(void* h, double* s26) { state_to(static_cast<Lio*>(h)->x, s26); }
+void orc_lio_set_cov(void* h, const double* P529) { Lio* l = static_cast<Lio*>(h); for (int i = 0; i < 529; i++) l->P.a[i] = P529[i]; }
+void orc_lio_get_cov(void* h, double* P529) { Lio* l = static_cast<Lio*>(h); for (int i = 0; i < 529; i++) P529[i] = l->P.a[i]; }
+void orc_lio_set_flags(void* h, int ekf_inited, int first_scan, double travel, double first_lidar_time) {
+    Lio* l = static_cast<Lio*>(h);
+    l->flg_EKF_inited = ekf_inited != 0;
+    l->flg_first_scan = first_scan != 0;
+    l->travel = travel;
+    l->first_lidar_time = first_lidar_time;
+}
+void orc_lio_set_stencil(void* h, int s) { static_cast<Lio*>(h)->ivox.set_stencil(s); }
+void orc_lio_map_add(void* h, const float* pts, int n, double travel) { static_cast<Lio*>(h)->ivox.add_points(reinterpret_cast<const P4*>(pts), n, travel); }
+uint64_t orc_lio_map_num_points(void* h) { return static_cast<Lio*>(h)->ivox.num_points(); }
+uint64_t orc_lio_map_num_voxels(void* h) { return static_cast<Lio*>(h)->ivox.grids.size(); }
+// dump all map points (unordered); returns count (or -needed if cap too small)
+int64_t orc_lio_map_dump(void* h, float* out, uint64_t cap) {
+    Lio* l = static_cast<Lio*>(h);
+    uint64_t n = l->ivox.num_points();
+    if (n > cap) return -(int64_t)n;
+    uint64_t k = 0;
+    for (auto& kv : l->ivox.cache)
+        for (auto& p : kv.second.pts) { std::memcpy(out + k * 4, &p, sizeof(P4)); k++; }
+    return (int64_t)n;
+}
+void orc_lio_set_ds(void* h, const float* ds_xyzi, int n) { static_cast<Lio*>(h)->set_ds(reinterpret_cast<const P4*>(ds_xyzi), n); }
+int orc_lio_get_ds(void* h, float* out, int cap) {
+    Lio* l = static_cast<Lio*>(h);
+    if (l->n_ds > cap) return -l->n_ds;
+    std::memcpy(out, l->ds_body.data(), sizeof(P4) * (size_t)l->n_ds);
+    return l->n_ds;
+}
+// one call of h_share_model_geometric at the current state; converge != 0 -> redo kNN.
+// outputs per ds point: selected[n], normvec[n*4] (n, pd2), nn_cnt[n], nn_pts[n*5*4]; JtJ36/Jtr6 before the
+// degeneracy projection; returns n_eff
+int orc_lio_linearize(void* h, int converge, uint8_t* selected, float* normvec, int* nn_cnt, float* nn_pts,
+                      double* JtJ36, double* Jtr6, double* sum_abs_res, int* degenerate) {
+    Lio* l = static_cast<Lio*>(h);
+    DynShare d;
+    d.converge = converge != 0;
+    const bool deg_en = l->degenerate_detect_en;
+    l->degenerate_detect_en = false;
+    l->h_share_model_geometric(l->x, d);
+    l->degenerate_detect_en = deg_en;
+    const int n = l->n_ds;
+    for (int i = 0; i < n; i++) {
+        if (selected) selected[i] = l->selected[i];
+        if (normvec) std::memcpy(normvec + (size_t)i * 4, &l->normvec[i], sizeof(P4));
+        if (nn_cnt) nn_cnt[i] = (int)l->nearest[i].size();
+        if (nn_pts)
+            for (int k = 0; k < 5; k++) {
+                P4 p = k < (int)l->nearest[i].size() ? l->nearest[i][k] : P4{0, 0, 0, 0};
+                std::memcpy(nn_pts + ((size_t)i * 5 + k) * 4, &p, sizeof(P4));
+            }
+    }
+    if (JtJ36) for (int i = 0; i < 36; i++) JtJ36[i] = 0;
+    if (Jtr6) for (int i = 0; i < 6; i++) Jtr6[i] = 0;
+    if (l->effct_feat_num >= 1) {
+        for (int r = 0; r < d.h_x.r; r++) {
+            for (int a = 0; a < 6; a++) {
+                if (Jtr6) Jtr6[a] += d.h_x(r, a) * d.h[r];
+                if (JtJ36) for (int b = 0; b < 6; b++) JtJ36[a * 6 + b] += d.h_x(r, a) * d.h_x(r, b);
+            }
+        }
+    }
+    if (sum_abs_res) *sum_abs_res = l->total_residual;
+    if (degenerate) {
+        // run the degeneracy logic on a scratch copy to report the decision
+        *degenerate = 0;
+        if (deg_en && l->effct_feat_num >= 1) {
+            DynShare d2;
+            d2.converge = false;
+            l->h_share_model_geometric(l->x, d2);
+            *degenerate = l->is_degenerate ? 1 : 0;
+        }
+    }
+    return l->effct_feat_num;
+}
+// run esekf::update_iterated_dyn_share_modified on the ds points set by orc_lio_set_ds; returns #passes logged
+int orc_lio_update(void* h) {
+    Lio* l = static_cast<Lio*>(h);
+    l->ds_world.resize(l->n_ds);
+    l->update_iterated(l->laser_cov);
+    return (int)l->log.size();
+}
+int orc_lio_pass_log(void* h, int i, int* knn, int* n_eff, int* valid, int* degenerate, double* sum_abs_res, double* JtJ36,
+                     double* Jtr6, double* dx23) {
+    Lio* l = static_cast<Lio*>(h);
+    if (i < 0 || i >= (int)l->log.size()) return -1;
+    const PassLog& p = l->log[i];
+    *knn = p.knn; *n_eff = p.n_eff; *valid = p.valid; *degenerate = p.degenerate; *sum_abs_res = p.sum_abs_res;
+    std::memcpy(JtJ36, p.JtJ, sizeof(p.JtJ));
+    std::memcpy(Jtr6, p.Jtr, sizeof(p.Jtr));
+    std::memcpy(dx23, p.dx, sizeof(p.dx));
+    return 0;
+}
+int orc_lio_map_incremental(void* h) { return static_cast<Lio*>(h)->map_incremental(); }
+int orc_lio_process_scan(void* h, const float* raw_xyzi, int n_raw, double lidar_beg_time) {
+    return static_cast<Lio*>(h)->process_scan(reinterpret_cast<const P4*>(raw_xyzi), n_raw, lidar_beg_time);
+}
+double orc_lio_travel(void* h) { return static_cast<Lio*>(h)->travel; }
+int orc_lio_is_degenerate(void* h) { return static_cast<Lio*>(h)->is_degenerate ? 1 : 0; }
+
+// manifold helpers exposed for the known-answer tests
+void orc_state_boxplus(const double* s26, const double* d23, double* out26) { State x; state_from(s26, x); state_boxplus(x, d23); state_to(x, out26); }
+void orc_state_boxminus(const double* a26, const double* b26, double* d23) { State a, b; state_from(a26, a); state_from(b26, b); state_boxminus(a, b, d23); }
+void orc_A_matrix(const double* v3, double* A9) { A_matrix(V3{{v3[0], v3[1], v3[2]}}, A9); }
+void orc_S2_Bx(const double* v3, double* Bx6) { S2_Bx(V3{{v3[0], v3[1], v3[2]}}, Bx6); }
+void orc_S2_Nx_yy(const double* v3, double* N6) { S2_Nx_yy(V3{{v3[0], v3[1], v3[2]}}, N6); }
+void orc_S2_Mx(const double* v3, const double* d2, double* M6) { S2_Mx(V3{{v3[0], v3[1], v3[2]}}, d2, M6); }
+void orc_eig3(const double* A9, double* w3, double* V9) { eig3(A9, w3, V9); }
+void orc_inverse(const double* A, int n, double* out) {
+    Mat M(n, n);
+    for (int i = 0; i < n * n; i++) M.a[i] = A[i];
+    Mat X = inverse(M);
+    for (int i = 0; i < n * n; i++) out[i] = X.a[i];
+}
+
+}  // extern "C"
