@@ -1,0 +1,176 @@
+/*
+ * lio_hip.h -- C ABI of the MI355X-native LIO scan-matching core (liblio_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of w111liang222/lidar-slam-detection:
+ * the per-scan  voxel-grid downsample -> map kNN -> point-to-plane residual + Jacobian
+ * accumulation -> iterated ESKF update -> map insert  loop of the FastLIO frontend.
+ * Every entry point names the reference interface it replaces (paths relative to
+ * /root/reference/slam/mapping/fastlio unless stated otherwise).
+ *
+ * Conventions
+ *   - plain C, opaque handles, caller-owned buffers, no exceptions cross the ABI;
+ *   - return value: >= 0 ok (often a count), < 0 one of LIO_E_*;
+ *   - points are XYZI float quadruples (16 B, "float4"); quaternions are (x, y, z, w);
+ *   - "_device" variants take pointers that are already resident in HBM on the handle's
+ *     device (e.g. a torch tensor's data_ptr()); the others take host pointers;
+ *   - a handle owns one HIP stream; a handle is not thread-safe; distinct handles may be
+ *     driven from distinct host threads / on distinct GPUs.
+ *   - there is NO CPU fallback: without a usable HIP device every create() returns NULL.
+ */
+#ifndef LIO_HIP_H_
+#define LIO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIO_OK 0
+#define LIO_E_INVALID (-1)     /* bad argument / handle */
+#define LIO_E_CAPACITY (-2)    /* a fixed capacity (points, voxels, ds points) would be exceeded */
+#define LIO_E_DEVICE (-3)      /* HIP runtime error (message via lio_last_error) */
+#define LIO_E_STATE (-4)       /* call order violated (e.g. linearize before a scan is set) */
+
+typedef struct lio_map lio_map;       /* iVox-equivalent hash-grid map resident in HBM */
+typedef struct lio_scan lio_scan;     /* one scan in flight: raw, downsampled, neighbour cache, gates */
+typedef struct lio_engine lio_engine; /* per-scan driver = the body of fastlio_main after IMU processing */
+
+const char* lio_last_error(void);
+int lio_device_count(void);
+/* bytes of HBM currently held by a map / scan handle (capacity planning on the 288 GB part) */
+uint64_t lio_map_bytes(const lio_map*);
+
+/* ---------------------------------------------------------------------------------------------
+ * Map: replaces faster_lio::IVox<3, DEFAULT, PointType>  (include/ivox3d/ivox3d.h:59-120)
+ *   voxel key = round-half-away(p / resolution) per axis (ivox3d.h:258-261)
+ *   stencils  = 1 (CENTER), 7 (NEARBY6), 19 (NEARBY18), 27 (NEARBY26), 75 ("NEARBY74", 5x5x3)
+ *               (ivox3d.h:179-210)
+ * ------------------------------------------------------------------------------------------- */
+/* ctor: IVox(Options) as configured at src/laserMapping.cpp:1060-1064.  max_points bounds the point
+ * pool (the pool is 2x that to leave slack for voxel growth), max_voxels the number of live voxels. */
+lio_map* lio_map_create(int device, float resolution, uint64_t max_points, uint64_t max_voxels, int stencil);
+void lio_map_destroy(lio_map*);
+/* IVox::SetNearByType (used at src/laserMapping.cpp:1241-1243) */
+int lio_map_set_stencil(lio_map*, int stencil);
+/* IVox::AddPoints(points, travel_distance)  (ivox3d.h:231-256).  Points are appended to their voxels;
+ * new voxels are stamped with `travel`.  LRU eviction is NOT performed (the reference
+ * evicts only above `capacity` voxels; this map reports LIO_E_CAPACITY instead of evicting). */
+int lio_map_insert(lio_map*, const float* world_xyzi, uint64_t n, double travel);
+int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double travel);
+/* IVox::NumValidGrids (ivox3d.h:173-176) and the total number of stored points */
+int lio_map_stats(lio_map*, uint64_t* n_points, uint64_t* n_voxels);
+/* all stored points, voxel by voxel in unspecified order; returns the count or -(needed) */
+int64_t lio_map_dump(lio_map*, float* out_xyzi, uint64_t cap_points);
+/* IVox::GetClosestPoint(pt, out, 5, 5.0) for a batch of world-frame queries (ivox3d.h:139-171):
+ * out_pts is n x 5 x 4 floats in the canonical order (d2, x, y, z) ascending, out_cnt[n] the number
+ * found (0..5).  Test/diagnostic entry; the per-scan path uses lio_p2plane_linearize. */
+int lio_map_knn(lio_map*, const float* world_xyzi, uint32_t n, float* out_pts, int32_t* out_cnt);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scan: replaces the file-scope per-scan buffers feats_undistort / feats_down_body /
+ * feats_down_world / Nearest_Points / point_selected_surf / normvec / res_last
+ * (src/laserMapping.cpp:86-124) and downSizeFilterSurf (src/laserMapping.cpp:127,1206-1207).
+ * The neighbour cache persists across scans exactly like Nearest_Points does.
+ * ------------------------------------------------------------------------------------------- */
+lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds);
+void lio_scan_destroy(lio_scan*);
+int lio_scan_upload(lio_scan*, const float* body_xyzi, uint32_t n_raw);          /* host -> HBM */
+int lio_scan_set_device(lio_scan*, const void* d_body_xyzi, uint32_t n_raw);     /* already in HBM (not copied) */
+/* pcl::VoxelGrid<PointType>::filter with setLeafSize(leaf, leaf, leaf) (PCL 1.9.1 voxel_grid.hpp,
+ * called at src/laserMapping.cpp:1206-1207): centroid of every occupied voxel, ascending voxel index.
+ * Asynchronous; *n_ds (may be NULL) is only filled when sync != 0. */
+int lio_scan_voxel_downsample(lio_scan*, float leaf, int sync, uint32_t* n_ds);
+/* bypass the filter: use these points as feats_down_body (tests, staged pipelines) */
+int lio_scan_set_ds(lio_scan*, const float* ds_body_xyzi, uint32_t n_ds);
+int lio_scan_num_ds(lio_scan*);                                                   /* syncs the stream */
+int lio_scan_download_ds(lio_scan*, float* out_xyzi, uint32_t cap);              /* feats_down_body */
+int lio_scan_download_world(lio_scan*, float* out_xyzi, uint32_t cap);           /* feats_down_world */
+/* per-point results of the last linearize: any pointer may be NULL.
+ * selected[n_ds] (point_selected_surf), normvec[n_ds*4] (n, pd2), nn_cnt[n_ds], nn_pts[n_ds*5*4] */
+int lio_scan_download_match(lio_scan*, uint8_t* selected, float* normvec, int32_t* nn_cnt, float* nn_pts);
+
+/* normal equations of one pass, all f64, reduced in a fixed order (run-to-run identical) */
+typedef struct lio_normal_eq {
+    double JtJ[36];      /* sum row6 row6^T, row6 = [n, (R_il p + t_il) x (R_wi^T n)]  (src/laserMapping.cpp:909-931) */
+    double Jtr[6];       /* sum row6 * (-pd2)                                               */
+    double nnT[9];       /* sum n n^T  (HTH of src/laserMapping.cpp:937)                     */
+    double eigvec[9];    /* eigenvectors of nnT as columns, ascending eigenvalue (row-major 3x3) */
+    double eigval[3];
+    double contri[3];    /* per eigenvector: sum |n^.v| over rows with |n^.v| > 0.1736 (src/laserMapping.cpp:946-964) */
+    double strong[3];    /* ... > 0.7070 */
+    double sum_abs_res;  /* total_residual (src/laserMapping.cpp:884) */
+    uint32_t n_eff;      /* effct_feat_num */
+    uint32_t n_ds;       /* feats_down_size */
+    uint32_t n_knn_candidates_lo, n_knn_candidates_hi; /* 64-bit count of in-stencil points visited (kNN passes) */
+} lio_normal_eq;
+
+/* One evaluation of h_share_model_geometric (src/laserMapping.cpp:813-932) without the host-side
+ * degeneracy projection: body->world transform, [redo_knn: stencil kNN into the neighbour cache],
+ * esti_plane (include/common_lib.h:236-268), residual gate, and the f64 accumulation of the
+ * 6-column Jacobian blocks.  pose_wi = (t_wi[3], q_wi[4]);  ext_il = (t_il[3], q_il[4]). */
+int lio_p2plane_linearize(lio_map*, lio_scan*, const double pose_wi[7], const double ext_il[7], int redo_knn,
+                          lio_normal_eq* out);
+/* rows of the last linearize for the (rare) N_eff < 23 branch of the filter
+ * (esekfom.hpp:1715-1744): h_x[n_eff*6] (first six columns) and h[n_eff], selected points in index order */
+int lio_p2plane_rows(lio_scan*, const double pose_wi[7], const double ext_il[7], double* h_x6, double* h, uint32_t cap_rows);
+/* map_incremental (src/laserMapping.cpp:523-576) with the final state: world transform, need_add test
+ * against the cached neighbours, insert.  Returns the number of points inserted. */
+int lio_map_incremental(lio_map*, lio_scan*, const double pose_wi[7], const double ext_il[7], float map_leaf,
+                        int ekf_inited, double travel);
+/* first-scan seeding (src/laserMapping.cpp:1227-1238): insert every downsampled point */
+int lio_map_seed(lio_map*, lio_scan*, const double pose_wi[7], const double ext_il[7], double travel);
+
+/* ---------------------------------------------------------------------------------------------
+ * Engine: replaces the part of fastlio_main() that follows p_imu->Process
+ * (src/laserMapping.cpp:1189-1304) together with esekf::update_iterated_dyn_share_modified
+ * (include/IKFoM_toolkit/esekfom/esekfom.hpp:1619-1931) and the constants of fastlio_init
+ * (src/laserMapping.cpp:1025-1124).  Host C++ (filter algebra, 23 DoF) over the calls above.
+ * State vector (26 doubles): pos3 rot4 R_il4 t_il3 vel3 bg3 ba3 grav3  (use-ikfom.hpp:12-21).
+ * ------------------------------------------------------------------------------------------- */
+lio_engine* lio_engine_create(int device, float resolution, int stencil, uint64_t max_points, uint64_t max_voxels,
+                              uint32_t max_raw, uint32_t max_ds);
+void lio_engine_destroy(lio_engine*);
+lio_map* lio_engine_map(lio_engine*);
+lio_scan* lio_engine_scan(lio_engine*);
+int lio_engine_set_state(lio_engine*, const double s26[26]);
+int lio_engine_get_state(lio_engine*, double s26[26]);
+int lio_engine_set_cov(lio_engine*, const double P[529]);
+int lio_engine_get_cov(lio_engine*, double P[529]);
+/* flg_EKF_inited, flg_first_scan, travel_distance, first_lidar_time (src/laserMapping.cpp:97-121) */
+int lio_engine_set_flags(lio_engine*, int ekf_inited, int first_scan, double travel, double first_lidar_time);
+double lio_engine_travel(lio_engine*);
+int lio_engine_is_degenerate(lio_engine*);
+/* kf.update_iterated_dyn_share_modified(LASER_POINT_COV) on the scan's current ds points; returns #passes */
+int lio_engine_update(lio_engine*);
+typedef struct lio_pass_log {
+    int32_t knn, n_eff, valid, degenerate;
+    double sum_abs_res;
+    double JtJ[36]; /* after the degeneracy projection, as consumed by the filter */
+    double Jtr[6];
+    double dx[23];
+} lio_pass_log;
+int lio_engine_pass_log(lio_engine*, int i, lio_pass_log* out);
+/* the per-scan body of fastlio_main: returns 0 first-scan latch, 1 map seeded, 2 too few points,
+ * 3 state updated + map_incremental done, < 0 error */
+int lio_engine_process_scan(lio_engine*, const float* raw_body_xyzi, uint32_t n_raw, double lidar_beg_time);
+int lio_engine_process_scan_device(lio_engine*, const void* d_raw_body_xyzi, uint32_t n_raw, double lidar_beg_time);
+/* per-stage device time of the last process_scan in microseconds (hipEvent based; the reference's
+ * equivalent timers are commented out at src/laserMapping.cpp:1314-1342) */
+typedef struct lio_timings {
+    float downsample_us, knn_us, linearize_us, insert_us, total_device_us;
+    float host_solve_us, total_wall_us;
+    int32_t n_knn_pass, n_pass, n_ds, n_eff_last, n_added;
+    uint64_t knn_candidates; /* in-stencil points visited over all kNN passes (C-bar * N_ds * n_knn) */
+} lio_timings;
+int lio_engine_timings(lio_engine*, lio_timings* out);
+int lio_engine_enable_timing(lio_engine*, int on);
+
+/* manifold helpers exposed for known-answer tests (mtk SO3/S2 boxplus/boxminus, SOn.hpp:233-245, S2.hpp:136-167) */
+void lio_state_boxplus(const double s26[26], const double d23[23], double out26[26]);
+void lio_state_boxminus(const double a26[26], const double b26[26], double d23[23]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIO_HIP_H_ */

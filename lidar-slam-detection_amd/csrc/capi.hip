@@ -1,0 +1,480 @@
+// capi.hip -- handle management and the kernel-level entry points of include/lio_hip.h.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "lio_common.h"
+
+namespace lio {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+template <typename T>
+static bool dev_alloc(T** p, uint64_t count, uint64_t* bytes) {
+    const uint64_t b = count * sizeof(T);
+    if (hipMalloc(reinterpret_cast<void**>(p), b ? b : 16) != hipSuccess) {
+        set_error("hipMalloc of %llu bytes failed", (unsigned long long)b);
+        *p = nullptr;
+        return false;
+    }
+    *bytes += b;
+    return true;
+}
+
+static int fill_stencil(StencilArgs& st, int id) {
+    // ivox3d.h:179-210 (GenerateNearbyGrids)
+    static const signed char n18[19][3] = {{0, 0, 0},  {-1, 0, 0}, {1, 0, 0},  {0, 1, 0},   {0, -1, 0}, {0, 0, -1}, {0, 0, 1},
+                                           {1, 1, 0},  {-1, 1, 0}, {1, -1, 0}, {-1, -1, 0}, {1, 0, 1},  {-1, 0, 1}, {1, 0, -1},
+                                           {-1, 0, -1}, {0, 1, 1}, {0, -1, 1}, {0, 1, -1},  {0, -1, -1}};
+    static const signed char n26x[8][3] = {{1, 1, 1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1}, {-1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, -1, -1}};
+    st.n = 0;
+    auto push = [&](int a, int b, int c) {
+        st.off[st.n][0] = (signed char)a; st.off[st.n][1] = (signed char)b; st.off[st.n][2] = (signed char)c;
+        st.n++;
+    };
+    if (id == 1) push(0, 0, 0);
+    else if (id == 7) for (int i = 0; i < 7; i++) push(n18[i][0], n18[i][1], n18[i][2]);
+    else if (id == 19) for (int i = 0; i < 19; i++) push(n18[i][0], n18[i][1], n18[i][2]);
+    else if (id == 27) {
+        for (int i = 0; i < 19; i++) push(n18[i][0], n18[i][1], n18[i][2]);
+        for (int i = 0; i < 8; i++) push(n26x[i][0], n26x[i][1], n26x[i][2]);
+    } else if (id == 75) {  // "NEARBY74": 5 x 5 x 3 including the centre
+        for (int i = -2; i <= 2; i++)
+            for (int j = -2; j <= 2; j++)
+                for (int k = -1; k <= 1; k++) push(i, j, k);
+    } else return LIO_E_INVALID;
+    return LIO_OK;
+}
+
+static int map_check(lio_map* m, hipStream_t st) {
+    if (hipMemcpyAsync(m->host_dev, m->dev, sizeof(MapDev), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        set_error("map status read-back failed: %s", hipGetErrorString(hipGetLastError()));
+        return LIO_E_DEVICE;
+    }
+    if (m->host_dev->err) {
+        set_error("map capacity exceeded (err bits 0x%x: 1 table full, 2 point pool full, 4 more than max_voxels voxels)", m->host_dev->err);
+        return LIO_E_CAPACITY;
+    }
+    return LIO_OK;
+}
+
+}  // namespace lio
+
+using namespace lio;
+
+extern "C" {
+
+const char* lio_last_error(void) { return g_err; }
+
+int lio_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+uint64_t lio_map_bytes(const lio_map* m) { return m ? m->bytes : 0; }
+
+lio_map* lio_map_create(int device, float resolution, uint64_t max_points, uint64_t max_voxels, int stencil) {
+    if (!(resolution > 0.f) || max_points == 0 || max_voxels == 0) { set_error("lio_map_create: bad argument"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("lio_map_create: no HIP device %d (this library has no CPU fallback)", device); return nullptr; }
+    lio_map* m = new lio_map();
+    memset(m, 0, sizeof(*m));
+    m->device = device;
+    m->res = resolution;
+    m->inv_res = 1.0f / resolution;
+    m->max_points = max_points;
+    m->max_voxels = max_voxels;
+    if (fill_stencil(m->stencil, stencil) != LIO_OK) { set_error("lio_map_create: stencil must be 1, 7, 19, 27 or 75"); delete m; return nullptr; }
+    m->stencil_id = stencil;
+    uint64_t cap = 1024;
+    while (cap < max_voxels * 2) cap <<= 1;  // load factor <= 0.5
+    if (cap > 0x40000000ull) { set_error("lio_map_create: max_voxels too large"); delete m; return nullptr; }
+    m->table_cap = (uint32_t)cap;
+    m->table_mask = (uint32_t)cap - 1;
+    // voxel regions double when they fill up and the old region is not recycled: <= 2 x (2 x points + 8 x voxels)
+    m->pool_cap = 4 * max_points + 16 * max_voxels;
+    if (m->pool_cap > 0xFFFFFFF0ull) m->pool_cap = 0xFFFFFFF0ull;
+    m->slot_of_point_cap = max_points;
+    m->stage_cap = 1u << 20;
+    bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
+    m->own_stream = ok;
+    ok = ok && dev_alloc(&m->table, cap, &m->bytes) && dev_alloc(&m->cap, cap, &m->bytes) && dev_alloc(&m->pending, cap, &m->bytes) &&
+         dev_alloc(&m->created, cap, &m->bytes) && dev_alloc(&m->pool, m->pool_cap, &m->bytes) && dev_alloc(&m->dev, 1, &m->bytes) &&
+         dev_alloc(&m->slot_of_point, m->slot_of_point_cap, &m->bytes) && dev_alloc(&m->stage, m->stage_cap, &m->bytes);
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&m->host_dev), sizeof(MapDev)) == hipSuccess;
+    if (ok) {
+        ok = hipMemsetAsync(m->table, 0xFF, cap * sizeof(Slot), m->stream) == hipSuccess &&  // key = empty; ptr/cnt fixed below
+             hipMemsetAsync(m->cap, 0, cap * 4, m->stream) == hipSuccess && hipMemsetAsync(m->pending, 0, cap * 4, m->stream) == hipSuccess &&
+             hipMemsetAsync(m->dev, 0, sizeof(MapDev), m->stream) == hipSuccess;
+    }
+    if (ok) {
+        // cnt must start at 0: clear the (ptr, cnt) halves with a strided 2D memset
+        ok = hipMemset2DAsync(reinterpret_cast<char*>(m->table) + 8, sizeof(Slot), 0, 8, cap, m->stream) == hipSuccess &&
+             hipStreamSynchronize(m->stream) == hipSuccess;
+    }
+    if (!ok) {
+        if (!g_err[0]) set_error("lio_map_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
+        lio_map_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+void lio_map_destroy(lio_map* m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->dev);
+    hipFree(m->slot_of_point); hipFree(m->stage);
+    if (m->host_dev) hipHostFree(m->host_dev);
+    if (m->stream && m->own_stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int lio_map_set_stencil(lio_map* m, int stencil) {
+    if (!m) return LIO_E_INVALID;
+    StencilArgs st;
+    if (fill_stencil(st, stencil) != LIO_OK) { set_error("stencil must be 1, 7, 19, 27 or 75"); return LIO_E_INVALID; }
+    m->stencil = st;
+    m->stencil_id = stencil;
+    return LIO_OK;
+}
+
+int lio_map_insert_device(lio_map* m, const void* d_pts, uint64_t n, double travel) {
+    if (!m || (!d_pts && n)) return LIO_E_INVALID;
+    hipSetDevice(m->device);
+    const uint64_t chunk = m->slot_of_point_cap;
+    for (uint64_t a = 0; a < n; a += chunk) {
+        const uint64_t c = (n - a) < chunk ? (n - a) : chunk;
+        const int rc = map_insert_dev(m, m->stream, reinterpret_cast<const float4*>(d_pts) + a, c, nullptr, travel);
+        if (rc != LIO_OK) return rc;
+    }
+    return map_check(m, m->stream);
+}
+
+int lio_map_insert(lio_map* m, const float* pts, uint64_t n, double travel) {
+    if (!m || (!pts && n)) return LIO_E_INVALID;
+    if (n == 0) return LIO_OK;
+    hipSetDevice(m->device);
+    float4* tmp = nullptr;
+    LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tmp), n * sizeof(float4)));
+    int rc = LIO_OK;
+    if (hipMemcpyAsync(tmp, pts, n * sizeof(float4), hipMemcpyHostToDevice, m->stream) != hipSuccess) {
+        set_error("lio_map_insert: upload failed");
+        rc = LIO_E_DEVICE;
+    } else {
+        rc = lio_map_insert_device(m, tmp, n, travel);
+    }
+    hipStreamSynchronize(m->stream);
+    hipFree(tmp);
+    return rc;
+}
+
+int lio_map_stats(lio_map* m, uint64_t* n_points, uint64_t* n_voxels) {
+    if (!m) return LIO_E_INVALID;
+    hipSetDevice(m->device);
+    const int rc = map_check(m, m->stream);
+    if (n_points) *n_points = m->host_dev->n_points;
+    if (n_voxels) *n_voxels = m->host_dev->n_voxels;
+    return rc;
+}
+
+int64_t lio_map_dump(lio_map* m, float* out, uint64_t cap_points) {
+    if (!m) return LIO_E_INVALID;
+    hipSetDevice(m->device);
+    if (map_check(m, m->stream) == LIO_E_DEVICE) return LIO_E_DEVICE;
+    const uint64_t n = m->host_dev->n_points;
+    if (n > cap_points || !out) return -(int64_t)n;
+    std::vector<Slot> tab(m->table_cap);
+    if (hipMemcpy(tab.data(), m->table, sizeof(Slot) * m->table_cap, hipMemcpyDeviceToHost) != hipSuccess) return LIO_E_DEVICE;
+    uint64_t k = 0;
+    for (uint32_t h = 0; h < m->table_cap; h++) {
+        if (tab[h].key == kEmptyKey || tab[h].cnt == 0) continue;
+        if (k + tab[h].cnt > cap_points) return LIO_E_CAPACITY;
+        if (hipMemcpy(out + k * 4, m->pool + tab[h].ptr, sizeof(float4) * tab[h].cnt, hipMemcpyDeviceToHost) != hipSuccess) return LIO_E_DEVICE;
+        k += tab[h].cnt;
+    }
+    return (int64_t)k;
+}
+
+int lio_map_knn(lio_map* m, const float* q, uint32_t n, float* out_pts, int32_t* out_cnt) {
+    if (!m || !q || !out_pts || !out_cnt) return LIO_E_INVALID;
+    if (n == 0) return LIO_OK;
+    hipSetDevice(m->device);
+    float4 *dq = nullptr, *dout = nullptr;
+    int32_t* dcnt = nullptr;
+    int rc = LIO_OK;
+    if (hipMalloc(reinterpret_cast<void**>(&dq), n * sizeof(float4)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dout), (size_t)n * 5 * sizeof(float4)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dcnt), n * sizeof(int32_t)) != hipSuccess) {
+        set_error("lio_map_knn: hipMalloc failed");
+        rc = LIO_E_DEVICE;
+    }
+    if (rc == LIO_OK) {
+        hipMemcpyAsync(dq, q, n * sizeof(float4), hipMemcpyHostToDevice, m->stream);
+        hipMemsetAsync(dout, 0, (size_t)n * 5 * sizeof(float4), m->stream);
+        hipMemsetAsync(dcnt, 0, n * sizeof(int32_t), m->stream);
+        rc = knn_batch(m, dq, n, dout, dcnt);
+    }
+    if (rc == LIO_OK) {
+        std::vector<float4> soa((size_t)n * 5);
+        if (hipMemcpyAsync(soa.data(), dout, soa.size() * sizeof(float4), hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipMemcpyAsync(out_cnt, dcnt, n * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess) {
+            set_error("lio_map_knn: %s", hipGetErrorString(hipGetLastError()));
+            rc = LIO_E_DEVICE;
+        } else {
+            for (uint32_t i = 0; i < n; i++)
+                for (int k = 0; k < 5; k++) memcpy(out_pts + ((size_t)i * 5 + k) * 4, &soa[(size_t)k * n + i], sizeof(float4));
+        }
+    }
+    hipFree(dq); hipFree(dout); hipFree(dcnt);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
+    if (max_raw == 0 || max_ds == 0) { set_error("lio_scan_create: bad argument"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("lio_scan_create: no HIP device %d (this library has no CPU fallback)", device); return nullptr; }
+    lio_scan* s = new lio_scan();
+    memset(s, 0, sizeof(*s));
+    s->device = device;
+    s->max_raw = max_raw;
+    s->max_ds = max_ds;
+    const uint32_t nblocks = (max_raw + 1023) / 1024;
+    s->partial_blocks = (max_ds + 127) / 128;
+    bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && dev_alloc(&s->raw_own, max_raw, &s->bytes) && dev_alloc(&s->ds_body, max_ds, &s->bytes) && dev_alloc(&s->ds_world, max_ds, &s->bytes) &&
+         dev_alloc(&s->nn_pts, (uint64_t)max_ds * 5, &s->bytes) && dev_alloc(&s->nn_cnt, max_ds, &s->bytes) && dev_alloc(&s->selected, max_ds, &s->bytes) &&
+         dev_alloc(&s->normvec, max_ds, &s->bytes) && dev_alloc(&s->keys_a, max_raw, &s->bytes) && dev_alloc(&s->keys_b, max_raw, &s->bytes) &&
+         dev_alloc(&s->vals_a, max_raw, &s->bytes) && dev_alloc(&s->vals_b, max_raw, &s->bytes) && dev_alloc(&s->hist, (uint64_t)256 * nblocks, &s->bytes) &&
+         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * 29, &s->bytes) &&
+         dev_alloc(&s->dev, 1, &s->bytes) && dev_alloc(&s->d_result, 1, &s->bytes);
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&s->host_dev), sizeof(ScanDev)) == hipSuccess &&
+         hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(lio_normal_eq)) == hipSuccess;
+    if (ok) {
+        // point_selected_surf starts all-true (laserMapping.cpp:1046), Nearest_Points empty
+        ok = hipMemsetAsync(s->selected, 1, max_ds, s->stream) == hipSuccess && hipMemsetAsync(s->nn_cnt, 0, (size_t)max_ds * 4, s->stream) == hipSuccess &&
+             hipMemsetAsync(s->nn_pts, 0, (size_t)max_ds * 5 * sizeof(float4), s->stream) == hipSuccess &&
+             hipMemsetAsync(s->normvec, 0, (size_t)max_ds * sizeof(float4), s->stream) == hipSuccess &&
+             hipMemsetAsync(s->dev, 0, sizeof(ScanDev), s->stream) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess;
+    }
+    if (!ok) {
+        if (!g_err[0]) set_error("lio_scan_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
+        lio_scan_destroy(s);
+        return nullptr;
+    }
+    s->raw = s->raw_own;
+    return s;
+}
+
+void lio_scan_destroy(lio_scan* s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    hipFree(s->raw_own); hipFree(s->ds_body); hipFree(s->ds_world); hipFree(s->nn_pts); hipFree(s->nn_cnt); hipFree(s->selected);
+    hipFree(s->normvec); hipFree(s->keys_a); hipFree(s->keys_b); hipFree(s->vals_a); hipFree(s->vals_b); hipFree(s->hist);
+    hipFree(s->blockcnt); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
+    if (s->host_dev) hipHostFree(s->host_dev);
+    if (s->h_result) hipHostFree(s->h_result);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int lio_scan_upload(lio_scan* s, const float* body, uint32_t n_raw) {
+    if (!s || (!body && n_raw)) return LIO_E_INVALID;
+    if (n_raw > s->max_raw) { set_error("scan of %u points exceeds max_raw %u", n_raw, s->max_raw); return LIO_E_CAPACITY; }
+    hipSetDevice(s->device);
+    if (n_raw) LIO_HIP_TRY(hipMemcpyAsync(s->raw_own, body, (size_t)n_raw * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    s->raw = s->raw_own;
+    s->n_raw = n_raw;
+    return LIO_OK;
+}
+
+int lio_scan_set_device(lio_scan* s, const void* d_body, uint32_t n_raw) {
+    if (!s || (!d_body && n_raw)) return LIO_E_INVALID;
+    if (n_raw > s->max_raw) { set_error("scan of %u points exceeds max_raw %u", n_raw, s->max_raw); return LIO_E_CAPACITY; }
+    s->raw = reinterpret_cast<const float4*>(d_body);
+    s->n_raw = n_raw;
+    return LIO_OK;
+}
+
+static int scan_sync_dev(lio_scan* s) {
+    LIO_HIP_TRY(hipMemcpyAsync(s->host_dev, s->dev, sizeof(ScanDev), hipMemcpyDeviceToHost, s->stream));
+    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->host_dev->err & 1u) {
+        set_error("downsampled scan exceeds max_ds %u", s->max_ds);
+        hipMemsetAsync(&s->dev->err, 0, 4, s->stream);
+        return LIO_E_CAPACITY;
+    }
+    return LIO_OK;
+}
+
+int lio_scan_voxel_downsample(lio_scan* s, float leaf, int sync, uint32_t* n_ds) {
+    if (!s || !(leaf > 0.f)) return LIO_E_INVALID;
+    hipSetDevice(s->device);
+    int rc = vg_downsample(s, leaf);
+    if (rc != LIO_OK) return rc;
+    rc = scan_begin(s);
+    if (rc != LIO_OK) return rc;
+    s->have_ds = -1;
+    if (sync) {
+        rc = scan_sync_dev(s);
+        if (rc != LIO_OK) return rc;
+        s->have_ds = (int)s->host_dev->n_ds;
+        if (n_ds) *n_ds = s->host_dev->n_ds;
+    }
+    return LIO_OK;
+}
+
+int lio_scan_set_ds(lio_scan* s, const float* ds, uint32_t n) {
+    if (!s || (!ds && n)) return LIO_E_INVALID;
+    if (n > s->max_ds) { set_error("%u downsampled points exceed max_ds %u", n, s->max_ds); return LIO_E_CAPACITY; }
+    hipSetDevice(s->device);
+    if (n) LIO_HIP_TRY(hipMemcpyAsync(s->ds_body, ds, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    int rc = scan_set_nds(s, n);
+    if (rc != LIO_OK) return rc;
+    rc = scan_begin(s);
+    if (rc != LIO_OK) return rc;
+    LIO_HIP_TRY(hipStreamSynchronize(s->stream));  // the host buffer may be released by the caller
+    s->have_ds = (int)n;
+    return LIO_OK;
+}
+
+int lio_scan_num_ds(lio_scan* s) {
+    if (!s) return LIO_E_INVALID;
+    hipSetDevice(s->device);
+    const int rc = scan_sync_dev(s);
+    if (rc != LIO_OK) return rc;
+    s->have_ds = (int)s->host_dev->n_ds;
+    return s->have_ds;
+}
+
+static int download_f4(lio_scan* s, const float4* src, float* out, uint32_t cap) {
+    const int n = lio_scan_num_ds(s);
+    if (n < 0) return n;
+    if ((uint32_t)n > cap) return LIO_E_CAPACITY;
+    if (n) {
+        LIO_HIP_TRY(hipMemcpyAsync(out, src, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return n;
+}
+
+int lio_scan_download_ds(lio_scan* s, float* out, uint32_t cap) { return (!s || !out) ? LIO_E_INVALID : download_f4(s, s->ds_body, out, cap); }
+int lio_scan_download_world(lio_scan* s, float* out, uint32_t cap) { return (!s || !out) ? LIO_E_INVALID : download_f4(s, s->ds_world, out, cap); }
+
+int lio_scan_download_match(lio_scan* s, uint8_t* selected, float* normvec, int32_t* nn_cnt, float* nn_pts) {
+    if (!s) return LIO_E_INVALID;
+    const int n = lio_scan_num_ds(s);
+    if (n <= 0) return n;
+    if (selected) LIO_HIP_TRY(hipMemcpyAsync(selected, s->selected, n, hipMemcpyDeviceToHost, s->stream));
+    if (normvec) LIO_HIP_TRY(hipMemcpyAsync(normvec, s->normvec, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    if (nn_cnt) LIO_HIP_TRY(hipMemcpyAsync(nn_cnt, s->nn_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
+    std::vector<float4> soa;
+    if (nn_pts) {
+        soa.resize((size_t)n * 5);
+        for (int k = 0; k < 5; k++)
+            LIO_HIP_TRY(hipMemcpyAsync(soa.data() + (size_t)k * n, s->nn_pts + (size_t)k * s->max_ds, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    }
+    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    if (nn_pts)
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 5; k++) memcpy(nn_pts + ((size_t)i * 5 + k) * 4, &soa[(size_t)k * n + i], sizeof(float4));
+    return n;
+}
+
+int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn, lio_normal_eq* out) {
+    if (!m || !s || !pose_wi || !ext_il || !out) return LIO_E_INVALID;
+    if (m->device != s->device) { set_error("map and scan live on different devices"); return LIO_E_INVALID; }
+    hipSetDevice(s->device);
+    const PoseArgs pose = make_pose(pose_wi, ext_il);
+    int rc = LIO_OK;
+    if (redo_knn) {
+        rc = map_knn_plane(m, s, pose, redo_knn);
+        if (rc != LIO_OK) return rc;
+    }
+    rc = p2plane_reduce(m, s, pose, redo_knn);
+    if (rc != LIO_OK) return rc;
+    LIO_HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(lio_normal_eq), hipMemcpyDeviceToHost, s->stream));
+    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    *out = *s->h_result;
+    s->have_ds = (int)out->n_ds;
+    return LIO_OK;
+}
+
+int lio_p2plane_rows(lio_scan* s, const double pose_wi[7], const double ext_il[7], double* h_x6, double* h, uint32_t cap_rows) {
+    if (!s || !h_x6 || !h) return LIO_E_INVALID;
+    const int n = lio_scan_num_ds(s);
+    if (n < 0) return n;
+    std::vector<uint8_t> sel(n);
+    std::vector<float4> nv(n), body(n);
+    if (n) {
+        LIO_HIP_TRY(hipMemcpyAsync(sel.data(), s->selected, n, hipMemcpyDeviceToHost, s->stream));
+        LIO_HIP_TRY(hipMemcpyAsync(nv.data(), s->normvec, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        LIO_HIP_TRY(hipMemcpyAsync(body.data(), s->ds_body, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    const double* qw = pose_wi + 3;
+    const double* ql = ext_il + 3;
+    auto qrot = [](const double q[4], const double v[3], double o[3]) {
+        double u[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+        u[0] += u[0]; u[1] += u[1]; u[2] += u[2];
+        const double c[3] = {q[1] * u[2] - q[2] * u[1], q[2] * u[0] - q[0] * u[2], q[0] * u[1] - q[1] * u[0]};
+        for (int i = 0; i < 3; i++) o[i] = (v[i] + q[3] * u[i]) + c[i];
+    };
+    uint32_t r = 0;
+    for (int i = 0; i < n; i++) {
+        if (!sel[i]) continue;
+        if (r >= cap_rows) return LIO_E_CAPACITY;
+        const double pb[3] = {body[i].x, body[i].y, body[i].z};
+        double pi[3];
+        qrot(ql, pb, pi);
+        for (int k = 0; k < 3; k++) pi[k] += ext_il[k];
+        const double nn[3] = {nv[i].x, nv[i].y, nv[i].z};
+        const double qc[4] = {-qw[0], -qw[1], -qw[2], qw[3]};
+        double C[3];
+        qrot(qc, nn, C);
+        double* row = h_x6 + (size_t)r * 6;
+        row[0] = nn[0]; row[1] = nn[1]; row[2] = nn[2];
+        row[3] = pi[1] * C[2] - pi[2] * C[1];
+        row[4] = pi[2] * C[0] - pi[0] * C[2];
+        row[5] = pi[0] * C[1] - pi[1] * C[0];
+        h[r] = -(double)nv[i].w;
+        r++;
+    }
+    return (int)r;
+}
+
+static int incremental_common(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], float map_leaf, int ekf_inited,
+                              int seed_all, double travel) {
+    if (!m || !s || !pose_wi || !ext_il) return LIO_E_INVALID;
+    if (m->device != s->device) { set_error("map and scan live on different devices"); return LIO_E_INVALID; }
+    hipSetDevice(s->device);
+    const PoseArgs pose = make_pose(pose_wi, ext_il);
+    int rc = incremental_classify(m, s, pose, map_leaf, ekf_inited, seed_all);
+    if (rc != LIO_OK) return rc;
+    const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
+    rc = map_insert_dev(m, s->stream, m->stage, bound, &m->dev->n_add, travel);
+    if (rc != LIO_OK) return rc;
+    rc = map_check(m, s->stream);
+    if (rc != LIO_OK) return rc;
+    return (int)m->host_dev->n_add;
+}
+
+int lio_map_incremental(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], float map_leaf, int ekf_inited, double travel) {
+    return incremental_common(m, s, pose_wi, ext_il, map_leaf, ekf_inited, 0, travel);
+}
+
+int lio_map_seed(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], double travel) {
+    return incremental_common(m, s, pose_wi, ext_il, 0.5f, 0, 1, travel);
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// lio_common.h -- internal declarations shared by the HIP translation units of liblio_hip.so.
+// Not part of the ABI (that is include/lio_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lio_hip.h"
+
+namespace lio {
+
+void set_error(const char* fmt, ...);
+
+#define LIO_HIP_TRY(expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            ::lio::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return LIO_E_DEVICE;                                                                  \
+        }                                                                                         \
+    } while (0)
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
+constexpr int kMaxStencil = 75;
+
+// one open-addressing slot of the voxel hash grid: 16 B, one probe = one 16-B load
+struct __attribute__((aligned(16))) Slot {
+    unsigned long long key;  // packed 3 x 21-bit voxel coordinate, kEmptyKey when free
+    uint32_t ptr;            // first point of the voxel in the pool (units of points)
+    uint32_t cnt;            // points stored
+};
+
+// device-resident status / counters of a map
+struct MapDev {
+    unsigned long long pool_top;     // bump allocator over the point pool
+    unsigned long long n_points;     // live points
+    uint32_t n_voxels;
+    uint32_t err;                    // bit0: table full, bit1: pool full
+    uint32_t n_add;                  // staging count for map_incremental
+    uint32_t pad;
+    unsigned long long knn_candidates;
+};
+
+// rigid transforms handed to kernels by value (doubles, as the reference computes them)
+struct PoseArgs {
+    double qw[4];  // rot  (x,y,z,w)
+    double tw[3];  // pos
+    double ql[4];  // offset_R_L_I
+    double tl[3];  // offset_T_L_I
+};
+
+// device-resident per-scan parameters (no host round trip between the downsample and its consumers)
+struct ScanDev {
+    uint32_t bbox_min[3];  // order-preserving uint encoding of float, init 0xFFFFFFFF
+    uint32_t bbox_max[3];  // init 0
+    uint32_t n_valid;      // finite input points
+    uint32_t n_ds;         // feats_down_size
+    uint32_t n_ds_prev;    // size of the neighbour cache before this scan (Nearest_Points.resize semantics)
+    uint32_t passthrough;  // PCL int32 overflow guard hit: output = input
+    uint32_t nbits;        // significant key bits for the radix sort
+    uint32_t err;          // bit0: n_ds > max_ds
+    int32_t minb[3];
+    int32_t mul1, mul2;
+    uint32_t total_cells;
+};
+
+struct StencilArgs {
+    int n;
+    signed char off[kMaxStencil][3];
+};
+
+}  // namespace lio
+
+struct lio_map {
+    int device;
+    hipStream_t stream;
+    float res, inv_res;
+    uint64_t max_points, max_voxels, pool_cap;
+    uint32_t table_cap, table_mask;  // power of two
+    lio::Slot* table;
+    uint32_t* cap;       // per-slot capacity of the voxel's pool region
+    uint32_t* pending;   // per-slot staging counter of a batch insert
+    float* created;      // per-slot travel distance at creation (ivox3d.h:240)
+    float4* pool;
+    lio::MapDev* dev;
+    lio::MapDev* host_dev;  // pinned mirror
+    uint32_t* slot_of_point;  // batch insert scratch
+    uint64_t slot_of_point_cap;
+    float4* stage;            // staging for host->device inserts and map_incremental
+    uint64_t stage_cap;
+    lio::StencilArgs stencil;
+    int stencil_id;
+    int own_stream;
+    uint64_t n_batches;
+    uint64_t bytes;
+};
+
+struct lio_scan {
+    int device;
+    hipStream_t stream;
+    uint32_t max_raw, max_ds;
+    uint32_t n_raw;
+    const float4* raw;   // points to raw_own or to a caller-owned device buffer
+    float4* raw_own;
+    float4* ds_body;
+    float4* ds_world;
+    float4* nn_pts;      // SoA: 5 planes of max_ds float4
+    int32_t* nn_cnt;
+    uint8_t* selected;
+    float4* normvec;
+    uint32_t *keys_a, *keys_b, *vals_a, *vals_b;
+    uint32_t* hist;      // radix histograms [256][nblocks]
+    uint32_t* blockcnt;  // head counts per tile
+    double* partial;     // per-block partial sums
+    uint32_t partial_blocks;
+    lio::ScanDev* dev;
+    lio::ScanDev* host_dev;       // pinned mirror
+    lio_normal_eq* d_result;
+    lio_normal_eq* h_result;      // pinned
+    int have_ds;
+    uint64_t bytes;
+};
+
+namespace lio {
+// kernels' host-side launchers (defined in the .hip files)
+int vg_downsample(lio_scan* s, float leaf);
+int scan_begin(lio_scan* s);
+int scan_set_nds(lio_scan* s, uint32_t n);
+int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t n, const uint32_t* d_n, double travel);
+int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);
+int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt);
+int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);
+int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float map_leaf, int ekf_inited, int seed_all);
+PoseArgs make_pose(const double pose_wi[7], const double ext_il[7]);
+}  // namespace lio

@@ -1,0 +1,465 @@
+// p2plane.hip -- point-to-plane measurement model of the FastLIO frontend on gfx950.
+//
+// Replaces the body of h_share_model_geometric
+// (/root/reference/slam/mapping/fastlio/src/laserMapping.cpp:813-982) and map_incremental's per-point
+// decision (:523-563):
+//   linearize_kernel  one lane per downsampled point: body->world (f64), esti_plane on the five cached
+//                     neighbours (include/common_lib.h:236-268: 5x3 column-pivoted Householder QR in f32),
+//                     residual gate (:860-871), Jacobian block [n, (R_il p + t_il) x (R_wi^T n)] (:909-931)
+//                     and a fixed-order f64 block reduction of J^T J (21), J^T h (6), sum|r|, count.
+//                     The N_eff x 15 matrix h_x of the reference never materialises.
+//   finalize_kernel   one workgroup: fixed-order sum of the block partials, 3x3 eigen-decomposition of
+//                     sum n n^T, and the six degeneracy sums of :946-964.
+//   classify_kernel   map_incremental's need_add test + ballot/prefix-sum compaction of the points to insert.
+// Per-point f32 arithmetic is written as explicit sequential IEEE operations (compiled with
+// -ffp-contract=off) in the operation order of Eigen's ColPivHouseholderQR so that gates flip exactly where
+// the CPU restatement's do.
+#include "lio_common.h"
+
+namespace lio {
+
+constexpr int kLinThreads = 128;
+constexpr int kAcc = 29;  // 21 (JtJ upper) + 6 (Jtr) + sum|r| + count
+
+__device__ inline void body_to_world_d(const PoseArgs& P, const float4 pb, double pi[3], float4& pw) {
+    const double vx = (double)pb.x, vy = (double)pb.y, vz = (double)pb.z;
+    double ux = P.ql[1] * vz - P.ql[2] * vy, uy = P.ql[2] * vx - P.ql[0] * vz, uz = P.ql[0] * vy - P.ql[1] * vx;
+    ux += ux; uy += uy; uz += uz;
+    double cx = P.ql[1] * uz - P.ql[2] * uy, cy = P.ql[2] * ux - P.ql[0] * uz, cz = P.ql[0] * uy - P.ql[1] * ux;
+    pi[0] = ((vx + P.ql[3] * ux) + cx) + P.tl[0];
+    pi[1] = ((vy + P.ql[3] * uy) + cy) + P.tl[1];
+    pi[2] = ((vz + P.ql[3] * uz) + cz) + P.tl[2];
+    ux = P.qw[1] * pi[2] - P.qw[2] * pi[1]; uy = P.qw[2] * pi[0] - P.qw[0] * pi[2]; uz = P.qw[0] * pi[1] - P.qw[1] * pi[0];
+    ux += ux; uy += uy; uz += uz;
+    cx = P.qw[1] * uz - P.qw[2] * uy; cy = P.qw[2] * ux - P.qw[0] * uz; cz = P.qw[0] * uy - P.qw[1] * ux;
+    pw.x = (float)(((pi[0] + P.qw[3] * ux) + cx) + P.tw[0]);
+    pw.y = (float)(((pi[1] + P.qw[3] * uy) + cy) + P.tw[1]);
+    pw.z = (float)(((pi[2] + P.qw[3] * uz) + cz) + P.tw[2]);
+    pw.w = pb.w;
+}
+
+// common_lib.h:236-268.  A n = -1 over the five neighbours, n by ColPivHouseholderQR::solve, then
+// pabcd = (n / |n|, 1 / |n|); false if any |n.q + d| > threshold.  All indices are compile-time after
+// unrolling so the 5x3 system lives in registers.
+__device__ inline bool esti_plane_dev(const float4 pt[5], float threshold, float pabcd[4]) {
+    float A[5][3], b[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { A[j][0] = pt[j].x; A[j][1] = pt[j].y; A[j][2] = pt[j].z; b[j] = -1.0f; }
+    const float eps = 1.1920929e-07f;
+    float normUpd[3], normDir[3], hcoef[3];
+    int perm[3] = {0, 1, 2};
+    float maxnorm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 5; r++) s = s + A[r][k] * A[r][k];
+        normDir[k] = sqrtf(s);
+        normUpd[k] = normDir[k];
+        maxnorm = fmaxf(maxnorm, normDir[k]);
+    }
+    const float thr_helper = ((maxnorm * eps) * (maxnorm * eps)) / 5.0f;
+    const float downdate_thr = sqrtf(eps);
+    int nonzero = 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int big = k;
+        float bigv = normUpd[k];
+#pragma unroll
+        for (int j = k + 1; j < 3; j++)
+            if (normUpd[j] > bigv) { bigv = normUpd[j]; big = j; }
+        const float big_sq = bigv * bigv;
+        if (nonzero == 3 && big_sq < thr_helper * (float)(5 - k)) nonzero = k;
+#pragma unroll
+        for (int j = k + 1; j < 3; j++) {
+            if (big == j) {
+#pragma unroll
+                for (int r = 0; r < 5; r++) { const float t = A[r][k]; A[r][k] = A[r][j]; A[r][j] = t; }
+                { const float t = normUpd[k]; normUpd[k] = normUpd[j]; normUpd[j] = t; }
+                { const float t = normDir[k]; normDir[k] = normDir[j]; normDir[j] = t; }
+                { const int t = perm[k]; perm[k] = perm[j]; perm[j] = t; }
+            }
+        }
+        const float c0 = A[k][k];
+        float tail = 0.f;
+#pragma unroll
+        for (int r = k + 1; r < 5; r++) tail = tail + A[r][k] * A[r][k];
+        float tau, beta;
+        if (tail <= 1.17549435e-38f) {
+            tau = 0.f;
+            beta = c0;
+#pragma unroll
+            for (int r = k + 1; r < 5; r++) A[r][k] = 0.f;
+        } else {
+            beta = sqrtf(c0 * c0 + tail);
+            if (c0 >= 0.f) beta = -beta;
+            const float den = c0 - beta;
+#pragma unroll
+            for (int r = k + 1; r < 5; r++) A[r][k] = A[r][k] / den;
+            tau = (beta - c0) / beta;
+        }
+        A[k][k] = beta;
+        hcoef[k] = tau;
+        if (tau != 0.f) {
+#pragma unroll
+            for (int j = k + 1; j < 3; j++) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = k + 1; r < 5; r++) t = t + A[r][k] * A[r][j];
+                t = t + A[k][j];
+                A[k][j] = A[k][j] - tau * t;
+#pragma unroll
+                for (int r = k + 1; r < 5; r++) A[r][j] = A[r][j] - (tau * A[r][k]) * t;
+            }
+        }
+#pragma unroll
+        for (int j = k + 1; j < 3; j++) {
+            if (normUpd[j] != 0.f) {
+                float t = fabsf(A[k][j]) / normUpd[j];
+                t = (1.f + t) * (1.f - t);
+                if (t < 0.f) t = 0.f;
+                const float ratio = normUpd[j] / normDir[j];
+                const float t2 = t * (ratio * ratio);
+                if (t2 <= downdate_thr) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = k + 1; r < 5; r++) s = s + A[r][j] * A[r][j];
+                    normDir[j] = sqrtf(s);
+                    normUpd[j] = normDir[j];
+                } else {
+                    normUpd[j] = normUpd[j] * sqrtf(t);
+                }
+            }
+        }
+    }
+    // c = Q^T b
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (k < nonzero) {
+            const float tau = hcoef[k];
+            if (tau != 0.f) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = k + 1; r < 5; r++) t = t + A[r][k] * b[r];
+                t = t + b[k];
+                b[k] = b[k] - tau * t;
+#pragma unroll
+                for (int r = k + 1; r < 5; r++) b[r] = b[r] - (tau * A[r][k]) * t;
+            }
+        }
+    }
+    float xs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 2; i >= 0; i--) {
+        if (i < nonzero) {
+            float s = b[i];
+#pragma unroll
+            for (int j = i + 1; j < 3; j++)
+                if (j < nonzero) s = s - A[i][j] * xs[j];
+            xs[i] = s / A[i][i];
+        }
+    }
+    float nv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (i < nonzero) {
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+                if (perm[i] == a) nv[a] = xs[i];
+        }
+    }
+    const float n = sqrtf((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
+    pabcd[0] = nv[0] / n;
+    pabcd[1] = nv[1] / n;
+    pabcd[2] = nv[2] / n;
+    pabcd[3] = 1.0f / n;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const float v = ((pabcd[0] * pt[j].x + pabcd[1] * pt[j].y) + pabcd[2] * pt[j].z) + pabcd[3];
+        if (fabsf(v) > threshold) ok = false;
+    }
+    return ok;
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, int redo_knn, const ScanDev* __restrict__ sd,
+                                                                const float4* __restrict__ ds_body, float4* __restrict__ ds_world,
+                                                                const float4* __restrict__ nn_pts, uint32_t nn_stride,
+                                                                const int32_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
+                                                                float4* __restrict__ normvec, double* __restrict__ partial) {
+    const uint32_t n = sd->n_ds;
+    if (blockIdx.x * kLinThreads >= n) return;  // finalize only reads the first ceil(n / kLinThreads) partials
+    const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
+    double acc[kAcc];
+#pragma unroll
+    for (int a = 0; a < kAcc; a++) acc[a] = 0.0;
+    if (i < n) {
+        const float4 pb = ds_body[i];
+        double pi[3];
+        float4 pw;
+        body_to_world_d(pose, pb, pi, pw);
+        ds_world[i] = pw;
+        // point_selected_surf is re-armed only by a neighbour search (laserMapping.cpp:842-854)
+        bool sel = redo_knn ? (nn_cnt[i] >= 5) : (selected[i] != 0);
+        if (sel) {
+            float4 near[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) near[k] = nn_pts[(size_t)k * nn_stride + i];
+            float pabcd[4];
+            sel = false;
+            if (esti_plane_dev(near, 0.1f, pabcd)) {
+                const float pd2 = ((pabcd[0] * pw.x + pabcd[1] * pw.y) + pabcd[2] * pw.z) + pabcd[3];
+                const double pbn = sqrt(((double)pb.x * pb.x + (double)pb.y * pb.y) + (double)pb.z * pb.z);
+                // float s = 1 - 0.9 * fabs(pd2) / sqrt(p_body.norm()); if (s > 0.9)   (laserMapping.cpp:861-863)
+                const float sc = (float)(1 - 0.9 * fabs((double)pd2) / sqrt(pbn));
+                if ((double)sc > 0.9) {
+                    sel = true;
+                    normvec[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pd2);
+                    // Jacobian block (laserMapping.cpp:909-931), f64
+                    const double nx = (double)pabcd[0], ny = (double)pabcd[1], nz = (double)pabcd[2];
+                    // C = rot.conjugate() * norm_vec
+                    const double qx = -pose.qw[0], qy = -pose.qw[1], qz = -pose.qw[2], qw = pose.qw[3];
+                    double ux = qy * nz - qz * ny, uy = qz * nx - qx * nz, uz = qx * ny - qy * nx;
+                    ux += ux; uy += uy; uz += uz;
+                    const double cx = (nx + qw * ux) + (qy * uz - qz * uy);
+                    const double cy = (ny + qw * uy) + (qz * ux - qx * uz);
+                    const double cz = (nz + qw * uz) + (qx * uy - qy * ux);
+                    double row[6];
+                    row[0] = nx; row[1] = ny; row[2] = nz;
+                    row[3] = pi[1] * cz - pi[2] * cy;  // A = point_crossmat * C = p_imu x C
+                    row[4] = pi[2] * cx - pi[0] * cz;
+                    row[5] = pi[0] * cy - pi[1] * cx;
+                    const double h = -(double)pd2;
+                    int t = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+#pragma unroll
+                        for (int c = a; c < 6; c++) acc[t++] = row[a] * row[c];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) acc[21 + a] = row[a] * h;
+                    acc[27] = (double)fabsf(pd2);
+                    acc[28] = 1.0;
+                }
+            }
+        }
+        selected[i] = sel ? 1 : 0;
+    }
+    __shared__ double red[kLinThreads / 64][kAcc];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < kAcc; a++) {
+        const double s = wave_sum(acc[a]);
+        if (lane == 0) red[wave][a] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAcc) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kLinThreads / 64; w++) s += red[w][threadIdx.x];
+        partial[(size_t)blockIdx.x * kAcc + threadIdx.x] = s;
+    }
+}
+
+// symmetric 3x3 eigen-decomposition, cyclic Jacobi in f64; eigenvalues ascending, eigenvectors as columns
+// (the reference calls Eigen::SelfAdjointEigenSolver at laserMapping.cpp:939-941)
+__device__ inline void eig3_dev(const double Ain[9], double w[3], double V[9]) {
+    double A[9];
+    for (int i = 0; i < 9; i++) { A[i] = Ain[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                const double apq = A[p * 3 + q];
+                if (apq == 0.0) continue;
+                const double app = A[p * 3 + p], aqq = A[q * 3 + q];
+                const double theta = (aqq - app) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+                    A[k * 3 + p] = c * akp - s * akq;
+                    A[k * 3 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+                    A[p * 3 + k] = c * apk - s * aqk;
+                    A[q * 3 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                    V[k * 3 + p] = c * vkp - s * vkq;
+                    V[k * 3 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (w[j] < w[i]) {
+                const double t = w[i]; w[i] = w[j]; w[j] = t;
+                for (int k = 0; k < 3; k++) { const double u = V[k * 3 + i]; V[k * 3 + i] = V[k * 3 + j]; V[k * 3 + j] = u; }
+            }
+}
+
+constexpr int kFinThreads = 1024;
+
+__global__ void __launch_bounds__(kFinThreads) finalize_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial,
+                                                               const uint8_t* __restrict__ selected, const float4* __restrict__ normvec,
+                                                               const MapDev* __restrict__ md, lio_normal_eq* __restrict__ out) {
+    __shared__ double acc[kAcc];
+    __shared__ double V[9];
+    __shared__ double red[kFinThreads / 64][6];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t n = sd->n_ds;
+    const uint32_t nb = (n + kLinThreads - 1) / kLinThreads;
+    // fixed-order reduction of the block partials: component c is owned by 32 lanes (stride-32 chunks,
+    // then a fixed xor tree) -> run-to-run identical
+    {
+        const int c = tid >> 5, l = tid & 31;
+        double s = 0.0;
+        if (c < kAcc)
+            for (uint32_t b = l; b < nb; b += 32) s += partial[(size_t)b * kAcc + c];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (c < kAcc && l == 0) acc[c] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        double J[36];
+        for (int a = 0; a < 6; a++)
+            for (int c = a; c < 6; c++) { J[a * 6 + c] = acc[t]; J[c * 6 + a] = acc[t]; t++; }
+        for (int k = 0; k < 36; k++) out->JtJ[k] = J[k];
+        for (int a = 0; a < 6; a++) out->Jtr[a] = acc[21 + a];
+        double N[9], w[3], Vl[9];
+        for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 3; c++) N[a * 3 + c] = J[a * 6 + c];
+        eig3_dev(N, w, Vl);
+        for (int k = 0; k < 9; k++) { out->nnT[k] = N[k]; out->eigvec[k] = Vl[k]; V[k] = Vl[k]; }
+        for (int k = 0; k < 3; k++) out->eigval[k] = w[k];
+        out->sum_abs_res = acc[27];
+        out->n_eff = (uint32_t)(acc[28] + 0.5);
+        out->n_ds = n;
+        const unsigned long long kc = md ? md->knn_candidates : 0ull;
+        out->n_knn_candidates_lo = (uint32_t)kc;
+        out->n_knn_candidates_hi = (uint32_t)(kc >> 32);
+    }
+    __syncthreads();
+    // degeneracy sums (laserMapping.cpp:946-964): rows re-normalised, |cos| against each eigenvector
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = tid; i < n; i += kFinThreads) {
+        if (!selected[i]) continue;
+        const float4 nv = normvec[i];
+        double f0 = (double)nv.x, f1 = (double)nv.y, f2 = (double)nv.z;
+        const double nn = sqrt(f0 * f0 + f1 * f1 + f2 * f2);
+        if (nn > 0) { f0 /= nn; f1 /= nn; f2 /= nn; }
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const float dotp = (float)fabs(f0 * V[0 * 3 + e] + f1 * V[1 * 3 + e] + f2 * V[2 * 3 + e]);
+            if (dotp > 0.1736f) s[e] += (double)dotp;
+            if (dotp > 0.7070f) s[3 + e] += (double)dotp;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
+        const double v = wave_sum(s[e]);
+        if (lane == 0) red[wave][e] = v;
+    }
+    __syncthreads();
+    if (tid < 6) {
+        double v = 0.0;
+        for (int w = 0; w < kFinThreads / 64; w++) v += red[w][tid];
+        if (tid < 3) out->contri[tid] = v;
+        else out->strong[tid - 3] = v;
+    }
+}
+
+int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {
+    const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
+    uint32_t blocks = (bound + kLinThreads - 1) / kLinThreads;
+    if (blocks == 0) blocks = 1;
+    if (blocks > s->partial_blocks) blocks = s->partial_blocks;
+    hipLaunchKernelGGL(linearize_kernel, blocks, kLinThreads, 0, s->stream, pose, redo_knn, s->dev, s->ds_body, s->ds_world, s->nn_pts,
+                       s->max_ds, s->nn_cnt, s->selected, s->normvec, s->partial);
+    hipLaunchKernelGGL(finalize_kernel, 1, kFinThreads, 0, s->stream, s->dev, s->partial, s->selected, s->normvec, m ? m->dev : nullptr,
+                       s->d_result);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+// map_incremental (laserMapping.cpp:523-563): which downsampled points enter the map
+__global__ void __launch_bounds__(256) classify_kernel(PoseArgs pose, const ScanDev* __restrict__ sd, const float4* __restrict__ ds_body,
+                                                       float4* __restrict__ ds_world, const float4* __restrict__ nn_pts, uint32_t nn_stride,
+                                                       const int32_t* __restrict__ nn_cnt, float map_leaf, int ekf_inited, int seed_all,
+                                                       float4* __restrict__ stage, MapDev* md) {
+    const uint32_t n = sd->n_ds;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        bool add = false;
+        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+            double pi[3];
+            body_to_world_d(pose, ds_body[i], pi, pw);
+            ds_world[i] = pw;
+            const int cnt = nn_cnt[i];
+            add = true;
+            if (!seed_all && cnt > 0 && ekf_inited) {
+                const double fs = (double)map_leaf;
+                float4 mid;
+                mid.x = (float)(floor((double)pw.x / fs) * fs + 0.5 * fs);
+                mid.y = (float)(floor((double)pw.y / fs) * fs + 0.5 * fs);
+                mid.z = (float)(floor((double)pw.z / fs) * fs + 0.5 * fs);
+                const float dist = ((pw.x - mid.x) * (pw.x - mid.x) + (pw.y - mid.y) * (pw.y - mid.y)) + (pw.z - mid.z) * (pw.z - mid.z);
+                const double half = 0.5 * fs;
+                const float4 n0 = nn_pts[i];
+                if (fabs((double)(n0.x - mid.x)) > half && fabs((double)(n0.y - mid.y)) > half && fabs((double)(n0.z - mid.z)) > half) {
+                    add = true;  // PointNoNeedDownsample
+                } else if (cnt >= 5) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const float4 q = nn_pts[(size_t)k * nn_stride + i];
+                        const float dq = ((q.x - mid.x) * (q.x - mid.x) + (q.y - mid.y) * (q.y - mid.y)) + (q.z - mid.z) * (q.z - mid.z);
+                        if (dq < dist) add = false;
+                    }
+                }
+            }
+        }
+        const unsigned long long m = __ballot(add);
+        uint32_t wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&md->n_add, (uint32_t)__popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (add) stage[wbase + __popcll(m & ((1ull << lane) - 1ull))] = pw;
+    }
+}
+
+int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float map_leaf, int ekf_inited, int seed_all) {
+    const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
+    if (bound > m->stage_cap) {
+        set_error("map_incremental: %u points exceed the staging capacity %llu", bound, (unsigned long long)m->stage_cap);
+        return LIO_E_CAPACITY;
+    }
+    uint32_t blocks = (bound + 255) / 256;
+    if (blocks == 0) blocks = 1;
+    LIO_HIP_TRY(hipMemsetAsync(&m->dev->n_add, 0, sizeof(uint32_t), s->stream));
+    hipLaunchKernelGGL(classify_kernel, blocks, 256, 0, s->stream, pose, s->dev, s->ds_body, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt,
+                       map_leaf, ekf_inited, seed_all, m->stage, m->dev);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+PoseArgs make_pose(const double pose_wi[7], const double ext_il[7]) {
+    PoseArgs p;
+    for (int i = 0; i < 3; i++) { p.tw[i] = pose_wi[i]; p.tl[i] = ext_il[i]; }
+    for (int i = 0; i < 4; i++) { p.qw[i] = pose_wi[3 + i]; p.ql[i] = ext_il[3 + i]; }
+    return p;
+}
+
+}  // namespace lio

@@ -1,0 +1,136 @@
+"""ctypes binding of liblio_hip.so (include/lio_hip.h) -- the MI355X-native LIO scan-matching core.
+
+There is no CPU fallback: importing this module without the built library raises, and every handle
+constructor raises when no HIP device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblio_hip.so")
+
+LIO_OK, LIO_E_INVALID, LIO_E_CAPACITY, LIO_E_DEVICE, LIO_E_STATE = 0, -1, -2, -3, -4
+
+# every symbol include/lio_hip.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "lio_last_error", "lio_device_count", "lio_map_bytes",
+    "lio_map_create", "lio_map_destroy", "lio_map_set_stencil", "lio_map_insert", "lio_map_insert_device", "lio_map_stats",
+    "lio_map_dump", "lio_map_knn",
+    "lio_scan_create", "lio_scan_destroy", "lio_scan_upload", "lio_scan_set_device", "lio_scan_voxel_downsample", "lio_scan_set_ds",
+    "lio_scan_num_ds", "lio_scan_download_ds", "lio_scan_download_world", "lio_scan_download_match",
+    "lio_p2plane_linearize", "lio_p2plane_rows", "lio_map_incremental", "lio_map_seed",
+    "lio_engine_create", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
+    "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
+    "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
+    "lio_engine_enable_timing", "lio_state_boxplus", "lio_state_boxminus",
+]
+
+
+class NormalEq(C.Structure):
+    _fields_ = [("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6), ("nnT", C.c_double * 9), ("eigvec", C.c_double * 9),
+                ("eigval", C.c_double * 3), ("contri", C.c_double * 3), ("strong", C.c_double * 3), ("sum_abs_res", C.c_double),
+                ("n_eff", C.c_uint32), ("n_ds", C.c_uint32), ("n_knn_candidates_lo", C.c_uint32), ("n_knn_candidates_hi", C.c_uint32)]
+
+
+class PassLog(C.Structure):
+    _fields_ = [("knn", C.c_int32), ("n_eff", C.c_int32), ("valid", C.c_int32), ("degenerate", C.c_int32), ("sum_abs_res", C.c_double),
+                ("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6), ("dx", C.c_double * 23)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("downsample_us", C.c_float), ("knn_us", C.c_float), ("linearize_us", C.c_float), ("insert_us", C.c_float),
+                ("total_device_us", C.c_float), ("host_solve_us", C.c_float), ("total_wall_us", C.c_float), ("n_knn_pass", C.c_int32),
+                ("n_pass", C.c_int32), ("n_ds", C.c_int32), ("n_eff_last", C.c_int32), ("n_added", C.c_int32),
+                ("knn_candidates", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback for the LIO hot path.")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, f64p, i32p, u8p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    u32, u64, dbl, flt, cint = C.c_uint32, C.c_uint64, C.c_double, C.c_float, C.c_int
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("lio_last_error", C.c_char_p)
+    sig("lio_device_count", cint)
+    sig("lio_map_bytes", u64, vp)
+    sig("lio_map_create", vp, cint, flt, u64, u64, cint)
+    sig("lio_map_destroy", None, vp)
+    sig("lio_map_set_stencil", cint, vp, cint)
+    sig("lio_map_insert", cint, vp, f32p, u64, dbl)
+    sig("lio_map_insert_device", cint, vp, vp, u64, dbl)
+    sig("lio_map_stats", cint, vp, C.POINTER(u64), C.POINTER(u64))
+    sig("lio_map_dump", C.c_int64, vp, f32p, u64)
+    sig("lio_map_knn", cint, vp, f32p, u32, f32p, i32p)
+    sig("lio_scan_create", vp, cint, u32, u32)
+    sig("lio_scan_destroy", None, vp)
+    sig("lio_scan_upload", cint, vp, f32p, u32)
+    sig("lio_scan_set_device", cint, vp, vp, u32)
+    sig("lio_scan_voxel_downsample", cint, vp, flt, cint, C.POINTER(u32))
+    sig("lio_scan_set_ds", cint, vp, f32p, u32)
+    sig("lio_scan_num_ds", cint, vp)
+    sig("lio_scan_download_ds", cint, vp, f32p, u32)
+    sig("lio_scan_download_world", cint, vp, f32p, u32)
+    sig("lio_scan_download_match", cint, vp, u8p, f32p, i32p, f32p)
+    sig("lio_p2plane_linearize", cint, vp, vp, f64p, f64p, cint, C.POINTER(NormalEq))
+    sig("lio_p2plane_rows", cint, vp, f64p, f64p, f64p, f64p, u32)
+    sig("lio_map_incremental", cint, vp, vp, f64p, f64p, flt, cint, dbl)
+    sig("lio_map_seed", cint, vp, vp, f64p, f64p, dbl)
+    sig("lio_engine_create", vp, cint, flt, cint, u64, u64, u32, u32)
+    sig("lio_engine_destroy", None, vp)
+    sig("lio_engine_map", vp, vp)
+    sig("lio_engine_scan", vp, vp)
+    sig("lio_engine_set_state", cint, vp, f64p)
+    sig("lio_engine_get_state", cint, vp, f64p)
+    sig("lio_engine_set_cov", cint, vp, f64p)
+    sig("lio_engine_get_cov", cint, vp, f64p)
+    sig("lio_engine_set_flags", cint, vp, cint, cint, dbl, dbl)
+    sig("lio_engine_travel", dbl, vp)
+    sig("lio_engine_is_degenerate", cint, vp)
+    sig("lio_engine_update", cint, vp)
+    sig("lio_engine_pass_log", cint, vp, cint, C.POINTER(PassLog))
+    sig("lio_engine_process_scan", cint, vp, f32p, u32, dbl)
+    sig("lio_engine_process_scan_device", cint, vp, vp, u32, dbl)
+    sig("lio_engine_timings", cint, vp, C.POINTER(Timings))
+    sig("lio_engine_enable_timing", cint, vp, cint)
+    sig("lio_state_boxplus", None, f64p, f64p, f64p)
+    sig("lio_state_boxminus", None, f64p, f64p, f64p)
+    _lib = L
+    return L
+
+
+class LioError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = lib().lio_last_error()
+        raise LioError(f"{what}: error {rc}: {msg.decode() if msg else ''}")
+    return rc
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))

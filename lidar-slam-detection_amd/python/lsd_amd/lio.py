@@ -1,0 +1,277 @@
+"""Host-side objects over the C ABI: Map (iVox), Scan (per-scan buffers) and Engine (fastlio_main body).
+
+Names and argument meaning follow the reference's FastLIO frontend
+(/root/reference/slam/mapping/fastlio/src/laserMapping.cpp): `Engine.process_scan` is the part of
+`fastlio_main()` that follows IMU processing, `Engine.update` is
+`kf.update_iterated_dyn_share_modified(LASER_POINT_COV)`, `Map.add` is `ivox->AddPoints`,
+`Map.knn` is `ivox->GetClosestPoint(p, out, 5, 5.0)`, `Scan.voxel_downsample` is `downSizeFilterSurf.filter`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, f32, f64, lib, ptr
+
+STATE_DIM = 26  # pos3 rot4(xyzw) R_il4 t_il3 vel3 bg3 ba3 grav3  (use-ikfom.hpp:12-21)
+DOF = 23
+G_LEN = 9.809
+
+
+def default_state():
+    s = np.zeros(STATE_DIM)
+    s[6] = 1.0
+    s[10] = 1.0
+    s[23] = G_LEN
+    return s
+
+
+def init_cov():
+    """covariance after IMU initialisation (IMU_Processing.hpp:224-231)"""
+    P = np.eye(23)
+    for i in (6, 7, 8, 9, 10, 11):
+        P[i, i] = 0.00001
+    for i in (15, 16, 17):
+        P[i, i] = 0.0001
+    for i in (18, 19, 20):
+        P[i, i] = 0.001
+    P[21, 21] = P[22, 22] = 0.00001
+    return P
+
+
+def _pose_ext(state):
+    s = f64(state)
+    pose = np.concatenate([s[0:3], s[3:7]])
+    ext = np.concatenate([s[11:14], s[7:11]])
+    return f64(pose), f64(ext)
+
+
+class Map:
+    def __init__(self, resolution=0.5, stencil=19, max_points=2_000_000, max_voxels=1_000_000, device=0, _borrow=None):
+        self._own = _borrow is None
+        self.h = _borrow if _borrow is not None else lib().lio_map_create(device, resolution, max_points, max_voxels, stencil)
+        if not self.h:
+            raise capi.LioError("lio_map_create failed: " + lib().lio_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self._own:
+            lib().lio_map_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def set_stencil(self, s):
+        check(lib().lio_map_set_stencil(self.h, s), "set_stencil")
+
+    def add(self, pts, travel=0.0):
+        p = f32(pts).reshape(-1, 4)
+        check(lib().lio_map_insert(self.h, ptr(p, C.c_float), len(p), float(travel)), "map insert")
+
+    def add_device(self, dptr, n, travel=0.0):
+        check(lib().lio_map_insert_device(self.h, C.c_void_p(dptr), n, float(travel)), "map insert (device)")
+
+    def stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().lio_map_stats(self.h, C.byref(a), C.byref(b)), "map stats")
+        return int(a.value), int(b.value)
+
+    @property
+    def num_points(self):
+        return self.stats()[0]
+
+    @property
+    def num_voxels(self):
+        return self.stats()[1]
+
+    @property
+    def nbytes(self):
+        return int(lib().lio_map_bytes(self.h))
+
+    def dump(self):
+        n = self.num_points
+        out = np.zeros((max(n, 1), 4), np.float32)
+        m = check(lib().lio_map_dump(self.h, ptr(out, C.c_float), max(n, 1)), "map dump")
+        return out[:m]
+
+    def knn(self, q):
+        q = f32(q).reshape(-1, 4)
+        out = np.zeros((len(q), 5, 4), np.float32)
+        cnt = np.zeros(len(q), np.int32)
+        check(lib().lio_map_knn(self.h, ptr(q, C.c_float), len(q), ptr(out, C.c_float), ptr(cnt, C.c_int32)), "map knn")
+        return out, cnt
+
+
+class Scan:
+    def __init__(self, max_raw=262144, max_ds=100000, device=0, _borrow=None):
+        self._own = _borrow is None
+        self.max_ds = max_ds
+        self.h = _borrow if _borrow is not None else lib().lio_scan_create(device, max_raw, max_ds)
+        if not self.h:
+            raise capi.LioError("lio_scan_create failed: " + lib().lio_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self._own:
+            lib().lio_scan_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def upload(self, body_xyzi):
+        p = f32(body_xyzi).reshape(-1, 4)
+        check(lib().lio_scan_upload(self.h, ptr(p, C.c_float), len(p)), "scan upload")
+        self._keep = p
+
+    def set_device(self, dptr, n):
+        check(lib().lio_scan_set_device(self.h, C.c_void_p(dptr), n), "scan set_device")
+
+    def voxel_downsample(self, leaf=0.5, sync=True):
+        n = C.c_uint32(0)
+        check(lib().lio_scan_voxel_downsample(self.h, float(leaf), int(sync), C.byref(n)), "voxel downsample")
+        return int(n.value)
+
+    def set_ds(self, ds):
+        d = f32(ds).reshape(-1, 4)
+        check(lib().lio_scan_set_ds(self.h, ptr(d, C.c_float), len(d)), "set_ds")
+
+    @property
+    def num_ds(self):
+        return check(lib().lio_scan_num_ds(self.h), "num_ds")
+
+    def get_ds(self):
+        out = np.zeros((self.max_ds, 4), np.float32)
+        n = check(lib().lio_scan_download_ds(self.h, ptr(out, C.c_float), self.max_ds), "download ds")
+        return out[:n].copy()
+
+    def get_world(self):
+        out = np.zeros((self.max_ds, 4), np.float32)
+        n = check(lib().lio_scan_download_world(self.h, ptr(out, C.c_float), self.max_ds), "download world")
+        return out[:n].copy()
+
+    def get_match(self):
+        n = self.num_ds
+        sel = np.zeros(n, np.uint8)
+        nv = np.zeros((n, 4), np.float32)
+        cnt = np.zeros(n, np.int32)
+        nn = np.zeros((n, 5, 4), np.float32)
+        check(lib().lio_scan_download_match(self.h, ptr(sel, C.c_uint8), ptr(nv, C.c_float), ptr(cnt, C.c_int32), ptr(nn, C.c_float)),
+              "download match")
+        return dict(selected=sel, normvec=nv, nn_cnt=cnt, nn=nn)
+
+
+def linearize(map_, scan, state, redo_knn=True):
+    """one evaluation of h_share_model_geometric at `state` (26 doubles); returns the normal equations"""
+    pose, ext = _pose_ext(state)
+    ne = capi.NormalEq()
+    check(lib().lio_p2plane_linearize(map_.h, scan.h, ptr(pose, C.c_double), ptr(ext, C.c_double), int(redo_knn), C.byref(ne)), "linearize")
+    return dict(n_eff=int(ne.n_eff), n_ds=int(ne.n_ds), JtJ=np.array(ne.JtJ).reshape(6, 6), Jtr=np.array(ne.Jtr),
+                nnT=np.array(ne.nnT).reshape(3, 3), eigvec=np.array(ne.eigvec).reshape(3, 3), eigval=np.array(ne.eigval),
+                contri=np.array(ne.contri), strong=np.array(ne.strong), sum_abs_res=float(ne.sum_abs_res),
+                knn_candidates=(int(ne.n_knn_candidates_hi) << 32) | int(ne.n_knn_candidates_lo))
+
+
+def map_incremental(map_, scan, state, map_leaf=0.5, ekf_inited=True, travel=0.0):
+    pose, ext = _pose_ext(state)
+    return check(lib().lio_map_incremental(map_.h, scan.h, ptr(pose, C.c_double), ptr(ext, C.c_double), float(map_leaf), int(ekf_inited),
+                                           float(travel)), "map_incremental")
+
+
+class Engine:
+    """The FastLIO per-scan engine (state + covariance + map + scan buffers) on one GPU."""
+
+    def __init__(self, resolution=0.5, stencil=75, max_points=2_000_000, max_voxels=1_000_000, max_raw=262144, max_ds=100000, device=0):
+        self.h = lib().lio_engine_create(device, resolution, stencil, max_points, max_voxels, max_raw, max_ds)
+        if not self.h:
+            raise capi.LioError("lio_engine_create failed: " + lib().lio_last_error().decode())
+        self.map = Map(_borrow=lib().lio_engine_map(self.h))
+        self.scan = Scan(max_ds=max_ds, _borrow=lib().lio_engine_scan(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lio_engine_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def set_state(self, s):
+        s = f64(s)
+        assert s.size == STATE_DIM
+        check(lib().lio_engine_set_state(self.h, ptr(s, C.c_double)))
+
+    def get_state(self):
+        s = np.zeros(STATE_DIM)
+        check(lib().lio_engine_get_state(self.h, ptr(s, C.c_double)))
+        return s
+
+    def set_cov(self, P):
+        P = f64(P).reshape(23, 23)
+        check(lib().lio_engine_set_cov(self.h, ptr(P, C.c_double)))
+
+    def get_cov(self):
+        P = np.zeros((23, 23))
+        check(lib().lio_engine_get_cov(self.h, ptr(P, C.c_double)))
+        return P
+
+    def set_flags(self, ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=0.0):
+        check(lib().lio_engine_set_flags(self.h, int(ekf_inited), int(first_scan), float(travel), float(first_lidar_time)))
+
+    def set_stencil(self, s):
+        self.map.set_stencil(s)
+
+    def map_add(self, pts, travel=0.0):
+        self.map.add(pts, travel)
+
+    def set_ds(self, ds):
+        self.scan.set_ds(ds)
+
+    def get_ds(self):
+        return self.scan.get_ds()
+
+    def update(self):
+        n = check(lib().lio_engine_update(self.h), "engine update")
+        logs = []
+        for i in range(n):
+            pl = capi.PassLog()
+            check(lib().lio_engine_pass_log(self.h, i, C.byref(pl)))
+            logs.append(dict(knn=pl.knn, n_eff=pl.n_eff, valid=pl.valid, degenerate=pl.degenerate, sum_abs_res=pl.sum_abs_res,
+                             JtJ=np.array(pl.JtJ).reshape(6, 6), Jtr=np.array(pl.Jtr), dx=np.array(pl.dx)))
+        return logs
+
+    def map_incremental(self, map_leaf=0.5, ekf_inited=True):
+        return map_incremental(self.map, self.scan, self.get_state(), map_leaf, ekf_inited, self.travel)
+
+    def process_scan(self, raw, lidar_beg_time):
+        r = f32(raw).reshape(-1, 4)
+        return check(lib().lio_engine_process_scan(self.h, ptr(r, C.c_float), len(r), float(lidar_beg_time)), "process_scan")
+
+    def process_scan_device(self, dptr, n, lidar_beg_time):
+        return check(lib().lio_engine_process_scan_device(self.h, C.c_void_p(dptr), n, float(lidar_beg_time)), "process_scan")
+
+    def enable_timing(self, on=True):
+        check(lib().lio_engine_enable_timing(self.h, int(on)))
+
+    def timings(self):
+        t = capi.Timings()
+        check(lib().lio_engine_timings(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    @property
+    def travel(self):
+        return lib().lio_engine_travel(self.h)
+
+    @property
+    def is_degenerate(self):
+        return bool(lib().lio_engine_is_degenerate(self.h))
+
+
+def state_boxplus(s, d):
+    s, d = f64(s), f64(d)
+    o = np.zeros(STATE_DIM)
+    lib().lio_state_boxplus(ptr(s, C.c_double), ptr(d, C.c_double), ptr(o, C.c_double))
+    return o
+
+
+def state_boxminus(a, b):
+    a, b = f64(a), f64(b)
+    o = np.zeros(DOF)
+    lib().lio_state_boxminus(ptr(a, C.c_double), ptr(b, C.c_double), ptr(o, C.c_double))
+    return o
