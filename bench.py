@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- registered points/sec of the LIO scan-matching hot path on MI355X.
+
+Workload (BASELINE.json metric): synthetic 64-beam scans (64 x 1875 = 120 000 points) registered against a
+1e7-point static map resident in HBM -- per scan: voxel-grid downsample (leaf 0.5 m) + the iterated ESKF
+update (<= 5 passes, each = body->world, [stencil kNN], plane fit, gate, J^T J reduction, host 23-DoF solve).
+A "step" is one scan.  Inputs (map + raw scans) are in HBM before the timed region.  Scans are independent,
+so with N GPUs every rank registers its own K scans against its own replica of the map (weak scaling, no
+data-path collective).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "lidar-slam-detection_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--map-points", type=int, default=10_000_000)
+    ap.add_argument("--n-az", type=int, default=1875)
+    ap.add_argument("--scan-pool", type=int, default=8, help="distinct scans cycled through the steps")
+    ap.add_argument("--cpu-scans", type=int, default=24, help="scans of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--seed", type=int, default=1000)
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the LIO hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from lsd_amd import lio, synth
+
+    # ---- synthetic workload (SURVEY.md section 8d, config 2 scaled to the metric's 1e7-point map) -------------
+    scene = synth.Scene(half=100.0, n_boxes=40, seed=1)
+    map_pts = scene.sample_surface(args.map_points, seed=2, sigma=0.01)
+    rng = np.random.default_rng(args.seed + rank)
+    scans = []
+    for k in range(args.scan_pool):
+        pos = np.array([rng.uniform(-4, 4), rng.uniform(-4, 4), 1.8])
+        q = synth.quat_from_rotvec([0, 0, rng.uniform(-np.pi, np.pi)])
+        raw, _ = synth.make_scan(scene, pos, q, seed=args.seed + 100 * rank + k, n_az=args.n_az, fov_deg=(-24.8, 2.0), max_range=150.0)
+        gp, gq = synth.perturb_pose(pos, q, seed=args.seed + 7 * k + rank, max_t=0.3, max_deg=2.0)
+        scans.append(dict(raw=raw, pos=pos, q=q, guess=synth.state_from_pose(gp, gq)))
+    n_raw = int(np.mean([len(s["raw"]) for s in scans]))
+
+    eng = lio.Engine(resolution=0.5, stencil=19, max_points=max(args.map_points, 1_000_000), max_voxels=max(args.map_points // 4, 1_000_000),
+                     max_raw=1 << 18, max_ds=100000, device=local_rank)
+    # the map goes to HBM once; the raw scans live in torch tensors on the device (inputs resident before timing)
+    d_map = torch.from_numpy(map_pts).to(dev)
+    torch.cuda.synchronize()
+    eng.map.add_device(d_map.data_ptr(), len(map_pts))
+    del d_map
+    d_scans = [torch.from_numpy(s["raw"]).to(dev) for s in scans]
+    torch.cuda.synchronize()
+    eng.set_static_map(True)
+    eng.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+    P0 = lio.init_cov()
+    map_points, map_voxels = eng.map.stats()
+
+    def step(i):
+        s = scans[i % len(scans)]
+        eng.set_state(s["guess"])
+        eng.set_cov(P0)
+        rc = eng.process_scan_device(d_scans[i % len(scans)].data_ptr(), len(s["raw"]), 1.0 + 0.1 * i)
+        if rc != 3:
+            raise RuntimeError(f"process_scan returned {rc}")
+
+    for i in range(args.warmup):
+        step(i)
+    # pose check outside the timed region: every pooled scan must land on its true pose
+    pose_err, ang_err = 0.0, 0.0
+    for k in range(len(scans)):
+        step(k)
+        st = eng.get_state()
+        pose_err = max(pose_err, float(np.linalg.norm(st[:3] - scans[k]["pos"])))
+        ang_err = max(ang_err, float(synth.quat_angle(st[3:7], scans[k]["q"])))
+
+    eng.scan.enable_kernel_timing(True)
+    eng.scan.kernel_times(reset=True)
+    cand0 = eng.timings()["knn_candidates"]
+    acc = dict(n_ds=0, n_pass=0, n_knn=0, pts=0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        tm = eng.timings()
+        acc["n_ds"] += tm["n_ds"]
+        acc["n_pass"] += tm["n_pass"]
+        acc["n_knn"] += tm["n_knn_pass"]
+        acc["pts"] += len(scans[i % len(scans)]["raw"])
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    barrier()
+    t_max = t_local
+    total_pts = acc["pts"]
+    if dist is not None:
+        tt = torch.tensor([t_local], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_max = float(tt.item())
+        tp = torch.tensor([float(acc["pts"])], device=dev, dtype=torch.float64)
+        dist.all_reduce(tp, op=dist.ReduceOp.SUM)
+        total_pts = float(tp.item())
+
+    kt = eng.scan.kernel_times(reset=True)
+    eng.scan.enable_kernel_timing(False)
+    cand = eng.timings()["knn_candidates"] - cand0
+    # ---- roofline of the dominant kernel (stencil kNN): algorithmic bytes per launch / measured launch time -----
+    # B_knn = N_ds * (16 query + 16 * S slot probes) + 16 * (points resident in the probed voxels)   [SURVEY.md 8d]
+    S = 19
+    launches = max(int(kt["knn_launches"]), 1)
+    knn_bytes = (acc["n_ds"] / max(args.steps, 1)) * (16 + 16 * S) + 16.0 * cand / launches
+    knn_us = kt["knn_us"] / launches
+    achieved = knn_bytes / (knn_us * 1e-6) / 1e9 if knn_us > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel="knn_kernel<16,0>", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, algorithmic_bytes_per_launch=int(knn_bytes),
+                    avg_launch_us=round(knn_us, 2), launches=launches,
+                    other_kernels_us={"linearize": round(kt["linearize_us"] / max(kt["linearize_launches"], 1), 2),
+                                      "finalize": round(kt["finalize_us"] / max(kt["finalize_launches"], 1), 2)})
+
+    # ---- CPU baseline: the oracle restatement of the same path on a bounded sample of the same workload ---------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_scans > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle  # test infrastructure; used here only as the timed CPU baseline / checker
+
+        threads = min(8, os.cpu_count() or 1)  # the reference parallelises the kNN loop over MP_PROC_NUM = 8 threads
+        o = oracle.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=threads)
+        o.map_add(map_pts)
+        o.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+        t_cpu, pts_cpu, worst_dp, worst_da = 0.0, 0, 0.0, 0.0
+        for i in range(args.cpu_scans):
+            s = scans[i % len(scans)]
+            o.set_state(s["guess"])
+            o.set_cov(P0)
+            c0 = time.perf_counter()
+            ds = oracle.voxel_downsample(s["raw"], 0.5)
+            o.set_ds(ds)
+            o.update()
+            t_cpu += time.perf_counter() - c0
+            pts_cpu += len(s["raw"])
+            if i < len(scans):  # full-size parity: GPU pose vs oracle pose on the same scan
+                step(i)
+                sg, so = eng.get_state(), o.get_state()
+                worst_dp = max(worst_dp, float(np.linalg.norm(sg[:3] - so[:3])))
+                worst_da = max(worst_da, float(synth.quat_angle(sg[3:7], so[3:7])))
+        cpu = dict(value=round(pts_cpu / t_cpu, 1), unit="points/s", cores=threads, kind="port",
+                   sample=f"{args.cpu_scans} scans of the same workload (oracle/lio_oracle.cpp: VoxelGrid + iVox kNN on {threads} OpenMP threads + "
+                          f"esti_plane + iterated ESKF, rest single-threaded as in the reference), {t_cpu:.1f} s",
+                   ms_per_scan=round(1e3 * t_cpu / args.cpu_scans, 2),
+                   gpu_vs_oracle_pose={"max_dpos_m": worst_dp, "max_drot_rad": worst_da})
+
+    if rank == 0:
+        value = total_pts / t_max
+        out = {
+            "metric": "registered points/sec (120k-pt scan vs 1e7-pt map, full iterate-to-converge)",
+            "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 per-point geometry / f64 transforms and reductions", "data": "synthetic",
+            "config": {"workload": f"64x{args.n_az} synthetic scan (~{n_raw} pts) vs {map_points}-pt static map ({map_voxels} voxels of 0.5 m), "
+                                   "voxel downsample + iterated ESKF update to convergence, one scan per step, scans sharded across GPUs",
+                       "n_raw": n_raw, "n_ds_avg": round(acc["n_ds"] / args.steps, 1), "passes_avg": round(acc["n_pass"] / args.steps, 2),
+                       "knn_passes_avg": round(acc["n_knn"] / args.steps, 2), "stencil": 19,
+                       "knn_candidates_per_query": round(cand / max(acc["n_ds"] / args.steps * acc["n_knn"], 1), 1),
+                       "map_bytes_hbm": eng.map.nbytes},
+            "pose_error_vs_truth": {"max_dpos_m": pose_err, "max_drot_rad": ang_err},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

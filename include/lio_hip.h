@@ -90,6 +90,16 @@ int lio_scan_download_world(lio_scan*, float* out_xyzi, uint32_t cap);          
  * selected[n_ds] (point_selected_surf), normvec[n_ds*4] (n, pd2), nn_cnt[n_ds], nn_pts[n_ds*5*4] */
 int lio_scan_download_match(lio_scan*, uint8_t* selected, float* normvec, int32_t* nn_cnt, float* nn_pts);
 
+/* live per-kernel timing with HIP events recorded on the handle's stream around every launch of the three
+ * per-pass kernels (bench.py's roofline leg).  Off by default; costs two event records per launch when on. */
+typedef struct lio_kernel_times {
+    double knn_us, linearize_us, finalize_us;          /* summed device time */
+    uint32_t knn_launches, linearize_launches, finalize_launches;
+    uint32_t pad;
+} lio_kernel_times;
+int lio_scan_enable_kernel_timing(lio_scan*, int on);
+int lio_scan_kernel_times(lio_scan*, lio_kernel_times* out, int reset);
+
 /* normal equations of one pass, all f64, reduced in a fixed order (run-to-run identical) */
 typedef struct lio_normal_eq {
     double JtJ[36];      /* sum row6 row6^T, row6 = [n, (R_il p + t_il) x (R_wi^T n)]  (src/laserMapping.cpp:909-931) */
@@ -165,6 +175,9 @@ typedef struct lio_timings {
 } lio_timings;
 int lio_engine_timings(lio_engine*, lio_timings* out);
 int lio_engine_enable_timing(lio_engine*, int on);
+/* on: process_scan skips map_incremental -- scan-to-map registration against a prebuilt static map
+ * (BASELINE.json configs 2 and 4); off (default): the reference's mapping behaviour */
+int lio_engine_set_static_map(lio_engine*, int on);
 
 /* manifold helpers exposed for known-answer tests (mtk SO3/S2 boxplus/boxminus, SOn.hpp:233-245, S2.hpp:136-167) */
 void lio_state_boxplus(const double s26[26], const double d23[23], double out26[26]);

@@ -65,6 +65,40 @@ static int map_check(lio_map* m, hipStream_t st) {
     return LIO_OK;
 }
 
+// live kernel timing: a recycled pool of event pairs per kernel class, resolved lazily
+struct KernelTimer {
+    static constexpr int kPool = 1024;
+    bool on = false;
+    hipEvent_t ev[3][kPool][2];
+    int used[3] = {0, 0, 0};
+    double us[3] = {0, 0, 0};
+    uint32_t launches[3] = {0, 0, 0};
+    bool created = false;
+    void resolve(hipStream_t st) {
+        hipStreamSynchronize(st);
+        for (int w = 0; w < 3; w++) {
+            for (int i = 0; i < used[w]; i++) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev[w][i][0], ev[w][i][1]) == hipSuccess) { us[w] += (double)ms * 1000.0; launches[w]++; }
+            }
+            used[w] = 0;
+        }
+    }
+};
+
+void kt_begin(lio_scan* s, int which) {
+    KernelTimer* k = s->kt;
+    if (!k || !k->on) return;
+    if (k->used[which] >= KernelTimer::kPool) k->resolve(s->stream);
+    hipEventRecord(k->ev[which][k->used[which]][0], s->stream);
+}
+void kt_end(lio_scan* s, int which) {
+    KernelTimer* k = s->kt;
+    if (!k || !k->on) return;
+    hipEventRecord(k->ev[which][k->used[which]][1], s->stream);
+    k->used[which]++;
+}
+
 }  // namespace lio
 
 using namespace lio;
@@ -284,8 +318,43 @@ void lio_scan_destroy(lio_scan* s) {
     hipFree(s->blockcnt); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
     if (s->host_dev) hipHostFree(s->host_dev);
     if (s->h_result) hipHostFree(s->h_result);
+    if (s->kt) {
+        if (s->kt->created)
+            for (int w = 0; w < 3; w++)
+                for (int i = 0; i < KernelTimer::kPool; i++) { hipEventDestroy(s->kt->ev[w][i][0]); hipEventDestroy(s->kt->ev[w][i][1]); }
+        delete s->kt;
+    }
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
+}
+
+int lio_scan_enable_kernel_timing(lio_scan* s, int on) {
+    if (!s) return LIO_E_INVALID;
+    hipSetDevice(s->device);
+    if (!s->kt) s->kt = new KernelTimer();
+    if (on && !s->kt->created) {
+        for (int w = 0; w < 3; w++)
+            for (int i = 0; i < KernelTimer::kPool; i++) {
+                LIO_HIP_TRY(hipEventCreate(&s->kt->ev[w][i][0]));
+                LIO_HIP_TRY(hipEventCreate(&s->kt->ev[w][i][1]));
+            }
+        s->kt->created = true;
+    }
+    s->kt->on = on != 0;
+    return LIO_OK;
+}
+
+int lio_scan_kernel_times(lio_scan* s, lio_kernel_times* out, int reset) {
+    if (!s || !out) return LIO_E_INVALID;
+    memset(out, 0, sizeof(*out));
+    if (!s->kt) return LIO_OK;
+    hipSetDevice(s->device);
+    s->kt->resolve(s->stream);
+    out->knn_us = s->kt->us[0]; out->linearize_us = s->kt->us[1]; out->finalize_us = s->kt->us[2];
+    out->knn_launches = s->kt->launches[0]; out->linearize_launches = s->kt->launches[1]; out->finalize_launches = s->kt->launches[2];
+    if (reset)
+        for (int w = 0; w < 3; w++) { s->kt->us[w] = 0; s->kt->launches[w] = 0; }
+    return LIO_OK;
 }
 
 int lio_scan_upload(lio_scan* s, const float* body, uint32_t n_raw) {

@@ -18,6 +18,7 @@ struct lio_engine {
     float leaf_surf = 0.5f, leaf_map = 0.5f;
     double init_time = 0.1, laser_cov = 0.001;
     bool degenerate_detect_en = true;
+    bool static_map = false;
     // file-scope state of laserMapping.cpp
     double travel = 0, first_lidar_time = 0;
     double last_pos_lid[3] = {0, 0, 0};
@@ -249,6 +250,7 @@ int lio_engine_pass_log(lio_engine* e, int i, lio_pass_log* out) {
 }
 
 int lio_engine_enable_timing(lio_engine* e, int on) { if (!e) return LIO_E_INVALID; e->timing = on != 0; return LIO_OK; }
+int lio_engine_set_static_map(lio_engine* e, int on) { if (!e) return LIO_E_INVALID; e->static_map = on != 0; return LIO_OK; }
 int lio_engine_timings(lio_engine* e, lio_timings* out) { if (!e || !out) return LIO_E_INVALID; *out = e->tm; return LIO_OK; }
 
 static int process_common(lio_engine* e, double lidar_beg_time) {
@@ -302,6 +304,11 @@ static int process_common(lio_engine* e, double lidar_beg_time) {
     }
     e->travel = e->travel + sqrt(d2);
     pose_arrays(e->kf.x, pose, ext);
+    if (e->static_map) {
+        e->tm.total_device_us = e->tm.downsample_us + e->tm.knn_us + e->tm.linearize_us;
+        e->tm.total_wall_us = (float)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+        return 3;
+    }
     if (e->timing) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, s->stream); }
     rc = lio_map_incremental(e->map, s, pose, ext, e->leaf_map, e->flg_EKF_inited ? 1 : 0, e->travel);
     if (e->timing) {

@@ -332,7 +332,10 @@ static int launch_knn(lio_map* m, hipStream_t st, const PoseArgs& pose, const fl
 
 int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {
     (void)redo_knn;
-    return launch_knn<0>(m, s->stream, pose, s->ds_body, 0, s->dev, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt, s->max_ds < s->n_raw || !s->n_raw ? s->max_ds : s->n_raw);
+    kt_begin(s, 0);
+    const int rc = launch_knn<0>(m, s->stream, pose, s->ds_body, 0, s->dev, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt, s->max_ds < s->n_raw || !s->n_raw ? s->max_ds : s->n_raw);
+    kt_end(s, 0);
+    return rc;
 }
 
 int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt) {

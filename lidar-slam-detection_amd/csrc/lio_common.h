@@ -97,7 +97,11 @@ struct lio_map {
     uint64_t bytes;
 };
 
+namespace lio {
+struct KernelTimer;  // capi.hip
+}
 struct lio_scan {
+    lio::KernelTimer* kt;
     int device;
     hipStream_t stream;
     uint32_t max_raw, max_ds;
@@ -128,6 +132,8 @@ namespace lio {
 int vg_downsample(lio_scan* s, float leaf);
 int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);
+void kt_begin(lio_scan* s, int which);
+void kt_end(lio_scan* s, int which);
 int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t n, const uint32_t* d_n, double travel);
 int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);
 int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt);

@@ -386,10 +386,14 @@ int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) 
     uint32_t blocks = (bound + kLinThreads - 1) / kLinThreads;
     if (blocks == 0) blocks = 1;
     if (blocks > s->partial_blocks) blocks = s->partial_blocks;
+    kt_begin(s, 1);
     hipLaunchKernelGGL(linearize_kernel, blocks, kLinThreads, 0, s->stream, pose, redo_knn, s->dev, s->ds_body, s->ds_world, s->nn_pts,
                        s->max_ds, s->nn_cnt, s->selected, s->normvec, s->partial);
+    kt_end(s, 1);
+    kt_begin(s, 2);
     hipLaunchKernelGGL(finalize_kernel, 1, kFinThreads, 0, s->stream, s->dev, s->partial, s->selected, s->normvec, m ? m->dev : nullptr,
                        s->d_result);
+    kt_end(s, 2);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

@@ -24,7 +24,8 @@ SYMBOLS = [
     "lio_engine_create", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
     "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
-    "lio_engine_enable_timing", "lio_state_boxplus", "lio_state_boxminus",
+    "lio_engine_enable_timing", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
+    "lio_state_boxplus", "lio_state_boxminus",
 ]
 
 
@@ -44,6 +45,11 @@ class Timings(C.Structure):
                 ("total_device_us", C.c_float), ("host_solve_us", C.c_float), ("total_wall_us", C.c_float), ("n_knn_pass", C.c_int32),
                 ("n_pass", C.c_int32), ("n_ds", C.c_int32), ("n_eff_last", C.c_int32), ("n_added", C.c_int32),
                 ("knn_candidates", C.c_uint64)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("knn_us", C.c_double), ("linearize_us", C.c_double), ("finalize_us", C.c_double), ("knn_launches", C.c_uint32),
+                ("linearize_launches", C.c_uint32), ("finalize_launches", C.c_uint32), ("pad", C.c_uint32)]
 
 
 _lib = None
@@ -107,6 +113,9 @@ def lib():
     sig("lio_engine_process_scan_device", cint, vp, vp, u32, dbl)
     sig("lio_engine_timings", cint, vp, C.POINTER(Timings))
     sig("lio_engine_enable_timing", cint, vp, cint)
+    sig("lio_engine_set_static_map", cint, vp, cint)
+    sig("lio_scan_enable_kernel_timing", cint, vp, cint)
+    sig("lio_scan_kernel_times", cint, vp, C.POINTER(KernelTimes), cint)
     sig("lio_state_boxplus", None, f64p, f64p, f64p)
     sig("lio_state_boxminus", None, f64p, f64p, f64p)
     _lib = L

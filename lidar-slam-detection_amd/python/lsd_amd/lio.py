@@ -147,6 +147,14 @@ class Scan:
         n = check(lib().lio_scan_download_world(self.h, ptr(out, C.c_float), self.max_ds), "download world")
         return out[:n].copy()
 
+    def enable_kernel_timing(self, on=True):
+        check(lib().lio_scan_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_times(self, reset=True):
+        t = capi.KernelTimes()
+        check(lib().lio_scan_kernel_times(self.h, C.byref(t), int(reset)))
+        return {k: getattr(t, k) for k, _ in t._fields_ if k != "pad"}
+
     def get_match(self):
         n = self.num_ds
         sel = np.zeros(n, np.uint8)
@@ -248,6 +256,9 @@ class Engine:
 
     def enable_timing(self, on=True):
         check(lib().lio_engine_enable_timing(self.h, int(on)))
+
+    def set_static_map(self, on=True):
+        check(lib().lio_engine_set_static_map(self.h, int(on)))
 
     def timings(self):
         t = capi.Timings()

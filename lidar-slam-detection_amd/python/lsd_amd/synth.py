@@ -144,10 +144,10 @@ def lidar_dirs(n_beams=64, n_az=1875, fov_deg=(-25.0, 15.0)):
     return d, t
 
 
-def make_scan(scene, pos, quat, seed=0, n_beams=64, n_az=1875, sigma=0.02, max_range=100.0, blind=0.1):
+def make_scan(scene, pos, quat, seed=0, n_beams=64, n_az=1875, sigma=0.02, max_range=100.0, blind=0.1, fov_deg=(-25.0, 15.0)):
     """one static-sensor scan from world pose (pos, quat xyzw); returns (body XYZI f32 (n,4), time offset f32 (n,))"""
     rng = np.random.default_rng(seed)
-    d_body, t = lidar_dirs(n_beams, n_az)
+    d_body, t = lidar_dirs(n_beams, n_az, fov_deg)
     R = quat_to_R(np.asarray(quat, np.float64))
     d_world = d_body @ R.T
     r = scene.raycast(pos, d_world, max_range)
