@@ -172,6 +172,10 @@ def main():
         t_cpu, pts_cpu, worst_dp, worst_da = 0.0, 0, 0.0, 0.0
         for i in range(args.cpu_scans):
             s = scans[i % len(scans)]
+            parity = i < len(scans)
+            if parity:  # equal histories: the neighbour cache (Nearest_Points) persists across scans on both sides
+                o.reset_cache()
+                eng.scan.reset()
             o.set_state(s["guess"])
             o.set_cov(P0)
             c0 = time.perf_counter()
@@ -180,7 +184,7 @@ def main():
             o.update()
             t_cpu += time.perf_counter() - c0
             pts_cpu += len(s["raw"])
-            if i < len(scans):  # full-size parity: GPU pose vs oracle pose on the same scan
+            if parity:  # full-size parity: GPU pose vs oracle pose on the same scan
                 step(i)
                 sg, so = eng.get_state(), o.get_state()
                 worst_dp = max(worst_dp, float(np.linalg.norm(sg[:3] - so[:3])))

@@ -75,6 +75,9 @@ int lio_map_knn(lio_map*, const float* world_xyzi, uint32_t n, float* out_pts, i
  * ------------------------------------------------------------------------------------------- */
 lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds);
 void lio_scan_destroy(lio_scan*);
+/* forget the neighbour cache and gate flags, as fastlio_init() does for Nearest_Points / point_selected_surf
+ * (src/laserMapping.cpp:1045-1047) */
+int lio_scan_reset(lio_scan*);
 int lio_scan_upload(lio_scan*, const float* body_xyzi, uint32_t n_raw);          /* host -> HBM */
 int lio_scan_set_device(lio_scan*, const void* d_body_xyzi, uint32_t n_raw);     /* already in HBM (not copied) */
 /* pcl::VoxelGrid<PointType>::filter with setLeafSize(leaf, leaf, leaf) (PCL 1.9.1 voxel_grid.hpp,

@@ -328,6 +328,16 @@ void lio_scan_destroy(lio_scan* s) {
     delete s;
 }
 
+int lio_scan_reset(lio_scan* s) {
+    if (!s) return LIO_E_INVALID;
+    hipSetDevice(s->device);
+    LIO_HIP_TRY(hipMemsetAsync(s->selected, 1, s->max_ds, s->stream));
+    LIO_HIP_TRY(hipMemsetAsync(s->nn_cnt, 0, (size_t)s->max_ds * 4, s->stream));
+    LIO_HIP_TRY(hipMemsetAsync(s->nn_pts, 0, (size_t)s->max_ds * 5 * sizeof(float4), s->stream));
+    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    return LIO_OK;
+}
+
 int lio_scan_enable_kernel_timing(lio_scan* s, int on) {
     if (!s) return LIO_E_INVALID;
     hipSetDevice(s->device);

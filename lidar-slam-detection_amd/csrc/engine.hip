@@ -63,10 +63,11 @@ int measure_pass(lio_engine* e, const LioState& x, bool converge, Measurement& m
         hipEventRecord(t1, e->scan->stream);
         hipEventSynchronize(t1);
         const float us = ev_us(t0, t1);
-        if (converge) { e->tm.knn_us += us; e->tm.n_knn_pass++; } else e->tm.linearize_us += us;
-        e->tm.n_pass++;
+        if (converge) e->tm.knn_us += us; else e->tm.linearize_us += us;
         hipEventDestroy(t0); hipEventDestroy(t1);
     }
+    e->tm.n_pass++;
+    if (converge) e->tm.n_knn_pass++;
     if (rc != LIO_OK) return rc;
     e->tm.n_ds = (int)ne.n_ds;
     e->tm.n_eff_last = (int)ne.n_eff;

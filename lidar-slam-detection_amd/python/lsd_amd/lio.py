@@ -116,6 +116,9 @@ class Scan:
 
     __del__ = close
 
+    def reset(self):
+        check(lib().lio_scan_reset(self.h), "scan reset")
+
     def upload(self, body_xyzi):
         p = f32(body_xyzi).reshape(-1, 4)
         check(lib().lio_scan_upload(self.h, ptr(p, C.c_float), len(p)), "scan upload")

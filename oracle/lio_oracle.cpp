@@ -1225,6 +1225,12 @@ int64_t orc_lio_map_dump(void* h, float* out, uint64_t cap) {
     return (int64_t)n;
 }
 void orc_lio_set_ds(void* h, const float* ds_xyzi, int n) { static_cast<Lio*>(h)->set_ds(reinterpret_cast<const P4*>(ds_xyzi), n); }
+// fastlio_init's reset of Nearest_Points / point_selected_surf (laserMapping.cpp:1045-1047)
+void orc_lio_reset_cache(void* h) {
+    Lio* l = static_cast<Lio*>(h);
+    l->nearest.clear();
+    l->selected.assign(kMaxPts, 1);
+}
 int orc_lio_get_ds(void* h, float* out, int cap) {
     Lio* l = static_cast<Lio*>(h);
     if (l->n_ds > cap) return -l->n_ds;

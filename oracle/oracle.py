@@ -68,6 +68,7 @@ def lib():
     L.orc_lio_map_dump.argtypes = [C.c_void_p, f32p, C.c_uint64]
     L.orc_lio_map_dump.restype = C.c_int64
     L.orc_lio_set_ds.argtypes = [C.c_void_p, f32p, C.c_int]
+    L.orc_lio_reset_cache.argtypes = [C.c_void_p]
     L.orc_lio_get_ds.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_lio_get_ds.restype = C.c_int
     L.orc_lio_linearize.argtypes = [C.c_void_p, C.c_int, u8p, f32p, i32p, f32p, f64p, f64p, f64p, i32p]
@@ -239,6 +240,9 @@ class Lio:
         d = _f32(ds).reshape(-1, 4)
         self._n = len(d)
         lib().orc_lio_set_ds(self.h, _p(d, C.c_float), len(d))
+
+    def reset_cache(self):
+        lib().orc_lio_reset_cache(self.h)
 
     def get_ds(self, cap=100000):
         out = np.zeros((cap, 4), np.float32)
