@@ -110,7 +110,8 @@ typedef struct lio_normal_eq {
     double nnT[9];       /* sum n n^T  (HTH of src/laserMapping.cpp:937)                     */
     double eigvec[9];    /* eigenvectors of nnT as columns, ascending eigenvalue (row-major 3x3) */
     double eigval[3];
-    double contri[3];    /* per eigenvector: sum |n^.v| over rows with |n^.v| > 0.1736 (src/laserMapping.cpp:946-964) */
+    double contri[3];    /* per eigenvector: sum |n^.v| over rows with |n^.v| > 0.1736 (src/laserMapping.cpp:946-964); +inf when
+                            the bound eigval[i] - 0.1736^2 n_eff >= 250 already proves "not degenerate" and the pass was skipped */
     double strong[3];    /* ... > 0.7070 */
     double sum_abs_res;  /* total_residual (src/laserMapping.cpp:884) */
     uint32_t n_eff;      /* effct_feat_num */
@@ -124,6 +125,8 @@ typedef struct lio_normal_eq {
  * 6-column Jacobian blocks.  pose_wi = (t_wi[3], q_wi[4]);  ext_il = (t_il[3], q_il[4]). */
 int lio_p2plane_linearize(lio_map*, lio_scan*, const double pose_wi[7], const double ext_il[7], int redo_knn,
                           lio_normal_eq* out);
+/* evaluate contri/strong on every pass even when the eigenvalue bound makes them moot (tests, diagnostics) */
+int lio_scan_force_degeneracy(lio_scan*, int on);
 /* rows of the last linearize for the (rare) N_eff < 23 branch of the filter
  * (esekfom.hpp:1715-1744): h_x[n_eff*6] (first six columns) and h[n_eff], selected points in index order */
 int lio_p2plane_rows(lio_scan*, const double pose_wi[7], const double ext_il[7], double* h_x6, double* h, uint32_t cap_rows);

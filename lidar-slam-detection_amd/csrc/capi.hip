@@ -3,6 +3,7 @@
 
 #include <vector>
 
+#include "eskf.h"
 #include "lio_common.h"
 
 namespace lio {
@@ -283,13 +284,13 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
     s->max_raw = max_raw;
     s->max_ds = max_ds;
     const uint32_t nblocks = (max_raw + 1023) / 1024;
-    s->partial_blocks = (max_ds + 127) / 128;
+    s->partial_blocks = (max_ds + kLinThreads - 1) / kLinThreads;
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && dev_alloc(&s->raw_own, max_raw, &s->bytes) && dev_alloc(&s->ds_body, max_ds, &s->bytes) && dev_alloc(&s->ds_world, max_ds, &s->bytes) &&
          dev_alloc(&s->nn_pts, (uint64_t)max_ds * 5, &s->bytes) && dev_alloc(&s->nn_cnt, max_ds, &s->bytes) && dev_alloc(&s->selected, max_ds, &s->bytes) &&
          dev_alloc(&s->normvec, max_ds, &s->bytes) && dev_alloc(&s->keys_a, max_raw, &s->bytes) && dev_alloc(&s->keys_b, max_raw, &s->bytes) &&
          dev_alloc(&s->vals_a, max_raw, &s->bytes) && dev_alloc(&s->vals_b, max_raw, &s->bytes) && dev_alloc(&s->hist, (uint64_t)256 * nblocks, &s->bytes) &&
-         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * 29, &s->bytes) &&
+         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
          dev_alloc(&s->dev, 1, &s->bytes) && dev_alloc(&s->d_result, 1, &s->bytes);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&s->host_dev), sizeof(ScanDev)) == hipSuccess &&
          hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(lio_normal_eq)) == hipSuccess;
@@ -315,7 +316,7 @@ void lio_scan_destroy(lio_scan* s) {
     if (s->stream) hipStreamSynchronize(s->stream);
     hipFree(s->raw_own); hipFree(s->ds_body); hipFree(s->ds_world); hipFree(s->nn_pts); hipFree(s->nn_cnt); hipFree(s->selected);
     hipFree(s->normvec); hipFree(s->keys_a); hipFree(s->keys_b); hipFree(s->vals_a); hipFree(s->vals_b); hipFree(s->hist);
-    hipFree(s->blockcnt); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
+    hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
     if (s->host_dev) hipHostFree(s->host_dev);
     if (s->h_result) hipHostFree(s->h_result);
     if (s->kt) {
@@ -486,6 +487,32 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
     LIO_HIP_TRY(hipStreamSynchronize(s->stream));
     *out = *s->h_result;
     s->have_ds = (int)out->n_ds;
+    // degeneracy detection (laserMapping.cpp:934-964).  The eigen-decomposition of sum n n^T runs here on the
+    // host.  A direction i is declared degenerate only if contri_i < 250 (and strong_i < 50), where
+    // contri_i = sum of a_j = |n^_j . v_i| over rows with a_j > 0.1736.  Since a_j <= 1, a_j >= a_j^2 and
+    //   contri_i >= sum_j a_j^2 - sum_{a_j <= 0.1736} a_j^2 >= lambda_i - 0.1736^2 N_eff.
+    // When that bound is >= 250 for all three eigenvalues the test cannot fire and the per-point pass is skipped
+    // (contri/strong are then reported as +inf = "not evaluated, provably not degenerate").
+    eig3_sym(out->nnT, out->eigval, out->eigvec);
+    bool need = s->force_degeneracy != 0;
+    for (int i = 0; i < 3; i++)
+        if (!(out->eigval[i] * (1.0 - 1e-5) - 0.030138 * (double)out->n_eff >= 250.0 + 1e-3)) need = true;
+    if (!need || out->n_eff == 0) {
+        for (int i = 0; i < 3; i++) { out->contri[i] = INFINITY; out->strong[i] = INFINITY; }
+        return LIO_OK;
+    }
+    LIO_HIP_TRY(hipMemcpyAsync(s->d_result->eigvec, out->eigvec, sizeof(double) * 9, hipMemcpyHostToDevice, s->stream));
+    rc = p2plane_degeneracy(s);
+    if (rc != LIO_OK) return rc;
+    LIO_HIP_TRY(hipMemcpyAsync(s->h_result->contri, s->d_result->contri, sizeof(double) * 6, hipMemcpyDeviceToHost, s->stream));
+    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < 3; i++) { out->contri[i] = s->h_result->contri[i]; out->strong[i] = s->h_result->strong[i]; }
+    return LIO_OK;
+}
+
+int lio_scan_force_degeneracy(lio_scan* s, int on) {
+    if (!s) return LIO_E_INVALID;
+    s->force_degeneracy = on != 0;
     return LIO_OK;
 }
 

@@ -284,6 +284,47 @@ bool mat_inverse(const double* A, int n, double* out) {
     return true;
 }
 
+// the reference calls Eigen::SelfAdjointEigenSolver<Matrix3d> (laserMapping.cpp:939-941); only the invariant
+// subspaces matter downstream (|n.v| sums and the projector sum_kept v v^T), so any convergent solver serves
+void eig3_sym(const double Ain[9], double w[3], double V[9]) {
+    double A[9];
+    for (int i = 0; i < 9; i++) { A[i] = Ain[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                const double apq = A[p * 3 + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+                    A[k * 3 + p] = c * akp - s * akq;
+                    A[k * 3 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+                    A[p * 3 + k] = c * apk - s * aqk;
+                    A[q * 3 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                    V[k * 3 + p] = c * vkp - s * vkq;
+                    V[k * 3 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (w[j] < w[i]) {
+                const double t = w[i]; w[i] = w[j]; w[j] = t;
+                for (int k = 0; k < 3; k++) { const double u = V[k * 3 + i]; V[k * 3 + i] = V[k * 3 + j]; V[k * 3 + j] = u; }
+            }
+}
+
 Eskf::Eskf() {
     memset(&x, 0, sizeof(x));
     x.rot[3] = 1.0;

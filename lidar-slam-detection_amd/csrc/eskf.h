@@ -36,6 +36,8 @@ void s2_Nx_yy(const double g[3], double N[6]);                    // 2 x 3
 void s2_Mx(const double g[3], const double delta[2], double M[6]);  // 3 x 2
 void quat_rotate(const double q[4], const double v[3], double out[3]);
 bool mat_inverse(const double* A, int n, double* out);  // LU with partial pivoting
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi): eigenvalues ascending, eigenvectors as columns of V (row-major)
+void eig3_sym(const double A[9], double w[3], double V[9]);
 
 // measurement of one pass as the filter sees it
 struct Measurement {

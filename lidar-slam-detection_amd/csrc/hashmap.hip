@@ -243,20 +243,50 @@ __global__ void __launch_bounds__(256) knn_kernel(const Slot* __restrict__ table
         }
         int kx = 0, ky = 0, kz = 0;
         pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
-        // 1. probe the stencil, compact the occupied voxels into LDS
+        // 1. probe the stencil, compact the occupied voxels into LDS.  A lane owns cells gl, gl+G, ...; the
+        //    home-slot loads of all its cells are issued back to back, collisions (rare at load <= 0.5) loop after.
         uint32_t nhit = 0;
-        for (int s0 = 0; s0 < st.n; s0 += G) {
-            const int s = s0 + gl;
-            uint32_t ptr = 0, cnt = 0;
-            bool hit = false;
-            if (active && s < st.n) hit = slot_lookup(table, mask, kx + st.off[s][0], ky + st.off[s][1], kz + st.off[s][2], ptr, cnt) && cnt > 0;
-            const unsigned long long m = __ballot(hit) & gmask;
-            if (hit) {
-                const uint32_t at = nhit + __popcll(m & ((1ull << lane) - 1ull));
-                v_ptr[grp][at] = ptr;
-                v_end[grp][at + 1] = cnt;
+        {
+            constexpr int KM = (kMaxStencil + G - 1) / G;
+            uint4 raw[KM];
+            uint32_t hh[KM];
+            unsigned long long want[KM];
+#pragma unroll
+            for (int k = 0; k < KM; k++) {
+                const int s = k * G + gl;
+                want[k] = kEmptyKey;
+                raw[k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+                if (active && s < st.n) {
+                    const int cx = kx + st.off[s][0], cy = ky + st.off[s][1], cz = kz + st.off[s][2];
+                    want[k] = pack_key(cx, cy, cz);
+                    hh[k] = brick_hash(cx, cy, cz, mask);
+                    raw[k] = *reinterpret_cast<const uint4*>(&table[hh[k]]);
+                }
             }
-            nhit += __popcll(m);
+#pragma unroll
+            for (int k = 0; k < KM; k++) {
+                if (k * G >= st.n) break;  // uniform
+                bool hit = false;
+                uint32_t ptr = 0, cnt = 0;
+                if (want[k] != kEmptyKey) {
+                    uint4 r = raw[k];
+                    uint32_t h = hh[k];
+                    for (uint32_t probe = 0; probe <= mask; probe++) {
+                        const unsigned long long kk = ((unsigned long long)r.y << 32) | r.x;
+                        if (kk == want[k]) { hit = r.w > 0; ptr = r.z; cnt = r.w; break; }
+                        if (kk == kEmptyKey) break;
+                        h = (h + 1) & mask;
+                        r = *reinterpret_cast<const uint4*>(&table[h]);
+                    }
+                }
+                const unsigned long long m = __ballot(hit) & gmask;
+                if (hit) {
+                    const uint32_t at = nhit + __popcll(m & ((1ull << lane) - 1ull));
+                    v_ptr[grp][at] = ptr;
+                    v_end[grp][at + 1] = cnt;
+                }
+                nhit += __popcll(m);
+            }
         }
         __syncthreads();
         // 2. exclusive prefix over the voxel counts (<= 75 entries; one lane, the group is in lockstep)
@@ -270,25 +300,41 @@ __global__ void __launch_bounds__(256) knn_kernel(const Slot* __restrict__ table
         }
         __syncthreads();
         const uint32_t total = active ? v_end[grp][nhit] : 0;
-        // 3. every lane keeps its own sorted top-5 over candidates gl, gl+G, ...
+        // 3. every lane keeps its own sorted top-5 over candidates gl, gl+G, ...; four candidate loads in flight
         Cand e0 = {INFINITY, kNoIdx}, e1 = e0, e2 = e0, e3 = e0, e4 = e0;
         uint32_t inrange = 0;
         uint32_t j = 0;
-        for (uint32_t c = gl; c < total; c += G) {
-            while (c >= v_end[grp][j + 1]) j++;
-            const uint32_t id = v_ptr[grp][j] + (c - v_end[grp][j]);
-            const float4 p = pool[id];
-            const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;  // ivox3d_node.hpp:12-15 (f32 squaredNorm)
-            if (d2 < 5.0f) {
-                inrange++;
-                Cand cd = {d2, id};
-                if (cand_less(cd, e4, pool)) {
-                    e4 = cd;
-                    if (cand_less(e4, e3, pool)) { Cand t = e3; e3 = e4; e4 = t; }
-                    if (cand_less(e3, e2, pool)) { Cand t = e2; e2 = e3; e3 = t; }
-                    if (cand_less(e2, e1, pool)) { Cand t = e1; e1 = e2; e2 = t; }
-                    if (cand_less(e1, e0, pool)) { Cand t = e0; e0 = e1; e1 = t; }
+        constexpr int U = 4;
+        for (uint32_t c0 = gl; c0 < total; c0 += U * G) {
+            uint32_t id[U];
+            float4 p[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = c0 + u * G;
+                id[u] = kNoIdx;
+                if (c < total) {
+                    while (c >= v_end[grp][j + 1]) j++;
+                    id[u] = v_ptr[grp][j] + (c - v_end[grp][j]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (id[u] != kNoIdx) p[u] = pool[id[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (id[u] == kNoIdx) continue;
+                const float dx = p[u].x - pw.x, dy = p[u].y - pw.y, dz = p[u].z - pw.z;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;  // ivox3d_node.hpp:12-15 (f32 squaredNorm)
+                if (d2 < 5.0f) {
+                    inrange++;
+                    Cand cd = {d2, id[u]};
+                    if (cand_less(cd, e4, pool)) {
+                        e4 = cd;
+                        if (cand_less(e4, e3, pool)) { Cand t = e3; e3 = e4; e4 = t; }
+                        if (cand_less(e3, e2, pool)) { Cand t = e2; e2 = e3; e3 = t; }
+                        if (cand_less(e2, e1, pool)) { Cand t = e1; e1 = e2; e2 = t; }
+                        if (cand_less(e1, e0, pool)) { Cand t = e0; e0 = e1; e1 = t; }
+                    }
                 }
             }
         }
@@ -313,7 +359,7 @@ __global__ void __launch_bounds__(256) knn_kernel(const Slot* __restrict__ table
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) visited += __shfl_xor(visited, off);
-    if (lane == 0 && visited) atomicAdd(&md->knn_candidates, visited);
+    if (lane == 0 && visited) atomicAdd(&md->knn_cand[blockIdx.x & 63], visited);
 }
 
 template <int MODE>

@@ -24,6 +24,8 @@ void set_error(const char* fmt, ...);
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
 constexpr int kMaxStencil = 75;
+constexpr int kLinThreads = 64;   // linearize_kernel workgroup size (one partial-sum record per workgroup)
+constexpr int kAcc = 29;          // 21 (JtJ upper) + 6 (Jtr) + sum|r| + count
 
 // one open-addressing slot of the voxel hash grid: 16 B, one probe = one 16-B load
 struct __attribute__((aligned(16))) Slot {
@@ -40,7 +42,7 @@ struct MapDev {
     uint32_t err;                    // bit0: table full, bit1: pool full
     uint32_t n_add;                  // staging count for map_incremental
     uint32_t pad;
-    unsigned long long knn_candidates;
+    unsigned long long knn_cand[64];  // sharded by workgroup: one hot counter would serialise ~13 ns per wave
 };
 
 // rigid transforms handed to kernels by value (doubles, as the reference computes them)
@@ -56,6 +58,7 @@ struct ScanDev {
     uint32_t bbox_min[3];  // order-preserving uint encoding of float, init 0xFFFFFFFF
     uint32_t bbox_max[3];  // init 0
     uint32_t n_valid;      // finite input points
+    uint32_t n_long;       // voxels queued for the wave-per-voxel centroid kernel
     uint32_t n_ds;         // feats_down_size
     uint32_t n_ds_prev;    // size of the neighbour cache before this scan (Nearest_Points.resize semantics)
     uint32_t passthrough;  // PCL int32 overflow guard hit: output = input
@@ -102,6 +105,7 @@ struct KernelTimer;  // capi.hip
 }
 struct lio_scan {
     lio::KernelTimer* kt;
+    int force_degeneracy;  // evaluate the degeneracy sums even when the eigenvalue bound makes them moot
     int device;
     hipStream_t stream;
     uint32_t max_raw, max_ds;
@@ -117,6 +121,9 @@ struct lio_scan {
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b;
     uint32_t* hist;      // radix histograms [256][nblocks]
     uint32_t* blockcnt;  // head counts per tile
+    uint32_t* hpos;      // first sorted position of every occupied voxel
+    uint32_t* longlist;  // voxels with long runs
+    float4* sorted;      // raw points gathered into (voxel, input index) order
     double* partial;     // per-block partial sums
     uint32_t partial_blocks;
     lio::ScanDev* dev;
@@ -138,6 +145,7 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
 int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);
 int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt);
 int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);
+int p2plane_degeneracy(lio_scan* s);
 int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float map_leaf, int ekf_inited, int seed_all);
 PoseArgs make_pose(const double pose_wi[7], const double ext_il[7]);
 }  // namespace lio

@@ -8,8 +8,10 @@
 //                     residual gate (:860-871), Jacobian block [n, (R_il p + t_il) x (R_wi^T n)] (:909-931)
 //                     and a fixed-order f64 block reduction of J^T J (21), J^T h (6), sum|r|, count.
 //                     The N_eff x 15 matrix h_x of the reference never materialises.
-//   finalize_kernel   one workgroup: fixed-order sum of the block partials, 3x3 eigen-decomposition of
-//                     sum n n^T, and the six degeneracy sums of :946-964.
+//   finalize_kernel   one workgroup: fixed-order sum of the block partials (the 3x3 eigen-decomposition of
+//                     sum n n^T is done by the host on the 36 returned doubles).
+//   degeneracy_kernel the six degeneracy sums of :946-964; launched only when the eigenvalue bound
+//                     lambda_i - 0.1736^2 N_eff >= 250 does not already decide the test (see capi.hip).
 //   classify_kernel   map_incremental's need_add test + ballot/prefix-sum compaction of the points to insert.
 // Per-point f32 arithmetic is written as explicit sequential IEEE operations (compiled with
 // -ffp-contract=off) in the operation order of Eigen's ColPivHouseholderQR so that gates flip exactly where
@@ -18,8 +20,6 @@
 
 namespace lio {
 
-constexpr int kLinThreads = 128;
-constexpr int kAcc = 29;  // 21 (JtJ upper) + 6 (Jtr) + sum|r| + count
 
 __device__ inline void body_to_world_d(const PoseArgs& P, const float4 pb, double pi[3], float4& pw) {
     const double vx = (double)pb.x, vy = (double)pb.y, vz = (double)pb.z;
@@ -266,57 +266,12 @@ __global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, i
     }
 }
 
-// symmetric 3x3 eigen-decomposition, cyclic Jacobi in f64; eigenvalues ascending, eigenvectors as columns
-// (the reference calls Eigen::SelfAdjointEigenSolver at laserMapping.cpp:939-941)
-__device__ inline void eig3_dev(const double Ain[9], double w[3], double V[9]) {
-    double A[9];
-    for (int i = 0; i < 9; i++) { A[i] = Ain[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
-    for (int sweep = 0; sweep < 60; sweep++) {
-        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
-        if (off < 1e-300) break;
-        for (int p = 0; p < 2; p++)
-            for (int q = p + 1; q < 3; q++) {
-                const double apq = A[p * 3 + q];
-                if (apq == 0.0) continue;
-                const double app = A[p * 3 + p], aqq = A[q * 3 + q];
-                const double theta = (aqq - app) / (2 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                const double c = 1 / sqrt(t * t + 1), s = t * c;
-                for (int k = 0; k < 3; k++) {
-                    const double akp = A[k * 3 + p], akq = A[k * 3 + q];
-                    A[k * 3 + p] = c * akp - s * akq;
-                    A[k * 3 + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < 3; k++) {
-                    const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
-                    A[p * 3 + k] = c * apk - s * aqk;
-                    A[q * 3 + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 3; k++) {
-                    const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
-                    V[k * 3 + p] = c * vkp - s * vkq;
-                    V[k * 3 + q] = s * vkp + c * vkq;
-                }
-            }
-    }
-    w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
-    for (int i = 0; i < 2; i++)
-        for (int j = i + 1; j < 3; j++)
-            if (w[j] < w[i]) {
-                const double t = w[i]; w[i] = w[j]; w[j] = t;
-                for (int k = 0; k < 3; k++) { const double u = V[k * 3 + i]; V[k * 3 + i] = V[k * 3 + j]; V[k * 3 + j] = u; }
-            }
-}
-
 constexpr int kFinThreads = 1024;
 
 __global__ void __launch_bounds__(kFinThreads) finalize_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial,
-                                                               const uint8_t* __restrict__ selected, const float4* __restrict__ normvec,
                                                                const MapDev* __restrict__ md, lio_normal_eq* __restrict__ out) {
     __shared__ double acc[kAcc];
-    __shared__ double V[9];
-    __shared__ double red[kFinThreads / 64][6];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x;
     const uint32_t n = sd->n_ds;
     const uint32_t nb = (n + kLinThreads - 1) / kLinThreads;
     // fixed-order reduction of the block partials: component c is owned by 32 lanes (stride-32 chunks,
@@ -338,24 +293,35 @@ __global__ void __launch_bounds__(kFinThreads) finalize_kernel(const ScanDev* __
             for (int c = a; c < 6; c++) { J[a * 6 + c] = acc[t]; J[c * 6 + a] = acc[t]; t++; }
         for (int k = 0; k < 36; k++) out->JtJ[k] = J[k];
         for (int a = 0; a < 6; a++) out->Jtr[a] = acc[21 + a];
-        double N[9], w[3], Vl[9];
         for (int a = 0; a < 3; a++)
-            for (int c = 0; c < 3; c++) N[a * 3 + c] = J[a * 6 + c];
-        eig3_dev(N, w, Vl);
-        for (int k = 0; k < 9; k++) { out->nnT[k] = N[k]; out->eigvec[k] = Vl[k]; V[k] = Vl[k]; }
-        for (int k = 0; k < 3; k++) out->eigval[k] = w[k];
+            for (int c = 0; c < 3; c++) out->nnT[a * 3 + c] = J[a * 6 + c];
+        for (int k = 0; k < 3; k++) { out->contri[k] = 0.0; out->strong[k] = 0.0; }
         out->sum_abs_res = acc[27];
         out->n_eff = (uint32_t)(acc[28] + 0.5);
         out->n_ds = n;
-        const unsigned long long kc = md ? md->knn_candidates : 0ull;
+        unsigned long long kc = 0ull;
+        if (md)
+            for (int k = 0; k < 64; k++) kc += md->knn_cand[k];
         out->n_knn_candidates_lo = (uint32_t)kc;
         out->n_knn_candidates_hi = (uint32_t)(kc >> 32);
     }
+}
+
+// degeneracy sums (laserMapping.cpp:946-964): rows re-normalised, |cos| against each eigenvector of sum n n^T.
+// Every addend is a float in (0.1736, 1] widened to double, so sums of up to 2^17 of them are exact in f64
+// and the f64 atomics below are order-independent: the result is run-to-run identical.
+__global__ void __launch_bounds__(256) degeneracy_kernel(const ScanDev* __restrict__ sd, const uint8_t* __restrict__ selected,
+                                                         const float4* __restrict__ normvec, lio_normal_eq* __restrict__ out) {
+    const uint32_t n = sd->n_ds;
+    if (blockIdx.x * 256u >= n) return;
+    __shared__ double red[4][6];
+    __shared__ double V[9];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 9) V[tid] = out->eigvec[tid];
     __syncthreads();
-    // degeneracy sums (laserMapping.cpp:946-964): rows re-normalised, |cos| against each eigenvector
     double s[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t i = tid; i < n; i += kFinThreads) {
-        if (!selected[i]) continue;
+    const uint32_t i = blockIdx.x * 256u + tid;
+    if (i < n && selected[i]) {
         const float4 nv = normvec[i];
         double f0 = (double)nv.x, f1 = (double)nv.y, f2 = (double)nv.z;
         const double nn = sqrt(f0 * f0 + f1 * f1 + f2 * f2);
@@ -374,10 +340,8 @@ __global__ void __launch_bounds__(kFinThreads) finalize_kernel(const ScanDev* __
     }
     __syncthreads();
     if (tid < 6) {
-        double v = 0.0;
-        for (int w = 0; w < kFinThreads / 64; w++) v += red[w][tid];
-        if (tid < 3) out->contri[tid] = v;
-        else out->strong[tid - 3] = v;
+        const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (v != 0.0) atomicAdd(tid < 3 ? &out->contri[tid] : &out->strong[tid - 3], v);
     }
 }
 
@@ -391,8 +355,7 @@ int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) 
                        s->max_ds, s->nn_cnt, s->selected, s->normvec, s->partial);
     kt_end(s, 1);
     kt_begin(s, 2);
-    hipLaunchKernelGGL(finalize_kernel, 1, kFinThreads, 0, s->stream, s->dev, s->partial, s->selected, s->normvec, m ? m->dev : nullptr,
-                       s->d_result);
+    hipLaunchKernelGGL(finalize_kernel, 1, kFinThreads, 0, s->stream, s->dev, s->partial, m ? m->dev : nullptr, s->d_result);
     kt_end(s, 2);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
@@ -455,6 +418,15 @@ int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float ma
     LIO_HIP_TRY(hipMemsetAsync(&m->dev->n_add, 0, sizeof(uint32_t), s->stream));
     hipLaunchKernelGGL(classify_kernel, blocks, 256, 0, s->stream, pose, s->dev, s->ds_body, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt,
                        map_leaf, ekf_inited, seed_all, m->stage, m->dev);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+// the degeneracy sums against the eigenvectors the host wrote into d_result->eigvec
+int p2plane_degeneracy(lio_scan* s) {
+    const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
+    hipLaunchKernelGGL(degeneracy_kernel, (bound + 255) / 256 ? (bound + 255) / 256 : 1, 256, 0, s->stream, s->dev, s->selected, s->normvec,
+                       s->d_result);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

@@ -10,16 +10,23 @@
 // index, which a stable LSD radix sort of (voxel index, point index) provides.
 //
 // Pipeline (all sizes stay on the device; nothing is read back between stages):
-//   bbox (wave shuffle + ordered-uint atomics) -> keys -> 4 x {hist, scan, stable scatter} (8-bit LSD radix,
-//   passes above the significant key bits degrade to a copy) -> head count -> ballot/prefix-sum compaction
-//   fused with the centroid walk.
+//   bbox      wave shuffle + LDS reduce, one set of ordered-uint atomics per workgroup
+//   keys      voxel index per point (every lane re-derives the grid from the bbox: no setup launch)
+//   4 x {hist, scatter}  stable 8-bit LSD radix sort of (key, point index); the scatter workgroups scan the
+//             [digit][tile] histogram themselves (no scan launch); passes above the significant key bits
+//             exit at once and the consumers pick the ping-pong buffer from the pass count
+//   count_heads / heads  voxel occupancy flags -> wave ballot + prefix-sum compaction (fixed order), fused
+//             with the gather of the points into sorted order
+//   centroid  one lane per voxel, sequential f32 sums; runs of >= 32 points are queued and summed one wave per
+//             run (coalesced loads, v_readlane broadcast) in the same sequential order
 #include "lio_common.h"
 
 namespace lio {
 
 constexpr int kThreads = 256;
-constexpr int kItems = 4;
-constexpr int kTile = kThreads * kItems;  // 1024 keys per workgroup
+constexpr int kItems = 8;
+constexpr int kTile = kThreads * kItems;  // 2048 keys per workgroup
+constexpr int kWaves = kThreads / 64;
 
 __device__ inline uint32_t f2ord(float f) {
     uint32_t u = __float_as_uint(f);
@@ -46,11 +53,28 @@ __global__ void __launch_bounds__(kThreads) vg_bbox_kernel(const float4* __restr
         mn2 = fminf(mn2, __shfl_xor(mn2, off)); mx2 = fmaxf(mx2, __shfl_xor(mx2, off));
         cnt += __shfl_xor(cnt, off);
     }
-    if ((threadIdx.x & 63) == 0 && cnt > 0) {
-        atomicMin(&sd->bbox_min[0], f2ord(mn0)); atomicMax(&sd->bbox_max[0], f2ord(mx0));
-        atomicMin(&sd->bbox_min[1], f2ord(mn1)); atomicMax(&sd->bbox_max[1], f2ord(mx1));
-        atomicMin(&sd->bbox_min[2], f2ord(mn2)); atomicMax(&sd->bbox_max[2], f2ord(mx2));
-        atomicAdd(&sd->n_valid, cnt);
+    // one set of atomics per workgroup: the seven words share one L2 line, every atomic on it serialises
+    __shared__ float red[kWaves][6];
+    __shared__ uint32_t redc[kWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave][0] = mn0; red[wave][1] = mn1; red[wave][2] = mn2;
+        red[wave][3] = mx0; red[wave][4] = mx1; red[wave][5] = mx2;
+        redc[wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWaves; w++) {
+            mn0 = fminf(mn0, red[w][0]); mn1 = fminf(mn1, red[w][1]); mn2 = fminf(mn2, red[w][2]);
+            mx0 = fmaxf(mx0, red[w][3]); mx1 = fmaxf(mx1, red[w][4]); mx2 = fmaxf(mx2, red[w][5]);
+            cnt += redc[w];
+        }
+        if (cnt > 0) {
+            atomicMin(&sd->bbox_min[0], f2ord(mn0)); atomicMax(&sd->bbox_max[0], f2ord(mx0));
+            atomicMin(&sd->bbox_min[1], f2ord(mn1)); atomicMax(&sd->bbox_max[1], f2ord(mx1));
+            atomicMin(&sd->bbox_min[2], f2ord(mn2)); atomicMax(&sd->bbox_max[2], f2ord(mx2));
+            atomicAdd(&sd->n_valid, cnt);
+        }
     }
 }
 
@@ -92,7 +116,7 @@ __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restr
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const VgGrid g = vg_derive(sd, inv);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sd->n_ds_prev = sd->n_ds;  // still the previous scan's size: the centroid kernel runs later
+        sd->n_ds_prev = sd->n_ds;  // still the previous scan's size: the heads kernel runs later
         sd->passthrough = g.pass;
         sd->total_cells = g.total;
         sd->nbits = g.total ? (32 - __clz(g.total)) : 0;  // keys 0..total (total = invalid marker) need bits(total)
@@ -113,10 +137,16 @@ __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restr
     }
 }
 
-// ---- stable LSD radix sort, 8 bits per pass ---------------------------------------------------------
-__global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
-                                                              uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
-    if ((uint32_t)shift >= sd->nbits) return;
+// ---- stable LSD radix sort, 8 bits per pass, ping-pong a -> b -> a ... ------------------------------------
+// pass p reads buffer (p & 1 ? b : a); the number of active passes is ceil(nbits / 8), so the sorted data end
+// up in (active & 1 ? b : a)
+__device__ inline uint32_t active_passes(const ScanDev* sd) { return (sd->nbits + 7u) >> 3; }
+
+__global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
+                                                              int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
+    if ((uint32_t)pass >= active_passes(sd)) return;
+    const uint32_t* keys = (pass & 1) ? kb : ka;
+    const int shift = pass * 8;
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -130,29 +160,6 @@ __global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __
     hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks, int shift, const ScanDev* sd) {
-    if ((uint32_t)shift >= sd->nbits) return;
-    __shared__ uint32_t s[256];
-    const int d = threadIdx.x;
-    uint32_t* row = hist + (size_t)d * nblocks;
-    uint32_t sum = 0;
-    for (uint32_t b = 0; b < nblocks; b++) sum += row[b];
-    s[d] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t t = (d >= off) ? s[d - off] : 0u;
-        __syncthreads();
-        s[d] += t;
-        __syncthreads();
-    }
-    uint32_t run = s[d] - sum;
-    for (uint32_t b = 0; b < nblocks; b++) {
-        const uint32_t t = row[b];
-        row[b] = run;
-        run += t;
-    }
-}
-
 __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
     unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -164,21 +171,18 @@ __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
     return peers;
 }
 
-__global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                                 uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n,
-                                                                 int shift, const uint32_t* __restrict__ hist, uint32_t nblocks,
-                                                                 const ScanDev* sd) {
+__global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
+                                                                 uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
+                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
+    if ((uint32_t)pass >= active_passes(sd)) return;
+    const uint32_t* kin = (pass & 1) ? kb : ka;
+    const uint32_t* vin = (pass & 1) ? vb : va;
+    uint32_t* kout = (pass & 1) ? ka : kb;
+    uint32_t* vout = (pass & 1) ? va : vb;
+    const int shift = pass * 8;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if ((uint32_t)shift >= sd->nbits) {  // pass above the significant bits: keep the ping-pong parity, copy through
-        const uint32_t base = blockIdx.x * kTile;
-#pragma unroll
-        for (int r = 0; r < kItems; r++) {
-            const uint32_t i = base + r * kThreads + tid;
-            if (i < n) { kout[i] = kin[i]; vout[i] = vin[i]; }
-        }
-        return;
-    }
-    __shared__ uint32_t wcnt[kThreads / 64][256];
+    __shared__ uint32_t wcnt[kWaves][256];
+    __shared__ uint32_t wsum[kWaves];
     // each wave owns a contiguous run of 64*kItems keys so that (round, lane) order == input order
     const uint32_t base = blockIdx.x * kTile + wave * (64 * kItems);
     uint32_t k[kItems], v[kItems];
@@ -190,8 +194,35 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
         k[r] = ok[r] ? kin[i] : 0u;
         v[r] = ok[r] ? vin[i] : 0u;
     }
-    for (int j = tid; j < (kThreads / 64) * 256; j += kThreads) (&wcnt[0][0])[j] = 0;
+    // this workgroup's global bases, from the raw [digit][tile] histogram: thread d owns digit d.
+    //   base[d] = sum_{d' < d} total[d'] + sum_{b' < b} hist[d][b']      (digit-major, then tile order = stable)
+    uint32_t tot = 0, pre = 0;
+    {
+        const uint32_t* row = hist + (size_t)tid * nblocks;
+        uint32_t b = 0;
+        for (; b + 4 <= nblocks; b += 4) {
+            const uint32_t h0 = row[b], h1 = row[b + 1], h2 = row[b + 2], h3 = row[b + 3];
+            tot += (h0 + h1) + (h2 + h3);
+            pre += (b < blockIdx.x ? h0 : 0u) + (b + 1 < blockIdx.x ? h1 : 0u) + (b + 2 < blockIdx.x ? h2 : 0u) + (b + 3 < blockIdx.x ? h3 : 0u);
+        }
+        for (; b < nblocks; b++) {
+            const uint32_t h0 = row[b];
+            tot += h0;
+            pre += b < blockIdx.x ? h0 : 0u;
+        }
+    }
+    uint32_t inc = tot;  // inclusive scan of the digit totals across the 256 threads
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    for (int j = tid; j < kWaves * 256; j += kThreads) (&wcnt[0][0])[j] = 0;
     __syncthreads();
+    uint32_t gbase = inc - tot + pre;
+    for (int w = 0; w < wave; w++) gbase += wsum[w];
+
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
@@ -202,9 +233,9 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
     }
     __syncthreads();
     {
-        uint32_t g = hist[tid * nblocks + blockIdx.x];
+        uint32_t g = gbase;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; w++) {
+        for (int w = 0; w < kWaves; w++) {
             const uint32_t t = wcnt[w][tid];
             wcnt[w][tid] = g;
             g += t;
@@ -225,8 +256,9 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
 }
 
 // ---- voxel heads: occupancy flags -> ballot + prefix-sum compaction -> centroid ------------------------
-__global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, const ScanDev* sd,
-                                                                  uint32_t* __restrict__ blockcnt) {
+__global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
+                                                                  const ScanDev* sd, uint32_t* __restrict__ blockcnt) {
+    const uint32_t* keys = (active_passes(sd) & 1) ? kb : ka;
     __shared__ uint32_t c;
     if (threadIdx.x == 0) c = 0;
     __syncthreads();
@@ -248,10 +280,12 @@ __global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = c;
 }
 
-__global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
-                                                               const uint32_t* __restrict__ vals, uint32_t n, ScanDev* sd,
-                                                               const uint32_t* __restrict__ blockcnt, float4* __restrict__ out,
-                                                               uint32_t max_ds) {
+// compaction of the voxel heads (ballot + prefix sum, fixed order) and the gather of the points into sorted order
+__global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ ka,
+                                                            const uint32_t* __restrict__ kb, const uint32_t* __restrict__ va,
+                                                            const uint32_t* __restrict__ vb, uint32_t n, ScanDev* sd,
+                                                            const uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ hpos,
+                                                            float4* __restrict__ sorted, float4* __restrict__ out, uint32_t max_ds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (sd->passthrough) {  // PCL overflow guard: output = input
         if (n > max_ds) {
@@ -266,8 +300,11 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __r
         if (blockIdx.x == 0 && tid == 0) sd->n_ds = n;
         return;
     }
-    __shared__ uint32_t red[kThreads / 64];
-    __shared__ uint32_t wtot[kThreads / 64];
+    const bool odd = active_passes(sd) & 1;
+    const uint32_t* keys = odd ? kb : ka;
+    const uint32_t* vals = odd ? vb : va;
+    __shared__ uint32_t red[kWaves];
+    __shared__ uint32_t wtot[kWaves];
     // exclusive prefix of the tiles before this one (fixed order -> deterministic output slots)
     uint32_t pre = 0;
     for (uint32_t b = tid; b < blockIdx.x; b += kThreads) pre += blockcnt[b];
@@ -276,7 +313,7 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __r
     if (lane == 0) red[wave] = pre;
     __syncthreads();
     uint32_t run = 0;
-    for (int w = 0; w < kThreads / 64; w++) run += red[w];
+    for (int w = 0; w < kWaves; w++) run += red[w];
     __syncthreads();
 
     const uint32_t total = sd->total_cells;
@@ -285,31 +322,23 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __r
     for (int r = 0; r < kItems; r++) {
         const uint32_t i = base + r * kThreads + tid;
         bool head = false;
-        uint32_t key = 0;
         if (i < n) {
-            key = keys[i];
+            const uint32_t key = keys[i];
             head = key < total && (i == 0 || keys[i - 1] != key);
+            sorted[i] = in[vals[i]];
         }
         const unsigned long long m = __ballot(head);
         if (lane == 0) wtot[wave] = __popcll(m);
         __syncthreads();
         uint32_t woff = 0, rtot = 0;
-        for (int w = 0; w < kThreads / 64; w++) {
+        for (int w = 0; w < kWaves; w++) {
             const uint32_t t = wtot[w];
             if (w < wave) woff += t;
             rtot += t;
         }
         if (head) {
             const uint32_t slot = run + woff + __popcll(m & lt);
-            float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-            uint32_t j = i;
-            do {
-                const float4 p = in[vals[j]];
-                sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; sw = sw + p.w;
-                j++;
-            } while (j < n && keys[j] == key);
-            const float c = (float)(j - i);
-            if (slot < max_ds) out[slot] = make_float4(sx / c, sy / c, sz / c, sw / c);
+            if (slot < max_ds) hpos[slot] = i;
         }
         run += rtot;
         __syncthreads();
@@ -317,6 +346,68 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __r
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         if (run > max_ds) { sd->err |= 1u; run = 0; }
         sd->n_ds = run;
+    }
+}
+
+// one lane per occupied voxel: centroid of its run in ascending input order (f32 running sums, as PCL does).
+// Runs shorter than 32 points are walked by the owning lane, four loads in flight.  Longer runs (the rings
+// close to the sensor: a few hundred voxels holding half of the points) are queued for the wave-per-voxel
+// kernel below, so that their latency is spread over the chip instead of serialising one wave.
+constexpr uint32_t kLongRun = 32;
+
+__global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
+                                                               ScanDev* __restrict__ sd, float4* __restrict__ out,
+                                                               uint32_t* __restrict__ longlist) {
+    if (sd->passthrough) return;
+    const uint32_t nv = sd->n_ds;
+    const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
+    if (v >= nv) return;
+    const uint32_t a = hpos[v];
+    const uint32_t b = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;  // invalid (non-finite) points sort behind every voxel
+    if (b - a >= kLongRun) {
+        longlist[atomicAdd(&sd->n_long, 1u)] = v;
+        return;
+    }
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+    for (uint32_t j = a; j < b; j += 4) {
+        float4 p[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k] = sorted[(j + k < b) ? (j + k) : (b - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (j + k < b) { sx = sx + p[k].x; sy = sy + p[k].y; sz = sz + p[k].z; sw = sw + p[k].w; }
+    }
+    const float c = (float)(b - a);
+    out[v] = make_float4(sx / c, sy / c, sz / c, sw / c);
+}
+
+// one wave per long run: 64 coalesced loads at a time, then the same sequential additions, fed by
+// v_readlane broadcasts (every lane forms the identical sum; lane 0 stores it)
+__global__ void __launch_bounds__(kThreads) vg_centroid_long_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
+                                                                    const ScanDev* __restrict__ sd, float4* __restrict__ out,
+                                                                    const uint32_t* __restrict__ longlist) {
+    if (sd->passthrough) return;
+    const uint32_t nv = sd->n_ds, nl = sd->n_long;
+    const int lane = threadIdx.x & 63;
+    const uint32_t nwaves = gridDim.x * kWaves;
+    for (uint32_t w = blockIdx.x * kWaves + (threadIdx.x >> 6); w < nl; w += nwaves) {
+        const uint32_t v = longlist[w];
+        const uint32_t ra = hpos[v];
+        const uint32_t rb = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;
+        float tx = 0.f, ty = 0.f, tz = 0.f, tw = 0.f;
+        for (uint32_t c = ra; c < rb; c += 64) {
+            const uint32_t j = c + lane;
+            const float4 p = sorted[j < rb ? j : rb - 1];
+            const int m = (rb - c) < 64u ? (int)(rb - c) : 64;
+            for (int k = 0; k < m; k++) {
+                tx = tx + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.x), k));
+                ty = ty + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.y), k));
+                tz = tz + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.z), k));
+                tw = tw + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.w), k));
+            }
+        }
+        const float cnt = (float)(rb - ra);
+        if (lane == 0) out[v] = make_float4(tx / cnt, ty / cnt, tz / cnt, tw / cnt);
     }
 }
 
@@ -336,26 +427,28 @@ int vg_downsample(lio_scan* s, float leaf) {
     const float inv = 1.0f / leaf;
     hipStream_t st = s->stream;
     LIO_HIP_TRY(hipMemsetAsync(s->dev->bbox_min, 0xFF, 12, st));
-    LIO_HIP_TRY(hipMemsetAsync(s->dev->bbox_max, 0, 16, st));  // bbox_max[3] + n_valid
+    LIO_HIP_TRY(hipMemsetAsync(s->dev->bbox_max, 0, 20, st));  // bbox_max[3] + n_valid + n_long
     const uint32_t nblocks = (n + kTile - 1) / kTile;
     if (n == 0) {
         hipLaunchKernelGGL(scan_set_nds_kernel, 1, 1, 0, st, s->dev, 0u);
         return LIO_OK;
     }
-    const uint32_t g1 = nblocks < 1024 ? nblocks : 1024;
+    const uint32_t g1 = nblocks < 64 ? nblocks : 64;
     hipLaunchKernelGGL(vg_bbox_kernel, g1, kThreads, 0, st, s->raw, n, s->dev);
-    hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a);
-    uint32_t *ka = s->keys_a, *kb = s->keys_b, *va = s->vals_a, *vb = s->vals_b;
+    hipLaunchKernelGGL(vg_keys_kernel, (n + kThreads - 1) / kThreads < 512 ? (n + kThreads - 1) / kThreads : 512, kThreads, 0, st, s->raw, n, inv,
+                       s->dev, s->keys_a, s->vals_a);
     for (int pass = 0; pass < 4; pass++) {
-        const int shift = pass * 8;
-        hipLaunchKernelGGL(radix_hist_kernel, nblocks, kThreads, 0, st, ka, n, shift, s->hist, nblocks, s->dev);
-        hipLaunchKernelGGL(radix_scan_kernel, 1, 256, 0, st, s->hist, nblocks, shift, s->dev);
-        hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, ka, va, kb, vb, n, shift, s->hist, nblocks, s->dev);
-        uint32_t* t = ka; ka = kb; kb = t;
-        t = va; va = vb; vb = t;
+        hipLaunchKernelGGL(radix_hist_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, pass, s->hist, nblocks, s->dev);
+        hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, s->keys_a, s->vals_a, s->keys_b, s->vals_b, n, pass, s->hist, nblocks,
+                           s->dev);
     }
-    hipLaunchKernelGGL(vg_count_heads_kernel, nblocks, kThreads, 0, st, ka, n, s->dev, s->blockcnt);
-    hipLaunchKernelGGL(vg_centroid_kernel, nblocks, kThreads, 0, st, s->raw, ka, va, n, s->dev, s->blockcnt, s->ds_body, s->max_ds);
+    hipLaunchKernelGGL(vg_count_heads_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, s->dev, s->blockcnt);
+    hipLaunchKernelGGL(vg_heads_kernel, nblocks, kThreads, 0, st, s->raw, s->keys_a, s->keys_b, s->vals_a, s->vals_b, n, s->dev, s->blockcnt,
+                       s->hpos, s->sorted, s->ds_body, s->max_ds);
+    const uint32_t vbound = n < s->max_ds ? n : s->max_ds;
+    hipLaunchKernelGGL(vg_centroid_kernel, (vbound + kThreads - 1) / kThreads, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body,
+                       s->longlist);
+    hipLaunchKernelGGL(vg_centroid_long_kernel, 256, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body, s->longlist);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

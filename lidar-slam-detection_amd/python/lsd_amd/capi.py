@@ -20,7 +20,7 @@ SYMBOLS = [
     "lio_map_dump", "lio_map_knn",
     "lio_scan_create", "lio_scan_destroy", "lio_scan_reset", "lio_scan_upload", "lio_scan_set_device", "lio_scan_voxel_downsample", "lio_scan_set_ds",
     "lio_scan_num_ds", "lio_scan_download_ds", "lio_scan_download_world", "lio_scan_download_match",
-    "lio_p2plane_linearize", "lio_p2plane_rows", "lio_map_incremental", "lio_map_seed",
+    "lio_p2plane_linearize", "lio_scan_force_degeneracy", "lio_p2plane_rows", "lio_map_incremental", "lio_map_seed",
     "lio_engine_create", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
     "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
@@ -94,6 +94,7 @@ def lib():
     sig("lio_scan_download_world", cint, vp, f32p, u32)
     sig("lio_scan_download_match", cint, vp, u8p, f32p, i32p, f32p)
     sig("lio_p2plane_linearize", cint, vp, vp, f64p, f64p, cint, C.POINTER(NormalEq))
+    sig("lio_scan_force_degeneracy", cint, vp, cint)
     sig("lio_p2plane_rows", cint, vp, f64p, f64p, f64p, f64p, u32)
     sig("lio_map_incremental", cint, vp, vp, f64p, f64p, flt, cint, dbl)
     sig("lio_map_seed", cint, vp, vp, f64p, f64p, dbl)

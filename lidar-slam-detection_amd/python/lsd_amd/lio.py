@@ -150,6 +150,9 @@ class Scan:
         n = check(lib().lio_scan_download_world(self.h, ptr(out, C.c_float), self.max_ds), "download world")
         return out[:n].copy()
 
+    def force_degeneracy(self, on=True):
+        check(lib().lio_scan_force_degeneracy(self.h, int(on)))
+
     def enable_kernel_timing(self, on=True):
         check(lib().lio_scan_enable_kernel_timing(self.h, int(on)))
 
