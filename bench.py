@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--scan-pool", type=int, default=8, help="distinct scans cycled through the steps")
     ap.add_argument("--cpu-scans", type=int, default=24, help="scans of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--streams", type=int, default=4, help="independent scans in flight per GPU (one engine + HIP stream + host thread each, "
+                                                              "all reading the one resident map)")
     args = ap.parse_args()
 
     import torch
@@ -72,30 +74,36 @@ def main():
         scans.append(dict(raw=raw, pos=pos, q=q, guess=synth.state_from_pose(gp, gq)))
     n_raw = int(np.mean([len(s["raw"]) for s in scans]))
 
-    eng = lio.Engine(resolution=0.5, stencil=19, max_points=max(args.map_points, 1_000_000), max_voxels=max(args.map_points // 4, 1_000_000),
-                     max_raw=1 << 18, max_ds=100000, device=local_rank)
+    import threading
+
+    the_map = lio.Map(resolution=0.5, stencil=19, max_points=max(args.map_points, 1_000_000), max_voxels=max(args.map_points // 4, 1_000_000),
+                      device=local_rank)
     # the map goes to HBM once; the raw scans live in torch tensors on the device (inputs resident before timing)
     d_map = torch.from_numpy(map_pts).to(dev)
     torch.cuda.synchronize()
-    eng.map.add_device(d_map.data_ptr(), len(map_pts))
+    the_map.add_device(d_map.data_ptr(), len(map_pts))
     del d_map
     d_scans = [torch.from_numpy(s["raw"]).to(dev) for s in scans]
     torch.cuda.synchronize()
-    eng.set_static_map(True)
-    eng.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+    n_streams = max(1, args.streams)
+    engines = [lio.Engine(max_raw=1 << 18, max_ds=100000, shared_map=the_map) for _ in range(n_streams)]
+    for e in engines:
+        e.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+    eng = engines[0]
     P0 = lio.init_cov()
-    map_points, map_voxels = eng.map.stats()
+    map_points, map_voxels = the_map.stats()
 
-    def step(i):
+    def step(i, e=None):
+        e = e or eng
         s = scans[i % len(scans)]
-        eng.set_state(s["guess"])
-        eng.set_cov(P0)
-        rc = eng.process_scan_device(d_scans[i % len(scans)].data_ptr(), len(s["raw"]), 1.0 + 0.1 * i)
+        e.set_state(s["guess"])
+        e.set_cov(P0)
+        rc = e.process_scan_device(d_scans[i % len(scans)].data_ptr(), len(s["raw"]), 1.0 + 0.1 * i)
         if rc != 3:
             raise RuntimeError(f"process_scan returned {rc}")
 
     for i in range(args.warmup):
-        step(i)
+        step(i, engines[i % n_streams])
     # pose check outside the timed region: every pooled scan must land on its true pose
     pose_err, ang_err = 0.0, 0.0
     for k in range(len(scans)):
@@ -104,27 +112,58 @@ def main():
         pose_err = max(pose_err, float(np.linalg.norm(st[:3] - scans[k]["pos"])))
         ang_err = max(ang_err, float(synth.quat_angle(st[3:7], scans[k]["q"])))
 
-    eng.scan.enable_kernel_timing(True)
-    eng.scan.kernel_times(reset=True)
-    cand0 = eng.timings()["knn_candidates"]
+    # single-stream latency of one scan (reported beside the throughput; not the timed region)
+    torch.cuda.synchronize()
+    l0 = time.perf_counter()
+    for i in range(20):
+        step(i)
+    latency_ms = 1e3 * (time.perf_counter() - l0) / 20
+
+    for e in engines:
+        e.scan.enable_kernel_timing(True)
+        e.scan.kernel_times(reset=True)
+    cand0 = the_map.knn_candidates
     acc = dict(n_ds=0, n_pass=0, n_knn=0, pts=0)
+    acc_lock = threading.Lock()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    errors = []
+
+    def worker(t):
+        e = engines[t]
+        loc = dict(n_ds=0, n_pass=0, n_knn=0, pts=0)
+        try:
+            for i in range(t, args.steps, n_streams):
+                step(i, e)
+                tm = e.timings()
+                loc["n_ds"] += tm["n_ds"]
+                loc["n_pass"] += tm["n_pass"]
+                loc["n_knn"] += tm["n_knn_pass"]
+                loc["pts"] += len(scans[i % len(scans)]["raw"])
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+        with acc_lock:
+            for k in loc:
+                acc[k] += loc[k]
+
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-        tm = eng.timings()
-        acc["n_ds"] += tm["n_ds"]
-        acc["n_pass"] += tm["n_pass"]
-        acc["n_knn"] += tm["n_knn_pass"]
-        acc["pts"] += len(scans[i % len(scans)]["raw"])
+    if n_streams == 1:
+        worker(0)
+    else:
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_streams)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
     barrier()
     t_max = t_local
     total_pts = acc["pts"]
@@ -136,9 +175,13 @@ def main():
         dist.all_reduce(tp, op=dist.ReduceOp.SUM)
         total_pts = float(tp.item())
 
-    kt = eng.scan.kernel_times(reset=True)
-    eng.scan.enable_kernel_timing(False)
-    cand = eng.timings()["knn_candidates"] - cand0
+    kt = dict(knn_us=0.0, linearize_us=0.0, finalize_us=0.0, knn_launches=0, linearize_launches=0, finalize_launches=0)
+    for e in engines:
+        k1 = e.scan.kernel_times(reset=True)
+        for k in kt:
+            kt[k] += k1[k]
+        e.scan.enable_kernel_timing(False)
+    cand = the_map.knn_candidates - cand0
     # ---- roofline of the dominant kernel (stencil kNN): algorithmic bytes per launch / measured launch time -----
     # B_knn = N_ds * (16 query + 16 * S slot probes) + 16 * (points resident in the probed voxels)   [SURVEY.md 8d]
     S = 19
@@ -153,7 +196,7 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = dict(bound="hbm", kernel="knn_kernel<16,0>", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(bound="hbm", kernel="knn_kernel<32,1,0>", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, algorithmic_bytes_per_launch=int(knn_bytes),
                     avg_launch_us=round(knn_us, 2), launches=launches,
                     other_kernels_us={"linearize": round(kt["linearize_us"] / max(kt["linearize_launches"], 1), 2),
@@ -207,7 +250,8 @@ def main():
                        "n_raw": n_raw, "n_ds_avg": round(acc["n_ds"] / args.steps, 1), "passes_avg": round(acc["n_pass"] / args.steps, 2),
                        "knn_passes_avg": round(acc["n_knn"] / args.steps, 2), "stencil": 19,
                        "knn_candidates_per_query": round(cand / max(acc["n_ds"] / args.steps * acc["n_knn"], 1), 1),
-                       "map_bytes_hbm": eng.map.nbytes},
+                       "map_bytes_hbm": the_map.nbytes, "streams_per_gpu": n_streams,
+                       "single_stream_latency_ms_per_scan": round(latency_ms, 4)},
             "pose_error_vs_truth": {"max_dpos_m": pose_err, "max_drot_rad": ang_err},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -60,6 +60,8 @@ int lio_map_insert(lio_map*, const float* world_xyzi, uint64_t n, double travel)
 int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double travel);
 /* IVox::NumValidGrids (ivox3d.h:173-176) and the total number of stored points */
 int lio_map_stats(lio_map*, uint64_t* n_points, uint64_t* n_voxels);
+/* running total of map points visited by stencil kNN queries (the C-bar * N_ds statistic of the roofline model) */
+uint64_t lio_map_knn_candidates(lio_map*);
 /* all stored points, voxel by voxel in unspecified order; returns the count or -(needed) */
 int64_t lio_map_dump(lio_map*, float* out_xyzi, uint64_t cap_points);
 /* IVox::GetClosestPoint(pt, out, 5, 5.0) for a batch of world-frame queries (ivox3d.h:139-171):
@@ -117,6 +119,8 @@ typedef struct lio_normal_eq {
     uint32_t n_eff;      /* effct_feat_num */
     uint32_t n_ds;       /* feats_down_size */
     uint32_t n_knn_candidates_lo, n_knn_candidates_hi; /* 64-bit count of in-stencil points visited (kNN passes) */
+    uint32_t n_tie;      /* kNN queries redone with the exact (d2, x, y, z) comparison because of an exact d2 tie */
+    uint32_t pad;
 } lio_normal_eq;
 
 /* One evaluation of h_share_model_geometric (src/laserMapping.cpp:813-932) without the host-side
@@ -146,6 +150,10 @@ int lio_map_seed(lio_map*, lio_scan*, const double pose_wi[7], const double ext_
  * ------------------------------------------------------------------------------------------- */
 lio_engine* lio_engine_create(int device, float resolution, int stencil, uint64_t max_points, uint64_t max_voxels,
                               uint32_t max_raw, uint32_t max_ds);
+/* an engine (state + covariance + scan buffers + stream) that registers scans against a map owned by someone
+ * else.  Several such engines may run concurrently from different host threads on one map: the map is then
+ * read-only (static-map mode is forced; map_incremental is skipped).  Destroying the engine leaves the map. */
+lio_engine* lio_engine_create_shared(lio_map* shared_map, uint32_t max_raw, uint32_t max_ds);
 void lio_engine_destroy(lio_engine*);
 lio_map* lio_engine_map(lio_engine*);
 lio_scan* lio_engine_scan(lio_engine*);

@@ -142,7 +142,7 @@ lio_map* lio_map_create(int device, float resolution, uint64_t max_points, uint6
     m->own_stream = ok;
     ok = ok && dev_alloc(&m->table, cap, &m->bytes) && dev_alloc(&m->cap, cap, &m->bytes) && dev_alloc(&m->pending, cap, &m->bytes) &&
          dev_alloc(&m->created, cap, &m->bytes) && dev_alloc(&m->pool, m->pool_cap, &m->bytes) && dev_alloc(&m->dev, 1, &m->bytes) &&
-         dev_alloc(&m->slot_of_point, m->slot_of_point_cap, &m->bytes) && dev_alloc(&m->stage, m->stage_cap, &m->bytes);
+         dev_alloc(&m->slot_of_point, m->slot_of_point_cap, &m->bytes) && dev_alloc(&m->tile_sum, cap / 2048 + 1, &m->bytes) && dev_alloc(&m->stage, m->stage_cap, &m->bytes);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&m->host_dev), sizeof(MapDev)) == hipSuccess;
     if (ok) {
         ok = hipMemsetAsync(m->table, 0xFF, cap * sizeof(Slot), m->stream) == hipSuccess &&  // key = empty; ptr/cnt fixed below
@@ -167,7 +167,7 @@ void lio_map_destroy(lio_map* m) {
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
     hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->dev);
-    hipFree(m->slot_of_point); hipFree(m->stage);
+    hipFree(m->slot_of_point); hipFree(m->tile_sum); hipFree(m->stage);
     if (m->host_dev) hipHostFree(m->host_dev);
     if (m->stream && m->own_stream) hipStreamDestroy(m->stream);
     delete m;
@@ -221,6 +221,16 @@ int lio_map_stats(lio_map* m, uint64_t* n_points, uint64_t* n_voxels) {
     return rc;
 }
 
+uint64_t lio_map_knn_candidates(lio_map* m) {
+    if (!m) return 0;
+    hipSetDevice(m->device);
+    MapDev tmp;
+    if (hipMemcpy(&tmp, m->dev, sizeof(MapDev), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    uint64_t s = 0;
+    for (int k = 0; k < 64; k++) s += tmp.knn_cand[k * 16];
+    return s;
+}
+
 int64_t lio_map_dump(lio_map* m, float* out, uint64_t cap_points) {
     if (!m) return LIO_E_INVALID;
     hipSetDevice(m->device);
@@ -245,8 +255,10 @@ int lio_map_knn(lio_map* m, const float* q, uint32_t n, float* out_pts, int32_t*
     hipSetDevice(m->device);
     float4 *dq = nullptr, *dout = nullptr;
     int32_t* dcnt = nullptr;
+    uint32_t* dtie = nullptr;
     int rc = LIO_OK;
     if (hipMalloc(reinterpret_cast<void**>(&dq), n * sizeof(float4)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dtie), ((size_t)n + 1) * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&dout), (size_t)n * 5 * sizeof(float4)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&dcnt), n * sizeof(int32_t)) != hipSuccess) {
         set_error("lio_map_knn: hipMalloc failed");
@@ -256,7 +268,8 @@ int lio_map_knn(lio_map* m, const float* q, uint32_t n, float* out_pts, int32_t*
         hipMemcpyAsync(dq, q, n * sizeof(float4), hipMemcpyHostToDevice, m->stream);
         hipMemsetAsync(dout, 0, (size_t)n * 5 * sizeof(float4), m->stream);
         hipMemsetAsync(dcnt, 0, n * sizeof(int32_t), m->stream);
-        rc = knn_batch(m, dq, n, dout, dcnt);
+        hipMemsetAsync(dtie, 0, sizeof(uint32_t), m->stream);
+        rc = knn_batch(m, dq, n, dout, dcnt, dtie);
     }
     if (rc == LIO_OK) {
         std::vector<float4> soa((size_t)n * 5);
@@ -270,7 +283,7 @@ int lio_map_knn(lio_map* m, const float* q, uint32_t n, float* out_pts, int32_t*
                 for (int k = 0; k < 5; k++) memcpy(out_pts + ((size_t)i * 5 + k) * 4, &soa[(size_t)k * n + i], sizeof(float4));
         }
     }
-    hipFree(dq); hipFree(dout); hipFree(dcnt);
+    hipFree(dq); hipFree(dout); hipFree(dcnt); hipFree(dtie);
     return rc;
 }
 
@@ -290,7 +303,7 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
          dev_alloc(&s->nn_pts, (uint64_t)max_ds * 5, &s->bytes) && dev_alloc(&s->nn_cnt, max_ds, &s->bytes) && dev_alloc(&s->selected, max_ds, &s->bytes) &&
          dev_alloc(&s->normvec, max_ds, &s->bytes) && dev_alloc(&s->keys_a, max_raw, &s->bytes) && dev_alloc(&s->keys_b, max_raw, &s->bytes) &&
          dev_alloc(&s->vals_a, max_raw, &s->bytes) && dev_alloc(&s->vals_b, max_raw, &s->bytes) && dev_alloc(&s->hist, (uint64_t)256 * nblocks, &s->bytes) &&
-         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
+         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->tie_list, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
          dev_alloc(&s->dev, 1, &s->bytes) && dev_alloc(&s->d_result, 1, &s->bytes);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&s->host_dev), sizeof(ScanDev)) == hipSuccess &&
          hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(lio_normal_eq)) == hipSuccess;
@@ -316,7 +329,7 @@ void lio_scan_destroy(lio_scan* s) {
     if (s->stream) hipStreamSynchronize(s->stream);
     hipFree(s->raw_own); hipFree(s->ds_body); hipFree(s->ds_world); hipFree(s->nn_pts); hipFree(s->nn_cnt); hipFree(s->selected);
     hipFree(s->normvec); hipFree(s->keys_a); hipFree(s->keys_b); hipFree(s->vals_a); hipFree(s->vals_b); hipFree(s->hist);
-    hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
+    hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->tie_list); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
     if (s->host_dev) hipHostFree(s->host_dev);
     if (s->h_result) hipHostFree(s->h_result);
     if (s->kt) {
@@ -485,6 +498,16 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
     if (rc != LIO_OK) return rc;
     LIO_HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(lio_normal_eq), hipMemcpyDeviceToHost, s->stream));
     LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->h_result->n_tie) {  // exact d2 ties among some top-6: redo those queries with the canonical comparison
+        const uint32_t nt = s->h_result->n_tie;
+        rc = map_knn_exact(m, s, pose, nt);
+        if (rc != LIO_OK) return rc;
+        rc = p2plane_reduce(m, s, pose, redo_knn);
+        if (rc != LIO_OK) return rc;
+        LIO_HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(lio_normal_eq), hipMemcpyDeviceToHost, s->stream));
+        LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+        s->h_result->n_tie = nt;
+    }
     *out = *s->h_result;
     s->have_ds = (int)out->n_ds;
     // degeneracy detection (laserMapping.cpp:934-964).  The eigen-decomposition of sum n n^T runs here on the

@@ -19,6 +19,8 @@ struct lio_engine {
     double init_time = 0.1, laser_cov = 0.001;
     bool degenerate_detect_en = true;
     bool static_map = false;
+    bool own_map = true;
+    bool map_seeded = false;  // NumValidGrids() != 0 observed (a map never becomes empty again)
     // file-scope state of laserMapping.cpp
     double travel = 0, first_lidar_time = 0;
     double last_pos_lid[3] = {0, 0, 0};
@@ -211,10 +213,24 @@ lio_engine* lio_engine_create(int device, float resolution, int stencil, uint64_
     return e;
 }
 
+lio_engine* lio_engine_create_shared(lio_map* shared_map, uint32_t max_raw, uint32_t max_ds) {
+    if (!shared_map) return nullptr;
+    lio_scan* s = lio_scan_create(shared_map->device, max_raw, max_ds);
+    if (!s) return nullptr;
+    lio_engine* e = new lio_engine();
+    e->map = shared_map;
+    e->scan = s;
+    e->own_map = false;
+    e->static_map = true;  // several engines read one map concurrently: nobody inserts
+    e->map_seeded = true;
+    memset(&e->tm, 0, sizeof(e->tm));
+    return e;
+}
+
 void lio_engine_destroy(lio_engine* e) {
     if (!e) return;
     lio_scan_destroy(e->scan);
-    lio_map_destroy(e->map);
+    if (e->own_map) lio_map_destroy(e->map);
     delete e;
 }
 
@@ -251,7 +267,12 @@ int lio_engine_pass_log(lio_engine* e, int i, lio_pass_log* out) {
 }
 
 int lio_engine_enable_timing(lio_engine* e, int on) { if (!e) return LIO_E_INVALID; e->timing = on != 0; return LIO_OK; }
-int lio_engine_set_static_map(lio_engine* e, int on) { if (!e) return LIO_E_INVALID; e->static_map = on != 0; return LIO_OK; }
+int lio_engine_set_static_map(lio_engine* e, int on) {
+    if (!e) return LIO_E_INVALID;
+    if (!e->own_map && !on) { set_error("an engine on a shared map is read-only"); return LIO_E_STATE; }
+    e->static_map = on != 0;
+    return LIO_OK;
+}
 int lio_engine_timings(lio_engine* e, lio_timings* out) { if (!e || !out) return LIO_E_INVALID; *out = e->tm; return LIO_OK; }
 
 static int process_common(lio_engine* e, double lidar_beg_time) {
@@ -279,9 +300,12 @@ static int process_common(lio_engine* e, double lidar_beg_time) {
     e->tm.n_ds = (int)n_ds;
     double pose[7], ext[7];
     uint64_t nv = 0;
-    rc = lio_map_stats(e->map, nullptr, &nv);
-    if (rc != LIO_OK) return rc;
-    if (nv == 0) {  // laserMapping.cpp:1227-1239: seed the map with the first downsampled scan
+    if (!e->map_seeded) {
+        rc = lio_map_stats(e->map, nullptr, &nv);
+        if (rc != LIO_OK) return rc;
+        e->map_seeded = nv != 0;
+    }
+    if (!e->map_seeded) {  // laserMapping.cpp:1227-1239: seed the map with the first downsampled scan
         if (n_ds > 5) {
             pose_arrays(e->kf.x, pose, ext);
             rc = lio_map_seed(e->map, s, pose, ext, e->travel);

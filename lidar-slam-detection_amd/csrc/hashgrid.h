@@ -1,0 +1,45 @@
+// hashgrid.h -- key packing and hashing of the voxel hash grid (shared by hashmap.hip and knn.hip)
+#pragma once
+#include "lio_common.h"
+
+namespace lio {
+
+__device__ __host__ inline unsigned long long pack_key(int x, int y, int z) {
+    return ((unsigned long long)((uint32_t)x & 0x1FFFFFu)) | ((unsigned long long)((uint32_t)y & 0x1FFFFFu) << 21) |
+           ((unsigned long long)((uint32_t)z & 0x1FFFFFu) << 42);
+}
+
+// "brick-coherent" hashing with double hashing BY WINDOW.  The 4x4x4 brick a voxel lies in picks a 64-slot
+// (1 KiB) window of the table, the voxel's position inside the brick picks the slot in the window, so the probes
+// of one stencil land in a handful of 128-B lines.  On a collision (the slot holds another brick's voxel) the
+// probe sequence moves to ANOTHER WINDOW (w + k * step, step odd => full cycle) and keeps the in-brick offset:
+// plain linear probing inside a window would walk the occupied runs that brick coherence creates (chains of
+// tens of dependent loads, each a DRAM round trip, for the empty-cell probes of every stencil).
+// Brick coordinates fit 19 bits, so the mixing uses the full-rate 24-bit multiplier (v_mul_u32_u24).
+struct BrickProbe {
+    uint32_t win, step, local;
+};
+
+__device__ inline BrickProbe brick_probe(int x, int y, int z) {
+    const uint32_t bx = (uint32_t)(x >> 2) & 0x7FFFFu, by = (uint32_t)(y >> 2) & 0x7FFFFu, bz = (uint32_t)(z >> 2) & 0x7FFFFu;
+    uint32_t h = __umul24(bx, 0x9E3779u) ^ (__umul24(by, 0x85EBCBu) + 0x7F4A7C15u) ^ __umul24(bz, 0xC2B2AFu);
+    h ^= h >> 15;
+    h = __umul24(h & 0xFFFFFFu, 0x2C1B3Du) ^ (h >> 9);
+    h ^= h >> 13;
+    BrickProbe p;
+    p.win = h;
+    p.step = (__umul24((h >> 7) & 0xFFFFFFu, 0x5BD1E9u) ^ (h << 11)) | 1u;
+    p.local = (uint32_t)(x & 3) | ((uint32_t)(y & 3) << 2) | ((uint32_t)(z & 3) << 4);
+    return p;
+}
+__device__ inline uint32_t brick_slot(const BrickProbe& p, uint32_t mask) { return ((p.win << 6) | p.local) & mask; }
+__device__ inline void brick_next(BrickProbe& p) { p.win += p.step; }
+
+// ivox3d.h:258-261: Pos2Grid = round(p * inv_res) per axis (std::round: half away from zero), in f32
+__device__ inline void pos2grid(float x, float y, float z, float inv_res, int& kx, int& ky, int& kz) {
+    kx = (int)roundf(x * inv_res);
+    ky = (int)roundf(y * inv_res);
+    kz = (int)roundf(z * inv_res);
+}
+
+}  // namespace lio

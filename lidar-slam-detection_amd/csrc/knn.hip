@@ -1,0 +1,385 @@
+// knn.hip -- stencil kNN on the voxel hash grid: IVox::GetClosestPoint(pt, out, 5, 5.0)
+// (/root/reference/slam/mapping/fastlio/include/ivox3d/ivox3d.h:139-171, ivox3d_node.hpp:107-127).
+//
+// Semantics: the 5 nearest of all points stored in the stencil voxels with d^2 < 5.0 (the per-voxel
+// nth_element of the reference is a pruning step that does not change that set), element order = the canonical
+// total order (d2, x, y, z) that oracle/lio_oracle.cpp uses; fewer than 5 -> all of them; none -> the output
+// is left untouched (stale neighbours survive, ivox3d.h:152-154).
+//
+// Mapping to the machine: G = 32 lanes (half a wave) work on one query.
+//   1. each lane probes one stencil cell (one 16-B slot load; 19 of 32 lanes busy for NEARBY18, three rounds
+//      for the 75-cell start-up stencil), hits are compacted into LDS with ballot + popcount and prefix-summed
+//      with lane shuffles;
+//   2. the candidate points of all hit voxels form one virtual array; lane l visits entries l, l+G, ... with four
+//      16-B loads in flight, and keeps its own sorted top-5 as 64-bit keys (d2 bits << 32 | pool index) through a
+//      branch-light compare-exchange chain;
+//   3. six rounds of a group-wide 64-bit min (shuffles) pop the global top-5 and the best loser.
+// Exact d2 ties between different points are the only case where (d2, index) order can differ from the
+// canonical (d2, x, y, z) order.  They are detected on the sorted top-6 and the query is queued for
+// knn_exact_kernel, which redoes it with the full comparison (rare: ~1e-6 per query on float data).
+#include "hashgrid.h"
+#include "lio_common.h"
+
+namespace lio {
+
+constexpr int kG = 32;                 // lanes per query
+constexpr int kGPB = 256 / kG;         // queries per workgroup
+constexpr unsigned long long kNoKey = 0xFFFFFFFFFFFFFFFFull;
+
+__device__ inline void body_to_world(const PoseArgs& P, const float4 pb, float4& pw) {
+    // laserMapping.cpp:831-836: p_global = rot * (offset_R_L_I * p_body + offset_T_L_I) + pos, in double, stored float.
+    // Quaternion * vector as Eigen's _transformVector: uv = 2 (q.vec x v); v + w uv + q.vec x uv
+    const double vx = (double)pb.x, vy = (double)pb.y, vz = (double)pb.z;
+    double ux = P.ql[1] * vz - P.ql[2] * vy, uy = P.ql[2] * vx - P.ql[0] * vz, uz = P.ql[0] * vy - P.ql[1] * vx;
+    ux += ux; uy += uy; uz += uz;
+    double cx = P.ql[1] * uz - P.ql[2] * uy, cy = P.ql[2] * ux - P.ql[0] * uz, cz = P.ql[0] * uy - P.ql[1] * ux;
+    const double ix = ((vx + P.ql[3] * ux) + cx) + P.tl[0];
+    const double iy = ((vy + P.ql[3] * uy) + cy) + P.tl[1];
+    const double iz = ((vz + P.ql[3] * uz) + cz) + P.tl[2];
+    ux = P.qw[1] * iz - P.qw[2] * iy; uy = P.qw[2] * ix - P.qw[0] * iz; uz = P.qw[0] * iy - P.qw[1] * ix;
+    ux += ux; uy += uy; uz += uz;
+    cx = P.qw[1] * uz - P.qw[2] * uy; cy = P.qw[2] * ux - P.qw[0] * uz; cz = P.qw[0] * uy - P.qw[1] * ux;
+    pw.x = (float)(((ix + P.qw[3] * ux) + cx) + P.tw[0]);
+    pw.y = (float)(((iy + P.qw[3] * uy) + cy) + P.tw[1]);
+    pw.z = (float)(((iz + P.qw[3] * uz) + cz) + P.tw[2]);
+    pw.w = pb.w;
+}
+
+struct GroupLds {
+    uint32_t v_ptr[kMaxStencil];
+    uint32_t v_beg[kMaxStencil + 1];  // exclusive prefix of the voxel counts; v_beg[nhit] = total
+};
+
+// probe the stencil of the group's query; on return the hit voxels are compacted in g (ptr, begin offsets) and
+// the total candidate count is returned.  All lanes of the wave must call this (ballots inside).
+template <int KM>
+__device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_t mask, const StencilArgs& st, bool active, int kx, int ky,
+                                         int kz, int gl, int lane, unsigned long long gmask, GroupLds& g, uint32_t& nhit_out) {
+    uint4 raw[KM];
+    BrickProbe bp[KM];
+    unsigned long long want[KM];
+#pragma unroll
+    for (int k = 0; k < KM; k++) {  // all home-slot loads first: independent, in flight together
+        const int s = k * kG + gl;
+        want[k] = kEmptyKey;
+        raw[k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+        bp[k] = BrickProbe{0u, 1u, 0u};
+        if (active && s < st.n) {
+            const int cx = kx + st.off[s][0], cy = ky + st.off[s][1], cz = kz + st.off[s][2];
+            want[k] = pack_key(cx, cy, cz);
+            bp[k] = brick_probe(cx, cy, cz);
+            raw[k] = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[k], mask)]);
+        }
+    }
+    uint32_t nhit = 0, total = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < KM; k++) {
+        uint32_t ptr = 0, cnt = 0;
+        if (want[k] != kEmptyKey) {
+            uint4 r = raw[k];
+            for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {  // double hashing by window; load factor <= 0.5
+                const unsigned long long kk = ((unsigned long long)r.y << 32) | r.x;
+                if (kk == want[k]) { ptr = r.z; cnt = r.w; break; }
+                if (kk == kEmptyKey) break;
+                brick_next(bp[k]);
+                r = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[k], mask)]);
+            }
+        }
+        const bool hit = cnt > 0;
+        const unsigned long long m = __ballot(hit) & gmask;
+        // exclusive prefix of cnt over the group's lanes (shuffle scan), offset by what earlier rounds found
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int off = 1; off < kG; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off, kG);
+            if (gl >= off) inc += t;
+        }
+        if (hit) {
+            const uint32_t at = nhit + __popcll(m & below);
+            g.v_ptr[at] = ptr;
+            g.v_beg[at] = total + inc - cnt;
+        }
+        nhit += __popcll(m);
+        total += __shfl(inc, kG - 1, kG);
+    }
+    if (gl == 0) g.v_beg[nhit] = total;
+    nhit_out = nhit;
+    return total;
+}
+
+__device__ inline unsigned long long umin64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+__device__ inline unsigned long long umax64(unsigned long long a, unsigned long long b) { return a < b ? b : a; }
+
+__device__ inline unsigned long long group_min64(unsigned long long v) {
+#pragma unroll
+    for (int off = kG / 2; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, kG), hi = __shfl_xor((uint32_t)(v >> 32), off, kG);
+        v = umin64(v, ((unsigned long long)hi << 32) | lo);
+    }
+    return v;
+}
+
+// MODE 0: queries are body-frame ds points of a scan (transformed here, world point stored);
+// MODE 1: queries are world-frame points (diagnostic lio_map_knn).
+template <int KM, int MODE>
+__global__ void __launch_bounds__(256) knn_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                  float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
+                                                  uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
+                                                  float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
+                                                  MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
+    __shared__ GroupLds lds[kGPB];
+    const int tid = threadIdx.x;
+    const int grp = tid / kG, gl = tid % kG;
+    const int lane = tid & 63;
+    GroupLds& g = lds[grp];
+    const uint32_t n = sd ? sd->n_ds : n_host;
+    const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
+    unsigned long long visited = 0;
+
+    for (uint32_t q0 = blockIdx.x * kGPB; q0 < n; q0 += gridDim.x * kGPB) {
+        const uint32_t q = q0 + grp;
+        const bool active = q < n;
+        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) {
+            const float4 pq = queries[q];
+            if (MODE == 0) {
+                body_to_world(pose, pq, pw);
+                if (gl == 0) world_out[q] = pw;
+            } else {
+                pw = pq;
+            }
+        }
+        int kx = 0, ky = 0, kz = 0;
+        pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
+        uint32_t nhit = 0;
+        const uint32_t total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
+        __syncthreads();
+        // every lane keeps its own ascending top-5 of keys (d2 bits << 32 | pool index)
+        unsigned long long e0 = kNoKey, e1 = kNoKey, e2 = kNoKey, e3 = kNoKey, e4 = kNoKey;
+        uint32_t inrange = 0;
+        uint32_t j = 0;
+        constexpr int U = 4;
+        for (uint32_t c0 = gl; c0 < total; c0 += U * kG) {
+            uint32_t id[U];
+            float4 p[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = c0 + u * kG;
+                id[u] = kNoIdx;
+                if (c < total) {
+                    while (c >= g.v_beg[j + 1]) j++;
+                    id[u] = g.v_ptr[j] + (c - g.v_beg[j]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (id[u] != kNoIdx) p[u] = pool[id[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (id[u] == kNoIdx) continue;
+                const float dx = p[u].x - pw.x, dy = p[u].y - pw.y, dz = p[u].z - pw.z;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;  // ivox3d_node.hpp:12-15 (f32 squaredNorm)
+                if (d2 < 5.0f) {
+                    inrange++;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | id[u];
+                    if (key < e4) {  // d2 >= 0: float order == unsigned order of the bits
+                        e4 = umax64(e3, key);
+                        unsigned long long t = umin64(e3, key);
+                        e3 = umax64(e2, t);
+                        t = umin64(e2, t);
+                        e2 = umax64(e1, t);
+                        t = umin64(e1, t);
+                        e1 = umax64(e0, t);
+                        e0 = umin64(e0, t);
+                    }
+                }
+            }
+        }
+        visited += total > (uint32_t)gl ? (total - gl + kG - 1) / kG : 0;
+#pragma unroll
+        for (int off = kG / 2; off > 0; off >>= 1) inrange += __shfl_xor(inrange, off, kG);
+        // merge: six rounds of group-wide min pop the global top-5 (lane r keeps winner r) and the best loser
+        unsigned long long win = kNoKey, prev = kNoKey;
+        bool tie = false;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const unsigned long long best = group_min64(e0);
+            if (r > 0 && best != kNoKey && (uint32_t)(best >> 32) == (uint32_t)(prev >> 32)) tie = true;  // equal d2, different point
+            prev = best;
+            if (gl == r) win = best;
+            if (best != kNoKey && e0 == best) { e0 = e1; e1 = e2; e2 = e3; e3 = e4; e4 = kNoKey; }
+        }
+        // results.  No in-range candidate at all: GetClosestPoint returns before touching the output
+        // (ivox3d.h:152-154), the cached neighbours of an earlier scan survive.
+        if (active && inrange > 0) {
+            if (gl < 5) nn_pts[(size_t)gl * nn_stride + q] = (win != kNoKey) ? pool[(uint32_t)win] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gl == 0) {
+                nn_cnt[q] = inrange < 5 ? (int32_t)inrange : 5;
+                if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
+            }
+        }
+        __syncthreads();
+    }
+    // statistics: one atomic per workgroup, spread over 64 counters that each own a 128-B line (same-line
+    // atomics serialise in one L2 channel at ~10 ns apiece -- 9k of them used to cost more than the kernel)
+    __shared__ unsigned long long vred[256 / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) visited += __shfl_xor(visited, off);
+    if (lane == 0) vred[tid >> 6] = visited;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long v = (vred[0] + vred[1]) + (vred[2] + vred[3]);
+        if (v) atomicAdd(&md->knn_cand[(blockIdx.x & 63) * 16], v);
+    }
+}
+
+// ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
+struct Cand {
+    float d2;
+    uint32_t id;
+};
+
+// strict total order (d2, x, y, z); the coordinate comparison only runs on exact d2 ties
+__device__ __noinline__ bool cand_tie_less(const Cand& a, const Cand& b, const float4* __restrict__ pool) {
+    if (a.id == b.id) return false;
+    if (a.id == kNoIdx || b.id == kNoIdx) return a.id < b.id;
+    const float4 pa = pool[a.id], pb = pool[b.id];
+    if (pa.x != pb.x) return pa.x < pb.x;
+    if (pa.y != pb.y) return pa.y < pb.y;
+    if (pa.z != pb.z) return pa.z < pb.z;
+    return a.id < b.id;
+}
+__device__ inline bool cand_less(const Cand& a, const Cand& b, const float4* __restrict__ pool) {
+    if (a.d2 != b.d2) return a.d2 < b.d2;
+    return cand_tie_less(a, b, pool);
+}
+
+template <int KM, int MODE>
+__global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                        float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
+                                                        float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
+                                                        const uint32_t* __restrict__ tie_list) {
+    __shared__ GroupLds lds[kGPB];
+    const int tid = threadIdx.x;
+    const int grp = tid / kG, gl = tid % kG;
+    const int lane = tid & 63;
+    GroupLds& g = lds[grp];
+    const uint32_t n = *n_tie;
+    const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
+    for (uint32_t w0 = blockIdx.x * kGPB; w0 < n; w0 += gridDim.x * kGPB) {
+        const uint32_t w = w0 + grp;
+        const bool active = w < n;
+        const uint32_t q = active ? tie_list[w] : 0u;
+        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) {
+            const float4 pq = queries[q];
+            if (MODE == 0) body_to_world(pose, pq, pw);
+            else pw = pq;
+        }
+        int kx = 0, ky = 0, kz = 0;
+        pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
+        uint32_t nhit = 0;
+        const uint32_t total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
+        __syncthreads();
+        Cand e[5];
+        for (int k = 0; k < 5; k++) e[k] = {INFINITY, kNoIdx};
+        uint32_t j = 0;
+        for (uint32_t c = gl; c < total; c += kG) {
+            while (c >= g.v_beg[j + 1]) j++;
+            const uint32_t id = g.v_ptr[j] + (c - g.v_beg[j]);
+            const float4 p = pool[id];
+            const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < 5.0f) {
+                Cand cd = {d2, id};
+                if (cand_less(cd, e[4], pool)) {
+                    e[4] = cd;
+                    for (int k = 4; k > 0; k--)
+                        if (cand_less(e[k], e[k - 1], pool)) { const Cand t = e[k - 1]; e[k - 1] = e[k]; e[k] = t; }
+                }
+            }
+        }
+        uint32_t win = kNoIdx;
+        for (int r = 0; r < 5; r++) {
+            Cand best = e[0];
+            for (int off = kG / 2; off > 0; off >>= 1) {
+                Cand o;
+                o.d2 = __shfl_xor(best.d2, off, kG);
+                o.id = __shfl_xor(best.id, off, kG);
+                if (cand_less(o, best, pool)) best = o;
+            }
+            if (gl == r) win = best.id;
+            if (best.id != kNoIdx && e[0].id == best.id) {
+                for (int k = 0; k < 4; k++) e[k] = e[k + 1];
+                e[4] = {INFINITY, kNoIdx};
+            }
+        }
+        if (active && gl < 5 && win != kNoIdx) nn_pts[(size_t)gl * nn_stride + q] = pool[win];
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+static int launch_knn(lio_map* m, hipStream_t st, const PoseArgs& pose, const float4* q, uint32_t n_host, const ScanDev* sd,
+                      float4* world_out, float4* nn_pts, uint32_t nn_stride, int32_t* nn_cnt, uint32_t n_bound, uint32_t* n_tie,
+                      uint32_t* tie_list) {
+    uint32_t blocks = (n_bound + kGPB - 1) / kGPB;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks == 0) return LIO_OK;
+    if (m->stencil.n <= kG) {
+        hipLaunchKernelGGL((knn_kernel<1, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q,
+                           n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, m->dev, n_tie, tie_list);
+    } else {
+        hipLaunchKernelGGL((knn_kernel<(kMaxStencil + kG - 1) / kG, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res,
+                           m->stencil, pose, q, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, m->dev, n_tie, tie_list);
+    }
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+template <int MODE>
+static int launch_knn_exact(lio_map* m, hipStream_t st, const PoseArgs& pose, const float4* q, float4* nn_pts, uint32_t nn_stride,
+                            uint32_t n_tie_host, const uint32_t* n_tie, const uint32_t* tie_list) {
+    uint32_t blocks = (n_tie_host + kGPB - 1) / kGPB;
+    if (blocks == 0) return LIO_OK;
+    if (blocks > 4096) blocks = 4096;
+    if (m->stencil.n <= kG) {
+        hipLaunchKernelGGL((knn_exact_kernel<1, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q,
+                           nn_pts, nn_stride, n_tie, tie_list);
+    } else {
+        hipLaunchKernelGGL((knn_exact_kernel<(kMaxStencil + kG - 1) / kG, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool,
+                           m->inv_res, m->stencil, pose, q, nn_pts, nn_stride, n_tie, tie_list);
+    }
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {
+    (void)redo_knn;
+    const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
+    kt_begin(s, 0);
+    const int rc = launch_knn<0>(m, s->stream, pose, s->ds_body, 0, s->dev, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt, bound,
+                                 &s->dev->n_tie, s->tie_list);
+    kt_end(s, 0);
+    return rc;
+}
+
+// redo the queued tie queries of the last map_knn_plane exactly (n_tie_host = count read back by the caller)
+int map_knn_exact(lio_map* m, lio_scan* s, const PoseArgs& pose, uint32_t n_tie_host) {
+    return launch_knn_exact<0>(m, s->stream, pose, s->ds_body, s->nn_pts, s->max_ds, n_tie_host, &s->dev->n_tie_done, s->tie_list);
+}
+
+int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt, uint32_t* d_tie /* [0] = count, [1..] = list */) {
+    PoseArgs pose;
+    memset(&pose, 0, sizeof(pose));
+    int rc = launch_knn<1>(m, m->stream, pose, d_q, n, nullptr, nullptr, d_out, n, d_cnt, n, d_tie, d_tie + 1);
+    if (rc != LIO_OK) return rc;
+    uint32_t nt = 0;
+    LIO_HIP_TRY(hipMemcpyAsync(&nt, d_tie, 4, hipMemcpyDeviceToHost, m->stream));
+    LIO_HIP_TRY(hipStreamSynchronize(m->stream));
+    if (nt) rc = launch_knn_exact<1>(m, m->stream, pose, d_q, d_out, n, nt, d_tie, d_tie + 1);
+    return rc;
+}
+
+}  // namespace lio

@@ -42,7 +42,7 @@ struct MapDev {
     uint32_t err;                    // bit0: table full, bit1: pool full
     uint32_t n_add;                  // staging count for map_incremental
     uint32_t pad;
-    unsigned long long knn_cand[64];  // sharded by workgroup: one hot counter would serialise ~13 ns per wave
+    unsigned long long knn_cand[64 * 16];  // 64 shards, one 128-B line each (same-line atomics serialise in one L2 channel)
 };
 
 // rigid transforms handed to kernels by value (doubles, as the reference computes them)
@@ -59,6 +59,8 @@ struct ScanDev {
     uint32_t bbox_max[3];  // init 0
     uint32_t n_valid;      // finite input points
     uint32_t n_long;       // voxels queued for the wave-per-voxel centroid kernel
+    uint32_t n_tie;        // kNN queries whose top-6 held an exact d2 tie (queued for the exact redo)
+    uint32_t n_tie_done;   // snapshot of n_tie taken by finalize_kernel
     uint32_t n_ds;         // feats_down_size
     uint32_t n_ds_prev;    // size of the neighbour cache before this scan (Nearest_Points.resize semantics)
     uint32_t passthrough;  // PCL int32 overflow guard hit: output = input
@@ -89,6 +91,7 @@ struct lio_map {
     float4* pool;
     lio::MapDev* dev;
     lio::MapDev* host_dev;  // pinned mirror
+    unsigned long long* tile_sum;  // prebuilt-map layout scan scratch
     uint32_t* slot_of_point;  // batch insert scratch
     uint64_t slot_of_point_cap;
     float4* stage;            // staging for host->device inserts and map_incremental
@@ -123,6 +126,7 @@ struct lio_scan {
     uint32_t* blockcnt;  // head counts per tile
     uint32_t* hpos;      // first sorted position of every occupied voxel
     uint32_t* longlist;  // voxels with long runs
+    uint32_t* tie_list;  // query indices with exact d2 ties
     float4* sorted;      // raw points gathered into (voxel, input index) order
     double* partial;     // per-block partial sums
     uint32_t partial_blocks;
@@ -143,7 +147,8 @@ void kt_begin(lio_scan* s, int which);
 void kt_end(lio_scan* s, int which);
 int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t n, const uint32_t* d_n, double travel);
 int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);
-int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt);
+int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt, uint32_t* d_tie);
+int map_knn_exact(lio_map* m, lio_scan* s, const PoseArgs& pose, uint32_t n_tie_host);
 int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);
 int p2plane_degeneracy(lio_scan* s);
 int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float map_leaf, int ekf_inited, int seed_all);

@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, i
 
 constexpr int kFinThreads = 1024;
 
-__global__ void __launch_bounds__(kFinThreads) finalize_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial,
+__global__ void __launch_bounds__(kFinThreads) finalize_kernel(ScanDev* __restrict__ sd, const double* __restrict__ partial,
                                                                const MapDev* __restrict__ md, lio_normal_eq* __restrict__ out) {
     __shared__ double acc[kAcc];
     const int tid = threadIdx.x;
@@ -299,9 +299,13 @@ __global__ void __launch_bounds__(kFinThreads) finalize_kernel(const ScanDev* __
         out->sum_abs_res = acc[27];
         out->n_eff = (uint32_t)(acc[28] + 0.5);
         out->n_ds = n;
+        out->n_tie = sd->n_tie;  // hand the tie queue to the host and re-arm it
+        out->pad = 0;
+        sd->n_tie_done = sd->n_tie;
+        sd->n_tie = 0;
         unsigned long long kc = 0ull;
         if (md)
-            for (int k = 0; k < 64; k++) kc += md->knn_cand[k];
+            for (int k = 0; k < 64; k++) kc += md->knn_cand[k * 16];
         out->n_knn_candidates_lo = (uint32_t)kc;
         out->n_knn_candidates_hi = (uint32_t)(kc >> 32);
     }

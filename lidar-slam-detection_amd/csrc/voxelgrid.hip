@@ -364,9 +364,19 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __r
     if (v >= nv) return;
     const uint32_t a = hpos[v];
     const uint32_t b = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;  // invalid (non-finite) points sort behind every voxel
-    if (b - a >= kLongRun) {
-        longlist[atomicAdd(&sd->n_long, 1u)] = v;
-        return;
+    // queue the long runs: one atomic per wave (ballot + popcount), not one per voxel
+    const bool is_long = b - a >= kLongRun;
+    const unsigned long long lm = __ballot(is_long);
+    if (lm) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)lm) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&sd->n_long, (uint32_t)__popcll(lm));
+        base = __shfl(base, leader);
+        if (is_long) {
+            longlist[base + __popcll(lm & ((1ull << lane) - 1ull))] = v;
+            return;
+        }
     }
     float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
     for (uint32_t j = a; j < b; j += 4) {
@@ -433,7 +443,7 @@ int vg_downsample(lio_scan* s, float leaf) {
         hipLaunchKernelGGL(scan_set_nds_kernel, 1, 1, 0, st, s->dev, 0u);
         return LIO_OK;
     }
-    const uint32_t g1 = nblocks < 64 ? nblocks : 64;
+    const uint32_t g1 = nblocks < 48 ? nblocks : 48;  // 7 same-line atomics per workgroup: keep the workgroups few
     hipLaunchKernelGGL(vg_bbox_kernel, g1, kThreads, 0, st, s->raw, n, s->dev);
     hipLaunchKernelGGL(vg_keys_kernel, (n + kThreads - 1) / kThreads < 512 ? (n + kThreads - 1) / kThreads : 512, kThreads, 0, st, s->raw, n, inv,
                        s->dev, s->keys_a, s->vals_a);

@@ -17,11 +17,11 @@ LIO_OK, LIO_E_INVALID, LIO_E_CAPACITY, LIO_E_DEVICE, LIO_E_STATE = 0, -1, -2, -3
 SYMBOLS = [
     "lio_last_error", "lio_device_count", "lio_map_bytes",
     "lio_map_create", "lio_map_destroy", "lio_map_set_stencil", "lio_map_insert", "lio_map_insert_device", "lio_map_stats",
-    "lio_map_dump", "lio_map_knn",
+    "lio_map_dump", "lio_map_knn", "lio_map_knn_candidates",
     "lio_scan_create", "lio_scan_destroy", "lio_scan_reset", "lio_scan_upload", "lio_scan_set_device", "lio_scan_voxel_downsample", "lio_scan_set_ds",
     "lio_scan_num_ds", "lio_scan_download_ds", "lio_scan_download_world", "lio_scan_download_match",
     "lio_p2plane_linearize", "lio_scan_force_degeneracy", "lio_p2plane_rows", "lio_map_incremental", "lio_map_seed",
-    "lio_engine_create", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
+    "lio_engine_create", "lio_engine_create_shared", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
     "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
     "lio_engine_enable_timing", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
@@ -32,7 +32,8 @@ SYMBOLS = [
 class NormalEq(C.Structure):
     _fields_ = [("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6), ("nnT", C.c_double * 9), ("eigvec", C.c_double * 9),
                 ("eigval", C.c_double * 3), ("contri", C.c_double * 3), ("strong", C.c_double * 3), ("sum_abs_res", C.c_double),
-                ("n_eff", C.c_uint32), ("n_ds", C.c_uint32), ("n_knn_candidates_lo", C.c_uint32), ("n_knn_candidates_hi", C.c_uint32)]
+                ("n_eff", C.c_uint32), ("n_ds", C.c_uint32), ("n_knn_candidates_lo", C.c_uint32), ("n_knn_candidates_hi", C.c_uint32),
+                ("n_tie", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class PassLog(C.Structure):
@@ -81,6 +82,7 @@ def lib():
     sig("lio_map_insert_device", cint, vp, vp, u64, dbl)
     sig("lio_map_stats", cint, vp, C.POINTER(u64), C.POINTER(u64))
     sig("lio_map_dump", C.c_int64, vp, f32p, u64)
+    sig("lio_map_knn_candidates", u64, vp)
     sig("lio_map_knn", cint, vp, f32p, u32, f32p, i32p)
     sig("lio_scan_create", vp, cint, u32, u32)
     sig("lio_scan_destroy", None, vp)
@@ -99,6 +101,7 @@ def lib():
     sig("lio_map_incremental", cint, vp, vp, f64p, f64p, flt, cint, dbl)
     sig("lio_map_seed", cint, vp, vp, f64p, f64p, dbl)
     sig("lio_engine_create", vp, cint, flt, cint, u64, u64, u32, u32)
+    sig("lio_engine_create_shared", vp, vp, u32, u32)
     sig("lio_engine_destroy", None, vp)
     sig("lio_engine_map", vp, vp)
     sig("lio_engine_scan", vp, vp)

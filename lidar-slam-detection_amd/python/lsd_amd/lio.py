@@ -87,6 +87,10 @@ class Map:
     def nbytes(self):
         return int(lib().lio_map_bytes(self.h))
 
+    @property
+    def knn_candidates(self):
+        return int(lib().lio_map_knn_candidates(self.h))
+
     def dump(self):
         n = self.num_points
         out = np.zeros((max(n, 1), 4), np.float32)
@@ -179,7 +183,7 @@ def linearize(map_, scan, state, redo_knn=True):
     check(lib().lio_p2plane_linearize(map_.h, scan.h, ptr(pose, C.c_double), ptr(ext, C.c_double), int(redo_knn), C.byref(ne)), "linearize")
     return dict(n_eff=int(ne.n_eff), n_ds=int(ne.n_ds), JtJ=np.array(ne.JtJ).reshape(6, 6), Jtr=np.array(ne.Jtr),
                 nnT=np.array(ne.nnT).reshape(3, 3), eigvec=np.array(ne.eigvec).reshape(3, 3), eigval=np.array(ne.eigval),
-                contri=np.array(ne.contri), strong=np.array(ne.strong), sum_abs_res=float(ne.sum_abs_res),
+                contri=np.array(ne.contri), strong=np.array(ne.strong), sum_abs_res=float(ne.sum_abs_res), n_tie=int(ne.n_tie),
                 knn_candidates=(int(ne.n_knn_candidates_hi) << 32) | int(ne.n_knn_candidates_lo))
 
 
@@ -192,8 +196,13 @@ def map_incremental(map_, scan, state, map_leaf=0.5, ekf_inited=True, travel=0.0
 class Engine:
     """The FastLIO per-scan engine (state + covariance + map + scan buffers) on one GPU."""
 
-    def __init__(self, resolution=0.5, stencil=75, max_points=2_000_000, max_voxels=1_000_000, max_raw=262144, max_ds=100000, device=0):
-        self.h = lib().lio_engine_create(device, resolution, stencil, max_points, max_voxels, max_raw, max_ds)
+    def __init__(self, resolution=0.5, stencil=75, max_points=2_000_000, max_voxels=1_000_000, max_raw=262144, max_ds=100000, device=0,
+                 shared_map=None):
+        if shared_map is not None:  # read-only engine on somebody else's map (several may run concurrently)
+            self._shared = shared_map
+            self.h = lib().lio_engine_create_shared(shared_map.h, max_raw, max_ds)
+        else:
+            self.h = lib().lio_engine_create(device, resolution, stencil, max_points, max_voxels, max_raw, max_ds)
         if not self.h:
             raise capi.LioError("lio_engine_create failed: " + lib().lio_last_error().decode())
         self.map = Map(_borrow=lib().lio_engine_map(self.h))

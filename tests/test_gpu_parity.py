@@ -83,6 +83,34 @@ def test_map_insert_and_knn_exact(oracle_mod, small_world):
         assert np.array_equal(ref_pts[..., :3].view(np.uint32), got_pts[..., :3].view(np.uint32)), st
 
 
+def test_knn_exact_ties_and_duplicates(oracle_mod):
+    """dyadic lattice map + mid-cell queries: many exact d2 ties between different points (and exact duplicates);
+    the (d2, x, y, z) canonical order must still be reproduced bit for bit (tie queue -> knn_exact_kernel)"""
+    _dev()
+    from lsd_amd import lio
+
+    ax = np.arange(-16, 16) * 0.25
+    X, Y, Z = np.meshgrid(ax, ax, np.arange(-4, 4) * 0.25, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel(), np.zeros(X.size)], 1).astype(np.float32)
+    pts = np.concatenate([pts, pts[::5]])  # exact duplicates
+    rng = np.random.default_rng(9)
+    qi = rng.integers(-14, 14, (4000, 3))
+    q = np.concatenate([qi * 0.25 + 0.125, np.zeros((4000, 1))], 1).astype(np.float32)
+    q[:, 2] = np.clip(q[:, 2], -0.875, 0.625)
+    q[::3, 0] += 0.0625  # some queries off-centre in x only: ties in (y, z) remain
+    iv = oracle_mod.IVox(res=0.5, stencil=19)
+    iv.add(pts)
+    m = lio.Map(resolution=0.5, stencil=19, max_points=200_000, max_voxels=100_000)
+    m.add(pts)
+    for st in (19, 75):
+        iv.set_stencil(st)
+        m.set_stencil(st)
+        ref_pts, ref_cnt, _ = iv.knn(q)
+        got_pts, got_cnt = m.knn(q)
+        assert np.array_equal(ref_cnt, got_cnt)
+        assert np.array_equal(ref_pts[..., :3].view(np.uint32), got_pts[..., :3].view(np.uint32))
+
+
 def _make_pair(oracle_mod, small_world, stencil=19):
     from lsd_amd import lio, synth
 
