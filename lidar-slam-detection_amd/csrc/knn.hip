@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) knn_kernel(const Slot* __restrict__ table
             for (int u = 0; u < U; u++) {
                 if (id[u] == kNoIdx) continue;
                 const float dx = p[u].x - pw.x, dy = p[u].y - pw.y, dz = p[u].z - pw.z;
-                const float d2 = (dx * dx + dy * dy) + dz * dz;  // ivox3d_node.hpp:12-15 (f32 squaredNorm)
+                const float d2 = dx * dx + (dy * dy + dz * dz);  // ivox3d_node.hpp:12-15: Vector3f::squaredNorm() = Eigen's unrolled tree x0 + (x1 + x2)
                 if (d2 < 5.0f) {
                     inrange++;
                     const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | id[u];
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__
             const uint32_t id = g.v_ptr[j] + (c - g.v_beg[j]);
             const float4 p = pool[id];
             const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const float d2 = dx * dx + (dy * dy + dz * dz);
             if (d2 < 5.0f) {
                 Cand cd = {d2, id};
                 if (cand_less(cd, e[4], pool)) {

@@ -14,8 +14,9 @@
 //                     lambda_i - 0.1736^2 N_eff >= 250 does not already decide the test (see capi.hip).
 //   classify_kernel   map_incremental's need_add test + ballot/prefix-sum compaction of the points to insert.
 // Per-point f32 arithmetic is written as explicit sequential IEEE operations (compiled with
-// -ffp-contract=off) in the operation order of Eigen's ColPivHouseholderQR so that gates flip exactly where
-// the CPU restatement's do.
+// -ffp-contract=off) in the operation order of Eigen's ColPivHouseholderQR (scalar build: unrolled redux trees for the
+// fixed-size norms, column-oriented triangular solve) so that gates flip exactly where the reference's own
+// esti_plane does (pinned through oracle/_ref, see tests/test_oracle_vs_ref.py).
 #include "lio_common.h"
 
 namespace lio {
@@ -51,9 +52,8 @@ __device__ inline bool esti_plane_dev(const float4 pt[5], float threshold, float
     float maxnorm = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 5; r++) s = s + A[r][k] * A[r][k];
+        // m_qr.col(k).norm(): fixed size 5 -> Eigen's completely unrolled redux is the tree (x0 + x1) + (x2 + (x3 + x4))
+        const float s = (A[0][k] * A[0][k] + A[1][k] * A[1][k]) + (A[2][k] * A[2][k] + (A[3][k] * A[3][k] + A[4][k] * A[4][k]));
         normDir[k] = sqrtf(s);
         normUpd[k] = normDir[k];
         maxnorm = fmaxf(maxnorm, normDir[k]);
@@ -148,15 +148,16 @@ __device__ inline bool esti_plane_dev(const float4 pt[5], float threshold, float
             }
         }
     }
+    // triangularView<Upper>().solveInPlace(): Eigen's column-major vector solve is column oriented
+    // (x_i = b_i / a_ii, then b_r -= x_i * a_ri for the rows above)
     float xs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 2; i >= 0; i--) {
         if (i < nonzero) {
-            float s = b[i];
+            xs[i] = b[i] / A[i][i];
 #pragma unroll
-            for (int j = i + 1; j < 3; j++)
-                if (j < nonzero) s = s - A[i][j] * xs[j];
-            xs[i] = s / A[i][i];
+            for (int r = 0; r < 3; r++)
+                if (r < i) b[r] = b[r] - xs[i] * A[r][i];
         }
     }
     float nv[3] = {0.f, 0.f, 0.f};
@@ -168,7 +169,7 @@ __device__ inline bool esti_plane_dev(const float4 pt[5], float threshold, float
                 if (perm[i] == a) nv[a] = xs[i];
         }
     }
-    const float n = sqrtf((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
+    const float n = sqrtf(nv[0] * nv[0] + (nv[1] * nv[1] + nv[2] * nv[2]));  // normvec.norm(): fixed size 3 -> tree x0 + (x1 + x2)
     pabcd[0] = nv[0] / n;
     pabcd[1] = nv[1] / n;
     pabcd[2] = nv[2] / n;
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, i
             sel = false;
             if (esti_plane_dev(near, 0.1f, pabcd)) {
                 const float pd2 = ((pabcd[0] * pw.x + pabcd[1] * pw.y) + pabcd[2] * pw.z) + pabcd[3];
-                const double pbn = sqrt(((double)pb.x * pb.x + (double)pb.y * pb.y) + (double)pb.z * pb.z);
+                const double pbn = sqrt((double)pb.x * pb.x + ((double)pb.y * pb.y + (double)pb.z * pb.z));  // V3D::norm(): Eigen tree x0 + (x1 + x2)
                 // float s = 1 - 0.9 * fabs(pd2) / sqrt(p_body.norm()); if (s > 0.9)   (laserMapping.cpp:861-863)
                 const float sc = (float)(1 - 0.9 * fabs((double)pd2) / sqrt(pbn));
                 if ((double)sc > 0.9) {

@@ -147,8 +147,9 @@ inline bool cand_less(const Cand& a, const Cand& b) {  // canonical total order
     return a.p.z < b.p.z;
 }
 inline float dist2(const P4& a, const P4& b) {  // ivox3d_node.hpp:12-15
+    // (pt1.getVector3fMap() - pt2.getVector3fMap()).squaredNorm(): fixed size 3 -> Eigen's unrolled redux tree x0 + (x1 + x2)
     float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    return (dx * dx + dy * dy) + dz * dz;
+    return dx * dx + (dy * dy + dz * dz);
 }
 
 struct IVoxNode {
@@ -266,8 +267,9 @@ bool esti_plane(float pabcd[4], const P4* pt, float threshold) {
     float hcoef[C];
     float maxnorm = 0.f;
     for (int k = 0; k < C; k++) {
-        float s = 0.f;
-        for (int r = 0; r < R; r++) s = s + A[r][k] * A[r][k];
+        // m_qr.col(k).norm(): fixed size 5 -> Eigen's completely unrolled redux is a balanced tree
+        // (redux_novec_unroller splits [0,5) into [0,2) and [2,5), the latter into [2,3) and [3,5))
+        const float s = (A[0][k] * A[0][k] + A[1][k] * A[1][k]) + (A[2][k] * A[2][k] + (A[3][k] * A[3][k] + A[4][k] * A[4][k]));
         normDir[k] = sqrtf(s);
         normUpd[k] = normDir[k];
         maxnorm = fmaxf(maxnorm, normDir[k]);
@@ -347,15 +349,16 @@ bool esti_plane(float pabcd[4], const P4* pt, float threshold) {
             for (int r = k + 1; r < R; r++) b[r] = b[r] - (tau * A[r][k]) * t;
         }
     }
+    // triangularView<Upper>().solveInPlace: Eigen's column-major vector solve is column oriented --
+    // x_i = b_i / a_ii, then b_r -= x_i * a_ri for the rows above (not the row-oriented dot-product form)
     float xs[C] = {0.f, 0.f, 0.f};
     for (int i = nonzero - 1; i >= 0; i--) {
-        float s = b[i];
-        for (int j = i + 1; j < nonzero; j++) s = s - A[i][j] * xs[j];
-        xs[i] = s / A[i][i];
+        xs[i] = b[i] / A[i][i];
+        for (int r = 0; r < i; r++) b[r] = b[r] - xs[i] * A[r][i];
     }
     float nv[C] = {0.f, 0.f, 0.f};
     for (int i = 0; i < nonzero; i++) nv[perm[i]] = xs[i];
-    const float n = sqrtf((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
+    const float n = sqrtf(nv[0] * nv[0] + (nv[1] * nv[1] + nv[2] * nv[2]));  // normvec.norm(): fixed size 3 -> tree x0 + (x1 + x2)
     pabcd[0] = nv[0] / n;
     pabcd[1] = nv[1] / n;
     pabcd[2] = nv[2] / n;
@@ -776,7 +779,7 @@ struct Lio {
                 selected[i] = 0;
                 if (esti_plane(pabcd, near.data(), 0.1f)) {
                     const float pd2 = ((pabcd[0] * pw.x + pabcd[1] * pw.y) + pabcd[2] * pw.z) + pabcd[3];
-                    const double pbn = std::sqrt(((double)pb.x * pb.x + (double)pb.y * pb.y) + (double)pb.z * pb.z);
+                    const double pbn = std::sqrt((double)pb.x * pb.x + ((double)pb.y * pb.y + (double)pb.z * pb.z));  // V3D::norm(): tree x0 + (x1 + x2)
                     // float s = 1 - 0.9 * fabs(pd2) / sqrt(p_body.norm());  (evaluated in double, stored float)
                     const float sc = (float)(1 - 0.9 * std::fabs((double)pd2) / std::sqrt(pbn));
                     if ((double)sc > 0.9) {

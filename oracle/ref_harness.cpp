@@ -1,0 +1,79 @@
+// oracle/ref_harness.cpp -- compiles the reference's OWN code for the two numerically delicate pieces of the
+// path, from where it lies under /root/reference (nothing is copied into this repo), behind a C ABI:
+//   * esti_plane<float>       slam/mapping/fastlio/include/common_lib.h:236-268   (Eigen colPivHouseholderQr)
+//   * faster_lio::IVox        slam/mapping/fastlio/include/ivox3d/ivox3d.h, ivox3d_node.hpp, eigen_types.h
+//   * calc_dist               common_lib.h:231-234
+// Eigen is the copy vendored in the reference tree (slam/thirdparty/fast_gicp/thirdparty/Eigen).  PCL is not
+// installed: oracle/ref_shims/pcl/* define the three point structs and PointCloud the headers name, and
+// common/mapping_types.h (OpenCV, queues -- unrelated to this path) is skipped by pre-defining its include guard.
+// The IKFoM filter (needs Boost.PP / Boost.Bind) and PCL's VoxelGrid are NOT covered: see DESIGN.md.
+// TEST INFRASTRUCTURE ONLY: built into oracle/_ref/libref_harness.so, used by tests/ and tools/make_golden.py.
+#define __MAPPING_TYPES_H
+#include <deque>
+#include <string>
+struct ImuType { double t; };
+struct RTKType { double t; };
+#include <common_lib.h>
+#include <ivox3d/ivox3d.h>
+
+#include <cstring>
+
+using IVoxT = faster_lio::IVox<3, faster_lio::IVoxNodeType::DEFAULT, PointType>;
+
+static PointType mk(const float* p) {
+    PointType q;
+    q.x = p[0]; q.y = p[1]; q.z = p[2]; q.intensity = p[3];
+    return q;
+}
+
+extern "C" {
+
+int ref_esti_plane(const float* five_xyzi, float threshold, float* pabcd) {
+    PointVector pts;
+    for (int j = 0; j < 5; j++) pts.push_back(mk(five_xyzi + 4 * j));
+    Matrix<float, 4, 1> r;
+    const bool ok = esti_plane<float>(r, pts, threshold);
+    for (int i = 0; i < 4; i++) pabcd[i] = r(i);
+    return ok ? 1 : 0;
+}
+
+float ref_calc_dist(const float* a, const float* b) { return calc_dist(mk(a), mk(b)); }
+
+void* ref_ivox_create(float res, int stencil, uint64_t capacity, double max_distance) {
+    IVoxT::Options o;
+    o.resolution_ = res;
+    o.capacity_ = (size_t)capacity;
+    o.max_distance_ = max_distance;
+    o.nearby_type_ = stencil == 1 ? IVoxT::NearbyType::CENTER : stencil == 7 ? IVoxT::NearbyType::NEARBY6 : stencil == 19 ? IVoxT::NearbyType::NEARBY18
+                     : stencil == 27 ? IVoxT::NearbyType::NEARBY26 : IVoxT::NearbyType::NEARBY74;
+    return new IVoxT(o);
+}
+void ref_ivox_destroy(void* h) { delete static_cast<IVoxT*>(h); }
+void ref_ivox_set_stencil(void* h, int stencil) {
+    static_cast<IVoxT*>(h)->SetNearByType(stencil == 1 ? IVoxT::NearbyType::CENTER : stencil == 7 ? IVoxT::NearbyType::NEARBY6
+                                          : stencil == 19 ? IVoxT::NearbyType::NEARBY18 : stencil == 27 ? IVoxT::NearbyType::NEARBY26
+                                                                                                        : IVoxT::NearbyType::NEARBY74);
+}
+void ref_ivox_add(void* h, const float* pts, int n, double travel) {
+    PointVector v;
+    v.reserve(n);
+    for (int i = 0; i < n; i++) v.push_back(mk(pts + 4 * (size_t)i));
+    static_cast<IVoxT*>(h)->AddPoints(v, travel);
+}
+uint64_t ref_ivox_num_voxels(void* h) { return static_cast<IVoxT*>(h)->NumValidGrids(); }
+// GetClosestPoint(pt, out, 5, 5.0) per query; out_pts n x 5 x 4, out_cnt n.  `out` starts empty for every query.
+void ref_ivox_knn(void* h, const float* q, int n, float* out_pts, int* out_cnt) {
+    IVoxT* iv = static_cast<IVoxT*>(h);
+    for (int i = 0; i < n; i++) {
+        PointVector near;
+        iv->GetClosestPoint(mk(q + 4 * (size_t)i), near, 5, 5.0);
+        out_cnt[i] = (int)near.size();
+        for (int k = 0; k < 5; k++) {
+            float* o = out_pts + ((size_t)i * 5 + k) * 4;
+            if (k < (int)near.size()) { o[0] = near[k].x; o[1] = near[k].y; o[2] = near[k].z; o[3] = near[k].intensity; }
+            else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+        }
+    }
+}
+
+}  // extern "C"

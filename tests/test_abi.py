@@ -1,0 +1,81 @@
+"""The C-ABI library loads and exports every symbol include/lio_hip.h declares; struct layouts agree between the
+header (compiled by gcc) and the ctypes mirror.  No compute calls: runs without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lio_hip.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lio_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported():
+    from lsd_amd import capi
+
+    L = capi.lib()
+    names = _declared()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in lio_hip.h but not exported by liblio_hip.so"
+    assert sorted(capi.SYMBOLS) == names, set(names) ^ set(capi.SYMBOLS)
+
+
+def test_struct_layouts_match_header():
+    from lsd_amd import capi
+
+    src = """
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "lio_hip.h"
+    int main(void) {
+        printf("%zu %zu %zu %zu %zu\\n", sizeof(lio_normal_eq), sizeof(lio_pass_log), sizeof(lio_timings), sizeof(lio_kernel_times),
+               offsetof(lio_normal_eq, n_eff));
+        return 0;
+    }"""
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = [int(x) for x in out]
+    assert sizes[0] == C.sizeof(capi.NormalEq)
+    assert sizes[1] == C.sizeof(capi.PassLog)
+    assert sizes[2] == C.sizeof(capi.Timings)
+    assert sizes[3] == C.sizeof(capi.KernelTimes)
+    assert sizes[4] == capi.NormalEq.n_eff.offset
+
+
+def test_no_cpu_fallback_without_a_device():
+    """on a box without a GPU every handle constructor must fail loudly (never a silent CPU path)"""
+    from lsd_amd import capi, lio
+
+    if capi.lib().lio_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(capi.LioError):
+        lio.Map()
+    with pytest.raises(capi.LioError):
+        lio.Scan()
+    with pytest.raises(capi.LioError):
+        lio.Engine()
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under the package may import, link or call it"""
+    pkg = os.path.join(ROOT, "lidar-slam-detection_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                bad = re.findall(r'#include\s*[<"][^>"]*oracle|^\s*(?:import|from)\s+oracle|liblio_oracle|\borc_[a-z]+\s*\(|libref_harness', txt, re.M)
+                assert not bad, (os.path.join(dp, f), bad)

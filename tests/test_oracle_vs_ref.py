@@ -1,0 +1,104 @@
+"""Pins the CPU oracle against the reference's OWN code (oracle/_ref/libref_harness.so = esti_plane and iVox
+compiled from /root/reference by `make -C oracle ref`).  Bit-exact for esti_plane; neighbour sets and voxel
+bookkeeping for iVox.  Skipped only where the harness has not been built (it travels to the GPU box prebuilt)."""
+import numpy as np
+import pytest
+
+import ref as refmod
+
+pytestmark = pytest.mark.skipif(not refmod.available(), reason="oracle/_ref/libref_harness.so not built (needs /root/reference)")
+
+
+def _plane_sets(rng, n):
+    """5-point neighbourhoods: noisy planes of random orientation/offset, plus generic and degenerate sets"""
+    out = []
+    for i in range(n):
+        kind = i % 5
+        nrm = rng.normal(size=3)
+        nrm /= np.linalg.norm(nrm)
+        c = rng.uniform(-80, 80, 3)
+        u = np.cross(nrm, rng.normal(size=3))
+        u /= np.linalg.norm(u)
+        v = np.cross(nrm, u)
+        ab = rng.uniform(-0.6, 0.6, (5, 2))
+        sig = [0.0, 0.005, 0.02, 0.08, 0.3][kind]
+        pts = c + ab[:, :1] * u + ab[:, 1:] * v + rng.normal(0, sig, (5, 1)) * nrm
+        if i % 37 == 0:
+            pts[3] = pts[2]  # duplicate point
+        if i % 41 == 0:
+            pts = c + ab[:, :1] * u  # collinear: rank deficient
+        out.append(np.concatenate([pts, np.zeros((5, 1))], 1).astype(np.float32))
+    return out
+
+
+def test_esti_plane_bit_exact(oracle_mod):
+    rng = np.random.default_rng(0)
+    n_ok = 0
+    for pts in _plane_sets(rng, 4000):
+        ok_r, p_r = refmod.esti_plane(pts)
+        ok_o, p_o = oracle_mod.esti_plane(pts)
+        both_finite = np.all(np.isfinite(p_r)) and np.all(np.isfinite(p_o))
+        assert ok_r == ok_o
+        if both_finite:
+            assert np.array_equal(p_r.view(np.uint32), p_o.view(np.uint32)), (pts, p_r, p_o)
+        n_ok += ok_r
+    assert 500 < n_ok < 3900  # both gate outcomes are exercised
+
+
+def test_ivox_knn_sets(oracle_mod):
+    rng = np.random.default_rng(1)
+    pts = np.concatenate([rng.uniform(-6, 6, (30000, 2)), rng.normal(0, 0.05, (30000, 1)), rng.uniform(0, 255, (30000, 1))], 1).astype(np.float32)
+    wall = np.concatenate([rng.uniform(-6, 6, (8000, 1)), np.full((8000, 1), 3.0) + rng.normal(0, 0.03, (8000, 1)), rng.uniform(0, 3, (8000, 1)),
+                           rng.uniform(0, 255, (8000, 1))], 1).astype(np.float32)
+    pts = np.concatenate([pts, wall])
+    q = pts[rng.choice(len(pts), 3000, replace=False)].copy()
+    q[:, :3] += rng.normal(0, 0.15, (len(q), 3)).astype(np.float32)
+    q[:50, 2] += 40.0  # nothing nearby
+    q[50:100, 2] += 1.2  # only a few candidates in range of the stencil
+    for stencil in (19, 75, 7, 27, 1):
+        r = refmod.IVox(stencil=stencil)
+        o = oracle_mod.IVox(stencil=stencil)
+        r.add(pts[:20000], 0.0)
+        r.add(pts[20000:], 3.0)
+        o.add(pts[:20000], 0.0)
+        o.add(pts[20000:], 3.0)
+        assert r.num_voxels == o.num_voxels
+        nn_r, cnt_r = r.knn(q)
+        nn_o, cnt_o, _ = o.knn(q)
+        assert np.array_equal(cnt_r, cnt_o), stencil
+        nn_r = refmod.canonical(nn_r, cnt_r, q)
+        assert np.array_equal(nn_r[..., :3].view(np.uint32), nn_o[..., :3].view(np.uint32)), stencil
+        # the reference's one ordering promise: element 0 is the nearest (ivox3d.h:163)
+        raw, _ = r.knn(q)
+        has = cnt_r > 0
+        assert np.array_equal(raw[has, 0, :3].view(np.uint32), nn_o[has, 0, :3].view(np.uint32))
+
+
+def test_ivox_lru_eviction_bookkeeping(oracle_mod):
+    """capacity / max_distance eviction (ivox3d.h:251-254): same voxel count after every batch"""
+    rng = np.random.default_rng(2)
+    r = refmod.IVox(stencil=19, capacity=300, max_distance=10.0)
+    o = oracle_mod.IVox(stencil=19, capacity=300, max_distance=10.0)
+    travel = 0.0
+    for step in range(40):
+        c = np.array([step * 1.5, 0.0, 0.0])
+        pts = np.concatenate([c + rng.uniform(-4, 4, (400, 3)) * [1, 1, 0.1], rng.uniform(0, 255, (400, 1))], 1).astype(np.float32)
+        travel += 1.5
+        r.add(pts, travel)
+        o.add(pts, travel)
+        assert r.num_voxels == o.num_voxels, step
+    q = np.concatenate([np.array([[50.0, 0, 0]]) + rng.uniform(-3, 3, (200, 3)) * [1, 1, 0.05], np.zeros((200, 1))], 1).astype(np.float32)
+    nn_r, cnt_r = r.knn(q)
+    nn_o, cnt_o, _ = o.knn(q)
+    assert np.array_equal(cnt_r, cnt_o)
+    assert np.array_equal(refmod.canonical(nn_r, cnt_r, q)[..., :3].view(np.uint32), nn_o[..., :3].view(np.uint32))
+
+
+def test_calc_dist(oracle_mod):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        a = rng.uniform(-100, 100, 4).astype(np.float32)
+        b = rng.uniform(-100, 100, 4).astype(np.float32)
+        d = (a[:3] - b[:3]).astype(np.float32)
+        want = np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+        assert np.float32(refmod.calc_dist(a, b)) == want

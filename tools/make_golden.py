@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz: small frozen input/output vectors for the LIO hot path.
+
+Run in the build container (needs /root/reference for the pinned pieces):
+    make -C oracle all ref && python tools/make_golden.py
+
+Provenance of every expected output is recorded in the file ("source" field):
+  * esti_plane.npz, ivox_knn.npz ...... the REFERENCE'S OWN CODE (oracle/_ref/libref_harness.so = esti_plane and
+                                        faster_lio::IVox compiled from /root/reference, scalar Eigen build)
+  * voxelgrid.npz, linearize.npz, update.npz ... the CPU oracle (oracle/lio_oracle.cpp), whose esti_plane and iVox
+                                        are themselves checked bit-for-bit against the files above; PCL VoxelGrid
+                                        and the IKFoM update cannot be built here and stay oracle-defined.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "lidar-slam-detection_amd", "python"), os.path.join(ROOT, "tests")]
+import oracle  # noqa: E402
+import ref as refmod  # noqa: E402
+from lsd_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    if not refmod.available():
+        raise SystemExit("oracle/_ref/libref_harness.so missing: run `make -C oracle ref` where /root/reference is mounted")
+    from test_oracle_vs_ref import _plane_sets
+
+    # 1. esti_plane: reference code
+    rng = np.random.default_rng(42)
+    sets = np.stack(_plane_sets(rng, 600))
+    ok = np.zeros(len(sets), np.uint8)
+    pabcd = np.zeros((len(sets), 4), np.float32)
+    for i, p in enumerate(sets):
+        o, r = refmod.esti_plane(p)
+        ok[i], pabcd[i] = o, r
+    np.savez_compressed(os.path.join(OUT, "esti_plane.npz"), points=sets, ok=ok, pabcd=pabcd,
+                        source="reference common_lib.h:236-268 via oracle/_ref (scalar Eigen)")
+
+    # 2. iVox kNN: reference code
+    scene = synth.Scene(half=30.0, n_boxes=8, seed=5)
+    map_pts = scene.sample_surface(8000, seed=6, sigma=0.01)
+    q = map_pts[rng.choice(len(map_pts), 400, replace=False)].copy()
+    q[:, :3] += rng.normal(0, 0.15, (400, 3)).astype(np.float32)
+    q[:10, 2] += 30.0
+    res = {}
+    for st in (19, 75):
+        iv = refmod.IVox(stencil=st)
+        iv.add(map_pts[:5000], 0.0)
+        iv.add(map_pts[5000:], 1.0)
+        nn, cnt = iv.knn(q)
+        res[f"nn{st}"] = refmod.canonical(nn, cnt, q)[..., :3]
+        res[f"cnt{st}"] = cnt
+        res[f"voxels{st}"] = iv.num_voxels
+    np.savez_compressed(os.path.join(OUT, "ivox_knn.npz"), map=map_pts, queries=q, **res,
+                        source="reference ivox3d.h:139-171,231-256 via oracle/_ref; lists sorted by (d2,x,y,z)")
+
+    # 3. voxel grid (PCL semantics restated; unpinned)
+    raw, _ = synth.make_scan(scene, [0.5, -1.0, 1.7], synth.quat_from_rotvec([0, 0, 0.4]), seed=8, n_beams=32, n_az=300)
+    raw = raw.copy()
+    raw[::97, 1] = np.nan
+    ds = oracle.voxel_downsample(raw, 0.5)
+    np.savez_compressed(os.path.join(OUT, "voxelgrid.npz"), raw=raw, leaf=np.float32(0.5), ds=ds,
+                        source="oracle restatement of PCL 1.9.1 VoxelGrid::applyFilter (PCL not in the reference tree: unpinned)")
+
+    # 4/5. one linearisation and one iterated update
+    true_pos, true_q = np.array([0.5, -1.0, 1.7]), synth.quat_from_rotvec([0, 0, 0.4])
+    gp, gq = synth.perturb_pose(true_pos, true_q, seed=9, max_t=0.15, max_deg=1.0)
+    state = synth.state_from_pose(gp, gq)
+    big_map = scene.sample_surface(60000, seed=10, sigma=0.01)
+    o = oracle.Lio(stencil=19, capacity=1 << 40, threads=4)
+    o.map_add(big_map)
+    o.set_state(state)
+    o.set_cov(oracle.init_cov())
+    o.set_flags(ekf_inited=True, first_scan=False)
+    o.set_ds(ds)
+    lin = o.linearize(converge=True)
+    np.savez_compressed(os.path.join(OUT, "linearize.npz"), map=big_map, ds=ds, state=state, selected=lin["selected"],
+                        normvec=lin["normvec"], nn_cnt=lin["nn_cnt"], nn=lin["nn"][..., :3], JtJ=lin["JtJ"], Jtr=lin["Jtr"],
+                        sum_abs_res=lin["sum_abs_res"], n_eff=lin["n_eff"],
+                        source="oracle h_share_model_geometric (laserMapping.cpp:813-932); its kNN and esti_plane are pinned to the reference")
+    o2 = oracle.Lio(stencil=19, capacity=1 << 40, threads=4)
+    o2.map_add(big_map)
+    o2.set_state(state)
+    o2.set_cov(oracle.init_cov())
+    o2.set_flags(ekf_inited=True, first_scan=False)
+    o2.set_ds(ds)
+    logs = o2.update()
+    np.savez_compressed(os.path.join(OUT, "update.npz"), state0=state, P0=oracle.init_cov(), state1=o2.get_state(), P1=o2.get_cov(),
+                        knn=np.array([l["knn"] for l in logs]), n_eff=np.array([l["n_eff"] for l in logs]),
+                        dx=np.stack([l["dx"] for l in logs]), true_pos=true_pos, true_q=true_q,
+                        source="oracle update_iterated_dyn_share_modified (esekfom.hpp:1619-1931); IKFoM needs Boost: unpinned")
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
