@@ -129,8 +129,11 @@ typedef struct lio_normal_eq {
  * 6-column Jacobian blocks.  pose_wi = (t_wi[3], q_wi[4]);  ext_il = (t_il[3], q_il[4]). */
 int lio_p2plane_linearize(lio_map*, lio_scan*, const double pose_wi[7], const double ext_il[7], int redo_knn,
                           lio_normal_eq* out);
-/* evaluate contri/strong on every pass even when the eigenvalue bound makes them moot (tests, diagnostics) */
-int lio_scan_force_degeneracy(lio_scan*, int on);
+/* how lio_p2plane_linearize treats the degeneracy sums: 0 = auto (evaluated only when the eigenvalue bound does not
+ * decide, default), 1 = always, 2 = never (the caller evaluates them itself, e.g. after a cross-GPU reduction) */
+int lio_scan_set_degeneracy_mode(lio_scan*, int mode);
+/* the degeneracy sums of the last linearize against the given eigenvectors (columns of a row-major 3x3) */
+int lio_p2plane_degeneracy(lio_scan*, const double V[9], double contri[3], double strong[3]);
 /* rows of the last linearize for the (rare) N_eff < 23 branch of the filter
  * (esekfom.hpp:1715-1744): h_x[n_eff*6] (first six columns) and h[n_eff], selected points in index order */
 int lio_p2plane_rows(lio_scan*, const double pose_wi[7], const double ext_il[7], double* h_x6, double* h, uint32_t cap_rows);
@@ -189,6 +192,15 @@ typedef struct lio_timings {
 } lio_timings;
 int lio_engine_timings(lio_engine*, lio_timings* out);
 int lio_engine_enable_timing(lio_engine*, int on);
+/* Joint registration across GPUs (BASELINE.json config 5: sub-maps one per GPU, all-gather of the per-shard
+ * J^T J / J^T r sums).  When a hook is set the engine calls it after every device linearisation with its LOCAL sums and
+ * continues with whatever the hook leaves in the buffer (the GLOBAL sums, identical on every rank):
+ *   first call,  n = 29: buf[0..20] J^T J upper triangle (row-major), buf[21..26] J^T r, buf[27] sum|r|, buf[28] n_eff
+ *   second call, n = 6 (only when the degeneracy bound on the GLOBAL eigenvalues does not decide): contri[3], strong[3]
+ * Every rank then runs the same 23-DoF update on the same numbers.  With a hook the N_eff < 23 branch of the filter
+ * uses the information form (rows live on different GPUs). */
+typedef void (*lio_reduce_fn)(void* ctx, double* buf, int n);
+int lio_engine_set_reduce_hook(lio_engine*, lio_reduce_fn fn, void* ctx);
 /* on: process_scan skips map_incremental -- scan-to-map registration against a prebuilt static map
  * (BASELINE.json configs 2 and 4); off (default): the reference's mapping behaviour */
 int lio_engine_set_static_map(lio_engine*, int on);

@@ -517,9 +517,10 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
     // When that bound is >= 250 for all three eigenvalues the test cannot fire and the per-point pass is skipped
     // (contri/strong are then reported as +inf = "not evaluated, provably not degenerate").
     eig3_sym(out->nnT, out->eigval, out->eigvec);
-    bool need = s->force_degeneracy != 0;
+    bool need = s->force_degeneracy == 1;
     for (int i = 0; i < 3; i++)
         if (!(out->eigval[i] * (1.0 - 1e-5) - 0.030138 * (double)out->n_eff >= 250.0 + 1e-3)) need = true;
+    if (s->force_degeneracy == 2) need = false;
     if (!need || out->n_eff == 0) {
         for (int i = 0; i < 3; i++) { out->contri[i] = INFINITY; out->strong[i] = INFINITY; }
         return LIO_OK;
@@ -533,9 +534,22 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
     return LIO_OK;
 }
 
-int lio_scan_force_degeneracy(lio_scan* s, int on) {
-    if (!s) return LIO_E_INVALID;
-    s->force_degeneracy = on != 0;
+int lio_scan_set_degeneracy_mode(lio_scan* s, int mode) {
+    if (!s || mode < 0 || mode > 2) return LIO_E_INVALID;
+    s->force_degeneracy = mode;
+    return LIO_OK;
+}
+
+int lio_p2plane_degeneracy(lio_scan* s, const double V[9], double contri[3], double strong[3]) {
+    if (!s || !V || !contri || !strong) return LIO_E_INVALID;
+    hipSetDevice(s->device);
+    LIO_HIP_TRY(hipMemcpyAsync(s->d_result->eigvec, V, sizeof(double) * 9, hipMemcpyHostToDevice, s->stream));
+    LIO_HIP_TRY(hipMemsetAsync(s->d_result->contri, 0, sizeof(double) * 6, s->stream));
+    const int rc = p2plane_degeneracy(s);
+    if (rc != LIO_OK) return rc;
+    LIO_HIP_TRY(hipMemcpyAsync(s->h_result->contri, s->d_result->contri, sizeof(double) * 6, hipMemcpyDeviceToHost, s->stream));
+    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < 3; i++) { contri[i] = s->h_result->contri[i]; strong[i] = s->h_result->strong[i]; }
     return LIO_OK;
 }
 

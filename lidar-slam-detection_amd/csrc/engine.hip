@@ -31,6 +31,8 @@ struct lio_engine {
     hipEvent_t ev[8];
     lio_timings tm;
     std::vector<double> rows6, hvec;
+    lio_reduce_fn reduce = nullptr;  // cross-GPU reduction of the normal equations (joint registration)
+    void* reduce_ctx = nullptr;
 };
 
 namespace {
@@ -71,6 +73,39 @@ int measure_pass(lio_engine* e, const LioState& x, bool converge, Measurement& m
     e->tm.n_pass++;
     if (converge) e->tm.n_knn_pass++;
     if (rc != LIO_OK) return rc;
+    if (e->reduce) {
+        // joint registration: this rank's sums -> global sums (fixed rank order inside the hook), then the
+        // degeneracy logic on the GLOBAL eigen-structure
+        double buf[29];
+        int t = 0;
+        for (int a = 0; a < 6; a++)
+            for (int c = a; c < 6; c++) buf[t++] = ne.JtJ[a * 6 + c];
+        for (int a = 0; a < 6; a++) buf[21 + a] = ne.Jtr[a];
+        buf[27] = ne.sum_abs_res;
+        buf[28] = (double)ne.n_eff;
+        e->reduce(e->reduce_ctx, buf, 29);
+        t = 0;
+        for (int a = 0; a < 6; a++)
+            for (int c = a; c < 6; c++) { ne.JtJ[a * 6 + c] = buf[t]; ne.JtJ[c * 6 + a] = buf[t]; t++; }
+        for (int a = 0; a < 6; a++) ne.Jtr[a] = buf[21 + a];
+        ne.sum_abs_res = buf[27];
+        ne.n_eff = (uint32_t)(buf[28] + 0.5);
+        for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 3; c++) ne.nnT[a * 3 + c] = ne.JtJ[a * 6 + c];
+        eig3_sym(ne.nnT, ne.eigval, ne.eigvec);
+        bool need = false;
+        for (int i = 0; i < 3; i++)
+            if (!(ne.eigval[i] * (1.0 - 1e-5) - 0.030138 * (double)ne.n_eff >= 250.0 + 1e-3)) need = true;
+        if (need && ne.n_eff > 0) {
+            double cs[6];
+            const int r2 = lio_p2plane_degeneracy(e->scan, ne.eigvec, cs, cs + 3);
+            if (r2 != LIO_OK) return r2;
+            e->reduce(e->reduce_ctx, cs, 6);
+            for (int i = 0; i < 3; i++) { ne.contri[i] = cs[i]; ne.strong[i] = cs[3 + i]; }
+        } else {
+            for (int i = 0; i < 3; i++) { ne.contri[i] = INFINITY; ne.strong[i] = INFINITY; }
+        }
+    }
     e->tm.n_ds = (int)ne.n_ds;
     e->tm.n_eff_last = (int)ne.n_eff;
     e->tm.knn_candidates = ((uint64_t)ne.n_knn_candidates_hi << 32) | ne.n_knn_candidates_lo;
@@ -137,7 +172,7 @@ int measure_pass(lio_engine* e, const LioState& x, bool converge, Measurement& m
             memcpy(m.HTh, v, sizeof(v));
         }
     }
-    if (m.n_rows < kDof) {  // dense branch of the filter needs the rows themselves
+    if (m.n_rows < kDof && !e->reduce) {  // dense branch of the filter needs the rows themselves
         e->rows6.resize((size_t)m.n_rows * 6);
         e->hvec.resize(m.n_rows);
         const int r = lio_p2plane_rows(e->scan, pose, ext, e->rows6.data(), e->hvec.data(), (uint32_t)m.n_rows);
@@ -267,6 +302,14 @@ int lio_engine_pass_log(lio_engine* e, int i, lio_pass_log* out) {
 }
 
 int lio_engine_enable_timing(lio_engine* e, int on) { if (!e) return LIO_E_INVALID; e->timing = on != 0; return LIO_OK; }
+int lio_engine_set_reduce_hook(lio_engine* e, lio_reduce_fn fn, void* ctx) {
+    if (!e) return LIO_E_INVALID;
+    e->reduce = fn;
+    e->reduce_ctx = ctx;
+    // with a hook the degeneracy sums are evaluated here, after the reduction, never inside linearize
+    return lio_scan_set_degeneracy_mode(e->scan, fn ? 2 : 0);
+}
+
 int lio_engine_set_static_map(lio_engine* e, int on) {
     if (!e) return LIO_E_INVALID;
     if (!e->own_map && !on) { set_error("an engine on a shared map is read-only"); return LIO_E_STATE; }

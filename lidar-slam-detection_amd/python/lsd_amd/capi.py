@@ -20,7 +20,7 @@ SYMBOLS = [
     "lio_map_dump", "lio_map_knn", "lio_map_knn_candidates",
     "lio_scan_create", "lio_scan_destroy", "lio_scan_reset", "lio_scan_upload", "lio_scan_set_device", "lio_scan_voxel_downsample", "lio_scan_set_ds",
     "lio_scan_num_ds", "lio_scan_download_ds", "lio_scan_download_world", "lio_scan_download_match",
-    "lio_p2plane_linearize", "lio_scan_force_degeneracy", "lio_p2plane_rows", "lio_map_incremental", "lio_map_seed",
+    "lio_p2plane_linearize", "lio_scan_set_degeneracy_mode", "lio_p2plane_degeneracy", "lio_engine_set_reduce_hook", "lio_p2plane_rows", "lio_map_incremental", "lio_map_seed",
     "lio_engine_create", "lio_engine_create_shared", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
     "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
@@ -52,6 +52,8 @@ class KernelTimes(C.Structure):
     _fields_ = [("knn_us", C.c_double), ("linearize_us", C.c_double), ("finalize_us", C.c_double), ("knn_launches", C.c_uint32),
                 ("linearize_launches", C.c_uint32), ("finalize_launches", C.c_uint32), ("pad", C.c_uint32)]
 
+
+REDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 _lib = None
 
@@ -96,7 +98,9 @@ def lib():
     sig("lio_scan_download_world", cint, vp, f32p, u32)
     sig("lio_scan_download_match", cint, vp, u8p, f32p, i32p, f32p)
     sig("lio_p2plane_linearize", cint, vp, vp, f64p, f64p, cint, C.POINTER(NormalEq))
-    sig("lio_scan_force_degeneracy", cint, vp, cint)
+    sig("lio_scan_set_degeneracy_mode", cint, vp, cint)
+    sig("lio_p2plane_degeneracy", cint, vp, f64p, f64p, f64p)
+    sig("lio_engine_set_reduce_hook", cint, vp, REDUCE_FN, vp)
     sig("lio_p2plane_rows", cint, vp, f64p, f64p, f64p, f64p, u32)
     sig("lio_map_incremental", cint, vp, vp, f64p, f64p, flt, cint, dbl)
     sig("lio_map_seed", cint, vp, vp, f64p, f64p, dbl)

@@ -154,8 +154,15 @@ class Scan:
         n = check(lib().lio_scan_download_world(self.h, ptr(out, C.c_float), self.max_ds), "download world")
         return out[:n].copy()
 
-    def force_degeneracy(self, on=True):
-        check(lib().lio_scan_force_degeneracy(self.h, int(on)))
+    def set_degeneracy_mode(self, mode):
+        """0 auto (bound-gated), 1 always evaluate, 2 never"""
+        check(lib().lio_scan_set_degeneracy_mode(self.h, int(mode)))
+
+    def degeneracy(self, V):
+        V = f64(V).reshape(3, 3)
+        c, s_ = np.zeros(3), np.zeros(3)
+        check(lib().lio_p2plane_degeneracy(self.h, ptr(V, C.c_double), ptr(c, C.c_double), ptr(s_, C.c_double)), "degeneracy")
+        return c, s_
 
     def enable_kernel_timing(self, on=True):
         check(lib().lio_scan_enable_kernel_timing(self.h, int(on)))
@@ -271,6 +278,20 @@ class Engine:
 
     def enable_timing(self, on=True):
         check(lib().lio_engine_enable_timing(self.h, int(on)))
+
+    def set_reduce_hook(self, fn):
+        """fn(buf: np.ndarray) replaces the engine's local normal-equation sums by the global ones IN PLACE
+        (see lsd_amd.dist.NormalEqAllGather); None removes the hook"""
+        if fn is None:
+            self._hook = None
+            check(lib().lio_engine_set_reduce_hook(self.h, capi.REDUCE_FN(0), None))
+            return
+
+        def _cb(_ctx, p, n):
+            fn(np.ctypeslib.as_array(p, shape=(n,)))
+
+        self._hook = capi.REDUCE_FN(_cb)  # keep the trampoline alive
+        check(lib().lio_engine_set_reduce_hook(self.h, self._hook, None))
 
     def set_static_map(self, on=True):
         check(lib().lio_engine_set_static_map(self.h, int(on)))
