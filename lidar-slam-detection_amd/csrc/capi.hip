@@ -306,13 +306,17 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
          dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->tie_list, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
          dev_alloc(&s->dev, 1, &s->bytes) && dev_alloc(&s->d_result, 1, &s->bytes);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&s->host_dev), sizeof(ScanDev)) == hipSuccess &&
-         hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(lio_normal_eq)) == hipSuccess;
+         hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(lio_normal_eq), hipHostMallocMapped) == hipSuccess &&
+         hipHostMalloc(reinterpret_cast<void**>(&s->host_nds), 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer(reinterpret_cast<void**>(&s->host_nds_dev), s->host_nds, 0) == hipSuccess &&
+         hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_result_dev), s->h_result, 0) == hipSuccess;
     if (ok) {
         // point_selected_surf starts all-true (laserMapping.cpp:1046), Nearest_Points empty
         ok = hipMemsetAsync(s->selected, 1, max_ds, s->stream) == hipSuccess && hipMemsetAsync(s->nn_cnt, 0, (size_t)max_ds * 4, s->stream) == hipSuccess &&
              hipMemsetAsync(s->nn_pts, 0, (size_t)max_ds * 5 * sizeof(float4), s->stream) == hipSuccess &&
              hipMemsetAsync(s->normvec, 0, (size_t)max_ds * sizeof(float4), s->stream) == hipSuccess &&
-             hipMemsetAsync(s->dev, 0, sizeof(ScanDev), s->stream) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess;
+             hipMemsetAsync(s->dev, 0, sizeof(ScanDev), s->stream) == hipSuccess &&
+             hipMemsetAsync(s->dev->bbox_min, 0xFF, 12, s->stream) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess;
     }
     if (!ok) {
         if (!g_err[0]) set_error("lio_scan_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -332,6 +336,7 @@ void lio_scan_destroy(lio_scan* s) {
     hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->tie_list); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
     if (s->host_dev) hipHostFree(s->host_dev);
     if (s->h_result) hipHostFree(s->h_result);
+    if (s->host_nds) hipHostFree(s->host_nds);
     if (s->kt) {
         if (s->kt->created)
             for (int w = 0; w < 3; w++)
@@ -419,10 +424,14 @@ int lio_scan_voxel_downsample(lio_scan* s, float leaf, int sync, uint32_t* n_ds)
     if (rc != LIO_OK) return rc;
     s->have_ds = -1;
     if (sync) {
-        rc = scan_sync_dev(s);
-        if (rc != LIO_OK) return rc;
-        s->have_ds = (int)s->host_dev->n_ds;
-        if (n_ds) *n_ds = s->host_dev->n_ds;
+        LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->host_nds[1] & 1u) {
+            set_error("downsampled scan exceeds max_ds %u", s->max_ds);
+            hipMemsetAsync(&s->dev->err, 0, 4, s->stream);
+            return LIO_E_CAPACITY;
+        }
+        s->have_ds = (int)s->host_nds[0];
+        if (n_ds) *n_ds = s->host_nds[0];
     }
     return LIO_OK;
 }
@@ -496,7 +505,7 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
     }
     rc = p2plane_reduce(m, s, pose, redo_knn);
     if (rc != LIO_OK) return rc;
-    LIO_HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(lio_normal_eq), hipMemcpyDeviceToHost, s->stream));
+    // finalize_kernel stores the record straight into mapped pinned host memory: no copy launch, one sync
     LIO_HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->h_result->n_tie) {  // exact d2 ties among some top-6: redo those queries with the canonical comparison
         const uint32_t nt = s->h_result->n_tie;
@@ -504,7 +513,6 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
         if (rc != LIO_OK) return rc;
         rc = p2plane_reduce(m, s, pose, redo_knn);
         if (rc != LIO_OK) return rc;
-        LIO_HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(lio_normal_eq), hipMemcpyDeviceToHost, s->stream));
         LIO_HIP_TRY(hipStreamSynchronize(s->stream));
         s->h_result->n_tie = nt;
     }
@@ -526,6 +534,7 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
         return LIO_OK;
     }
     LIO_HIP_TRY(hipMemcpyAsync(s->d_result->eigvec, out->eigvec, sizeof(double) * 9, hipMemcpyHostToDevice, s->stream));
+    LIO_HIP_TRY(hipMemsetAsync(s->d_result->contri, 0, sizeof(double) * 6, s->stream));
     rc = p2plane_degeneracy(s);
     if (rc != LIO_OK) return rc;
     LIO_HIP_TRY(hipMemcpyAsync(s->h_result->contri, s->d_result->contri, sizeof(double) * 6, hipMemcpyDeviceToHost, s->stream));

@@ -10,8 +10,9 @@
 //   1. each lane probes one stencil cell (one 16-B slot load; 19 of 32 lanes busy for NEARBY18, three rounds
 //      for the 75-cell start-up stencil), hits are compacted into LDS with ballot + popcount and prefix-summed
 //      with lane shuffles;
-//   2. the candidate points of all hit voxels form one virtual array; lane l visits entries l, l+G, ... with four
-//      16-B loads in flight, and keeps its own sorted top-5 as 64-bit keys (d2 bits << 32 | pool index) through a
+//   2. voxel-major sweep: four voxel descriptors at a time come back from LDS as two ds_read_b128, lane l takes
+//      point l (l+32, ...) of each of the four voxels -- four coalesced 16-B loads in flight, addresses are
+//      base + lane -- and keeps its own sorted top-5 as 64-bit keys (d2 bits << 32 | pool index) through a
 //      branch-light compare-exchange chain;
 //   3. six rounds of a group-wide 64-bit min (shuffles) pop the global top-5 and the best loser.
 // Exact d2 ties between different points are the only case where (d2, index) order can differ from the
@@ -45,12 +46,14 @@ __device__ inline void body_to_world(const PoseArgs& P, const float4 pb, float4&
     pw.w = pb.w;
 }
 
-struct GroupLds {
-    uint32_t v_ptr[kMaxStencil];
-    uint32_t v_beg[kMaxStencil + 1];  // exclusive prefix of the voxel counts; v_beg[nhit] = total
+// the occupied voxels of one query's stencil, compacted: 16-B aligned so that four descriptors come back from one
+// ds_read_b128; entries nhit .. nhit+3 are zero-filled (count 0) so that batches of four need no bounds test
+struct __attribute__((aligned(16))) GroupLds {
+    uint32_t v_ptr[kMaxStencil + 5];
+    uint32_t v_cnt[kMaxStencil + 5];
 };
 
-// probe the stencil of the group's query; on return the hit voxels are compacted in g (ptr, begin offsets) and
+// probe the stencil of the group's query; on return the hit voxels are compacted in g (ptr, cnt) and
 // the total candidate count is returned.  All lanes of the wave must call this (ballots inside).
 template <int KM>
 __device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_t mask, const StencilArgs& st, bool active, int kx, int ky,
@@ -88,22 +91,18 @@ __device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_
         }
         const bool hit = cnt > 0;
         const unsigned long long m = __ballot(hit) & gmask;
-        // exclusive prefix of cnt over the group's lanes (shuffle scan), offset by what earlier rounds found
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int off = 1; off < kG; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off, kG);
-            if (gl >= off) inc += t;
-        }
         if (hit) {
             const uint32_t at = nhit + __popcll(m & below);
             g.v_ptr[at] = ptr;
-            g.v_beg[at] = total + inc - cnt;
+            g.v_cnt[at] = cnt;
         }
         nhit += __popcll(m);
-        total += __shfl(inc, kG - 1, kG);
+        uint32_t sum = cnt;
+#pragma unroll
+        for (int off = kG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kG);
+        total += sum;
     }
-    if (gl == 0) g.v_beg[nhit] = total;
+    if (gl < 4) { g.v_ptr[nhit + gl] = 0; g.v_cnt[nhit + gl] = 0; }
     nhit_out = nhit;
     return total;
 }
@@ -158,45 +157,42 @@ __global__ void __launch_bounds__(256) knn_kernel(const Slot* __restrict__ table
         // every lane keeps its own ascending top-5 of keys (d2 bits << 32 | pool index)
         unsigned long long e0 = kNoKey, e1 = kNoKey, e2 = kNoKey, e3 = kNoKey, e4 = kNoKey;
         uint32_t inrange = 0;
-        uint32_t j = 0;
-        constexpr int U = 4;
-        for (uint32_t c0 = gl; c0 < total; c0 += U * kG) {
-            uint32_t id[U];
-            float4 p[U];
+        // voxel-major sweep: four voxel descriptors per ds_read_b128 pair, lane l takes point l (l+32, ...) of each --
+        // addresses are base + lane (no per-candidate search), four 16-B loads in flight per lane
+        for (uint32_t s0 = 0; s0 < nhit; s0 += 4) {
+            const uint4 vp = *reinterpret_cast<const uint4*>(&g.v_ptr[s0]);
+            const uint4 vc = *reinterpret_cast<const uint4*>(&g.v_cnt[s0]);
+            const uint32_t ptr4[4] = {vp.x, vp.y, vp.z, vp.w};
+            const uint32_t cnt4[4] = {vc.x, vc.y, vc.z, vc.w};
+            const uint32_t cmax = max(max(vc.x, vc.y), max(vc.z, vc.w));
+            for (uint32_t i0 = gl; i0 < cmax + gl; i0 += kG) {
+                float4 p[4];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t c = c0 + u * kG;
-                id[u] = kNoIdx;
-                if (c < total) {
-                    while (c >= g.v_beg[j + 1]) j++;
-                    id[u] = g.v_ptr[j] + (c - g.v_beg[j]);
-                }
-            }
+                for (int u = 0; u < 4; u++)
+                    if (i0 < cnt4[u]) p[u] = pool[ptr4[u] + i0];
 #pragma unroll
-            for (int u = 0; u < U; u++)
-                if (id[u] != kNoIdx) p[u] = pool[id[u]];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (id[u] == kNoIdx) continue;
-                const float dx = p[u].x - pw.x, dy = p[u].y - pw.y, dz = p[u].z - pw.z;
-                const float d2 = dx * dx + (dy * dy + dz * dz);  // ivox3d_node.hpp:12-15: Vector3f::squaredNorm() = Eigen's unrolled tree x0 + (x1 + x2)
-                if (d2 < 5.0f) {
-                    inrange++;
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | id[u];
-                    if (key < e4) {  // d2 >= 0: float order == unsigned order of the bits
-                        e4 = umax64(e3, key);
-                        unsigned long long t = umin64(e3, key);
-                        e3 = umax64(e2, t);
-                        t = umin64(e2, t);
-                        e2 = umax64(e1, t);
-                        t = umin64(e1, t);
-                        e1 = umax64(e0, t);
-                        e0 = umin64(e0, t);
+                for (int u = 0; u < 4; u++) {
+                    if (i0 >= cnt4[u]) continue;
+                    const float dx = p[u].x - pw.x, dy = p[u].y - pw.y, dz = p[u].z - pw.z;
+                    const float d2 = dx * dx + (dy * dy + dz * dz);  // ivox3d_node.hpp:12-15: Vector3f::squaredNorm() = Eigen's unrolled tree x0 + (x1 + x2)
+                    if (d2 < 5.0f) {
+                        inrange++;
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (ptr4[u] + i0);
+                        if (key < e4) {  // d2 >= 0: float order == unsigned order of the bits
+                            e4 = umax64(e3, key);
+                            unsigned long long t = umin64(e3, key);
+                            e3 = umax64(e2, t);
+                            t = umin64(e2, t);
+                            e2 = umax64(e1, t);
+                            t = umin64(e1, t);
+                            e1 = umax64(e0, t);
+                            e0 = umin64(e0, t);
+                        }
                     }
                 }
             }
         }
-        visited += total > (uint32_t)gl ? (total - gl + kG - 1) / kG : 0;
+        if (gl == 0) visited += total;
 #pragma unroll
         for (int off = kG / 2; off > 0; off >>= 1) inrange += __shfl_xor(inrange, off, kG);
         // merge: six rounds of group-wide min pop the global top-5 (lane r keeps winner r) and the best loser
@@ -284,19 +280,21 @@ __global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__
         __syncthreads();
         Cand e[5];
         for (int k = 0; k < 5; k++) e[k] = {INFINITY, kNoIdx};
-        uint32_t j = 0;
-        for (uint32_t c = gl; c < total; c += kG) {
-            while (c >= g.v_beg[j + 1]) j++;
-            const uint32_t id = g.v_ptr[j] + (c - g.v_beg[j]);
-            const float4 p = pool[id];
-            const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
-            const float d2 = dx * dx + (dy * dy + dz * dz);
-            if (d2 < 5.0f) {
-                Cand cd = {d2, id};
-                if (cand_less(cd, e[4], pool)) {
-                    e[4] = cd;
-                    for (int k = 4; k > 0; k--)
-                        if (cand_less(e[k], e[k - 1], pool)) { const Cand t = e[k - 1]; e[k - 1] = e[k]; e[k] = t; }
+        (void)total;
+        for (uint32_t sv = 0; sv < nhit; sv++) {
+            const uint32_t vptr = g.v_ptr[sv], vcnt = g.v_cnt[sv];
+            for (uint32_t i = gl; i < vcnt; i += kG) {
+                const uint32_t id = vptr + i;
+                const float4 p = pool[id];
+                const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
+                const float d2 = dx * dx + (dy * dy + dz * dz);
+                if (d2 < 5.0f) {
+                    Cand cd = {d2, id};
+                    if (cand_less(cd, e[4], pool)) {
+                        e[4] = cd;
+                        for (int k = 4; k > 0; k--)
+                            if (cand_less(e[k], e[k - 1], pool)) { const Cand t = e[k - 1]; e[k - 1] = e[k]; e[k] = t; }
+                    }
                 }
             }
         }

@@ -133,7 +133,10 @@ struct lio_scan {
     lio::ScanDev* dev;
     lio::ScanDev* host_dev;       // pinned mirror
     lio_normal_eq* d_result;
-    lio_normal_eq* h_result;      // pinned
+    uint32_t* host_nds;           // pinned, mapped: {n_ds, err} written by vg_heads_kernel
+    uint32_t* host_nds_dev;
+    lio_normal_eq* h_result;      // pinned, mapped
+    lio_normal_eq* h_result_dev;  // device-side alias of h_result (finalize_kernel writes the record there)
     int have_ds;
     uint64_t bytes;
 };

@@ -251,18 +251,22 @@ __global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, i
         }
         selected[i] = sel ? 1 : 0;
     }
-    __shared__ double red[kLinThreads / 64][kAcc];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // workgroup reduction through LDS, transposed: lane l parks its 29 addends in column l, then 29 lanes each sum
+    // one row in lane order (fixed order -> run-to-run identical).  A butterfly of 29 x 6 64-bit shuffles costs
+    // ~700 ds_bpermute per wave; this is 29 conflict-free ds_write_b64 + 32 ds_read_b128 per summing lane.
+    __shared__ double red[kAcc][kLinThreads];
 #pragma unroll
-    for (int a = 0; a < kAcc; a++) {
-        const double s = wave_sum(acc[a]);
-        if (lane == 0) red[wave][a] = s;
-    }
+    for (int a = 0; a < kAcc; a++) red[a][threadIdx.x] = acc[a];
     __syncthreads();
     if (threadIdx.x < kAcc) {
+        const double2* row = reinterpret_cast<const double2*>(&red[threadIdx.x][0]);
         double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < kLinThreads / 64; w++) s += red[w][threadIdx.x];
+#pragma unroll 8
+        for (int k = 0; k < kLinThreads / 2; k++) {
+            const double2 v = row[k];
+            s += v.x;
+            s += v.y;
+        }
         partial[(size_t)blockIdx.x * kAcc + threadIdx.x] = s;
     }
 }
@@ -360,7 +364,7 @@ int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) 
                        s->max_ds, s->nn_cnt, s->selected, s->normvec, s->partial);
     kt_end(s, 1);
     kt_begin(s, 2);
-    hipLaunchKernelGGL(finalize_kernel, 1, kFinThreads, 0, s->stream, s->dev, s->partial, m ? m->dev : nullptr, s->d_result);
+    hipLaunchKernelGGL(finalize_kernel, 1, kFinThreads, 0, s->stream, s->dev, s->partial, m ? m->dev : nullptr, s->h_result_dev);
     kt_end(s, 2);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;

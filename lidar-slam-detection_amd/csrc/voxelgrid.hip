@@ -285,11 +285,11 @@ __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __rest
                                                             const uint32_t* __restrict__ kb, const uint32_t* __restrict__ va,
                                                             const uint32_t* __restrict__ vb, uint32_t n, ScanDev* sd,
                                                             const uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ hpos,
-                                                            float4* __restrict__ sorted, float4* __restrict__ out, uint32_t max_ds) {
+                                                            float4* __restrict__ sorted, float4* __restrict__ out, uint32_t max_ds, uint32_t* __restrict__ host_nds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (sd->passthrough) {  // PCL overflow guard: output = input
         if (n > max_ds) {
-            if (blockIdx.x == 0 && tid == 0) { sd->err |= 1u; sd->n_ds = 0; }
+            if (blockIdx.x == 0 && tid == 0) { sd->err |= 1u; sd->n_ds = 0; host_nds[0] = 0; host_nds[1] = 1u; }
             return;
         }
         const uint32_t base = blockIdx.x * kTile;
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __rest
             const uint32_t i = base + r * kThreads + tid;
             if (i < n) out[i] = in[i];
         }
-        if (blockIdx.x == 0 && tid == 0) sd->n_ds = n;
+        if (blockIdx.x == 0 && tid == 0) { sd->n_ds = n; host_nds[0] = n; host_nds[1] = 0u; }
         return;
     }
     const bool odd = active_passes(sd) & 1;
@@ -344,8 +344,11 @@ __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __rest
         __syncthreads();
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
-        if (run > max_ds) { sd->err |= 1u; run = 0; }
+        uint32_t err = 0;
+        if (run > max_ds) { sd->err |= 1u; run = 0; err = 1u; }
         sd->n_ds = run;
+        host_nds[0] = run;  // mapped pinned host words: the host reads them after one stream sync, no copy launch
+        host_nds[1] = err;
     }
 }
 
@@ -427,20 +430,27 @@ __global__ void scan_set_nds_kernel(ScanDev* sd, uint32_t n) {
 }
 
 // Nearest_Points.resize(feats_down_size) (laserMapping.cpp:1274): entries beyond the new size are destroyed
-__global__ void scan_begin_kernel(const ScanDev* sd, int32_t* __restrict__ nn_cnt) {
+// ... and re-arm the bbox / counters for the next scan's downsample (saves two memset launches per scan)
+__global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt) {
     const uint32_t lo = sd->n_ds, hi = sd->n_ds_prev;
     for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) nn_cnt[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        sd->bbox_min[threadIdx.x] = 0xFFFFFFFFu;
+        sd->bbox_max[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) { sd->n_valid = 0; sd->n_long = 0; }
+    }
 }
 
 int vg_downsample(lio_scan* s, float leaf) {
     const uint32_t n = s->n_raw;
     const float inv = 1.0f / leaf;
     hipStream_t st = s->stream;
-    LIO_HIP_TRY(hipMemsetAsync(s->dev->bbox_min, 0xFF, 12, st));
-    LIO_HIP_TRY(hipMemsetAsync(s->dev->bbox_max, 0, 20, st));  // bbox_max[3] + n_valid + n_long
+    // bbox / n_valid / n_long were re-armed by the previous scan_begin_kernel (or at creation)
     const uint32_t nblocks = (n + kTile - 1) / kTile;
     if (n == 0) {
         hipLaunchKernelGGL(scan_set_nds_kernel, 1, 1, 0, st, s->dev, 0u);
+        s->host_nds[0] = 0;
+        s->host_nds[1] = 0;
         return LIO_OK;
     }
     const uint32_t g1 = nblocks < 48 ? nblocks : 48;  // 7 same-line atomics per workgroup: keep the workgroups few
@@ -454,7 +464,7 @@ int vg_downsample(lio_scan* s, float leaf) {
     }
     hipLaunchKernelGGL(vg_count_heads_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, s->dev, s->blockcnt);
     hipLaunchKernelGGL(vg_heads_kernel, nblocks, kThreads, 0, st, s->raw, s->keys_a, s->keys_b, s->vals_a, s->vals_b, n, s->dev, s->blockcnt,
-                       s->hpos, s->sorted, s->ds_body, s->max_ds);
+                       s->hpos, s->sorted, s->ds_body, s->max_ds, s->host_nds_dev);
     const uint32_t vbound = n < s->max_ds ? n : s->max_ds;
     hipLaunchKernelGGL(vg_centroid_kernel, (vbound + kThreads - 1) / kThreads, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body,
                        s->longlist);
