@@ -412,21 +412,38 @@ int Eskf::step(Work& w, double R, const Measurement& m, int i, bool& converge, i
             }
         }
     } else {
-        // P_temp = (P/R)^-1; P_temp[0:15,0:15] += HTH; P_inv = P_temp^-1   (esekfom.hpp:1782-1809)
-        double Pt[N * N], P_temp[N * N], P_inv[N * N];
-        for (int k = 0; k < N * N; k++) Pt[k] = P[k] / R;
-        mat_inverse(Pt, N, P_temp);
+        // esekfom.hpp:1782-1809:  P_temp = (P/R)^-1;  P_temp[0:15,0:15] += HTH;  P_inv = P_temp^-1;
+        //                         K_h = P_inv[:, 0:15] h_x^T h;  K_x[:, 0:15] = P_inv[:, 0:15] HTH.
+        // HTH is non-zero only in its leading 6x6 block B (extrinsic_est_en == false), so with A = (P/R)^-1,
+        // E = the first six unit columns and the matrix inversion lemma,
+        //   P_inv E = (A + E B E^T)^-1 E = (P/R) E (I6 + B (P/R)_66)^-1 ,
+        // which is all K_h and K_x need: one 6x6 inverse instead of the reference's two 23x23 ones (and no
+        // inverse of the possibly singular, degeneracy-projected B).  Same quantities, better conditioned.
+        double G[N * 6], M6[36], M6i[36];
+        for (int a = 0; a < N; a++)
+            for (int c = 0; c < 6; c++) G[a * 6 + c] = P[a * N + c] / R;
         for (int a = 0; a < 6; a++)
-            for (int b = 0; b < 6; b++) P_temp[a * N + b] += m.HTH[a * 6 + b];
-        mat_inverse(P_temp, N, P_inv);
+            for (int c = 0; c < 6; c++) {
+                double v = (a == c) ? 1.0 : 0.0;
+                for (int k = 0; k < 6; k++) v += m.HTH[a * 6 + k] * G[k * 6 + c];
+                M6[a * 6 + c] = v;
+            }
+        mat_inverse(M6, 6, M6i);
+        double Pi6[N * 6];  // P_inv[:, 0:6]
+        for (int a = 0; a < N; a++)
+            for (int c = 0; c < 6; c++) {
+                double v = 0;
+                for (int k = 0; k < 6; k++) v += G[a * 6 + k] * M6i[k * 6 + c];
+                Pi6[a * 6 + c] = v;
+            }
         for (int a = 0; a < N; a++) {
             double s = 0;
-            for (int c = 0; c < 6; c++) s += P_inv[a * N + c] * m.HTh[c];
+            for (int c = 0; c < 6; c++) s += Pi6[a * 6 + c] * m.HTh[c];
             w.K_h[a] = s;
-            for (int b = 0; b < 6; b++) {
+            for (int bcol = 0; bcol < 6; bcol++) {
                 double v = 0;
-                for (int c = 0; c < 6; c++) v += P_inv[a * N + c] * m.HTH[c * 6 + b];
-                w.K_x[a * N + b] = v;
+                for (int c = 0; c < 6; c++) v += Pi6[a * 6 + c] * m.HTH[c * 6 + bcol];
+                w.K_x[a * N + bcol] = v;
             }
         }
     }
