@@ -102,6 +102,8 @@ typedef struct lio_kernel_times {
     uint32_t knn_launches, linearize_launches, finalize_launches;
     uint32_t pad;
 } lio_kernel_times;
+/* on = bit mask of the kernel classes to time: 1 kNN (what bench.py's timed region uses: two event records per
+ * kNN launch), 2 linearize (+ report), 0 = off */
 int lio_scan_enable_kernel_timing(lio_scan*, int on);
 int lio_scan_kernel_times(lio_scan*, lio_kernel_times* out, int reset);
 
@@ -120,7 +122,7 @@ typedef struct lio_normal_eq {
     uint32_t n_ds;       /* feats_down_size */
     uint32_t n_knn_candidates_lo, n_knn_candidates_hi; /* 64-bit count of in-stencil points visited (kNN passes) */
     uint32_t n_tie;      /* kNN queries redone with the exact (d2, x, y, z) comparison because of an exact d2 tie */
-    uint32_t pad;
+    uint32_t seq;        /* sequence number of this record (the host-side wait spins on it) */
 } lio_normal_eq;
 
 /* One evaluation of h_share_model_geometric (src/laserMapping.cpp:813-932) without the host-side
@@ -201,6 +203,23 @@ int lio_engine_enable_timing(lio_engine*, int on);
  * uses the information form (rows live on different GPUs). */
 typedef void (*lio_reduce_fn)(void* ctx, double* buf, int n);
 int lio_engine_set_reduce_hook(lio_engine*, lio_reduce_fn fn, void* ctx);
+/* Throughput mode: register a batch of independent scans with `n_engines` engines running concurrently (one host
+ * thread + HIP stream per engine, jobs handed out through an atomic counter).  Every job = set_state(state_in) +
+ * set_cov(cov_in) + lio_engine_process_scan_device(d_raw, n_raw, lidar_beg_time); outputs are filled per job.
+ * Intended for engines created with lio_engine_create_shared on one read-only map (independent scans of several
+ * sensors / sequences, relocalisation candidates, map-merge alignments). */
+typedef struct lio_scan_job {
+    const void* d_raw;          /* device pointer, XYZI float4 */
+    uint32_t n_raw;
+    uint32_t pad;
+    double lidar_beg_time;
+    const double* state_in;     /* 26 doubles */
+    const double* cov_in;       /* 529 doubles */
+    double* state_out;          /* 26 doubles, may be NULL */
+    int32_t rc;                 /* return code of process_scan */
+    int32_t n_ds, n_pass, n_knn_pass;
+} lio_scan_job;
+int lio_engines_process_batch(lio_engine** engines, int n_engines, lio_scan_job* jobs, int n_jobs);
 /* on: process_scan skips map_incremental -- scan-to-map registration against a prebuilt static map
  * (BASELINE.json configs 2 and 4); off (default): the reference's mapping behaviour */
 int lio_engine_set_static_map(lio_engine*, int on);

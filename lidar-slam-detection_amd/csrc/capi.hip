@@ -69,7 +69,7 @@ static int map_check(lio_map* m, hipStream_t st) {
 // live kernel timing: a recycled pool of event pairs per kernel class, resolved lazily
 struct KernelTimer {
     static constexpr int kPool = 1024;
-    bool on = false;
+    int on = 0;  // bit mask of timed kernel classes: 1 kNN, 2 linearize(+report), 4 unused
     hipEvent_t ev[3][kPool][2];
     int used[3] = {0, 0, 0};
     double us[3] = {0, 0, 0};
@@ -89,15 +89,32 @@ struct KernelTimer {
 
 void kt_begin(lio_scan* s, int which) {
     KernelTimer* k = s->kt;
-    if (!k || !k->on) return;
+    if (!k || !(k->on & (1 << which))) return;
     if (k->used[which] >= KernelTimer::kPool) k->resolve(s->stream);
     hipEventRecord(k->ev[which][k->used[which]][0], s->stream);
 }
 void kt_end(lio_scan* s, int which) {
     KernelTimer* k = s->kt;
-    if (!k || !k->on) return;
+    if (!k || !(k->on & (1 << which))) return;
     hipEventRecord(k->ev[which][k->used[which]][1], s->stream);
     k->used[which]++;
+}
+
+// wait for the record of the last linearize launch: spin on the sequence word in mapped host memory (a few us
+// cheaper than hipStreamSynchronize per filter pass); falls back to a stream sync if the kernel never reports
+int wait_report(lio_scan* s) {
+    volatile uint32_t* seq = &s->h_result->seq;
+    const uint32_t want = s->seq_expected;
+    for (uint64_t spin = 0; *seq != want; spin++) {
+        __builtin_ia32_pause();
+        if (spin > 20000000ull) {  // ~100 ms: something went wrong on the device
+            LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+            if (*seq != want) { set_error("linearize_kernel did not report (seq %u, expected %u)", *seq, want); return LIO_E_DEVICE; }
+            break;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return LIO_OK;
 }
 
 }  // namespace lio
@@ -323,6 +340,8 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
         lio_scan_destroy(s);
         return nullptr;
     }
+    memset(s->h_result, 0, sizeof(lio_normal_eq));
+    s->host_nds[0] = s->host_nds[1] = 0;
     s->raw = s->raw_own;
     return s;
 }
@@ -369,7 +388,7 @@ int lio_scan_enable_kernel_timing(lio_scan* s, int on) {
             }
         s->kt->created = true;
     }
-    s->kt->on = on != 0;
+    s->kt->on = on & 7;
     return LIO_OK;
 }
 
@@ -505,15 +524,17 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
     }
     rc = p2plane_reduce(m, s, pose, redo_knn);
     if (rc != LIO_OK) return rc;
-    // finalize_kernel stores the record straight into mapped pinned host memory: no copy launch, one sync
-    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    // the reporting workgroup stores the record straight into mapped pinned host memory: no copy launch, no sync call
+    rc = wait_report(s);
+    if (rc != LIO_OK) return rc;
     if (s->h_result->n_tie) {  // exact d2 ties among some top-6: redo those queries with the canonical comparison
         const uint32_t nt = s->h_result->n_tie;
         rc = map_knn_exact(m, s, pose, nt);
         if (rc != LIO_OK) return rc;
         rc = p2plane_reduce(m, s, pose, redo_knn);
         if (rc != LIO_OK) return rc;
-        LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+        rc = wait_report(s);
+        if (rc != LIO_OK) return rc;
         s->h_result->n_tie = nt;
     }
     *out = *s->h_result;

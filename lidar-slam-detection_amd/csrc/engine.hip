@@ -2,7 +2,9 @@
 // (/root/reference/slam/mapping/fastlio/src/laserMapping.cpp:1189-1304), as host C++ over the kernel-level
 // C ABI.  Constants follow fastlio_init (laserMapping.cpp:1025-1124): 4 (+1) filter passes, leaf 0.5 m for
 // both filters, INIT_TIME 0.1 s, LASER_POINT_COV 0.001, degeneracy detection on, extrinsic estimation off.
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "eskf.h"
@@ -404,6 +406,42 @@ int lio_engine_process_scan_device(lio_engine* e, const void* d_raw, uint32_t n_
     const int rc = lio_scan_set_device(e->scan, d_raw, n_raw);
     if (rc != LIO_OK) return rc;
     return process_common(e, lidar_beg_time);
+}
+
+int lio_engines_process_batch(lio_engine** engines, int n_engines, lio_scan_job* jobs, int n_jobs) {
+    if (!engines || n_engines < 1 || (!jobs && n_jobs)) return LIO_E_INVALID;
+    for (int i = 0; i < n_engines; i++)
+        if (!engines[i]) return LIO_E_INVALID;
+    std::atomic<int> next(0);
+    std::atomic<int> first_err(0);
+    auto work = [&](int t) {
+        lio_engine* e = engines[t];
+        for (;;) {
+            const int j = next.fetch_add(1);
+            if (j >= n_jobs) break;
+            lio_scan_job& job = jobs[j];
+            int rc = LIO_E_INVALID;
+            if (job.state_in && job.cov_in) {
+                state_from_array(job.state_in, e->kf.x);
+                memcpy(e->kf.P, job.cov_in, sizeof(double) * 529);
+                rc = lio_engine_process_scan_device(e, job.d_raw, job.n_raw, job.lidar_beg_time);
+            }
+            job.rc = rc;
+            job.n_ds = e->tm.n_ds;
+            job.n_pass = e->tm.n_pass;
+            job.n_knn_pass = e->tm.n_knn_pass;
+            if (job.state_out) state_to_array(e->kf.x, job.state_out);
+            if (rc < 0) { int z = 0; first_err.compare_exchange_strong(z, rc); }
+        }
+    };
+    if (n_engines == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_engines; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    return first_err.load();
 }
 
 void lio_state_boxplus(const double s26[26], const double d23[23], double out26[26]) {

@@ -60,7 +60,9 @@ struct ScanDev {
     uint32_t n_valid;      // finite input points
     uint32_t n_long;       // voxels queued for the wave-per-voxel centroid kernel
     uint32_t n_tie;        // kNN queries whose top-6 held an exact d2 tie (queued for the exact redo)
-    uint32_t n_tie_done;   // snapshot of n_tie taken by finalize_kernel
+    uint32_t n_tie_done;   // snapshot of n_tie taken by the reporting workgroup of linearize_kernel
+    uint32_t lin_ticket;   // arrival counter of linearize_kernel's workgroups (last arriver reports)
+    uint32_t seq;          // sequence number of the last report
     uint32_t n_ds;         // feats_down_size
     uint32_t n_ds_prev;    // size of the neighbour cache before this scan (Nearest_Points.resize semantics)
     uint32_t passthrough;  // PCL int32 overflow guard hit: output = input
@@ -136,7 +138,8 @@ struct lio_scan {
     uint32_t* host_nds;           // pinned, mapped: {n_ds, err} written by vg_heads_kernel
     uint32_t* host_nds_dev;
     lio_normal_eq* h_result;      // pinned, mapped
-    lio_normal_eq* h_result_dev;  // device-side alias of h_result (finalize_kernel writes the record there)
+    lio_normal_eq* h_result_dev;  // device-side alias of h_result (linearize_kernel's last workgroup writes the record there)
+    uint32_t seq_expected;        // sequence number the next report will carry
     int have_ds;
     uint64_t bytes;
 };

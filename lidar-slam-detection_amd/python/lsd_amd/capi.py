@@ -24,7 +24,7 @@ SYMBOLS = [
     "lio_engine_create", "lio_engine_create_shared", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
     "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
-    "lio_engine_enable_timing", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
+    "lio_engine_enable_timing", "lio_engines_process_batch", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
 ]
 
@@ -33,7 +33,7 @@ class NormalEq(C.Structure):
     _fields_ = [("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6), ("nnT", C.c_double * 9), ("eigvec", C.c_double * 9),
                 ("eigval", C.c_double * 3), ("contri", C.c_double * 3), ("strong", C.c_double * 3), ("sum_abs_res", C.c_double),
                 ("n_eff", C.c_uint32), ("n_ds", C.c_uint32), ("n_knn_candidates_lo", C.c_uint32), ("n_knn_candidates_hi", C.c_uint32),
-                ("n_tie", C.c_uint32), ("pad", C.c_uint32)]
+                ("n_tie", C.c_uint32), ("seq", C.c_uint32)]
 
 
 class PassLog(C.Structure):
@@ -46,6 +46,12 @@ class Timings(C.Structure):
                 ("total_device_us", C.c_float), ("host_solve_us", C.c_float), ("total_wall_us", C.c_float), ("n_knn_pass", C.c_int32),
                 ("n_pass", C.c_int32), ("n_ds", C.c_int32), ("n_eff_last", C.c_int32), ("n_added", C.c_int32),
                 ("knn_candidates", C.c_uint64)]
+
+
+class ScanJob(C.Structure):
+    _fields_ = [("d_raw", C.c_void_p), ("n_raw", C.c_uint32), ("pad", C.c_uint32), ("lidar_beg_time", C.c_double),
+                ("state_in", C.POINTER(C.c_double)), ("cov_in", C.POINTER(C.c_double)), ("state_out", C.POINTER(C.c_double)),
+                ("rc", C.c_int32), ("n_ds", C.c_int32), ("n_pass", C.c_int32), ("n_knn_pass", C.c_int32)]
 
 
 class KernelTimes(C.Structure):
@@ -122,6 +128,7 @@ def lib():
     sig("lio_engine_process_scan_device", cint, vp, vp, u32, dbl)
     sig("lio_engine_timings", cint, vp, C.POINTER(Timings))
     sig("lio_engine_enable_timing", cint, vp, cint)
+    sig("lio_engines_process_batch", cint, C.POINTER(vp), cint, C.POINTER(ScanJob), cint)
     sig("lio_engine_set_static_map", cint, vp, cint)
     sig("lio_scan_enable_kernel_timing", cint, vp, cint)
     sig("lio_scan_kernel_times", cint, vp, C.POINTER(KernelTimes), cint)

@@ -164,8 +164,9 @@ class Scan:
         check(lib().lio_p2plane_degeneracy(self.h, ptr(V, C.c_double), ptr(c, C.c_double), ptr(s_, C.c_double)), "degeneracy")
         return c, s_
 
-    def enable_kernel_timing(self, on=True):
-        check(lib().lio_scan_enable_kernel_timing(self.h, int(on)))
+    def enable_kernel_timing(self, mask=3):
+        """bit mask: 1 = kNN kernel, 2 = linearize kernel, 0 = off"""
+        check(lib().lio_scan_enable_kernel_timing(self.h, int(mask)))
 
     def kernel_times(self, reset=True):
         t = capi.KernelTimes()
@@ -308,6 +309,28 @@ class Engine:
     @property
     def is_degenerate(self):
         return bool(lib().lio_engine_is_degenerate(self.h))
+
+
+def process_batch(engines, jobs):
+    """register independent scans concurrently (C++ worker threads, one per engine; see lio_engines_process_batch).
+    jobs: list of dicts {dptr, n, t, state (26,), cov (23,23)}; returns (rc, list of result dicts)"""
+    n = len(jobs)
+    arr = (capi.ScanJob * n)()
+    keep = []
+    outs = np.zeros((n, STATE_DIM))
+    for i, j in enumerate(jobs):
+        st, cv = f64(j["state"]), f64(j["cov"]).reshape(-1)
+        keep += [st, cv]
+        arr[i].d_raw = j["dptr"]
+        arr[i].n_raw = j["n"]
+        arr[i].lidar_beg_time = float(j["t"])
+        arr[i].state_in = ptr(st, C.c_double)
+        arr[i].cov_in = ptr(cv, C.c_double)
+        arr[i].state_out = outs[i].ctypes.data_as(C.POINTER(C.c_double))
+    hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    rc = lib().lio_engines_process_batch(hs, len(engines), arr, n)
+    res = [dict(rc=arr[i].rc, n_ds=arr[i].n_ds, n_pass=arr[i].n_pass, n_knn_pass=arr[i].n_knn_pass, state=outs[i]) for i in range(n)]
+    return rc, res
 
 
 def state_boxplus(s, d):
