@@ -224,6 +224,43 @@ int lio_engines_process_batch(lio_engine** engines, int n_engines, lio_scan_job*
  * (BASELINE.json configs 2 and 4); off (default): the reference's mapping behaviour */
 int lio_engine_set_static_map(lio_engine*, int on);
 
+/* ---------------------------------------------------------------------------------------------
+ * Localization matcher: replaces fast_gicp::NDTCuda<PointXYZI, PointXYZI> as select_registration_method("NDT_CUDA")
+ * configures it (slam/backend/hdl_graph_slam/src/hdl_graph_slam/registrations.cpp:105-118: P2D, resolution 1.0,
+ * DIRECT7) behind pcl::Registration's setInputTarget / setInputSource / align
+ * (slam/localization/hdl_localization/src/hdl_localization/pose_estimator.cpp:246-247).
+ * The source cloud is a lio_scan (upload + lio_scan_voxel_downsample with leaf = map_resolution, as
+ * hdl_localization_nodelet.cpp:333-344 does); transforms are row-major 4x4 doubles.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lio_ndt lio_ndt;
+/* NDTCuda() + setResolution + setNeighborSearchMethod(DIRECT1 / DIRECT7 / DIRECT27  ->  search_method 1 / 7 / 27) */
+lio_ndt* lio_ndt_create(int device, float resolution, int search_method, uint64_t max_points, uint64_t max_voxels, uint32_t max_source_points);
+void lio_ndt_destroy(lio_ndt*);
+/* setInputTarget -> NDTCudaCore::set_target_cloud -> create_target_voxelmap (ndt_cuda.cu:105-141): Gaussian voxel map
+ * (mean, covariance), PLANE regularisation, inverse covariance.  Replaces any previous target. */
+int lio_ndt_set_target(lio_ndt*, const float* xyzi, uint64_t n);
+int lio_ndt_set_target_device(lio_ndt*, const void* d_xyzi, uint64_t n);
+int lio_ndt_num_voxels(lio_ndt*);
+/* diagnostic: statistics of the voxel that contains p; returns its point count (0 = no such voxel) */
+int lio_ndt_voxel_at(lio_ndt*, const float p[3], float mean[3], float cinv[9]);
+/* NDTCuda::linearize (update_corr = 1, with_derivatives = 1: update_correspondences + compute_error with H, b) and
+ * NDTCuda::compute_error (update_corr = 0, with_derivatives = 0: error on the cached pairs)  (ndt_cuda_impl.hpp:82-90) */
+int lio_ndt_linearize(lio_ndt*, lio_scan* source, const double T[16], int update_corr, int with_derivatives, double H[36], double b[6],
+                      double* err, uint32_t* n_corr);
+typedef struct lio_ndt_params {
+    int32_t max_iterations;           /* setMaximumIterations (64) */
+    int32_t lm_max_iterations;        /* lm_max_iterations_ (10) */
+    double rotation_epsilon_deg;      /* setRotationEpsilon (0.1) */
+    double transformation_epsilon;    /* setTransformationEpsilon (0.01) */
+    double lm_init_lambda_factor;     /* 1e-9 */
+    double max_process_time_ms;       /* setMaxProcessTime; <= 0: no wall-clock cut-off */
+} lio_ndt_params;
+void lio_ndt_default_params(lio_ndt_params*);
+/* pcl::Registration::align(guess) -> LsqRegistration::computeTransformation with step_lm
+ * (lsq_registration_impl.hpp:71-109,163-208); out = final transformation, *converged = hasConverged() */
+int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_ndt_params* params, double out[16], int* iterations,
+                  int* converged);
+
 /* manifold helpers exposed for known-answer tests (mtk SO3/S2 boxplus/boxminus, SOn.hpp:233-245, S2.hpp:136-167) */
 void lio_state_boxplus(const double s26[26], const double d23[23], double out26[26]);
 void lio_state_boxminus(const double a26[26], const double b26[26], double d23[23]);

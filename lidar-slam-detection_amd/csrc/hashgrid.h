@@ -42,4 +42,12 @@ __device__ inline void pos2grid(float x, float y, float z, float inv_res, int& k
     kz = (int)roundf(z * inv_res);
 }
 
+// fast_gicp's Gaussian-voxel key (vector3_hash.cuh:35-38): (x.array() / resolution - 0.5).floor() in f32 -- cells
+// centred on integer multiples of the resolution, different from both iVox (round) and map_incremental (floor)
+__device__ inline void pos2grid_ndt(float x, float y, float z, float res, int& kx, int& ky, int& kz) {
+    kx = (int)floorf(x / res - 0.5f);
+    ky = (int)floorf(y / res - 0.5f);
+    kz = (int)floorf(z / res - 0.5f);
+}
+
 }  // namespace lio

@@ -26,14 +26,15 @@ namespace lio {
 __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint32_t mask, uint32_t* __restrict__ pending,
                                                                float* __restrict__ created, const float4* __restrict__ pts,
                                                                unsigned long long n_host, const uint32_t* __restrict__ n_dev,
-                                                               float inv_res, float travel, uint32_t max_voxels, MapDev* md,
-                                                               uint32_t* __restrict__ slot_of_point) {
+                                                               float inv_res, float res, int key_mode, float travel, uint32_t max_voxels,
+                                                               MapDev* md, uint32_t* __restrict__ slot_of_point) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const float4 p = pts[i];
         int kx, ky, kz;
-        pos2grid(p.x, p.y, p.z, inv_res, kx, ky, kz);
+        if (key_mode == 0) pos2grid(p.x, p.y, p.z, inv_res, kx, ky, kz);
+        else pos2grid_ndt(p.x, p.y, p.z, res, kx, ky, kz);
         const unsigned long long key = pack_key(kx, ky, kz);
         BrickProbe bp = brick_probe(kx, ky, kz);
         uint32_t found = kNoIdx;
@@ -202,7 +203,8 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
     const bool layout = m->n_batches == 0;
     m->n_batches++;
     hipLaunchKernelGGL(map_insert_claim_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->table_mask, m->pending, m->created,
-                       d_pts, (unsigned long long)n, d_n, m->inv_res, (float)travel, (uint32_t)m->max_voxels, m->dev, m->slot_of_point);
+                       d_pts, (unsigned long long)n, d_n, m->inv_res, m->res, m->key_mode, (float)travel, (uint32_t)m->max_voxels, m->dev,
+                       m->slot_of_point);
     if (layout) {
         const uint32_t ntiles = (m->table_cap + kScanTile - 1) / kScanTile;
         hipLaunchKernelGGL(map_layout_sums_kernel, ntiles, 256, 0, stream, m->pending, m->table_cap, m->tile_sum);

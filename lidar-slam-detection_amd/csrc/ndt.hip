@@ -1,0 +1,740 @@
+// ndt.hip -- the scan-to-map matcher of the reference's localization mode: fast_gicp::NDTCuda in P2D mode
+// (point-to-distribution NDT, DIRECT1/7/27 neighbourhoods, Levenberg-Marquardt on SE(3)), rebuilt for gfx950.
+//
+// Reference (paths relative to /root/reference/slam/thirdparty/fast_gicp):
+//   GaussianVoxelMap::create_voxelmap ........ src/fast_gicp/cuda/gaussian_voxelmap.cu:213-235 (+ :122-152, :182-202)
+//   covariance_regularization (PLANE) ........ src/fast_gicp/cuda/covariance_regularization.cu:15-52,105-116
+//   find_voxel_correspondences ............... src/fast_gicp/cuda/find_voxel_correspondences.cu:16-111
+//   p2d_ndt_compute_derivatives .............. src/fast_gicp/cuda/ndt_compute_derivatives.cu:33-102,187-208
+//   NDTCudaCore / NDTCuda .................... src/fast_gicp/cuda/ndt_cuda.cu, include/fast_gicp/ndt/impl/ndt_cuda_impl.hpp
+//   LsqRegistration (LM), se3_exp ............ include/fast_gicp/gicp/impl/lsq_registration_impl.hpp:71-208, so3/so3.hpp:58-105
+// The reference is a chain of Thrust functors: a bounded-probe bucket table rebuilt with doubling, 13 float atomics
+// per point, seven transform launches + remove_if per linearisation and an f32 tree reduction of 43-float tuples,
+// with host<->device copies of two Isometry3f per cost evaluation.  Here:
+//   * the target map reuses the brick-coherent hash grid of hashmap.hip with the Gaussian-voxel key; one lane per
+//     voxel then folds its points IN INPUT ORDER (f32, as the reference's sums are; the order makes it reproducible),
+//     regularises (closed-form 3x3 eigen-solver) and stores mean + inverse covariance as one 64-byte record;
+//   * one kernel per cost evaluation: a lane per source point walks its 7 (1, 27) neighbour cells -- probes issued
+//     back to back --, evaluates the f32 terms and accumulates f64; correspondences are cached per point so that the
+//     LM trial evaluations reuse the linearisation point's pairs exactly as the reference does;
+//   * the 43 sums leave through mapped host memory (spin-wait), the 6-DoF LM step runs on the host in f64.
+// Deviations (all documented in DESIGN.md): every target point is assigned (the reference drops < 1 % when its
+// bounded probing fails); sums are f64 in a fixed order (the reference: f32, unordered).
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+#include "hashgrid.h"
+#include "lio_common.h"
+
+namespace lio {
+
+struct __attribute__((aligned(64))) NdtVoxel {
+    float mean[3];
+    int32_t n;
+    float cinv[9];
+    float pad[3];
+};
+
+constexpr int kNdtThreads = 64;
+constexpr int kNdtAcc = 43;  // H (36, row-major) + b (6) + err
+constexpr int kNdtMaxOff = 27;
+
+struct NdtOffsets {
+    int n;
+    signed char off[kNdtMaxOff][3];
+};
+
+struct NdtXform {  // Eigen::Isometry3f as the kernels need it
+    float R[9];
+    float t[3];
+};
+
+__device__ __host__ inline float sum3f(float a, float b, float c) { return a + (b + c); }  // Eigen's unrolled 3-term redux
+
+__device__ inline void inv3_dev(const float m[9], float r[9]) {  // Eigen compute_inverse<Matrix3f>: cofactors / determinant
+#define M_(i, j) m[(i) * 3 + (j)]
+#define COF_(i, j) (M_(((i) + 1) % 3, ((j) + 1) % 3) * M_(((i) + 2) % 3, ((j) + 2) % 3) - M_(((i) + 1) % 3, ((j) + 2) % 3) * M_(((i) + 2) % 3, ((j) + 1) % 3))
+    const float c0 = COF_(0, 0), c1 = COF_(1, 0), c2 = COF_(2, 0);
+    const float det = sum3f(c0 * M_(0, 0), c1 * M_(1, 0), c2 * M_(2, 0));
+    const float invdet = 1.0f / det;
+    r[0] = c0 * invdet; r[1] = c1 * invdet; r[2] = c2 * invdet;
+    r[3] = COF_(0, 1) * invdet; r[4] = COF_(1, 1) * invdet; r[5] = COF_(2, 1) * invdet;
+    r[6] = COF_(0, 2) * invdet; r[7] = COF_(1, 2) * invdet; r[8] = COF_(2, 2) * invdet;
+#undef COF_
+#undef M_
+}
+
+__device__ inline void mul3_dev(const float a[9], const float b[9], float c[9]) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c[i * 3 + j] = sum3f(a[i * 3] * b[j], a[i * 3 + 1] * b[3 + j], a[i * 3 + 2] * b[6 + j]);
+}
+__device__ inline void cross3_dev(const float a[3], const float b[3], float c[3]) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ inline float sqn3_dev(const float a[3]) { return sum3f(a[0] * a[0], a[1] * a[1], a[2] * a[2]); }
+
+__device__ inline void extract_kernel_dev(const float t[9], float res[3], float rep[3]) {
+    int i0 = 0;
+    float best = fabsf(t[0]);
+    if (fabsf(t[4]) > best) { best = fabsf(t[4]); i0 = 1; }
+    if (fabsf(t[8]) > best) { best = fabsf(t[8]); i0 = 2; }
+    float ca[3], cb[3];
+    for (int r = 0; r < 3; r++) { rep[r] = t[r * 3 + i0]; ca[r] = t[r * 3 + (i0 + 1) % 3]; cb[r] = t[r * 3 + (i0 + 2) % 3]; }
+    float x0[3], x1[3];
+    cross3_dev(rep, ca, x0);
+    cross3_dev(rep, cb, x1);
+    const float n0 = sqn3_dev(x0), n1 = sqn3_dev(x1);
+    if (n0 > n1) { const float s = sqrtf(n0); for (int r = 0; r < 3; r++) res[r] = x0[r] / s; }
+    else { const float s = sqrtf(n1); for (int r = 0; r < 3; r++) res[r] = x1[r] / s; }
+}
+
+// SelfAdjointEigenSolver<Matrix3f>::computeDirect (closed form): eigenvalues ascending, eigenvectors as columns of V
+__device__ inline void eig3_direct_dev(const float cov[9], float w[3], float V[9]) {
+    float m[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) m[i * 3 + j] = (j <= i) ? cov[i * 3 + j] : cov[j * 3 + i];
+    const float shift = sum3f(cov[0], cov[4], cov[8]) / 3.0f;
+    m[0] -= shift; m[4] -= shift; m[8] -= shift;
+    float scale = 0.f;
+    for (int k = 0; k < 9; k++) scale = fmaxf(scale, fabsf(m[k]));
+    if (scale > 0.f)
+        for (int k = 0; k < 9; k++) m[k] /= scale;
+#define M_(i, j) m[(i) * 3 + (j)]
+    const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = sqrtf(3.0f);
+    const float c0 = M_(0, 0) * M_(1, 1) * M_(2, 2) + 2.0f * M_(1, 0) * M_(2, 0) * M_(2, 1) - M_(0, 0) * M_(2, 1) * M_(2, 1) -
+                     M_(1, 1) * M_(2, 0) * M_(2, 0) - M_(2, 2) * M_(1, 0) * M_(1, 0);
+    const float c1 = M_(0, 0) * M_(1, 1) - M_(1, 0) * M_(1, 0) + M_(0, 0) * M_(2, 2) - M_(2, 0) * M_(2, 0) + M_(1, 1) * M_(2, 2) - M_(2, 1) * M_(2, 1);
+    const float c2 = M_(0, 0) + M_(1, 1) + M_(2, 2);
+#undef M_
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+    a_over_3 = fmaxf(a_over_3, 0.f);
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+    q = fmaxf(q, 0.f);
+    const float rho = sqrtf(a_over_3);
+    const float theta = atan2f(sqrtf(q), half_b) * s_inv3;
+    const float ct = cosf(theta), st = sinf(theta);
+    w[0] = c2_over_3 - rho * (ct + s_sqrt3 * st);
+    w[1] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+    w[2] = c2_over_3 + 2.0f * rho * ct;
+    const float eps = 1.1920929e-07f;
+    float col[3][3];
+    if ((w[2] - w[0]) <= eps) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) col[i][j] = (i == j) ? 1.f : 0.f;
+    } else {
+        float d0 = w[2] - w[1];
+        const float d1 = w[1] - w[0];
+        int k = 0, l = 2;
+        if (d0 > d1) { k = 2; l = 0; d0 = d1; }
+        float tmp[9];
+        for (int i = 0; i < 9; i++) tmp[i] = m[i];
+        tmp[0] -= w[k]; tmp[4] -= w[k]; tmp[8] -= w[k];
+        extract_kernel_dev(tmp, col[k], col[l]);
+        if (d0 <= 2 * eps * d1) {
+            const float dot = sum3f(col[k][0] * col[l][0], col[k][1] * col[l][1], col[k][2] * col[l][2]);
+            for (int r = 0; r < 3; r++) col[l][r] -= dot * col[l][r];
+            const float nn = sqrtf(sqn3_dev(col[l]));
+            for (int r = 0; r < 3; r++) col[l][r] /= nn;
+        } else {
+            for (int i = 0; i < 9; i++) tmp[i] = m[i];
+            tmp[0] -= w[l]; tmp[4] -= w[l]; tmp[8] -= w[l];
+            float dummy[3];
+            extract_kernel_dev(tmp, col[l], dummy);
+        }
+        float c[3];
+        cross3_dev(col[2], col[0], c);
+        const float nn = sqrtf(sqn3_dev(c));
+        for (int r = 0; r < 3; r++) col[1][r] = c[r] / nn;
+    }
+    for (int i = 0; i < 3; i++) w[i] = w[i] * scale + shift;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) V[r * 3 + c] = col[c][r];
+}
+
+// w = original point index, so that the voxel fold can run in input order whatever order the pool received the points
+__global__ void __launch_bounds__(256) ndt_stamp_kernel(const float4* __restrict__ in, float4* __restrict__ out, unsigned long long n) {
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
+        const float4 p = in[i];
+        out[i] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)i));
+    }
+}
+
+// one lane per table slot: ndt_finalize_voxels_kernel + PLANE regularisation + the inverse the cost kernel needs
+__global__ void __launch_bounds__(256) ndt_fold_kernel(const Slot* __restrict__ table, uint32_t table_cap, const float4* __restrict__ pool,
+                                                       NdtVoxel* __restrict__ vox) {
+    for (uint32_t h = blockIdx.x * 256u + threadIdx.x; h < table_cap; h += gridDim.x * 256u) {
+        const Slot s = table[h];
+        NdtVoxel v;
+        v.n = 0;
+        if (s.key != kEmptyKey && s.cnt > 0) {
+            float sx[3] = {0.f, 0.f, 0.f}, sc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // selection by ascending original index: O(cnt^2) reads of a voxel that sits in L1/L2
+            long long last = -1;
+            for (uint32_t it = 0; it < s.cnt; it++) {
+                uint32_t best = 0xFFFFFFFFu, at = 0;
+                for (uint32_t k = 0; k < s.cnt; k++) {
+                    const uint32_t idx = __float_as_uint(pool[s.ptr + k].w);
+                    if ((long long)idx > last && idx < best) { best = idx; at = k; }
+                }
+                last = best;
+                const float4 p = pool[s.ptr + at];
+                const float q[3] = {p.x, p.y, p.z};
+                for (int a = 0; a < 3; a++) sx[a] = sx[a] + q[a];
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) sc[a * 3 + b] = sc[a * 3 + b] + q[a] * q[b];
+            }
+            const float nf = (float)s.cnt;
+            float cov[9];
+            for (int a = 0; a < 3; a++) v.mean[a] = sx[a] / nf;
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) cov[a * 3 + b] = (sc[a * 3 + b] - v.mean[a] * sx[b]) / nf;
+            float w[3], V[9], Vi[9], VD[9], R[9];
+            eig3_direct_dev(cov, w, V);
+            inv3_dev(V, Vi);
+            const float D[9] = {1e-3f, 0.f, 0.f, 0.f, 1.0f, 0.f, 0.f, 0.f, 1.0f};
+            mul3_dev(V, D, VD);
+            mul3_dev(VD, Vi, R);
+            inv3_dev(R, v.cinv);
+            v.n = (int32_t)s.cnt;
+        }
+        if (v.n) vox[h] = v;
+        else vox[h].n = 0;
+    }
+}
+
+__device__ inline void xform_dev(const NdtXform& X, const float4 p, float o[3]) {
+    for (int i = 0; i < 3; i++) o[i] = sum3f(X.R[i * 3] * p.x, X.R[i * 3 + 1] * p.y, X.R[i * 3 + 2] * p.z) + X.t[i];
+}
+
+struct NdtDev {
+    uint32_t n_corr;  // correspondences of the last update (all offsets)
+    uint32_t seq;
+};
+struct NdtReport {  // mapped pinned host memory
+    double acc[kNdtAcc];
+    uint32_t n_corr;
+    uint32_t seq;
+};
+
+// one cost evaluation.  UPDATE: look the neighbour voxels up at x_lin and cache them (find_voxel_correspondences);
+// DERIV: accumulate H and b besides the error (linearize) -- otherwise the error only (LM trial, compute_error)
+template <bool UPDATE, bool DERIV, int NO>
+__global__ void __launch_bounds__(kNdtThreads) ndt_cost_kernel(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox,
+                                                               float res, NdtOffsets offs, NdtXform x_lin, NdtXform x,
+                                                               const float4* __restrict__ src, const ScanDev* __restrict__ sd,
+                                                               uint32_t* __restrict__ corr, uint32_t corr_stride, double* __restrict__ partial,
+                                                               NdtDev* nd) {
+    const uint32_t n = sd->n_ds;
+    if (blockIdx.x * kNdtThreads >= n) return;
+    const uint32_t i = blockIdx.x * kNdtThreads + threadIdx.x;
+    constexpr int NA = DERIV ? kNdtAcc : 1;
+    double acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) acc[a] = 0.0;
+    uint32_t my_corr = 0;
+    if (i < n) {
+        const float4 p = src[i];
+        uint32_t slot[NO];
+        if (UPDATE) {
+            float tl[3];
+            xform_dev(x_lin, p, tl);
+            int kx, ky, kz;
+            pos2grid_ndt(tl[0], tl[1], tl[2], res, kx, ky, kz);
+            // all home-slot probes first (independent loads in flight), then resolve
+            uint4 raw[NO];
+            BrickProbe bp[NO];
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                bp[o] = brick_probe(kx + offs.off[o][0], ky + offs.off[o][1], kz + offs.off[o][2]);
+                raw[o] = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[o], mask)]);
+            }
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                const unsigned long long want = pack_key(kx + offs.off[o][0], ky + offs.off[o][1], kz + offs.off[o][2]);
+                uint4 r = raw[o];
+                uint32_t found = kNoIdx;
+                for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
+                    const unsigned long long kk = ((unsigned long long)r.y << 32) | r.x;
+                    if (kk == want) { found = r.w > 0 ? brick_slot(bp[o], mask) : kNoIdx; break; }
+                    if (kk == kEmptyKey) break;
+                    brick_next(bp[o]);
+                    r = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[o], mask)]);
+                }
+                slot[o] = found;
+                corr[(size_t)o * corr_stride + i] = found;
+                if (found != kNoIdx) my_corr++;
+            }
+        } else {
+#pragma unroll
+            for (int o = 0; o < NO; o++) slot[o] = corr[(size_t)o * corr_stride + i];
+        }
+        float tp[3];
+        xform_dev(x, p, tp);
+#pragma unroll
+        for (int o = 0; o < NO; o++) {
+            if (slot[o] == kNoIdx) continue;
+            // one 64-byte record: mean, count, inverse covariance
+            const float4* rec = reinterpret_cast<const float4*>(&vox[slot[o]]);
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            const int cnt = __float_as_int(r0.w);
+            if (cnt <= 6) continue;  // ndt_compute_derivatives.cu:61
+            const float ci[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
+            const float e[3] = {r0.x - tp[0], r0.y - tp[1], r0.z - tp[2]};
+            const float nrm = sqrtf(sqn3_dev(e));
+            const float ksq = res * res;
+            const float w = ksq / (ksq + nrm * nrm);  // cauchy(resolution, |e|)
+            const float we[3] = {w * e[0], w * e[1], w * e[2]};
+            float wc[3];
+            for (int c = 0; c < 3; c++) wc[c] = sum3f(we[0] * ci[c], we[1] * ci[3 + c], we[2] * ci[6 + c]);
+            const float err = sum3f(wc[0] * e[0], wc[1] * e[1], wc[2] * e[2]);
+            if (DERIV) {
+                const float J[3][6] = {{0.f, -tp[2], tp[1], -1.f, 0.f, 0.f}, {tp[2], 0.f, -tp[0], 0.f, -1.f, 0.f}, {-tp[1], tp[0], 0.f, 0.f, 0.f, -1.f}};
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    float B[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) B[c] = sum3f((w * J[0][r]) * ci[c], (w * J[1][r]) * ci[3 + c], (w * J[2][r]) * ci[6 + c]);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) acc[r * 6 + c] += (double)sum3f(B[0] * J[0][c], B[1] * J[1][c], B[2] * J[2][c]);
+                    acc[36 + r] += (double)sum3f(B[0] * e[0], B[1] * e[1], B[2] * e[2]);
+                }
+                acc[42] += (double)err;
+            } else {
+                acc[0] += (double)err;
+            }
+        }
+    }
+    __shared__ double red[NA][kNdtThreads];
+#pragma unroll
+    for (int a = 0; a < NA; a++) red[a][threadIdx.x] = acc[a];
+    __syncthreads();
+    if (threadIdx.x < NA) {
+        const double2* row = reinterpret_cast<const double2*>(&red[threadIdx.x][0]);
+        double s = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < kNdtThreads / 2; k++) {
+            const double2 v = row[k];
+            s += v.x;
+            s += v.y;
+        }
+        partial[(size_t)blockIdx.x * kNdtAcc + threadIdx.x] = s;
+    }
+    if (UPDATE) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) my_corr += __shfl_xor(my_corr, off);
+        if (threadIdx.x == 0 && my_corr) atomicAdd(&nd->n_corr, my_corr);
+    }
+}
+
+__global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial, int na, NdtDev* nd,
+                                                          NdtReport* __restrict__ out) {
+    __shared__ double acc[kNdtAcc];
+    const int tid = threadIdx.x;
+    const uint32_t nb = (sd->n_ds + kNdtThreads - 1) / kNdtThreads;
+    if (tid < kNdtAcc) acc[tid] = 0.0;
+    __syncthreads();
+    // component c owned by lanes c*16 .. c*16+15 (43 * 16 = 688 lanes): stride-16 chunks, then a fixed xor tree
+    {
+        const int c = tid >> 4, l = tid & 15;
+        double s = 0.0;
+        if (c < na)
+            for (uint32_t b = l; b < nb; b += 16) s += partial[(size_t)b * kNdtAcc + c];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (c < na && l == 0) acc[c] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (na == 1) { out->acc[42] = acc[0]; }
+        else for (int k = 0; k < kNdtAcc; k++) out->acc[k] = acc[k];
+        out->n_corr = nd->n_corr;
+        __threadfence_system();
+        const uint32_t seq = nd->seq + 1u;
+        nd->seq = seq;
+        *reinterpret_cast<volatile uint32_t*>(&out->seq) = seq;
+    }
+}
+
+}  // namespace lio
+
+using namespace lio;
+
+struct lio_ndt {
+    int device;
+    float res;
+    lio_map* map;  // hash grid with the Gaussian-voxel key; owns the stream used for builds
+    NdtVoxel* vox;
+    NdtOffsets offs;
+    uint32_t* corr;  // [n_offsets][max_src]
+    uint32_t max_src;
+    double* partial;
+    NdtDev* dev;
+    NdtReport* report;      // mapped host
+    NdtReport* report_dev;  // device alias
+    uint32_t seq_expected;
+    float4* stamp;  // staging for set_target
+    uint64_t stamp_cap;
+    uint64_t max_points;
+    int method;
+};
+
+namespace {
+
+int fill_offsets(NdtOffsets& o, int method) {  // ndt_cuda.cu:36-78
+    o.n = 0;
+    auto push = [&](int a, int b, int c) { o.off[o.n][0] = (signed char)a; o.off[o.n][1] = (signed char)b; o.off[o.n][2] = (signed char)c; o.n++; };
+    if (method == 1) push(0, 0, 0);
+    else if (method == 7) { push(0, 0, 0); push(1, 0, 0); push(-1, 0, 0); push(0, 1, 0); push(0, -1, 0); push(0, 0, 1); push(0, 0, -1); }
+    else if (method == 27) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) push(i - 1, j - 1, k - 1); }
+    else return LIO_E_INVALID;
+    return LIO_OK;
+}
+
+NdtXform to_xform(const double T[16]) {  // trans.cast<float>()
+    NdtXform x;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) x.R[i * 3 + j] = (float)T[i * 4 + j]; x.t[i] = (float)T[i * 4 + 3]; }
+    return x;
+}
+
+int ndt_wait(lio_ndt* n, hipStream_t st) {
+    volatile uint32_t* seq = &n->report->seq;
+    const uint32_t want = n->seq_expected;
+    for (uint64_t spin = 0; *seq != want; spin++) {
+        __builtin_ia32_pause();
+        if (spin > 20000000ull) {
+            LIO_HIP_TRY(hipStreamSynchronize(st));
+            if (*seq != want) { set_error("ndt_report_kernel did not report"); return LIO_E_DEVICE; }
+            break;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return LIO_OK;
+}
+
+// one cost evaluation on the scan's stream: update (optional) + error (+ H, b)
+int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16], bool update, bool deriv, double* H, double* b, double* err,
+             uint32_t* n_corr) {
+    const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
+    if (bound > n->max_src) { set_error("source scan of %u points exceeds the matcher's capacity %u", bound, n->max_src); return LIO_E_CAPACITY; }
+    uint32_t blocks = (bound + kNdtThreads - 1) / kNdtThreads;
+    if (blocks == 0) blocks = 1;
+    const NdtXform xl = to_xform(x_lin), xx = to_xform(x);
+    hipStream_t st = s->stream;
+    if (update) LIO_HIP_TRY(hipMemsetAsync(&n->dev->n_corr, 0, 4, st));
+#define NDT_LAUNCH(U, D, NO)                                                                                                                       \
+    hipLaunchKernelGGL((ndt_cost_kernel<U, D, NO>), blocks, kNdtThreads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xl, xx, \
+                       s->ds_body, s->dev, n->corr, n->max_src, n->partial, n->dev)
+#define NDT_DISPATCH(NO)                            \
+    do {                                            \
+        if (update && deriv) NDT_LAUNCH(true, true, NO);   \
+        else if (update) NDT_LAUNCH(true, false, NO);      \
+        else if (deriv) NDT_LAUNCH(false, true, NO);       \
+        else NDT_LAUNCH(false, false, NO);                 \
+    } while (0)
+    if (n->offs.n == 1) NDT_DISPATCH(1);
+    else if (n->offs.n == 7) NDT_DISPATCH(7);
+    else NDT_DISPATCH(27);
+#undef NDT_DISPATCH
+#undef NDT_LAUNCH
+    hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, deriv ? kNdtAcc : 1, n->dev, n->report_dev);
+    LIO_HIP_TRY(hipGetLastError());
+    n->seq_expected++;
+    const int rc = ndt_wait(n, st);
+    if (rc != LIO_OK) return rc;
+    if (deriv && H && b) {
+        for (int k = 0; k < 36; k++) H[k] = n->report->acc[k];
+        for (int k = 0; k < 6; k++) b[k] = n->report->acc[36 + k];
+    }
+    if (err) *err = n->report->acc[42];
+    if (n_corr) *n_corr = n->report->n_corr;
+    return LIO_OK;
+}
+
+// ---- host side: SE(3) and the LM step (lsq_registration_impl.hpp, so3.hpp), f64 ----------------------------------
+void se3_exp_h(const double a[6], double T[16]) {
+    const double wx = a[0], wy = a[1], wz = a[2];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    double imag, real;
+    if (theta_sq < 1e-10) {
+        const double tq = theta_sq * theta_sq;
+        imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
+        real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
+    } else {
+        const double th = sqrt(theta_sq), h = 0.5 * th;
+        imag = sin(h) / th;
+        real = cos(h);
+    }
+    const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+    const double theta = sqrt(theta_sq);
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9], V[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += O[i * 3 + k] * O[k * 3 + j]; O2[i * 3 + j] = s; }
+    if (theta < 1e-10) memcpy(V, R, sizeof(V));
+    else {
+        const double tsq = theta * theta;
+        for (int k = 0; k < 9; k++) V[k] = ((k % 4 == 0) ? 1.0 : 0.0) + (1.0 - cos(theta)) / tsq * O[k] + (theta - sin(theta)) / (tsq * theta) * O2[k];
+    }
+    for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = V[i * 3] * a[3] + V[i * 3 + 1] * a[4] + V[i * 3 + 2] * a[5];
+    }
+}
+void mul44_h(const double A[16], const double B[16], double C[16]) {
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j]; C[i * 4 + j] = s; }
+}
+double rot_angle_deg_h(const double T[16]) {  // Eigen::AngleAxisd(delta.linear()).angle() / pi * 180 (via the quaternion)
+    const double tr = T[0] + T[5] + T[10];
+    double w, x, y, z;
+    if (tr > 0) {
+        double t = sqrt(tr + 1.0);
+        w = 0.5 * t; t = 0.5 / t;
+        x = (T[9] - T[6]) * t; y = (T[2] - T[8]) * t; z = (T[4] - T[1]) * t;
+    } else {
+        int i = 0;
+        if (T[5] > T[0]) i = 1;
+        if (T[10] > T[i * 5]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double t = sqrt(T[i * 5] - T[j * 5] - T[k * 5] + 1.0);
+        double q[3];
+        q[i] = 0.5 * t; t = 0.5 / t;
+        w = (T[k * 4 + j] - T[j * 4 + k]) * t;
+        q[j] = (T[j * 4 + i] + T[i * 4 + j]) * t;
+        q[k] = (T[k * 4 + i] + T[i * 4 + k]) * t;
+        x = q[0]; y = q[1]; z = q[2];
+    }
+    return 2.0 * atan2(sqrt(x * x + y * y + z * z), fabs(w)) / M_PI * 180.0;
+}
+// (H + lambda I) d = -b by LDL^T on the lower triangle (the reference: Eigen::LDLT<Matrix<double,6,6>>, same solution)
+bool ldlt_solve6(const double A[36], const double rhs[6], double x[6]) {
+    double L[36] = {0}, D[6];
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k] * D[k];
+        if (d == 0.0 || !std::isfinite(d)) return false;
+        D[j] = d;
+        L[j * 6 + j] = 1.0;
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
+            L[i * 6 + j] = s / d;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
+    for (int i = 0; i < 6; i++) y[i] /= D[i];
+    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
+    return true;
+}
+bool converged_h(const lio_ndt_params& p, const double D[16], double loosen) {
+    const double r_delta = 1.0 / (p.rotation_epsilon_deg * loosen) * rot_angle_deg_h(D);
+    double tmax = 0;
+    for (int i = 0; i < 3; i++) tmax = fmax(tmax, 1.0 / (p.transformation_epsilon * loosen) * fabs(D[i * 4 + 3]));
+    return fmax(r_delta, tmax) < 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+lio_ndt* lio_ndt_create(int device, float resolution, int search_method, uint64_t max_points, uint64_t max_voxels, uint32_t max_source_points) {
+    if (!(resolution > 0.f) || !max_points || !max_voxels || !max_source_points) { set_error("lio_ndt_create: bad argument"); return nullptr; }
+    lio_ndt* n = new lio_ndt();
+    memset(n, 0, sizeof(*n));
+    if (fill_offsets(n->offs, search_method) != LIO_OK) { set_error("lio_ndt_create: search method must be 1, 7 or 27"); delete n; return nullptr; }
+    n->method = search_method;
+    n->map = lio_map_create(device, resolution, max_points, max_voxels, 1);
+    if (!n->map) { delete n; return nullptr; }
+    n->map->key_mode = 1;
+    n->device = device;
+    n->res = resolution;
+    n->max_src = max_source_points;
+    n->max_points = max_points;
+    n->stamp_cap = max_points;
+    bool ok = hipMalloc(reinterpret_cast<void**>(&n->vox), (size_t)n->map->table_cap * sizeof(NdtVoxel)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->corr), (size_t)kNdtMaxOff * max_source_points * 4) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->partial), (size_t)((max_source_points + kNdtThreads - 1) / kNdtThreads) * kNdtAcc * 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->dev), sizeof(NdtDev)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->stamp), (size_t)n->stamp_cap * sizeof(float4)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&n->report), sizeof(NdtReport), hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void**>(&n->report_dev), n->report, 0) == hipSuccess;
+    if (ok) {
+        memset(n->report, 0, sizeof(NdtReport));
+        ok = hipMemset(n->dev, 0, sizeof(NdtDev)) == hipSuccess && hipMemset(n->vox, 0, (size_t)n->map->table_cap * sizeof(NdtVoxel)) == hipSuccess;
+    }
+    if (!ok) { set_error("lio_ndt_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); lio_ndt_destroy(n); return nullptr; }
+    return n;
+}
+
+void lio_ndt_destroy(lio_ndt* n) {
+    if (!n) return;
+    hipSetDevice(n->device);
+    if (n->map) { hipStreamSynchronize(n->map->stream); lio_map_destroy(n->map); }
+    hipFree(n->vox); hipFree(n->corr); hipFree(n->partial); hipFree(n->dev); hipFree(n->stamp);
+    if (n->report) hipHostFree(n->report);
+    delete n;
+}
+
+int lio_ndt_set_target_device(lio_ndt* n, const void* d_xyzi, uint64_t np) {
+    if (!n || (!d_xyzi && np)) return LIO_E_INVALID;
+    if (np > n->stamp_cap) { set_error("target cloud of %llu points exceeds max_points %llu", (unsigned long long)np, (unsigned long long)n->stamp_cap); return LIO_E_CAPACITY; }
+    hipSetDevice(n->device);
+    lio_map* m = n->map;
+    hipStream_t st = m->stream;
+    // setInputTarget replaces the target: start from an empty grid
+    LIO_HIP_TRY(hipMemsetAsync(m->table, 0xFF, (size_t)m->table_cap * sizeof(Slot), st));
+    LIO_HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(m->table) + 8, sizeof(Slot), 0, 8, m->table_cap, st));
+    LIO_HIP_TRY(hipMemsetAsync(m->cap, 0, (size_t)m->table_cap * 4, st));
+    LIO_HIP_TRY(hipMemsetAsync(m->pending, 0, (size_t)m->table_cap * 4, st));
+    LIO_HIP_TRY(hipMemsetAsync(m->dev, 0, sizeof(MapDev), st));
+    m->n_batches = 0;
+    if (np) {
+        uint64_t blocks = (np + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(ndt_stamp_kernel, (uint32_t)blocks, 256, 0, st, reinterpret_cast<const float4*>(d_xyzi), n->stamp, (unsigned long long)np);
+        const int rc = map_insert_dev(m, st, n->stamp, np, nullptr, 0.0);
+        if (rc != LIO_OK) return rc;
+    }
+    uint32_t fb = (m->table_cap + 255) / 256;
+    if (fb > 16384) fb = 16384;
+    hipLaunchKernelGGL(ndt_fold_kernel, fb, 256, 0, st, m->table, m->table_cap, m->pool, n->vox);
+    LIO_HIP_TRY(hipGetLastError());
+    uint64_t pts = 0, vx = 0;
+    return lio_map_stats(m, &pts, &vx);
+}
+
+int lio_ndt_set_target(lio_ndt* n, const float* xyzi, uint64_t np) {
+    if (!n || (!xyzi && np)) return LIO_E_INVALID;
+    hipSetDevice(n->device);
+    float4* tmp = nullptr;
+    if (np) {
+        LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tmp), np * sizeof(float4)));
+        if (hipMemcpy(tmp, xyzi, np * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) { hipFree(tmp); set_error("lio_ndt_set_target: upload failed"); return LIO_E_DEVICE; }
+    }
+    const int rc = lio_ndt_set_target_device(n, tmp, np);
+    hipStreamSynchronize(n->map->stream);
+    hipFree(tmp);
+    return rc;
+}
+
+int lio_ndt_num_voxels(lio_ndt* n) {
+    if (!n) return LIO_E_INVALID;
+    uint64_t pts = 0, vx = 0;
+    const int rc = lio_map_stats(n->map, &pts, &vx);
+    return rc < 0 ? rc : (int)vx;
+}
+
+int lio_ndt_voxel_at(lio_ndt* n, const float p[3], float mean[3], float cinv[9]) {
+    if (!n || !p) return LIO_E_INVALID;
+    hipSetDevice(n->device);
+    lio_map* m = n->map;
+    hipStreamSynchronize(m->stream);
+    const int kx = (int)floorf(p[0] / n->res - 0.5f), ky = (int)floorf(p[1] / n->res - 0.5f), kz = (int)floorf(p[2] / n->res - 0.5f);
+    std::vector<Slot> tab(m->table_cap);  // diagnostic path: whole-table read-back
+    if (hipMemcpy(tab.data(), m->table, sizeof(Slot) * m->table_cap, hipMemcpyDeviceToHost) != hipSuccess) return LIO_E_DEVICE;
+    const unsigned long long want = pack_key(kx, ky, kz);
+    for (uint32_t h = 0; h < m->table_cap; h++) {
+        if (tab[h].key != want || tab[h].cnt == 0) continue;
+        NdtVoxel v;
+        if (hipMemcpy(&v, n->vox + h, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return LIO_E_DEVICE;
+        if (mean) memcpy(mean, v.mean, 12);
+        if (cinv) memcpy(cinv, v.cinv, 36);
+        return v.n;
+    }
+    return 0;
+}
+
+int lio_ndt_linearize(lio_ndt* n, lio_scan* s, const double T[16], int update_corr, int with_derivatives, double H[36], double b[6], double* err,
+                      uint32_t* n_corr) {
+    if (!n || !s || !T) return LIO_E_INVALID;
+    if (n->device != s->device) { set_error("matcher and scan live on different devices"); return LIO_E_INVALID; }
+    hipSetDevice(n->device);
+    hipStreamSynchronize(n->map->stream);  // the target build ran on the map's stream
+    return ndt_eval(n, s, T, T, update_corr != 0, with_derivatives != 0, H, b, err, n_corr);
+}
+
+void lio_ndt_default_params(lio_ndt_params* p) {
+    if (!p) return;
+    // registrations.cpp:110-113 (NDT_CUDA) over the LsqRegistration defaults (lsq_registration_impl.hpp:20-32)
+    p->max_iterations = 64;
+    p->rotation_epsilon_deg = 0.1;
+    p->transformation_epsilon = 0.01;
+    p->lm_max_iterations = 10;
+    p->lm_init_lambda_factor = 1e-9;
+    p->max_process_time_ms = -1.0;
+}
+
+int lio_ndt_align(lio_ndt* n, lio_scan* s, const double guess[16], const lio_ndt_params* prm, double out[16], int* iterations, int* converged) {
+    if (!n || !s || !guess || !out) return LIO_E_INVALID;
+    if (n->device != s->device) { set_error("matcher and scan live on different devices"); return LIO_E_INVALID; }
+    hipSetDevice(n->device);
+    hipStreamSynchronize(n->map->stream);
+    lio_ndt_params p;
+    if (prm) p = *prm; else lio_ndt_default_params(&p);
+    double x0[16];
+    memcpy(x0, guess, sizeof(x0));
+    double lambda = -1.0;
+    bool conv = false;
+    int it_done = 0;
+    const auto clock0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < p.max_iterations && !conv; it++) {  // LsqRegistration::computeTransformation
+        it_done = it;
+        double H[36], b[6], delta[16], y0 = 0;
+        int rc = ndt_eval(n, s, x0, x0, true, true, H, b, &y0, nullptr);  // linearize = update_correspondences + compute_error
+        if (rc != LIO_OK) return rc;
+        if (lambda < 0.0) {
+            double mx = 0;
+            for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(H[i * 7]));
+            lambda = p.lm_init_lambda_factor * mx;
+        }
+        double nu = 2.0;
+        bool ok = false;
+        for (int i = 0; i < p.lm_max_iterations; i++) {  // step_lm
+            double A[36], nb[6], d[6];
+            for (int k = 0; k < 36; k++) A[k] = H[k] + ((k % 7 == 0) ? lambda : 0.0);
+            for (int k = 0; k < 6; k++) nb[k] = -b[k];
+            if (!ldlt_solve6(A, nb, d)) break;
+            se3_exp_h(d, delta);
+            double xi[16], yi = 0;
+            mul44_h(delta, x0, xi);
+            rc = ndt_eval(n, s, x0, xi, false, false, nullptr, nullptr, &yi, nullptr);  // compute_error(xi) on the cached pairs
+            if (rc != LIO_OK) return rc;
+            double den = 0;
+            for (int k = 0; k < 6; k++) den += d[k] * (lambda * d[k] - b[k]);
+            const double rho = (y0 - yi) / den;
+            if (rho < 0) {
+                if (converged_h(p, delta, 10.0)) { ok = true; break; }
+                lambda = nu * lambda;
+                nu = 2 * nu;
+                continue;
+            }
+            memcpy(x0, xi, sizeof(x0));
+            lambda = lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+            ok = true;
+            break;
+        }
+        if (!ok) break;  // "lm not converged!!"
+        conv = converged_h(p, delta, 1.0);
+        if (p.max_process_time_ms > 0) {  // lsq_registration_impl.hpp:94-104
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clock0).count();
+            if (ms > p.max_process_time_ms && converged_h(p, delta, 10.0)) { conv = true; break; }
+            else if (ms > 1.5 * p.max_process_time_ms) break;
+        }
+    }
+    memcpy(out, x0, sizeof(x0));
+    if (iterations) *iterations = it_done;
+    if (converged) *converged = conv ? 1 : 0;
+    return LIO_OK;
+}
+
+}  // extern "C"

@@ -26,6 +26,8 @@ SYMBOLS = [
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
     "lio_engine_enable_timing", "lio_engines_process_batch", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
+    "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_voxel_at",
+    "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align",
 ]
 
 
@@ -52,6 +54,11 @@ class ScanJob(C.Structure):
     _fields_ = [("d_raw", C.c_void_p), ("n_raw", C.c_uint32), ("pad", C.c_uint32), ("lidar_beg_time", C.c_double),
                 ("state_in", C.POINTER(C.c_double)), ("cov_in", C.POINTER(C.c_double)), ("state_out", C.POINTER(C.c_double)),
                 ("rc", C.c_int32), ("n_ds", C.c_int32), ("n_pass", C.c_int32), ("n_knn_pass", C.c_int32)]
+
+
+class NdtParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("lm_max_iterations", C.c_int32), ("rotation_epsilon_deg", C.c_double),
+                ("transformation_epsilon", C.c_double), ("lm_init_lambda_factor", C.c_double), ("max_process_time_ms", C.c_double)]
 
 
 class KernelTimes(C.Structure):
@@ -132,6 +139,15 @@ def lib():
     sig("lio_engine_set_static_map", cint, vp, cint)
     sig("lio_scan_enable_kernel_timing", cint, vp, cint)
     sig("lio_scan_kernel_times", cint, vp, C.POINTER(KernelTimes), cint)
+    sig("lio_ndt_create", vp, cint, flt, cint, u64, u64, u32)
+    sig("lio_ndt_destroy", None, vp)
+    sig("lio_ndt_set_target", cint, vp, f32p, u64)
+    sig("lio_ndt_set_target_device", cint, vp, vp, u64)
+    sig("lio_ndt_num_voxels", cint, vp)
+    sig("lio_ndt_voxel_at", cint, vp, f32p, f32p, f32p)
+    sig("lio_ndt_linearize", cint, vp, vp, f64p, cint, cint, f64p, f64p, f64p, C.POINTER(u32))
+    sig("lio_ndt_default_params", None, C.POINTER(NdtParams))
+    sig("lio_ndt_align", cint, vp, vp, f64p, C.POINTER(NdtParams), f64p, C.POINTER(cint), C.POINTER(cint))
     sig("lio_state_boxplus", None, f64p, f64p, f64p)
     sig("lio_state_boxminus", None, f64p, f64p, f64p)
     _lib = L

@@ -311,6 +311,58 @@ class Engine:
         return bool(lib().lio_engine_is_degenerate(self.h))
 
 
+class Ndt:
+    """The localization matcher (fast_gicp::NDTCuda, P2D): set_target = setInputTarget, the source is a Scan
+    (upload + voxel_downsample = setInputSource), align = pcl::Registration::align(guess)."""
+
+    def __init__(self, resolution=1.0, search_method=7, max_points=1_000_000, max_voxels=500_000, max_source_points=100_000, device=0):
+        self.h = lib().lio_ndt_create(device, resolution, search_method, max_points, max_voxels, max_source_points)
+        if not self.h:
+            raise capi.LioError("lio_ndt_create failed: " + lib().lio_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lio_ndt_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def set_target(self, pts):
+        p = f32(pts).reshape(-1, 4)
+        check(lib().lio_ndt_set_target(self.h, ptr(p, C.c_float), len(p)), "ndt set_target")
+
+    def set_target_device(self, dptr, n):
+        check(lib().lio_ndt_set_target_device(self.h, C.c_void_p(dptr), n), "ndt set_target (device)")
+
+    @property
+    def num_voxels(self):
+        return check(lib().lio_ndt_num_voxels(self.h), "ndt num_voxels")
+
+    def voxel_at(self, p):
+        p = f32(p)
+        mean, cinv = np.zeros(3, np.float32), np.zeros(9, np.float32)
+        n = check(lib().lio_ndt_voxel_at(self.h, ptr(p, C.c_float), ptr(mean, C.c_float), ptr(cinv, C.c_float)), "ndt voxel_at")
+        return n, mean, cinv.reshape(3, 3)
+
+    def linearize(self, scan, T, update_corr=True, with_derivatives=True):
+        T = f64(T).reshape(4, 4)
+        H, b, e, nc = np.zeros(36), np.zeros(6), C.c_double(0), C.c_uint32(0)
+        check(lib().lio_ndt_linearize(self.h, scan.h, ptr(T, C.c_double), int(update_corr), int(with_derivatives), ptr(H, C.c_double),
+                                      ptr(b, C.c_double), C.byref(e), C.byref(nc)), "ndt linearize")
+        return dict(n_corr=int(nc.value), H=H.reshape(6, 6), b=b, err=e.value)
+
+    def align(self, scan, guess, **params):
+        g = f64(guess).reshape(4, 4)
+        prm = capi.NdtParams()
+        lib().lio_ndt_default_params(C.byref(prm))
+        for k, v in params.items():
+            setattr(prm, k, v)
+        out = np.zeros((4, 4))
+        it, conv = C.c_int(0), C.c_int(0)
+        check(lib().lio_ndt_align(self.h, scan.h, ptr(g, C.c_double), C.byref(prm), ptr(out, C.c_double), C.byref(it), C.byref(conv)), "ndt align")
+        return out, bool(conv.value), int(it.value)
+
+
 def process_batch(engines, jobs):
     """register independent scans concurrently (C++ worker threads, one per engine; see lio_engines_process_batch).
     jobs: list of dicts {dptr, n, t, state (26,), cov (23,23)}; returns (rc, list of result dicts)"""

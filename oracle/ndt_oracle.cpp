@@ -1,0 +1,480 @@
+// =============================================================================
+// oracle/ndt_oracle.cpp -- CPU ORACLE of the localization matcher (TEST INFRASTRUCTURE ONLY)
+//
+// Restates fast_gicp::NDTCuda in P2D mode as the reference configures it for scan-to-map matching
+// (slam/backend/hdl_graph_slam/src/hdl_graph_slam/registrations.cpp:105-118: resolution 1.0, DIRECT7,
+// rotation epsilon 0.1 deg, translation epsilon 0.01 m, 64 iterations).  Paths relative to
+// /root/reference/slam/thirdparty/fast_gicp:
+//   voxel key / hash ......... include/fast_gicp/cuda/vector3_hash.cuh:35-38
+//   target voxel map ......... src/fast_gicp/cuda/gaussian_voxelmap.cu:122-152,182-202,213-235
+//   PLANE regularisation ..... src/fast_gicp/cuda/covariance_regularization.cu:15-52,105-116
+//                              (Eigen SelfAdjointEigenSolver<Matrix3f>::computeDirect + 3x3 inverse, restated)
+//   correspondences .......... src/fast_gicp/cuda/find_voxel_correspondences.cu:16-111, ndt_cuda.cu:36-78
+//   P2D derivatives .......... src/fast_gicp/cuda/ndt_compute_derivatives.cu:33-102,187-208
+//   LM on SE(3) .............. include/fast_gicp/gicp/impl/lsq_registration_impl.hpp:71-131,163-208
+//   se3_exp .................. include/fast_gicp/so3/so3.hpp:58-105
+//
+// PARITY STATUS: the CUDA/Thrust sources cannot be compiled here; the reference itself is not run-to-run
+// deterministic on this path (float atomics in the map build, bounded hash probing that drops < 1 % of the points,
+// a Thrust tree reduction in f32).  This oracle fixes the unspecified orders -- every point is assigned, per-voxel
+// sums run in input order, per-pair terms are f32 as in the reference but summed in f64 in (offset, point) order --
+// and is pinned where real reference code can be compiled: so3.hpp's se3_exp and Eigen's computeDirect / 3x3 inverse
+// through oracle/_ref (tests/test_ndt_oracle_vs_ref.py).  Everything else: parity unpinned.
+// The 50 ms wall-clock timeout of the reference's LM loop (lsq_registration_impl.hpp:94-104) is not modelled.
+// =============================================================================
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct K3 {
+    int x, y, z;
+    bool operator==(const K3& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct K3H {
+    size_t operator()(const K3& k) const {
+        uint64_t h = 0;
+        auto comb = [&](uint64_t v) {  // vector3_hash.cuh:8-18 (boost hash_combine, 64 bit)
+            const uint64_t m = 0xc6a4a7935bd1e995ull;
+            v *= m; v ^= v >> 47; v *= m;
+            h ^= v; h *= m; h += 0xe6546b64;
+        };
+        comb((uint64_t)(int64_t)k.x); comb((uint64_t)(int64_t)k.y); comb((uint64_t)(int64_t)k.z);
+        return (size_t)h;
+    }
+};
+
+inline K3 voxel_coord(const float p[3], float res) {  // (x.array() / resolution - 0.5).floor().cast<int>()
+    return {(int)std::floor(p[0] / res - 0.5f), (int)std::floor(p[1] / res - 0.5f), (int)std::floor(p[2] / res - 0.5f)};
+}
+
+inline float sum3(float a, float b, float c) { return a + (b + c); }  // Eigen's unrolled redux of three terms
+
+// 3x3 inverse, Eigen compute_inverse<Matrix3f> (LU/InverseImpl.h): cofactors / determinant
+void inv3(const float m[9], float r[9]) {
+    auto M = [&](int i, int j) { return m[i * 3 + j]; };
+    auto cof = [&](int i, int j) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return M(i1, j1) * M(i2, j2) - M(i1, j2) * M(i2, j1);
+    };
+    const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+    const float det = sum3(c0 * M(0, 0), c1 * M(1, 0), c2 * M(2, 0));
+    const float invdet = 1.0f / det;
+    r[0] = c0 * invdet; r[1] = c1 * invdet; r[2] = c2 * invdet;
+    r[3] = cof(0, 1) * invdet; r[4] = cof(1, 1) * invdet; r[5] = cof(2, 1) * invdet;
+    r[6] = cof(0, 2) * invdet; r[7] = cof(1, 2) * invdet; r[8] = cof(2, 2) * invdet;
+}
+
+void mul3(const float a[9], const float b[9], float c[9]) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c[i * 3 + j] = sum3(a[i * 3] * b[j], a[i * 3 + 1] * b[3 + j], a[i * 3 + 2] * b[6 + j]);
+}
+
+inline void cross3(const float a[3], const float b[3], float c[3]) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline float sqn3(const float a[3]) { return sum3(a[0] * a[0], a[1] * a[1], a[2] * a[2]); }
+
+// SelfAdjointEigenSolver<Matrix3f>::computeDirect (Eigenvalues/SelfAdjointEigenSolver.h, 3x3 specialisation):
+// shift by trace/3, scale by the largest |entry|, trigonometric roots, eigenvectors from cross products.
+// eigenvalues ascending in w, eigenvectors as columns of V (row-major 3x3).  Uses the lower triangle.
+void eig3_direct(const float cov[9], float w[3], float V[9]) {
+    float m[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) m[i * 3 + j] = (j <= i) ? cov[i * 3 + j] : cov[j * 3 + i];
+    const float shift = sum3(cov[0], cov[4], cov[8]) / 3.0f;  // mat.trace() / 3 (diagonal().sum(): tree a + (b + c))
+    m[0] -= shift; m[4] -= shift; m[8] -= shift;
+    float scale = 0.f;
+    for (int k = 0; k < 9; k++) scale = std::fmax(scale, std::fabs(m[k]));
+    if (scale > 0.f)
+        for (int k = 0; k < 9; k++) m[k] /= scale;
+    auto M = [&](int i, int j) { return m[i * 3 + j]; };
+    // computeRoots
+    const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = std::sqrt(3.0f);
+    const float c0 = M(0, 0) * M(1, 1) * M(2, 2) + 2.0f * M(1, 0) * M(2, 0) * M(2, 1) - M(0, 0) * M(2, 1) * M(2, 1) - M(1, 1) * M(2, 0) * M(2, 0) -
+                     M(2, 2) * M(1, 0) * M(1, 0);
+    const float c1 = M(0, 0) * M(1, 1) - M(1, 0) * M(1, 0) + M(0, 0) * M(2, 2) - M(2, 0) * M(2, 0) + M(1, 1) * M(2, 2) - M(2, 1) * M(2, 1);
+    const float c2 = M(0, 0) + M(1, 1) + M(2, 2);
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+    a_over_3 = std::fmax(a_over_3, 0.f);
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+    q = std::fmax(q, 0.f);
+    const float rho = std::sqrt(a_over_3);
+    const float theta = std::atan2(std::sqrt(q), half_b) * s_inv3;
+    const float ct = std::cos(theta), st = std::sin(theta);
+    w[0] = c2_over_3 - rho * (ct + s_sqrt3 * st);
+    w[1] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+    w[2] = c2_over_3 + 2.0f * rho * ct;
+    const float eps = 1.1920929e-07f;
+    float col[3][3];  // eigenvector columns
+    if ((w[2] - w[0]) <= eps) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) col[i][j] = (i == j) ? 1.f : 0.f;
+    } else {
+        auto extract_kernel = [&](float t[9], float res[3], float rep[3]) {
+            int i0 = 0;
+            float best = std::fabs(t[0]);
+            if (std::fabs(t[4]) > best) { best = std::fabs(t[4]); i0 = 1; }
+            if (std::fabs(t[8]) > best) { best = std::fabs(t[8]); i0 = 2; }
+            float ca[3], cb[3];
+            for (int r = 0; r < 3; r++) { rep[r] = t[r * 3 + i0]; ca[r] = t[r * 3 + (i0 + 1) % 3]; cb[r] = t[r * 3 + (i0 + 2) % 3]; }
+            float x0[3], x1[3];
+            cross3(rep, ca, x0);
+            cross3(rep, cb, x1);
+            const float n0 = sqn3(x0), n1 = sqn3(x1);
+            if (n0 > n1) { const float s = std::sqrt(n0); for (int r = 0; r < 3; r++) res[r] = x0[r] / s; }
+            else { const float s = std::sqrt(n1); for (int r = 0; r < 3; r++) res[r] = x1[r] / s; }
+        };
+        float d0 = w[2] - w[1];
+        const float d1 = w[1] - w[0];
+        int k = 0, l = 2;
+        if (d0 > d1) { k = 2; l = 0; d0 = d1; }  // Eigen overwrites d0 only: the test below compares against the original d1
+        float tmp[9];
+        std::memcpy(tmp, m, sizeof(tmp));
+        tmp[0] -= w[k]; tmp[4] -= w[k]; tmp[8] -= w[k];
+        extract_kernel(tmp, col[k], col[l]);
+        if (d0 <= 2 * eps * d1) {
+            const float dot = sum3(col[k][0] * col[l][0], col[k][1] * col[l][1], col[k][2] * col[l][2]);
+            for (int r = 0; r < 3; r++) col[l][r] -= dot * col[l][r];
+            const float nn = std::sqrt(sqn3(col[l]));
+            for (int r = 0; r < 3; r++) col[l][r] /= nn;
+        } else {
+            std::memcpy(tmp, m, sizeof(tmp));
+            tmp[0] -= w[l]; tmp[4] -= w[l]; tmp[8] -= w[l];
+            float dummy[3];
+            extract_kernel(tmp, col[l], dummy);
+        }
+        float c[3];
+        cross3(col[2], col[0], c);
+        const float nn = std::sqrt(sqn3(c));
+        for (int r = 0; r < 3; r++) col[1][r] = c[r] / nn;
+    }
+    for (int i = 0; i < 3; i++) w[i] = w[i] * scale + shift;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) V[r * 3 + c] = col[c][r];
+}
+
+// covariance_regularization.cu:105-116 (PLANE): cov <- V diag(1e-3, 1, 1) V^-1
+void regularize_plane(float cov[9]) {
+    float w[3], V[9], Vi[9], VD[9];
+    eig3_direct(cov, w, V);
+    inv3(V, Vi);
+    const float D[9] = {1e-3f, 0, 0, 0, 1.0f, 0, 0, 0, 1.0f};
+    mul3(V, D, VD);
+    mul3(VD, Vi, cov);
+}
+
+struct Voxel {
+    int n = 0;
+    float mean[3] = {0, 0, 0};
+    float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float cinv[9];
+};
+
+struct Ndt {
+    float res = 1.0f;
+    std::vector<K3> offsets;
+    std::unordered_map<K3, int, K3H> index;
+    std::vector<Voxel> vox;
+    std::vector<float> src;                 // xyz per source point
+    std::vector<int> corr_src, corr_vox;    // correspondences of the last linearisation (offset-major order)
+    // LM settings (registrations.cpp:110-113)
+    int max_iterations = 64, lm_max_iterations = 10;
+    double rot_eps = 0.1, trans_eps = 0.01, lm_init_lambda_factor = 1e-9, lm_lambda = -1.0;
+    int iterations = 0;
+    bool converged = false;
+
+    void set_method(int m) {  // ndt_cuda.cu:36-78
+        offsets.clear();
+        if (m == 1) offsets.push_back({0, 0, 0});
+        else if (m == 7) {
+            const int o[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+            for (auto& a : o) offsets.push_back({a[0], a[1], a[2]});
+        } else {
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) offsets.push_back({i - 1, j - 1, k - 1});
+        }
+    }
+
+    void set_target(const float* pts, int n) {  // points are xyz(i) with stride 4
+        index.clear();
+        vox.clear();
+        for (int i = 0; i < n; i++) {
+            const float* p = pts + 4 * (size_t)i;
+            const K3 k = voxel_coord(p, res);
+            auto it = index.find(k);
+            int v;
+            if (it == index.end()) { v = (int)vox.size(); index.emplace(k, v); vox.emplace_back(); }
+            else v = it->second;
+            Voxel& x = vox[v];
+            x.n++;
+            for (int a = 0; a < 3; a++) x.mean[a] = x.mean[a] + p[a];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) x.cov[a * 3 + b] = x.cov[a * 3 + b] + p[a] * p[b];  // mean * mean.transpose()
+        }
+        for (Voxel& x : vox) {  // ndt_finalize_voxels_kernel, then PLANE regularisation, then the inverse the derivative kernel takes
+            float sum_pts[3] = {x.mean[0], x.mean[1], x.mean[2]};
+            const float nf = (float)x.n;
+            for (int a = 0; a < 3; a++) x.mean[a] = x.mean[a] / nf;
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) x.cov[a * 3 + b] = (x.cov[a * 3 + b] - x.mean[a] * sum_pts[b]) / nf;
+            regularize_plane(x.cov);
+            inv3(x.cov, x.cinv);
+        }
+    }
+
+    static void to_f32(const double T[16], float R[9], float t[3]) {
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[i * 3 + j] = (float)T[i * 4 + j]; t[i] = (float)T[i * 4 + 3]; }
+    }
+    static void xform(const float R[9], const float t[3], const float* p, float o[3]) {
+        for (int i = 0; i < 3; i++) o[i] = sum3(R[i * 3] * p[0], R[i * 3 + 1] * p[1], R[i * 3 + 2] * p[2]) + t[i];
+    }
+
+    void update_correspondences(const double T[16]) {  // find_voxel_correspondences.cu:83-111
+        float R[9], t[3];
+        to_f32(T, R, t);
+        corr_src.clear();
+        corr_vox.clear();
+        const int n = (int)src.size() / 3;
+        for (const K3& off : offsets)
+            for (int i = 0; i < n; i++) {
+                float tp[3];
+                xform(R, t, &src[3 * (size_t)i], tp);
+                K3 k = voxel_coord(tp, res);
+                k = {k.x + off.x, k.y + off.y, k.z + off.z};
+                auto it = index.find(k);
+                if (it != index.end()) { corr_src.push_back(i); corr_vox.push_back(it->second); }
+            }
+    }
+
+    double compute_error(const double T[16], double* H36, double* b6) const {  // ndt_compute_derivatives.cu:50-91
+        float R[9], t[3];
+        to_f32(T, R, t);
+        double err_sum = 0;
+        if (H36) { std::memset(H36, 0, sizeof(double) * 36); std::memset(b6, 0, sizeof(double) * 6); }
+        for (size_t c = 0; c < corr_src.size(); c++) {
+            const Voxel& v = vox[corr_vox[c]];
+            if (v.n <= 6) continue;
+            float tp[3], e[3];
+            xform(R, t, &src[3 * (size_t)corr_src[c]], tp);
+            for (int a = 0; a < 3; a++) e[a] = v.mean[a] - tp[a];
+            const float nrm = std::sqrt(sqn3(e));
+            const float ksq = res * res;
+            const float w = ksq / (ksq + nrm * nrm);  // cauchy(resolution, |e|)
+            // B = (w J^T) C^-1 (6x3), J = [skew(tp) | -I]
+            const float J[3][6] = {{0.f, -tp[2], tp[1], -1.f, 0.f, 0.f}, {tp[2], 0.f, -tp[0], 0.f, -1.f, 0.f}, {-tp[1], tp[0], 0.f, 0.f, 0.f, -1.f}};
+            float B[6][3];
+            for (int r = 0; r < 6; r++)
+                for (int cc = 0; cc < 3; cc++)
+                    B[r][cc] = sum3((w * J[0][r]) * v.cinv[0 * 3 + cc], (w * J[1][r]) * v.cinv[1 * 3 + cc], (w * J[2][r]) * v.cinv[2 * 3 + cc]);
+            float we[3] = {w * e[0], w * e[1], w * e[2]}, wc[3];
+            for (int cc = 0; cc < 3; cc++) wc[cc] = sum3(we[0] * v.cinv[cc], we[1] * v.cinv[3 + cc], we[2] * v.cinv[6 + cc]);
+            err_sum += (double)sum3(wc[0] * e[0], wc[1] * e[1], wc[2] * e[2]);
+            if (H36) {
+                for (int r = 0; r < 6; r++) {
+                    for (int cc = 0; cc < 6; cc++) H36[r * 6 + cc] += (double)sum3(B[r][0] * J[0][cc], B[r][1] * J[1][cc], B[r][2] * J[2][cc]);
+                    b6[r] += (double)sum3(B[r][0] * e[0], B[r][1] * e[1], B[r][2] * e[2]);
+                }
+            }
+        }
+        return err_sum;
+    }
+};
+
+// ---- SE(3) helpers in f64 (so3.hpp:58-105) -----------------------------------------------------
+void se3_exp(const double a[6], double T[16]) {
+    const double wx = a[0], wy = a[1], wz = a[2];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    double imag, real;
+    if (theta_sq < 1e-10) {
+        const double tq = theta_sq * theta_sq;
+        imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
+        real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
+    } else {
+        const double th = std::sqrt(theta_sq), h = 0.5 * th;
+        imag = std::sin(h) / th;
+        real = std::cos(h);
+    }
+    const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+    double R[9];
+    {  // Quaterniond::toRotationMatrix
+        const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+        const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+        R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+        R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+        R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+    }
+    const double theta = std::sqrt(theta_sq);
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9], V[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += O[i * 3 + k] * O[k * 3 + j]; O2[i * 3 + j] = s; }
+    if (theta < 1e-10) std::memcpy(V, R, sizeof(V));
+    else {
+        const double tsq = theta * theta;
+        for (int k = 0; k < 9; k++) V[k] = ((k % 4 == 0) ? 1.0 : 0.0) + (1.0 - std::cos(theta)) / tsq * O[k] + (theta - std::sin(theta)) / (tsq * theta) * O2[k];
+    }
+    for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = V[i * 3] * a[3] + V[i * 3 + 1] * a[4] + V[i * 3 + 2] * a[5];
+    }
+}
+void mul44(const double A[16], const double B[16], double C[16]) {
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j]; C[i * 4 + j] = s; }
+}
+double rot_angle_deg(const double T[16]) {  // Eigen::AngleAxisd(R).angle() in degrees
+    // AngleAxis(matrix) goes through the quaternion: angle = 2 atan2(|vec|, |w|)
+    const double m00 = T[0], m11 = T[5], m22 = T[10];
+    const double tr = m00 + m11 + m22;
+    double w, x, y, z;
+    if (tr > 0) {
+        double t = std::sqrt(tr + 1.0);
+        w = 0.5 * t; t = 0.5 / t;
+        x = (T[9] - T[6]) * t; y = (T[2] - T[8]) * t; z = (T[4] - T[1]) * t;
+    } else {
+        int i = 0;
+        if (m11 > m00) i = 1;
+        if (m22 > T[i * 5]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double t = std::sqrt(T[i * 5] - T[j * 5] - T[k * 5] + 1.0);
+        double q[3];
+        q[i] = 0.5 * t; t = 0.5 / t;
+        w = (T[k * 4 + j] - T[j * 4 + k]) * t;
+        q[j] = (T[j * 4 + i] + T[i * 4 + j]) * t;
+        q[k] = (T[k * 4 + i] + T[i * 4 + k]) * t;
+        x = q[0]; y = q[1]; z = q[2];
+    }
+    const double n = std::sqrt(x * x + y * y + z * z);
+    return 2.0 * std::atan2(n, std::fabs(w)) / M_PI * 180.0;
+}
+// 6x6 LDLT-free solve: Gaussian elimination with partial pivoting (the reference uses Eigen::LDLT; same solution to rounding)
+bool solve6(const double A[36], const double b[6], double x[6]) {
+    double M[6][7];
+    for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) M[i][j] = A[i * 6 + j]; M[i][6] = b[i]; }
+    for (int k = 0; k < 6; k++) {
+        int p = k;
+        for (int i = k + 1; i < 6; i++) if (std::fabs(M[i][k]) > std::fabs(M[p][k])) p = i;
+        if (M[p][k] == 0.0) return false;
+        if (p != k) for (int j = 0; j < 7; j++) std::swap(M[k][j], M[p][j]);
+        for (int i = k + 1; i < 6; i++) { const double f = M[i][k] / M[k][k]; for (int j = k; j < 7; j++) M[i][j] -= f * M[k][j]; }
+    }
+    for (int i = 5; i >= 0; i--) { double s = M[i][6]; for (int j = i + 1; j < 6; j++) s -= M[i][j] * x[j]; x[i] = s / M[i][i]; }
+    return true;
+}
+
+bool converged_test(const Ndt& n, const double D[16], double loosen) {
+    const double R = rot_angle_deg(D);
+    const double r_delta = 1.0 / (n.rot_eps * loosen) * R;
+    double tmax = 0;
+    for (int i = 0; i < 3; i++) tmax = std::fmax(tmax, 1.0 / (n.trans_eps * loosen) * std::fabs(D[i * 4 + 3]));
+    return std::fmax(r_delta, tmax) < 1;
+}
+
+// LsqRegistration::computeTransformation with step_lm (lsq_registration_impl.hpp:71-109,163-208)
+void align(Ndt& n, const double guess[16], double out[16]) {
+    double x0[16];
+    std::memcpy(x0, guess, sizeof(x0));
+    n.lm_lambda = -1.0;
+    n.converged = false;
+    n.iterations = 0;
+    for (int it = 0; it < n.max_iterations && !n.converged; it++) {
+        n.iterations = it;
+        double H[36], b[6], delta[16];
+        n.update_correspondences(x0);  // linearize = update_correspondences + compute_error (ndt_cuda_impl.hpp:82-85)
+        const double y0 = n.compute_error(x0, H, b);
+        if (n.lm_lambda < 0.0) {
+            double mx = 0;
+            for (int i = 0; i < 6; i++) mx = std::fmax(mx, std::fabs(H[i * 7]));
+            n.lm_lambda = n.lm_init_lambda_factor * mx;
+        }
+        double nu = 2.0;
+        bool ok = false;
+        for (int i = 0; i < n.lm_max_iterations; i++) {
+            double A[36], nb[6], d[6];
+            for (int k = 0; k < 36; k++) A[k] = H[k] + ((k % 7 == 0) ? n.lm_lambda : 0.0);
+            for (int k = 0; k < 6; k++) nb[k] = -b[k];
+            if (!solve6(A, nb, d)) break;
+            se3_exp(d, delta);
+            double xi[16];
+            mul44(delta, x0, xi);
+            const double yi = n.compute_error(xi, nullptr, nullptr);
+            double den = 0;
+            for (int k = 0; k < 6; k++) den += d[k] * (n.lm_lambda * d[k] - b[k]);
+            const double rho = (y0 - yi) / den;
+            if (rho < 0) {
+                if (converged_test(n, delta, 10.0)) { ok = true; break; }
+                n.lm_lambda = nu * n.lm_lambda;
+                nu = 2 * nu;
+                continue;
+            }
+            std::memcpy(x0, xi, sizeof(x0));
+            n.lm_lambda = n.lm_lambda * std::fmax(1.0 / 3.0, 1 - std::pow(2 * rho - 1, 3));
+            ok = true;
+            break;
+        }
+        if (!ok) break;  // "lm not converged!!"
+        n.converged = converged_test(n, delta, 1.0);
+    }
+    std::memcpy(out, x0, sizeof(x0));
+}
+
+}  // namespace
+
+extern "C" {
+void* ndt_create(float resolution, int method) {
+    Ndt* n = new Ndt();
+    n->res = resolution;
+    n->set_method(method);
+    return n;
+}
+void ndt_destroy(void* h) { delete static_cast<Ndt*>(h); }
+void ndt_set_params(void* h, int max_iter, double rot_eps_deg, double trans_eps) {
+    Ndt* n = static_cast<Ndt*>(h);
+    n->max_iterations = max_iter; n->rot_eps = rot_eps_deg; n->trans_eps = trans_eps;
+}
+void ndt_set_target(void* h, const float* xyzi, int n) { static_cast<Ndt*>(h)->set_target(xyzi, n); }
+int ndt_num_voxels(void* h) { return (int)static_cast<Ndt*>(h)->vox.size(); }
+// voxel lookup by a point that falls into it: returns n (0 if absent), fills mean[3], cov[9] (regularised), cinv[9]
+int ndt_voxel_at(void* h, const float* p, float* mean, float* cov, float* cinv) {
+    Ndt* n = static_cast<Ndt*>(h);
+    auto it = n->index.find(voxel_coord(p, n->res));
+    if (it == n->index.end()) return 0;
+    const Voxel& v = n->vox[it->second];
+    std::memcpy(mean, v.mean, 12); std::memcpy(cov, v.cov, 36); std::memcpy(cinv, v.cinv, 36);
+    return v.n;
+}
+void ndt_set_source(void* h, const float* xyzi, int n) {
+    Ndt* d = static_cast<Ndt*>(h);
+    d->src.resize(3 * (size_t)n);
+    for (int i = 0; i < n; i++) for (int a = 0; a < 3; a++) d->src[3 * (size_t)i + a] = xyzi[4 * (size_t)i + a];
+}
+// linearize at T (row-major 4x4): update correspondences + H, b, error; returns #correspondences
+int ndt_linearize(void* h, const double* T, double* H36, double* b6, double* err) {
+    Ndt* n = static_cast<Ndt*>(h);
+    n->update_correspondences(T);
+    *err = n->compute_error(T, H36, b6);
+    return (int)n->corr_src.size();
+}
+double ndt_compute_error(void* h, const double* T) { return static_cast<Ndt*>(h)->compute_error(T, nullptr, nullptr); }
+int ndt_align(void* h, const double* guess, double* out, int* iterations) {
+    Ndt* n = static_cast<Ndt*>(h);
+    align(*n, guess, out);
+    *iterations = n->iterations;
+    return n->converged ? 1 : 0;
+}
+void ndt_se3_exp(const double* a6, double* T16) { se3_exp(a6, T16); }
+void ndt_regularize_plane(const float* cov9, float* out9, float* inv9) {
+    float c[9];
+    std::memcpy(c, cov9, 36);
+    regularize_plane(c);
+    std::memcpy(out9, c, 36);
+    inv3(c, inv9);
+}
+void ndt_eig3_direct(const float* cov9, float* w3, float* V9) { eig3_direct(cov9, w3, V9); }
+}

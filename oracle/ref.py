@@ -33,6 +33,10 @@ def lib():
         L.ref_ivox_num_voxels.argtypes = [C.c_void_p]
         L.ref_ivox_num_voxels.restype = C.c_uint64
         L.ref_ivox_knn.argtypes = [C.c_void_p, f32p, C.c_int, f32p, i32p]
+        f64p = C.POINTER(C.c_double)
+        L.ref_se3_exp.argtypes = [f64p, f64p]
+        L.ref_eig3_direct.argtypes = [f32p, f32p, f32p]
+        L.ref_regularize_plane.argtypes = [f32p, f32p, f32p]
         _lib = L
     return _lib
 
@@ -55,6 +59,27 @@ def esti_plane(five_xyzi, thr=0.1):
 def calc_dist(a, b):
     a, b = _f32(a), _f32(b)
     return float(lib().ref_calc_dist(_p(a, C.c_float), _p(b, C.c_float)))
+
+
+def se3_exp(a):
+    a = np.ascontiguousarray(a, np.float64)
+    T = np.zeros((4, 4))
+    lib().ref_se3_exp(_p(a, C.c_double), _p(T, C.c_double))
+    return T
+
+
+def eig3_direct(cov):
+    c = _f32(cov).reshape(3, 3)
+    w, V = np.zeros(3, np.float32), np.zeros((3, 3), np.float32)
+    lib().ref_eig3_direct(_p(c, C.c_float), _p(w, C.c_float), _p(V, C.c_float))
+    return w, V
+
+
+def regularize_plane(cov):
+    c = _f32(cov).reshape(3, 3)
+    out, inv = np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32)
+    lib().ref_regularize_plane(_p(c, C.c_float), _p(out, C.c_float), _p(inv, C.c_float))
+    return out, inv
 
 
 class IVox:

@@ -15,6 +15,8 @@ struct ImuType { double t; };
 struct RTKType { double t; };
 #include <common_lib.h>
 #include <ivox3d/ivox3d.h>
+#include <Eigen/Eigenvalues>
+#include <fast_gicp/so3/so3.hpp>
 
 #include <cstring>
 
@@ -74,6 +76,36 @@ void ref_ivox_knn(void* h, const float* q, int n, float* out_pts, int* out_cnt) 
             else { o[0] = o[1] = o[2] = o[3] = 0.f; }
         }
     }
+}
+
+// ---- localization matcher pieces that are plain Eigen / header-only reference code ---------------------------
+// fast_gicp::se3_exp (slam/thirdparty/fast_gicp/include/fast_gicp/so3/so3.hpp:80-105), the reference's own code
+void ref_se3_exp(const double* a6, double* T16) {
+    Eigen::Matrix<double, 6, 1> a;
+    for (int i = 0; i < 6; i++) a[i] = a6[i];
+    const Eigen::Isometry3d T = fast_gicp::se3_exp(a);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) T16[i * 4 + j] = T.matrix()(i, j);
+}
+// the Eigen calls of covariance_regularization.cu:15-52,105-116 (PLANE) and ndt_compute_derivatives.cu:69: the .cu
+// files cannot be compiled here, but their arithmetic is these three Eigen expressions on Matrix3f
+void ref_eig3_direct(const float* cov9, float* w3, float* V9) {
+    Eigen::Matrix3f C;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C(i, j) = cov9[i * 3 + j];
+    Eigen::SelfAdjointEigenSolver<Eigen::Matrix3f> eig;
+    eig.computeDirect(C);
+    for (int i = 0; i < 3; i++) { w3[i] = eig.eigenvalues()[i]; for (int j = 0; j < 3; j++) V9[i * 3 + j] = eig.eigenvectors()(i, j); }
+}
+void ref_regularize_plane(const float* cov9, float* out9, float* inv9) {
+    Eigen::Matrix3f C;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C(i, j) = cov9[i * 3 + j];
+    Eigen::SelfAdjointEigenSolver<Eigen::Matrix3f> eig;
+    eig.computeDirect(C);
+    const Eigen::Matrix3f vecs = eig.eigenvectors();
+    const Eigen::Matrix3f vecs_inv = vecs.inverse();
+    const Eigen::Matrix3f values_diag = Eigen::Vector3f(1e-3f, 1.0f, 1.0f).asDiagonal();
+    const Eigen::Matrix3f R = (vecs * values_diag * vecs_inv).eval();
+    const Eigen::Matrix3f Ri = R.inverse();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { out9[i * 3 + j] = R(i, j); inv9[i * 3 + j] = Ri(i, j); }
 }
 
 }  // extern "C"
