@@ -11,9 +11,10 @@
 // The reference is a chain of Thrust functors: a bounded-probe bucket table rebuilt with doubling, 13 float atomics
 // per point, seven transform launches + remove_if per linearisation and an f32 tree reduction of 43-float tuples,
 // with host<->device copies of two Isometry3f per cost evaluation.  Here:
-//   * the target map reuses the brick-coherent hash grid of hashmap.hip with the Gaussian-voxel key; one lane per
-//     voxel then folds its points IN INPUT ORDER (f32, as the reference's sums are; the order makes it reproducible),
-//     regularises (closed-form 3x3 eigen-solver) and stores mean + inverse covariance as one 64-byte record;
+//   * the target map reuses the brick-coherent hash grid of hashmap.hip with the Gaussian-voxel key; one wave per
+//     voxel then folds its points in a FIXED order derived from the input order (f32, as the reference's sums are;
+//     the order makes it reproducible), regularises (closed-form 3x3 eigen-solver) and stores mean + inverse
+//     covariance as one 64-byte record;
 //   * one kernel per cost evaluation: a lane per source point walks its 7 (1, 27) neighbour cells -- probes issued
 //     back to back --, evaluates the f32 terms and accumulates f64; correspondences are cached per point so that the
 //     LM trial evaluations reuse the linearisation point's pairs exactly as the reference does;
@@ -164,35 +165,98 @@ __global__ void __launch_bounds__(256) ndt_stamp_kernel(const float4* __restrict
     }
 }
 
-// one lane per table slot: ndt_finalize_voxels_kernel + PLANE regularisation + the inverse the cost kernel needs
-__global__ void __launch_bounds__(256) ndt_fold_kernel(const Slot* __restrict__ table, uint32_t table_cap, const float4* __restrict__ pool,
-                                                       NdtVoxel* __restrict__ vox) {
-    for (uint32_t h = blockIdx.x * 256u + threadIdx.x; h < table_cap; h += gridDim.x * 256u) {
+// list of the occupied slots (wave-aggregated append)
+__global__ void __launch_bounds__(256) ndt_list_kernel(const Slot* __restrict__ table, uint32_t table_cap, uint32_t* __restrict__ list,
+                                                       uint32_t* __restrict__ n_list, NdtVoxel* __restrict__ vox) {
+    const int lane = threadIdx.x & 63;
+    for (uint32_t h0 = blockIdx.x * 256u; h0 < table_cap; h0 += gridDim.x * 256u) {
+        const uint32_t h = h0 + threadIdx.x;
+        bool occ = false;
+        if (h < table_cap) {
+            occ = table[h].key != kEmptyKey && table[h].cnt > 0;
+            if (!occ) vox[h].n = 0;
+        }
+        const unsigned long long m = __ballot(occ);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(n_list, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (occ) list[base + __popcll(m & ((1ull << lane) - 1ull))] = h;
+        }
+    }
+}
+
+// One wave per occupied voxel: ndt_finalize_voxels_kernel + PLANE regularisation + the inverse the cost kernel needs.
+// The reference accumulates sum x and sum x x^T with unordered float atomics; here the order is fixed: the voxel's
+// points are sorted by their input index (bitonic sort in LDS), lane l accumulates the points at sorted positions
+// l, l + 64, ... in f32, and the 64 partial sums are combined in lane order -- for voxels of <= 64 points that IS the
+// plain input-order sum.  Voxels beyond kNdtSortMax points fall back to pool order (flagged; none at map scale).
+constexpr uint32_t kNdtSortMax = 2048;
+
+__global__ void __launch_bounds__(256) ndt_fold_kernel(const Slot* __restrict__ table, const float4* __restrict__ pool,
+                                                       const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                       NdtVoxel* __restrict__ vox, uint32_t* __restrict__ n_unsorted) {
+    __shared__ unsigned long long keys_s[4][kNdtSortMax];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    volatile unsigned long long* keys = keys_s[wave];
+    const uint32_t nv = *n_list;
+    for (uint32_t vi = blockIdx.x * 4 + wave; vi < nv; vi += gridDim.x * 4) {
+        const uint32_t h = list[vi];
         const Slot s = table[h];
-        NdtVoxel v;
-        v.n = 0;
-        if (s.key != kEmptyKey && s.cnt > 0) {
-            float sx[3] = {0.f, 0.f, 0.f}, sc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            // selection by ascending original index: O(cnt^2) reads of a voxel that sits in L1/L2
-            long long last = -1;
-            for (uint32_t it = 0; it < s.cnt; it++) {
-                uint32_t best = 0xFFFFFFFFu, at = 0;
-                for (uint32_t k = 0; k < s.cnt; k++) {
-                    const uint32_t idx = __float_as_uint(pool[s.ptr + k].w);
-                    if ((long long)idx > last && idx < best) { best = idx; at = k; }
+        const uint32_t cnt = s.cnt;
+        const bool sorted = cnt <= kNdtSortMax;
+        uint32_t np2 = 1;
+        if (sorted) {
+            while (np2 < cnt) np2 <<= 1;
+            for (uint32_t k = lane; k < np2; k += 64)
+                keys[k] = k < cnt ? (((unsigned long long)__float_as_uint(pool[s.ptr + k].w) << 32) | k) : ~0ull;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t k = 2; k <= np2; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = lane; t < np2; t += 64) {
+                        const uint32_t l = t ^ j;
+                        if (l > t) {
+                            const unsigned long long a = keys[t], b = keys[l];
+                            const bool up = (t & k) == 0;
+                            if ((a > b) == up) { keys[t] = b; keys[l] = a; }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
-                last = best;
-                const float4 p = pool[s.ptr + at];
-                const float q[3] = {p.x, p.y, p.z};
-                for (int a = 0; a < 3; a++) sx[a] = sx[a] + q[a];
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) sc[a * 3 + b] = sc[a * 3 + b] + q[a] * q[b];
-            }
-            const float nf = (float)s.cnt;
-            float cov[9];
-            for (int a = 0; a < 3; a++) v.mean[a] = sx[a] / nf;
+        } else if (lane == 0) {
+            atomicAdd(n_unsorted, 1u);
+        }
+        float acc[12];  // sum x (3) + sum x x^T (9)
+#pragma unroll
+        for (int a = 0; a < 12; a++) acc[a] = 0.f;
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            const uint32_t pos = sorted ? (uint32_t)keys[k] : k;
+            const float4 p = pool[s.ptr + pos];
+            const float q[3] = {p.x, p.y, p.z};
+#pragma unroll
+            for (int a = 0; a < 3; a++) acc[a] = acc[a] + q[a];
+#pragma unroll
             for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) cov[a * 3 + b] = (sc[a * 3 + b] - v.mean[a] * sx[b]) / nf;
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) acc[3 + a * 3 + b2] = acc[3 + a * 3 + b2] + q[a] * q[b2];
+        }
+        // combine the lane partials in lane order (every lane forms the identical sums)
+        float tot[12];
+#pragma unroll
+        for (int a = 0; a < 12; a++) tot[a] = 0.f;
+        const int nl = cnt < 64 ? (int)cnt : 64;
+        for (int l = 0; l < nl; l++) {
+#pragma unroll
+            for (int a = 0; a < 12; a++) tot[a] = tot[a] + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[a]), l));
+        }
+        if (lane == 0) {
+            NdtVoxel v;
+            const float nf = (float)cnt;
+            float cov[9];
+            for (int a = 0; a < 3; a++) v.mean[a] = tot[a] / nf;
+            for (int a = 0; a < 3; a++)
+                for (int b2 = 0; b2 < 3; b2++) cov[a * 3 + b2] = (tot[3 + a * 3 + b2] - v.mean[a] * tot[b2]) / nf;
             float w[3], V[9], Vi[9], VD[9], R[9];
             eig3_direct_dev(cov, w, V);
             inv3_dev(V, Vi);
@@ -200,10 +264,11 @@ __global__ void __launch_bounds__(256) ndt_fold_kernel(const Slot* __restrict__ 
             mul3_dev(V, D, VD);
             mul3_dev(VD, Vi, R);
             inv3_dev(R, v.cinv);
-            v.n = (int32_t)s.cnt;
+            v.n = (int32_t)cnt;
+            v.pad[0] = v.pad[1] = v.pad[2] = 0.f;
+            vox[h] = v;
         }
-        if (v.n) vox[h] = v;
-        else vox[h].n = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
@@ -378,6 +443,8 @@ struct lio_ndt {
     NdtReport* report_dev;  // device alias
     uint32_t seq_expected;
     float4* stamp;  // staging for set_target
+    uint32_t* list;      // occupied slots
+    uint32_t* list_cnt;  // [0] count, [1] voxels folded in pool order (more than kNdtSortMax points)
     uint64_t stamp_cap;
     uint64_t max_points;
     int method;
@@ -566,6 +633,8 @@ lio_ndt* lio_ndt_create(int device, float resolution, int search_method, uint64_
               hipMalloc(reinterpret_cast<void**>(&n->partial), (size_t)((max_source_points + kNdtThreads - 1) / kNdtThreads) * kNdtAcc * 8) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->dev), sizeof(NdtDev)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->stamp), (size_t)n->stamp_cap * sizeof(float4)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->list), (size_t)n->map->table_cap * 4) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->list_cnt), 8) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&n->report), sizeof(NdtReport), hipHostMallocMapped) == hipSuccess &&
               hipHostGetDevicePointer(reinterpret_cast<void**>(&n->report_dev), n->report, 0) == hipSuccess;
     if (ok) {
@@ -580,7 +649,7 @@ void lio_ndt_destroy(lio_ndt* n) {
     if (!n) return;
     hipSetDevice(n->device);
     if (n->map) { hipStreamSynchronize(n->map->stream); lio_map_destroy(n->map); }
-    hipFree(n->vox); hipFree(n->corr); hipFree(n->partial); hipFree(n->dev); hipFree(n->stamp);
+    hipFree(n->vox); hipFree(n->corr); hipFree(n->partial); hipFree(n->dev); hipFree(n->stamp); hipFree(n->list); hipFree(n->list_cnt);
     if (n->report) hipHostFree(n->report);
     delete n;
 }
@@ -607,7 +676,9 @@ int lio_ndt_set_target_device(lio_ndt* n, const void* d_xyzi, uint64_t np) {
     }
     uint32_t fb = (m->table_cap + 255) / 256;
     if (fb > 16384) fb = 16384;
-    hipLaunchKernelGGL(ndt_fold_kernel, fb, 256, 0, st, m->table, m->table_cap, m->pool, n->vox);
+    LIO_HIP_TRY(hipMemsetAsync(n->list_cnt, 0, 8, st));
+    hipLaunchKernelGGL(ndt_list_kernel, fb, 256, 0, st, m->table, m->table_cap, n->list, n->list_cnt, n->vox);
+    hipLaunchKernelGGL(ndt_fold_kernel, 4096, 256, 0, st, m->table, m->pool, n->list, n->list_cnt, n->vox, n->list_cnt + 1);
     LIO_HIP_TRY(hipGetLastError());
     uint64_t pts = 0, vx = 0;
     return lio_map_stats(m, &pts, &vx);

@@ -202,28 +202,44 @@ struct Ndt {
         }
     }
 
+    // The reference accumulates with unordered float atomics (gaussian_voxelmap.cu:139-148).  Fixed here (and in the
+    // HIP path) as: the voxel's points in input order, point k goes to partial sum (k mod 64), the 64 partials are
+    // combined in order 0..63 -- for voxels of <= 64 points this is the plain input-order sum.
     void set_target(const float* pts, int n) {  // points are xyz(i) with stride 4
         index.clear();
         vox.clear();
+        std::vector<std::vector<int>> members;
         for (int i = 0; i < n; i++) {
             const float* p = pts + 4 * (size_t)i;
             const K3 k = voxel_coord(p, res);
             auto it = index.find(k);
             int v;
-            if (it == index.end()) { v = (int)vox.size(); index.emplace(k, v); vox.emplace_back(); }
+            if (it == index.end()) { v = (int)vox.size(); index.emplace(k, v); vox.emplace_back(); members.emplace_back(); }
             else v = it->second;
-            Voxel& x = vox[v];
-            x.n++;
-            for (int a = 0; a < 3; a++) x.mean[a] = x.mean[a] + p[a];
-            for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) x.cov[a * 3 + b] = x.cov[a * 3 + b] + p[a] * p[b];  // mean * mean.transpose()
+            members[v].push_back(i);
         }
-        for (Voxel& x : vox) {  // ndt_finalize_voxels_kernel, then PLANE regularisation, then the inverse the derivative kernel takes
-            float sum_pts[3] = {x.mean[0], x.mean[1], x.mean[2]};
+        for (size_t v = 0; v < vox.size(); v++) {
+            Voxel& x = vox[v];
+            const std::vector<int>& mem = members[v];
+            x.n = (int)mem.size();
+            float part[64][12];
+            std::memset(part, 0, sizeof(part));
+            for (size_t k = 0; k < mem.size(); k++) {
+                const float* p = pts + 4 * (size_t)mem[k];
+                float* a = part[k % 64];
+                for (int c = 0; c < 3; c++) a[c] = a[c] + p[c];
+                for (int c = 0; c < 3; c++)
+                    for (int d = 0; d < 3; d++) a[3 + c * 3 + d] = a[3 + c * 3 + d] + p[c] * p[d];  // mean * mean.transpose()
+            }
+            float tot[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const size_t nl = mem.size() < 64 ? mem.size() : 64;
+            for (size_t l = 0; l < nl; l++)
+                for (int c = 0; c < 12; c++) tot[c] = tot[c] + part[l][c];
+            // ndt_finalize_voxels_kernel, then PLANE regularisation, then the inverse the derivative kernel takes
             const float nf = (float)x.n;
-            for (int a = 0; a < 3; a++) x.mean[a] = x.mean[a] / nf;
+            for (int a = 0; a < 3; a++) x.mean[a] = tot[a] / nf;
             for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) x.cov[a * 3 + b] = (x.cov[a * 3 + b] - x.mean[a] * sum_pts[b]) / nf;
+                for (int b = 0; b < 3; b++) x.cov[a * 3 + b] = (tot[3 + a * 3 + b] - x.mean[a] * tot[b]) / nf;
             regularize_plane(x.cov);
             inv3(x.cov, x.cinv);
         }

@@ -62,3 +62,22 @@ def test_linearize_update_golden_gpu():
     assert np.linalg.norm(s1[:3] - u["state1"][:3]) < 1e-4 and synth.quat_angle(s1[3:7], u["state1"][3:7]) < 1e-5
     assert np.abs(s1 - u["state1"]).max() < 1e-8
     assert np.allclose(e.get_cov(), u["P1"], rtol=1e-6, atol=1e-12)
+
+
+def test_ndt_golden_gpu():
+    from lsd_amd import lio
+
+    d = np.load(os.path.join(G, "ndt.npz"))
+    g = lio.Ndt(resolution=1.0, search_method=7, max_points=100_000, max_voxels=50_000, max_source_points=1 << 16)
+    g.set_target(d["map"])
+    assert g.num_voxels == int(d["n_voxels"])
+    s = lio.Scan(max_raw=1 << 16, max_ds=1 << 16)
+    s.set_ds(d["ds"])
+    lin = g.linearize(s, d["T_guess"])
+    assert lin["n_corr"] == int(d["n_corr"])
+    assert np.allclose(lin["H"], d["H"], rtol=1e-3, atol=1e-3 * np.abs(d["H"]).max())
+    assert np.allclose(lin["b"], d["b"], rtol=1e-3, atol=1e-3 * np.abs(d["b"]).max())
+    T, conv, its = g.align(s, d["T_guess"])
+    assert conv == bool(d["converged"]) and its == int(d["iterations"])
+    R = T[:3, :3] @ d["T_aligned"][:3, :3].T
+    assert np.linalg.norm(T[:3, 3] - d["T_aligned"][:3, 3]) < 1e-4 and np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1)) < 1e-5

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Localization-matcher timing (BASELINE.json config 4): 64x1875 scans, VoxelGrid(leaf) + NDT-P2D LM alignment against a
+map resident in HBM.  Two targets: the reference's semantic (a <= 200k-point local map, localization.cpp:305-308) and the
+prebuilt dense map.  Prints one JSON line per case.   python tools/bench_ndt.py [--dense-points 50000000]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lidar-slam-detection_amd", "python"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dense-points", type=int, default=50_000_000)
+    ap.add_argument("--scans", type=int, default=100)
+    ap.add_argument("--leaf", type=float, default=0.2)
+    args = ap.parse_args()
+    import torch
+
+    from lsd_amd import lio, synth
+
+    dev = torch.device("cuda", 0)
+    scene = synth.Scene(half=100.0, n_boxes=40, seed=1)
+    rng = np.random.default_rng(7)
+    scans = []
+    for k in range(8):
+        pos = np.array([rng.uniform(-4, 4), rng.uniform(-4, 4), 1.8])
+        q = synth.quat_from_rotvec([0, 0, rng.uniform(-np.pi, np.pi)])
+        raw, _ = synth.make_scan(scene, pos, q, seed=50 + k, fov_deg=(-24.8, 2.0), max_range=150.0)
+        gp, gq = synth.perturb_pose(pos, q, seed=70 + k, max_t=0.5, max_deg=3.0)
+        T, G = np.eye(4), np.eye(4)
+        T[:3, :3], T[:3, 3] = synth.quat_to_R(q), pos
+        G[:3, :3], G[:3, 3] = synth.quat_to_R(gq), gp
+        scans.append((torch.from_numpy(raw).to(dev), len(raw), T, G))
+    s = lio.Scan(max_raw=1 << 18, max_ds=200000)
+    for name, npts in (("local_200k", 200_000), ("dense", args.dense_points)):
+        pts = scene.sample_surface(npts, seed=2, sigma=0.01)
+        if name == "local_200k":  # 30 m radius around the sensor, like the reference's local map
+            pts = pts[np.linalg.norm(pts[:, :2], axis=1) < 30.0]
+        n = lio.Ndt(resolution=1.0, search_method=7, max_points=len(pts), max_voxels=max(len(pts) // 4, 200_000), max_source_points=200000)
+        d = torch.from_numpy(pts).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n.set_target_device(d.data_ptr(), len(pts))
+        nvox = n.num_voxels
+        t_build = time.perf_counter() - t0
+        del d
+        errs, its, nds = [], [], []
+        for w in range(8):
+            s.set_device(scans[w][0].data_ptr(), scans[w][1])
+            s.voxel_downsample(args.leaf)
+            n.align(s, scans[w][3])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.scans):
+            d_raw, n_raw, T, G = scans[i % len(scans)]
+            s.set_device(d_raw.data_ptr(), n_raw)
+            nds.append(s.voxel_downsample(args.leaf))
+            Ta, conv, it = n.align(s, G)
+            its.append(it + 1)
+            errs.append(float(np.linalg.norm(Ta[:3, 3] - T[:3, 3])))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"case": name, "target_points": len(pts), "target_voxels": nvox, "target_build_ms": round(1e3 * t_build, 2),
+                          "ms_per_scan": round(1e3 * dt / args.scans, 4), "scans_per_s": round(args.scans / dt, 1),
+                          "registered_points_per_s": round(120000 * args.scans / dt, 1), "n_ds_avg": float(np.mean(nds)),
+                          "lm_iterations_avg": float(np.mean(its)), "pos_err_m_median": float(np.median(errs)), "leaf": args.leaf}), flush=True)
+        n.close()
+
+
+if __name__ == "__main__":
+    main()

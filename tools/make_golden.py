@@ -95,6 +95,25 @@ def main():
                         knn=np.array([l["knn"] for l in logs]), n_eff=np.array([l["n_eff"] for l in logs]),
                         dx=np.stack([l["dx"] for l in logs]), true_pos=true_pos, true_q=true_q,
                         source="oracle update_iterated_dyn_share_modified (esekfom.hpp:1619-1931); IKFoM needs Boost: unpinned")
+    # 6. localization matcher (NDT-P2D): one linearisation and one alignment
+    import ndt as ondt
+
+    nd_map = scene.sample_surface(40000, seed=12, sigma=0.02)
+    nd = ondt.Ndt(1.0, 7)
+    nd.set_target(nd_map)
+    nd.set_source(ds)
+    T_true = np.eye(4)
+    T_true[:3, :3] = synth.quat_to_R(true_q)
+    T_true[:3, 3] = true_pos
+    gp2, gq2 = synth.perturb_pose(true_pos, true_q, seed=13, max_t=0.4, max_deg=2.5)
+    T_guess = np.eye(4)
+    T_guess[:3, :3] = synth.quat_to_R(gq2)
+    T_guess[:3, 3] = gp2
+    lin_n = nd.linearize(T_guess)
+    T_al, conv, its = nd.align(T_guess)
+    np.savez_compressed(os.path.join(OUT, "ndt.npz"), map=nd_map, ds=ds, T_guess=T_guess, T_true=T_true, n_voxels=nd.num_voxels,
+                        n_corr=lin_n["n_corr"], H=lin_n["H"], b=lin_n["b"], err=lin_n["err"], T_aligned=T_al, converged=conv, iterations=its,
+                        source="oracle/ndt_oracle.cpp (fast_gicp NDTCuda P2D restated; CUDA sources not buildable: unpinned except se3_exp / Eigen pieces)")
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
