@@ -23,7 +23,10 @@
 
 namespace lio {
 
-constexpr int kG = 32;                 // lanes per query
+#ifndef LIO_KNN_G
+#define LIO_KNN_G 32
+#endif
+constexpr int kG = LIO_KNN_G;          // lanes per query
 constexpr int kGPB = 256 / kG;         // queries per workgroup
 constexpr unsigned long long kNoKey = 0xFFFFFFFFFFFFFFFFull;
 
@@ -136,7 +139,13 @@ __global__ void __launch_bounds__(256) knn_kernel(const Slot* __restrict__ table
     const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
     unsigned long long visited = 0;
 
-    for (uint32_t q0 = blockIdx.x * kGPB; q0 < n; q0 += gridDim.x * kGPB) {
+    // XCD-aware workgroup -> query mapping: the dispatcher deals workgroups round-robin to the 8 XCDs (b % 8), each
+    // with its own L2.  Consecutive queries are spatial neighbours that share most of their candidate voxels, so
+    // every XCD gets one CONTIGUOUS eighth of the queries (gridDim.x is a multiple of 8): the shared voxels are then
+    // fetched into one L2 instead of up to eight.  Placement only affects speed, never results.
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t vb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    for (uint32_t q0 = vb * kGPB; q0 < n; q0 += gridDim.x * kGPB) {
         const uint32_t q = q0 + grp;
         const bool active = q < n;
         float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -325,13 +334,16 @@ static int launch_knn(lio_map* m, hipStream_t st, const PoseArgs& pose, const fl
     uint32_t blocks = (n_bound + kGPB - 1) / kGPB;
     if (blocks > 16384) blocks = 16384;
     if (blocks == 0) return LIO_OK;
-    if (m->stencil.n <= kG) {
-        hipLaunchKernelGGL((knn_kernel<1, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q,
-                           n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, m->dev, n_tie, tie_list);
-    } else {
-        hipLaunchKernelGGL((knn_kernel<(kMaxStencil + kG - 1) / kG, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res,
-                           m->stencil, pose, q, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, m->dev, n_tie, tie_list);
-    }
+    blocks = (blocks + 7u) & ~7u;  // multiple of 8: one contiguous slice of the queries per XCD
+#define KNN_LAUNCH(KM)                                                                                                                  \
+    hipLaunchKernelGGL((knn_kernel<KM, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q, n_host, \
+                       sd, world_out, nn_pts, nn_stride, nn_cnt, m->dev, n_tie, tie_list)
+    const int km = (m->stencil.n + kG - 1) / kG;  // stencil cells per lane
+    if (km <= 1) KNN_LAUNCH(1);
+    else if (km <= 2) KNN_LAUNCH(2);
+    else if (km <= 3) KNN_LAUNCH(3);
+    else KNN_LAUNCH((kMaxStencil + kG - 1) / kG);
+#undef KNN_LAUNCH
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }
@@ -342,13 +354,15 @@ static int launch_knn_exact(lio_map* m, hipStream_t st, const PoseArgs& pose, co
     uint32_t blocks = (n_tie_host + kGPB - 1) / kGPB;
     if (blocks == 0) return LIO_OK;
     if (blocks > 4096) blocks = 4096;
-    if (m->stencil.n <= kG) {
-        hipLaunchKernelGGL((knn_exact_kernel<1, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q,
-                           nn_pts, nn_stride, n_tie, tie_list);
-    } else {
-        hipLaunchKernelGGL((knn_exact_kernel<(kMaxStencil + kG - 1) / kG, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool,
-                           m->inv_res, m->stencil, pose, q, nn_pts, nn_stride, n_tie, tie_list);
-    }
+#define KNNX_LAUNCH(KM)                                                                                                                      \
+    hipLaunchKernelGGL((knn_exact_kernel<KM, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q, nn_pts, \
+                       nn_stride, n_tie, tie_list)
+    const int km = (m->stencil.n + kG - 1) / kG;
+    if (km <= 1) KNNX_LAUNCH(1);
+    else if (km <= 2) KNNX_LAUNCH(2);
+    else if (km <= 3) KNNX_LAUNCH(3);
+    else KNNX_LAUNCH((kMaxStencil + kG - 1) / kG);
+#undef KNNX_LAUNCH
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

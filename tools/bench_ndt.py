@@ -39,9 +39,11 @@ def main():
         scans.append((torch.from_numpy(raw).to(dev), len(raw), T, G))
     s = lio.Scan(max_raw=1 << 18, max_ds=200000)
     for name, npts in (("local_200k", 200_000), ("dense", args.dense_points)):
-        pts = scene.sample_surface(npts, seed=2, sigma=0.01)
-        if name == "local_200k":  # 30 m radius around the sensor, like the reference's local map
-            pts = pts[np.linalg.norm(pts[:, :2], axis=1) < 30.0]
+        if name == "local_200k":  # <= 200k points within 30 m of the sensor, like the reference's local map
+            pts = scene.sample_surface(3_200_000, seed=2, sigma=0.01)
+            pts = pts[np.linalg.norm(pts[:, :2], axis=1) < 30.0][:200_000]
+        else:
+            pts = scene.sample_surface(npts, seed=2, sigma=0.01)
         n = lio.Ndt(resolution=1.0, search_method=7, max_points=len(pts), max_voxels=max(len(pts) // 4, 200_000), max_source_points=200000)
         d = torch.from_numpy(pts).to(dev)
         torch.cuda.synchronize()
