@@ -191,9 +191,52 @@ typedef struct lio_timings {
     float host_solve_us, total_wall_us;
     int32_t n_knn_pass, n_pass, n_ds, n_eff_last, n_added;
     uint64_t knn_candidates; /* in-stencil points visited over all kNN passes (C-bar * N_ds * n_knn) */
+    float undistort_us;      /* lio_fastlio_main only: pose upload + point filter + motion compensation kernels */
+    float imu_host_us;       /* lio_fastlio_main only: host forward propagation (esekf::predict per IMU sample) */
 } lio_timings;
 int lio_engine_timings(lio_engine*, lio_timings* out);
 int lio_engine_enable_timing(lio_engine*, int on);
+/* ---------------------------------------------------------------------------------------------------------------
+ * The IMU front half: the reference's FastLIO entry points, one to one.  After lio_fastlio_init the engine is driven
+ * exactly like the reference's module: sensor threads enqueue, the LIO thread calls lio_fastlio_main in a loop
+ * (slam/mapping/fastlio/src/fastlio.cpp:185-210,262-276).
+ *   lio_fastlio_init ............ fastlio_init          src/laserMapping.cpp:1025-1124 (extR row-major 3x3)
+ *   lio_fastlio_is_init ......... fastlio_is_init       src/laserMapping.cpp:740-743
+ *   lio_fastlio_imu_enqueue ..... fastlio_imu_enqueue   src/laserMapping.cpp:397-415 (acc in m/s^2, divided by 9.81 inside)
+ *   lio_fastlio_pcl_enqueue ..... fastlio_pcl_enqueue   src/laserMapping.cpp:311-330 + Preprocess::velodyne_handler
+ *                                 src/preprocess.cpp:395-451: xyzi float4 + PointAttr::stamp (us relative to the header
+ *                                 stamp, common/mapping_types.h:26-29); header_stamp in seconds
+ *   lio_fastlio_main ............ fastlio_main          src/laserMapping.cpp:1126-1310: sync_packages (:445-520),
+ *                                 ImuProcess::Process (src/IMU_Processing.hpp:408-450: IMU_init :164-236, UndistortPcl
+ *                                 :238-406 with esekf::predict esekfom.hpp:279-383), then the scan-matching path
+ *   lio_fastlio_odometry ........ fastlio_odometry      src/laserMapping.cpp:692-712 (two row-major 4x4)
+ *   lio_fastlio_state ........... fastlio_state         src/laserMapping.cpp:714-738 (20 doubles)
+ * lio_fastlio_main returns one of LIO_MAIN_* (the reference returns false for IDLE and true otherwise) or a negative
+ * error.  The enqueue calls may come from other threads than lio_fastlio_main (the reference's mtx_buffer). */
+#define LIO_MAIN_FIRST_SCAN 0 /* first scan only latches first_lidar_time */
+#define LIO_MAIN_SEEDED 1     /* map was empty: seeded with this scan */
+#define LIO_MAIN_SKIPPED 2    /* too few points */
+#define LIO_MAIN_UPDATED 3    /* state updated, map extended */
+#define LIO_MAIN_IMU_INIT 4   /* IMU initialisation still collecting samples (no cloud registered) */
+#define LIO_MAIN_IDLE 5       /* sync_packages found nothing to do */
+int lio_fastlio_init(lio_engine*, const double extT[3], const double extR[9], int filter_num, int max_point_num, double scan_period,
+                     int undistort);
+int lio_fastlio_is_init(lio_engine*);
+int lio_fastlio_imu_enqueue(lio_engine*, double stamp, const double gyr[3], const double acc_ms2[3]);
+int lio_fastlio_pcl_enqueue(lio_engine*, const float* xyzi, const uint32_t* stamp_us, uint32_t n, double header_stamp);
+/* device-resident scan: the two buffers must stay valid until the lio_fastlio_main call that consumes them returned */
+int lio_fastlio_pcl_enqueue_device(lio_engine*, const void* d_xyzi, const void* d_stamp_us, uint32_t n, double header_stamp);
+int lio_fastlio_main(lio_engine*);
+int lio_fastlio_odometry(lio_engine*, double odom_s[16], double odom_e[16]);
+int lio_fastlio_state(lio_engine*, double out[20]);
+/* test visibility: p_imu->start_state_point as a 26-double state, feats_undistort (dropped points are NaN), and one
+ * esekf::predict step on the host (esekfom.hpp:279-383; Q = diagonal of the 12 x 12 process noise: ng, na, nbg, nba;
+ * acc in m/s^2) */
+int lio_fastlio_start_state(lio_engine*, double s26[26]);
+int lio_fastlio_download_undistorted(lio_engine*, float* out_xyzi, uint32_t cap, uint32_t* n);
+int lio_state_predict(const double s26[26], const double P[529], double dt, const double Q[12], const double acc[3], const double gyro[3],
+                      double s26_out[26], double P_out[529]);
+
 /* Joint registration across GPUs (BASELINE.json config 5: sub-maps one per GPU, all-gather of the per-shard
  * J^T J / J^T r sums).  When a hook is set the engine calls it after every device linearisation with its LOCAL sums and
  * continues with whatever the hook leaves in the buffer (the GLOBAL sums, identical on every rank):

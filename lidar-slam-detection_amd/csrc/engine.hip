@@ -4,6 +4,8 @@
 // both filters, INIT_TIME 0.1 s, LASER_POINT_COV 0.001, degeneracy detection on, extrinsic estimation off.
 #include <atomic>
 #include <chrono>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -12,7 +14,58 @@
 
 using namespace lio;
 
+// ---- IMU front half of fastlio_main: the buffers of laserMapping.cpp:397-415,311-330,445-520 and the members of
+// ImuProcess (IMU_Processing.hpp:31-85) ----
+struct ImuSample {
+    double stamp;
+    double acc[3], gyr[3];  // acc in units of g (fastlio_imu_enqueue divides by 9.81)
+};
+struct PinnedScan {  // one pinned staging buffer: xyzi then stamps
+    float4* xyzi = nullptr;
+    uint32_t* stamp = nullptr;
+};
+struct PendingScan {
+    double beg = 0;
+    uint32_t n = 0;
+    const float4* d_xyzi = nullptr;   // device-resident input (caller keeps it alive until fastlio_main consumed it)
+    const uint32_t* d_stamp = nullptr;
+    int pinned = -1;                  // index into Frontend::pool for host input
+};
+struct Frontend {
+    std::mutex mtx;  // mtx_buffer: the enqueue calls come from sensor threads
+    std::deque<ImuSample> imu_buffer;
+    std::deque<PendingScan> lidar_buffer;
+    std::vector<PinnedScan> pool;
+    std::vector<int> pool_free;
+    // fastlio_init arguments / Preprocess members
+    double scan_period = 0.1, blind = 0.1;
+    int filter_num = 1, max_point_num = -1;
+    bool undistort = true;
+    double Lidar_T[3] = {0, 0, 0}, Lidar_R[4] = {0, 0, 0, 1};
+    // ImuProcess members
+    bool b_first_frame = true, imu_need_init = true;
+    int init_iter_num = 1;
+    double mean_acc[3] = {0, 0, -1.0}, mean_gyr[3] = {0, 0, 0};
+    double cov_acc[3] = {0.1, 0.1, 0.1}, cov_gyr[3] = {0.1, 0.1, 0.1};
+    double cov_acc_scale[3] = {0.1, 0.1, 0.1}, cov_gyr_scale[3] = {0.1, 0.1, 0.1};
+    double cov_bias_gyr[3] = {0.0001, 0.0001, 0.0001}, cov_bias_acc[3] = {0.0001, 0.0001, 0.0001};
+    double vel_last[3] = {0, 0, 0}, angvel_last[3] = {0, 0, 0}, acc_s_last[3] = {0, 0, 0};
+    double mean_acc_norm = 0;
+    ImuSample last_imu{};
+    double last_lidar_end_time = 0;
+    LioState start_state, end_state;
+    bool have_undistorted = false;
+    // device side
+    float4* d_in = nullptr;
+    uint32_t* d_stamp = nullptr;
+    ImuPoseDev* d_poses = nullptr;
+    ImuPoseDev* h_poses = nullptr;  // pinned
+    unsigned long long* d_first = nullptr;
+    int n_poses = 0;
+};
+
 struct lio_engine {
+    Frontend* fe = nullptr;
     lio_map* map;
     lio_scan* scan;
     Eskf kf;
@@ -264,8 +317,10 @@ lio_engine* lio_engine_create_shared(lio_map* shared_map, uint32_t max_raw, uint
     return e;
 }
 
+static void frontend_destroy(lio_engine* e);
 void lio_engine_destroy(lio_engine* e) {
     if (!e) return;
+    frontend_destroy(e);
     lio_scan_destroy(e->scan);
     if (e->own_map) lio_map_destroy(e->map);
     delete e;
@@ -320,15 +375,20 @@ int lio_engine_set_static_map(lio_engine* e, int on) {
 }
 int lio_engine_timings(lio_engine* e, lio_timings* out) { if (!e || !out) return LIO_E_INVALID; *out = e->tm; return LIO_OK; }
 
+static int process_core(lio_engine* e, double lidar_beg_time);
 static int process_common(lio_engine* e, double lidar_beg_time) {
-    lio_scan* s = e->scan;
-    const auto w0 = std::chrono::steady_clock::now();
     memset(&e->tm, 0, sizeof(e->tm));
     if (e->flg_first_scan) {  // laserMapping.cpp:1171-1177
         e->first_lidar_time = lidar_beg_time;
         e->flg_first_scan = false;
         return 0;
     }
+    return process_core(e, lidar_beg_time);
+}
+// fastlio_main from "feats_undistort->empty()" on (laserMapping.cpp:1193-1304)
+static int process_core(lio_engine* e, double lidar_beg_time) {
+    lio_scan* s = e->scan;
+    const auto w0 = std::chrono::steady_clock::now();
     if (s->n_raw == 0) return 2;  // "FastLio undistort points is empty"
     e->flg_EKF_inited = (lidar_beg_time - e->first_lidar_time) < e->init_time ? false : true;
     hipEvent_t t0, t1;
@@ -456,6 +516,427 @@ void lio_state_boxminus(const double a26[26], const double b26[26], double d23[2
     state_from_array(a26, a);
     state_from_array(b26, b);
     state_boxminus(a, b, d23);
+}
+
+// =====================================================================================================================
+// IMU front half: fastlio_init / fastlio_imu_enqueue / fastlio_pcl_enqueue / sync_packages / ImuProcess / fastlio_main /
+// fastlio_odometry / fastlio_state of laserMapping.cpp + IMU_Processing.hpp.  Host side: the buffers, IMU initialisation
+// and the 23-DoF forward propagation (a dozen row-sparse 23 x 23 updates per scan); device side: the point filter and
+// the per-point motion compensation (undistort.hip), writing straight into the scan buffer the VoxelGrid reads.
+// =====================================================================================================================
+static void frontend_destroy(lio_engine* e) {
+    Frontend* f = e->fe;
+    if (!f) return;
+    hipSetDevice(e->scan->device);
+    hipStreamSynchronize(e->scan->stream);
+    for (PinnedScan& b : f->pool) hipHostFree(b.xyzi);
+    if (f->d_in) hipFree(f->d_in);
+    if (f->d_stamp) hipFree(f->d_stamp);
+    if (f->d_poses) hipFree(f->d_poses);
+    if (f->d_first) hipFree(f->d_first);
+    if (f->h_poses) hipHostFree(f->h_poses);
+    delete f;
+    e->fe = nullptr;
+}
+
+// Eigen's rotation-matrix -> quaternion assignment (what SO3(rotation_matrix) does for Lidar_R_wrt_IMU)
+static void quat_from_matrix(const double m[9], double q[4]) {
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
+        q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+        q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    }
+}
+
+static inline double norm3_eig(const double v[3]) { return sqrt(v[0] * v[0] + (v[1] * v[1] + v[2] * v[2])); }
+
+static void fe_set_Q(const Frontend* f, double Q[12]) {
+    for (int i = 0; i < 3; i++) { Q[i] = f->cov_gyr[i]; Q[3 + i] = f->cov_acc[i]; Q[6 + i] = f->cov_bias_gyr[i]; Q[9 + i] = f->cov_bias_acc[i]; }
+}
+
+// IMU_Processing.hpp:164-236
+static void fe_imu_init(lio_engine* e, const std::vector<ImuSample>& imu, double lidar_end) {
+    Frontend* f = e->fe;
+    int& N = f->init_iter_num;
+    if (f->b_first_frame) {  // Reset()
+        f->mean_acc[0] = 0; f->mean_acc[1] = 0; f->mean_acc[2] = -1.0;
+        for (int i = 0; i < 3; i++) { f->mean_gyr[i] = 0; f->vel_last[i] = 0; f->angvel_last[i] = 0; }
+        f->imu_need_init = true;
+        f->last_imu = ImuSample{};
+        N = 1;
+        f->b_first_frame = false;
+        for (int i = 0; i < 3; i++) { f->mean_acc[i] = imu.front().acc[i]; f->mean_gyr[i] = imu.front().gyr[i]; }
+    }
+    for (const ImuSample& m : imu) {
+        for (int i = 0; i < 3; i++) {
+            f->mean_acc[i] += (m.acc[i] - f->mean_acc[i]) / N;
+            f->mean_gyr[i] += (m.gyr[i] - f->mean_gyr[i]) / N;
+            f->cov_acc[i] = f->cov_acc[i] * (N - 1.0) / N + (m.acc[i] - f->mean_acc[i]) * (m.acc[i] - f->mean_acc[i]) * (N - 1.0) / (N * N);
+            f->cov_gyr[i] = f->cov_gyr[i] * (N - 1.0) / N + (m.gyr[i] - f->mean_gyr[i]) * (m.gyr[i] - f->mean_gyr[i]) * (N - 1.0) / (N * N);
+        }
+        N++;
+    }
+    const double na = norm3_eig(f->mean_acc), ng = norm3_eig(f->mean_gyr);
+    f->mean_acc_norm = na;
+    if (fabs(na - 1.0) > 0.1 || ng > (10.0 / 180.0 * M_PI)) {  // "FastLIO IMU init is not stable, reset"
+        f->b_first_frame = true;
+        return;
+    }
+    LioState& x = e->kf.x;
+    {   // S2(-mean_acc / |mean_acc| * G_m_s2): the S2 ctor re-normalises to length 9.809 (S2.hpp:124-127)
+        double g[3] = {-f->mean_acc[0] / na * 9.81, -f->mean_acc[1] / na * 9.81, -f->mean_acc[2] / na * 9.81};
+        const double z = g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);
+        if (z > 0) { const double nz = sqrt(z); for (int i = 0; i < 3; i++) g[i] /= nz; }
+        for (int i = 0; i < 3; i++) x.grav[i] = g[i] * kS2Length;
+    }
+    for (int i = 0; i < 3; i++) { x.vel[i] = f->vel_last[i]; x.bg[i] = 0; x.ba[i] = 0; x.til[i] = f->Lidar_T[i]; }
+    for (int i = 0; i < 4; i++) x.ril[i] = f->Lidar_R[i];
+    double* P = e->kf.P;
+    for (int i = 0; i < kDof * kDof; i++) P[i] = 0;
+    for (int i = 0; i < kDof; i++) P[i * kDof + i] = 1.0;
+    for (int i = 6; i < 12; i++) P[i * kDof + i] = 0.00001;
+    for (int i = 15; i < 18; i++) P[i * kDof + i] = 0.0001;
+    for (int i = 18; i < 21; i++) P[i * kDof + i] = 0.001;
+    P[21 * kDof + 21] = P[22 * kDof + 22] = 0.00001;
+    f->last_imu = imu.back();
+    f->last_lidar_end_time = lidar_end;
+    f->start_state = x;
+}
+
+static void fe_after_predict(lio_engine* e, const double angvel_avr[3], const double acc_avr[3]) {
+    Frontend* f = e->fe;
+    const LioState& x = e->kf.x;
+    const double amb[3] = {acc_avr[0] - x.ba[0], acc_avr[1] - x.ba[1], acc_avr[2] - x.ba[2]};
+    double a[3];
+    quat_rotate(x.rot, amb, a);
+    for (int i = 0; i < 3; i++) { f->angvel_last[i] = angvel_avr[i] - x.bg[i]; f->acc_s_last[i] = a[i] + x.grav[i]; }
+}
+
+static void quat_to_R_eig(const double q[4], double R[9]) {  // Eigen::QuaternionBase::toRotationMatrix
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+static int fe_push_pose(lio_engine* e, double off) {
+    Frontend* f = e->fe;
+    if (f->n_poses >= kMaxImuPoses) { set_error("more than %d IMU samples in one scan", kMaxImuPoses - 2); return LIO_E_CAPACITY; }
+    ImuPoseDev& p = f->h_poses[f->n_poses++];
+    const LioState& x = e->kf.x;
+    p.off = off;
+    for (int i = 0; i < 3; i++) { p.acc[i] = f->acc_s_last[i]; p.gyr[i] = f->angvel_last[i]; p.vel[i] = x.vel[i]; p.pos[i] = x.pos[i]; }
+    quat_to_R_eig(x.rot, p.R);
+    return LIO_OK;
+}
+
+// ImuProcess::UndistortPcl (IMU_Processing.hpp:238-406): forward propagation on the host, backward propagation on the device
+static int fe_undistort(lio_engine* e, const PendingScan& sc, const std::vector<ImuSample>& meas_imu, double lidar_end) {
+    Frontend* f = e->fe;
+    lio_scan* s = e->scan;
+    const auto h0 = std::chrono::steady_clock::now();
+    // the points start travelling first: the propagation below overlaps the copy
+    const float4* d_in = sc.d_xyzi;
+    const uint32_t* d_stamp = sc.d_stamp;
+    if (sc.pinned >= 0) {
+        const PinnedScan& b = f->pool[sc.pinned];
+        LIO_HIP_TRY(hipMemcpyAsync(f->d_in, b.xyzi, (size_t)sc.n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+        LIO_HIP_TRY(hipMemcpyAsync(f->d_stamp, b.stamp, (size_t)sc.n * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        d_in = f->d_in;
+        d_stamp = f->d_stamp;
+    }
+    const double na = norm3_eig(f->mean_acc);
+    double Q[12];
+    fe_set_Q(f, Q);
+    if (sc.beg > f->last_lidar_end_time) {  // predict the state at the scan start time
+        const double acc_avr[3] = {f->last_imu.acc[0] * 9.81 / na, f->last_imu.acc[1] * 9.81 / na, f->last_imu.acc[2] * 9.81 / na};
+        e->kf.predict(sc.beg - f->last_lidar_end_time, Q, acc_avr, f->last_imu.gyr);
+        fe_after_predict(e, f->last_imu.gyr, acc_avr);
+        f->last_lidar_end_time = sc.beg;
+    }
+    f->start_state = e->kf.x;
+    const double pcl_beg = sc.beg, pcl_end = lidar_end;
+    f->n_poses = 0;
+    int rc = fe_push_pose(e, 0.0);
+    const size_t nv = meas_imu.size() + 1;  // v_imu = last_imu_ + meas.imu
+    auto v_imu = [&](size_t k) -> const ImuSample& { return k == 0 ? f->last_imu : meas_imu[k - 1]; };
+    const double imu_end_time = v_imu(nv - 1).stamp;
+    for (size_t k = 0; k + 1 < nv && rc == LIO_OK; k++) {
+        const ImuSample &head = v_imu(k), &tail = v_imu(k + 1);
+        if (tail.stamp < f->last_lidar_end_time) continue;
+        double angvel_avr[3], acc_avr[3];
+        for (int i = 0; i < 3; i++) { angvel_avr[i] = 0.5 * (head.gyr[i] + tail.gyr[i]); acc_avr[i] = 0.5 * (head.acc[i] + tail.acc[i]) * 9.81 / na; }
+        double dt = head.stamp < f->last_lidar_end_time ? tail.stamp - f->last_lidar_end_time : tail.stamp - head.stamp;
+        dt = std::min(1.0, dt);
+        e->kf.predict(dt, Q, acc_avr, angvel_avr);
+        fe_after_predict(e, angvel_avr, acc_avr);
+        rc = fe_push_pose(e, tail.stamp - pcl_beg);
+    }
+    if (rc != LIO_OK) return rc;
+    {   // the pos and attitude prediction at the frame end
+        const ImuSample& b = v_imu(nv - 1);
+        const double acc_avr[3] = {b.acc[0] * 9.81 / na, b.acc[1] * 9.81 / na, b.acc[2] * 9.81 / na};
+        const double note = pcl_end > imu_end_time ? 1.0 : -1.0;
+        const double dt = std::min(1.0, note * (pcl_end - imu_end_time));
+        e->kf.predict(dt, Q, acc_avr, b.gyr);
+        fe_after_predict(e, b.gyr, acc_avr);
+        rc = fe_push_pose(e, pcl_end - pcl_beg);
+        if (rc != LIO_OK) return rc;
+    }
+    f->last_imu = meas_imu.back();
+    f->last_lidar_end_time = pcl_end;
+    e->tm.imu_host_us = (float)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
+    // backward propagation
+    UndistortArgs A;
+    const LioState& x = e->kf.x;
+    for (int i = 0; i < 3; i++) { A.pos_e[i] = x.pos[i]; A.til[i] = x.til[i]; }
+    for (int i = 0; i < 4; i++) { A.rot_e[i] = x.rot[i]; A.ril[i] = x.ril[i]; }
+    A.blind2 = f->blind * f->blind;
+    A.n_poses = f->n_poses;
+    A.filter_num = f->max_point_num > 0 ? std::max(1, (int)sc.n / f->max_point_num) : f->filter_num;
+    A.undistort = f->undistort ? 1 : 0;
+    hipEvent_t t0, t1;
+    if (e->timing) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, s->stream); }
+    LIO_HIP_TRY(hipMemcpyAsync(f->d_poses, f->h_poses, sizeof(ImuPoseDev) * (size_t)f->n_poses, hipMemcpyHostToDevice, s->stream));
+    rc = undistort_launch(s->stream, d_in, d_stamp, sc.n, s->raw_own, f->d_poses, A, f->d_first);
+    if (e->timing) {
+        hipEventRecord(t1, s->stream);
+        hipEventSynchronize(t1);
+        e->tm.undistort_us = ev_us(t0, t1);
+        hipEventDestroy(t0); hipEventDestroy(t1);
+    }
+    if (rc != LIO_OK) return rc;
+    s->raw = s->raw_own;
+    s->n_raw = sc.n;
+    f->have_undistorted = sc.n != 0;
+    return LIO_OK;
+}
+
+static void fe_release(Frontend* f, const PendingScan& sc) {
+    if (sc.pinned < 0) return;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    f->pool_free.push_back(sc.pinned);
+}
+
+int lio_fastlio_init(lio_engine* e, const double extT[3], const double extR[9], int filter_num, int max_point_num, double scan_period, int undistort) {
+    if (!e || !extT || !extR || !(scan_period > 0)) return LIO_E_INVALID;
+    lio_scan* s = e->scan;
+    hipSetDevice(s->device);
+    frontend_destroy(e);
+    Frontend* f = new Frontend();
+    e->fe = f;
+    for (int i = 0; i < 3; i++) f->Lidar_T[i] = extT[i];
+    quat_from_matrix(extR, f->Lidar_R);
+    f->filter_num = filter_num > 0 ? filter_num : 1;
+    f->max_point_num = max_point_num;
+    f->scan_period = scan_period;
+    f->undistort = undistort != 0;
+    LIO_HIP_TRY(hipMalloc(&f->d_in, (size_t)s->max_raw * sizeof(float4)));
+    LIO_HIP_TRY(hipMalloc(&f->d_stamp, (size_t)s->max_raw * sizeof(uint32_t)));
+    LIO_HIP_TRY(hipMalloc(&f->d_poses, sizeof(ImuPoseDev) * kMaxImuPoses));
+    LIO_HIP_TRY(hipMalloc(&f->d_first, sizeof(unsigned long long)));
+    LIO_HIP_TRY(hipMemsetAsync(f->d_first, 0xff, sizeof(unsigned long long), s->stream));
+    LIO_HIP_TRY(hipHostMalloc(&f->h_poses, sizeof(ImuPoseDev) * kMaxImuPoses, hipHostMallocDefault));
+    // the file-scope state fastlio_init resets (laserMapping.cpp:1033-1046,1107-1110)
+    e->kf = Eskf();
+    e->travel = 0;
+    e->first_lidar_time = 0;
+    e->flg_first_scan = true;
+    e->flg_EKF_inited = false;
+    e->is_degenerate = false;
+    for (int i = 0; i < 3; i++) e->last_pos_lid[i] = 0;
+    f->start_state = e->kf.x;
+    f->end_state = e->kf.x;
+    lio_scan_reset(s);
+    return LIO_OK;
+}
+
+int lio_fastlio_is_init(lio_engine* e) { return e && e->fe && !e->fe->imu_need_init ? 1 : 0; }  // ImuProcess::IsInit
+
+int lio_fastlio_imu_enqueue(lio_engine* e, double stamp, const double gyr[3], const double acc_ms2[3]) {
+    if (!e || !e->fe || !gyr || !acc_ms2) return LIO_E_INVALID;
+    ImuSample m;
+    m.stamp = stamp;
+    for (int i = 0; i < 3; i++) { m.gyr[i] = gyr[i]; m.acc[i] = acc_ms2[i] / 9.81; }
+    std::lock_guard<std::mutex> lk(e->fe->mtx);
+    e->fe->imu_buffer.push_back(m);
+    return LIO_OK;
+}
+
+static int fe_enqueue(lio_engine* e, const float* xyzi, const uint32_t* stamp_us, uint32_t n, double header_stamp, bool device) {
+    if (!e || !e->fe || (n && (!xyzi || !stamp_us))) return LIO_E_INVALID;
+    Frontend* f = e->fe;
+    lio_scan* s = e->scan;
+    if (n > s->max_raw) { set_error("scan of %u points exceeds max_raw %u", n, s->max_raw); return LIO_E_CAPACITY; }
+    PendingScan sc;
+    sc.beg = header_stamp;
+    sc.n = n;
+    if (device) {
+        sc.d_xyzi = reinterpret_cast<const float4*>(xyzi);
+        sc.d_stamp = stamp_us;
+    } else {
+        int slot = -1;
+        {
+            std::lock_guard<std::mutex> lk(f->mtx);
+            if (!f->pool_free.empty()) { slot = f->pool_free.back(); f->pool_free.pop_back(); }
+        }
+        if (slot < 0) {  // grow the pool of pinned staging buffers (recycled by fastlio_main)
+            hipSetDevice(s->device);
+            PinnedScan b;
+            void* mem = nullptr;
+            LIO_HIP_TRY(hipHostMalloc(&mem, (size_t)s->max_raw * (sizeof(float4) + sizeof(uint32_t)), hipHostMallocDefault));
+            b.xyzi = static_cast<float4*>(mem);
+            b.stamp = reinterpret_cast<uint32_t*>(b.xyzi + s->max_raw);
+            std::lock_guard<std::mutex> lk(f->mtx);
+            f->pool.push_back(b);
+            slot = (int)f->pool.size() - 1;
+        }
+        PinnedScan b;
+        { std::lock_guard<std::mutex> lk(f->mtx); b = f->pool[slot]; }
+        memcpy(b.xyzi, xyzi, (size_t)n * sizeof(float4));
+        memcpy(b.stamp, stamp_us, (size_t)n * sizeof(uint32_t));
+        sc.pinned = slot;
+    }
+    std::lock_guard<std::mutex> lk(f->mtx);
+    f->lidar_buffer.push_back(sc);
+    return LIO_OK;
+}
+int lio_fastlio_pcl_enqueue(lio_engine* e, const float* xyzi, const uint32_t* stamp_us, uint32_t n, double header_stamp) {
+    return fe_enqueue(e, xyzi, stamp_us, n, header_stamp, false);
+}
+int lio_fastlio_pcl_enqueue_device(lio_engine* e, const void* d_xyzi, const void* d_stamp_us, uint32_t n, double header_stamp) {
+    return fe_enqueue(e, static_cast<const float*>(d_xyzi), static_cast<const uint32_t*>(d_stamp_us), n, header_stamp, true);
+}
+
+int lio_fastlio_main(lio_engine* e) {
+    if (!e || !e->fe) return LIO_E_INVALID;
+    Frontend* f = e->fe;
+    lio_scan* s = e->scan;
+    PendingScan sc;
+    std::vector<ImuSample> meas_imu;
+    double lidar_end;
+    {   // sync_packages (laserMapping.cpp:445-520)
+        std::lock_guard<std::mutex> lk(f->mtx);
+        if (f->lidar_buffer.empty() || f->imu_buffer.empty()) return LIO_MAIN_IDLE;
+        sc = f->lidar_buffer.front();
+        f->lidar_buffer.pop_front();
+        lidar_end = sc.beg + f->scan_period;
+        while (!f->imu_buffer.empty() && !(f->imu_buffer.front().stamp > lidar_end)) {
+            meas_imu.push_back(f->imu_buffer.front());
+            f->imu_buffer.pop_front();
+        }
+    }
+    hipSetDevice(s->device);
+    memset(&e->tm, 0, sizeof(e->tm));
+    if (e->flg_first_scan) {  // laserMapping.cpp:1171-1177
+        e->first_lidar_time = sc.beg;
+        e->flg_first_scan = false;
+        fe_release(f, sc);
+        return LIO_MAIN_FIRST_SCAN;
+    }
+    int rc;
+    if (meas_imu.empty()) {
+        // ImuProcess::Process returns at once: feats_undistort still holds the PREVIOUS scan's cloud, which fastlio_main
+        // then registers again (IMU_Processing.hpp:413, laserMapping.cpp:1189-1197)
+        fe_release(f, sc);
+        if (!f->have_undistorted) return LIO_MAIN_IMU_INIT;
+        rc = process_core(e, sc.beg);
+        f->end_state = e->kf.x;
+        return rc;
+    }
+    if (f->imu_need_init) {  // IMU_Processing.hpp:416-441
+        fe_imu_init(e, meas_imu, lidar_end);
+        f->imu_need_init = true;
+        f->last_imu = meas_imu.back();
+        if (f->init_iter_num > 100) {  // MAX_INI_COUNT
+            f->imu_need_init = false;
+            for (int i = 0; i < 3; i++) { f->cov_acc[i] = f->cov_acc_scale[i]; f->cov_gyr[i] = f->cov_gyr_scale[i]; }
+        }
+        fe_release(f, sc);
+        return LIO_MAIN_IMU_INIT;
+    }
+    rc = fe_undistort(e, sc, meas_imu, lidar_end);
+    if (rc != LIO_OK) { fe_release(f, sc); return rc; }
+    rc = process_core(e, sc.beg);
+    if (sc.pinned >= 0) hipStreamSynchronize(s->stream);  // the staging buffer goes back to the pool only after its copy ran
+    fe_release(f, sc);
+    f->end_state = e->kf.x;
+    return rc;
+}
+
+static void odom_matrix(const LioState& x, double T[16]) {  // pos + Quaterniond(rot).normalized().toRotationMatrix()
+    double q[4] = {x.rot[0], x.rot[1], x.rot[2], x.rot[3]};
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (n2 > 0) { const double n = sqrt(n2); for (int i = 0; i < 4; i++) q[i] /= n; }
+    double R[9];
+    quat_to_R_eig(q, R);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = x.pos[i];
+        T[12 + i] = 0;
+    }
+    T[15] = 1;
+}
+int lio_fastlio_odometry(lio_engine* e, double odom_s[16], double odom_e[16]) {
+    if (!e || !e->fe || !odom_s || !odom_e) return LIO_E_INVALID;
+    odom_matrix(e->fe->start_state, odom_s);
+    odom_matrix(e->kf.x, odom_e);
+    return LIO_OK;
+}
+int lio_fastlio_state(lio_engine* e, double out[20]) {  // laserMapping.cpp:714-738: start_state_point + mean_acc_norm
+    if (!e || !e->fe || !out) return LIO_E_INVALID;
+    const LioState& x = e->fe->start_state;
+    for (int i = 0; i < 3; i++) { out[i] = x.pos[i]; out[7 + i] = x.vel[i]; out[10 + i] = x.ba[i]; out[13 + i] = x.bg[i]; out[16 + i] = x.grav[i]; }
+    for (int i = 0; i < 4; i++) out[3 + i] = x.rot[i];
+    out[19] = e->fe->mean_acc_norm;
+    return LIO_OK;
+}
+int lio_fastlio_start_state(lio_engine* e, double s26[26]) {
+    if (!e || !e->fe || !s26) return LIO_E_INVALID;
+    state_to_array(e->fe->start_state, s26);
+    return LIO_OK;
+}
+int lio_fastlio_download_undistorted(lio_engine* e, float* out_xyzi, uint32_t cap, uint32_t* n) {
+    if (!e || !e->fe || !n) return LIO_E_INVALID;
+    lio_scan* s = e->scan;
+    *n = e->fe->have_undistorted ? s->n_raw : 0;
+    if (*n > cap) return LIO_E_CAPACITY;
+    if (*n && !out_xyzi) return LIO_E_INVALID;
+    hipSetDevice(s->device);
+    if (*n) {
+        LIO_HIP_TRY(hipMemcpyAsync(out_xyzi, s->raw, (size_t)*n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return LIO_OK;
+}
+int lio_state_predict(const double s26[26], const double P[529], double dt, const double Q[12], const double acc[3], const double gyro[3],
+                      double s26_out[26], double P_out[529]) {
+    if (!s26 || !P || !Q || !acc || !gyro || !s26_out || !P_out) return LIO_E_INVALID;
+    Eskf kf;
+    state_from_array(s26, kf.x);
+    memcpy(kf.P, P, sizeof(double) * 529);
+    kf.predict(dt, Q, acc, gyro);
+    state_to_array(kf.x, s26_out);
+    memcpy(P_out, kf.P, sizeof(double) * 529);
+    return LIO_OK;
 }
 
 }  // extern "C"

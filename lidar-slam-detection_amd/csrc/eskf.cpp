@@ -490,4 +490,147 @@ int Eskf::step(Work& w, double R, const Measurement& m, int i, bool& converge, i
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// predict.  F_x1 = I + f_x_final * dt has ~40 entries off the identity and W = dt * f_w_final ~24, so the two
+// 23^3 products of the reference are done row-sparse: the non-zero pattern is read off the dense matrices
+// (built exactly as esekfom.hpp builds them) and the sums skip exact zeros in the original k order, which
+// leaves every result bit unchanged.
+// ---------------------------------------------------------------------------------------------------------
+void Eskf::predict(double dt, const double Q[12], const double acc[3], const double gyro[3]) {
+    constexpr int n = kDof;
+    // get_f: 24 entries, only pos / rot / vel rows are non-zero
+    double f[24] = {0};
+    const double amb[3] = {acc[0] - x.ba[0], acc[1] - x.ba[1], acc[2] - x.ba[2]};
+    double a_in[3];
+    quat_rotate(x.rot, amb, a_in);
+    for (int i = 0; i < 3; i++) { f[i] = x.vel[i]; f[3 + i] = gyro[i] - x.bg[i]; f[12 + i] = a_in[i] + x.grav[i]; }
+    // df_dx (24 x 23), df_dw (24 x 12)
+    static thread_local double fx[24 * n], fw[24 * 12], fxf[n * n], fwf[n * 12], F1[n * n], FP[n * n], Pn[n * n];
+    memset(fx, 0, sizeof(fx));
+    memset(fw, 0, sizeof(fw));
+    double R[9], H[9], RH[9];
+    quat_to_R(x.rot, R);
+    hat3(amb, H);
+    mm3(R, H, RH);
+    for (int i = 0; i < 3; i++) {
+        fx[i * n + 12 + i] = 1.0;
+        fx[(3 + i) * n + 15 + i] = -1.0;
+        for (int j = 0; j < 3; j++) {
+            fx[(12 + i) * n + 3 + j] = -RH[i * 3 + j];
+            fx[(12 + i) * n + 18 + j] = -R[i * 3 + j];
+            fw[(12 + i) * 12 + 3 + j] = -R[i * 3 + j];
+        }
+        fw[(3 + i) * 12 + i] = -1.0;
+        fw[(15 + i) * 12 + 6 + i] = 1.0;
+        fw[(18 + i) * 12 + 9 + i] = 1.0;
+    }
+    const double zero2[2] = {0, 0};
+    {
+        double Mx[6];
+        s2_Mx(x.grav, zero2, Mx);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 2; j++) fx[(12 + i) * n + 21 + j] = Mx[i * 2 + j];
+    }
+    const LioState x_before = x;
+    // x_.oplus(f_, dt): vect += dt * f, SO3 *= exp(f, dt / 2 inside mtk exp), S2 with f == 0 stays
+    for (int i = 0; i < 3; i++) {
+        x.pos[i] += dt * f[i]; x.til[i] += dt * f[9 + i]; x.vel[i] += dt * f[12 + i]; x.bg[i] += dt * f[15 + i]; x.ba[i] += dt * f[18 + i];
+    }
+    {
+        double e[4], q[4];
+        so3_exp(f + 3, dt / 2, e);
+        quat_mul(x.rot, e, q);
+        memcpy(x.rot, q, sizeof(q));
+        so3_exp(f + 6, dt / 2, e);
+        quat_mul(x.ril, e, q);
+        memcpy(x.ril, q, sizeof(q));
+    }
+    memset(fxf, 0, sizeof(fxf));
+    memset(fwf, 0, sizeof(fwf));
+    for (int i = 0; i < n * n; i++) F1[i] = 0;
+    for (int i = 0; i < n; i++) F1[i * n + i] = 1.0;
+    static const int vect_idx[5] = {0, 9, 12, 15, 18};
+    for (int v = 0; v < 5; v++)
+        for (int j = 0; j < 3; j++) {
+            memcpy(fxf + (vect_idx[v] + j) * n, fx + (vect_idx[v] + j) * n, sizeof(double) * n);
+            memcpy(fwf + (vect_idx[v] + j) * 12, fw + (vect_idx[v] + j) * 12, sizeof(double) * 12);
+        }
+    for (int idx = 3; idx <= 6; idx += 3) {  // SO3 states: F_x1 block = exp(seg, scalar(1/2) == 0) = identity (esekfom.hpp:312)
+        const double seg[3] = {-f[idx] * dt, -f[idx + 1] * dt, -f[idx + 2] * dt};
+        double A[9];
+        so3_A_matrix(seg, A);
+        for (int i = 0; i < n; i++) {
+            const double v[3] = {fx[idx * n + i], fx[(idx + 1) * n + i], fx[(idx + 2) * n + i]};
+            for (int a = 0; a < 3; a++) fxf[(idx + a) * n + i] = A[a * 3] * v[0] + A[a * 3 + 1] * v[1] + A[a * 3 + 2] * v[2];
+        }
+        for (int i = 0; i < 12; i++) {
+            const double v[3] = {fw[idx * 12 + i], fw[(idx + 1) * 12 + i], fw[(idx + 2) * 12 + i]};
+            for (int a = 0; a < 3; a++) fwf[(idx + a) * 12 + i] = A[a * 3] * v[0] + A[a * 3 + 1] * v[1] + A[a * 3 + 2] * v[2];
+        }
+    }
+    {  // S2 state: idx 21 (dof), dim 21
+        const double seg[3] = {f[21] * dt, f[22] * dt, f[23] * dt};
+        double Nx[6], Mx[6], Hb[9], A[9], T[9], res23[6];
+        s2_Nx_yy(x.grav, Nx);
+        s2_Mx(x_before.grav, zero2, Mx);
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) {
+                double s2 = 0;
+                for (int k = 0; k < 3; k++) s2 += Nx[a * 3 + k] * Mx[k * 2 + b];
+                F1[(21 + a) * n + 21 + b] = s2;
+            }
+        hat3(x_before.grav, Hb);
+        so3_A_matrix(seg, A);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s2 = 0;
+                for (int k = 0; k < 3; k++) s2 += Hb[i * 3 + k] * A[j * 3 + k];
+                T[i * 3 + j] = s2;
+            }
+        for (int a = 0; a < 2; a++)
+            for (int j = 0; j < 3; j++) {
+                double s2 = 0;
+                for (int k = 0; k < 3; k++) s2 += Nx[a * 3 + k] * T[k * 3 + j];
+                res23[a * 3 + j] = -s2;
+            }
+        for (int i = 0; i < n; i++) {
+            const double v[3] = {fx[21 * n + i], fx[22 * n + i], fx[23 * n + i]};
+            for (int a = 0; a < 2; a++) fxf[(21 + a) * n + i] = res23[a * 3] * v[0] + res23[a * 3 + 1] * v[1] + res23[a * 3 + 2] * v[2];
+        }
+        for (int i = 0; i < 12; i++) {
+            const double v[3] = {fw[21 * 12 + i], fw[22 * 12 + i], fw[23 * 12 + i]};
+            for (int a = 0; a < 2; a++) fwf[(21 + a) * 12 + i] = res23[a * 3] * v[0] + res23[a * 3 + 1] * v[1] + res23[a * 3 + 2] * v[2];
+        }
+    }
+    for (int i = 0; i < n * n; i++) F1[i] += fxf[i] * dt;
+    // row-sparse patterns
+    int nzc[n][n], nzn[n], wzc[n][12], wzn[n];
+    for (int i = 0; i < n; i++) {
+        nzn[i] = 0;
+        for (int k = 0; k < n; k++)
+            if (F1[i * n + k] != 0.0) nzc[i][nzn[i]++] = k;
+        wzn[i] = 0;
+        for (int k = 0; k < 12; k++) {
+            fwf[i * 12 + k] = dt * fwf[i * 12 + k];
+            if (fwf[i * 12 + k] != 0.0) wzc[i][wzn[i]++] = k;
+        }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s2 = 0;
+            for (int c = 0; c < nzn[i]; c++) { const int k = nzc[i][c]; s2 += F1[i * n + k] * P[k * n + j]; }
+            FP[i * n + j] = s2;
+        }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s2 = 0;
+            for (int c = 0; c < nzn[j]; c++) { const int k = nzc[j][c]; s2 += FP[i * n + k] * F1[j * n + k]; }
+            double q = 0;
+            if (wzn[i] && wzn[j])
+                for (int c = 0; c < wzn[i]; c++) { const int k = wzc[i][c]; q += fwf[i * 12 + k] * Q[k] * fwf[j * 12 + k]; }
+            Pn[i * n + j] = s2 + q;
+        }
+    memcpy(P, Pn, sizeof(Pn));
+}
+
 }  // namespace lio

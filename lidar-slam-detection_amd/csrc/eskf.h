@@ -7,6 +7,7 @@
 //   A_matrix, exp, log ........ mtk/src/mtkmath.hpp:142-174,235-288
 //   S2 Bx / Nx_yy / Mx ........ mtk/types/S2.hpp:179-197,259-280
 //   iterated update ........... esekfom/esekfom.hpp:1619-1931 (update_iterated_dyn_share_modified)
+//   forward propagation ....... esekfom/esekfom.hpp:279-383 (predict), use-ikfom.hpp:47-88 (process model)
 // The update consumes the 6x6 / 6 normal equations that the device reduction produces instead of an
 // N x 15 Jacobian: with extrinsic_est_en == false (laserMapping.cpp:82) columns 6..14 of h_x are zero, so
 // h_x^T h_x and h_x^T h are exactly those blocks.
@@ -56,6 +57,9 @@ struct Eskf {
     int maximum_iter = 4;  // fastlio_init: NUM_MAX_ITERATIONS 4 (laserMapping.cpp:1026,1116)
 
     Eskf();
+    // esekf::predict (esekfom.hpp:279-383) with get_f / df_dx / df_dw of use-ikfom.hpp:47-88.  Q is the diagonal of the
+    // 12 x 12 process noise (ng, na, nbg, nba).  acc in m/s^2, gyro in rad/s.
+    void predict(double dt, const double Q[12], const double acc[3], const double gyro[3]);
     // one call of update_iterated_dyn_share_modified; `measure(x, converge, m)` plays h_dyn_share.
     // Returns the number of measurement evaluations made.
     template <typename F>

@@ -147,6 +147,20 @@ struct lio_scan {
 
 namespace lio {
 // kernels' host-side launchers (defined in the .hip files)
+// ---- IMU front half (undistort.hip) ----
+constexpr int kMaxImuPoses = 128;
+struct ImuPoseDev {  // Pose6D of common_lib.h:31-39 in f64, as UndistortPcl fills it (IMU_Processing.hpp:284,337,357)
+    double off;      // offset_time from the scan start, s
+    double acc[3], gyr[3], vel[3], pos[3], R[9];
+};
+struct UndistortArgs {
+    double pos_e[3], rot_e[4], ril[4], til[3];  // state at the scan end
+    double blind2;
+    int n_poses, filter_num, undistort;
+};
+int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const ImuPoseDev* d_poses,
+                     const UndistortArgs& args, unsigned long long* d_first_key);
+
 int vg_downsample(lio_scan* s, float leaf);
 int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);

@@ -1,0 +1,146 @@
+// undistort.hip -- Preprocess::velodyne_handler's point filter + ImuProcess::UndistortPcl's backward propagation
+// (/root/reference/slam/mapping/fastlio/src/preprocess.cpp:395-451, IMU_Processing.hpp:371-404) as one pass over the
+// raw scan in HBM.
+//
+// The reference sorts the cloud by per-point time and walks it backwards with a moving IMU-segment cursor; on the
+// device every point finds its segment itself (<= 128 IMU poses, staged in LDS) and is compensated independently:
+//   P_c = R_LI^T ( R_e^T ( R_h Exp(w_t dt) (R_LI P + t_LI) + p_h + v_h dt + a_t dt^2 / 2 - p_e ) - t_LI )
+// in f64 with Eigen's scalar evaluation order (-ffp-contract=off; sin / cos are the device libm, so results agree with
+// the CPU to the last f32 bit except where a 1-ulp f64 difference crosses an f32 rounding boundary).
+// Points the reference would not have pushed into the cloud (blind radius, point_filter_num) are written as NaN: the
+// VoxelGrid kernels drop non-finite points, which is the same thing as their not being there.
+// 20 B in (xyzi + stamp) and 16 B out per point: HBM-bound, ~4.5 MB per 120 k-point scan.
+#include "lio_common.h"
+
+namespace lio {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ inline void cross3d(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// Eigen QuaternionBase::_transformVector
+__device__ inline void qrot_d(const double q[4], const double v[3], double o[3]) {
+    double uv[3], c2[3];
+    cross3d(q, v, uv);
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    cross3d(q, uv, c2);
+    for (int a = 0; a < 3; a++) o[a] = (v[a] + q[3] * uv[a]) + c2[a];
+}
+
+__device__ inline void compensate(const UndistortArgs& A, const ImuPoseDev* poses, int h, double t, float& px, float& py, float& pz) {
+    const ImuPoseDev& head = poses[h];
+    const ImuPoseDev& tail = poses[h + 1];
+    const double dt = t - head.off;
+    // so3_math.h Exp(ang_vel, dt)
+    double Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double w0 = tail.gyr[0], w1 = tail.gyr[1], w2 = tail.gyr[2];
+    const double n = sqrt(w0 * w0 + (w1 * w1 + w2 * w2));
+    if (n > 0.0000001) {
+        const double ax = w0 / n, ay = w1 / n, az = w2 / n;
+        const double K[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+        const double th = n * dt, sn = sin(th), cs = 1.0 - cos(th);
+        double sK[9];
+        for (int i = 0; i < 9; i++) sK[i] = cs * K[i];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                const double kk = sK[i * 3] * K[j] + (sK[i * 3 + 1] * K[3 + j] + sK[i * 3 + 2] * K[6 + j]);
+                Rd[i * 3 + j] = (Rd[i * 3 + j] + sn * K[i * 3 + j]) + kk;
+            }
+    }
+    double Ri[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Ri[i * 3 + j] = head.R[i * 3] * Rd[j] + (head.R[i * 3 + 1] * Rd[3 + j] + head.R[i * 3 + 2] * Rd[6 + j]);
+    const double Pi[3] = {(double)px, (double)py, (double)pz};
+    double T_ei[3], pl[3], pw[3], pe[3], pc[3];
+    for (int a = 0; a < 3; a++) T_ei[a] = head.pos[a] + head.vel[a] * dt + 0.5 * tail.acc[a] * dt * dt - A.pos_e[a];
+    qrot_d(A.ril, Pi, pl);
+    for (int a = 0; a < 3; a++) pl[a] += A.til[a];
+    for (int a = 0; a < 3; a++) pw[a] = (Ri[a * 3] * pl[0] + (Ri[a * 3 + 1] * pl[1] + Ri[a * 3 + 2] * pl[2])) + T_ei[a];
+    const double rc[4] = {-A.rot_e[0], -A.rot_e[1], -A.rot_e[2], A.rot_e[3]};
+    qrot_d(rc, pw, pe);
+    for (int a = 0; a < 3; a++) pe[a] -= A.til[a];
+    const double lc[4] = {-A.ril[0], -A.ril[1], -A.ril[2], A.ril[3]};
+    qrot_d(lc, pe, pc);
+    px = (float)pc[0]; py = (float)pc[1]; pz = (float)pc[2];
+}
+
+// the last head whose offset lies strictly before t; -1 when t <= poses[0].off (the point stays as it is)
+__device__ inline int find_segment(const ImuPoseDev* poses, int n_poses, double t) {
+    int h = -1;
+    for (int k = n_poses - 2; k >= 0; k--)
+        if (t > poses[k].off) { h = k; break; }
+    return h;
+}
+
+__global__ __launch_bounds__(kThreads) void undistort_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ stamp_us, uint32_t n,
+                                                             float4* __restrict__ out, const ImuPoseDev* __restrict__ g_poses, UndistortArgs A,
+                                                             unsigned long long* first_key) {
+    __shared__ ImuPoseDev poses[kMaxImuPoses];
+    {
+        const double* src = reinterpret_cast<const double*>(g_poses);
+        double* dst = reinterpret_cast<double*>(poses);
+        const int words = A.n_poses * (int)(sizeof(ImuPoseDev) / sizeof(double));
+        for (int i = threadIdx.x; i < words; i += kThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    float4 p = in[i];
+    const float nanv = __int_as_float(0x7fc00000);
+    bool keep = (A.filter_num <= 1) || (i % (uint32_t)A.filter_num == 0);
+    keep = keep && ((double)(p.x * p.x + p.y * p.y + p.z * p.z) > A.blind2);
+    if (!keep) {
+        out[i] = make_float4(nanv, nanv, nanv, p.w);
+        return;
+    }
+    if (A.undistort) {
+        const float t_ms = (float)stamp_us[i] / 1000.0f;  // added_pt.curvature = attr.stamp / 1000.0f (ms)
+        const double t = (double)t_ms / double(1000);
+        const int h = find_segment(poses, A.n_poses, t);
+        if (h >= 0) compensate(A, poses, h, t, p.x, p.y, p.z);
+        // earliest kept point (lowest index among equals): the sorted cloud's begin(), see undistort_first_kernel
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t_ms) << 32) | i;
+        if (key < *reinterpret_cast<volatile unsigned long long*>(first_key)) atomicMin(first_key, key);
+    }
+    out[i] = p;
+}
+
+// The reference's backward walk parks its iterator on the earliest point (`if (it_pcl == begin) break`) and lets every
+// earlier IMU segment compensate that one point AGAIN, on the already compensated coordinates (IMU_Processing.hpp:371-404).
+// It only happens when that point's time is > 0; kept for parity.  One thread.
+__global__ void undistort_first_kernel(float4* out, const ImuPoseDev* __restrict__ poses, UndistortArgs A, unsigned long long* first_key) {
+    const unsigned long long key = *first_key;
+    *first_key = ~0ull;  // re-arm for the next scan
+    if (key == ~0ull) return;
+    const uint32_t i = (uint32_t)key;
+    const float t_ms = __uint_as_float((uint32_t)(key >> 32));
+    const double t = (double)t_ms / double(1000);
+    const int h = find_segment(poses, A.n_poses, t);
+    if (h <= 0) return;
+    float4 p = out[i];
+    for (int k = h - 1; k >= 0; k--)
+        if (t > poses[k].off) compensate(A, poses, k, t, p.x, p.y, p.z);
+    out[i] = p;
+}
+
+}  // namespace
+
+int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const ImuPoseDev* d_poses,
+                     const UndistortArgs& args, unsigned long long* d_first_key) {
+    if (n == 0) return LIO_OK;
+    if (args.undistort && (args.n_poses < 2 || args.n_poses > kMaxImuPoses)) {
+        set_error("undistort: %d IMU poses (2..%d supported)", args.n_poses, kMaxImuPoses);
+        return LIO_E_CAPACITY;
+    }
+    hipLaunchKernelGGL(undistort_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, d_in, d_stamp_us, n, d_out, d_poses, args, d_first_key);
+    if (args.undistort) hipLaunchKernelGGL(undistort_first_kernel, dim3(1), dim3(1), 0, stream, d_out, d_poses, args, d_first_key);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+}  // namespace lio

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblio_hip.so")
 
 LIO_OK, LIO_E_INVALID, LIO_E_CAPACITY, LIO_E_DEVICE, LIO_E_STATE = 0, -1, -2, -3, -4
+MAIN_FIRST_SCAN, MAIN_SEEDED, MAIN_SKIPPED, MAIN_UPDATED, MAIN_IMU_INIT, MAIN_IDLE = 0, 1, 2, 3, 4, 5  # lio_fastlio_main
 
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
@@ -26,6 +27,9 @@ SYMBOLS = [
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
     "lio_engine_enable_timing", "lio_engines_process_batch", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
+    "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
+    "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
+    "lio_state_predict",
     "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_voxel_at",
     "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align",
 ]
@@ -47,7 +51,7 @@ class Timings(C.Structure):
     _fields_ = [("downsample_us", C.c_float), ("knn_us", C.c_float), ("linearize_us", C.c_float), ("insert_us", C.c_float),
                 ("total_device_us", C.c_float), ("host_solve_us", C.c_float), ("total_wall_us", C.c_float), ("n_knn_pass", C.c_int32),
                 ("n_pass", C.c_int32), ("n_ds", C.c_int32), ("n_eff_last", C.c_int32), ("n_added", C.c_int32),
-                ("knn_candidates", C.c_uint64)]
+                ("knn_candidates", C.c_uint64), ("undistort_us", C.c_float), ("imu_host_us", C.c_float)]
 
 
 class ScanJob(C.Structure):
@@ -137,6 +141,17 @@ def lib():
     sig("lio_engine_enable_timing", cint, vp, cint)
     sig("lio_engines_process_batch", cint, C.POINTER(vp), cint, C.POINTER(ScanJob), cint)
     sig("lio_engine_set_static_map", cint, vp, cint)
+    sig("lio_fastlio_init", cint, vp, f64p, f64p, cint, cint, dbl, cint)
+    sig("lio_fastlio_is_init", cint, vp)
+    sig("lio_fastlio_imu_enqueue", cint, vp, dbl, f64p, f64p)
+    sig("lio_fastlio_pcl_enqueue", cint, vp, f32p, C.POINTER(u32), u32, dbl)
+    sig("lio_fastlio_pcl_enqueue_device", cint, vp, vp, vp, u32, dbl)
+    sig("lio_fastlio_main", cint, vp)
+    sig("lio_fastlio_odometry", cint, vp, f64p, f64p)
+    sig("lio_fastlio_state", cint, vp, f64p)
+    sig("lio_fastlio_start_state", cint, vp, f64p)
+    sig("lio_fastlio_download_undistorted", cint, vp, f32p, u32, C.POINTER(u32))
+    sig("lio_state_predict", cint, f64p, f64p, dbl, f64p, f64p, f64p, f64p, f64p)
     sig("lio_scan_enable_kernel_timing", cint, vp, cint)
     sig("lio_scan_kernel_times", cint, vp, C.POINTER(KernelTimes), cint)
     sig("lio_ndt_create", vp, cint, flt, cint, u64, u64, u32)

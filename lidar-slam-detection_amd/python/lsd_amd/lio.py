@@ -280,6 +280,55 @@ class Engine:
     def enable_timing(self, on=True):
         check(lib().lio_engine_enable_timing(self.h, int(on)))
 
+    # ---- the IMU front half: fastlio_init / _imu_enqueue / _pcl_enqueue / _main / _odometry / _state
+    # (reference: slam/mapping/fastlio/src/laserMapping.cpp:1025,397,311,1126,692,714) ----
+    def fastlio_init(self, extT=(0.0, 0.0, 0.0), extR=np.eye(3), filter_num=1, max_point_num=-1, scan_period=0.1, undistort=True):
+        t, r = f64(extT), f64(extR).reshape(-1)
+        assert t.size == 3 and r.size == 9
+        check(lib().lio_fastlio_init(self.h, ptr(t, C.c_double), ptr(r, C.c_double), filter_num, max_point_num, float(scan_period), int(undistort)))
+
+    def fastlio_is_init(self):
+        return bool(lib().lio_fastlio_is_init(self.h))
+
+    def fastlio_imu_enqueue(self, stamp, gyr, acc_ms2):
+        g, a = f64(gyr), f64(acc_ms2)
+        check(lib().lio_fastlio_imu_enqueue(self.h, float(stamp), ptr(g, C.c_double), ptr(a, C.c_double)))
+
+    def fastlio_pcl_enqueue(self, xyzi, stamp_us, header_stamp):
+        p = f32(xyzi).reshape(-1, 4)
+        t = np.ascontiguousarray(stamp_us, np.uint32)
+        assert len(t) == len(p)
+        check(lib().lio_fastlio_pcl_enqueue(self.h, ptr(p, C.c_float), ptr(t, C.c_uint32), len(p), float(header_stamp)))
+
+    def fastlio_pcl_enqueue_device(self, d_xyzi, d_stamp_us, n, header_stamp):
+        check(lib().lio_fastlio_pcl_enqueue_device(self.h, C.c_void_p(d_xyzi), C.c_void_p(d_stamp_us), n, float(header_stamp)))
+
+    def fastlio_main(self):
+        """one fastlio_main pass; returns capi MAIN_* (IDLE when there was nothing to do)"""
+        return check(lib().lio_fastlio_main(self.h), "fastlio_main")
+
+    def fastlio_odometry(self):
+        a, b = np.zeros(16), np.zeros(16)
+        check(lib().lio_fastlio_odometry(self.h, ptr(a, C.c_double), ptr(b, C.c_double)))
+        return a.reshape(4, 4), b.reshape(4, 4)
+
+    def fastlio_state(self):
+        s = np.zeros(20)
+        check(lib().lio_fastlio_state(self.h, ptr(s, C.c_double)))
+        return s
+
+    def fastlio_start_state(self):
+        s = np.zeros(STATE_DIM)
+        check(lib().lio_fastlio_start_state(self.h, ptr(s, C.c_double)))
+        return s
+
+    def undistorted(self, cap=300000):
+        out = np.zeros((cap, 4), np.float32)
+        n = C.c_uint32(0)
+        check(lib().lio_fastlio_download_undistorted(self.h, ptr(out, C.c_float), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+
     def set_reduce_hook(self, fn):
         """fn(buf: np.ndarray) replaces the engine's local normal-equation sums by the global ones IN PLACE
         (see lsd_amd.dist.NormalEqAllGather); None removes the hook"""
@@ -397,3 +446,13 @@ def state_boxminus(a, b):
     o = np.zeros(DOF)
     lib().lio_state_boxminus(ptr(a, C.c_double), ptr(b, C.c_double), ptr(o, C.c_double))
     return o
+
+
+def state_predict(s, P, dt, Q12, acc, gyro):
+    """one esekf::predict step on the host (no GPU needed): returns (state26, P 23x23)"""
+    s, P, q, a, g = f64(s), f64(P).reshape(-1), f64(Q12), f64(acc), f64(gyro)
+    assert s.size == STATE_DIM and P.size == 529 and q.size == 12
+    so, Po = np.zeros(STATE_DIM), np.zeros(529)
+    check(lib().lio_state_predict(ptr(s, C.c_double), ptr(P, C.c_double), float(dt), ptr(q, C.c_double), ptr(a, C.c_double), ptr(g, C.c_double),
+                                  ptr(so, C.c_double), ptr(Po, C.c_double)))
+    return so, Po.reshape(23, 23)

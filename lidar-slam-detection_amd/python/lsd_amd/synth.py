@@ -98,33 +98,35 @@ class Scene:
         return out
 
     def raycast(self, origin, dirs, max_range=100.0):
-        """first-hit range along unit `dirs` (n,3) from `origin` (3,); inf where nothing is hit"""
-        o = np.asarray(origin, np.float64)
+        """first-hit range along unit `dirs` (n,3) from `origin` (3,) or per-ray origins (n,3); inf where nothing is hit"""
         d = np.asarray(dirs, np.float64)
         n = len(d)
+        o = np.broadcast_to(np.asarray(origin, np.float64), (n, 3))
         t_best = np.full(n, np.inf)
         with np.errstate(divide="ignore", invalid="ignore"):
             # ground
-            tg = -o[2] / d[:, 2]
+            tg = -o[:, 2] / d[:, 2]
             hit = (d[:, 2] < 0) & (tg > 0)
-            pg = o[None, :2] + d[:, :2] * tg[:, None]
+            pg = o[:, :2] + d[:, :2] * tg[:, None]
             hit &= (np.abs(pg[:, 0]) <= self.half) & (np.abs(pg[:, 1]) <= self.half)
             t_best = np.where(hit, tg, t_best)
             # perimeter walls (seen from inside)
             for ax in (0, 1):
                 for sgn in (-1.0, 1.0):
-                    tw = (sgn * self.half - o[ax]) / d[:, ax]
-                    pw = o[None, :] + d * tw[:, None]
+                    tw = (sgn * self.half - o[:, ax]) / d[:, ax]
+                    pw = o + d * tw[:, None]
                     ok = (tw > 0) & (np.abs(pw[:, 1 - ax]) <= self.half) & (pw[:, 2] >= 0) & (pw[:, 2] <= self.wall_h)
                     t_best = np.where(ok & (tw < t_best), tw, t_best)
             # boxes near enough to matter (slab test)
             c = (self.lo + self.hi) / 2
             rad = np.linalg.norm((self.hi - self.lo)[:, :2] / 2, axis=1)
-            near = np.linalg.norm(c[:, :2] - o[None, :2], axis=1) - rad < max_range
+            om = o.mean(0)
+            spread = np.linalg.norm(o[:, :2] - om[None, :2], axis=1).max() if n else 0.0
+            near = np.linalg.norm(c[:, :2] - om[None, :2], axis=1) - rad < max_range + spread
             inv = 1.0 / d
             for lo, hi in zip(self.lo[near], self.hi[near]):
-                t1 = (lo[None, :] - o[None, :]) * inv
-                t2 = (hi[None, :] - o[None, :]) * inv
+                t1 = (lo[None, :] - o) * inv
+                t2 = (hi[None, :] - o) * inv
                 tmin = np.nanmax(np.minimum(t1, t2), axis=1)
                 tmax = np.nanmin(np.maximum(t1, t2), axis=1)
                 ok = (tmax >= tmin) & (tmin > 0)
@@ -178,3 +180,89 @@ def state_from_pose(pos, quat, grav=(0.0, 0.0, -9.809)):
     s[10] = 1.0
     s[23:26] = grav
     return s
+
+
+# ---------------------------------------------------------------------------
+# moving sensor: analytic IMU-body trajectory, IMU samples and motion-distorted sweeps (the inputs of the FastLIO front
+# half: fastlio_imu_enqueue / fastlio_pcl_enqueue)
+# ---------------------------------------------------------------------------
+class Trajectory:
+    """Body (IMU) pose over time: at rest for `t_static` seconds (IMU initialisation needs > 100 quiet samples), then a
+    smooth drive with yaw / pitch / roll oscillations.  World frame z up, gravity (0, 0, -9.81)."""
+
+    def __init__(self, p0=(0.0, 0.0, 1.8), t_static=1.5, speed=6.0, tau=1.5, sway=1.5, yaw_amp=0.5, pitch_amp=0.03, roll_amp=0.04, heading=0.3):
+        self.p0 = np.asarray(p0, np.float64)
+        self.t_static, self.speed, self.tau, self.sway = t_static, speed, tau, sway
+        self.yaw_amp, self.pitch_amp, self.roll_amp, self.heading = yaw_amp, pitch_amp, roll_amp, heading
+
+    def _u(self, t):
+        return np.maximum(0.0, np.asarray(t, np.float64) - self.t_static)
+
+    def pos(self, t):
+        u = self._u(t)
+        s = self.speed * (u - self.tau * (1.0 - np.exp(-u / self.tau)))  # distance along the heading, s'(0) = 0
+        lat = self.sway * (1.0 - np.cos(0.7 * u))
+        z = 0.05 * (1.0 - np.cos(2.3 * u))
+        c, sn = np.cos(self.heading), np.sin(self.heading)
+        return np.stack([self.p0[0] + c * s - sn * lat, self.p0[1] + sn * s + c * lat, self.p0[2] + z], -1)
+
+    def R(self, t):
+        u = self._u(t)
+        yaw = self.heading + self.yaw_amp * (1.0 - np.cos(0.5 * u))
+        pitch = self.pitch_amp * (1.0 - np.cos(1.9 * u))
+        roll = self.roll_amp * (1.0 - np.cos(1.3 * u))
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        R = np.empty(np.shape(u) + (3, 3))
+        R[..., 0, 0] = cy * cp; R[..., 0, 1] = cy * sp * sr - sy * cr; R[..., 0, 2] = cy * sp * cr + sy * sr
+        R[..., 1, 0] = sy * cp; R[..., 1, 1] = sy * sp * sr + cy * cr; R[..., 1, 2] = sy * sp * cr - cy * sr
+        R[..., 2, 0] = -sp;     R[..., 2, 1] = cp * sr;                R[..., 2, 2] = cp * cr
+        return R
+
+    def quat(self, t):
+        """(x, y, z, w) of R(t), scalar t"""
+        R = self.R(float(t))
+        w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+        return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+
+    def imu(self, t, g=9.81):
+        """ideal gyro (rad/s, body) and accelerometer (specific force, m/s^2, body) at scalar t"""
+        h = 1e-5
+        R = self.R(t)
+        W = R.T @ (self.R(t + h) - self.R(t - h)) / (2 * h)
+        gyr = np.array([W[2, 1] - W[1, 2], W[0, 2] - W[2, 0], W[1, 0] - W[0, 1]]) / 2
+        h = 1e-4
+        acc_w = (self.pos(t + h) - 2 * self.pos(t) + self.pos(t - h)) / (h * h)
+        return gyr, R.T @ (acc_w + np.array([0.0, 0.0, g]))
+
+
+def make_sweep(scene, traj, t_beg, scan_period=0.1, ext_R=np.eye(3), ext_t=(0.0, 0.0, 0.0), seed=0, n_beams=64, n_az=1875, sigma=0.02,
+               max_range=100.0, fov_deg=(-25.0, 15.0)):
+    """one sweep of a MOVING spinning lidar: ray i leaves at t_beg + stamp_i from the pose the trajectory has then.
+    Returns (lidar-frame XYZI f32 (n,4), stamp_us uint32 (n,)) in firing order; nothing is filtered (blind-zone returns stay)."""
+    rng = np.random.default_rng(seed)
+    d_l, frac = lidar_dirs(n_beams, n_az, fov_deg)
+    stamp_us = np.round(frac * scan_period * 1e6).astype(np.uint32)
+    t_az = t_beg + stamp_us[::n_beams].astype(np.float64) * 1e-6  # one pose per azimuth step
+    Rw = traj.R(t_az) @ np.asarray(ext_R, np.float64)                 # (n_az, 3, 3) lidar -> world
+    ow = traj.pos(t_az) + traj.R(t_az) @ np.asarray(ext_t, np.float64)
+    d_w = np.einsum("aij,abj->abi", Rw, d_l.reshape(n_az, n_beams, 3)).reshape(-1, 3)
+    o_w = np.repeat(ow, n_beams, axis=0)
+    r = scene.raycast(o_w, d_w, max_range)
+    ok = np.isfinite(r)
+    r = r + rng.normal(0.0, sigma, size=r.shape)
+    ok &= r > 0.0
+    pts = d_l[ok] * r[ok, None]
+    inten = rng.uniform(0, 255, size=ok.sum())
+    return np.concatenate([pts, inten[:, None]], 1).astype(np.float32), stamp_us[ok]
+
+
+def imu_stream(traj, t0, t1, rate=200.0, seed=0, gyr_sigma=0.0, acc_sigma=0.0):
+    """IMU samples (stamp, gyr (3,), acc m/s^2 (3,)) for t0 <= t < t1"""
+    rng = np.random.default_rng(seed)
+    out = []
+    k0, k1 = int(np.ceil(t0 * rate - 1e-9)), int(np.ceil(t1 * rate - 1e-9))
+    for k in range(k0, k1):
+        t = k / rate
+        g, a = traj.imu(t)
+        out.append((t, g + rng.normal(0, gyr_sigma, 3), a + rng.normal(0, acc_sigma, 3)))
+    return out

@@ -48,6 +48,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <list>
 #include <unordered_map>
 #include <vector>
@@ -465,6 +466,43 @@ inline void hat(const V3& v, double H[9]) {
 }
 inline void mm3(const double A[9], const double B[9], double C[9]) {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[i * 3 + k] * B[k * 3 + j]; C[i * 3 + j] = s; }
+}
+
+// ---- so3_math.h Exp(ang_vel, dt) and the per-point compensation of UndistortPcl, in Eigen's scalar evaluation order
+// (3-term dot products associate as x0 + (x1 + x2); checked bit for bit against oracle/_ref, tests/test_oracle_vs_ref.py)
+inline void mm3_eig(const double A[9], const double B[9], double C[9]) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + (A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j]);
+}
+inline void so3_Exp_rodrigues(const V3& w, double dt, double R[9]) {  // so3_math.h:36-60
+    const double n = std::sqrt(w[0] * w[0] + (w[1] * w[1] + w[2] * w[2]));
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (n > 0.0000001) {
+        V3 ax{{w[0] / n, w[1] / n, w[2] / n}};
+        double K[9], sK[9], KK[9];
+        hat(ax, K);
+        const double th = n * dt, sn = std::sin(th), cs = 1.0 - std::cos(th);
+        for (int i = 0; i < 9; i++) sK[i] = cs * K[i];
+        mm3_eig(sK, K, KK);
+        for (int i = 0; i < 9; i++) R[i] = (R[i] + sn * K[i]) + KK[i];
+    }
+}
+struct P4;
+inline void undistort_point(const double headR[9], const V3& hvel, const V3& hpos, const V3& tacc, const V3& tgyr, double dt, float pxyz[3],
+                            const V3& epos, const Quat& erot, const Quat& ril, const V3& til) {  // IMU_Processing.hpp:386-394
+    double Rd[9], Ri[9];
+    so3_Exp_rodrigues(tgyr, dt, Rd);
+    mm3_eig(headR, Rd, Ri);
+    V3 Pi{{(double)pxyz[0], (double)pxyz[1], (double)pxyz[2]}};
+    V3 T_ei;
+    for (int a = 0; a < 3; a++) T_ei[a] = hpos[a] + hvel[a] * dt + 0.5 * tacc[a] * dt * dt - epos[a];
+    V3 pl = qrot(ril, Pi);
+    for (int a = 0; a < 3; a++) pl[a] += til[a];
+    V3 pw;
+    for (int a = 0; a < 3; a++) pw[a] = (Ri[a * 3] * pl[0] + (Ri[a * 3 + 1] * pl[1] + Ri[a * 3 + 2] * pl[2])) + T_ei[a];
+    V3 pe = qrot(qconj(erot), pw);
+    for (int a = 0; a < 3; a++) pe[a] -= til[a];
+    V3 pc = qrot(qconj(ril), pe);
+    pxyz[0] = (float)pc[0]; pxyz[1] = (float)pc[1]; pxyz[2] = (float)pc[2];
 }
 
 const double kTol = 1e-11;  // MTK::tolerance<double>()
@@ -1089,6 +1127,310 @@ struct Lio {
         nearest.resize(n);  // Nearest_Points.resize: surviving entries keep their content (laserMapping.cpp:1274)
     }
 
+    // ------------------------------------------------------------------------------------------
+    // IMU front half of fastlio_main: buffers + sync_packages (laserMapping.cpp:397-415,445-520), ImuProcess
+    // (IMU_Processing.hpp: ctor :84-104, IMU_init :164-236, UndistortPcl :238-406, Process :408-450) and
+    // esekf::predict (esekfom.hpp:279-383) with the process model of use-ikfom.hpp:36-88.
+    // IMU accelerations are in units of g inside (fastlio_imu_enqueue divides by 9.81, laserMapping.cpp:410).
+    // ------------------------------------------------------------------------------------------
+    struct Imu { double stamp; V3 acc, gyr; };
+    struct ScanIn { std::vector<P4> pts; std::vector<float> t_ms; double beg; };
+    struct Pose6 { double off; V3 acc, gyr, vel, pos; double R[9]; };
+    std::deque<Imu> imu_buffer;
+    std::deque<ScanIn> lidar_buffer;
+    double lidar_mean_scantime = 0.1;  // scan_period (laserMapping.cpp:1121)
+    // ImuProcess members
+    bool b_first_frame = true, imu_need_init = true;
+    int init_iter_num = 1;
+    V3 mean_acc{{0, 0, -1.0}}, mean_gyr{{0, 0, 0}}, cov_acc{{0.1, 0.1, 0.1}}, cov_gyr{{0.1, 0.1, 0.1}};
+    V3 cov_acc_scale{{0.1, 0.1, 0.1}}, cov_gyr_scale{{0.1, 0.1, 0.1}}, cov_bias_gyr{{0.0001, 0.0001, 0.0001}}, cov_bias_acc{{0.0001, 0.0001, 0.0001}};
+    V3 vel_last{{0, 0, 0}}, angvel_last{{0, 0, 0}}, acc_s_last{{0, 0, 0}};
+    Imu last_imu{0, {{0, 0, 0}}, {{0, 0, 0}}};
+    double last_lidar_end_time = 0;
+    double Qd[12] = {1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 1e-5, 1e-5, 1e-5, 1e-5, 1e-5, 1e-5};  // process_noise_cov(): ng, na, nbg, nba
+    bool undistort_en = true;
+    double blind = 0.1;
+    V3 Lidar_T{{0, 0, 0}};
+    Quat Lidar_R{0, 0, 0, 1};
+    int point_filter_num = 1;
+    std::vector<P4> feats_undistort;
+    State odom_start, odom_end;  // states before / after the scan (fastlio_odometry)
+
+    void imu_enqueue(double stamp, const double gyr[3], const double acc_ms2[3]) {
+        Imu m;
+        m.stamp = stamp;
+        for (int i = 0; i < 3; i++) { m.gyr[i] = gyr[i]; m.acc[i] = acc_ms2[i] / 9.81; }
+        imu_buffer.push_back(m);
+    }
+    // Preprocess::velodyne_handler (preprocess.cpp:395-451, feature extraction off, point_filter_num 1): curvature =
+    // per-point time in ms (float), points inside the blind radius dropped
+    void pcl_enqueue(const P4* pts, const uint32_t* t_us, int n, double stamp) {
+        ScanIn sc;
+        sc.beg = stamp;
+        for (int i = 0; i < n; i++) {
+            const P4& p = pts[i];
+            if (i % point_filter_num == 0 && (double)(p.x * p.x + p.y * p.y + p.z * p.z) > blind * blind) {
+                sc.pts.push_back(p);
+                sc.t_ms.push_back(t_us[i] / 1000.0f);  // uint32 -> float, then the f32 division (preprocess.cpp:406)
+            }
+        }
+        lidar_buffer.push_back(std::move(sc));
+    }
+
+    // esekf::predict.  State dims (24): pos0 rot3 ril6 til9 vel12 bg15 ba18 grav21(3); dofs (23): ... grav21(2)
+    void predict(double dt, const V3& acc, const V3& gyro) {
+        const int n = 23;
+        // f (get_f)
+        double f[24] = {0};
+        V3 amb{{acc[0] - x.ba[0], acc[1] - x.ba[1], acc[2] - x.ba[2]}};
+        V3 a_in = qrot(x.rot, amb);
+        for (int i = 0; i < 3; i++) { f[i] = x.vel[i]; f[3 + i] = gyro[i] - x.bg[i]; f[12 + i] = a_in[i] + x.grav[i]; }
+        // f_x (24 x 23), f_w (24 x 12)
+        Mat fx(24, 23), fw(24, 12);
+        double R[9], H[9], RH[9];
+        qtoR(x.rot, R);
+        hat(amb, H);
+        mm3(R, H, RH);
+        for (int i = 0; i < 3; i++) {
+            fx(i, 12 + i) = 1.0;
+            fx(3 + i, 15 + i) = -1.0;
+            for (int j = 0; j < 3; j++) { fx(12 + i, 3 + j) = -RH[i * 3 + j]; fx(12 + i, 18 + j) = -R[i * 3 + j]; fw(12 + i, 3 + j) = -R[i * 3 + j]; }
+            fw(3 + i, i) = -1.0;
+            fw(15 + i, 6 + i) = 1.0;
+            fw(18 + i, 9 + i) = 1.0;
+        }
+        {
+            double zero2[2] = {0, 0}, Mx[6];
+            S2_Mx(x.grav, zero2, Mx);
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 2; j++) fx(12 + i, 21 + j) = Mx[i * 2 + j];
+        }
+        const State x_before = x;
+        // x_.oplus(f_, dt): vect += dt * f; SO3 *= exp(f, dt) (SOn.hpp:242-245, exp(vec, scale) -> mtk exp(vec, scale / 2));
+        // S2::oplus with f == 0 is the identity rotation; til / bg / ba / ril have f == 0
+        for (int i = 0; i < 3; i++) { x.pos[i] += dt * f[i]; x.til[i] += dt * f[9 + i]; x.vel[i] += dt * f[12 + i]; x.bg[i] += dt * f[15 + i]; x.ba[i] += dt * f[18 + i]; }
+        x.rot = qmul(x.rot, mtk_exp(V3{{f[3], f[4], f[5]}}, dt / 2));
+        x.ril = qmul(x.ril, mtk_exp(V3{{f[6], f[7], f[8]}}, dt / 2));
+        Mat F1 = Mat::eye(n), fxf(n, n), fwf(n, 12);
+        // vect states: idx == dim for the first 21 dims except the SO3 ones handled below
+        const int vect_idx[5] = {0, 9, 12, 15, 18};
+        for (int v = 0; v < 5; v++)
+            for (int j = 0; j < 3; j++) {
+                for (int i = 0; i < n; i++) fxf(vect_idx[v] + j, i) = fx(vect_idx[v] + j, i);
+                for (int i = 0; i < 12; i++) fwf(vect_idx[v] + j, i) = fw(vect_idx[v] + j, i);
+            }
+        const int so3_idx[2] = {3, 6};
+        for (int si = 0; si < 2; si++) {
+            const int idx = so3_idx[si];
+            V3 seg{{-f[idx] * dt, -f[idx + 1] * dt, -f[idx + 2] * dt}};
+            // F_x1 block = exp(seg, scalar(1/2) == 0).toRotationMatrix() == identity (esekfom.hpp:312)
+            double A[9];
+            A_matrix(seg, A);
+            for (int i = 0; i < n; i++) {
+                double v[3] = {fx(idx, i), fx(idx + 1, i), fx(idx + 2, i)};
+                for (int a = 0; a < 3; a++) fxf(idx + a, i) = A[a * 3] * v[0] + A[a * 3 + 1] * v[1] + A[a * 3 + 2] * v[2];
+            }
+            for (int i = 0; i < 12; i++) {
+                double v[3] = {fw(idx, i), fw(idx + 1, i), fw(idx + 2, i)};
+                for (int a = 0; a < 3; a++) fwf(idx + a, i) = A[a * 3] * v[0] + A[a * 3 + 1] * v[1] + A[a * 3 + 2] * v[2];
+            }
+        }
+        {  // S2 at idx 21, dim 21
+            V3 seg{{f[21] * dt, f[22] * dt, f[23] * dt}};
+            double Nx[6], Mx[6], zero2[2] = {0, 0};
+            S2_Nx_yy(x.grav, Nx);
+            S2_Mx(x_before.grav, zero2, Mx);
+            // res = exp(seg, 0) == identity
+            for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { double s2 = 0; for (int k = 0; k < 3; k++) s2 += Nx[a * 3 + k] * Mx[k * 2 + b]; F1(21 + a, 21 + b) = s2; }
+            double Hb[9], A[9], T[9], res23[6];
+            hat(x_before.grav, Hb);
+            A_matrix(seg, A);
+            // res_temp_S2 = -Nx * I * x_before_hat * A^T
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s2 = 0; for (int k = 0; k < 3; k++) s2 += Hb[i * 3 + k] * A[j * 3 + k]; T[i * 3 + j] = s2; }
+            for (int a = 0; a < 2; a++) for (int j = 0; j < 3; j++) { double s2 = 0; for (int k = 0; k < 3; k++) s2 += Nx[a * 3 + k] * T[k * 3 + j]; res23[a * 3 + j] = -s2; }
+            for (int i = 0; i < n; i++) {
+                double v[3] = {fx(21, i), fx(22, i), fx(23, i)};
+                for (int a = 0; a < 2; a++) fxf(21 + a, i) = res23[a * 3] * v[0] + res23[a * 3 + 1] * v[1] + res23[a * 3 + 2] * v[2];
+            }
+            for (int i = 0; i < 12; i++) {
+                double v[3] = {fw(21, i), fw(22, i), fw(23, i)};
+                for (int a = 0; a < 2; a++) fwf(21 + a, i) = res23[a * 3] * v[0] + res23[a * 3 + 1] * v[1] + res23[a * 3 + 2] * v[2];
+            }
+        }
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) F1(i, j) += fxf(i, j) * dt;
+        Mat FP = mul(F1, P);
+        Mat Pn = mul(FP, transpose(F1));
+        Mat W(n, 12);
+        for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) W(i, j) = dt * fwf(i, j);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                double s2 = 0;
+                for (int k = 0; k < 12; k++) s2 += W(i, k) * Qd[k] * W(j, k);
+                Pn(i, j) += s2;
+            }
+        P = Pn;
+    }
+
+    void set_Q() {
+        for (int i = 0; i < 3; i++) { Qd[i] = cov_gyr[i]; Qd[3 + i] = cov_acc[i]; Qd[6 + i] = cov_bias_gyr[i]; Qd[9 + i] = cov_bias_acc[i]; }
+    }
+
+    void imu_init(const std::vector<Imu>& imu, double lidar_beg, double lidar_end) {
+        int& N = init_iter_num;
+        if (b_first_frame) {
+            // Reset()
+            mean_acc = {{0, 0, -1.0}}; mean_gyr = {{0, 0, 0}}; vel_last = {{0, 0, 0}}; angvel_last = {{0, 0, 0}};
+            imu_need_init = true; init_iter_num = 1; last_imu = Imu{0, {{0, 0, 0}}, {{0, 0, 0}}};
+            N = 1;
+            b_first_frame = false;
+            mean_acc = imu.front().acc;
+            mean_gyr = imu.front().gyr;
+        }
+        for (const Imu& m : imu) {
+            for (int i = 0; i < 3; i++) {
+                mean_acc[i] += (m.acc[i] - mean_acc[i]) / N;
+                mean_gyr[i] += (m.gyr[i] - mean_gyr[i]) / N;
+                cov_acc[i] = cov_acc[i] * (N - 1.0) / N + (m.acc[i] - mean_acc[i]) * (m.acc[i] - mean_acc[i]) * (N - 1.0) / (N * N);
+                cov_gyr[i] = cov_gyr[i] * (N - 1.0) / N + (m.gyr[i] - mean_gyr[i]) * (m.gyr[i] - mean_gyr[i]) * (N - 1.0) / (N * N);
+            }
+            N++;
+        }
+        const double na = std::sqrt(mean_acc[0] * mean_acc[0] + (mean_acc[1] * mean_acc[1] + mean_acc[2] * mean_acc[2]));
+        const double ng = std::sqrt(mean_gyr[0] * mean_gyr[0] + (mean_gyr[1] * mean_gyr[1] + mean_gyr[2] * mean_gyr[2]));
+        if (std::fabs(na - 1.0) > 0.1 || ng > (10.0 / 180.0 * M_PI)) { b_first_frame = true; return; }
+        {   // init_state.grav = S2(-mean_acc / |mean_acc| * G_m_s2): the S2 ctor re-normalises to length 9.809 (S2.hpp:124-127)
+            V3 g{{-mean_acc[0] / na * 9.81, -mean_acc[1] / na * 9.81, -mean_acc[2] / na * 9.81}};
+            const double z = g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);
+            if (z > 0) { const double nz = std::sqrt(z); for (int i = 0; i < 3; i++) g[i] /= nz; }
+            for (int i = 0; i < 3; i++) x.grav[i] = g[i] * kS2Len;
+        }
+        for (int i = 0; i < 3; i++) { x.vel[i] = vel_last[i]; x.bg[i] = 0; x.ba[i] = 0; }
+        x.til = Lidar_T; x.ril = Lidar_R;  // init_state.offset_T_L_I / offset_R_L_I = Lidar_*_wrt_IMU
+        P = Mat::eye(23);
+        for (int i : {6, 7, 8, 9, 10, 11}) P(i, i) = 0.00001;
+        for (int i : {15, 16, 17}) P(i, i) = 0.0001;
+        for (int i : {18, 19, 20}) P(i, i) = 0.001;
+        P(21, 21) = P(22, 22) = 0.00001;
+        last_imu = imu.back();
+        last_lidar_end_time = lidar_end;
+        (void)lidar_beg;
+    }
+
+    void pose6(std::vector<Pose6>& out, double off) {
+        Pose6 p;
+        p.off = off; p.acc = acc_s_last; p.gyr = angvel_last; p.vel = x.vel; p.pos = x.pos;
+        qtoR(x.rot, p.R);
+        out.push_back(p);
+    }
+    void after_predict(const V3& angvel_avr, const V3& acc_avr) {
+        for (int i = 0; i < 3; i++) angvel_last[i] = angvel_avr[i] - x.bg[i];
+        V3 amb{{acc_avr[0] - x.ba[0], acc_avr[1] - x.ba[1], acc_avr[2] - x.ba[2]}};
+        acc_s_last = qrot(x.rot, amb);
+        for (int i = 0; i < 3; i++) acc_s_last[i] += x.grav[i];
+    }
+
+    void undistort_pcl(const ScanIn& sc, const std::vector<Imu>& meas_imu, double lidar_end, std::vector<P4>& out) {
+        const double na = std::sqrt(mean_acc[0] * mean_acc[0] + (mean_acc[1] * mean_acc[1] + mean_acc[2] * mean_acc[2]));
+        set_Q();
+        if (sc.beg > last_lidar_end_time) {
+            V3 acc_avr{{last_imu.acc[0] * 9.81 / na, last_imu.acc[1] * 9.81 / na, last_imu.acc[2] * 9.81 / na}};
+            predict(sc.beg - last_lidar_end_time, acc_avr, last_imu.gyr);
+            after_predict(last_imu.gyr, acc_avr);
+            last_lidar_end_time = sc.beg;
+        }
+        odom_start = x;
+        std::vector<Imu> v_imu;
+        v_imu.push_back(last_imu);
+        for (const Imu& m : meas_imu) v_imu.push_back(m);
+        const double imu_end_time = v_imu.back().stamp, pcl_beg = sc.beg, pcl_end = lidar_end;
+        std::vector<Pose6> poses;
+        pose6(poses, 0.0);
+        for (size_t k = 0; k + 1 < v_imu.size(); k++) {
+            const Imu &head = v_imu[k], &tail = v_imu[k + 1];
+            if (tail.stamp < last_lidar_end_time) continue;
+            V3 angvel_avr, acc_avr;
+            for (int i = 0; i < 3; i++) { angvel_avr[i] = 0.5 * (head.gyr[i] + tail.gyr[i]); acc_avr[i] = 0.5 * (head.acc[i] + tail.acc[i]) * 9.81 / na; }
+            double dt = head.stamp < last_lidar_end_time ? tail.stamp - last_lidar_end_time : tail.stamp - head.stamp;
+            dt = std::min(1.0, dt);
+            predict(dt, acc_avr, angvel_avr);
+            after_predict(angvel_avr, acc_avr);
+            pose6(poses, tail.stamp - pcl_beg);
+        }
+        {
+            V3 angvel_avr = v_imu.back().gyr, acc_avr;
+            for (int i = 0; i < 3; i++) acc_avr[i] = v_imu.back().acc[i] * 9.81 / na;
+            const double note = pcl_end > imu_end_time ? 1.0 : -1.0;
+            double dt = std::min(1.0, note * (pcl_end - imu_end_time));
+            predict(dt, acc_avr, angvel_avr);
+            after_predict(angvel_avr, acc_avr);
+            pose6(poses, pcl_end - pcl_beg);
+        }
+        last_imu = meas_imu.back();
+        last_lidar_end_time = pcl_end;
+        // backward propagation.  The reference sorts the cloud by time (std::sort, unstable) and walks it from the back;
+        // every point is compensated with the IMU segment [head, tail) that contains its time -- restated per point, in
+        // input order (the downstream VoxelGrid does not depend on the order of distinct voxels).  One quirk of the walk is
+        // kept: when the earliest point has t > 0 the iterator parks on it (`if (it_pcl == begin) break`) and every earlier
+        // segment compensates it AGAIN, on the already compensated coordinates (IMU_Processing.hpp:371-404).  With several
+        // points sharing the minimum time std::sort decides which one sits at begin(); the lowest input index is used here.
+        out = sc.pts;
+        if (!undistort_en || out.empty()) return;
+        size_t first = 0;
+        for (size_t i = 1; i < out.size(); i++)
+            if (sc.t_ms[i] < sc.t_ms[first]) first = i;
+        auto compensate = [&](P4& p, double t, int h) {
+            const Pose6 &head = poses[h], &tail = poses[h + 1];
+            float q[3] = {p.x, p.y, p.z};
+            undistort_point(head.R, head.vel, head.pos, tail.acc, tail.gyr, t - head.off, q, x.pos, x.rot, x.ril, x.til);
+            p.x = q[0]; p.y = q[1]; p.z = q[2];
+        };
+        for (size_t i = 0; i < out.size(); i++) {
+            const double t = (double)sc.t_ms[i] / 1000.0;
+            int h = -1;  // the last head with head.off < t (points with t <= poses[0].off == 0 stay untouched)
+            for (int k = (int)poses.size() - 2; k >= 0; k--)
+                if (t > poses[k].off) { h = k; break; }
+            if (h < 0) continue;
+            compensate(out[i], t, h);
+            if (i == first)
+                for (int k = h - 1; k >= 0; k--)
+                    if (t > poses[k].off) compensate(out[i], t, k);
+        }
+    }
+
+    // fastlio_main (laserMapping.cpp:1126-1310): returns 5 nothing to do, 0 first-scan latch, 4 IMU initialising,
+    // 1 map seeded, 2 too few points, 3 state updated
+    int frontend_main() {
+        if (lidar_buffer.empty() || imu_buffer.empty()) return 5;
+        ScanIn sc = std::move(lidar_buffer.front());
+        lidar_buffer.pop_front();
+        const double lidar_end = sc.beg + lidar_mean_scantime;
+        std::vector<Imu> meas_imu;
+        while (!imu_buffer.empty() && !(imu_buffer.front().stamp > lidar_end)) { meas_imu.push_back(imu_buffer.front()); imu_buffer.pop_front(); }
+        if (flg_first_scan) { first_lidar_time = sc.beg; flg_first_scan = false; return 0; }
+        // Process() returns at once when no IMU sample fell into the scan: feats_undistort keeps the PREVIOUS scan's cloud
+        // and fastlio_main registers that again (IMU_Processing.hpp:413, laserMapping.cpp:1189-1197)
+        if (meas_imu.empty()) {
+            if (feats_undistort.empty()) return 4;
+            const int rc0 = process_scan_core(feats_undistort.data(), (int)feats_undistort.size(), sc.beg);
+            odom_end = x;
+            return rc0;
+        }
+        if (imu_need_init) {
+            imu_init(meas_imu, sc.beg, lidar_end);
+            imu_need_init = true;
+            last_imu = meas_imu.back();
+            if (init_iter_num > 100) {  // MAX_INI_COUNT (IMU_Processing.hpp:25)
+                imu_need_init = false;
+                cov_acc = cov_acc_scale;
+                cov_gyr = cov_gyr_scale;
+            }
+            return 4;
+        }
+        undistort_pcl(sc, meas_imu, lidar_end, feats_undistort);
+        const int rc = process_scan_core(feats_undistort.data(), (int)feats_undistort.size(), sc.beg);
+        odom_end = x;
+        return rc;
+    }
+
     // fastlio_main after p_imu->Process (laserMapping.cpp:1189-1304).  `raw` plays
     // feats_undistort; the caller has already put the propagated state/covariance in x/P.
     // returns: 0 first-scan latch, 1 seeded map, 2 too few points, 3 updated, <0 error
@@ -1098,6 +1440,9 @@ struct Lio {
             flg_first_scan = false;
             return 0;
         }
+        return process_scan_core(raw, n_raw, lidar_beg_time);
+    }
+    int process_scan_core(const P4* raw, int n_raw, double lidar_beg_time) {
         if (n_raw <= 0) return 2;
         flg_EKF_inited = (lidar_beg_time - first_lidar_time) < init_time ? false : true;
         std::vector<P4> ds;
@@ -1310,6 +1655,46 @@ int orc_lio_process_scan(void* h, const float* raw_xyzi, int n_raw, double lidar
 }
 double orc_lio_travel(void* h) { return static_cast<Lio*>(h)->travel; }
 int orc_lio_is_degenerate(void* h) { return static_cast<Lio*>(h)->is_degenerate ? 1 : 0; }
+
+// IMU front half
+void orc_lio_imu_enqueue(void* h, double stamp, const double* gyr, const double* acc_ms2) { static_cast<Lio*>(h)->imu_enqueue(stamp, gyr, acc_ms2); }
+void orc_lio_pcl_enqueue(void* h, const float* xyzi, const uint32_t* t_us, int n, double stamp) {
+    static_cast<Lio*>(h)->pcl_enqueue(reinterpret_cast<const P4*>(xyzi), t_us, n, stamp);
+}
+void orc_lio_frontend_config(void* h, const double* extT, const double* extR_xyzw, int filter_num, double scan_period, int undistort) {
+    Lio* l = static_cast<Lio*>(h);
+    l->Lidar_T = V3{{extT[0], extT[1], extT[2]}};
+    l->Lidar_R = Quat{extR_xyzw[0], extR_xyzw[1], extR_xyzw[2], extR_xyzw[3]};
+    l->point_filter_num = filter_num > 0 ? filter_num : 1;
+    l->lidar_mean_scantime = scan_period;
+    l->undistort_en = undistort != 0;
+}
+int orc_lio_frontend_main(void* h) { return static_cast<Lio*>(h)->frontend_main(); }
+void orc_lio_predict(void* h, double dt, const double* acc, const double* gyro) {
+    static_cast<Lio*>(h)->predict(dt, V3{{acc[0], acc[1], acc[2]}}, V3{{gyro[0], gyro[1], gyro[2]}});
+}
+int orc_lio_get_undistorted(void* h, float* out, int cap) {
+    Lio* l = static_cast<Lio*>(h);
+    const int n = (int)l->feats_undistort.size();
+    if (n > cap) return -n;
+    std::memcpy(out, l->feats_undistort.data(), sizeof(P4) * (size_t)n);
+    return n;
+}
+void orc_lio_get_odometry(void* h, double* s26_start, double* s26_end) {
+    Lio* l = static_cast<Lio*>(h);
+    state_to(l->odom_start, s26_start);
+    state_to(l->odom_end, s26_end);
+}
+
+void orc_so3_Exp(const double* w3, double dt, double* R9) { so3_Exp_rodrigues(V3{{w3[0], w3[1], w3[2]}}, dt, R9); }
+void orc_undistort_point(const double* R_imu9, const double* vel3, const double* pos3, const double* acc3, const double* gyr3, double dt,
+                         const float* p_xyz, const double* end_pos3, const double* end_rot_xyzw, const double* ril_xyzw, const double* til3, float* out_xyz) {
+    auto v3 = [](const double* p) { return V3{{p[0], p[1], p[2]}}; };
+    auto q4 = [](const double* p) { return Quat{p[0], p[1], p[2], p[3]}; };
+    float q[3] = {p_xyz[0], p_xyz[1], p_xyz[2]};
+    undistort_point(R_imu9, v3(vel3), v3(pos3), v3(acc3), v3(gyr3), dt, q, v3(end_pos3), q4(end_rot_xyzw), q4(ril_xyzw), v3(til3));
+    out_xyz[0] = q[0]; out_xyz[1] = q[1]; out_xyz[2] = q[2];
+}
 
 // manifold helpers exposed for the known-answer tests
 void orc_state_boxplus(const double* s26, const double* d23, double* out26) { State x; state_from(s26, x); state_boxplus(x, d23); state_to(x, out26); }

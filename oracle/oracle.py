@@ -69,6 +69,17 @@ def lib():
     L.orc_lio_map_dump.restype = C.c_int64
     L.orc_lio_set_ds.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_lio_reset_cache.argtypes = [C.c_void_p]
+    L.orc_lio_imu_enqueue.argtypes = [C.c_void_p, C.c_double, f64p, f64p]
+    L.orc_lio_pcl_enqueue.argtypes = [C.c_void_p, f32p, C.POINTER(C.c_uint32), C.c_int, C.c_double]
+    L.orc_lio_frontend_config.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, C.c_int]
+    L.orc_lio_frontend_main.argtypes = [C.c_void_p]
+    L.orc_lio_frontend_main.restype = C.c_int
+    L.orc_lio_predict.argtypes = [C.c_void_p, C.c_double, f64p, f64p]
+    L.orc_lio_get_undistorted.argtypes = [C.c_void_p, f32p, C.c_int]
+    L.orc_lio_get_undistorted.restype = C.c_int
+    L.orc_lio_get_odometry.argtypes = [C.c_void_p, f64p, f64p]
+    L.orc_so3_Exp.argtypes = [f64p, C.c_double, f64p]
+    L.orc_undistort_point.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_double, f32p, f64p, f64p, f64p, f64p, f32p]
     L.orc_lio_get_ds.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_lio_get_ds.restype = C.c_int
     L.orc_lio_linearize.argtypes = [C.c_void_p, C.c_int, u8p, f32p, i32p, f32p, f64p, f64p, f64p, i32p]
@@ -241,6 +252,36 @@ class Lio:
         self._n = len(d)
         lib().orc_lio_set_ds(self.h, _p(d, C.c_float), len(d))
 
+    def imu_enqueue(self, stamp, gyr, acc_ms2):
+        g, a = _f64(gyr), _f64(acc_ms2)
+        lib().orc_lio_imu_enqueue(self.h, float(stamp), _p(g, C.c_double), _p(a, C.c_double))
+
+    def pcl_enqueue(self, xyzi, t_us, stamp):
+        p, t = _f32(xyzi).reshape(-1, 4), np.ascontiguousarray(t_us, np.uint32)
+        lib().orc_lio_pcl_enqueue(self.h, _p(p, C.c_float), _p(t, C.c_uint32), len(p), float(stamp))
+
+    def frontend_config(self, extT=(0, 0, 0), extR_xyzw=(0, 0, 0, 1), filter_num=1, scan_period=0.1, undistort=True):
+        t, r = _f64(extT), _f64(extR_xyzw)
+        lib().orc_lio_frontend_config(self.h, _p(t, C.c_double), _p(r, C.c_double), filter_num, float(scan_period), int(undistort))
+
+    def frontend_main(self):
+        return lib().orc_lio_frontend_main(self.h)
+
+    def predict(self, dt, acc, gyro):
+        a, g = _f64(acc), _f64(gyro)
+        lib().orc_lio_predict(self.h, float(dt), _p(a, C.c_double), _p(g, C.c_double))
+
+    def get_undistorted(self, cap=300000):
+        out = np.zeros((cap, 4), np.float32)
+        n = lib().orc_lio_get_undistorted(self.h, _p(out, C.c_float), cap)
+        assert n >= 0
+        return out[:n].copy()
+
+    def get_odometry(self):
+        a, b = np.zeros(STATE_DIM), np.zeros(STATE_DIM)
+        lib().orc_lio_get_odometry(self.h, _p(a, C.c_double), _p(b, C.c_double))
+        return a, b
+
     def reset_cache(self):
         lib().orc_lio_reset_cache(self.h)
 
@@ -350,3 +391,19 @@ def inverse(A):
     o = np.zeros_like(A)
     lib().orc_inverse(_p(A, C.c_double), n, _p(o, C.c_double))
     return o
+
+
+def so3_Exp(w, dt):
+    w = _f64(w)
+    R = np.zeros(9)
+    lib().orc_so3_Exp(_p(w, C.c_double), float(dt), _p(R, C.c_double))
+    return R.reshape(3, 3)
+
+
+def undistort_point(R_imu, vel, pos, acc, gyr, dt, p, end_pos, end_rot, ril, til):
+    a = [_f64(v).ravel() for v in (R_imu, vel, pos, acc, gyr)]
+    b = [_f64(v).ravel() for v in (end_pos, end_rot, ril, til)]
+    pp = _f32(p)
+    out = np.zeros(3, np.float32)
+    lib().orc_undistort_point(*[_p(v, C.c_double) for v in a], float(dt), _p(pp, C.c_float), *[_p(v, C.c_double) for v in b], _p(out, C.c_float))
+    return out

@@ -37,6 +37,8 @@ def lib():
         L.ref_se3_exp.argtypes = [f64p, f64p]
         L.ref_eig3_direct.argtypes = [f32p, f32p, f32p]
         L.ref_regularize_plane.argtypes = [f32p, f32p, f32p]
+        L.ref_so3_Exp.argtypes = [f64p, C.c_double, f64p]
+        L.ref_undistort_point.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_double, f32p, f64p, f64p, f64p, f64p, f32p]
         _lib = L
     return _lib
 
@@ -73,6 +75,22 @@ def eig3_direct(cov):
     w, V = np.zeros(3, np.float32), np.zeros((3, 3), np.float32)
     lib().ref_eig3_direct(_p(c, C.c_float), _p(w, C.c_float), _p(V, C.c_float))
     return w, V
+
+
+def so3_Exp(w, dt):
+    w = np.ascontiguousarray(w, np.float64)
+    R = np.zeros(9)
+    lib().ref_so3_Exp(_p(w, C.c_double), float(dt), _p(R, C.c_double))
+    return R.reshape(3, 3)
+
+
+def undistort_point(R_imu, vel, pos, acc, gyr, dt, p, end_pos, end_rot, ril, til):
+    a = [np.ascontiguousarray(v, np.float64).ravel() for v in (R_imu, vel, pos, acc, gyr)]
+    b = [np.ascontiguousarray(v, np.float64).ravel() for v in (end_pos, end_rot, ril, til)]
+    pp = _f32(p)
+    out = np.zeros(3, np.float32)
+    lib().ref_undistort_point(*[_p(v, C.c_double) for v in a], float(dt), _p(pp, C.c_float), *[_p(v, C.c_double) for v in b], _p(out, C.c_float))
+    return out
 
 
 def regularize_plane(cov):

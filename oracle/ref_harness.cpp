@@ -108,4 +108,30 @@ void ref_regularize_plane(const float* cov9, float* out9, float* inv9) {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { out9[i * 3 + j] = R(i, j); inv9[i * 3 + j] = Ri(i, j); }
 }
 
+// so3_math.h Exp(ang_vel, dt) -- the reference's own template -- and the per-point compensation of
+// ImuProcess::UndistortPcl (IMU_Processing.hpp:386-394).  UndistortPcl itself needs the IKFoM state (boost
+// preprocessor), so the one expression is restated here over the same Eigen types (MTK::SO3 derives from
+// Eigen::Quaternion, MTK::vect from Eigen::Matrix): what is pinned is Eigen's operation order for it.
+void ref_so3_Exp(const double* w3, double dt, double* R9) {
+    Eigen::Vector3d w(w3[0], w3[1], w3[2]);
+    Eigen::Matrix3d R = Exp(w, dt);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R9[i * 3 + j] = R(i, j);
+}
+void ref_undistort_point(const double* R_imu9, const double* vel3, const double* pos3, const double* acc3, const double* gyr3, double dt,
+                         const float* p_xyz, const double* end_pos3, const double* end_rot_xyzw, const double* ril_xyzw, const double* til3, float* out_xyz) {
+    Eigen::Matrix3d R_imu;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R_imu(i, j) = R_imu9[i * 3 + j];
+    Eigen::Vector3d vel_imu(vel3[0], vel3[1], vel3[2]), pos_imu(pos3[0], pos3[1], pos3[2]), acc_imu(acc3[0], acc3[1], acc3[2]);
+    Eigen::Vector3d angvel_avr(gyr3[0], gyr3[1], gyr3[2]), end_pos(end_pos3[0], end_pos3[1], end_pos3[2]), til(til3[0], til3[1], til3[2]);
+    Eigen::Quaterniond rot(end_rot_xyzw[3], end_rot_xyzw[0], end_rot_xyzw[1], end_rot_xyzw[2]);
+    Eigen::Quaterniond ril(ril_xyzw[3], ril_xyzw[0], ril_xyzw[1], ril_xyzw[2]);
+    Eigen::Matrix3d R_i(R_imu * Exp(angvel_avr, dt));
+    Eigen::Vector3d P_i(p_xyz[0], p_xyz[1], p_xyz[2]);
+    Eigen::Vector3d T_ei(pos_imu + vel_imu * dt + 0.5 * acc_imu * dt * dt - end_pos);
+    Eigen::Vector3d P_compensate = ril.conjugate() * (rot.conjugate() * (R_i * (ril * P_i + til) + T_ei) - til);
+    out_xyz[0] = P_compensate(0);
+    out_xyz[1] = P_compensate(1);
+    out_xyz[2] = P_compensate(2);
+}
+
 }  // extern "C"

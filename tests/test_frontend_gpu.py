@@ -1,0 +1,135 @@
+"""The IMU front half of the HIP path (lio_fastlio_* entry points: buffers, IMU initialisation, forward propagation,
+per-point motion compensation on the device, then the scan-matching path) against the CPU oracle on a synthetic drive.
+The compensation runs in f64 with device sin / cos: a point may differ from the CPU by one f32 ulp where a last-bit f64
+difference crosses a rounding boundary; poses are held to the north-star tolerance 1e-4 m / 1e-5 rad."""
+import numpy as np
+import pytest
+
+from test_frontend_cpu import OracleFront, pose_error, run_drive
+
+pytestmark = pytest.mark.gpu
+
+
+class HipFront:
+    def __init__(self, **cfg):
+        from lsd_amd import lio
+
+        self.e = lio.Engine(max_points=4_000_000, max_voxels=1 << 20, max_raw=1 << 18, max_ds=100000)
+        self.e.fastlio_init(**cfg)
+        self.imu_enqueue = self.e.fastlio_imu_enqueue
+        self.pcl_enqueue = self.e.fastlio_pcl_enqueue
+        self.main = self.e.fastlio_main
+        self.get_state = self.e.get_state
+
+
+def _dev():
+    from lsd_amd import capi
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on the GPU box")
+
+
+def test_drive_matches_oracle(oracle_mod, scene):
+    _dev()
+    from lsd_amd import capi, synth
+
+    tr = synth.Trajectory()
+    hip = HipFront(scan_period=0.1)
+    orc = OracleFront(oracle_mod, scan_period=0.1)
+    und_stats = []
+
+    def check_cloud(k, rc, pts, st):
+        if rc != capi.MAIN_UPDATED:
+            return
+        a = hip.e.undistorted()
+        keep = np.isfinite(a[:, 0])
+        b = orc.L.get_undistorted()
+        assert keep.sum() == len(b)  # the blind filter dropped the same points
+        a = a[keep]
+        assert np.array_equal(a[:, 3], b[:, 3])
+        ulp = np.abs(a[:, :3].view(np.int32).astype(np.int64) - b[:, :3].view(np.int32).astype(np.int64))
+        und_stats.append(((ulp > 0).mean(), ulp.max(), np.abs(a[:, :3] - b[:, :3]).max()))
+
+    n = 22
+
+    class Both:
+        def imu_enqueue(self, *a):
+            hip.imu_enqueue(*a)
+            orc.imu_enqueue(*a)
+
+        def pcl_enqueue(self, *a):
+            hip.pcl_enqueue(*a)
+            orc.pcl_enqueue(*a)
+
+        def main(self):
+            self.rc = (hip.main(), orc.main())
+            return self.rc[0]
+
+        def get_state(self):
+            return np.stack([hip.get_state(), orc.get_state()])
+
+    both = Both()
+    rcs = []
+    res = run_drive(both, scene, tr, n, on_scan=lambda k, rc, p, s: (rcs.append(both.rc), check_cloud(k, rc, p, s)))
+    assert all(a == b for a, b in rcs), rcs
+    assert [a for a, _ in rcs][:7] == [0, 4, 4, 4, 4, 4, 1]
+    for k, (rc, st) in enumerate(res):
+        dp = np.linalg.norm(st[0][0:3] - st[1][0:3])
+        dr = synth.quat_angle(st[0][3:7], st[1][3:7])
+        assert dp < 1e-4 and dr < 1e-5, (k, dp, dr)
+        assert np.abs(st[0][14:17] - st[1][14:17]).max() < 1e-3
+    frac, mx, mabs = np.array(und_stats).T
+    print("undistorted cloud vs oracle: differing coordinates %.2e (max %d ulp, %.2e m)" % (frac.mean(), mx.max(), mabs.max()))
+    assert frac.max() < 1e-3 and mx.max() <= 2 and mabs.max() < 2e-5
+    for k in range(7, n):
+        dp, dr = pose_error(tr, res[k][1][0], (k + 1) * 0.1)
+        assert dp < 0.03 and dr < 5e-3, (k, dp, dr)
+    o_s, o_e = hip.e.fastlio_odometry()
+    assert np.allclose(o_e[:3, 3], res[-1][1][0][0:3]) and np.allclose(o_e[3], [0, 0, 0, 1])
+    assert np.allclose(hip.e.fastlio_start_state(), orc.L.get_odometry()[0], atol=1e-4)
+    assert hip.e.fastlio_is_init()
+    assert abs(hip.e.fastlio_state()[19] - 1.0) < 1e-3  # mean_acc_norm in g
+
+
+def test_device_resident_enqueue_and_filters(oracle_mod, scene):
+    """the device-pointer enqueue gives the same result as the host one; point_filter_num and the undistort switch follow
+    the oracle; a scan without any IMU sample re-registers the previous cloud (the reference's behaviour)"""
+    _dev()
+    import torch
+    from lsd_amd import capi, synth
+
+    tr = synth.Trajectory()
+    cfg = dict(scan_period=0.1, filter_num=3, undistort=False)
+    hip, orc = HipFront(**cfg), OracleFront(oracle_mod, **cfg)
+    imu = synth.imu_stream(tr, 0.0, 2.0, rate=200.0)
+    keep_alive = []
+    ii = 0
+    for k in range(14):
+        tb = k * 0.1
+        pts, st = synth.make_sweep(scene, tr, tb, n_beams=64, n_az=1200, seed=k, fov_deg=(-24.8, 2.0))
+        drop_imu = k == 12  # nothing arrives for this scan
+        while ii < len(imu) and imu[ii][0] <= tb + 0.1:
+            if not drop_imu:
+                hip.imu_enqueue(*imu[ii])
+                orc.imu_enqueue(*imu[ii])
+            ii += 1
+        if drop_imu:  # sync_packages needs a non-empty IMU buffer: a sample beyond the scan end is queued but not consumed
+            hip.imu_enqueue(imu[ii][0] + 0.2, imu[ii][1], imu[ii][2])
+            orc.imu_enqueue(imu[ii][0] + 0.2, imu[ii][1], imu[ii][2])
+        d_p = torch.from_numpy(pts).cuda()
+        d_t = torch.from_numpy(st.astype(np.int64)).to(torch.int32).cuda()  # same 32 bits as uint32
+        keep_alive.append((d_p, d_t))
+        torch.cuda.synchronize()
+        hip.e.fastlio_pcl_enqueue_device(d_p.data_ptr(), d_t.data_ptr(), len(pts), tb)
+        orc.pcl_enqueue(pts, st, tb)
+        ra, rb = hip.main(), orc.main()
+        assert ra == rb, (k, ra, rb)
+        if ra == capi.MAIN_UPDATED and not drop_imu:
+            a = hip.e.undistorted()
+            b = orc.L.get_undistorted()
+            a = a[np.isfinite(a[:, 0])]
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # no compensation: the filters alone, bit-exact
+            assert abs(len(b) - (len(pts) + 2) // 3) <= len(pts) // 100
+        sa, sb = hip.get_state(), orc.get_state()
+        assert np.linalg.norm(sa[0:3] - sb[0:3]) < 1e-4 and synth.quat_angle(sa[3:7], sb[3:7]) < 1e-5, k
+    assert hip.main() == capi.MAIN_IDLE

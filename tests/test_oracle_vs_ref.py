@@ -102,3 +102,25 @@ def test_calc_dist(oracle_mod):
         d = (a[:3] - b[:3]).astype(np.float32)
         want = np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
         assert np.float32(refmod.calc_dist(a, b)) == want
+
+
+def test_undistort_point_and_Exp_bit_exact(oracle_mod):
+    """so3_math.h Exp(ang_vel, dt) (the reference's template) and the per-point compensation expression of
+    ImuProcess::UndistortPcl evaluated by real Eigen (scalar build): the oracle reproduces both bit for bit"""
+    ref = refmod
+    from lsd_amd import synth
+
+    rng = np.random.default_rng(0)
+    for _ in range(5000):
+        q = lambda: synth.quat_from_rotvec(rng.normal(size=3) * 0.5)
+        Rm = synth.quat_to_R(q())
+        vel, pos, acc, gyr = rng.normal(size=3) * 5, rng.normal(size=3) * 50, rng.normal(size=3) * 3, rng.normal(size=3) * 0.5
+        dt = rng.uniform(0, 0.02)
+        p = (rng.normal(size=3) * 30).astype(np.float32)
+        epos, erot, ril, til = pos + rng.normal(size=3) * 0.5, q(), q(), rng.normal(size=3) * 0.3
+        a = oracle_mod.undistort_point(Rm, vel, pos, acc, gyr, dt, p, epos, erot, ril, til)
+        b = ref.undistort_point(Rm, vel, pos, acc, gyr, dt, p, epos, erot, ril, til)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(oracle_mod.so3_Exp(gyr, dt).view(np.uint64), ref.so3_Exp(gyr, dt).view(np.uint64))
+    # below the 1e-7 rad/s gate Exp is the identity
+    assert np.array_equal(oracle_mod.so3_Exp([1e-9, 0, 0], 0.1), np.eye(3)) and np.array_equal(ref.so3_Exp([1e-9, 0, 0], 0.1), np.eye(3))
