@@ -80,7 +80,8 @@ def test_drive_matches_oracle(oracle_mod, scene):
         assert np.abs(st[0][14:17] - st[1][14:17]).max() < 1e-3
     frac, mx, mabs = np.array(und_stats).T
     print("undistorted cloud vs oracle: differing coordinates %.2e (max %d ulp, %.2e m)" % (frac.mean(), mx.max(), mabs.max()))
-    assert frac.max() < 1e-3 and mx.max() <= 2 and mabs.max() < 2e-5
+    # once the two filter states differ in their last bits the clouds do too (the poses are inputs of the compensation)
+    assert frac.max() < 1e-3 and mabs.max() < 1e-5
     for k in range(7, n):
         dp, dr = pose_error(tr, res[k][1][0], (k + 1) * 0.1)
         assert dp < 0.03 and dr < 5e-3, (k, dp, dr)
@@ -95,8 +96,20 @@ def test_device_resident_enqueue_and_filters(oracle_mod, scene):
     """the device-pointer enqueue gives the same result as the host one; point_filter_num and the undistort switch follow
     the oracle; a scan without any IMU sample re-registers the previous cloud (the reference's behaviour)"""
     _dev()
-    import torch
+    import ctypes as C
     from lsd_amd import capi, synth
+
+    # device buffers from the HIP runtime the library itself is linked against (no second runtime in the process)
+    hip_rt = C.CDLL("libamdhip64.so")
+    hip_rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip_rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        d = C.c_void_p()
+        assert hip_rt.hipMalloc(C.byref(d), a.nbytes) == 0
+        assert hip_rt.hipMemcpy(d, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        return d
 
     tr = synth.Trajectory()
     cfg = dict(scan_period=0.1, filter_num=3, undistort=False)
@@ -116,11 +129,9 @@ def test_device_resident_enqueue_and_filters(oracle_mod, scene):
         if drop_imu:  # sync_packages needs a non-empty IMU buffer: a sample beyond the scan end is queued but not consumed
             hip.imu_enqueue(imu[ii][0] + 0.2, imu[ii][1], imu[ii][2])
             orc.imu_enqueue(imu[ii][0] + 0.2, imu[ii][1], imu[ii][2])
-        d_p = torch.from_numpy(pts).cuda()
-        d_t = torch.from_numpy(st.astype(np.int64)).to(torch.int32).cuda()  # same 32 bits as uint32
+        d_p, d_t = to_device(pts), to_device(st)
         keep_alive.append((d_p, d_t))
-        torch.cuda.synchronize()
-        hip.e.fastlio_pcl_enqueue_device(d_p.data_ptr(), d_t.data_ptr(), len(pts), tb)
+        hip.e.fastlio_pcl_enqueue_device(d_p.value, d_t.value, len(pts), tb)
         orc.pcl_enqueue(pts, st, tb)
         ra, rb = hip.main(), orc.main()
         assert ra == rb, (k, ra, rb)
@@ -133,3 +144,6 @@ def test_device_resident_enqueue_and_filters(oracle_mod, scene):
         sa, sb = hip.get_state(), orc.get_state()
         assert np.linalg.norm(sa[0:3] - sb[0:3]) < 1e-4 and synth.quat_angle(sa[3:7], sb[3:7]) < 1e-5, k
     assert hip.main() == capi.MAIN_IDLE
+    for d_p, d_t in keep_alive:
+        hip_rt.hipFree(d_p)
+        hip_rt.hipFree(d_t)
