@@ -231,9 +231,13 @@ int lio_fastlio_odometry(lio_engine*, double odom_s[16], double odom_e[16]);
 int lio_fastlio_state(lio_engine*, double out[20]);
 /* test visibility: p_imu->start_state_point as a 26-double state, feats_undistort (dropped points are NaN), and one
  * esekf::predict step on the host (esekfom.hpp:279-383; Q = diagonal of the 12 x 12 process noise: ng, na, nbg, nba;
- * acc in m/s^2) */
+ * acc in m/s^2); and one update_iterated_dyn_share_modified (esekfom.hpp:1619-1931) on the host with a caller-supplied
+ * measurement model fn(ctx, state26, converge, &n, rows6 n x 6, h n, cap) -> valid, for pinning the filter algebra */
 int lio_fastlio_start_state(lio_engine*, double s26[26]);
 int lio_fastlio_download_undistorted(lio_engine*, float* out_xyzi, uint32_t cap, uint32_t* n);
+typedef int (*lio_meas_fn)(void* ctx, const double* s26, int converge, int* n, double* rows6, double* h, int cap);
+int lio_eskf_update_cb(const double s26[26], const double P[529], double R, int max_iter, lio_meas_fn fn, void* ctx, int cap, double s26_out[26],
+                       double P_out[529]);
 int lio_state_predict(const double s26[26], const double P[529], double dt, const double Q[12], const double acc[3], const double gyro[3],
                       double s26_out[26], double P_out[529]);
 

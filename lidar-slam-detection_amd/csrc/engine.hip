@@ -20,9 +20,12 @@ struct ImuSample {
     double stamp;
     double acc[3], gyr[3];  // acc in units of g (fastlio_imu_enqueue divides by 9.81)
 };
-struct PinnedScan {  // one pinned staging buffer: xyzi then stamps
+struct PinnedScan {  // one staging slot: pinned host buffer (xyzi then stamps), its device twin and the copy-done event
     float4* xyzi = nullptr;
     uint32_t* stamp = nullptr;
+    float4* d_xyzi = nullptr;
+    uint32_t* d_stamp = nullptr;
+    hipEvent_t copied = nullptr;
 };
 struct PendingScan {
     double beg = 0;
@@ -56,8 +59,7 @@ struct Frontend {
     LioState start_state, end_state;
     bool have_undistorted = false;
     // device side
-    float4* d_in = nullptr;
-    uint32_t* d_stamp = nullptr;
+    hipStream_t copy_stream = nullptr;  // host scans travel at enqueue time, overlapping the scan being registered
     ImuPoseDev* d_poses = nullptr;
     ImuPoseDev* h_poses = nullptr;  // pinned
     unsigned long long* d_first = nullptr;
@@ -529,9 +531,9 @@ static void frontend_destroy(lio_engine* e) {
     if (!f) return;
     hipSetDevice(e->scan->device);
     hipStreamSynchronize(e->scan->stream);
-    for (PinnedScan& b : f->pool) hipHostFree(b.xyzi);
-    if (f->d_in) hipFree(f->d_in);
-    if (f->d_stamp) hipFree(f->d_stamp);
+    if (f->copy_stream) hipStreamSynchronize(f->copy_stream);
+    for (PinnedScan& b : f->pool) { hipHostFree(b.xyzi); hipFree(b.d_xyzi); hipEventDestroy(b.copied); }
+    if (f->copy_stream) hipStreamDestroy(f->copy_stream);
     if (f->d_poses) hipFree(f->d_poses);
     if (f->d_first) hipFree(f->d_first);
     if (f->h_poses) hipHostFree(f->h_poses);
@@ -653,15 +655,14 @@ static int fe_undistort(lio_engine* e, const PendingScan& sc, const std::vector<
     Frontend* f = e->fe;
     lio_scan* s = e->scan;
     const auto h0 = std::chrono::steady_clock::now();
-    // the points start travelling first: the propagation below overlaps the copy
     const float4* d_in = sc.d_xyzi;
     const uint32_t* d_stamp = sc.d_stamp;
-    if (sc.pinned >= 0) {
-        const PinnedScan& b = f->pool[sc.pinned];
-        LIO_HIP_TRY(hipMemcpyAsync(f->d_in, b.xyzi, (size_t)sc.n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-        LIO_HIP_TRY(hipMemcpyAsync(f->d_stamp, b.stamp, (size_t)sc.n * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-        d_in = f->d_in;
-        d_stamp = f->d_stamp;
+    if (sc.pinned >= 0) {  // a host scan has been travelling since lio_fastlio_pcl_enqueue
+        PinnedScan b;
+        { std::lock_guard<std::mutex> lk(f->mtx); b = f->pool[sc.pinned]; }
+        LIO_HIP_TRY(hipStreamWaitEvent(s->stream, b.copied, 0));
+        d_in = b.d_xyzi;
+        d_stamp = b.d_stamp;
     }
     const double na = norm3_eig(f->mean_acc);
     double Q[12];
@@ -749,8 +750,7 @@ int lio_fastlio_init(lio_engine* e, const double extT[3], const double extR[9], 
     f->max_point_num = max_point_num;
     f->scan_period = scan_period;
     f->undistort = undistort != 0;
-    LIO_HIP_TRY(hipMalloc(&f->d_in, (size_t)s->max_raw * sizeof(float4)));
-    LIO_HIP_TRY(hipMalloc(&f->d_stamp, (size_t)s->max_raw * sizeof(uint32_t)));
+    LIO_HIP_TRY(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
     LIO_HIP_TRY(hipMalloc(&f->d_poses, sizeof(ImuPoseDev) * kMaxImuPoses));
     LIO_HIP_TRY(hipMalloc(&f->d_first, sizeof(unsigned long long)));
     LIO_HIP_TRY(hipMemsetAsync(f->d_first, 0xff, sizeof(unsigned long long), s->stream));
@@ -798,13 +798,18 @@ static int fe_enqueue(lio_engine* e, const float* xyzi, const uint32_t* stamp_us
             std::lock_guard<std::mutex> lk(f->mtx);
             if (!f->pool_free.empty()) { slot = f->pool_free.back(); f->pool_free.pop_back(); }
         }
-        if (slot < 0) {  // grow the pool of pinned staging buffers (recycled by fastlio_main)
-            hipSetDevice(s->device);
+        hipSetDevice(s->device);
+        if (slot < 0) {  // grow the pool of staging slots (recycled by fastlio_main)
             PinnedScan b;
-            void* mem = nullptr;
-            LIO_HIP_TRY(hipHostMalloc(&mem, (size_t)s->max_raw * (sizeof(float4) + sizeof(uint32_t)), hipHostMallocDefault));
+            void *mem = nullptr, *dmem = nullptr;
+            const size_t bytes = (size_t)s->max_raw * (sizeof(float4) + sizeof(uint32_t));
+            LIO_HIP_TRY(hipHostMalloc(&mem, bytes, hipHostMallocDefault));
+            LIO_HIP_TRY(hipMalloc(&dmem, bytes));
+            LIO_HIP_TRY(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
             b.xyzi = static_cast<float4*>(mem);
             b.stamp = reinterpret_cast<uint32_t*>(b.xyzi + s->max_raw);
+            b.d_xyzi = static_cast<float4*>(dmem);
+            b.d_stamp = reinterpret_cast<uint32_t*>(b.d_xyzi + s->max_raw);
             std::lock_guard<std::mutex> lk(f->mtx);
             f->pool.push_back(b);
             slot = (int)f->pool.size() - 1;
@@ -813,6 +818,11 @@ static int fe_enqueue(lio_engine* e, const float* xyzi, const uint32_t* stamp_us
         { std::lock_guard<std::mutex> lk(f->mtx); b = f->pool[slot]; }
         memcpy(b.xyzi, xyzi, (size_t)n * sizeof(float4));
         memcpy(b.stamp, stamp_us, (size_t)n * sizeof(uint32_t));
+        if (n) {
+            LIO_HIP_TRY(hipMemcpyAsync(b.d_xyzi, b.xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, f->copy_stream));
+            LIO_HIP_TRY(hipMemcpyAsync(b.d_stamp, b.stamp, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, f->copy_stream));
+        }
+        LIO_HIP_TRY(hipEventRecord(b.copied, f->copy_stream));
         sc.pinned = slot;
     }
     std::lock_guard<std::mutex> lk(f->mtx);
@@ -934,6 +944,41 @@ int lio_state_predict(const double s26[26], const double P[529], double dt, cons
     state_from_array(s26, kf.x);
     memcpy(kf.P, P, sizeof(double) * 529);
     kf.predict(dt, Q, acc, gyro);
+    state_to_array(kf.x, s26_out);
+    memcpy(P_out, kf.P, sizeof(double) * 529);
+    return LIO_OK;
+}
+
+// Host-only: one esekf::update_iterated_dyn_share_modified (esekfom.hpp:1619-1931) on the product's filter with the
+// measurement model supplied by the caller -- fn(ctx, state26, converge, &n, rows n x 6 (first six columns of h_x), h n,
+// cap) -> valid.  The device path hands the filter the 6 x 6 normal equations; here they are summed from the rows.  Used
+// by the CPU tests that pin the filter algebra against the reference's own IKFoM code.
+int lio_eskf_update_cb(const double s26[26], const double P[529], double R, int max_iter, lio_meas_fn fn, void* ctx, int cap, double s26_out[26],
+                       double P_out[529]) {
+    if (!s26 || !P || !fn || !s26_out || !P_out || cap <= 0 || max_iter < 0) return LIO_E_INVALID;
+    Eskf kf;
+    state_from_array(s26, kf.x);
+    memcpy(kf.P, P, sizeof(double) * 529);
+    kf.maximum_iter = max_iter;
+    std::vector<double> rows((size_t)cap * 6), hv(cap);
+    auto measure = [&](const LioState& x, bool converge, Measurement& m) {
+        double st[26];
+        state_to_array(x, st);
+        int n = 0;
+        if (!fn(ctx, st, converge ? 1 : 0, &n, rows.data(), hv.data(), cap) || n <= 0 || n > cap) { m.valid = false; return; }
+        m.valid = true;
+        m.n_rows = n;
+        for (int a = 0; a < 36; a++) m.HTH[a] = 0;
+        for (int a = 0; a < 6; a++) m.HTh[a] = 0;
+        for (int r = 0; r < n; r++)
+            for (int a = 0; a < 6; a++) {
+                for (int b = 0; b < 6; b++) m.HTH[a * 6 + b] += rows[(size_t)r * 6 + a] * rows[(size_t)r * 6 + b];
+                m.HTh[a] += rows[(size_t)r * 6 + a] * hv[r];
+            }
+        m.rows6 = rows.data();
+        m.h = hv.data();
+    };
+    kf.update_iterated(R, measure, nullptr, nullptr);
     state_to_array(kf.x, s26_out);
     memcpy(P_out, kf.P, sizeof(double) * 529);
     return LIO_OK;

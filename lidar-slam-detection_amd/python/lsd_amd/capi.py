@@ -29,7 +29,7 @@ SYMBOLS = [
     "lio_state_boxplus", "lio_state_boxminus",
     "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
-    "lio_state_predict",
+    "lio_state_predict", "lio_eskf_update_cb",
     "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_voxel_at",
     "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align",
 ]
@@ -45,6 +45,9 @@ class NormalEq(C.Structure):
 class PassLog(C.Structure):
     _fields_ = [("knn", C.c_int32), ("n_eff", C.c_int32), ("valid", C.c_int32), ("degenerate", C.c_int32), ("sum_abs_res", C.c_double),
                 ("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6), ("dx", C.c_double * 23)]
+
+
+MEAS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
 
 
 class Timings(C.Structure):
@@ -151,7 +154,9 @@ def lib():
     sig("lio_fastlio_state", cint, vp, f64p)
     sig("lio_fastlio_start_state", cint, vp, f64p)
     sig("lio_fastlio_download_undistorted", cint, vp, f32p, u32, C.POINTER(u32))
+    sig("lio_eskf_update_cb", cint, f64p, f64p, dbl, cint, MEAS_FN, vp, cint, f64p, f64p)
     sig("lio_state_predict", cint, f64p, f64p, dbl, f64p, f64p, f64p, f64p, f64p)
+    sig("lio_eskf_update_cb", cint, f64p, f64p, dbl, cint, MEAS_FN, vp, cint, f64p, f64p)
     sig("lio_scan_enable_kernel_timing", cint, vp, cint)
     sig("lio_scan_kernel_times", cint, vp, C.POINTER(KernelTimes), cint)
     sig("lio_ndt_create", vp, cint, flt, cint, u64, u64, u32)

@@ -456,3 +456,28 @@ def state_predict(s, P, dt, Q12, acc, gyro):
     check(lib().lio_state_predict(ptr(s, C.c_double), ptr(P, C.c_double), float(dt), ptr(q, C.c_double), ptr(a, C.c_double), ptr(g, C.c_double),
                                   ptr(so, C.c_double), ptr(Po, C.c_double)))
     return so, Po.reshape(23, 23)
+
+
+def make_meas_fn(model):
+    """wrap model(state26, converge) -> (rows (n, 6), h (n,)) or None as the C measurement callback of lio_eskf_update_cb"""
+    def _cb(ctx, s26, converge, n_out, rows, h, cap):
+        r = model(np.ctypeslib.as_array(s26, shape=(STATE_DIM,)).copy(), bool(converge))
+        if r is None:
+            return 0
+        R, H = np.asarray(r[0], np.float64).reshape(-1, 6), np.asarray(r[1], np.float64).ravel()
+        n = len(H)
+        assert n <= cap and len(R) == n
+        np.ctypeslib.as_array(rows, shape=(cap * 6,))[:n * 6] = R.ravel()
+        np.ctypeslib.as_array(h, shape=(cap,))[:n] = H
+        n_out[0] = n
+        return 1
+    return capi.MEAS_FN(_cb)
+
+
+def eskf_update(s, P, R, model, max_iter=4, cap=4096):
+    """one iterated ESKF update on the host filter with a Python measurement model (see make_meas_fn)"""
+    s, P = f64(s), f64(P).reshape(-1)
+    so, Po = np.zeros(STATE_DIM), np.zeros(529)
+    fn = make_meas_fn(model)
+    check(lib().lio_eskf_update_cb(ptr(s, C.c_double), ptr(P, C.c_double), float(R), max_iter, fn, None, cap, ptr(so, C.c_double), ptr(Po, C.c_double)))
+    return so, Po.reshape(23, 23)

@@ -893,7 +893,25 @@ struct Lio {
     }
 
     // laserMapping.cpp:984-1023 (wheelspeed_en == false -> wheel block never valid)
+    // measurement model supplied from outside (tests/test_ikfom_vs_ref.py drives the oracle, the product's host filter and
+    // the reference's real esekf with the same rows): fn(ctx, state26, converge, &n, rows n x 6, h n, cap) -> valid
+    typedef int (*meas_fn)(void* ctx, const double* s26, int converge, int* n, double* rows6, double* h, int cap);
+    meas_fn ext_fn = nullptr;
+    void* ext_ctx = nullptr;
+    int ext_cap = 0;
     void h_share_model(const State& s, DynShare& d) {
+        if (ext_fn) {
+            double s26[26];
+            state_to(s, s26);
+            std::vector<double> rows((size_t)ext_cap * 6), hv(ext_cap);
+            int n = 0;
+            if (!ext_fn(ext_ctx, s26, d.converge ? 1 : 0, &n, rows.data(), hv.data(), ext_cap)) { d.valid = false; return; }
+            d.h_x = Mat(n, 15);
+            d.h.assign(hv.begin(), hv.begin() + n);
+            for (int r = 0; r < n; r++) for (int c = 0; c < 6; c++) d.h_x(r, c) = rows[(size_t)r * 6 + c];
+            effct_feat_num = n;
+            return;
+        }
         DynShare geo = d;  // copy: stale h_x / h of the previous pass survive an early return
         h_share_model_geometric(s, geo);
         const int n_terms = (int)geo.h.size();
@@ -1694,6 +1712,18 @@ void orc_undistort_point(const double* R_imu9, const double* vel3, const double*
     float q[3] = {p_xyz[0], p_xyz[1], p_xyz[2]};
     undistort_point(R_imu9, v3(vel3), v3(pos3), v3(acc3), v3(gyr3), dt, q, v3(end_pos3), q4(end_rot_xyzw), q4(ril_xyzw), v3(til3));
     out_xyz[0] = q[0]; out_xyz[1] = q[1]; out_xyz[2] = q[2];
+}
+
+// esekf::update_iterated_dyn_share_modified with an externally supplied measurement model
+void orc_kf_update_cb(const double* s26, const double* P, double R, int max_iter, Lio::meas_fn fn, void* ctx, int cap, double* s26_out, double* P_out) {
+    Lio l(0.5f, 19, 1000, 100.0);
+    state_from(s26, l.x);
+    for (int i = 0; i < 23; i++) for (int j = 0; j < 23; j++) l.P(i, j) = P[i * 23 + j];
+    l.max_iter = max_iter;
+    l.ext_fn = fn; l.ext_ctx = ctx; l.ext_cap = cap;
+    l.update_iterated(R);
+    state_to(l.x, s26_out);
+    for (int i = 0; i < 23; i++) for (int j = 0; j < 23; j++) P_out[i * 23 + j] = l.P(i, j);
 }
 
 // manifold helpers exposed for the known-answer tests

@@ -17,6 +17,9 @@ DOF = 23
 G_LEN = 9.809
 
 
+MEAS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+
+
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "lio_oracle.cpp")):
         subprocess.check_call(["make", "-C", _HERE, "liblio_oracle.so"], stdout=subprocess.DEVNULL)
@@ -78,6 +81,7 @@ def lib():
     L.orc_lio_get_undistorted.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_lio_get_undistorted.restype = C.c_int
     L.orc_lio_get_odometry.argtypes = [C.c_void_p, f64p, f64p]
+    L.orc_kf_update_cb.argtypes = [f64p, f64p, C.c_double, C.c_int, MEAS_FN, C.c_void_p, C.c_int, f64p, f64p]
     L.orc_so3_Exp.argtypes = [f64p, C.c_double, f64p]
     L.orc_undistort_point.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_double, f32p, f64p, f64p, f64p, f64p, f32p]
     L.orc_lio_get_ds.argtypes = [C.c_void_p, f32p, C.c_int]
@@ -407,3 +411,11 @@ def undistort_point(R_imu, vel, pos, acc, gyr, dt, p, end_pos, end_rot, ril, til
     out = np.zeros(3, np.float32)
     lib().orc_undistort_point(*[_p(v, C.c_double) for v in a], float(dt), _p(pp, C.c_float), *[_p(v, C.c_double) for v in b], _p(out, C.c_float))
     return out
+
+
+def kf_update(s, P, R, meas_fn, max_iter=4, cap=4096):
+    """esekf::update_iterated_dyn_share_modified restated, with a caller-supplied measurement model (a MEAS_FN)"""
+    s, P = _f64(s), _f64(P).reshape(-1)
+    so, Po = np.zeros(STATE_DIM), np.zeros(529)
+    lib().orc_kf_update_cb(_p(s, C.c_double), _p(P, C.c_double), float(R), max_iter, meas_fn, None, cap, _p(so, C.c_double), _p(Po, C.c_double))
+    return so, Po.reshape(23, 23)
