@@ -36,9 +36,9 @@ def main():
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--n-az", type=int, default=1875)
     ap.add_argument("--scan-pool", type=int, default=8, help="distinct scans cycled through the steps")
-    ap.add_argument("--cpu-scans", type=int, default=24, help="scans of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-scans", type=int, default=320, help="scans of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=1000)
-    ap.add_argument("--streams", type=int, default=4, help="independent scans in flight per GPU (one engine + HIP stream + host thread each, "
+    ap.add_argument("--streams", type=int, default=8, help="independent scans in flight per GPU (one engine + HIP stream + host thread each, "
                                                               "all reading the one resident map)")
     args = ap.parse_args()
 

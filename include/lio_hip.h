@@ -203,6 +203,7 @@ int lio_engine_enable_timing(lio_engine*, int on);
  *   lio_fastlio_init ............ fastlio_init          src/laserMapping.cpp:1025-1124 (extR row-major 3x3)
  *   lio_fastlio_is_init ......... fastlio_is_init       src/laserMapping.cpp:740-743
  *   lio_fastlio_imu_enqueue ..... fastlio_imu_enqueue   src/laserMapping.cpp:397-415 (acc in m/s^2, divided by 9.81 inside)
+ *   lio_fastlio_ins_enqueue ..... fastlio_ins_enqueue   src/laserMapping.cpp:417-441
  *   lio_fastlio_pcl_enqueue ..... fastlio_pcl_enqueue   src/laserMapping.cpp:311-330 + Preprocess::velodyne_handler
  *                                 src/preprocess.cpp:395-451: xyzi float4 + PointAttr::stamp (us relative to the header
  *                                 stamp, common/mapping_types.h:26-29); header_stamp in seconds
@@ -223,6 +224,10 @@ int lio_fastlio_init(lio_engine*, const double extT[3], const double extR[9], in
                      int undistort);
 int lio_fastlio_is_init(lio_engine*);
 int lio_fastlio_imu_enqueue(lio_engine*, double stamp, const double gyr[3], const double acc_ms2[3]);
+/* fastlio_ins_enqueue (src/laserMapping.cpp:417-441) after the ENU -> ego -> IMU rotation the reference applies there:
+ * vel_imu = Lidar_R_wrt_IMU * Tve^-1 * (Ve, Vn, Vu), third component zeroed by the caller as :436 does.  Only IMU
+ * initialisation reads it (IMU_Processing.hpp:201-204; the wheel-speed rows are compiled out, wheelspeed_en == false) */
+int lio_fastlio_ins_enqueue(lio_engine*, double stamp, const double vel_imu[3]);
 int lio_fastlio_pcl_enqueue(lio_engine*, const float* xyzi, const uint32_t* stamp_us, uint32_t n, double header_stamp);
 /* device-resident scan: the two buffers must stay valid until the lio_fastlio_main call that consumes them returned */
 int lio_fastlio_pcl_enqueue_device(lio_engine*, const void* d_xyzi, const void* d_stamp_us, uint32_t n, double header_stamp);

@@ -4,6 +4,7 @@
 // both filters, INIT_TIME 0.1 s, LASER_POINT_COV 0.001, degeneracy detection on, extrinsic estimation off.
 #include <atomic>
 #include <chrono>
+#include <array>
 #include <deque>
 #include <mutex>
 #include <thread>
@@ -38,6 +39,7 @@ struct Frontend {
     std::mutex mtx;  // mtx_buffer: the enqueue calls come from sensor threads
     std::deque<ImuSample> imu_buffer;
     std::deque<PendingScan> lidar_buffer;
+    std::deque<std::pair<double, std::array<double, 3>>> ins_buffer;  // (stamp s, velocity in the IMU frame)
     std::vector<PinnedScan> pool;
     std::vector<int> pool_free;
     // fastlio_init arguments / Preprocess members
@@ -572,7 +574,7 @@ static void fe_set_Q(const Frontend* f, double Q[12]) {
 }
 
 // IMU_Processing.hpp:164-236
-static void fe_imu_init(lio_engine* e, const std::vector<ImuSample>& imu, double lidar_end) {
+static void fe_imu_init(lio_engine* e, const std::vector<ImuSample>& imu, double lidar_end, const double* ins_vel) {
     Frontend* f = e->fe;
     int& N = f->init_iter_num;
     if (f->b_first_frame) {  // Reset()
@@ -593,6 +595,8 @@ static void fe_imu_init(lio_engine* e, const std::vector<ImuSample>& imu, double
         }
         N++;
     }
+    if (ins_vel)  // IMU_Processing.hpp:201-204: the last INS velocity of this scan is the initial velocity
+        for (int i = 0; i < 3; i++) f->vel_last[i] = ins_vel[i];
     const double na = norm3_eig(f->mean_acc), ng = norm3_eig(f->mean_gyr);
     f->mean_acc_norm = na;
     if (fabs(na - 1.0) > 0.1 || ng > (10.0 / 180.0 * M_PI)) {  // "FastLIO IMU init is not stable, reset"
@@ -781,6 +785,15 @@ int lio_fastlio_imu_enqueue(lio_engine* e, double stamp, const double gyr[3], co
     return LIO_OK;
 }
 
+// fastlio_ins_enqueue (laserMapping.cpp:417-441) after its ENU -> ego -> IMU rotation: the caller passes the velocity in the
+// IMU frame (the reference zeroes its third component, :436); consumed by IMU initialisation only (wheelspeed_en == false)
+int lio_fastlio_ins_enqueue(lio_engine* e, double stamp, const double vel_imu[3]) {
+    if (!e || !e->fe || !vel_imu) return LIO_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->fe->mtx);
+    e->fe->ins_buffer.push_back({stamp, {vel_imu[0], vel_imu[1], vel_imu[2]}});
+    return LIO_OK;
+}
+
 static int fe_enqueue(lio_engine* e, const float* xyzi, const uint32_t* stamp_us, uint32_t n, double header_stamp, bool device) {
     if (!e || !e->fe || (n && (!xyzi || !stamp_us))) return LIO_E_INVALID;
     Frontend* f = e->fe;
@@ -843,6 +856,8 @@ int lio_fastlio_main(lio_engine* e) {
     PendingScan sc;
     std::vector<ImuSample> meas_imu;
     double lidar_end;
+    double ins_vel[3] = {0, 0, 0};
+    bool have_ins = false;
     {   // sync_packages (laserMapping.cpp:445-520)
         std::lock_guard<std::mutex> lk(f->mtx);
         if (f->lidar_buffer.empty() || f->imu_buffer.empty()) return LIO_MAIN_IDLE;
@@ -852,6 +867,11 @@ int lio_fastlio_main(lio_engine* e) {
         while (!f->imu_buffer.empty() && !(f->imu_buffer.front().stamp > lidar_end)) {
             meas_imu.push_back(f->imu_buffer.front());
             f->imu_buffer.pop_front();
+        }
+        while (!f->ins_buffer.empty() && !(f->ins_buffer.front().first > lidar_end)) {  // meas.ins (laserMapping.cpp:495-503)
+            for (int i = 0; i < 3; i++) ins_vel[i] = f->ins_buffer.front().second[i];
+            have_ins = true;
+            f->ins_buffer.pop_front();
         }
     }
     hipSetDevice(s->device);
@@ -873,7 +893,7 @@ int lio_fastlio_main(lio_engine* e) {
         return rc;
     }
     if (f->imu_need_init) {  // IMU_Processing.hpp:416-441
-        fe_imu_init(e, meas_imu, lidar_end);
+        fe_imu_init(e, meas_imu, lidar_end, have_ins ? ins_vel : nullptr);
         f->imu_need_init = true;
         f->last_imu = meas_imu.back();
         if (f->init_iter_num > 100) {  // MAX_INI_COUNT

@@ -27,7 +27,7 @@ SYMBOLS = [
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
     "lio_engine_enable_timing", "lio_engines_process_batch", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
-    "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
+    "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_ins_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
     "lio_state_predict", "lio_eskf_update_cb",
     "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_voxel_at",
@@ -147,6 +147,7 @@ def lib():
     sig("lio_fastlio_init", cint, vp, f64p, f64p, cint, cint, dbl, cint)
     sig("lio_fastlio_is_init", cint, vp)
     sig("lio_fastlio_imu_enqueue", cint, vp, dbl, f64p, f64p)
+    sig("lio_fastlio_ins_enqueue", cint, vp, dbl, f64p)
     sig("lio_fastlio_pcl_enqueue", cint, vp, f32p, C.POINTER(u32), u32, dbl)
     sig("lio_fastlio_pcl_enqueue_device", cint, vp, vp, vp, u32, dbl)
     sig("lio_fastlio_main", cint, vp)

@@ -294,6 +294,10 @@ class Engine:
         g, a = f64(gyr), f64(acc_ms2)
         check(lib().lio_fastlio_imu_enqueue(self.h, float(stamp), ptr(g, C.c_double), ptr(a, C.c_double)))
 
+    def fastlio_ins_enqueue(self, stamp, vel_imu):
+        v = f64(vel_imu)
+        check(lib().lio_fastlio_ins_enqueue(self.h, float(stamp), ptr(v, C.c_double)))
+
     def fastlio_pcl_enqueue(self, xyzi, stamp_us, header_stamp):
         p = f32(xyzi).reshape(-1, 4)
         t = np.ascontiguousarray(stamp_us, np.uint32)

@@ -1156,6 +1156,7 @@ struct Lio {
     struct Pose6 { double off; V3 acc, gyr, vel, pos; double R[9]; };
     std::deque<Imu> imu_buffer;
     std::deque<ScanIn> lidar_buffer;
+    std::deque<std::pair<double, V3>> ins_buffer;  // (stamp, velocity in the IMU frame) -- fastlio_ins_enqueue after its rotations
     double lidar_mean_scantime = 0.1;  // scan_period (laserMapping.cpp:1121)
     // ImuProcess members
     bool b_first_frame = true, imu_need_init = true;
@@ -1292,7 +1293,7 @@ struct Lio {
         for (int i = 0; i < 3; i++) { Qd[i] = cov_gyr[i]; Qd[3 + i] = cov_acc[i]; Qd[6 + i] = cov_bias_gyr[i]; Qd[9 + i] = cov_bias_acc[i]; }
     }
 
-    void imu_init(const std::vector<Imu>& imu, double lidar_beg, double lidar_end) {
+    void imu_init(const std::vector<Imu>& imu, double lidar_beg, double lidar_end, const V3* ins_vel = nullptr) {
         int& N = init_iter_num;
         if (b_first_frame) {
             // Reset()
@@ -1312,6 +1313,7 @@ struct Lio {
             }
             N++;
         }
+        if (ins_vel) vel_last = *ins_vel;  // IMU_Processing.hpp:201-204
         const double na = std::sqrt(mean_acc[0] * mean_acc[0] + (mean_acc[1] * mean_acc[1] + mean_acc[2] * mean_acc[2]));
         const double ng = std::sqrt(mean_gyr[0] * mean_gyr[0] + (mean_gyr[1] * mean_gyr[1] + mean_gyr[2] * mean_gyr[2]));
         if (std::fabs(na - 1.0) > 0.1 || ng > (10.0 / 180.0 * M_PI)) { b_first_frame = true; return; }
@@ -1423,6 +1425,9 @@ struct Lio {
         const double lidar_end = sc.beg + lidar_mean_scantime;
         std::vector<Imu> meas_imu;
         while (!imu_buffer.empty() && !(imu_buffer.front().stamp > lidar_end)) { meas_imu.push_back(imu_buffer.front()); imu_buffer.pop_front(); }
+        bool have_ins = false;
+        V3 ins_vel{{0, 0, 0}};
+        while (!ins_buffer.empty() && !(ins_buffer.front().first > lidar_end)) { ins_vel = ins_buffer.front().second; have_ins = true; ins_buffer.pop_front(); }
         if (flg_first_scan) { first_lidar_time = sc.beg; flg_first_scan = false; return 0; }
         // Process() returns at once when no IMU sample fell into the scan: feats_undistort keeps the PREVIOUS scan's cloud
         // and fastlio_main registers that again (IMU_Processing.hpp:413, laserMapping.cpp:1189-1197)
@@ -1433,7 +1438,7 @@ struct Lio {
             return rc0;
         }
         if (imu_need_init) {
-            imu_init(meas_imu, sc.beg, lidar_end);
+            imu_init(meas_imu, sc.beg, lidar_end, have_ins ? &ins_vel : nullptr);
             imu_need_init = true;
             last_imu = meas_imu.back();
             if (init_iter_num > 100) {  // MAX_INI_COUNT (IMU_Processing.hpp:25)
@@ -1687,6 +1692,7 @@ void orc_lio_frontend_config(void* h, const double* extT, const double* extR_xyz
     l->lidar_mean_scantime = scan_period;
     l->undistort_en = undistort != 0;
 }
+void orc_lio_ins_enqueue(void* h, double stamp, const double* v) { static_cast<Lio*>(h)->ins_buffer.push_back({stamp, V3{{v[0], v[1], v[2]}}}); }
 int orc_lio_frontend_main(void* h) { return static_cast<Lio*>(h)->frontend_main(); }
 void orc_lio_predict(void* h, double dt, const double* acc, const double* gyro) {
     static_cast<Lio*>(h)->predict(dt, V3{{acc[0], acc[1], acc[2]}}, V3{{gyro[0], gyro[1], gyro[2]}});

@@ -75,6 +75,7 @@ def lib():
     L.orc_lio_imu_enqueue.argtypes = [C.c_void_p, C.c_double, f64p, f64p]
     L.orc_lio_pcl_enqueue.argtypes = [C.c_void_p, f32p, C.POINTER(C.c_uint32), C.c_int, C.c_double]
     L.orc_lio_frontend_config.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, C.c_int]
+    L.orc_lio_ins_enqueue.argtypes = [C.c_void_p, C.c_double, f64p]
     L.orc_lio_frontend_main.argtypes = [C.c_void_p]
     L.orc_lio_frontend_main.restype = C.c_int
     L.orc_lio_predict.argtypes = [C.c_void_p, C.c_double, f64p, f64p]
@@ -267,6 +268,10 @@ class Lio:
     def frontend_config(self, extT=(0, 0, 0), extR_xyzw=(0, 0, 0, 1), filter_num=1, scan_period=0.1, undistort=True):
         t, r = _f64(extT), _f64(extR_xyzw)
         lib().orc_lio_frontend_config(self.h, _p(t, C.c_double), _p(r, C.c_double), filter_num, float(scan_period), int(undistort))
+
+    def ins_enqueue(self, stamp, vel_imu):
+        v = _f64(vel_imu)
+        lib().orc_lio_ins_enqueue(self.h, float(stamp), _p(v, C.c_double))
 
     def frontend_main(self):
         return lib().orc_lio_frontend_main(self.h)

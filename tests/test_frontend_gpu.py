@@ -129,6 +129,9 @@ def test_device_resident_enqueue_and_filters(oracle_mod, scene):
         if drop_imu:  # sync_packages needs a non-empty IMU buffer: a sample beyond the scan end is queued but not consumed
             hip.imu_enqueue(imu[ii][0] + 0.2, imu[ii][1], imu[ii][2])
             orc.imu_enqueue(imu[ii][0] + 0.2, imu[ii][1], imu[ii][2])
+        if k == 3:  # a GNSS velocity during IMU initialisation becomes the initial velocity on both sides
+            hip.e.fastlio_ins_enqueue(tb + 0.05, [0.01, -0.02, 0.0])
+            orc.L.ins_enqueue(tb + 0.05, [0.01, -0.02, 0.0])
         d_p, d_t = to_device(pts), to_device(st)
         keep_alive.append((d_p, d_t))
         hip.e.fastlio_pcl_enqueue_device(d_p.value, d_t.value, len(pts), tb)
