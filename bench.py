@@ -100,6 +100,13 @@ def main():
         if rc != 3:
             raise RuntimeError(f"process_scan returned {rc}")
 
+    # Setup, untimed: push enough launches through every engine's stream for the HIP runtime to finish growing its
+    # per-queue pools -- a one-off ~35 ms stall shows up after roughly 190 scans (~5 000 kernel launches) of a fresh
+    # process and never again (tools/experiments/README.md); a service hits it once at start-up.
+    prime = [dict(dptr=d_scans[i % len(scans)].data_ptr(), n=len(scans[i % len(scans)]["raw"]), t=1.0 + 0.1 * i, state=scans[i % len(scans)]["guess"],
+                  cov=P0) for i in range(40 * n_streams)]
+    lio.process_batch(engines, prime)
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i, engines[i % n_streams])
     # pose check outside the timed region: every pooled scan must land on its true pose
@@ -164,6 +171,17 @@ def main():
         for k in kt:
             kt[k] += k1[k]
         e.scan.enable_kernel_timing(0)
+    # the same kernel launched alone (one stream, nothing else in flight): with S > 1 streams the event interval of a
+    # launch in the timed region also contains the time it shares the device with other scans' kernels
+    eng.scan.enable_kernel_timing(1)
+    eng.scan.kernel_times(reset=True)
+    cand1 = the_map.knn_candidates
+    for i in range(32):
+        step(i)
+    k1 = eng.scan.kernel_times(reset=True)
+    iso_launches = max(int(k1["knn_launches"]), 1)
+    iso_us = k1["knn_us"] / iso_launches
+    iso_bytes = (acc["n_ds"] / max(args.steps, 1)) * (16 + 16 * 19) + 16.0 * (the_map.knn_candidates - cand1) / iso_launches
     # the other per-pass kernel, timed outside the timed region
     eng.scan.enable_kernel_timing(2)
     eng.scan.kernel_times(reset=True)
@@ -178,7 +196,10 @@ def main():
     launches = max(int(kt["knn_launches"]), 1)
     knn_bytes = (acc["n_ds"] / max(args.steps, 1)) * (16 + 16 * S) + 16.0 * cand / launches
     knn_us = kt["knn_us"] / launches
-    achieved = knn_bytes / (knn_us * 1e-6) / 1e9 if knn_us > 0 else 0.0
+    shared = knn_bytes / (knn_us * 1e-6) / 1e9 if knn_us > 0 else 0.0
+    # roofline of the KERNEL = its launches with the device to itself (agrees with rocprofv3's per-kernel duration); the
+    # figure over the timed region (S scans in flight, kernels of different scans overlapping) is reported beside it
+    achieved = iso_bytes / (iso_us * 1e-6) / 1e9 if iso_us > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
     if os.path.exists(tpath):
@@ -187,8 +208,10 @@ def main():
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel="knn_kernel<32,1,0>", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, algorithmic_bytes_per_launch=int(knn_bytes),
-                    avg_launch_us=round(knn_us, 2), launches=launches,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, algorithmic_bytes_per_launch=int(iso_bytes),
+                    avg_launch_us=round(iso_us, 2), launches=iso_launches,
+                    timed_region={"avg_launch_us": round(knn_us, 2), "launches": launches, "achieved": round(shared, 1),
+                                  "frac": round(shared / HBM_PEAK_GBS, 4), "streams": n_streams},
                     other_kernels_us={"linearize+report": round(kt["linearize_us"] / max(kt["linearize_launches"], 1), 2)})
 
     # ---- CPU baseline: the oracle restatement of the same path on a bounded sample of the same workload ---------

@@ -54,7 +54,7 @@ class Map:
             raise capi.LioError("lio_map_create failed: " + lib().lio_last_error().decode())
 
     def close(self):
-        if getattr(self, "h", None) and self._own:
+        if getattr(self, "h", None) and self._own and lib is not None:  # `lib` is gone at interpreter shutdown
             lib().lio_map_destroy(self.h)
         self.h = None
 
@@ -114,7 +114,7 @@ class Scan:
             raise capi.LioError("lio_scan_create failed: " + lib().lio_last_error().decode())
 
     def close(self):
-        if getattr(self, "h", None) and self._own:
+        if getattr(self, "h", None) and self._own and lib is not None:
             lib().lio_scan_destroy(self.h)
         self.h = None
 
@@ -217,7 +217,7 @@ class Engine:
         self.scan = Scan(max_ds=max_ds, _borrow=lib().lio_engine_scan(self.h))
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib().lio_engine_destroy(self.h)
         self.h = None
 
@@ -374,7 +374,7 @@ class Ndt:
             raise capi.LioError("lio_ndt_create failed: " + lib().lio_last_error().decode())
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib().lio_ndt_destroy(self.h)
         self.h = None
 
