@@ -756,8 +756,7 @@ int lio_fastlio_init(lio_engine* e, const double extT[3], const double extR[9], 
     f->undistort = undistort != 0;
     LIO_HIP_TRY(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
     LIO_HIP_TRY(hipMalloc(&f->d_poses, sizeof(ImuPoseDev) * kMaxImuPoses));
-    LIO_HIP_TRY(hipMalloc(&f->d_first, sizeof(unsigned long long)));
-    LIO_HIP_TRY(hipMemsetAsync(f->d_first, 0xff, sizeof(unsigned long long), s->stream));
+    LIO_HIP_TRY(hipMalloc(&f->d_first, sizeof(unsigned long long) * ((size_t)s->max_raw / 256 + 1)));  // workgroup minima of undistort_kernel
     LIO_HIP_TRY(hipHostMalloc(&f->h_poses, sizeof(ImuPoseDev) * kMaxImuPoses, hipHostMallocDefault));
     // the file-scope state fastlio_init resets (laserMapping.cpp:1033-1046,1107-1110)
     e->kf = Eskf();

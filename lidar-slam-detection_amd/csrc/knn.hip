@@ -182,6 +182,7 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
         uint32_t d0 = 0xFFFFFFFFu, d1 = 0xFFFFFFFFu, dd2 = 0xFFFFFFFFu, d3 = 0xFFFFFFFFu, d4 = 0xFFFFFFFFu;
         uint32_t i0d = 0xFFFFFFFFu, i1d = 0xFFFFFFFFu, i2d = 0xFFFFFFFFu, i3d = 0xFFFFFFFFu, i4d = 0xFFFFFFFFu;
         uint32_t inrange = 0;
+        bool drop_tie = false;
         // voxel-major sweep: kU voxel descriptors per batch come back from LDS as ds_read_b128 pairs, lane l takes point l
         // (l+32, ...) of each -- addresses are base + lane (no per-candidate search), kU 16-B loads in flight per lane
         for (uint32_t s0 = 0; s0 < nhit; s0 += kU) {
@@ -221,12 +222,13 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
                             dd2 = med3_u32(d1, dd2, kd);
                             d1 = med3_u32(d0, d1, kd);
                             d0 = min(d0, kd);
+                        } else {
+                            drop_tie |= kd == d4;  // a candidate as far as this lane's fifth is not kept: see the merge
                         }
                     }
                 }
             }
         }
-        const uint32_t lane_seen = inrange;
         unsigned long long e0 = ((unsigned long long)d0 << 32) | i0d, e1 = ((unsigned long long)d1 << 32) | i1d,
                            e2 = ((unsigned long long)dd2 << 32) | i2d, e3 = ((unsigned long long)d3 << 32) | i3d,
                            e4 = ((unsigned long long)d4 << 32) | i4d;
@@ -245,9 +247,10 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
             if (gl == r) win = best;
             if (best != kNoKey && e0 == best) { e0 = e1; e1 = e2; e2 = e3; e3 = e4; e4 = kNoKey; pops++; }
         }
-        // a lane whose whole list went into the top-6 although it had seen more candidates may have dropped one that
-        // belongs there (only possible with all five of the lane's entries among the six best): redo exactly
-        if (__ballot(pops >= 5 && lane_seen > 5) & gmask) tie = true;
+        // The per-lane lists cannot lose a member of the top-5 (whatever a lane drops is no nearer than its own fifth), but
+        // a dropped candidate exactly as far as that fifth would be an undetected tie if all five of the lane's entries
+        // are among the six best: redo such a query exactly.
+        if (__ballot(pops >= 5 && drop_tie) & gmask) tie = true;
         // results.  No in-range candidate at all: GetClosestPoint returns before touching the output
         // (ivox3d.h:152-154), the cached neighbours of an earlier scan survive.
         if (active && inrange > 0) {

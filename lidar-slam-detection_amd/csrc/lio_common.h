@@ -159,7 +159,7 @@ struct UndistortArgs {
     int n_poses, filter_num, undistort;
 };
 int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const ImuPoseDev* d_poses,
-                     const UndistortArgs& args, unsigned long long* d_first_key);
+                     const UndistortArgs& args, unsigned long long* d_block_min /* ceil(n / 256) words of scratch */);
 
 int vg_downsample(lio_scan* s, float leaf);
 int scan_begin(lio_scan* s);

@@ -18,7 +18,7 @@ def main(path, note=""):
     print(f"# durations in microseconds (rocpd stores ns); {sum(r[1] for r in rows)} dispatches, {tot / 1e3:.1f} us of kernel time")
     print("%-64s %8s %12s %10s %10s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
     for name, calls, total, avg, mn, mx in rows:
-        short = name.split("(")[0][-64:]
+        short = name.replace("(anonymous namespace)::", "").split("(")[0][-64:]
         print("%-64s %8d %12.1f %10.2f %10.2f %10.2f %7.2f" % (short, calls, total / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * total / tot))
 
 
