@@ -58,6 +58,16 @@ int lio_map_set_stencil(lio_map*, int stencil);
  * evicts only above `capacity` voxels; this map reports LIO_E_CAPACITY instead of evicting). */
 int lio_map_insert(lio_map*, const float* world_xyzi, uint64_t n, double travel);
 int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double travel);
+/* IVox::Options capacity_ / max_distance_ (ivox3d.h:46-52; 100000 voxels / 100 m at src/laserMapping.cpp:1060-1064): turn
+ * on the LRU list of IVox::AddPoints (ivox3d.h:231-256) -- after every inserted point the least recently touched voxel is
+ * dropped while the map holds more than `capacity_voxels` voxels and that voxel was created more than `max_distance` of
+ * travel ago.  Call before the first insert; `max_voxels` of lio_map_create stays the hard limit and must be larger (the map
+ * overshoots its capacity while nothing is old enough to go).  Off by default (nothing is ever dropped).
+ * lio_map_lru_stats: voxels evicted so far, and an UPPER BOUND on the back-of-list voxels that were touched by the very
+ * batch that was evicting around them (if such a voxel's first point comes after its turn to go, the reference's point-by-
+ * point order drops and re-creates it; here it keeps its points -- the one case where the maps can differ). */
+int lio_map_set_lru(lio_map*, uint64_t capacity_voxels, double max_distance);
+int lio_map_lru_stats(lio_map*, uint64_t* n_evicted, uint64_t* n_interleaved);
 /* IVox::NumValidGrids (ivox3d.h:173-176) and the total number of stored points */
 int lio_map_stats(lio_map*, uint64_t* n_points, uint64_t* n_voxels);
 /* running total of map points visited by stencil kNN queries (the C-bar * N_ds statistic of the roofline model) */

@@ -60,7 +60,7 @@ static int map_check(lio_map* m, hipStream_t st) {
         return LIO_E_DEVICE;
     }
     if (m->host_dev->err) {
-        set_error("map capacity exceeded (err bits 0x%x: 1 table full, 2 point pool full, 4 more than max_voxels voxels)", m->host_dev->err);
+        set_error("map capacity exceeded (err bits 0x%x: 1 table full, 2 point pool full, 4 more than max_voxels voxels, 8 LRU log overrun)", m->host_dev->err);
         return LIO_E_CAPACITY;
     }
     return LIO_OK;
@@ -185,9 +185,45 @@ void lio_map_destroy(lio_map* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->dev);
     hipFree(m->slot_of_point); hipFree(m->tile_sum); hipFree(m->stage);
+    hipFree(m->touch); hipFree(m->prev_touch); hipFree(m->touch2); hipFree(m->prev_touch2); hipFree(m->lru_log); hipFree(m->free_items);
+    hipFree(m->table2); hipFree(m->cap2); hipFree(m->pending2); hipFree(m->created2); hipFree(m->remap);
     if (m->host_dev) hipHostFree(m->host_dev);
     if (m->stream && m->own_stream) hipStreamDestroy(m->stream);
     delete m;
+}
+
+// IVox::Options capacity_ / max_distance_ (ivox3d.h:46-52, set at laserMapping.cpp:1060-1064): enable the LRU list
+int lio_map_set_lru(lio_map* m, uint64_t capacity_voxels, double max_distance) {
+    if (!m || capacity_voxels == 0 || !(max_distance >= 0)) return LIO_E_INVALID;
+    if (m->key_mode != 0) { set_error("lio_map_set_lru: only iVox maps evict"); return LIO_E_STATE; }
+    if (m->n_batches != 0) { set_error("lio_map_set_lru: call before the first insert"); return LIO_E_STATE; }
+    if (capacity_voxels >= m->max_voxels) { set_error("lio_map_set_lru: capacity %llu must be below max_voxels %llu (the map may exceed its capacity while no voxel is old enough to go)", (unsigned long long)capacity_voxels, (unsigned long long)m->max_voxels); return LIO_E_INVALID; }
+    hipSetDevice(m->device);
+    const size_t cap = m->table_cap;
+    uint64_t lc = 1024;
+    while (lc < 8 * (uint64_t)m->max_voxels) lc <<= 1;  // live entries <= voxels; stale ones are skipped as the tail passes them
+    m->lru_log_cap = lc;
+    m->free_cap = (uint32_t)m->max_voxels;
+    bool ok = dev_alloc(&m->touch, cap, &m->bytes) && dev_alloc(&m->prev_touch, cap, &m->bytes) && dev_alloc(&m->touch2, cap, &m->bytes) &&
+              dev_alloc(&m->prev_touch2, cap, &m->bytes) && dev_alloc(&m->lru_log, lc, &m->bytes) && dev_alloc(&m->free_items, (uint64_t)24 * m->free_cap, &m->bytes) &&
+              dev_alloc(&m->table2, cap, &m->bytes) && dev_alloc(&m->cap2, cap, &m->bytes) && dev_alloc(&m->pending2, cap, &m->bytes) &&
+              dev_alloc(&m->created2, cap, &m->bytes) && dev_alloc(&m->remap, cap, &m->bytes);
+    ok = ok && hipMemsetAsync(m->touch, 0, cap * 8, m->stream) == hipSuccess && hipMemsetAsync(m->prev_touch, 0, cap * 8, m->stream) == hipSuccess &&
+         hipMemsetAsync(m->prev_touch2, 0, cap * 8, m->stream) == hipSuccess && hipMemsetAsync(m->lru_log, 0, lc * sizeof(LruEntry), m->stream) == hipSuccess &&
+         hipStreamSynchronize(m->stream) == hipSuccess;
+    if (!ok) { if (!g_err[0]) set_error("lio_map_set_lru: allocation failed"); return LIO_E_DEVICE; }
+    m->lru_capacity = capacity_voxels;
+    m->lru_max_distance = (float)max_distance;
+    return LIO_OK;
+}
+
+int lio_map_lru_stats(lio_map* m, uint64_t* n_evicted, uint64_t* n_interleaved) {
+    if (!m) return LIO_E_INVALID;
+    hipSetDevice(m->device);
+    const int rc = map_check(m, m->stream);
+    if (n_evicted) *n_evicted = m->host_dev->n_evicted;
+    if (n_interleaved) *n_interleaved = m->host_dev->n_lru_interleaved;
+    return rc;
 }
 
 int lio_map_set_stencil(lio_map* m, int stencil) {
@@ -258,7 +294,7 @@ int64_t lio_map_dump(lio_map* m, float* out, uint64_t cap_points) {
     if (hipMemcpy(tab.data(), m->table, sizeof(Slot) * m->table_cap, hipMemcpyDeviceToHost) != hipSuccess) return LIO_E_DEVICE;
     uint64_t k = 0;
     for (uint32_t h = 0; h < m->table_cap; h++) {
-        if (tab[h].key == kEmptyKey || tab[h].cnt == 0) continue;
+        if (tab[h].key == kEmptyKey || tab[h].key == kTombKey || tab[h].cnt == 0) continue;
         if (k + tab[h].cnt > cap_points) return LIO_E_CAPACITY;
         if (hipMemcpy(out + k * 4, m->pool + tab[h].ptr, sizeof(float4) * tab[h].cnt, hipMemcpyDeviceToHost) != hipSuccess) return LIO_E_DEVICE;
         k += tab[h].cnt;

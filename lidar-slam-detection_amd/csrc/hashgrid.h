@@ -29,7 +29,10 @@ __device__ inline BrickProbe brick_probe(int x, int y, int z) {
     BrickProbe p;
     p.win = h;
     p.step = (__umul24((h >> 7) & 0xFFFFFFu, 0x5BD1E9u) ^ (h << 11)) | 1u;
-    p.local = (uint32_t)(x & 3) | ((uint32_t)(y & 3) << 2) | ((uint32_t)(z & 3) << 4);
+    // in-window position = in-brick offset XOR six hash bits of the brick: still one distinct slot per voxel of the brick, but
+    // bricks no longer agree on which of the 64 positions a given offset uses -- a map that is mostly one ground plane (one
+    // value of z & 3) would otherwise crowd a quarter of the positions and overflow them at a quarter of the nominal load
+    p.local = ((uint32_t)(x & 3) | ((uint32_t)(y & 3) << 2) | ((uint32_t)(z & 3) << 4)) ^ ((h >> 17) & 63u);
     return p;
 }
 __device__ inline uint32_t brick_slot(const BrickProbe& p, uint32_t mask) { return ((p.win << 6) | p.local) & mask; }

@@ -15,19 +15,23 @@
 // kNN semantics (ivox3d.h:139-171 + ivox3d_node.hpp:107-127): the 5 nearest of all points stored in the
 // stencil voxels with d^2 < 5.0 -- the per-voxel nth_element there is a pruning step that does not change
 // that set.  Ties are broken by the canonical total order (d2, x, y, z) that oracle/lio_oracle.cpp uses.
+#include <utility>
+
 #include "hashgrid.h"
 #include "lio_common.h"
 
 namespace lio {
 
 // ---------------------------------------------------------------------------------------------------
-// batch insert = IVox::AddPoints (ivox3d.h:231-256) without the LRU list
+// batch insert = IVox::AddPoints (ivox3d.h:231-256); the LRU list is further down
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint32_t mask, uint32_t* __restrict__ pending,
                                                                float* __restrict__ created, const float4* __restrict__ pts,
                                                                unsigned long long n_host, const uint32_t* __restrict__ n_dev,
                                                                float inv_res, float res, int key_mode, float travel, uint32_t max_voxels,
-                                                               MapDev* md, uint32_t* __restrict__ slot_of_point) {
+                                                               MapDev* md, uint32_t* __restrict__ slot_of_point,
+                                                               unsigned long long* __restrict__ touch, unsigned long long* __restrict__ prev_touch,
+                                                               unsigned long long stamp_base) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -58,6 +62,10 @@ __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint
             slot_of_point[i] = kNoIdx;
             continue;
         }
+        if (touch) {  // the LAST point of the batch that lands in a voxel decides its LRU position
+            const unsigned long long old = atomicMax(&touch[found], stamp_base + i);
+            if (old < stamp_base) prev_touch[found] = old;  // exactly one thread per voxel and batch sees the stamp of an earlier batch
+        }
         const uint32_t before = atomicAdd(&pending[found], 1u);
         // the first arriver of a voxel in this batch is its leader (bit 31) and sizes the region in pass 2
         slot_of_point[i] = found | (before == 0 ? 0x80000000u : 0u);
@@ -67,7 +75,8 @@ __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint
 __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint32_t* __restrict__ cap, uint32_t* __restrict__ pending,
                                                               float4* pool, unsigned long long pool_cap, unsigned long long n_host,
                                                               const uint32_t* __restrict__ n_dev, MapDev* md,
-                                                              const uint32_t* __restrict__ slot_of_point) {
+                                                              const uint32_t* __restrict__ slot_of_point, const uint32_t* __restrict__ free_items,
+                                                              uint32_t free_cap) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -80,10 +89,19 @@ __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint3
         if (need <= cap[h]) continue;
         uint32_t ncap = 8;  // leave room: the voxel is on the sensor's path and will be appended to again
         while (ncap < need) ncap <<= 1;
-        const unsigned long long at = atomicAdd(&md->pool_top, (unsigned long long)ncap);
-        if (at + ncap > pool_cap) {
-            atomicOr(&md->err, 2u);
-            continue;
+        unsigned long long at = ~0ull;
+        if (free_items) {  // a region an evicted voxel gave back (this kernel only pops, lru_evict_kernel only pushes)
+            const int c = 31 - __clz(ncap);
+            const int t = atomicSub(&md->free_top[c], 1);
+            if (t > 0) at = free_items[(size_t)c * free_cap + (uint32_t)(t - 1)];
+            else atomicAdd(&md->free_top[c], 1);
+        }
+        if (at == ~0ull) {
+            at = atomicAdd(&md->pool_top, (unsigned long long)ncap);
+            if (at + ncap > pool_cap) {
+                atomicOr(&md->err, 2u);
+                continue;
+            }
         }
         const uint32_t old = table[h].ptr;
         for (uint32_t j = 0; j < have; j++) pool[at + j] = pool[old + j];
@@ -191,6 +209,234 @@ __global__ void __launch_bounds__(256) map_insert_write_kernel(Slot* table, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LRU eviction = the grids_cache_ list of IVox::AddPoints (ivox3d.h:231-256).  The reference touches voxels one point at a
+// time (splice to the list front) and, after every point, drops the list's back if the map holds more than `capacity`
+// voxels and that voxel was created more than max_distance of travel ago.  Here:
+//   * every slot carries the stamp (batch << 26 | point index) of its last touch (atomicMax in the claim kernel);
+//   * lru_append_kernel appends one log entry per voxel touched by the batch, in point order (the point that holds a
+//     voxel's final stamp emits it), so the log is sorted by stamp: an entry is live iff its stamp is still the slot's;
+//   * lru_evict_kernel walks the log from its tail: live entries ARE the list from the back.  The number of evictions the
+//     point-by-point process performs is order independent, E = clamp(n_voxels - capacity, 0, n_points_in_batch), cut short
+//     at the first candidate younger than max_distance (the reference then keeps testing that same back voxel).
+// Evicted slots become tombstones (probes walk on), their pool regions go to per-size free lists that the grow kernel
+// pops; the table is rebuilt into its twin when tombstones pile up (map_rebuild).  A victim touched again later in the
+// SAME batch would be re-created by the reference; that needs capacity < one scan's footprint and is reported as an
+// error instead (err bit 4).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) lru_append_kernel(const uint32_t* __restrict__ slot_of_point, const unsigned long long* __restrict__ touch,
+                                                          unsigned long long n_host, const uint32_t* __restrict__ n_dev, unsigned long long stamp_base,
+                                                          LruEntry* __restrict__ log, unsigned long long log_mask, MapDev* md) {
+    const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
+    __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long head_s;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) { head_s = md->log_head; md->log_head_prev = md->log_head; }
+    __syncthreads();
+    for (unsigned long long base = 0; base < n; base += 1024) {
+        const unsigned long long i = base + tid;
+        uint32_t h = 0;
+        bool flag = false;
+        if (i < n) {
+            const uint32_t sp = slot_of_point[i];
+            if (sp != kNoIdx) {
+                h = sp & 0x7FFFFFFFu;
+                flag = touch[h] == stamp_base + i;
+            }
+        }
+        const unsigned long long m = __ballot(flag);
+        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        uint32_t off = 0, total = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) off += wsum[w];
+            total += wsum[w];
+        }
+        if (flag) {
+            LruEntry e;
+            e.stamp = stamp_base + i;
+            e.slot = h;
+            e.pad = 0;
+            log[(head_s + off + rank) & log_mask] = e;
+        }
+        __syncthreads();
+        if (tid == 0) head_s += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        md->log_head = head_s;
+        if (head_s - md->log_tail > log_mask + 1ull) atomicOr(&md->err, 8u);  // log overrun: more live + stale entries than the ring holds
+    }
+}
+
+__global__ void __launch_bounds__(256) lru_evict_kernel(Slot* table, uint32_t* __restrict__ cap, const float* __restrict__ created,
+                                                        unsigned long long* __restrict__ touch, const unsigned long long* __restrict__ prev_touch,
+                                                        unsigned long long stamp_base, const LruEntry* __restrict__ log,
+                                                        unsigned long long log_mask, uint32_t* __restrict__ free_items, uint32_t free_cap,
+                                                        unsigned long long n_host, const uint32_t* __restrict__ n_dev, uint32_t capacity,
+                                                        float travel, float max_distance, MapDev* md) {
+    const unsigned long long n_add = n_dev ? (unsigned long long)*n_dev : n_host;
+    __shared__ uint32_t wsum[4];
+    __shared__ unsigned long long first_young_s, tail_s;
+    __shared__ uint32_t want_s, pts_s;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t n_vox = md->n_voxels;
+    const unsigned long long limit = md->log_head_prev;  // never evict what this very batch touched
+    if (tid == 0) {
+        unsigned long long e = n_vox > capacity ? (unsigned long long)(n_vox - capacity) : 0ull;
+        want_s = (uint32_t)(e < n_add ? e : n_add);
+        tail_s = md->log_tail;
+        pts_s = 0;
+    }
+    __syncthreads();
+    uint32_t done = 0;
+    bool stop = false;
+    while (!stop) {
+        const uint32_t want = want_s - done;
+        const unsigned long long tail = tail_s;
+        if (want == 0 || tail >= limit) break;
+        const unsigned long long idx = tail + tid;
+        LruEntry e;
+        e.stamp = 0; e.slot = 0; e.pad = 0;
+        bool live = false, young = false;
+        if (idx < limit) {
+            e = log[idx & log_mask];
+            const unsigned long long now = touch[e.slot];
+            live = e.stamp != 0 && now == e.stamp;
+            young = live && !((travel - created[e.slot]) > max_distance);
+            // this voxel sat at the back of the list until the current batch touched it: the reference may have dropped and
+            // re-created it in between (point-by-point order); counted, not reproduced
+            if (!live && e.stamp != 0 && now >= stamp_base && prev_touch[e.slot] == e.stamp) atomicAdd(&md->n_lru_interleaved, 1ull);
+        }
+        if (tid == 0) first_young_s = ~0ull;
+        __syncthreads();
+        if (young) atomicMin(&first_young_s, idx);
+        const unsigned long long m = __ballot(live);
+        const uint32_t rank_w = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        uint32_t rank = rank_w;
+        for (int w = 0; w < wave; w++) rank += wsum[w];
+        const unsigned long long fy = first_young_s;
+        const bool evict = live && idx < fy && rank < want;
+        if (evict) {
+            const uint32_t h = e.slot;
+            const uint32_t c = cap[h], cnt = table[h].cnt, ptr = table[h].ptr;
+            table[h].key = kTombKey;
+            table[h].cnt = 0;
+            cap[h] = 0;
+            touch[h] = 0;
+            atomicAdd(&pts_s, cnt);
+            if (c >= 8 && free_items) {
+                const int cls = 31 - __clz(c);
+                const int pos = atomicAdd(&md->free_top[cls], 1);
+                if (pos >= 0 && (uint32_t)pos < free_cap) free_items[(size_t)cls * free_cap + (uint32_t)pos] = ptr;
+                else atomicSub(&md->free_top[cls], 1);
+            }
+        }
+        // where the walk resumes: at the first young voxel (the reference keeps testing it), right after the last eviction when
+        // the quota is used up, else after this chunk
+        const unsigned long long ev_mask = __ballot(evict);
+        __syncthreads();
+        if (lane == 0) wsum[wave] = __popcll(ev_mask);
+        __syncthreads();
+        const uint32_t n_ev = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        unsigned long long next = tail + 256;
+        if (next > limit) next = limit;
+        if (fy != ~0ull) {
+            next = fy;
+            stop = true;
+        } else if (done + n_ev >= want_s) {
+            // the last evicted entry is the (want)-th live one of the chunk: everything up to it is consumed
+            __shared__ unsigned long long last_s;
+            if (tid == 0) last_s = 0;
+            __syncthreads();
+            if (evict) atomicMax(&last_s, idx + 1);
+            __syncthreads();
+            next = last_s > tail ? last_s : next;
+            stop = true;
+        }
+        done += n_ev;
+        __syncthreads();
+        if (tid == 0) tail_s = next;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        md->log_tail = tail_s;
+        if (done) {
+            md->n_voxels = n_vox - done;
+            md->n_points -= pts_s;
+            md->n_tombs += done;
+            md->n_evicted += done;
+        }
+    }
+}
+
+// table rebuild: live slots are re-inserted into the twin table (no tombstones), the touch log is re-pointed
+__global__ void __launch_bounds__(256) rebuild_insert_kernel(const Slot* __restrict__ told, const uint32_t* __restrict__ cap_old,
+                                                             const float* __restrict__ created_old, const unsigned long long* __restrict__ touch_old,
+                                                             const unsigned long long* __restrict__ prev_old, Slot* tnew, uint32_t* __restrict__ cap_new,
+                                                             float* __restrict__ created_new, unsigned long long* __restrict__ touch_new,
+                                                             unsigned long long* __restrict__ prev_new, uint32_t table_cap, uint32_t mask,
+                                                             uint32_t* __restrict__ remap, MapDev* md) {
+    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    if (h >= table_cap) return;
+    const Slot s = told[h];
+    remap[h] = kNoIdx;
+    if (s.key == kEmptyKey || s.key == kTombKey) return;
+    const int kx = ((int)((uint32_t)(s.key & 0x1FFFFFu) << 11)) >> 11, ky = ((int)((uint32_t)((s.key >> 21) & 0x1FFFFFu) << 11)) >> 11,
+              kz = ((int)((uint32_t)((s.key >> 42) & 0x1FFFFFu) << 11)) >> 11;
+    BrickProbe bp = brick_probe(kx, ky, kz);
+    for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
+        const uint32_t g = brick_slot(bp, mask);
+        if (atomicCAS(&tnew[g].key, kEmptyKey, s.key) == kEmptyKey) {
+            tnew[g].ptr = s.ptr;
+            tnew[g].cnt = s.cnt;
+            cap_new[g] = cap_old[h];
+            created_new[g] = created_old[h];
+            touch_new[g] = touch_old[h];
+            prev_new[g] = prev_old[h];
+            remap[h] = g;
+            return;
+        }
+        brick_next(bp);
+    }
+    atomicOr(&md->err, 1u);
+}
+
+__global__ void __launch_bounds__(256) rebuild_log_kernel(LruEntry* __restrict__ log, unsigned long long log_mask, const unsigned long long* __restrict__ touch_old,
+                                                          const uint32_t* __restrict__ remap, MapDev* md) {
+    const unsigned long long tail = md->log_tail, head = md->log_head;
+    for (unsigned long long i = tail + blockIdx.x * 256ull + threadIdx.x; i < head; i += (unsigned long long)gridDim.x * 256ull) {
+        LruEntry e = log[i & log_mask];
+        if (e.stamp != 0 && touch_old[e.slot] == e.stamp && remap[e.slot] != kNoIdx) e.slot = remap[e.slot];
+        else e.stamp = 0;  // stale: superseded or evicted
+        log[i & log_mask] = e;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) md->n_tombs = 0;
+}
+
+int map_rebuild(lio_map* m, hipStream_t stream) {
+    LIO_HIP_TRY(hipMemsetAsync(m->table2, 0xFF, (size_t)m->table_cap * sizeof(Slot), stream));
+    LIO_HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(m->table2) + 8, sizeof(Slot), 0, 8, m->table_cap, stream));
+    LIO_HIP_TRY(hipMemsetAsync(m->cap2, 0, (size_t)m->table_cap * 4, stream));
+    LIO_HIP_TRY(hipMemsetAsync(m->pending2, 0, (size_t)m->table_cap * 4, stream));
+    LIO_HIP_TRY(hipMemsetAsync(m->touch2, 0, (size_t)m->table_cap * 8, stream));
+    hipLaunchKernelGGL(rebuild_insert_kernel, (m->table_cap + 255) / 256, 256, 0, stream, m->table, m->cap, m->created, m->touch, m->prev_touch, m->table2,
+                       m->cap2, m->created2, m->touch2, m->prev_touch2, m->table_cap, m->table_mask, m->remap, m->dev);
+    hipLaunchKernelGGL(rebuild_log_kernel, 256, 256, 0, stream, m->lru_log, (unsigned long long)(m->lru_log_cap - 1), m->touch, m->remap, m->dev);
+    std::swap(m->table, m->table2);
+    std::swap(m->cap, m->cap2);
+    std::swap(m->pending, m->pending2);
+    std::swap(m->created, m->created2);
+    std::swap(m->touch, m->touch2);
+    std::swap(m->prev_touch, m->prev_touch2);
+    m->tomb_bound = 0;
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
 int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t n, const uint32_t* d_n, double travel) {
     if (n == 0) return LIO_OK;
     if (n > m->slot_of_point_cap) {
@@ -202,9 +448,16 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
     // the first batch into an empty map is a prebuilt-map load: exact sizes, brick-coherent pool order
     const bool layout = m->n_batches == 0;
     m->n_batches++;
+    const bool lru = m->lru_capacity != 0;
+    const unsigned long long stamp_base = (unsigned long long)m->n_batches << kStampIdxBits;
+    if (lru && n >= (1ull << kStampIdxBits)) { set_error("map insert batch of %llu points is too large for the LRU stamps", (unsigned long long)n); return LIO_E_CAPACITY; }
+    if (lru && m->tomb_bound > m->table_cap / 4) {  // tombstones of evicted voxels may fill a quarter of the table: rebuild it first
+        const int rc = map_rebuild(m, stream);
+        if (rc != LIO_OK) return rc;
+    }
     hipLaunchKernelGGL(map_insert_claim_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->table_mask, m->pending, m->created,
                        d_pts, (unsigned long long)n, d_n, m->inv_res, m->res, m->key_mode, (float)travel, (uint32_t)m->max_voxels, m->dev,
-                       m->slot_of_point);
+                       m->slot_of_point, lru ? m->touch : nullptr, m->prev_touch, stamp_base);
     if (layout) {
         const uint32_t ntiles = (m->table_cap + kScanTile - 1) / kScanTile;
         hipLaunchKernelGGL(map_layout_sums_kernel, ntiles, 256, 0, stream, m->pending, m->table_cap, m->tile_sum);
@@ -212,10 +465,19 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
         hipLaunchKernelGGL(map_layout_assign_kernel, ntiles, 256, 0, stream, m->table, m->cap, m->pending, m->table_cap, m->tile_sum);
     } else {
         hipLaunchKernelGGL(map_insert_grow_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->cap, m->pending, m->pool,
-                           (unsigned long long)m->pool_cap, (unsigned long long)n, d_n, m->dev, m->slot_of_point);
+                           (unsigned long long)m->pool_cap, (unsigned long long)n, d_n, m->dev, m->slot_of_point, lru ? m->free_items : nullptr,
+                           m->free_cap);
     }
     hipLaunchKernelGGL(map_insert_write_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->cap, m->pool, d_pts,
                        (unsigned long long)n, d_n, m->slot_of_point);
+    if (lru) {
+        hipLaunchKernelGGL(lru_append_kernel, 1, 1024, 0, stream, m->slot_of_point, m->touch, (unsigned long long)n, d_n, stamp_base, m->lru_log,
+                           (unsigned long long)(m->lru_log_cap - 1), m->dev);
+        hipLaunchKernelGGL(lru_evict_kernel, 1, 256, 0, stream, m->table, m->cap, m->created, m->touch, m->prev_touch, stamp_base, m->lru_log,
+                           (unsigned long long)(m->lru_log_cap - 1), m->free_items, m->free_cap, (unsigned long long)n, d_n, (uint32_t)m->lru_capacity,
+                           (float)travel, m->lru_max_distance, m->dev);
+        m->tomb_bound += n;
+    }
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

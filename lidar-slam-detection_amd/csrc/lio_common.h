@@ -22,6 +22,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint64_t kTombKey = 0xFFFFFFFFFFFFFFFEull;  // slot of an evicted voxel: probes walk on, inserts do not reuse it (tables are rebuilt)
 constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
 constexpr int kMaxStencil = 75;
 constexpr int kLinThreads = 64;   // linearize_kernel workgroup size (one partial-sum record per workgroup)
@@ -41,7 +42,12 @@ struct MapDev {
     uint32_t n_voxels;
     uint32_t err;                    // bit0: table full, bit1: pool full
     uint32_t n_add;                  // staging count for map_incremental
-    uint32_t pad;
+    uint32_t n_tombs;                // evicted slots since the last table rebuild
+    // LRU bookkeeping (ivox3d.h:231-256), only used when lio_map_set_lru enabled it
+    unsigned long long log_head, log_tail, log_head_prev;  // touch log: entries appended / consumed / head before the current batch
+    unsigned long long n_evicted;    // voxels evicted so far
+    unsigned long long n_lru_interleaved;  // LRU-back voxels that the batch evicting around them also touched (see hashmap.hip)
+    int free_top[24];                // recycled pool regions by size class (floor(log2(capacity)))
     unsigned long long knn_cand[64 * 16];  // 64 shards, one 128-B line each (same-line atomics serialise in one L2 channel)
 };
 
@@ -80,7 +86,27 @@ struct StencilArgs {
 
 }  // namespace lio
 
+struct LruEntry {  // one entry of the touch log: the voxel in `slot` was last touched at `stamp` -- unless touched again since
+    unsigned long long stamp;
+    uint32_t slot, pad;
+};
+constexpr int kStampIdxBits = 26;  // stamp = batch number << 26 | index of the point inside the batch
+
 struct lio_map {
+    // LRU eviction (off while lru_capacity == 0)
+    uint64_t lru_capacity;
+    float lru_max_distance;
+    unsigned long long* touch;   // per-slot stamp of the last AddPoints touch
+    unsigned long long* prev_touch;  // the stamp it had before the current batch touched it
+    LruEntry* lru_log;           // ring, ordered by stamp
+    uint64_t lru_log_cap;        // power of two
+    uint32_t* free_items;        // [24][free_cap] recycled region offsets
+    uint32_t free_cap;
+    uint64_t tomb_bound;         // evictions possible since the last rebuild (host-side upper bound)
+    lio::Slot* table2;           // second set of per-slot arrays: target of a table rebuild, then swapped
+    uint32_t *cap2, *pending2, *remap;
+    float* created2;
+    unsigned long long *touch2, *prev_touch2;
     int device;
     hipStream_t stream;
     float res, inv_res;

@@ -53,6 +53,15 @@ class Map:
         if not self.h:
             raise capi.LioError("lio_map_create failed: " + lib().lio_last_error().decode())
 
+    def set_lru(self, capacity_voxels, max_distance=100.0):
+        """IVox capacity_ / max_distance_: least-recently-touched voxels are dropped above `capacity_voxels` (call before the first add)"""
+        check(lib().lio_map_set_lru(self.h, int(capacity_voxels), float(max_distance)), "set_lru")
+
+    def lru_stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().lio_map_lru_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def close(self):
         if getattr(self, "h", None) and self._own and lib is not None:  # `lib` is gone at interpreter shutdown
             lib().lio_map_destroy(self.h)

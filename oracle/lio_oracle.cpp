@@ -1521,6 +1521,15 @@ void orc_ivox_set_stencil(void* h, int stencil) { static_cast<IVox*>(h)->set_ste
 void orc_ivox_add(void* h, const float* pts, int n, double travel) { static_cast<IVox*>(h)->add_points(reinterpret_cast<const P4*>(pts), n, travel); }
 uint64_t orc_ivox_num_voxels(void* h) { return static_cast<IVox*>(h)->grids.size(); }
 uint64_t orc_ivox_num_points(void* h) { return static_cast<IVox*>(h)->num_points(); }
+int64_t orc_ivox_dump(void* h, float* out, uint64_t cap) {  // all stored points, list order (most recently touched voxel first)
+    IVox* v = static_cast<IVox*>(h);
+    const uint64_t n = v->num_points();
+    if (n > cap) return -(int64_t)n;
+    uint64_t k = 0;
+    for (auto& kv : v->cache)
+        for (auto& p : kv.second.pts) { std::memcpy(out + k * 4, &p, sizeof(P4)); k++; }
+    return (int64_t)n;
+}
 // pure kNN (no stale-content semantics): out_pts is n x 5 x 4 floats, out_cnt n ints.
 // returns the total number of in-range candidates visited (for the C-bar statistic of SURVEY 8d)
 uint64_t orc_ivox_knn(void* h, const float* q_xyzi, int n, float* out_pts, int* out_cnt, int threads) {

@@ -49,6 +49,8 @@ def lib():
     L.orc_ivox_num_voxels.argtypes = [C.c_void_p]
     L.orc_ivox_num_voxels.restype = C.c_uint64
     L.orc_ivox_num_points.argtypes = [C.c_void_p]
+    L.orc_ivox_dump.argtypes = [C.c_void_p, f32p, C.c_uint64]
+    L.orc_ivox_dump.restype = C.c_int64
     L.orc_ivox_num_points.restype = C.c_uint64
     L.orc_ivox_knn.argtypes = [C.c_void_p, f32p, C.c_int, f32p, i32p, C.c_int]
     L.orc_ivox_knn.restype = C.c_uint64
@@ -163,6 +165,13 @@ class IVox:
     @property
     def num_points(self):
         return int(lib().orc_ivox_num_points(self.h))
+
+    def dump(self):
+        n = self.num_points
+        out = np.zeros((max(n, 1), 4), np.float32)
+        got = lib().orc_ivox_dump(self.h, _p(out, C.c_float), n)
+        assert got == n
+        return out[:n]
 
     def knn(self, q, threads=8):
         q = _f32(q).reshape(-1, 4)

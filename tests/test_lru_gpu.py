@@ -1,0 +1,92 @@
+"""LRU eviction of the device map (lio_map_set_lru: IVox capacity_ / max_distance_, ivox3d.h:231-256) against the oracle's
+iVox, whose list bookkeeping is pinned to the reference's own code (tests/test_oracle_vs_ref.py).  Voxel sets, point sets
+and neighbour queries must stay identical batch after batch while voxels are created, re-touched, evicted, their pool
+regions recycled and the table rebuilt."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(a):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1, 4)
+    return a[np.lexsort((a[:, 3], a[:, 2], a[:, 1], a[:, 0]))]
+
+
+def _batch(scene_pts, cx, rng, n, half=8.0):
+    sel = np.flatnonzero(np.abs(scene_pts[:, 0] - cx) < half)
+    return scene_pts[rng.choice(sel, size=min(n, len(sel)), replace=False)]
+
+
+@pytest.mark.parametrize("max_voxels", [40000, 12000])  # the small table (32768 slots) is rebuilt every few batches
+def test_lru_eviction_matches_oracle(oracle_mod, scene, max_voxels):
+    from lsd_amd import capi, lio
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(5)
+    pts = scene.sample_surface(400_000, seed=9, sigma=0.01)
+    pts = pts[(np.abs(pts[:, 1]) < 25) & (pts[:, 2] < 6)]
+    cap, maxd = 1500, 30.0  # older than the 16 m the insert window spans: no victim is ever inside the batch that evicts it
+    m = lio.Map(resolution=0.5, stencil=19, max_points=600_000, max_voxels=max_voxels)
+    m.set_lru(cap, maxd)
+    o = oracle_mod.IVox(res=0.5, stencil=19, capacity=cap, max_distance=maxd)
+    centres = list(np.linspace(-70, 70, 44))  # a drive in one direction: voxels fall off the back of the list as they age
+    travel, last = 0.0, centres[0]
+    for b, cx in enumerate(centres):
+        travel += abs(cx - last) + 0.3
+        last = cx
+        batch = _batch(pts, cx, rng, 2500)
+        m.add(batch, travel=travel)
+        o.add(batch, travel=travel)
+        npts, nvox = m.stats()
+        assert (nvox, npts) == (o.num_voxels, o.num_points), (b, nvox, npts, o.num_voxels, o.num_points)
+        if b % 6 == 5 or b == len(centres) - 1:
+            assert np.array_equal(_rows(m.dump()), _rows(o.dump())), b
+            q = _batch(pts, cx, rng, 300, half=12.0) + rng.normal(0, 0.05, (300, 4)).astype(np.float32)
+            nn_g, cnt_g = m.knn(q)
+            nn_o, cnt_o, _ = o.knn(q)
+            assert np.array_equal(cnt_g, cnt_o) and np.array_equal(nn_g.view(np.uint32), nn_o.view(np.uint32)), b
+    evicted, interleaved = m.lru_stats()
+    assert evicted > 1000  # `interleaved` is an upper bound (voxels near the back that the batch touched in time count too)
+
+
+def test_revisiting_the_back_of_the_list_is_counted(oracle_mod, scene):
+    """A batch that touches the very voxels it is evicting around (tiny max_distance, overlapping windows, a return to the start):
+    the reference's point-by-point order drops and re-creates some of them, the device keeps their points and counts them"""
+    from lsd_amd import lio
+
+    rng = np.random.default_rng(8)
+    pts = scene.sample_surface(300_000, seed=11, sigma=0.01)
+    pts = pts[(np.abs(pts[:, 1]) < 25) & (pts[:, 2] < 6)]
+    m = lio.Map(resolution=0.5, stencil=19, max_points=600_000, max_voxels=40000)
+    m.set_lru(1500, 2.0)
+    travel = 0.0
+    for cx in list(np.linspace(-40, 40, 24)) + [-40.0, -38.0, -36.0]:
+        travel += 4.0
+        m.add(_batch(pts, cx, rng, 2500), travel=travel)
+    npts, nvox = m.stats()
+    evicted, interleaved = m.lru_stats()
+    assert evicted > 1000 and interleaved > 0 and nvox <= 1500 + 2500
+    assert len(m.dump()) == npts
+
+
+def test_young_voxels_are_not_evicted(oracle_mod, scene):
+    """above capacity but nothing older than max_distance: the map overshoots (ivox3d.h:251), then drains once travel catches up"""
+    from lsd_amd import lio
+
+    rng = np.random.default_rng(6)
+    pts = scene.sample_surface(200_000, seed=10, sigma=0.01)
+    pts = pts[(np.abs(pts[:, 1]) < 20) & (pts[:, 2] < 6)]
+    m = lio.Map(resolution=0.5, stencil=19, max_points=400_000, max_voxels=30000)
+    m.set_lru(2000, 50.0)  # more than one insert window holds (~1400 voxels): the footprint itself is never a victim
+    o = oracle_mod.IVox(res=0.5, stencil=19, capacity=2000, max_distance=50.0)
+    for b, (cx, travel) in enumerate([(-40, 1.0), (-30, 11.0), (-20, 21.0), (-10, 31.0), (0, 41.0), (10, 52.0), (20, 63.0), (30, 120.0), (30, 121.0), (30, 122.0)]):
+        batch = _batch(pts, cx, rng, 2000)
+        m.add(batch, travel=travel)
+        o.add(batch, travel=travel)
+        npts, nvox = m.stats()
+        assert (nvox, npts) == (o.num_voxels, o.num_points), (b, nvox, o.num_voxels)
+        if b == 4:
+            assert nvox > 2000  # overshoot
+    assert np.array_equal(_rows(m.dump()), _rows(o.dump()))
