@@ -28,6 +28,18 @@ sys.path.insert(0, os.path.join(ROOT, "lidar-slam-detection_amd", "python"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 
 
+def usable_cpus():
+    """host CPUs this process may use: the affinity mask, capped by the cgroup quota (cpu.max) of the container"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -38,7 +50,7 @@ def main():
     ap.add_argument("--scan-pool", type=int, default=8, help="distinct scans cycled through the steps")
     ap.add_argument("--cpu-scans", type=int, default=320, help="scans of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=1000)
-    ap.add_argument("--streams", type=int, default=8, help="independent scans in flight per GPU (one engine + HIP stream + host thread each, "
+    ap.add_argument("--streams", type=int, default=0, help="independent scans in flight per GPU (one engine + HIP stream + host thread each, "
                                                               "all reading the one resident map)")
     args = ap.parse_args()
 
@@ -83,7 +95,9 @@ def main():
     del d_map
     d_scans = [torch.from_numpy(s["raw"]).to(dev) for s in scans]
     torch.cuda.synchronize()
-    n_streams = max(1, args.streams)
+    n_streams = args.streams
+    if n_streams <= 0:  # default: 8 scans in flight per GPU, fewer when the ranks of this node have to share few host CPUs
+        n_streams = max(2, min(8, usable_cpus() // max(world, 1) - 1))
     engines = [lio.Engine(max_raw=1 << 18, max_ds=100000, shared_map=the_map) for _ in range(n_streams)]
     for e in engines:
         e.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)

@@ -4,6 +4,8 @@
 #include <vector>
 
 #include "eskf.h"
+#include <sched.h>
+
 #include "lio_common.h"
 
 namespace lio {
@@ -107,7 +109,8 @@ int wait_report(lio_scan* s) {
     const uint32_t want = s->seq_expected;
     for (uint64_t spin = 0; *seq != want; spin++) {
         __builtin_ia32_pause();
-        if (spin > 20000000ull) {  // ~100 ms: something went wrong on the device
+        if (spin > 4000 && (spin & 63) == 0) sched_yield();  // a pass normally reports within ~30 us; beyond that let other engines' threads run
+        if (spin > 20000000ull) {  // >= 100 ms: something went wrong on the device
             LIO_HIP_TRY(hipStreamSynchronize(s->stream));
             if (*seq != want) { set_error("linearize_kernel did not report (seq %u, expected %u)", *seq, want); return LIO_E_DEVICE; }
             break;

@@ -26,6 +26,8 @@
 #include <vector>
 
 #include "hashgrid.h"
+#include <sched.h>
+
 #include "lio_common.h"
 
 namespace lio {
@@ -473,6 +475,7 @@ int ndt_wait(lio_ndt* n, hipStream_t st) {
     const uint32_t want = n->seq_expected;
     for (uint64_t spin = 0; *seq != want; spin++) {
         __builtin_ia32_pause();
+        if (spin > 4000 && (spin & 63) == 0) sched_yield();
         if (spin > 20000000ull) {
             LIO_HIP_TRY(hipStreamSynchronize(st));
             if (*seq != want) { set_error("ndt_report_kernel did not report"); return LIO_E_DEVICE; }
