@@ -210,7 +210,9 @@ int lio_engine_enable_timing(lio_engine*, int on);
  * The IMU front half: the reference's FastLIO entry points, one to one.  After lio_fastlio_init the engine is driven
  * exactly like the reference's module: sensor threads enqueue, the LIO thread calls lio_fastlio_main in a loop
  * (slam/mapping/fastlio/src/fastlio.cpp:185-210,262-276).
- *   lio_fastlio_init ............ fastlio_init          src/laserMapping.cpp:1025-1124 (extR row-major 3x3)
+ *   lio_fastlio_init ............ fastlio_init          src/laserMapping.cpp:1025-1124 (extR row-major 3x3); also turns on the
+ *                                 map's LRU list with the reference's 100000 voxels / 100 m when the engine owns an empty
+ *                                 map created with max_voxels > 100000
  *   lio_fastlio_is_init ......... fastlio_is_init       src/laserMapping.cpp:740-743
  *   lio_fastlio_imu_enqueue ..... fastlio_imu_enqueue   src/laserMapping.cpp:397-415 (acc in m/s^2, divided by 9.81 inside)
  *   lio_fastlio_ins_enqueue ..... fastlio_ins_enqueue   src/laserMapping.cpp:417-441

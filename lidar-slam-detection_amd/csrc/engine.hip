@@ -769,6 +769,10 @@ int lio_fastlio_init(lio_engine* e, const double extT[3], const double extR[9], 
     f->start_state = e->kf.x;
     f->end_state = e->kf.x;
     lio_scan_reset(s);
+    // ivox_options of fastlio_init (laserMapping.cpp:1060-1064): capacity_ 100000 voxels, max_distance_ 100 m.  Only an engine
+    // that owns a still empty map with room above the soft capacity gets the LRU list; otherwise the map keeps everything.
+    if (e->own_map && e->map->n_batches == 0 && e->map->lru_capacity == 0 && e->map->max_voxels > 100000)
+        return lio_map_set_lru(e->map, 100000, 100.0);
     return LIO_OK;
 }
 
