@@ -117,6 +117,15 @@ __device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_
     return total;
 }
 
+// The LDS staging area of a query group is written and read by lanes of ONE wave only: ordering within the wave is all that
+// is needed (LDS operations of a wave complete in order), no workgroup barrier -- the four waves of a workgroup never wait
+// for each other.
+__device__ inline void group_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ inline uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -174,7 +183,7 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
         pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
         uint32_t nhit = 0;
         const uint32_t total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
-        __syncthreads();
+        group_lds_sync();
         // every lane keeps its own ascending top-5 as (d2 bits, pool index) pairs, ordered by d2 alone: candidates with an
         // equal d2 keep their arrival order -- any such pair that reaches the global top-6 is an exact tie and the query
         // is redone by knn_exact_kernel anyway.  Insertion is the branch-free parallel form: five independent compares
@@ -260,7 +269,7 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
                 if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
             }
         }
-        __syncthreads();
+        group_lds_sync();
     }
     // statistics: one atomic per workgroup, spread over 64 counters that each own a 128-B line (same-line
     // atomics serialise in one L2 channel at ~10 ns apiece -- 9k of them used to cost more than the kernel)
@@ -407,7 +416,11 @@ int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {
     (void)redo_knn;
     const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
     kt_begin(s, 0);
-    const int rc = launch_knn<0>(m, s->stream, pose, s->ds_body, 0, s->dev, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt, bound,
+    // the query count comes from the host whenever it knows it (the usual case: the downsample was waited for): one dependent
+    // global load less at the head of every wave
+    const bool known = s->have_ds > 0;
+    const int rc = launch_knn<0>(m, s->stream, pose, s->ds_body, known ? (uint32_t)s->have_ds : 0u, known ? nullptr : s->dev, s->ds_world, s->nn_pts,
+                                 s->max_ds, s->nn_cnt, bound,
                                  &s->dev->n_tie, s->tie_list);
     kt_end(s, 0);
     return rc;
