@@ -325,6 +325,29 @@ void lio_ndt_default_params(lio_ndt_params*);
 int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_ndt_params* params, double out[16], int* iterations,
                   int* converged);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The localisation loop around the matcher: hdl_localization::PoseEstimator (slam/localization/hdl_localization/src/
+ * pose_estimator.cpp) = a 23-state unscented Kalman filter (include/kkl/alg/unscented_kalman_filter.hpp:42-262 over
+ * include/hdl_localization/pose_system.hpp:14-115; f32 like the reference), host C++:
+ *   create ........ PoseEstimator::PoseEstimator      pose_estimator.cpp:22-66 (imu_ext row-major 4 x 4, quaternion (w, x, y, z))
+ *   predict ....... predict(stamp) / predict(stamp, acc, gyro)   :142-186 (acc, gyro NULL = no IMU); returns 1 if a step was made
+ *   match ......... match(observation, ..., stamp, cloud, gps = none, ...)  :188-300: lio_ndt_align from the filter's pose, the
+ *                   5 m / 10 deg gate, quaternion hemisphere; returns 1 / 0 = the reference's bool
+ *   correct ....... correct(stamp, observation)       :348-360
+ *   matrix / get .. matrix(), ukf->mean / cov
+ * GNSS fusion (fusion_pose), the INS state queue (get_timed_pose) and the fitness score are not built. */
+typedef struct lio_pose_estimator lio_pose_estimator;
+lio_pose_estimator* lio_pose_estimator_create(const float imu_ext[16], uint64_t stamp_us, const float pos[3], const float quat_wxyz[4],
+                                              double cool_time_duration);
+void lio_pose_estimator_destroy(lio_pose_estimator*);
+int lio_pose_estimator_predict(lio_pose_estimator*, uint64_t stamp_us, const float acc[3], const float gyro[3]);
+int lio_pose_estimator_match(lio_pose_estimator*, lio_ndt* target, lio_scan* source, const lio_ndt_params* params, float observation[7],
+                             int* iterations);
+int lio_pose_estimator_correct(lio_pose_estimator*, uint64_t stamp_us, const float observation[7]);
+int lio_pose_estimator_get(lio_pose_estimator*, float mean23[23], float cov529[529]);
+int lio_pose_estimator_set(lio_pose_estimator*, const float mean23[23], const float cov529[529]);
+int lio_pose_estimator_matrix(lio_pose_estimator*, float T[16]);
+
 /* manifold helpers exposed for known-answer tests (mtk SO3/S2 boxplus/boxminus, SOn.hpp:233-245, S2.hpp:136-167) */
 void lio_state_boxplus(const double s26[26], const double d23[23], double out26[26]);
 void lio_state_boxminus(const double a26[26], const double b26[26], double d23[23]);

@@ -27,6 +27,8 @@ SYMBOLS = [
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
     "lio_engine_enable_timing", "lio_engines_process_batch", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
+    "lio_pose_estimator_create", "lio_pose_estimator_destroy", "lio_pose_estimator_predict", "lio_pose_estimator_match",
+    "lio_pose_estimator_correct", "lio_pose_estimator_get", "lio_pose_estimator_set", "lio_pose_estimator_matrix",
     "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_ins_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
     "lio_state_predict", "lio_eskf_update_cb",
@@ -146,6 +148,14 @@ def lib():
     sig("lio_engine_enable_timing", cint, vp, cint)
     sig("lio_engines_process_batch", cint, C.POINTER(vp), cint, C.POINTER(ScanJob), cint)
     sig("lio_engine_set_static_map", cint, vp, cint)
+    sig("lio_pose_estimator_create", vp, f32p, u64, f32p, f32p, dbl)
+    sig("lio_pose_estimator_destroy", None, vp)
+    sig("lio_pose_estimator_predict", cint, vp, u64, f32p, f32p)
+    sig("lio_pose_estimator_match", cint, vp, vp, vp, C.POINTER(NdtParams), f32p, C.POINTER(cint))
+    sig("lio_pose_estimator_correct", cint, vp, u64, f32p)
+    sig("lio_pose_estimator_get", cint, vp, f32p, f32p)
+    sig("lio_pose_estimator_set", cint, vp, f32p, f32p)
+    sig("lio_pose_estimator_matrix", cint, vp, f32p)
     sig("lio_fastlio_init", cint, vp, f64p, f64p, cint, cint, dbl, cint)
     sig("lio_fastlio_is_init", cint, vp)
     sig("lio_fastlio_imu_enqueue", cint, vp, dbl, f64p, f64p)

@@ -494,3 +494,57 @@ def eskf_update(s, P, R, model, max_iter=4, cap=4096):
     fn = make_meas_fn(model)
     check(lib().lio_eskf_update_cb(ptr(s, C.c_double), ptr(P, C.c_double), float(R), max_iter, fn, None, cap, ptr(so, C.c_double), ptr(Po, C.c_double)))
     return so, Po.reshape(23, 23)
+
+
+class PoseEstimator:
+    """hdl_localization::PoseEstimator over the device matcher: 23-state UKF (host, f32) + lio_ndt_align.
+    Stamps in microseconds, quaternions (w, x, y, z), as in the reference."""
+
+    def __init__(self, pos, quat_wxyz, stamp_us=0, imu_ext=np.eye(4), cool_time=1.0):
+        a, b, c = f32(imu_ext).reshape(-1), f32(pos), f32(quat_wxyz)
+        self.h = lib().lio_pose_estimator_create(ptr(a, C.c_float), int(stamp_us), ptr(b, C.c_float), ptr(c, C.c_float), float(cool_time))
+        if not self.h:
+            raise capi.LioError("lio_pose_estimator_create failed")
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().lio_pose_estimator_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def predict(self, stamp_us, acc=None, gyro=None):
+        if acc is None:
+            return check(lib().lio_pose_estimator_predict(self.h, int(stamp_us), None, None), "predict")
+        a, g = f32(acc), f32(gyro)
+        return check(lib().lio_pose_estimator_predict(self.h, int(stamp_us), ptr(a, C.c_float), ptr(g, C.c_float)), "predict")
+
+    def match(self, ndt, scan, params=None):
+        """returns (ok, observation (7,), LM iterations)"""
+        obs = np.zeros(7, np.float32)
+        it = C.c_int(0)
+        p = params
+        if p is None:
+            p = capi.NdtParams()
+            lib().lio_ndt_default_params(C.byref(p))
+        ok = check(lib().lio_pose_estimator_match(self.h, ndt.h, scan.h, C.byref(p), ptr(obs, C.c_float), C.byref(it)), "match")
+        return bool(ok), obs, it.value
+
+    def correct(self, stamp_us, observation):
+        z = f32(observation)
+        check(lib().lio_pose_estimator_correct(self.h, int(stamp_us), ptr(z, C.c_float)), "correct")
+
+    def get(self):
+        m, c = np.zeros(23, np.float32), np.zeros(529, np.float32)
+        check(lib().lio_pose_estimator_get(self.h, ptr(m, C.c_float), ptr(c, C.c_float)))
+        return m, c.reshape(23, 23)
+
+    def set(self, mean=None, cov=None):
+        m = f32(mean) if mean is not None else None
+        c = f32(cov).reshape(-1) if cov is not None else None
+        check(lib().lio_pose_estimator_set(self.h, ptr(m, C.c_float) if m is not None else None, ptr(c, C.c_float) if c is not None else None))
+
+    def matrix(self):
+        T = np.zeros(16, np.float32)
+        check(lib().lio_pose_estimator_matrix(self.h, ptr(T, C.c_float)))
+        return T.reshape(4, 4)
