@@ -114,6 +114,13 @@ def main():
     np.savez_compressed(os.path.join(OUT, "ndt.npz"), map=nd_map, ds=ds, T_guess=T_guess, T_true=T_true, n_voxels=nd.num_voxels,
                         n_corr=lin_n["n_corr"], H=lin_n["H"], b=lin_n["b"], err=lin_n["err"], T_aligned=T_al, converged=conv, iterations=its,
                         source="oracle/ndt_oracle.cpp (fast_gicp NDTCuda P2D restated; CUDA sources not buildable: unpinned except se3_exp / Eigen pieces)")
+    # ---- localisation UKF: a scripted drive through the reference's OWN filter code (oracle/_ref/libref_ukf.so) ----
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_ukf_vs_ref as tu  # the script (IMU steps, IMU-less steps, observations) lives with the test that replays it
+
+    ops = tu.script(0, 60)
+    np.savez_compressed(os.path.join(OUT, "ukf.npz"), seed=0, n=60, trace=tu.run_reference(ops).astype(np.float32),
+                        source="kkl/alg/unscented_kalman_filter.hpp + hdl_localization/pose_system.hpp compiled from /root/reference (oracle/ref_ukf.cpp)")
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
