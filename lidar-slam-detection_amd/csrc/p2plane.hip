@@ -297,28 +297,44 @@ __global__ void __launch_bounds__(kFinThreads) finalize_kernel(ScanDev* __restri
         if (c < kAcc && l == 0) acc[c] = s;
     }
     __syncthreads();
-    if (tid == 0) {
-        int t = 0;
-        double J[36];
-        for (int a = 0; a < 6; a++)
-            for (int c = a; c < 6; c++) { J[a * 6 + c] = acc[t]; J[c * 6 + a] = acc[t]; t++; }
-        for (int k = 0; k < 36; k++) out->JtJ[k] = J[k];
-        for (int a = 0; a < 6; a++) out->Jtr[a] = acc[21 + a];
-        for (int a = 0; a < 3; a++)
-            for (int c = 0; c < 3; c++) out->nnT[a * 3 + c] = J[a * 6 + c];
-        for (int k = 0; k < 3; k++) { out->contri[k] = 0.0; out->strong[k] = 0.0; }
-        out->sum_abs_res = acc[27];
-        out->n_eff = (uint32_t)(acc[28] + 0.5);
-        out->n_ds = n;
-        out->n_tie = sd->n_tie;  // hand the tie queue to the host and re-arm it
-        sd->n_tie_done = sd->n_tie;
-        sd->n_tie = 0;
-        unsigned long long kc = 0ull;
-        if (md)
-            for (int k = 0; k < 64; k++) kc += md->knn_cand[k * 16];
-        out->n_knn_candidates_lo = (uint32_t)kc;
-        out->n_knn_candidates_hi = (uint32_t)(kc >> 32);
+    // the record goes out through 64 lanes at once (a handful of PCIe writes instead of ~60 dependent-looking single stores), then
+    // one system-scope fence and the sequence word
+    if (tid < 64) {
+        // acc[] holds the upper triangle row by row: index of (a, c), a <= c
+        if (tid < 36) {
+            int a = tid / 6, c = tid % 6;
+            if (a > c) { const int u = a; a = c; c = u; }
+            const int t = a * 6 - a * (a - 1) / 2 + (c - a);
+            out->JtJ[tid] = acc[t];
+        } else if (tid < 42) {
+            out->Jtr[tid - 36] = acc[21 + (tid - 36)];
+        } else if (tid < 51) {
+            const int k = tid - 42;
+            int a = k / 3, c = k % 3;
+            if (a > c) { const int u = a; a = c; c = u; }
+            out->nnT[k] = acc[a * 6 - a * (a - 1) / 2 + (c - a)];
+        } else if (tid < 54) {
+            out->contri[tid - 51] = 0.0;
+        } else if (tid < 57) {
+            out->strong[tid - 54] = 0.0;
+        } else if (tid == 57) {
+            out->sum_abs_res = acc[27];
+            out->n_eff = (uint32_t)(acc[28] + 0.5);
+            out->n_ds = n;
+            out->n_tie = sd->n_tie;  // hand the tie queue to the host and re-arm it
+            sd->n_tie_done = sd->n_tie;
+            sd->n_tie = 0;
+        } else if (tid == 58) {
+            unsigned long long kc = 0ull;
+            if (md)
+                for (int k = 0; k < 64; k++) kc += md->knn_cand[k * 16];
+            out->n_knn_candidates_lo = (uint32_t)kc;
+            out->n_knn_candidates_hi = (uint32_t)(kc >> 32);
+        }
         __threadfence_system();
+    }
+    __syncthreads();
+    if (tid == 0) {
         const uint32_t seq = sd->seq + 1u;
         sd->seq = seq;
         *reinterpret_cast<volatile uint32_t*>(&out->seq) = seq;
