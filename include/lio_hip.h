@@ -348,6 +348,22 @@ int lio_pose_estimator_get(lio_pose_estimator*, float mean23[23], float cov529[5
 int lio_pose_estimator_set(lio_pose_estimator*, const float mean23[23], const float cov529[529]);
 int lio_pose_estimator_matrix(lio_pose_estimator*, float T[16]);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Local-map assembly for localisation on the device: Localization::runUpdateLocalMap (slam/localization/src/
+ * localization.cpp:303-373).  Key-frame clouds (map frame) are stored once in HBM; lio_localmap_update does one pass of the
+ * loop body -- skip if the pose moved less than update_distance (10 m) since the last update, radius search (30 m) over the
+ * key-frame positions nearest first, thinning by key_frame_distance, concatenation until max_local_points (200000), VoxelGrid
+ * with `leaf`, new NDT target -- with device-to-device copies only.  Returns 0 nothing to do, 1 target replaced, 2 out of map
+ * (:364-367), 3 nearest key frame >= 20 m away (:352-354); the target is dropped in cases 2 and 3. */
+typedef struct lio_localmap lio_localmap;
+lio_localmap* lio_localmap_create(int device, uint64_t max_total_points, uint32_t max_local_points, uint32_t max_keyframe_points);
+void lio_localmap_destroy(lio_localmap*);
+int lio_localmap_add_keyframe(lio_localmap*, const float* world_xyzi, uint32_t n, const float position[3]);
+int lio_localmap_num_keyframes(lio_localmap*);
+int lio_localmap_update(lio_localmap*, lio_ndt* target, const double pose_xyz[3], double update_distance, double radius, double key_frame_distance,
+                        float leaf, int* n_keyframes, uint32_t* n_points);
+int lio_localmap_download(lio_localmap*, float* out_xyzi, uint32_t cap);
+
 /* manifold helpers exposed for known-answer tests (mtk SO3/S2 boxplus/boxminus, SOn.hpp:233-245, S2.hpp:136-167) */
 void lio_state_boxplus(const double s26[26], const double d23[23], double out26[26]);
 void lio_state_boxminus(const double a26[26], const double b26[26], double d23[23]);

@@ -27,6 +27,8 @@ SYMBOLS = [
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
     "lio_engine_enable_timing", "lio_engines_process_batch", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
+    "lio_localmap_create", "lio_localmap_destroy", "lio_localmap_add_keyframe", "lio_localmap_num_keyframes", "lio_localmap_update",
+    "lio_localmap_download",
     "lio_pose_estimator_create", "lio_pose_estimator_destroy", "lio_pose_estimator_predict", "lio_pose_estimator_match",
     "lio_pose_estimator_correct", "lio_pose_estimator_get", "lio_pose_estimator_set", "lio_pose_estimator_matrix",
     "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_ins_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
@@ -148,6 +150,12 @@ def lib():
     sig("lio_engine_enable_timing", cint, vp, cint)
     sig("lio_engines_process_batch", cint, C.POINTER(vp), cint, C.POINTER(ScanJob), cint)
     sig("lio_engine_set_static_map", cint, vp, cint)
+    sig("lio_localmap_create", vp, cint, u64, u32, u32)
+    sig("lio_localmap_destroy", None, vp)
+    sig("lio_localmap_add_keyframe", cint, vp, f32p, u32, f32p)
+    sig("lio_localmap_num_keyframes", cint, vp)
+    sig("lio_localmap_update", cint, vp, vp, f64p, dbl, dbl, dbl, flt, C.POINTER(cint), C.POINTER(u32))
+    sig("lio_localmap_download", cint, vp, f32p, u32)
     sig("lio_pose_estimator_create", vp, f32p, u64, f32p, f32p, dbl)
     sig("lio_pose_estimator_destroy", None, vp)
     sig("lio_pose_estimator_predict", cint, vp, u64, f32p, f32p)

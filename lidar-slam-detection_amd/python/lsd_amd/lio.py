@@ -548,3 +548,37 @@ class PoseEstimator:
         T = np.zeros(16, np.float32)
         check(lib().lio_pose_estimator_matrix(self.h, ptr(T, C.c_float)))
         return T.reshape(4, 4)
+
+
+class LocalMap:
+    """Localization::runUpdateLocalMap on the device: key-frame clouds resident in HBM, local map = gather + VoxelGrid + NDT target"""
+
+    def __init__(self, max_total_points=20_000_000, max_local_points=200_000, max_keyframe_points=200_000, device=0):
+        self.h = lib().lio_localmap_create(device, max_total_points, max_local_points, max_keyframe_points)
+        if not self.h:
+            raise capi.LioError("lio_localmap_create failed: " + lib().lio_last_error().decode())
+        self._cap = max_local_points + max_keyframe_points
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().lio_localmap_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def add_keyframe(self, world_xyzi, position):
+        p, c = f32(world_xyzi).reshape(-1, 4), f32(position)
+        return check(lib().lio_localmap_add_keyframe(self.h, ptr(p, C.c_float), len(p), ptr(c, C.c_float)), "add_keyframe")
+
+    def update(self, ndt, pose_xyz, update_distance=10.0, radius=30.0, key_frame_distance=1.0, leaf=0.2):
+        """returns (code, key frames used, points in the new target); code as lio_localmap_update"""
+        x = f64(pose_xyz)
+        nk, npts = C.c_int(0), C.c_uint32(0)
+        rc = check(lib().lio_localmap_update(self.h, ndt.h, ptr(x, C.c_double), float(update_distance), float(radius), float(key_frame_distance), float(leaf),
+                                             C.byref(nk), C.byref(npts)), "localmap update")
+        return rc, nk.value, npts.value
+
+    def download(self):
+        out = np.zeros((self._cap, 4), np.float32)
+        n = check(lib().lio_localmap_download(self.h, ptr(out, C.c_float), self._cap))
+        return out[:n].copy()

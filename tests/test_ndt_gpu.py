@@ -139,3 +139,62 @@ def test_pose_estimator_loop_tracks_a_drive(scene):
         assert dp < 0.3 and dr < 0.05, (k, dp, dr)
     assert n_ok >= 15, n_ok
     print("pose estimator loop: worst position error %.3f m, %d / 19 matches accepted" % (worst, n_ok))
+
+
+def test_local_map_assembly_on_device(oracle_mod, scene):
+    """Localization::runUpdateLocalMap with the key frames resident in HBM: selection (radius, nearest first, thinning, point
+    cap), VoxelGrid and target build -- the downsampled local map is bit-identical to the oracle's VoxelGrid of the same
+    concatenation, the matcher built from it aligns a scan, and the skip / out-of-map / far-key-frame branches fire"""
+    from lsd_amd import capi, lio, synth
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(3)
+    lm = lio.LocalMap(max_total_points=6_000_000, max_local_points=200_000, max_keyframe_points=80_000)
+    frames, poses = [], []
+    for k in range(40):  # key frames every 2 m along x, clouds already in the map frame
+        pos = np.array([-40.0 + 2.0 * k, rng.uniform(-0.5, 0.5), 1.8])
+        q = synth.quat_from_rotvec([0, 0, rng.uniform(-0.2, 0.2)])
+        raw, _ = synth.make_scan(scene, pos, q, seed=100 + k, n_az=600, fov_deg=(-24.8, 2.0))
+        w = raw.copy()
+        w[:, :3] = (raw[:, :3].astype(np.float64) @ synth.quat_to_R(q).T + pos).astype(np.float32)
+        frames.append(w)
+        poses.append(pos.astype(np.float32))
+        assert lm.add_keyframe(w, pos) == k
+    ndt = lio.Ndt(resolution=1.0, search_method=7, max_points=400_000, max_voxels=200_000, max_source_points=1 << 17)
+    pose = np.array([3.0, 0.2, 1.8])
+    rc, nk, npts = lm.update(ndt, pose, key_frame_distance=3.0, leaf=0.2)
+    assert rc == 1
+    # the reference's selection, restated: nearest first, skip key frames closer than key_frame_distance (in range) to the last taken
+    d = np.sqrt(((np.array(poses) - pose.astype(np.float32)) ** 2).sum(1).astype(np.float32))
+    order = [i for i in np.argsort(d, kind="stable") if d[i] ** 2 <= 900.0]
+    take, acc, total = [], 0.0, 0
+    for i in order:
+        if total and (d[i] - acc) < 3.0:
+            continue
+        acc = d[i]
+        take.append(i)
+        total += len(frames[i])
+        if total >= 200_000:
+            break
+    assert nk == len(take)
+    want = oracle_mod.voxel_downsample(np.concatenate([frames[i] for i in take]), 0.2)
+    got = lm.download()
+    assert npts == len(want) == len(got) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the target built from it localises a fresh scan
+    tq = synth.quat_from_rotvec([0, 0, 0.1])
+    raw, _ = synth.make_scan(scene, pose, tq, seed=999, n_az=900, fov_deg=(-24.8, 2.0))
+    src = lio.Scan(max_raw=1 << 18, max_ds=1 << 17)
+    src.upload(raw)
+    src.voxel_downsample(0.2)
+    T0 = np.eye(4)
+    T0[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0, 0, 0.12]))
+    T0[:3, 3] = pose + [0.15, -0.1, 0.02]
+    T, conv, it = ndt.align(src, T0)
+    assert conv and np.linalg.norm(T[:3, 3] - pose) < 0.05
+    # branches
+    assert lm.update(ndt, pose + [4.0, 0, 0])[0] == 0            # moved less than 10 m: nothing to do
+    assert lm.update(ndt, pose + [12.0, 0, 0], key_frame_distance=3.0)[0] == 1
+    assert lm.update(ndt, np.array([500.0, 0, 0]))[0] == 2        # no key frame within 30 m: out of map, target dropped
+    assert ndt.num_voxels == 0
+    assert lm.update(ndt, np.array([62.0, 0.0, 1.8]))[0] == 3     # nearest key frame 24 m away: target dropped
