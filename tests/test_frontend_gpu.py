@@ -203,3 +203,44 @@ def test_slam_wrapper_process_boundary(scene):
     finally:
         sw.deinit_slam()
     print("slam_wrapper.process: worst position error %.4f m" % worst)
+
+
+def test_front_half_edge_cases(oracle_mod, scene):
+    """empty and all-blind clouds, the max_point_num decimation, an oversized scan, re-initialisation"""
+    _dev()
+    from lsd_amd import capi, lio, synth
+
+    tr = synth.Trajectory()
+    e = lio.Engine(max_points=2_000_000, max_voxels=1 << 19, max_raw=1 << 17, max_ds=60000)
+    e.fastlio_init(scan_period=0.1, max_point_num=30000)  # point_filter_num = max(1, n / 30000)
+    o = oracle_mod.Lio()
+    imu = synth.imu_stream(tr, 0.0, 1.6, rate=200.0)
+    ii = 0
+    for k in range(12):
+        tb = k * 0.1
+        pts, st = synth.make_sweep(scene, tr, tb, n_beams=64, n_az=1500, seed=k, fov_deg=(-24.8, 2.0))
+        if k == 9:
+            pts, st = pts[:0], st[:0]                       # an empty cloud
+        if k == 10:
+            pts = pts.copy()
+            pts[:, :3] *= np.float32(0.0005)                # everything inside the blind radius
+        o.frontend_config(scan_period=0.1, filter_num=max(1, len(pts) // 30000))
+        while ii < len(imu) and imu[ii][0] <= tb + 0.12:
+            e.fastlio_imu_enqueue(*imu[ii])
+            o.imu_enqueue(*imu[ii])
+            ii += 1
+        e.fastlio_pcl_enqueue(pts, st, tb)
+        o.pcl_enqueue(pts, st, tb)
+        ra, rb = e.fastlio_main(), o.frontend_main()
+        assert ra == rb or (k in (9, 10) and ra in (capi.MAIN_SEEDED, capi.MAIN_SKIPPED) and rb in (capi.MAIN_SEEDED, capi.MAIN_SKIPPED)), (k, ra, rb)
+        if ra == capi.MAIN_UPDATED:
+            a = e.undistorted()
+            assert np.isfinite(a[:, 0]).sum() == len(o.get_undistorted())
+        sa, sb = e.get_state(), o.get_state()
+        assert np.linalg.norm(sa[0:3] - sb[0:3]) < 1e-4 and synth.quat_angle(sa[3:7], sb[3:7]) < 1e-5, k
+    big = np.zeros(((1 << 17) + 1, 4), np.float32)
+    with pytest.raises(capi.LioError):
+        e.fastlio_pcl_enqueue(big, np.zeros(len(big), np.uint32), 2.0)
+    e.fastlio_init(scan_period=0.1)  # fastlio_init again: buffers, filter and flags start over
+    assert not e.fastlio_is_init() and e.fastlio_main() == capi.MAIN_IDLE
+    assert np.array_equal(e.get_state(), lio.default_state())
