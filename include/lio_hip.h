@@ -311,6 +311,10 @@ int lio_ndt_voxel_at(lio_ndt*, const float p[3], float mean[3], float cinv[9]);
  * NDTCuda::compute_error (update_corr = 0, with_derivatives = 0: error on the cached pairs)  (ndt_cuda_impl.hpp:82-90) */
 int lio_ndt_linearize(lio_ndt*, lio_scan* source, const double T[16], int update_corr, int with_derivatives, double H[36], double b[6],
                       double* err, uint32_t* n_corr);
+/* pcl::Registration::getFitnessScore(max_range) as pose_estimator.cpp:262 calls it (max_range 25 = a SQUARED distance): mean
+ * squared distance from the transformed source points to their nearest target point, over those within range; *score is
+ * DBL_MAX when none is (PCL's value).  Exact nearest neighbours, from the target points the voxel grid retains. */
+int lio_ndt_fitness_score(lio_ndt*, lio_scan* source, const double T[16], double max_range, double* score, uint32_t* n_inliers);
 typedef struct lio_ndt_params {
     int32_t max_iterations;           /* setMaximumIterations (64) */
     int32_t lm_max_iterations;        /* lm_max_iterations_ (10) */

@@ -431,6 +431,67 @@ __global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restr
 
 using namespace lio;
 
+// pcl::Registration::getFitnessScore(max_range) (called at pose_estimator.cpp:262 during the warm-up): mean squared distance
+// from every transformed source point to its nearest target point, over the points whose nearest neighbour lies within max_range
+// (a SQUARED distance, pcl/registration/impl/registration.hpp).  The target's points sit in the voxel grid's pool: an exact
+// nearest neighbour by rings of cells around the query's cell -- after ring r every unseen point is at least r * res away, so
+// the search stops as soon as the best distance is within that (or the range is exhausted).
+__global__ void __launch_bounds__(256) ndt_fitness_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, float res,
+                                                          NdtXform X, const float4* __restrict__ src, const ScanDev* __restrict__ sd, float max_range_sq,
+                                                          double* __restrict__ partial) {
+    const uint32_t n = sd->n_ds;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    double my_sum = 0.0;
+    uint32_t my_cnt = 0;
+    if (i < n) {
+        const float4 p = src[i];
+        // pcl::transformPointCloud with a Matrix4f: accumulated left to right
+        const float tx = ((X.R[0] * p.x + X.R[1] * p.y) + X.R[2] * p.z) + X.t[0];
+        const float ty = ((X.R[3] * p.x + X.R[4] * p.y) + X.R[5] * p.z) + X.t[1];
+        const float tz = ((X.R[6] * p.x + X.R[7] * p.y) + X.R[8] * p.z) + X.t[2];
+        int kx, ky, kz;
+        pos2grid_ndt(tx, ty, tz, res, kx, ky, kz);
+        float best = INFINITY;
+        for (int r = 0;; r++) {
+            for (int dz = -r; dz <= r; dz++)
+                for (int dy = -r; dy <= r; dy++)
+                    for (int dx = -r; dx <= r; dx++) {
+                        if (max(max(abs(dx), abs(dy)), abs(dz)) != r) continue;
+                        const unsigned long long want = pack_key(kx + dx, ky + dy, kz + dz);
+                        BrickProbe bp = brick_probe(kx + dx, ky + dy, kz + dz);
+                        for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
+                            const Slot sl = table[brick_slot(bp, mask)];
+                            if (sl.key == want) {
+                                for (uint32_t j = 0; j < sl.cnt; j++) {
+                                    const float4 q = pool[sl.ptr + j];
+                                    const float ex = q.x - tx, ey = q.y - ty, ez = q.z - tz;
+                                    const float d2 = (ex * ex + ey * ey) + ez * ez;
+                                    best = fminf(best, d2);
+                                }
+                                break;
+                            }
+                            if (sl.key == kEmptyKey) break;
+                            brick_next(bp);
+                        }
+                    }
+            const float reach = (float)r * res;
+            if (best <= reach * reach || reach * reach > max_range_sq) break;
+        }
+        if (best <= max_range_sq) { my_sum = (double)best; my_cnt = 1; }
+    }
+    __shared__ double ssum[4];
+    __shared__ uint32_t scnt[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { my_sum += __shfl_xor(my_sum, off); my_cnt += __shfl_xor(my_cnt, off); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = my_sum; scnt[threadIdx.x >> 6] = my_cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        partial[blockIdx.x * 2 + 1] = (double)((scnt[0] + scnt[1]) + (scnt[2] + scnt[3]));
+    }
+}
+
+
 struct lio_ndt {
     int device;
     float res;
@@ -699,6 +760,33 @@ int lio_ndt_set_target(lio_ndt* n, const float* xyzi, uint64_t np) {
     hipStreamSynchronize(n->map->stream);
     hipFree(tmp);
     return rc;
+}
+
+int lio_ndt_fitness_score(lio_ndt* n, lio_scan* s, const double T[16], double max_range, double* score, uint32_t* n_inliers) {
+    if (!n || !s || !T || !score || !(max_range > 0)) return LIO_E_INVALID;
+    if (n->device != s->device) { set_error("matcher and scan live on different devices"); return LIO_E_INVALID; }
+    hipSetDevice(n->device);
+    hipStreamSynchronize(n->map->stream);  // the target build ran on the map's stream
+    const int nd = lio_scan_num_ds(s);
+    if (nd < 0) return nd;
+    *score = 1.7976931348623157e308;  // std::numeric_limits<double>::max(): "no correspondence"
+    if (n_inliers) *n_inliers = 0;
+    if (nd == 0) return LIO_OK;
+    const uint32_t blocks = ((uint32_t)nd + 255u) / 256u;
+    double* d_part = nullptr;
+    LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_part), sizeof(double) * 2 * blocks));
+    hipLaunchKernelGGL(ndt_fitness_kernel, blocks, 256, 0, s->stream, n->map->table, n->map->table_mask, n->map->pool, n->res, to_xform(T), s->ds_body, s->dev,
+                       (float)max_range, d_part);
+    std::vector<double> part(2 * (size_t)blocks);
+    hipError_t e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(d_part);
+    if (e != hipSuccess) { set_error("fitness score read-back failed: %s", hipGetErrorString(e)); return LIO_E_DEVICE; }
+    double sum = 0.0, cnt = 0.0;
+    for (uint32_t b = 0; b < blocks; b++) { sum += part[2 * b]; cnt += part[2 * b + 1]; }
+    if (cnt > 0) *score = sum / cnt;
+    if (n_inliers) *n_inliers = (uint32_t)cnt;
+    return LIO_OK;
 }
 
 int lio_ndt_num_voxels(lio_ndt* n) {

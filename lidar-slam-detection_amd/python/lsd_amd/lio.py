@@ -413,6 +413,13 @@ class Ndt:
                                       ptr(b, C.c_double), C.byref(e), C.byref(nc)), "ndt linearize")
         return dict(n_corr=int(nc.value), H=H.reshape(6, 6), b=b, err=e.value)
 
+    def fitness_score(self, scan, T, max_range=25.0):
+        """pcl getFitnessScore(max_range): (mean squared nearest-neighbour distance, points within range)"""
+        t = f64(T).reshape(4, 4)
+        sc, ni = C.c_double(0.0), C.c_uint32(0)
+        check(lib().lio_ndt_fitness_score(self.h, scan.h, ptr(t, C.c_double), float(max_range), C.byref(sc), C.byref(ni)), "fitness score")
+        return sc.value, ni.value
+
     def align(self, scan, guess, **params):
         g = f64(guess).reshape(4, 4)
         prm = capi.NdtParams()

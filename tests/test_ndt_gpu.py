@@ -198,3 +198,40 @@ def test_local_map_assembly_on_device(oracle_mod, scene):
     assert lm.update(ndt, np.array([500.0, 0, 0]))[0] == 2        # no key frame within 30 m: out of map, target dropped
     assert ndt.num_voxels == 0
     assert lm.update(ndt, np.array([62.0, 0.0, 1.8]))[0] == 3     # nearest key frame 24 m away: target dropped
+
+
+def test_fitness_score_exact_nearest_neighbours(scene):
+    """getFitnessScore(max_range): exact nearest neighbours by rings of target voxels vs brute force in the same f32 arithmetic"""
+    from lsd_amd import capi, lio, synth
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(12)
+    target = scene.sample_surface(400_000, seed=31, sigma=0.01)
+    target = target[np.linalg.norm(target[:, :2], axis=1) < 35.0][:40_000]
+    ndt = lio.Ndt(resolution=1.0, search_method=7, max_points=len(target) + 1, max_voxels=100_000, max_source_points=1 << 16)
+    ndt.set_target(target)
+    src_pts = np.concatenate([target[rng.choice(len(target), 2500, replace=False)] + rng.normal(0, 0.05, (2500, 4)).astype(np.float32),
+                              np.concatenate([rng.uniform(-60, 60, (500, 2)), rng.uniform(5, 30, (500, 1)), np.zeros((500, 1))], 1).astype(np.float32)])
+    scan = lio.Scan(max_raw=1 << 16, max_ds=1 << 16)
+    scan.set_ds(src_pts)
+    T = np.eye(4)
+    T[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0.01, -0.02, 0.05]))
+    T[:3, 3] = [0.3, -0.2, 0.1]
+    Tf = T.astype(np.float32)
+    tp = np.stack([((Tf[r, 0] * src_pts[:, 0] + Tf[r, 1] * src_pts[:, 1]) + Tf[r, 2] * src_pts[:, 2]) + Tf[r, 3] for r in range(3)], 1)
+    best = np.full(len(tp), np.inf, np.float32)
+    for a in range(0, len(tp), 200):
+        d = tp[a:a + 200, None, :] - target[None, :, :3]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        best[a:a + 200] = d2.min(1)
+    for max_range in (25.0, 1.0, 1e-3):
+        inl = best <= np.float32(max_range)
+        score, n_in = ndt.fitness_score(scan, T, max_range)
+        assert n_in == inl.sum(), (max_range, n_in, inl.sum())
+        assert abs(score - best[inl].astype(np.float64).mean()) <= 1e-12 * max(1.0, score)
+    far = src_pts.copy()
+    far[:, 2] += 500.0
+    scan.set_ds(far)
+    score, n_in = ndt.fitness_score(scan, T, 25.0)
+    assert n_in == 0 and score > 1e300  # PCL: std::numeric_limits<double>::max()
