@@ -112,8 +112,11 @@ __device__ inline VgGrid vg_derive(const ScanDev* sd, float inv) {
     return g;
 }
 
+// voxel index of every point + the histogram of its lowest digit: one workgroup per sort tile, so the first radix pass needs
+// no histogram launch of its own (the later passes histogram the re-ordered keys)
 __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
-                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
+                                                           uint32_t nblocks) {
     const VgGrid g = vg_derive(sd, inv);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sd->n_ds_prev = sd->n_ds;  // still the previous scan's size: the heads kernel runs later
@@ -123,18 +126,33 @@ __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restr
         sd->minb[0] = g.minb[0]; sd->minb[1] = g.minb[1]; sd->minb[2] = g.minb[2];
         sd->mul1 = g.mul1; sd->mul2 = g.mul2;
     }
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 p = in[i];
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kTile;
+    float4 p[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        const uint32_t i = base + r * kThreads + threadIdx.x;
+        if (i < n) p[r] = in[i];
+    }
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        const uint32_t i = base + r * kThreads + threadIdx.x;
+        if (i >= n) continue;
         uint32_t key = g.total;  // invalid marker sorts behind every occupied voxel
-        if (g.total && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-            const int i0 = (int)(floorf(p.x * inv) - (float)g.minb[0]);
-            const int i1 = (int)(floorf(p.y * inv) - (float)g.minb[1]);
-            const int i2 = (int)(floorf(p.z * inv) - (float)g.minb[2]);
+        if (g.total && isfinite(p[r].x) && isfinite(p[r].y) && isfinite(p[r].z)) {
+            const int i0 = (int)(floorf(p[r].x * inv) - (float)g.minb[0]);
+            const int i1 = (int)(floorf(p[r].y * inv) - (float)g.minb[1]);
+            const int i2 = (int)(floorf(p[r].z * inv) - (float)g.minb[2]);
             key = (uint32_t)(i0 + i1 * g.mul1 + i2 * g.mul2);
         }
         keys[i] = key;
         vals[i] = i;
+        atomicAdd(&h[key & 255u], 1u);
     }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // ---- stable LSD radix sort, 8 bits per pass, ping-pong a -> b -> a ... ------------------------------------
@@ -455,10 +473,9 @@ int vg_downsample(lio_scan* s, float leaf) {
     }
     const uint32_t g1 = nblocks < 48 ? nblocks : 48;  // 7 same-line atomics per workgroup: keep the workgroups few
     hipLaunchKernelGGL(vg_bbox_kernel, g1, kThreads, 0, st, s->raw, n, s->dev);
-    hipLaunchKernelGGL(vg_keys_kernel, (n + kThreads - 1) / kThreads < 512 ? (n + kThreads - 1) / kThreads : 512, kThreads, 0, st, s->raw, n, inv,
-                       s->dev, s->keys_a, s->vals_a);
+    hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a, s->hist, nblocks);
     for (int pass = 0; pass < 4; pass++) {
-        hipLaunchKernelGGL(radix_hist_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, pass, s->hist, nblocks, s->dev);
+        if (pass > 0) hipLaunchKernelGGL(radix_hist_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, pass, s->hist, nblocks, s->dev);
         hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, s->keys_a, s->vals_a, s->keys_b, s->vals_b, n, pass, s->hist, nblocks,
                            s->dev);
     }
