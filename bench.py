@@ -221,7 +221,7 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = dict(bound="hbm", kernel="knn_kernel<32,1,0>", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(bound="hbm", kernel="knn_kernel<2, 0> (16 lanes per query)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, algorithmic_bytes_per_launch=int(iso_bytes),
                     avg_launch_us=round(iso_us, 2), launches=iso_launches,
                     timed_region={"avg_launch_us": round(knn_us, 2), "launches": launches, "achieved": round(shared, 1),

@@ -6,12 +6,13 @@
 // total order (d2, x, y, z) that oracle/lio_oracle.cpp uses; fewer than 5 -> all of them; none -> the output
 // is left untouched (stale neighbours survive, ivox3d.h:152-154).
 //
-// Mapping to the machine: G = 32 lanes (half a wave) work on one query.
-//   1. each lane probes one stencil cell (one 16-B slot load; 19 of 32 lanes busy for NEARBY18, three rounds
-//      for the 75-cell start-up stencil), hits are compacted into LDS with ballot + popcount and prefix-summed
+// Mapping to the machine: G = 16 lanes (a quarter wave) work on one query, four queries per wave (G = 32 costs the same alone
+// and ~8 % more GPU time with several scans in flight: fewer lanes idle on voxels of ~40 points).
+//   1. each lane probes stencil cells (one 16-B slot load each; two rounds for NEARBY18, five for the 75-cell start-up
+//      stencil), hits are compacted into LDS with ballot + popcount and prefix-summed
 //      with lane shuffles;
 //   2. voxel-major sweep: four voxel descriptors at a time come back from LDS as two ds_read_b128, lane l takes
-//      point l (l+32, ...) of each of the four voxels -- four coalesced 16-B loads in flight, addresses are
+//      point l (l+G, ...) of each of the four voxels -- four coalesced 16-B loads in flight, addresses are
 //      base + lane -- and keeps its own sorted top-5 as (d2 bits, pool index) pairs: branch-free insertion, five
 //      independent compares, v_min / v_med3 for the distances and two selects per slot for the indices;
 //   3. six rounds of a group-wide 64-bit min (shuffles) pop the global top-5 and the best loser.
@@ -24,7 +25,7 @@
 namespace lio {
 
 #ifndef LIO_KNN_G
-#define LIO_KNN_G 32
+#define LIO_KNN_G 16
 #endif
 #ifndef LIO_KNN_U
 #define LIO_KNN_U 4
