@@ -96,8 +96,8 @@ def main():
     d_scans = [torch.from_numpy(s["raw"]).to(dev) for s in scans]
     torch.cuda.synchronize()
     n_streams = args.streams
-    if n_streams <= 0:  # default: 8 scans in flight per GPU, fewer when the ranks of this node have to share few host CPUs
-        n_streams = max(2, min(8, usable_cpus() // max(world, 1) - 1))
+    if n_streams <= 0:  # default: 12 scans in flight per GPU, fewer when the ranks of this node have to share few host CPUs
+        n_streams = max(2, min(12, usable_cpus() // max(world, 1) - 1))
     engines = [lio.Engine(max_raw=1 << 18, max_ds=100000, shared_map=the_map) for _ in range(n_streams)]
     for e in engines:
         e.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
