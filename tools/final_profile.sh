@@ -14,7 +14,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- py
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o r -- python $R/bench.py --steps 32 --warmup 8 --cpu-scans 0 --streams 1 > /dev/null 2> $O/pmc_write.err
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_front -o r -- python $R/tools/bench_frontend.py --scans 40 --timing 0 > $O/frontend.json 2> $O/prof_front.err
 cd $R
-python tools/rocprof_summary.py $(find $O/prof -name "*_results.db" | head -1) "command: rocprofv3 --kernel-trace --stats -- python bench.py (defaults: 8 streams, 200 steps, 20 warm-up)" > $O/kernel_stats.txt
+python tools/rocprof_summary.py $(find $O/prof -name "*_results.db" | head -1) "command: rocprofv3 --kernel-trace --stats -- python bench.py (defaults: up to 12 streams, 200 steps, 20 warm-up)" > $O/kernel_stats.txt
 python tools/rocprof_summary.py $(find $O/prof_front -name "*_results.db" | head -1) "command: rocprofv3 --kernel-trace --stats -- python tools/bench_frontend.py --scans 40 --timing 0" > $O/frontend_kernel_stats.txt
 python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*_results.db" | head -1) $(find $O/pmc_write -name "*_results.db" | head -1) > $O/knn_traffic.json
 timeout 300 python tools/bench_frontend.py --scans 40 > $O/frontend_timing.json 2>&1
