@@ -3,7 +3,14 @@
  *
  * This is the drop-in boundary for ONE hot path of w111liang222/lidar-slam-detection:
  * the per-scan  voxel-grid downsample -> map kNN -> point-to-plane residual + Jacobian
- * accumulation -> iterated ESKF update -> map insert  loop of the FastLIO frontend.
+ * accumulation -> iterated ESKF update -> map insert  loop of the FastLIO frontend, and
+ * the callers either side of it:
+ *   lio_map_* / lio_scan_* / lio_p2plane_* ... the kernels' level (iVox, VoxelGrid, h_share_model)
+ *   lio_engine_* ........................... fastlio_main after IMU processing, the 23-DoF filter
+ *   lio_fastlio_* .......................... the reference's FastLIO entry points one to one (IMU front half included)
+ *   lio_engines_process_batch, lio_engine_set_reduce_hook ... throughput mode, joint registration across GPUs
+ *   lio_ndt_* / lio_pose_estimator_* / lio_localmap_* ........ the localisation mode's matcher, its filter, its local map
+ *   lio_state_* / lio_eskf_update_cb ....... host-only helpers that pin the filter algebra
  * Every entry point names the reference interface it replaces (paths relative to
  * /root/reference/slam/mapping/fastlio unless stated otherwise).
  *
