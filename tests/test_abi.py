@@ -79,3 +79,15 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 bad = re.findall(r'#include\s*[<"][^>"]*oracle|^\s*(?:import|from)\s+oracle|liblio_oracle|\borc_[a-z]+\s*\(|libref_harness', txt, re.M)
                 assert not bad, (os.path.join(dp, f), bad)
+
+
+def test_header_is_plain_c():
+    """the boundary is a C ABI: the header must compile as C99 on its own (no C++, no HIP, no torch types)"""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "h.c")
+        with open(src, "w") as f:
+            f.write('#include "lio_hip.h"\nint main(void) { lio_normal_eq ne; lio_ndt_params p; (void)ne; (void)p; return LIO_OK; }\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src])
