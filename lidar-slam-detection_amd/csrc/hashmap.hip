@@ -92,9 +92,13 @@ __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint3
         unsigned long long at = ~0ull;
         if (free_items) {  // a region an evicted voxel gave back (this kernel only pops, lru_evict_kernel only pushes)
             const int c = 31 - __clz(ncap);
-            const int t = atomicSub(&md->free_top[c], 1);
-            if (t > 0) at = free_items[(size_t)c * free_cap + (uint32_t)(t - 1)];
-            else atomicAdd(&md->free_top[c], 1);
+            // look before popping: the counters share cache lines and same-line atomics serialise (~10 ns each) -- with empty
+            // lists (no eviction yet) two atomics per growing voxel cost 50 us per scan
+            if (*reinterpret_cast<volatile int*>(&md->free_top[c]) > 0) {
+                const int t = atomicSub(&md->free_top[c], 1);
+                if (t > 0) at = free_items[(size_t)c * free_cap + (uint32_t)(t - 1)];
+                else atomicAdd(&md->free_top[c], 1);
+            }
         }
         if (at == ~0ull) {
             at = atomicAdd(&md->pool_top, (unsigned long long)ncap);
