@@ -237,32 +237,47 @@ __global__ void __launch_bounds__(1024) lru_append_kernel(const uint32_t* __rest
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) { head_s = md->log_head; md->log_head_prev = md->log_head; }
     __syncthreads();
-    for (unsigned long long base = 0; base < n; base += 1024) {
-        const unsigned long long i = base + tid;
-        uint32_t h = 0;
-        bool flag = false;
-        if (i < n) {
-            const uint32_t sp = slot_of_point[i];
-            if (sp != kNoIdx) {
-                h = sp & 0x7FFFFFFFu;
-                flag = touch[h] == stamp_base + i;
+    constexpr int kI = 4;  // consecutive points per lane: 4096 points per round of the one workgroup
+    for (unsigned long long base = 0; base < n; base += 1024ull * kI) {
+        uint32_t hs[kI];
+        bool fl[kI];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < kI; j++) {
+            const unsigned long long i = base + (unsigned long long)tid * kI + j;
+            hs[j] = 0;
+            fl[j] = false;
+            if (i < n) {
+                const uint32_t sp = slot_of_point[i];
+                if (sp != kNoIdx) {
+                    hs[j] = sp & 0x7FFFFFFFu;
+                    fl[j] = touch[hs[j]] == stamp_base + i;
+                }
             }
+            mine += fl[j] ? 1u : 0u;
         }
-        const unsigned long long m = __ballot(flag);
-        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(m);
+        uint32_t inc = mine;  // inclusive scan of the per-lane counts: wave shuffles, then the 16 wave totals
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        uint32_t off = 0, total = 0;
+        uint32_t off = inc - mine, total = 0;
         for (int w = 0; w < 16; w++) {
             if (w < wave) off += wsum[w];
             total += wsum[w];
         }
-        if (flag) {
+#pragma unroll
+        for (int j = 0; j < kI; j++) {
+            if (!fl[j]) continue;
             LruEntry e;
-            e.stamp = stamp_base + i;
-            e.slot = h;
+            e.stamp = stamp_base + base + (unsigned long long)tid * kI + j;
+            e.slot = hs[j];
             e.pad = 0;
-            log[(head_s + off + rank) & log_mask] = e;
+            log[(head_s + off) & log_mask] = e;
+            off++;
         }
         __syncthreads();
         if (tid == 0) head_s += total;
