@@ -48,7 +48,7 @@ struct Frontend {
     bool undistort = true;
     double Lidar_T[3] = {0, 0, 0}, Lidar_R[4] = {0, 0, 0, 1};
     // ImuProcess members
-    bool b_first_frame = true, imu_need_init = true;
+    bool b_first_frame = true, imu_need_init = true, state_init_done = false;
     int init_iter_num = 1;
     double mean_acc[3] = {0, 0, -1.0}, mean_gyr[3] = {0, 0, 0};
     double cov_acc[3] = {0.1, 0.1, 0.1}, cov_gyr[3] = {0.1, 0.1, 0.1};
@@ -581,6 +581,7 @@ static void fe_imu_init(lio_engine* e, const std::vector<ImuSample>& imu, double
         f->mean_acc[0] = 0; f->mean_acc[1] = 0; f->mean_acc[2] = -1.0;
         for (int i = 0; i < 3; i++) { f->mean_gyr[i] = 0; f->vel_last[i] = 0; f->angvel_last[i] = 0; }
         f->imu_need_init = true;
+        f->state_init_done = false;
         f->last_imu = ImuSample{};
         N = 1;
         f->b_first_frame = false;
@@ -776,7 +777,7 @@ int lio_fastlio_init(lio_engine* e, const double extT[3], const double extR[9], 
     return LIO_OK;
 }
 
-int lio_fastlio_is_init(lio_engine* e) { return e && e->fe && !e->fe->imu_need_init ? 1 : 0; }  // ImuProcess::IsInit
+int lio_fastlio_is_init(lio_engine* e) { return e && e->fe && e->fe->state_init_done ? 1 : 0; }  // ImuProcess::IsInit: state_init_done_
 
 int lio_fastlio_imu_enqueue(lio_engine* e, double stamp, const double gyr[3], const double acc_ms2[3]) {
     if (!e || !e->fe || !gyr || !acc_ms2) return LIO_E_INVALID;
@@ -906,6 +907,7 @@ int lio_fastlio_main(lio_engine* e) {
         fe_release(f, sc);
         return LIO_MAIN_IMU_INIT;
     }
+    f->state_init_done = true;  // IMU_Processing.hpp:443: set by the first scan that is undistorted, one scan after imu_need_init_ clears
     rc = fe_undistort(e, sc, meas_imu, lidar_end);
     if (rc != LIO_OK) { fe_release(f, sc); return rc; }
     rc = process_core(e, sc.beg);

@@ -8,14 +8,17 @@
 // cpu_baseline leg do.
 //
 // PARITY STATUS: the reference ships no tests, fixtures or golden vectors for
-// this path and cannot be built as a whole here
-// (PCL, Boost, OpenCV absent).  The pieces of the reference that *can* be
-// compiled from where they lie (iVox, esti_plane, the MTK manifold math and the
-// IKFoM iterated update) are compiled into oracle/_ref by oracle/Makefile and
-// this restatement is checked against them in tests/test_oracle_vs_ref.py (the
-// committed fixtures under tests/golden/ come from that build).  PCL VoxelGrid
-// is third-party source that is not in the tree: that one stage stays
-// "parity unpinned" (restated from PCL 1.9.1 voxel_grid.hpp semantics).
+// this path and its own build (cmake, PCL, Boost,
+// OpenCV) cannot run here.  Its sources for this path DO compile from where they
+// lie once those dependencies are shimmed (oracle/ref_shims): oracle/Makefile
+// builds, into oracle/_ref, the pieces (iVox, esti_plane, MTK / IKFoM filter:
+// tests/test_oracle_vs_ref.py, tests/test_ikfom_vs_ref.py, fixtures under
+// tests/golden/) and the whole translation units laserMapping.cpp +
+// IMU_Processing.hpp + preprocess.cpp driven end to end
+// (oracle/ref_fastlio.cpp, tests/test_fastlio_vs_ref.py), and this restatement
+// is checked against them.  PCL VoxelGrid is third-party source that is not in
+// the tree: that one stage stays "parity unpinned" (restated from PCL 1.9.1
+// voxel_grid.hpp semantics).
 //
 // Reference lines followed (paths relative to /root/reference/slam/mapping/fastlio):
 //   voxel downsample ........ PCL 1.9.1 VoxelGrid::applyFilter, called at
@@ -780,6 +783,7 @@ struct Lio {
         x.pos = {{0, 0, 0}}; x.rot = {0, 0, 0, 1}; x.ril = {0, 0, 0, 1};
         x.til = x.vel = x.bg = x.ba = {{0, 0, 0}};
         x.grav = {{kS2Len, 0, 0}};
+        odom_start = odom_end = x;  // start_state_point = state_ikfom() (IMU_Processing.hpp:103)
     }
 
     P4 body_to_world(const State& s, const P4& pb) const {  // laserMapping.cpp:189-198 / 831-836
@@ -1159,7 +1163,7 @@ struct Lio {
     std::deque<std::pair<double, V3>> ins_buffer;  // (stamp, velocity in the IMU frame) -- fastlio_ins_enqueue after its rotations
     double lidar_mean_scantime = 0.1;  // scan_period (laserMapping.cpp:1121)
     // ImuProcess members
-    bool b_first_frame = true, imu_need_init = true;
+    bool b_first_frame = true, imu_need_init = true, state_init_done = false;
     int init_iter_num = 1;
     V3 mean_acc{{0, 0, -1.0}}, mean_gyr{{0, 0, 0}}, cov_acc{{0.1, 0.1, 0.1}}, cov_gyr{{0.1, 0.1, 0.1}};
     V3 cov_acc_scale{{0.1, 0.1, 0.1}}, cov_gyr_scale{{0.1, 0.1, 0.1}}, cov_bias_gyr{{0.0001, 0.0001, 0.0001}}, cov_bias_acc{{0.0001, 0.0001, 0.0001}};
@@ -1298,7 +1302,7 @@ struct Lio {
         if (b_first_frame) {
             // Reset()
             mean_acc = {{0, 0, -1.0}}; mean_gyr = {{0, 0, 0}}; vel_last = {{0, 0, 0}}; angvel_last = {{0, 0, 0}};
-            imu_need_init = true; init_iter_num = 1; last_imu = Imu{0, {{0, 0, 0}}, {{0, 0, 0}}};
+            imu_need_init = true; state_init_done = false; init_iter_num = 1; last_imu = Imu{0, {{0, 0, 0}}, {{0, 0, 0}}};
             N = 1;
             b_first_frame = false;
             mean_acc = imu.front().acc;
@@ -1332,6 +1336,7 @@ struct Lio {
         P(21, 21) = P(22, 22) = 0.00001;
         last_imu = imu.back();
         last_lidar_end_time = lidar_end;
+        odom_start = x;  // start_state_point = kf_state.get_x() (IMU_Processing.hpp:234)
         (void)lidar_beg;
     }
 
@@ -1448,6 +1453,7 @@ struct Lio {
             }
             return 4;
         }
+        state_init_done = true;  // IMU_Processing.hpp:443
         undistort_pcl(sc, meas_imu, lidar_end, feats_undistort);
         const int rc = process_scan_core(feats_undistort.data(), (int)feats_undistort.size(), sc.beg);
         odom_end = x;
@@ -1617,6 +1623,12 @@ int orc_lio_get_ds(void* h, float* out, int cap) {
     std::memcpy(out, l->ds_body.data(), sizeof(P4) * (size_t)l->n_ds);
     return l->n_ds;
 }
+int orc_lio_get_ds_world(void* h, float* out, int cap) {  // feats_down_world as the last linearisation left it
+    Lio* l = static_cast<Lio*>(h);
+    if (l->n_ds > cap || (int)l->ds_world.size() < l->n_ds) return -l->n_ds;
+    std::memcpy(out, l->ds_world.data(), sizeof(P4) * (size_t)l->n_ds);
+    return l->n_ds;
+}
 // one call of h_share_model_geometric at the current state; converge != 0 -> redo kNN.
 // outputs per ds point: selected[n], normvec[n*4] (n, pd2), nn_cnt[n], nn_pts[n*5*4]; JtJ36/Jtr6 before the
 // degeneracy projection; returns n_eff
@@ -1713,6 +1725,7 @@ int orc_lio_get_undistorted(void* h, float* out, int cap) {
     std::memcpy(out, l->feats_undistort.data(), sizeof(P4) * (size_t)n);
     return n;
 }
+int orc_lio_is_init(void* h) { return static_cast<Lio*>(h)->state_init_done ? 1 : 0; }  // ImuProcess::IsInit
 void orc_lio_get_odometry(void* h, double* s26_start, double* s26_end) {
     Lio* l = static_cast<Lio*>(h);
     state_to(l->odom_start, s26_start);

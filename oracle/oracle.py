@@ -84,6 +84,8 @@ def lib():
     L.orc_lio_get_undistorted.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_lio_get_undistorted.restype = C.c_int
     L.orc_lio_get_odometry.argtypes = [C.c_void_p, f64p, f64p]
+    L.orc_lio_is_init.argtypes = [C.c_void_p]
+    L.orc_lio_get_ds_world.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_kf_update_cb.argtypes = [f64p, f64p, C.c_double, C.c_int, MEAS_FN, C.c_void_p, C.c_int, f64p, f64p]
     L.orc_so3_Exp.argtypes = [f64p, C.c_double, f64p]
     L.orc_undistort_point.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_double, f32p, f64p, f64p, f64p, f64p, f32p]
@@ -295,6 +297,9 @@ class Lio:
         assert n >= 0
         return out[:n].copy()
 
+    def is_init(self):
+        return bool(lib().orc_lio_is_init(self.h))
+
     def get_odometry(self):
         a, b = np.zeros(STATE_DIM), np.zeros(STATE_DIM)
         lib().orc_lio_get_odometry(self.h, _p(a, C.c_double), _p(b, C.c_double))
@@ -308,6 +313,12 @@ class Lio:
         n = lib().orc_lio_get_ds(self.h, _p(out, C.c_float), cap)
         assert n >= 0
         self._n = n
+        return out[:n].copy()
+
+    def get_ds_world(self, cap=100000):
+        out = np.zeros((cap, 4), np.float32)
+        n = lib().orc_lio_get_ds_world(self.h, _p(out, C.c_float), cap)
+        assert n >= 0
         return out[:n].copy()
 
     def linearize(self, converge=True):
@@ -337,6 +348,18 @@ class Lio:
             logs.append(dict(knn=knn.value, n_eff=ne.value, valid=va.value, degenerate=dg.value, sum_abs_res=sr.value,
                              JtJ=JtJ.reshape(6, 6), Jtr=Jtr, dx=dx))
         return logs
+
+    def pass_logs(self):
+        """the passes of the last update (also after frontend_main)"""
+        logs, i = [], 0
+        while True:
+            knn, ne, va, dg = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            sr = C.c_double()
+            JtJ, Jtr, dx = np.zeros(36), np.zeros(6), np.zeros(23)
+            if lib().orc_lio_pass_log(self.h, i, C.byref(knn), C.byref(ne), C.byref(va), C.byref(dg), C.byref(sr), _p(JtJ, C.c_double), _p(Jtr, C.c_double), _p(dx, C.c_double)) < 0:
+                return logs
+            logs.append(dict(knn=knn.value, n_eff=ne.value, valid=va.value, degenerate=dg.value, sum_abs_res=sr.value, JtJ=JtJ.reshape(6, 6), Jtr=Jtr, dx=dx))
+            i += 1
 
     def map_incremental(self):
         return lib().orc_lio_map_incremental(self.h)

@@ -5,14 +5,11 @@
 //   * calc_dist               common_lib.h:231-234
 // Eigen is the copy vendored in the reference tree (slam/thirdparty/fast_gicp/thirdparty/Eigen).  PCL is not
 // installed: oracle/ref_shims/pcl/* define the three point structs and PointCloud the headers name, and
-// common/mapping_types.h (OpenCV, queues -- unrelated to this path) is skipped by pre-defining its include guard.
+// common/mapping_types.h (OpenCV, queues -- unrelated to this path) is replaced by oracle/ref_shims/mapping_types.h.
 // The IKFoM filter (needs Boost.PP / Boost.Bind) and PCL's VoxelGrid are NOT covered: see DESIGN.md.
 // TEST INFRASTRUCTURE ONLY: built into oracle/_ref/libref_harness.so, used by tests/ and tools/make_golden.py.
-#define __MAPPING_TYPES_H
 #include <deque>
 #include <string>
-struct ImuType { double t; };
-struct RTKType { double t; };
 #include <common_lib.h>
 #include <ivox3d/ivox3d.h>
 #include <Eigen/Eigenvalues>

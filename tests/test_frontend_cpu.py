@@ -1,7 +1,7 @@
 """IMU front half on the CPU: the product's host-side forward propagation (csrc/eskf.cpp Eskf::predict, through the
-C ABI, no GPU needed) against the oracle, the oracle's propagation against first principles (the reference's predict
-needs the IKFoM/boost toolchain and cannot be compiled here, so the pin is the physics: a numerical Jacobian of the
-state transition and an analytic trajectory), and the oracle's whole front half tracking a synthetic drive."""
+C ABI, no GPU needed) against the oracle, the oracle's propagation against first principles (a numerical Jacobian of the
+state transition and an analytic trajectory; the pins against the reference's own filter and translation units are
+tests/test_ikfom_vs_ref.py and tests/test_fastlio_vs_ref.py), and the oracle's whole front half tracking a synthetic drive."""
 import numpy as np
 
 
