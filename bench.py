@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--n-az", type=int, default=1875)
     ap.add_argument("--scan-pool", type=int, default=8, help="distinct scans cycled through the steps")
     ap.add_argument("--cpu-scans", type=int, default=320, help="scans of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--ref-scans", type=int, default=160, help="scans of the same workload timed on the reference's own code, oracle/_ref/libref_fastlio_release.so (0 = skip)")
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--streams", type=int, default=0, help="independent scans in flight per GPU (one engine + HIP stream + host thread each, "
                                                               "all reading the one resident map)")
@@ -258,11 +259,47 @@ def main():
                 sg, so = eng.get_state(), o.get_state()
                 worst_dp = max(worst_dp, float(np.linalg.norm(sg[:3] - so[:3])))
                 worst_da = max(worst_da, float(synth.quat_angle(sg[3:7], so[3:7])))
-        cpu = dict(value=round(pts_cpu / t_cpu, 1), unit="points/s", cores=threads, kind="port",
-                   sample=f"{args.cpu_scans} scans of the same workload (oracle/lio_oracle.cpp: VoxelGrid + iVox kNN on {threads} OpenMP threads + "
-                          f"esti_plane + iterated ESKF, rest single-threaded as in the reference), {t_cpu:.1f} s",
-                   ms_per_scan=round(1e3 * t_cpu / args.cpu_scans, 2),
-                   gpu_vs_oracle_pose={"max_dpos_m": worst_dp, "max_drot_rad": worst_da})
+        port = dict(value=round(pts_cpu / t_cpu, 1), unit="points/s", cores=threads, kind="port",
+                    sample=f"{args.cpu_scans} scans of the same workload (oracle/lio_oracle.cpp: VoxelGrid + iVox kNN on {threads} OpenMP threads + "
+                           f"esti_plane + iterated ESKF, rest single-threaded as in the reference), {t_cpu:.1f} s",
+                    ms_per_scan=round(1e3 * t_cpu / args.cpu_scans, 2),
+                    gpu_vs_oracle_pose={"max_dpos_m": worst_dp, "max_drot_rad": worst_da})
+        cpu = port
+        # ---- the reference's OWN code on the same workload: laserMapping.cpp / iVox / IKFoM compiled from /root/reference with the
+        # flags of its CMakeLists.txt (oracle/ref_fastlio.cpp, prebuilt into oracle/_ref by build(); travels to the GPU box) -----
+        import ref_fastlio  # oracle/ref_fastlio.py
+
+        if args.ref_scans > 0 and ref_fastlio.available(release=True):
+            del o
+            ref_fastlio.use_release_build()
+            R = ref_fastlio.RefFastLio()
+            R.set_logging(False)
+            R.map_add(map_pts)
+            R.set_nearby(18)
+            t_ref, pts_ref, ref_dp, ref_da = 0.0, 0, 0.0, 0.0
+            for i in range(args.ref_scans):
+                s = scans[i % len(scans)]
+                parity = i < len(scans)
+                if parity:
+                    R.reset_cache()
+                    eng.scan.reset()
+                c0 = time.perf_counter()
+                rc_ref, sr, _ = R.register(s["raw"], s["guess"], P0)
+                t_ref += time.perf_counter() - c0
+                pts_ref += len(s["raw"])
+                if rc_ref != 3:
+                    raise RuntimeError(f"reference registration returned {rc_ref}")
+                if parity:  # GPU pose vs the reference's pose (neighbour order and dense-algebra rounding differ: tolerance, not bits)
+                    step(i)
+                    sg = eng.get_state()
+                    ref_dp = max(ref_dp, float(np.linalg.norm(sg[:3] - sr[:3])))
+                    ref_da = max(ref_da, float(synth.quat_angle(sg[3:7], sr[3:7])))
+            cpu = dict(value=round(pts_ref / t_ref, 1), unit="points/s", cores=8, kind="reference",
+                       sample=f"{args.ref_scans} scans of the same workload through the reference's own laserMapping.cpp h_share_model + iVox + esekfom "
+                              f"update_iterated_dyn_share_modified (oracle/_ref/libref_fastlio_release.so: -O3 -DNDEBUG, MP_EN with MP_PROC_NUM=8 as its "
+                              f"CMakeLists.txt sets on x86_64; pcl::VoxelGrid replaced by the oracle's restatement), {t_ref:.1f} s",
+                       ms_per_scan=round(1e3 * t_ref / args.ref_scans, 2),
+                       gpu_vs_reference_pose={"max_dpos_m": ref_dp, "max_drot_rad": ref_da}, port=port)
 
     if rank == 0:
         value = total_pts / t_max

@@ -39,7 +39,7 @@ struct HCall {
     double total_residual, HtH[36], Hth[6];
 };
 static std::vector<HCall> g_calls;
-static int g_canonical = 0;
+static int g_canonical = 0, g_log = 1;
 extern "C" void ref_fl_canonical_neighbours();
 // canonical-order mode: a search pass has just refreshed Nearest_Points; order every list canonically, restore the selection flags to
 // what the search branch sets (laserMapping.cpp:850) and linearise again WITHOUT a new search -- the reference's own code on the
@@ -53,6 +53,7 @@ static void canonical_relinearise(state_ikfom& s, esekfom::dyn_share_datastruct<
     d.converge = true;
 }
 static void h_share_logged(state_ikfom& s, esekfom::dyn_share_datastruct<double>& d) {
+    if (!g_log && !g_canonical) { h_share_model(s, d); return; }  // timing runs: the reference's model and nothing else
     HCall c;
     state_to26(s, c.s26);
     c.converge = d.converge ? 1 : 0;
@@ -139,6 +140,59 @@ void ref_fl_canonical_neighbours() {
 }
 
 void ref_fl_set_canonical(int on) { g_canonical = on; }
+void ref_fl_set_logging(int on) { g_log = on; }
+
+// ---- the registration step alone, for bench.py's cpu_baseline ("reference") and full-size parity: a static map, a raw cloud, a prior.
+// What runs is the reference's: IVox::AddPoints, SetNearByType, the block of fastlio_main between the downsample and the filter update
+// (laserMapping.cpp:1204-1222, 1266-1272) and esekf::update_iterated_dyn_share_modified with h_share_model.
+int ref_fl_map_add(const float* xyzi, int n) {
+    PointVector v(n);
+    for (int i = 0; i < n; i++) { v[i].x = xyzi[4 * i]; v[i].y = xyzi[4 * i + 1]; v[i].z = xyzi[4 * i + 2]; v[i].intensity = xyzi[4 * i + 3]; }
+    ivox->AddPoints(v, travel_distance);
+    return (int)ivox->NumValidGrids();
+}
+void ref_fl_set_nearby(int n) {  // 18 / 26 / 74 (fastlio_main switches NEARBY74 -> NEARBY18 one second after the first scan)
+    ivox->SetNearByType(n == 18 ? IVoxType::NearbyType::NEARBY18 : n == 26 ? IVoxType::NearbyType::NEARBY26 : IVoxType::NearbyType::NEARBY74);
+}
+int ref_fl_register(const float* raw_xyzi, int n, const double* s26, const double* P529, double* s26_out, double* P529_out) {
+    feats_undistort->points.resize(n);
+    for (int i = 0; i < n; i++) {
+        PointType& p = feats_undistort->points[i];
+        p.x = raw_xyzi[4 * i]; p.y = raw_xyzi[4 * i + 1]; p.z = raw_xyzi[4 * i + 2]; p.intensity = raw_xyzi[4 * i + 3];
+    }
+    state_ikfom x;
+    x.pos = vect3(Eigen::Vector3d(s26[0], s26[1], s26[2]));
+    x.rot.coeffs() = Eigen::Vector4d(s26[3], s26[4], s26[5], s26[6]);
+    x.offset_R_L_I.coeffs() = Eigen::Vector4d(s26[7], s26[8], s26[9], s26[10]);
+    x.offset_T_L_I = vect3(Eigen::Vector3d(s26[11], s26[12], s26[13]));
+    x.vel = vect3(Eigen::Vector3d(s26[14], s26[15], s26[16]));
+    x.bg = vect3(Eigen::Vector3d(s26[17], s26[18], s26[19]));
+    x.ba = vect3(Eigen::Vector3d(s26[20], s26[21], s26[22]));
+    x.grav.vec = Eigen::Vector3d(s26[23], s26[24], s26[25]);
+    kf.change_x(x);
+    esekfom::esekf<state_ikfom, 12, input_ikfom>::cov P;
+    for (int r = 0; r < 23; r++) for (int c = 0; c < 23; c++) P(r, c) = P529[23 * r + c];
+    kf.change_P(P);
+    state_point = kf.get_x();
+    flg_EKF_inited = true;
+    downSizeFilterSurf.setInputCloud(feats_undistort);
+    downSizeFilterSurf.filter(*feats_down_body);
+    feats_down_size = feats_down_body->points.size();
+    if (feats_down_size < 5) return 2;
+    normvec->resize(feats_down_size);
+    feats_down_world->resize(feats_down_size);
+    Nearest_Points.resize(feats_down_size);
+    double solve_H_time = 0;
+    kf.update_iterated_dyn_share_modified(LASER_POINT_COV, solve_H_time);
+    state_point = kf.get_x();
+    state_to26(state_point, s26_out);
+    if (P529_out) { auto Q = kf.get_P(); for (int r = 0; r < 23; r++) for (int c = 0; c < 23; c++) P529_out[23 * r + c] = Q(r, c); }
+    return 3;
+}
+void ref_fl_reset_cache() {  // fastlio_init's reset of Nearest_Points / point_selected_surf (laserMapping.cpp:1045, 1089)
+    Nearest_Points.clear();
+    memset(point_selected_surf, true, sizeof(point_selected_surf));
+}
 int ref_fl_num_calls() { return (int)g_calls.size(); }
 void ref_fl_clear_calls() { g_calls.clear(); }
 int ref_fl_call(int i, double* s26, int* flags4, double* total_residual, double* HtH36, double* Hth6) {

@@ -8,19 +8,31 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "_ref", "libref_fastlio.so")
+_PATH = os.path.join(_HERE, "_ref", "libref_fastlio.so")  # parity build: scalar Eigen, no FMA contraction, kNN loop on one thread
+_PATH_RELEASE = os.path.join(_HERE, "_ref", "libref_fastlio_release.so")  # the reference's own CMake flags: -O3 -DNDEBUG, MP_EN on 8 threads
 _lib = None
+_which = None
 
 
-def available():
-    return os.path.exists(_PATH)
+def available(release=False):
+    return os.path.exists(_PATH_RELEASE if release else _PATH)
+
+
+def use_release_build():
+    """select the build with the reference's CMake flags (for timing); one build per process -- both define the same globals"""
+    global _which
+    assert _lib is None or _which == _PATH_RELEASE
+    _which = _PATH_RELEASE
 
 
 def lib():
-    global _lib
+    global _lib, _which
     if _lib is None:
         C.CDLL(os.path.join(_HERE, "liblio_oracle.so"), mode=C.RTLD_GLOBAL)  # orc_voxel_downsample for the VoxelGrid shim
-        L = C.CDLL(_PATH)
+        _which = _which or _PATH
+        L = C.CDLL(_which)
+        L.ref_fl_map_add.argtypes = [C.POINTER(C.c_float), C.c_int]
+        L.ref_fl_register.argtypes = [C.POINTER(C.c_float), C.c_int] + [C.POINTER(C.c_double)] * 4
         f64p, f32p, u32p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
         L.ref_fl_init.argtypes = [f64p, f64p, C.c_int, C.c_int, C.c_double, C.c_int]
         L.ref_fl_imu_enqueue.argtypes = [C.c_double, f64p, f64p]
@@ -131,6 +143,27 @@ class RefFastLio:
         if clear:
             lib().ref_fl_clear_calls()
         return out
+
+    def set_logging(self, on):
+        lib().ref_fl_set_logging(int(on))
+
+    def map_add(self, xyzi):
+        p = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        return lib().ref_fl_map_add(_p(p, C.c_float), len(p))
+
+    def set_nearby(self, n):
+        lib().ref_fl_set_nearby(int(n))
+
+    def reset_cache(self):
+        lib().ref_fl_reset_cache()
+
+    def register(self, raw_xyzi, state26, P):
+        """downsample + iterated filter update of one raw cloud against the current map from a given prior (no map insert)"""
+        r = np.ascontiguousarray(raw_xyzi, np.float32).reshape(-1, 4)
+        s, Pi = np.ascontiguousarray(state26, np.float64), np.ascontiguousarray(P, np.float64).reshape(-1)
+        so, Po = np.zeros(26), np.zeros(529)
+        rc = lib().ref_fl_register(_p(r, C.c_float), len(r), _p(s), _p(Pi), _p(so), _p(Po))
+        return rc, so, Po.reshape(23, 23)
 
     def map_voxels(self):
         return lib().ref_fl_map_voxels()
