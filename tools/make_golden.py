@@ -9,7 +9,9 @@ Provenance of every expected output is recorded in the file ("source" field):
                                         faster_lio::IVox compiled from /root/reference, scalar Eigen build)
   * voxelgrid.npz, linearize.npz, update.npz ... the CPU oracle (oracle/lio_oracle.cpp), whose esti_plane and iVox
                                         are themselves checked bit-for-bit against the files above; PCL VoxelGrid
-                                        and the IKFoM update cannot be built here and stay oracle-defined.
+                                        is not in the tree and stays oracle-defined.
+  * ukf.npz ........................... the reference's UKF + pose system (oracle/_ref/libref_ukf.so)
+  * fastlio_drive.npz ................. the reference's whole FastLIO translation units (oracle/_ref/libref_fastlio.so)
 """
 import os
 import sys
@@ -25,8 +27,51 @@ from lsd_amd import synth  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def fastlio_drive():
+    """a 14-scan synthetic drive through the reference's OWN FastLIO translation units (oracle/_ref/libref_fastlio.so), once with
+    its neighbour lists put in canonical order, once untouched; replayed by tests/test_fastlio_golden.py (oracle on the CPU, HIP
+    path on the GPU box, where /root/reference does not exist)"""
+    import ref_fastlio
+    import test_fastlio_vs_ref as tf
+
+    if not ref_fastlio.available():
+        raise SystemExit("oracle/_ref/libref_fastlio.so missing: run `make -C oracle ref` where /root/reference is mounted")
+    scene = synth.Scene(half=100.0, n_boxes=40, seed=1)  # tests/conftest.py `scene`
+    out = {}
+    for name, canonical, distinct in (("canonical", True, True), ("native", False, False)):
+        rec = dict(und6=None, vox=[], init=[], n_eff=[], start=[], odom_e=[])
+
+        def on_scan(k, L, R, o):
+            if k == 6:
+                rec["und6"] = R.undistorted()[:, :4].copy()
+                rec["ds6"] = R.down_body()
+            rec["vox"].append(R.map_voxels())
+            rec["init"].append(R.is_init())
+            rec["n_eff"].append(R.info()["effct_feat_num"])
+            rec["start"].append(o["ref_start"])
+            rec["odom_e"].append(R.odometry()[1])
+
+        _, _, _, res = tf._drive(oracle, scene, 14, canonical=canonical, distinct=distinct, on_scan=on_scan)
+        out[name + "_state"] = np.stack([r["ref"] for r in res])
+        out[name + "_P"] = np.stack([r["ref_P"] for r in res])
+        out[name + "_start"] = np.stack(rec["start"])
+        out[name + "_odom_e"] = np.stack(rec["odom_e"])
+        out[name + "_voxels"] = np.array(rec["vox"])
+        out[name + "_is_init"] = np.array(rec["init"])
+        out[name + "_n_eff"] = np.array(rec["n_eff"])
+        if canonical:  # (the untouched run's cloud is the same set in std::sort's order)
+            out["und6"] = rec["und6"]
+            out["ds6"] = rec["ds6"]
+    np.savez_compressed(os.path.join(OUT, "fastlio_drive.npz"), n_scans=14, **out,
+                        source="laserMapping.cpp + IMU_Processing.hpp + preprocess.cpp + iVox + IKFoM compiled whole from /root/reference "
+                               "(oracle/ref_fastlio.cpp); pcl::VoxelGrid = the oracle's restatement; inputs = tests/test_fastlio_vs_ref.py _drive")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "fastlio":
+        fastlio_drive()
+        return
     if not refmod.available():
         raise SystemExit("oracle/_ref/libref_harness.so missing: run `make -C oracle ref` where /root/reference is mounted")
     from test_oracle_vs_ref import _plane_sets
@@ -121,6 +166,7 @@ def main():
     ops = tu.script(0, 60)
     np.savez_compressed(os.path.join(OUT, "ukf.npz"), seed=0, n=60, trace=tu.run_reference(ops).astype(np.float32),
                         source="kkl/alg/unscented_kalman_filter.hpp + hdl_localization/pose_system.hpp compiled from /root/reference (oracle/ref_ukf.cpp)")
+    fastlio_drive()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
