@@ -102,6 +102,14 @@ int lio_scan_set_device(lio_scan*, const void* d_body_xyzi, uint32_t n_raw);    
 /* pcl::VoxelGrid<PointType>::filter with setLeafSize(leaf, leaf, leaf) (PCL 1.9.1 voxel_grid.hpp,
  * called at src/laserMapping.cpp:1206-1207): centroid of every occupied voxel, ascending voxel index.
  * Asynchronous; *n_ds (may be NULL) is only filled when sync != 0. */
+/* undistortPoints(const Eigen::Matrix4f& delta_pose, PointCloudAttrPtr&, double scan_period)   slam/common/slam_utils.cpp:163-191,
+ * called by the localisation mode before the downsample (hdl_localization_nodelet.cpp:224-227) with delta_pose = start^-1 * stop of the
+ * filter's prediction: constant-velocity motion compensation of the uploaded cloud, p' = Exp(r * log(delta)) p with r = stamp / period,
+ * all in f32 as there.  delta_pose is row-major; stamp_us[i] is PointAttr::stamp (us from the scan start), a host array
+ * (stamps_on_device = 0) or a device array.  Runs on the scan's stream; the result replaces the scan's raw cloud (a caller-owned
+ * device cloud given by lio_scan_set_device is not written).  lio_scan_download_raw returns the point count. */
+int lio_scan_undistort_delta(lio_scan*, const uint32_t* stamp_us, int stamps_on_device, const float delta_pose[16], double scan_period);
+int lio_scan_download_raw(lio_scan*, float* out_xyzi, uint32_t cap);
 int lio_scan_voxel_downsample(lio_scan*, float leaf, int sync, uint32_t* n_ds);
 /* bypass the filter: use these points as feats_down_body (tests, staged pipelines) */
 int lio_scan_set_ds(lio_scan*, const float* ds_body_xyzi, uint32_t n_ds);

@@ -462,6 +462,87 @@ int lio_scan_set_device(lio_scan* s, const void* d_body, uint32_t n_raw) {
     return LIO_OK;
 }
 
+// ---- constant-velocity motion compensation of the localisation mode (slam_utils.cpp:163-191) ----
+// Host part, once per scan, in f32 exactly as Eigen evaluates it there: Quaternionf(delta.block<3,3>(0,0)) (Shoemake, Quaternion.h
+// quaternionbase_assign_impl<Other,3,3>), AngleAxisf(quaternion) (AngleAxis.h:170-190, with stableNorm below epsilon).
+static void delta_pose_args(const float D[16], double scan_period, DeltaArgs& A) {
+    const float m[3][3] = {{D[0], D[1], D[2]}, {D[4], D[5], D[6]}, {D[8], D[9], D[10]}};
+    float q[4];  // x y z w
+    float t = m[0][0] + (m[1][1] + m[2][2]);
+    if (t > 0.f) {
+        t = sqrtf(t + 1.0f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (m[2][1] - m[1][2]) * t;
+        q[1] = (m[0][2] - m[2][0]) * t;
+        q[2] = (m[1][0] - m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrtf(m[i][i] - m[j][j] - m[k][k] + 1.0f);
+        q[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[3] = (m[k][j] - m[j][k]) * t;
+        q[j] = (m[j][i] + m[i][j]) * t;
+        q[k] = (m[k][i] + m[i][k]) * t;
+    }
+    float n = sqrtf(q[0] * q[0] + (q[1] * q[1] + q[2] * q[2]));
+    if (n < 1.1920929e-07f) {  // stableNorm (StableNorm.h:18-50 on one 3-segment): scaled by the largest |coefficient|, summed in sequence
+        const float mx = fmaxf(fabsf(q[0]), fmaxf(fabsf(q[1]), fabsf(q[2])));
+        float scale = 0.f, inv = 1.f, ssq = 0.f;
+        if (mx > scale) {
+            const float tmp = 1.f / mx;
+            if (tmp > 3.4028235e+38f) { inv = 3.4028235e+38f; scale = 1.f / inv; }
+            else { scale = mx; inv = tmp; }
+        }
+        if (scale > 0.f) {
+            const float a = q[0] * inv, b = q[1] * inv, c2 = q[2] * inv;
+            ssq = (a * a + b * b) + c2 * c2;
+        }
+        n = scale * sqrtf(ssq);
+    }
+    float angle = 0.f, axis[3] = {1.f, 0.f, 0.f};
+    if (n != 0.f) {
+        angle = 2.f * atan2f(n, fabsf(q[3]));
+        if (q[3] < 0.f) n = -n;
+        for (int i = 0; i < 3; i++) axis[i] = q[i] / n;
+    }
+    for (int i = 0; i < 3; i++) {
+        A.t[i] = D[4 * i + 3];
+        A.aa[i] = angle * axis[i];
+    }
+    A.scan_period = scan_period;
+}
+
+int lio_scan_undistort_delta(lio_scan* s, const uint32_t* stamp_us, int stamps_on_device, const float delta_pose[16], double scan_period) {
+    if (!s || !delta_pose || (!stamp_us && s->n_raw)) return LIO_E_INVALID;
+    if (s->n_raw == 0) return LIO_OK;
+    hipSetDevice(s->device);
+    const uint32_t* d_stamp = stamp_us;
+    if (!stamps_on_device) {  // the key buffer of the downsample is free until lio_scan_voxel_downsample runs (same stream)
+        LIO_HIP_TRY(hipMemcpyAsync(s->keys_b, stamp_us, (size_t)s->n_raw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        d_stamp = s->keys_b;
+    }
+    DeltaArgs A;
+    delta_pose_args(delta_pose, scan_period, A);
+    const int rc = undistort_delta_launch(s->stream, s->raw, d_stamp, s->n_raw, s->raw_own, A);  // in place when the scan owns its cloud
+    if (rc != LIO_OK) return rc;
+    s->raw = s->raw_own;
+    if (!stamps_on_device) LIO_HIP_TRY(hipStreamSynchronize(s->stream));  // the caller's stamp array may go away
+    return LIO_OK;
+}
+
+int lio_scan_download_raw(lio_scan* s, float* out_xyzi, uint32_t cap) {
+    if (!s || !out_xyzi) return LIO_E_INVALID;
+    if (s->n_raw > cap) { set_error("raw cloud of %u points exceeds cap %u", s->n_raw, cap); return LIO_E_CAPACITY; }
+    hipSetDevice(s->device);
+    if (s->n_raw) LIO_HIP_TRY(hipMemcpyAsync(out_xyzi, s->raw, (size_t)s->n_raw * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    return (int)s->n_raw;
+}
+
 static int scan_sync_dev(lio_scan* s) {
     LIO_HIP_TRY(hipMemcpyAsync(s->host_dev, s->dev, sizeof(ScanDev), hipMemcpyDeviceToHost, s->stream));
     LIO_HIP_TRY(hipStreamSynchronize(s->stream));

@@ -184,6 +184,12 @@ struct UndistortArgs {
     double blind2;
     int n_poses, filter_num, undistort;
 };
+struct DeltaArgs {  // undistortPoints(delta_pose, ...): delta translation, angle * axis of the delta rotation (f32), scan period
+    float t[3];
+    float aa[3];
+    double scan_period;
+};
+int undistort_delta_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const DeltaArgs& args);
 int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const ImuPoseDev* d_poses,
                      const UndistortArgs& args, unsigned long long* d_block_min /* ceil(n / 256) words of scratch */);
 

@@ -192,7 +192,50 @@ __global__ void __launch_bounds__(64) undistort_first_kernel(float4* out, const 
     out[i] = p;
 }
 
+// ---- localisation mode: constant-velocity compensation, undistortPoints(delta_pose, points, scan_period) of
+// slam/common/slam_utils.cpp:163-191.  Everything is f32 as in the reference (Eigen Matrix<float,6,1> / AngleAxisf / Quaternionf /
+// Affine3f, pcl::transformPoint); sums follow Eigen's fixed-size orders x0 + (x1 + x2) and (x0 + x1) + (x2 + x3).  sin / cos of the half angle are evaluated in
+// f64 and rounded to f32, which is what a correctly rounded sinf / cosf returns except within ~1e-8 of a rounding boundary.
+__global__ __launch_bounds__(kThreads) void undistort_delta_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ stamp_us, uint32_t n,
+                                                                   float4* __restrict__ out, DeltaArgs A) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    const float ratio = (float)(((double)stamp_us[i] / 1000000.0) / A.scan_period);  // float t_diff_ratio = (stamp / 1000000.0) / scan_period
+    const float tx = ratio * A.t[0], ty = ratio * A.t[1], tz = ratio * A.t[2];
+    const float wx = ratio * A.aa[0], wy = ratio * A.aa[1], wz = ratio * A.aa[2];
+    const float norm = sqrtf(wx * wx + (wy * wy + wz * wz));
+    float r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
+    if (!((double)norm < 1e-8)) {
+        const float ax = wx / norm, ay = wy / norm, az = wz / norm;
+        const float ha = 0.5f * norm;
+        const float w = (float)cos((double)ha), sh = (float)sin((double)ha);
+        const float x = sh * ax, y = sh * ay, z = sh * az;
+        // QuaternionBase::toRotationMatrix
+        const float t2x = 2.f * x, t2y = 2.f * y, t2z = 2.f * z;
+        const float twx = t2x * w, twy = t2y * w, twz = t2z * w;
+        const float txx = t2x * x, txy = t2y * x, txz = t2z * x;
+        const float tyy = t2y * y, tyz = t2z * y, tzz = t2z * z;
+        r00 = 1.f - (tyy + tzz); r01 = txy - twz; r02 = txz + twy;
+        r10 = txy + twz; r11 = 1.f - (txx + tzz); r12 = tyz - twx;
+        r20 = txz - twy; r21 = tyz + twx; r22 = 1.f - (txx + tyy);
+    }
+    // transform * v = [R t] [v; 1]: four terms in Eigen's fixed-size order (x0 + x1) + (x2 + x3)
+    float4 o = p;
+    o.x = (r00 * p.x + r01 * p.y) + (r02 * p.z + tx);
+    o.y = (r10 * p.x + r11 * p.y) + (r12 * p.z + ty);
+    o.z = (r20 * p.x + r21 * p.y) + (r22 * p.z + tz);
+    out[i] = o;
+}
+
 }  // namespace
+
+int undistort_delta_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const DeltaArgs& args) {
+    if (n == 0) return LIO_OK;
+    hipLaunchKernelGGL(undistort_delta_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, d_in, d_stamp_us, n, d_out, args);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
 
 int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const ImuPoseDev* d_poses,
                      const UndistortArgs& args, unsigned long long* d_block_min) {

@@ -140,6 +140,24 @@ class Scan:
     def set_device(self, dptr, n):
         check(lib().lio_scan_set_device(self.h, C.c_void_p(dptr), n), "scan set_device")
 
+    def undistort_delta(self, stamp_us, delta_pose, scan_period=0.1, on_device=False):
+        """undistortPoints(delta_pose, points, scan_period) of the localisation mode (slam_utils.cpp:163-191) on the uploaded cloud;
+        stamp_us: host uint32 array, or a device pointer with on_device=True"""
+        d = np.ascontiguousarray(delta_pose, np.float32).reshape(16)
+        if on_device:
+            sp = C.c_void_p(int(stamp_us))
+        else:
+            self._stamps = np.ascontiguousarray(stamp_us, np.uint32)
+            sp = C.c_void_p(self._stamps.ctypes.data)
+        check(lib().lio_scan_undistort_delta(self.h, sp, int(on_device), d.ctypes.data_as(C.POINTER(C.c_float)), float(scan_period)), "undistort_delta")
+
+    def download_raw(self, cap=1 << 18):
+        out = np.zeros((cap, 4), np.float32)
+        n = lib().lio_scan_download_raw(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), cap)
+        if n < 0:
+            check(n, "download_raw")
+        return out[:n].copy()
+
     def voxel_downsample(self, leaf=0.5, sync=True):
         n = C.c_uint32(0)
         check(lib().lio_scan_voxel_downsample(self.h, float(leaf), int(sync), C.byref(n)), "voxel downsample")

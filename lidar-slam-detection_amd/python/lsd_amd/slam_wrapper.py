@@ -18,7 +18,7 @@ import numpy as np
 
 from . import capi, lio
 
-_ANG2RAD = np.pi / 180.0
+_ANG2RAD = 0.01745329251994  # the reference's truncated constant (slam_utils.cpp:88), not pi / 180
 _state = None
 
 

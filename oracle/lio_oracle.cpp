@@ -52,6 +52,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <list>
 #include <unordered_map>
 #include <vector>
@@ -1730,6 +1731,73 @@ void orc_lio_get_odometry(void* h, double* s26_start, double* s26_end) {
     Lio* l = static_cast<Lio*>(h);
     state_to(l->odom_start, s26_start);
     state_to(l->odom_end, s26_end);
+}
+
+// ---- undistortPoints(delta_pose, points, scan_period), slam/common/slam_utils.cpp:163-191 (localisation mode), f32 throughout.
+// Per scan: Quaternionf(delta.block<3,3>(0,0)) (Eigen Quaternion.h quaternionbase_assign_impl<Other,3,3>), AngleAxisf(q) (AngleAxis.h:170-190;
+// stableNorm below epsilon: StableNorm.h:18-50 on one dynamic 3-segment, summed in sequence).  Per point: r = (stamp / 1e6) / period as float,
+// log = r * [t; angle * axis], rotation = Quaternionf(AngleAxisf(|w|, w / |w|)).toRotationMatrix(), p' = [R t] [p; 1] (Transform * vector is the
+// 3x4 affine part times the homogeneous vector: fixed-size sum of four terms (x0 + x1) + (x2 + x3); pcl::transformPoint of PCL 1.9.1).
+void orc_undistort_delta(const float* D, float* xyzi, const uint32_t* stamp_us, int n, double scan_period) {
+    const float m[3][3] = {{D[0], D[1], D[2]}, {D[4], D[5], D[6]}, {D[8], D[9], D[10]}};
+    float q[4];
+    float t = m[0][0] + (m[1][1] + m[2][2]);
+    if (t > 0.f) {
+        t = std::sqrt(t + 1.0f); q[3] = 0.5f * t; t = 0.5f / t;
+        q[0] = (m[2][1] - m[1][2]) * t; q[1] = (m[0][2] - m[2][0]) * t; q[2] = (m[1][0] - m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0f); q[i] = 0.5f * t; t = 0.5f / t;
+        q[3] = (m[k][j] - m[j][k]) * t; q[j] = (m[j][i] + m[i][j]) * t; q[k] = (m[k][i] + m[i][k]) * t;
+    }
+    float nrm = std::sqrt(q[0] * q[0] + (q[1] * q[1] + q[2] * q[2]));
+    if (nrm < std::numeric_limits<float>::epsilon()) {
+        const float mx = std::max(std::fabs(q[0]), std::max(std::fabs(q[1]), std::fabs(q[2])));
+        float scale = 0.f, inv = 1.f, ssq = 0.f;
+        if (mx > scale) {
+            const float tmp = 1.f / mx;
+            if (tmp > std::numeric_limits<float>::max()) { inv = std::numeric_limits<float>::max(); scale = 1.f / inv; }
+            else { scale = mx; inv = tmp; }
+        }
+        if (scale > 0.f) { const float a = q[0] * inv, b = q[1] * inv, c = q[2] * inv; ssq = (a * a + b * b) + c * c; }
+        nrm = scale * std::sqrt(ssq);
+    }
+    float angle = 0.f, axis[3] = {1.f, 0.f, 0.f};
+    if (nrm != 0.f) {
+        angle = 2.f * std::atan2(nrm, std::fabs(q[3]));
+        if (q[3] < 0.f) nrm = -nrm;
+        for (int i = 0; i < 3; i++) axis[i] = q[i] / nrm;
+    }
+    const float tr[3] = {D[3], D[7], D[11]};
+    const float aa[3] = {angle * axis[0], angle * axis[1], angle * axis[2]};
+    for (int i = 0; i < n; i++) {
+        float* p = xyzi + 4 * (size_t)i;
+        const float r = (float)(((double)stamp_us[i] / 1000000.0) / scan_period);
+        const float tx = r * tr[0], ty = r * tr[1], tz = r * tr[2];
+        const float wx = r * aa[0], wy = r * aa[1], wz = r * aa[2];
+        const float norm = std::sqrt(wx * wx + (wy * wy + wz * wz));
+        float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (!((double)norm < 1e-8)) {
+            const float ax = wx / norm, ay = wy / norm, az = wz / norm;
+            const float ha = 0.5f * norm;
+            const float w = std::cos(ha), sh = std::sin(ha);
+            const float x = sh * ax, y = sh * ay, z = sh * az;
+            const float t2x = 2.f * x, t2y = 2.f * y, t2z = 2.f * z;
+            const float twx = t2x * w, twy = t2y * w, twz = t2z * w;
+            const float txx = t2x * x, txy = t2y * x, txz = t2z * x;
+            const float tyy = t2y * y, tyz = t2z * y, tzz = t2z * z;
+            R[0] = 1.f - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+            R[3] = txy + twz; R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+            R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.f - (txx + tyy);
+        }
+        const float px = p[0], py = p[1], pz = p[2];
+        p[0] = (R[0] * px + R[1] * py) + (R[2] * pz + tx);
+        p[1] = (R[3] * px + R[4] * py) + (R[5] * pz + ty);
+        p[2] = (R[6] * px + R[7] * py) + (R[8] * pz + tz);
+    }
 }
 
 void orc_so3_Exp(const double* w3, double dt, double* R9) { so3_Exp_rodrigues(V3{{w3[0], w3[1], w3[2]}}, dt, R9); }

@@ -85,6 +85,7 @@ def lib():
     L.orc_lio_get_undistorted.restype = C.c_int
     L.orc_lio_get_odometry.argtypes = [C.c_void_p, f64p, f64p]
     L.orc_lio_is_init.argtypes = [C.c_void_p]
+    L.orc_undistort_delta.argtypes = [f32p, f32p, C.POINTER(C.c_uint32), C.c_int, C.c_double]
     L.orc_lio_get_ds_world.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_kf_update_cb.argtypes = [f64p, f64p, C.c_double, C.c_int, MEAS_FN, C.c_void_p, C.c_int, f64p, f64p]
     L.orc_so3_Exp.argtypes = [f64p, C.c_double, f64p]
@@ -375,6 +376,14 @@ class Lio:
     @property
     def is_degenerate(self):
         return bool(lib().orc_lio_is_degenerate(self.h))
+
+
+def undistort_delta(xyzi, stamp_us, delta_pose, scan_period=0.1):
+    """undistortPoints(delta_pose, points, scan_period), slam_utils.cpp:163-191"""
+    p = np.array(xyzi, np.float32).reshape(-1, 4).copy()
+    st, d = np.ascontiguousarray(stamp_us, np.uint32), np.ascontiguousarray(delta_pose, np.float32).reshape(16)
+    lib().orc_undistort_delta(_p(d, C.c_float), _p(p, C.c_float), _p(st, C.c_uint32), len(p), float(scan_period))
+    return p
 
 
 def state_boxplus(s, d):

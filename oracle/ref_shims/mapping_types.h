@@ -7,8 +7,10 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <map>
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
+#include <opencv2/opencv.hpp>
 
 typedef pcl::PointXYZI Point;
 typedef pcl::PointCloud<Point> PointCloud;
@@ -36,6 +38,14 @@ struct RTKType {
     std::string sensor, state;
     int dimension = 2;
     double precision = 100.0;
+    Eigen::Matrix4d T = Eigen::Matrix4d::Identity();
+};
+
+struct PoseType {
+    double latitude = 0, longitude = 0, altitude = 0, heading = 0, pitch = 0, roll = 0;
+    int status = 0;
+    std::string state;
+    uint64_t timestamp = 0;
     Eigen::Matrix4d T = Eigen::Matrix4d::Identity();
 };
 

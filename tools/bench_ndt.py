@@ -73,6 +73,22 @@ def main():
                           "registered_points_per_s": round(120000 * args.scans / dt, 1), "n_ds_avg": float(np.mean(nds)),
                           "lm_iterations_avg": float(np.mean(its)), "pos_err_m_median": float(np.median(errs)), "leaf": args.leaf}), flush=True)
         n.close()
+    # the step before the matcher in the localisation mode: constant-velocity motion compensation (slam_utils.cpp:163-191), stamps resident
+    d_raw, n_raw, _, _ = scans[0]
+    d_st = torch.from_numpy(rng.integers(0, 100000, n_raw).astype(np.uint32).view(np.int32)).to(dev)
+    D = np.eye(4, dtype=np.float32)
+    D[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0.002, -0.001, 0.03])).astype(np.float32)
+    D[:3, 3] = [1.2, 0.05, 0.0]
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(200):
+            s.set_device(d_raw.data_ptr(), n_raw)
+            s.undistort_delta(d_st.data_ptr(), D, 0.1, on_device=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(json.dumps({"case": "undistort_delta", "points": n_raw, "us_per_scan": round(1e6 * dt / 200, 2),
+                      "algorithmic_GBps": round(n_raw * 36 / (dt / 200) / 1e9, 1)}), flush=True)
 
 
 if __name__ == "__main__":

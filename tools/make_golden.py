@@ -12,6 +12,7 @@ Provenance of every expected output is recorded in the file ("source" field):
                                         is not in the tree and stays oracle-defined.
   * ukf.npz ........................... the reference's UKF + pose system (oracle/_ref/libref_ukf.so)
   * fastlio_drive.npz ................. the reference's whole FastLIO translation units (oracle/_ref/libref_fastlio.so)
+  * undistort_delta.npz ............... the reference's slam_utils.cpp undistortPoints (oracle/_ref/libref_slam_utils.so)
 """
 import os
 import sys
@@ -67,10 +68,40 @@ def fastlio_drive():
                                "(oracle/ref_fastlio.cpp); pcl::VoxelGrid = the oracle's restatement; inputs = tests/test_fastlio_vs_ref.py _drive")
 
 
+def undistort_delta_cases(rng, n=3000):
+    """inputs of the constant-velocity compensation: rotations from 3 rad down to exactly none, with and without translation"""
+    pts = (rng.normal(size=(n, 4)) * 30).astype(np.float32)
+    pts[7, :3] = np.nan
+    st = rng.integers(0, 100001, n).astype(np.uint32)
+    st[:5] = [0, 100000, 1, 99999, 50000]
+    deltas = []
+    for case, scale in enumerate([3.0, 1e-1, 1e-3, 1e-6, 1e-8, 0.0, 2.5, 1e-2]):
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec(rng.normal(size=3) * scale)).astype(np.float32)
+        T[:3, 3] = rng.normal(size=3) * (1.0 if case % 3 else 0.0)
+        deltas.append(T)
+    return pts, st, np.stack(deltas)
+
+
+def slam_utils():
+    """undistortPoints(delta_pose, ...) through the reference's OWN slam_utils.cpp (oracle/_ref/libref_slam_utils.so)"""
+    import ref_slam_utils as rs
+
+    if not rs.available():
+        raise SystemExit("oracle/_ref/libref_slam_utils.so missing: run `make -C oracle ref` where /root/reference is mounted")
+    pts, st, deltas = undistort_delta_cases(np.random.default_rng(5))
+    out = np.stack([rs.undistort_delta(pts, st, D, 0.1) for D in deltas])
+    np.savez_compressed(os.path.join(OUT, "undistort_delta.npz"), points=pts, stamp_us=st, deltas=deltas, scan_period=0.1, out=out,
+                        source="slam/common/slam_utils.cpp:163-191 compiled whole from /root/reference (oracle/ref_slam_utils.cpp); pcl::transformPoint = PCL 1.9.1's one-liner")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "fastlio":
         fastlio_drive()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "slam_utils":
+        slam_utils()
         return
     if not refmod.available():
         raise SystemExit("oracle/_ref/libref_harness.so missing: run `make -C oracle ref` where /root/reference is mounted")
@@ -167,6 +198,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "ukf.npz"), seed=0, n=60, trace=tu.run_reference(ops).astype(np.float32),
                         source="kkl/alg/unscented_kalman_filter.hpp + hdl_localization/pose_system.hpp compiled from /root/reference (oracle/ref_ukf.cpp)")
     fastlio_drive()
+    slam_utils()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
