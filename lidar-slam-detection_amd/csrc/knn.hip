@@ -33,10 +33,12 @@ namespace lio {
 #ifndef LIO_KNN_WAVES
 #define LIO_KNN_WAVES 1
 #endif
+#ifndef LIO_KNN_PRUNE
+#define LIO_KNN_PRUNE 1  // distance-ordered sweep with exact pruning of stencil voxels that cannot hold one of the five nearest
+#endif
 constexpr int kG = LIO_KNN_G;          // lanes per query
 constexpr int kU = LIO_KNN_U;          // voxels swept together (loads in flight per lane), multiple of 4
 constexpr int kGPB = 256 / kG;         // queries per workgroup
-constexpr unsigned long long kNoKey = 0xFFFFFFFFFFFFFFFFull;
 
 __device__ inline void body_to_world(const PoseArgs& P, const float4 pb, float4& pw) {
     // laserMapping.cpp:831-836: p_global = rot * (offset_R_L_I * p_body + offset_T_L_I) + pos, in double, stored float.
@@ -57,12 +59,134 @@ __device__ inline void body_to_world(const PoseArgs& P, const float4 pb, float4&
     pw.w = pb.w;
 }
 
+// Reductions over the kG lanes of a query group.  With kG = 16 a group is exactly one DPP row: four v_min / v_add with a row-rotate
+// modifier (row_ror:8, 4, 2, 1) leave the result in every lane, no LDS crossbar (ds_bpermute) round trips -- the kernel used to issue
+// ~100 of those per query, each a dependent ~100-cycle wait.
+template <int CTRL>
+__device__ inline uint32_t dpp_row(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ inline uint32_t group_min32(uint32_t v) {
+    if constexpr (kG == 16) {
+        v = min(v, dpp_row<0x128>(v));
+        v = min(v, dpp_row<0x124>(v));
+        v = min(v, dpp_row<0x122>(v));
+        v = min(v, dpp_row<0x121>(v));
+    } else {
+#pragma unroll
+        for (int off = kG / 2; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, kG));
+    }
+    return v;
+}
+__device__ inline uint32_t group_sum32(uint32_t v) {
+    if constexpr (kG == 16) {
+        v += dpp_row<0x128>(v);
+        v += dpp_row<0x124>(v);
+        v += dpp_row<0x122>(v);
+        v += dpp_row<0x121>(v);
+    } else {
+#pragma unroll
+        for (int off = kG / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kG);
+    }
+    return v;
+}
+
 // the occupied voxels of one query's stencil, compacted: 16-B aligned so that four descriptors come back from one
 // ds_read_b128; entries nhit .. nhit+3 are zero-filled (count 0) so that batches of four need no bounds test
 struct __attribute__((aligned(16))) GroupLds {
     uint32_t v_ptr[kMaxStencil + kU + 1];
     uint32_t v_cnt[kMaxStencil + kU + 1];
+    uint32_t v_dmin[kMaxStencil + kU + 1];  // bits of a lower bound of the squared distance from the query to any point of the voxel
 };
+
+// A voxel with key c holds points with |p_a * inv_res - c_a| <= 0.5 evaluated in f32 (pos2grid): |p_a - c_a * res| <= res / 2 up to
+// rounding of the product (6e-8 |p_a|).  The bound below shrinks the box side by 0.5 mm + 1e-6 |q_a| per axis (covers that rounding
+// and the one of q_a - c_a * res up to |q| ~ 10 km) and the sum by 1e-5 (covers the f32 evaluation of the candidates' own d2), so it
+// never exceeds the d2 the sweep would compute for a point of that voxel.
+__device__ inline uint32_t cell_min_d2_bits(float qx, float qy, float qz, int cx, int cy, int cz, float res) {
+    const float h = 0.5f * res;
+    const float ax = fmaxf(fabsf(qx - (float)cx * res) - h - (5e-4f + 1e-6f * fabsf(qx)), 0.f);
+    const float ay = fmaxf(fabsf(qy - (float)cy * res) - h - (5e-4f + 1e-6f * fabsf(qy)), 0.f);
+    const float az = fmaxf(fabsf(qz - (float)cz * res) - h - (5e-4f + 1e-6f * fabsf(qz)), 0.f);
+    return __float_as_uint((ax * ax + (ay * ay + az * az)) * 0.99999f);
+}
+
+// probe_stencil for stencils of at most 2 * kG cells (NEARBY6 / 18 / 26) with the hits BUCKETED by that lower bound: bucket 0 below
+// (res / 4)^2, bucket 1 below (res / 2)^2, bucket 2 the rest.  On return the list in g is bucket 0, then 1, then 2 (order inside a
+// bucket = stencil order), n0 / n01 are the list positions where buckets 1 and 2 start.
+template <int KM>
+__device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table, uint32_t mask, const StencilArgs& st, bool active, float4 pw,
+                                                  float res, int kx, int ky, int kz, int gl, int lane, unsigned long long gmask, GroupLds& g,
+                                                  uint32_t& nhit_out, uint32_t& n0_out, uint32_t& n01_out) {
+    static_assert(KM <= 2, "bucketed probe: at most 2 cells per lane");
+    uint4 raw[KM];
+    BrickProbe bp[KM];
+    unsigned long long want[KM];
+    uint32_t dmin[KM];
+#pragma unroll
+    for (int k = 0; k < KM; k++) {
+        const int s = k * kG + gl;
+        want[k] = kEmptyKey;
+        raw[k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+        bp[k] = BrickProbe{0u, 1u, 0u};
+        dmin[k] = 0xFFFFFFFFu;
+        if (active && s < st.n) {
+            const int cx = kx + st.off[s][0], cy = ky + st.off[s][1], cz = kz + st.off[s][2];
+            want[k] = pack_key(cx, cy, cz);
+            bp[k] = brick_probe(cx, cy, cz);
+            raw[k] = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[k], mask)]);
+            dmin[k] = cell_min_d2_bits(pw.x, pw.y, pw.z, cx, cy, cz, res);
+        }
+    }
+    const uint32_t b1 = __float_as_uint(0.0625f * res * res), b2 = __float_as_uint(0.25f * res * res);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t ptr[KM], cnt[KM], total = 0;
+    int bucket[KM];
+    unsigned long long mb[KM][3];
+#pragma unroll
+    for (int k = 0; k < KM; k++) {
+        ptr[k] = 0; cnt[k] = 0;
+        if (want[k] != kEmptyKey) {
+            uint4 r = raw[k];
+            for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
+                const unsigned long long kk = ((unsigned long long)r.y << 32) | r.x;
+                if (kk == want[k]) { ptr[k] = r.z; cnt[k] = r.w; break; }
+                if (kk == kEmptyKey) break;
+                brick_next(bp[k]);
+                r = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[k], mask)]);
+            }
+        }
+        const bool hit = cnt[k] > 0;
+        bucket[k] = dmin[k] < b1 ? 0 : (dmin[k] < b2 ? 1 : 2);
+#pragma unroll
+        for (int b = 0; b < 3; b++) mb[k][b] = __ballot(hit && bucket[k] == b) & gmask;
+        total += group_sum32(cnt[k]);
+    }
+    uint32_t nb[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < KM; k++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) nb[b] += __popcll(mb[k][b]);
+    const uint32_t base[3] = {0, nb[0], nb[0] + nb[1]};
+    const uint32_t nhit = nb[0] + nb[1] + nb[2];
+#pragma unroll
+    for (int k = 0; k < KM; k++) {
+        if (cnt[k] > 0) {
+            uint32_t at = base[bucket[k]];
+#pragma unroll
+            for (int kk = 0; kk < k; kk++) at += __popcll(mb[kk][bucket[k]]);
+            at += __popcll(mb[k][bucket[k]] & below);
+            g.v_ptr[at] = ptr[k];
+            g.v_cnt[at] = cnt[k];
+            g.v_dmin[at] = dmin[k];
+        }
+    }
+    if (gl < kU) { g.v_ptr[nhit + gl] = 0; g.v_cnt[nhit + gl] = 0; g.v_dmin[nhit + gl] = 0xFFFFFFFFu; }
+    nhit_out = nhit;
+    n0_out = base[1];
+    n01_out = base[2];
+    return total;
+}
 
 // probe the stencil of the group's query; on return the hit voxels are compacted in g (ptr, cnt) and
 // the total candidate count is returned.  All lanes of the wave must call this (ballots inside).
@@ -144,6 +268,20 @@ __device__ inline unsigned long long group_min64(unsigned long long v) {
     return v;
 }
 
+// An upper bound of the squared distance of the query's fifth nearest candidate, from what the lanes hold so far: any lane's own fifth
+// (its five entries are five candidates at most that far), and the fifth smallest of the lanes' nearest (five candidates in five
+// lanes; equal values are counted once, which can only loosen the bound).  0xFFFFFFFF while fewer than five candidates are known.
+__device__ inline uint32_t fifth_bound(uint32_t d0, uint32_t d4) {
+    uint32_t t = group_min32(d4);
+    uint32_t v = d0, m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        m = group_min32(v);
+        if (v == m) v = 0xFFFFFFFFu;
+    }
+    return min(t, m);
+}
+
 // MODE 0: queries are body-frame ds points of a scan (transformed here, world point stored);
 // MODE 1: queries are world-frame points (diagnostic lio_map_knn).
 template <int KM, int MODE>
@@ -160,6 +298,9 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
     const uint32_t n = sd ? sd->n_ds : n_host;
     const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
     unsigned long long visited = 0;
+    const float res = 1.0f / inv_res;
+    const uint32_t b1_bits = __float_as_uint(0.0625f * res * res), b2_bits = __float_as_uint(0.25f * res * res);
+    (void)b1_bits; (void)b2_bits;
 
     // XCD-aware workgroup -> query mapping: the dispatcher deals workgroups round-robin to the 8 XCDs (b % 8), each
     // with its own L2.  Consecutive queries are spatial neighbours that share most of their candidate voxels, so
@@ -183,7 +324,10 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
         int kx = 0, ky = 0, kz = 0;
         pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
         uint32_t nhit = 0;
-        const uint32_t total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
+        constexpr bool kPrune = LIO_KNN_PRUNE && KM <= 2;
+        uint32_t n0 = 0, n01 = 0, total;
+        if constexpr (kPrune) total = probe_stencil_bucketed<KM>(table, mask, st, active, pw, res, kx, ky, kz, gl, lane, gmask, g, nhit, n0, n01);
+        else total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
         group_lds_sync();
         // every lane keeps its own ascending top-5 as (d2 bits, pool index) pairs, ordered by d2 alone: candidates with an
         // equal d2 keep their arrival order -- any such pair that reaches the global top-6 is an exact tie and the query
@@ -198,10 +342,28 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
         for (uint32_t s0 = 0; s0 < nhit; s0 += kU) {
             uint32_t ptr4[kU], cnt4[kU];
             uint32_t cmax = 0;
+            uint32_t bound5 = 0xFFFFFFFFu;
+            if constexpr (kPrune) {
+                // exact pruning: a voxel whose nearest possible point is farther than five candidates already seen cannot change the
+                // five nearest (nor tie with the fifth: the comparison is strict); the list is in distance buckets, so once the bound
+                // is below the floor of the bucket the next batch starts in, nothing that follows can matter either
+                if (s0 > 0) {
+                    bound5 = fifth_bound(d0, d4);
+                    const uint32_t floor_bits = s0 < n0 ? 0u : (s0 < n01 ? b1_bits : b2_bits);
+                    if (bound5 < floor_bits) break;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < kU; u += 4) {
                 const uint4 vp = *reinterpret_cast<const uint4*>(&g.v_ptr[s0 + u]);
-                const uint4 vc = *reinterpret_cast<const uint4*>(&g.v_cnt[s0 + u]);
+                uint4 vc = *reinterpret_cast<const uint4*>(&g.v_cnt[s0 + u]);
+                if constexpr (kPrune) {
+                    const uint4 vd = *reinterpret_cast<const uint4*>(&g.v_dmin[s0 + u]);
+                    if (vd.x > bound5) vc.x = 0;
+                    if (vd.y > bound5) vc.y = 0;
+                    if (vd.z > bound5) vc.z = 0;
+                    if (vd.w > bound5) vc.w = 0;
+                }
                 ptr4[u] = vp.x; ptr4[u + 1] = vp.y; ptr4[u + 2] = vp.z; ptr4[u + 3] = vp.w;
                 cnt4[u] = vc.x; cnt4[u + 1] = vc.y; cnt4[u + 2] = vc.z; cnt4[u + 3] = vc.w;
                 cmax = max(cmax, max(max(vc.x, vc.y), max(vc.z, vc.w)));
@@ -239,23 +401,25 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
                 }
             }
         }
-        unsigned long long e0 = ((unsigned long long)d0 << 32) | i0d, e1 = ((unsigned long long)d1 << 32) | i1d,
-                           e2 = ((unsigned long long)dd2 << 32) | i2d, e3 = ((unsigned long long)d3 << 32) | i3d,
-                           e4 = ((unsigned long long)d4 << 32) | i4d;
         if (gl == 0) visited += total;
-#pragma unroll
-        for (int off = kG / 2; off > 0; off >>= 1) inrange += __shfl_xor(inrange, off, kG);
-        // merge: six rounds of group-wide min pop the global top-5 (lane r keeps winner r) and the best loser
-        unsigned long long win = kNoKey, prev = kNoKey;
+        inrange = group_sum32(inrange);
+        // merge: six rounds pop the group's smallest (d2, index) head -- the global top-5 (lane r keeps winner r) and the best loser
+        uint32_t win = 0xFFFFFFFFu, prev_d = 0xFFFFFFFFu;
         bool tie = false;
         int pops = 0;
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            const unsigned long long best = group_min64(e0);
-            if (r > 0 && best != kNoKey && (uint32_t)(best >> 32) == (uint32_t)(prev >> 32)) tie = true;  // equal d2, different point
-            prev = best;
-            if (gl == r) win = best;
-            if (best != kNoKey && e0 == best) { e0 = e1; e1 = e2; e2 = e3; e3 = e4; e4 = kNoKey; pops++; }
+            const uint32_t bd = group_min32(d0);
+            const uint32_t bi = group_min32(d0 == bd ? i0d : 0xFFFFFFFFu);
+            const bool some = bi != 0xFFFFFFFFu;  // an empty head is (0xFFFFFFFF, 0xFFFFFFFF); a real d2 < 5 is never all ones
+            if (r > 0 && some && bd == prev_d) tie = true;  // equal d2, different point
+            prev_d = some ? bd : 0xFFFFFFFFu;
+            if (gl == r) win = bi;
+            if (some && d0 == bd && i0d == bi) {
+                d0 = d1; d1 = dd2; dd2 = d3; d3 = d4; d4 = 0xFFFFFFFFu;
+                i0d = i1d; i1d = i2d; i2d = i3d; i3d = i4d; i4d = 0xFFFFFFFFu;
+                pops++;
+            }
         }
         // The per-lane lists cannot lose a member of the top-5 (whatever a lane drops is no nearer than its own fifth), but
         // a dropped candidate exactly as far as that fifth would be an undetected tie if all five of the lane's entries
@@ -264,7 +428,7 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
         // results.  No in-range candidate at all: GetClosestPoint returns before touching the output
         // (ivox3d.h:152-154), the cached neighbours of an earlier scan survive.
         if (active && inrange > 0) {
-            if (gl < 5) nn_pts[(size_t)gl * nn_stride + q] = (win != kNoKey) ? pool[(uint32_t)win] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gl < 5) nn_pts[(size_t)gl * nn_stride + q] = (win != 0xFFFFFFFFu) ? pool[win] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (gl == 0) {
                 nn_cnt[q] = inrange < 5 ? (int32_t)inrange : 5;
                 if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
