@@ -330,6 +330,14 @@ int lio_ndt_linearize(lio_ndt*, lio_scan* source, const double T[16], int update
  * squared distance from the transformed source points to their nearest target point, over those within range; *score is
  * DBL_MAX when none is (PCL's value).  Exact nearest neighbours, from the target points the voxel grid retains. */
 int lio_ndt_fitness_score(lio_ndt*, lio_scan* source, const double T[16], double max_range, double* score, uint32_t* n_inliers);
+/* calc_fitness_score(cloud1, cloud2, relpose, max_range) of the map-merge / loop-closure tools, slam/localization/include/overlap_merge.hpp:
+ * 206-263: the target is cloud1 after `filter` (:196-204: sqrt(x^2 + y^2) < xy_range && z > min_z -- applied by the caller before
+ * lio_ndt_set_target), the source is cloud2 (all its points: lio_scan_set_ds), transformed by relpose (pcl::transformPointCloud, f32) and
+ * then put through the same filter here.  *score = mean squared nearest-neighbour distance over the source points whose neighbour is
+ * within max_range (squared, as PCL's kd-tree returns it), *inlier_ratio = their share of the filtered source; (DBL_MAX, 0) if none.
+ * The reference's constants: xy_range 100.0, min_z 0.5. */
+int lio_ndt_overlap_score(lio_ndt*, lio_scan* source, const double relpose[16], double max_range, double xy_range, double min_z, double* score,
+                          double* inlier_ratio);
 typedef struct lio_ndt_params {
     int32_t max_iterations;           /* setMaximumIterations (64) */
     int32_t lm_max_iterations;        /* lm_max_iterations_ (10) */
@@ -354,7 +362,7 @@ int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_
  *                   5 m / 10 deg gate, quaternion hemisphere; returns 1 / 0 = the reference's bool
  *   correct ....... correct(stamp, observation)       :348-360
  *   matrix / get .. matrix(), ukf->mean / cov
- * GNSS fusion (fusion_pose), the INS state queue (get_timed_pose) and the fitness score are not built. */
+ * GNSS fusion (fusion_pose) and the INS state queue (get_timed_pose) are not built; the fitness score is lio_ndt_fitness_score. */
 typedef struct lio_pose_estimator lio_pose_estimator;
 lio_pose_estimator* lio_pose_estimator_create(const float imu_ext[16], uint64_t stamp_us, const float pos[3], const float quat_wxyz[4],
                                               double cool_time_duration);

@@ -438,12 +438,22 @@ using namespace lio;
 // the search stops as soon as the best distance is within that (or the range is exhausted).
 __global__ void __launch_bounds__(256) ndt_fitness_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, float res,
                                                           NdtXform X, const float4* __restrict__ src, const ScanDev* __restrict__ sd, float max_range_sq,
-                                                          double* __restrict__ partial) {
+                                                          float xy_range, float min_z, double* __restrict__ partial) {
     const uint32_t n = sd->n_ds;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     double my_sum = 0.0;
-    uint32_t my_cnt = 0;
-    if (i < n) {
+    uint32_t my_cnt = 0, my_kept = 0;
+    bool keep = i < n;
+    if (keep && xy_range > 0.f) {
+        // overlap_merge.hpp:196-204 `filter`, applied to the TRANSFORMED source (:237-239): sqrt(x^2 + y^2) < range && z > floor
+        const float4 p = src[i];
+        const float tx = ((X.R[0] * p.x + X.R[1] * p.y) + X.R[2] * p.z) + X.t[0];
+        const float ty = ((X.R[3] * p.x + X.R[4] * p.y) + X.R[5] * p.z) + X.t[1];
+        const float tz = ((X.R[6] * p.x + X.R[7] * p.y) + X.R[8] * p.z) + X.t[2];
+        keep = sqrtf(tx * tx + ty * ty) < xy_range && tz > min_z;
+    }
+    if (keep) {
+        my_kept = 1;
         const float4 p = src[i];
         // pcl::transformPointCloud with a Matrix4f: accumulated left to right
         const float tx = ((X.R[0] * p.x + X.R[1] * p.y) + X.R[2] * p.z) + X.t[0];
@@ -480,14 +490,15 @@ __global__ void __launch_bounds__(256) ndt_fitness_kernel(const Slot* __restrict
         if (best <= max_range_sq) { my_sum = (double)best; my_cnt = 1; }
     }
     __shared__ double ssum[4];
-    __shared__ uint32_t scnt[4];
+    __shared__ uint32_t scnt[4], skept[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { my_sum += __shfl_xor(my_sum, off); my_cnt += __shfl_xor(my_cnt, off); }
-    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = my_sum; scnt[threadIdx.x >> 6] = my_cnt; }
+    for (int off = 32; off > 0; off >>= 1) { my_sum += __shfl_xor(my_sum, off); my_cnt += __shfl_xor(my_cnt, off); my_kept += __shfl_xor(my_kept, off); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = my_sum; scnt[threadIdx.x >> 6] = my_cnt; skept[threadIdx.x >> 6] = my_kept; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[blockIdx.x * 2] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
-        partial[blockIdx.x * 2 + 1] = (double)((scnt[0] + scnt[1]) + (scnt[2] + scnt[3]));
+        partial[blockIdx.x * 3] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        partial[blockIdx.x * 3 + 1] = (double)((scnt[0] + scnt[1]) + (scnt[2] + scnt[3]));
+        partial[blockIdx.x * 3 + 2] = (double)((skept[0] + skept[1]) + (skept[2] + skept[3]));
     }
 }
 
@@ -762,7 +773,8 @@ int lio_ndt_set_target(lio_ndt* n, const float* xyzi, uint64_t np) {
     return rc;
 }
 
-int lio_ndt_fitness_score(lio_ndt* n, lio_scan* s, const double T[16], double max_range, double* score, uint32_t* n_inliers) {
+static int fitness_common(lio_ndt* n, lio_scan* s, const double T[16], double max_range, float xy_range, float min_z, double* score, uint32_t* n_inliers,
+                          uint32_t* n_kept) {
     if (!n || !s || !T || !score || !(max_range > 0)) return LIO_E_INVALID;
     if (n->device != s->device) { set_error("matcher and scan live on different devices"); return LIO_E_INVALID; }
     hipSetDevice(n->device);
@@ -771,21 +783,38 @@ int lio_ndt_fitness_score(lio_ndt* n, lio_scan* s, const double T[16], double ma
     if (nd < 0) return nd;
     *score = 1.7976931348623157e308;  // std::numeric_limits<double>::max(): "no correspondence"
     if (n_inliers) *n_inliers = 0;
+    if (n_kept) *n_kept = 0;
     if (nd == 0) return LIO_OK;
     const uint32_t blocks = ((uint32_t)nd + 255u) / 256u;
     double* d_part = nullptr;
-    LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_part), sizeof(double) * 2 * blocks));
+    LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_part), sizeof(double) * 3 * blocks));
     hipLaunchKernelGGL(ndt_fitness_kernel, blocks, 256, 0, s->stream, n->map->table, n->map->table_mask, n->map->pool, n->res, to_xform(T), s->ds_body, s->dev,
-                       (float)max_range, d_part);
-    std::vector<double> part(2 * (size_t)blocks);
+                       (float)max_range, xy_range, min_z, d_part);
+    std::vector<double> part(3 * (size_t)blocks);
     hipError_t e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     hipFree(d_part);
     if (e != hipSuccess) { set_error("fitness score read-back failed: %s", hipGetErrorString(e)); return LIO_E_DEVICE; }
-    double sum = 0.0, cnt = 0.0;
-    for (uint32_t b = 0; b < blocks; b++) { sum += part[2 * b]; cnt += part[2 * b + 1]; }
+    double sum = 0.0, cnt = 0.0, kept = 0.0;
+    for (uint32_t b = 0; b < blocks; b++) { sum += part[3 * b]; cnt += part[3 * b + 1]; kept += part[3 * b + 2]; }
     if (cnt > 0) *score = sum / cnt;
     if (n_inliers) *n_inliers = (uint32_t)cnt;
+    if (n_kept) *n_kept = (uint32_t)kept;
+    return LIO_OK;
+}
+
+int lio_ndt_fitness_score(lio_ndt* n, lio_scan* s, const double T[16], double max_range, double* score, uint32_t* n_inliers) {
+    return fitness_common(n, s, T, max_range, 0.f, 0.f, score, n_inliers, nullptr);
+}
+
+int lio_ndt_overlap_score(lio_ndt* n, lio_scan* s, const double relpose[16], double max_range, double xy_range, double min_z, double* score,
+                          double* inlier_ratio) {
+    if (!(xy_range > 0) || !inlier_ratio) return LIO_E_INVALID;
+    uint32_t n_in = 0, n_kept = 0;
+    const int rc = fitness_common(n, s, relpose, max_range, (float)xy_range, (float)min_z, score, &n_in, &n_kept);
+    if (rc != LIO_OK) return rc;
+    // overlap_merge.hpp:259-262: (fitness / nr, nr / filtered source size), or (DBL_MAX, 0) without a single inlier
+    *inlier_ratio = n_in > 0 ? (double)n_in / (double)n_kept : 0.0;
     return LIO_OK;
 }
 

@@ -34,7 +34,7 @@ SYMBOLS = [
     "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_ins_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
     "lio_state_predict", "lio_eskf_update_cb",
-    "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_fitness_score", "lio_ndt_voxel_at",
+    "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_fitness_score", "lio_ndt_overlap_score", "lio_ndt_voxel_at",
     "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align",
 ]
 
@@ -187,6 +187,7 @@ def lib():
     sig("lio_ndt_set_target", cint, vp, f32p, u64)
     sig("lio_ndt_set_target_device", cint, vp, vp, u64)
     sig("lio_ndt_fitness_score", cint, vp, vp, f64p, dbl, f64p, C.POINTER(u32))
+    sig("lio_ndt_overlap_score", cint, vp, vp, f64p, dbl, dbl, dbl, f64p, f64p)
     sig("lio_ndt_num_voxels", cint, vp)
     sig("lio_ndt_voxel_at", cint, vp, f32p, f32p, f32p)
     sig("lio_ndt_linearize", cint, vp, vp, f64p, cint, cint, f64p, f64p, f64p, C.POINTER(u32))

@@ -391,6 +391,13 @@ class Engine:
         return bool(lib().lio_engine_is_degenerate(self.h))
 
 
+def overlap_filter(cloud, xy_range=100.0, min_z=0.5):
+    """`filter` of overlap_merge.hpp:196-204: keep sqrt(x^2 + y^2) < range && z > floor (f32)"""
+    c = np.ascontiguousarray(cloud, np.float32).reshape(-1, 4)
+    d = np.sqrt(c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1])
+    return c[(d < np.float32(xy_range)) & (c[:, 2] > np.float32(min_z))]
+
+
 class Ndt:
     """The localization matcher (fast_gicp::NDTCuda, P2D): set_target = setInputTarget, the source is a Scan
     (upload + voxel_downsample = setInputSource), align = pcl::Registration::align(guess)."""
@@ -437,6 +444,15 @@ class Ndt:
         sc, ni = C.c_double(0.0), C.c_uint32(0)
         check(lib().lio_ndt_fitness_score(self.h, scan.h, ptr(t, C.c_double), float(max_range), C.byref(sc), C.byref(ni)), "fitness score")
         return sc.value, ni.value
+
+    def overlap_score(self, scan, relpose, max_range=1.0, xy_range=100.0, min_z=0.5):
+        """calc_fitness_score of overlap_merge.hpp:206-263 against this target (filter the target cloud with `overlap_filter` first):
+        (mean squared nearest-neighbour distance of the inliers, inlier share of the filtered source)"""
+        t = f64(relpose).reshape(4, 4)
+        sc, ir = C.c_double(0.0), C.c_double(0.0)
+        check(lib().lio_ndt_overlap_score(self.h, scan.h, ptr(t, C.c_double), float(max_range), float(xy_range), float(min_z), C.byref(sc), C.byref(ir)),
+              "overlap score")
+        return sc.value, ir.value
 
     def align(self, scan, guess, **params):
         g = f64(guess).reshape(4, 4)

@@ -235,3 +235,54 @@ def test_fitness_score_exact_nearest_neighbours(scene):
     scan.set_ds(far)
     score, n_in = ndt.fitness_score(scan, T, 25.0)
     assert n_in == 0 and score > 1e300  # PCL: std::numeric_limits<double>::max()
+
+
+def test_overlap_score_of_the_map_merge_tools(scene):
+    """calc_fitness_score(cloud1, cloud2, relpose, max_range) (overlap_merge.hpp:206-263): both clouds through the range / floor filter
+    (the source AFTER the transform), exact nearest neighbours, mean squared distance of the inliers and their share -- against brute
+    force in the same f32 arithmetic"""
+    from lsd_amd import capi, lio, synth
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(21)
+    cloud1 = scene.sample_surface(300_000, seed=33, sigma=0.01)
+    cloud1 = cloud1[np.linalg.norm(cloud1[:, :2], axis=1) < 120.0][:60_000]
+    cloud1[:, 2] += 1.0  # part of the cloud below the 0.5 m floor, part above
+    T = np.eye(4)
+    T[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0.0, 0.01, 0.2]))
+    T[:3, 3] = [2.0, -1.0, 0.05]
+    Ti = np.linalg.inv(T)
+    pick = cloud1[rng.choice(len(cloud1), 6000, replace=False)]
+    cloud2 = pick.copy()
+    cloud2[:, :3] = pick[:, :3] @ Ti[:3, :3].T + Ti[:3, 3] + rng.normal(0, 0.1, (6000, 3))
+    cloud2 = np.concatenate([cloud2, np.concatenate([rng.uniform(-150, 150, (800, 2)), rng.uniform(-2, 40, (800, 1)), np.zeros((800, 1))], 1)]).astype(np.float32)
+    target = lio.overlap_filter(cloud1)
+    assert 0 < len(target) < len(cloud1)
+    ndt = lio.Ndt(resolution=1.0, search_method=7, max_points=len(target) + 1, max_voxels=200_000, max_source_points=1 << 16)
+    ndt.set_target(target)
+    scan = lio.Scan(max_raw=1 << 16, max_ds=1 << 16)
+    scan.set_ds(cloud2)
+    Tf = T.astype(np.float32)
+    tp = np.stack([((Tf[r, 0] * cloud2[:, 0] + Tf[r, 1] * cloud2[:, 1]) + Tf[r, 2] * cloud2[:, 2]) + Tf[r, 3] for r in range(3)], 1)
+    kept = (np.sqrt(tp[:, 0] * tp[:, 0] + tp[:, 1] * tp[:, 1]) < np.float32(100.0)) & (tp[:, 2] > np.float32(0.5))
+    assert 0.3 * len(tp) < kept.sum() < len(tp)
+    tk = tp[kept]
+    best = np.full(len(tk), np.inf, np.float32)
+    for a in range(0, len(tk), 100):
+        d = tk[a:a + 100, None, :] - target[None, :, :3]
+        best[a:a + 100] = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).min(1)
+    for max_range in (1.0, 25.0, 4e-3, 1e-7):
+        inl = best <= np.float32(max_range)
+        score, ratio = ndt.overlap_score(scan, T, max_range)
+        if inl.sum() == 0:
+            assert score > 1e300 and ratio == 0.0 and max_range < 1e-3
+            continue
+        assert abs(ratio - inl.sum() / kept.sum()) < 1e-15
+        assert abs(score - best[inl].astype(np.float64).mean()) <= 1e-12 * max(1.0, score)
+    # nothing survives the filter / nothing within range: (DBL_MAX, 0)
+    up = cloud2.copy()
+    up[:, 2] -= 100.0
+    scan.set_ds(up)
+    score, ratio = ndt.overlap_score(scan, T, 1.0)
+    assert score > 1e300 and ratio == 0.0
