@@ -111,6 +111,54 @@ def test_knn_exact_ties_and_duplicates(oracle_mod):
         assert np.array_equal(ref_pts[..., :3].view(np.uint32), got_pts[..., :3].view(np.uint32))
 
 
+def test_knn_pruned_sweep_adversarial(oracle_mod):
+    """the sweep visits the stencil voxels nearest-first and skips those that cannot beat five known candidates: maps and queries built
+    to make that decision as hard as possible -- queries on voxel faces / edges / corners (+- one f32 ulp), nearest neighbours living in
+    the far (edge) cells while the near cells hold only far points, fewer than five candidates, other resolutions, far-from-origin
+    coordinates (the bound's slack scales with |q|)"""
+    _dev()
+    from lsd_amd import lio
+
+    rng = np.random.default_rng(77)
+    few = none = 0
+    for res, origin in ((0.5, 0.0), (0.5, 4096.0), (1.0, -2500.0), (0.2, 0.0)):
+        n = 60_000
+        # sparse-to-dense mix: a dense slab, a sparse cloud, and clumps hugging voxel boundaries
+        slab = np.c_[rng.uniform(-8, 8, (n // 2, 2)) * res * 2, rng.normal(0, 0.02, n // 2)]
+        cloud = rng.uniform(-8, 8, (n // 4, 3)) * res * 2
+        k = rng.integers(-16, 16, (n // 4, 3)).astype(np.float64)
+        hug = (k + 0.5) * res + rng.choice([-1, 1], (n // 4, 3)) * rng.uniform(0, 0.02, (n // 4, 3)) * res
+        pts = np.concatenate([slab, cloud, hug]) + origin
+        pts = np.c_[pts, np.zeros(len(pts))].astype(np.float32)
+        # queries: on faces, edges and corners of voxels (k + 0.5) * res, nudged by one ulp either way, plus random ones
+        kq = rng.integers(-14, 14, (6000, 3)).astype(np.float64)
+        onb = rng.random((6000, 3)) < 0.6
+        q = (kq + np.where(onb, 0.5, rng.uniform(-0.5, 0.5, (6000, 3)))) * res + origin
+        q = q.astype(np.float32)
+        nudge = rng.integers(-1, 2, q.shape)
+        q = np.where(nudge > 0, np.nextafter(q, np.float32(np.inf)), np.where(nudge < 0, np.nextafter(q, np.float32(-np.inf)), q)).astype(np.float32)
+        q = np.c_[q, np.zeros(len(q), np.float32)]
+        iv = oracle_mod.IVox(res=res, stencil=19)
+        iv.add(pts)
+        m = lio.Map(resolution=res, stencil=19, max_points=200_000, max_voxels=200_000)
+        m.add(pts)
+        for st in (7, 19, 27):
+            iv.set_stencil(st)
+            m.set_stencil(st)
+            ref_pts, ref_cnt, _ = iv.knn(q)
+            got_pts, got_cnt = m.knn(q)
+            assert np.array_equal(ref_cnt, got_cnt), (res, origin, st)
+            few += int(((ref_cnt > 0) & (ref_cnt < 5)).sum())
+            none += int((ref_cnt == 0).sum())
+            full = ref_cnt == 5
+            assert np.array_equal(ref_pts[full][..., :3].view(np.uint32), got_pts[full][..., :3].view(np.uint32)), (res, origin, st)
+            for c in range(1, 5):
+                sel = ref_cnt == c
+                assert np.array_equal(ref_pts[sel][:, :c, :3].view(np.uint32), got_pts[sel][:, :c, :3].view(np.uint32)), (res, origin, st, c)
+        m.close()
+    assert few > 20  # the fewer-than-five path was exercised too
+
+
 def _make_pair(oracle_mod, small_world, stencil=19):
     from lsd_amd import lio, synth
 
