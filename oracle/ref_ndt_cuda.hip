@@ -6,6 +6,11 @@
 // built into oracle/_ref/libref_ndt_cuda.so by `make -C oracle ref`.
 #include <fast_gicp/cuda/gaussian_voxelmap.cuh>
 #include <fast_gicp/cuda/ndt_cuda.cuh>
+// ... and the registration object the reference instantiates around it: fast_gicp::NDTCuda<PointT, PointT> with LsqRegistration's
+// Levenberg-Marquardt loop (ndt_cuda_impl.hpp, lsq_registration_impl.hpp); PCL's Registration base class, PointCloud and
+// boost::format are shims (oracle/ref_shims)
+#include <fast_gicp/ndt/impl/ndt_cuda_impl.hpp>
+#include <fast_gicp/gicp/impl/lsq_registration_impl.hpp>
 
 #include <thrust/host_vector.h>
 
@@ -23,7 +28,45 @@ static std::vector<Eigen::Vector3f, Eigen::aligned_allocator<Eigen::Vector3f>> t
     return c;
 }
 
+using RefNdt = fast_gicp::NDTCuda<pcl::PointXYZI, pcl::PointXYZI>;
+static pcl::PointCloud<pcl::PointXYZI>::Ptr to_pcl(const float* xyzi, int n) {
+    pcl::PointCloud<pcl::PointXYZI>::Ptr c(new pcl::PointCloud<pcl::PointXYZI>());
+    c->points.resize(n);
+    for (int i = 0; i < n; i++) { c->points[i].x = xyzi[4 * i]; c->points[i].y = xyzi[4 * i + 1]; c->points[i].z = xyzi[4 * i + 2]; c->points[i].intensity = xyzi[4 * i + 3]; }
+    c->width = n; c->height = 1;
+    return c;
+}
+
 extern "C" {
+// select_registration_method("NDT_CUDA") of backend/hdl_graph_slam/src/hdl_graph_slam/registrations.cpp:107-118, same setter calls
+void* ref_ndtreg_create(double resolution, int search_method, double max_process_time_ms) {
+    RefNdt* r = new RefNdt();
+    r->setTransformationEpsilon(0.01);
+    r->setRotationEpsilon(0.1);
+    r->setMaximumIterations(64);
+    r->setResolution(resolution);
+    r->setDistanceMode(fast_gicp::NDTDistanceMode::P2D);
+    r->setNeighborSearchMethod(search_method == 1 ? fast_gicp::NeighborSearchMethod::DIRECT1
+                               : search_method == 27 ? fast_gicp::NeighborSearchMethod::DIRECT27 : fast_gicp::NeighborSearchMethod::DIRECT7, 0.0);
+    r->setMaxProcessTime((int64_t)max_process_time_ms);
+    return r;
+}
+void ref_ndtreg_destroy(void* h) { delete static_cast<RefNdt*>(h); }
+void ref_ndtreg_set_target(void* h, const float* xyzi, int n) { static_cast<RefNdt*>(h)->setInputTarget(to_pcl(xyzi, n)); }
+void ref_ndtreg_set_source(void* h, const float* xyzi, int n) { static_cast<RefNdt*>(h)->setInputSource(to_pcl(xyzi, n)); }
+// registration->align(aligned, guess); returns hasConverged, fills the final transformation (row-major) and the iteration count
+int ref_ndtreg_align(void* h, const float* guess16, float* T16, int* iterations) {
+    RefNdt* r = static_cast<RefNdt*>(h);
+    Eigen::Matrix4f G;
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) G(a, b) = guess16[4 * a + b];
+    pcl::PointCloud<pcl::PointXYZI> aligned;
+    r->align(aligned, G);
+    const Eigen::Matrix4f T = r->getFinalTransformation();
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) T16[4 * a + b] = T(a, b);
+    if (iterations) *iterations = static_cast<pcl::Registration<pcl::PointXYZI, pcl::PointXYZI, float>*>(r)->nr_iterations_;
+    return r->hasConverged() ? 1 : 0;
+}
+
 // search_method: 1 / 7 / 27 (DIRECT1 / DIRECT7 / DIRECT27); distance mode P2D as select_registration_method("NDT_CUDA") sets it
 void* ref_ndt_create(double resolution, int search_method) {
     NDTCudaCore* c = new NDTCudaCore();

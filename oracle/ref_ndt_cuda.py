@@ -31,6 +31,12 @@ def lib():
         L.ref_ndt_compute_error.argtypes = [C.c_void_p, f64p, f64p, f64p]
         L.ref_ndt_compute_error.restype = C.c_double
         L.ref_ndt_valid_pairs.argtypes = [C.c_void_p]
+        L.ref_ndtreg_create.restype = C.c_void_p
+        L.ref_ndtreg_create.argtypes = [C.c_double, C.c_int, C.c_double]
+        L.ref_ndtreg_destroy.argtypes = [C.c_void_p]
+        L.ref_ndtreg_set_target.argtypes = [C.c_void_p, f32p, C.c_int]
+        L.ref_ndtreg_set_source.argtypes = [C.c_void_p, f32p, C.c_int]
+        L.ref_ndtreg_align.argtypes = [C.c_void_p, f32p, f32p, i32p]
         _lib = L
     return _lib
 
@@ -79,3 +85,29 @@ class NdtCudaCore:
     def compute_error(self, T):
         t = np.ascontiguousarray(T, np.float64).reshape(16)
         return lib().ref_ndt_compute_error(self.h, _p(t, C.c_double), None, None)
+
+
+class NdtCudaRegistration:
+    """fast_gicp::NDTCuda<PointXYZI, PointXYZI> configured as select_registration_method("NDT_CUDA") does (registrations.cpp:107-118):
+    setInputTarget / setInputSource / align(guess) with LsqRegistration's Levenberg-Marquardt loop"""
+
+    def __init__(self, resolution=1.0, search_method=7, max_process_time_ms=-1):
+        self.h = lib().ref_ndtreg_create(float(resolution), int(search_method), float(max_process_time_ms))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ref_ndtreg_destroy(self.h)
+        self.h = None
+
+    def set_target(self, xyzi):
+        p = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        lib().ref_ndtreg_set_target(self.h, _p(p, C.c_float), len(p))
+
+    def set_source(self, xyzi):
+        p = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        lib().ref_ndtreg_set_source(self.h, _p(p, C.c_float), len(p))
+
+    def align(self, guess):
+        g, T, it = np.ascontiguousarray(guess, np.float32).reshape(16), np.zeros(16, np.float32), C.c_int(0)
+        conv = lib().ref_ndtreg_align(self.h, _p(g, C.c_float), _p(T, C.c_float), C.byref(it))
+        return T.reshape(4, 4).astype(np.float64), bool(conv), it.value

@@ -107,7 +107,26 @@ def main():
                     if rep:
                         t_lin_ref.append(t1 - t0)
                         t_lin_hip.append(t2 - t1)
-            print(json.dumps({"case": name + "_vs_reference_kernels", "target_points": len(pts), "reference_build_ms": round(1e3 * t_ref_build, 2),
+            # the whole alignment through the reference's registration object (fast_gicp::NDTCuda + LsqRegistration's LM loop)
+            reg = ref.NdtCudaRegistration(1.0, 7)
+            reg.set_target(pts)
+            t_al_ref, t_al_hip, dpos = [], [], []
+            for w in range(2):
+                reg.set_source(ds_host[w])
+                s.set_ds(ds_host[w])
+                for rep in range(5):
+                    t0 = time.perf_counter()
+                    Tr, conv_r, it_r = reg.align(scans[w][3])
+                    t1 = time.perf_counter()
+                    Tg, conv_g, it_g = n.align(s, scans[w][3])
+                    t2 = time.perf_counter()
+                    if rep:
+                        t_al_ref.append(t1 - t0)
+                        t_al_hip.append(t2 - t1)
+                dpos.append(float(np.linalg.norm(Tr[:3, 3] - Tg[:3, 3])))
+            reg.close()
+            print(json.dumps({"case": name + "_vs_reference_kernels", "reference_align_ms": round(1e3 * float(np.median(t_al_ref)), 3),
+                              "hip_align_ms": round(1e3 * float(np.median(t_al_hip)), 3), "align_iterations": [it_r + 1, it_g + 1], "align_dpos_m": max(dpos), "target_points": len(pts), "reference_build_ms": round(1e3 * t_ref_build, 2),
                               "hip_build_ms": round(1e3 * t_build, 2), "reference_linearize_ms": round(1e3 * float(np.median(t_lin_ref)), 3),
                               "hip_linearize_ms": round(1e3 * float(np.median(t_lin_hip)), 3), "pairs_reference": lr["n_corr"], "pairs_hip": lg["n_corr"],
                               "cost_rel_diff": abs(lg["err"] / lr["err"] - 1), "note": "linearize: synchronous calls on both sides, same downsampled source; reference_build_ms includes its host-to-device copy of the cloud, hip_build_ms starts from a device-resident cloud"}), flush=True)
