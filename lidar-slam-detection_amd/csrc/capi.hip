@@ -363,7 +363,7 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
          dev_alloc(&s->dev, 1, &s->bytes) && dev_alloc(&s->d_result, 1, &s->bytes);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&s->host_dev), sizeof(ScanDev)) == hipSuccess &&
          hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(lio_normal_eq), hipHostMallocMapped) == hipSuccess &&
-         hipHostMalloc(reinterpret_cast<void**>(&s->host_nds), 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+         hipHostMalloc(reinterpret_cast<void**>(&s->host_nds), 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
          hipHostGetDevicePointer(reinterpret_cast<void**>(&s->host_nds_dev), s->host_nds, 0) == hipSuccess &&
          hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_result_dev), s->h_result, 0) == hipSuccess;
     if (ok) {
@@ -380,7 +380,8 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
         return nullptr;
     }
     memset(s->h_result, 0, sizeof(lio_normal_eq));
-    s->host_nds[0] = s->host_nds[1] = 0;
+    s->host_nds[0] = s->host_nds[1] = s->host_nds[2] = s->host_nds[3] = 0;
+    s->pred_passes = 4;
     s->raw = s->raw_own;
     return s;
 }
@@ -557,21 +558,34 @@ static int scan_sync_dev(lio_scan* s) {
 int lio_scan_voxel_downsample(lio_scan* s, float leaf, int sync, uint32_t* n_ds) {
     if (!s || !(leaf > 0.f)) return LIO_E_INVALID;
     hipSetDevice(s->device);
-    int rc = vg_downsample(s, leaf);
-    if (rc != LIO_OK) return rc;
-    rc = scan_begin(s);
-    if (rc != LIO_OK) return rc;
-    s->have_ds = -1;
-    if (sync) {
+    // The sort needs ceil(log2(cells of the bounding box) / 8) radix passes, known only on the device.  A caller that waits for the
+    // result lets the next scan launch just as many as this one needed (two launches fewer for the usual 17..24-bit keys); the device
+    // checks, and a scan whose box needs more is run again with all four.  Without a wait there is no check: all four are launched.
+    int passes = sync ? s->pred_passes : 4;
+    for (;;) {
+        int rc = vg_downsample(s, leaf, passes);
+        if (rc != LIO_OK) return rc;
+        rc = scan_begin(s);
+        if (rc != LIO_OK) return rc;
+        s->have_ds = -1;
+        if (!sync) return LIO_OK;
         LIO_HIP_TRY(hipStreamSynchronize(s->stream));
-        if (s->host_nds[1] & 1u) {
-            set_error("downsampled scan exceeds max_ds %u", s->max_ds);
+        if ((s->host_nds[1] & 2u) && passes < 4) {  // under-launched sort: nothing downstream has consumed the result yet
             hipMemsetAsync(&s->dev->err, 0, 4, s->stream);
-            return LIO_E_CAPACITY;
+            passes = 4;
+            continue;
         }
-        s->have_ds = (int)s->host_nds[0];
-        if (n_ds) *n_ds = s->host_nds[0];
+        break;
     }
+    if (s->host_nds[1] & 1u) {
+        set_error("downsampled scan exceeds max_ds %u", s->max_ds);
+        hipMemsetAsync(&s->dev->err, 0, 4, s->stream);
+        return LIO_E_CAPACITY;
+    }
+    const int needed = (int)s->host_nds[2];
+    s->pred_passes = needed >= 1 && needed <= 4 ? needed : 4;
+    s->have_ds = (int)s->host_nds[0];
+    if (n_ds) *n_ds = s->host_nds[0];
     return LIO_OK;
 }
 

@@ -151,7 +151,7 @@ struct lio_scan {
     uint8_t* selected;
     float4* normvec;
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b;
-    uint32_t* hist;      // radix histograms [256][nblocks]
+    uint32_t* hist;      // radix histograms [nblocks][256]
     uint32_t* blockcnt;  // head counts per tile
     uint32_t* hpos;      // first sorted position of every occupied voxel
     uint32_t* longlist;  // voxels with long runs
@@ -162,7 +162,8 @@ struct lio_scan {
     lio::ScanDev* dev;
     lio::ScanDev* host_dev;       // pinned mirror
     lio_normal_eq* d_result;
-    uint32_t* host_nds;           // pinned, mapped: {n_ds, err} written by vg_heads_kernel
+    uint32_t* host_nds;           // pinned, mapped: {n_ds, err, radix passes the scan needed} written by vg_heads_kernel
+    int pred_passes;              // radix passes the last waited-for downsample needed (4 until known)
     uint32_t* host_nds_dev;
     lio_normal_eq* h_result;      // pinned, mapped
     lio_normal_eq* h_result_dev;  // device-side alias of h_result (linearize_kernel's last workgroup writes the record there)
@@ -193,7 +194,7 @@ int undistort_delta_launch(hipStream_t stream, const float4* d_in, const uint32_
 int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const ImuPoseDev* d_poses,
                      const UndistortArgs& args, unsigned long long* d_block_min /* ceil(n / 256) words of scratch */);
 
-int vg_downsample(lio_scan* s, float leaf);
+int vg_downsample(lio_scan* s, float leaf, int passes /* radix passes to launch, 1..4 */);
 int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);
 void kt_begin(lio_scan* s, int which);

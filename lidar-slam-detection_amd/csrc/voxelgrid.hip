@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restr
         atomicAdd(&h[key & 255u], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];  // [tile][digit]: one coalesced 1-KiB row per workgroup
 }
 
 // ---- stable LSD radix sort, 8 bits per pass, ping-pong a -> b -> a ... ------------------------------------
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];  // [tile][digit]: one coalesced 1-KiB row per workgroup
 }
 
 __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
@@ -212,19 +212,21 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __res
         k[r] = ok[r] ? kin[i] : 0u;
         v[r] = ok[r] ? vin[i] : 0u;
     }
-    // this workgroup's global bases, from the raw [digit][tile] histogram: thread d owns digit d.
+    // this workgroup's global bases, from the raw per-tile histograms: thread d owns digit d.
     //   base[d] = sum_{d' < d} total[d'] + sum_{b' < b} hist[d][b']      (digit-major, then tile order = stable)
     uint32_t tot = 0, pre = 0;
     {
-        const uint32_t* row = hist + (size_t)tid * nblocks;
+        // [tile][digit] layout: for a given tile the 256 threads read one contiguous 1-KiB row (it used to be [digit][tile]: every lane
+        // of a load in a different cache line, 64 transactions per instruction)
+        const uint32_t* col = hist + tid;
         uint32_t b = 0;
         for (; b + 4 <= nblocks; b += 4) {
-            const uint32_t h0 = row[b], h1 = row[b + 1], h2 = row[b + 2], h3 = row[b + 3];
+            const uint32_t h0 = col[(size_t)b * 256u], h1 = col[(size_t)(b + 1) * 256u], h2 = col[(size_t)(b + 2) * 256u], h3 = col[(size_t)(b + 3) * 256u];
             tot += (h0 + h1) + (h2 + h3);
             pre += (b < blockIdx.x ? h0 : 0u) + (b + 1 < blockIdx.x ? h1 : 0u) + (b + 2 < blockIdx.x ? h2 : 0u) + (b + 3 < blockIdx.x ? h3 : 0u);
         }
         for (; b < nblocks; b++) {
-            const uint32_t h0 = row[b];
+            const uint32_t h0 = col[(size_t)b * 256u];
             tot += h0;
             pre += b < blockIdx.x ? h0 : 0u;
         }
@@ -303,9 +305,11 @@ __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __rest
                                                             const uint32_t* __restrict__ kb, const uint32_t* __restrict__ va,
                                                             const uint32_t* __restrict__ vb, uint32_t n, ScanDev* sd,
                                                             const uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ hpos,
-                                                            float4* __restrict__ sorted, float4* __restrict__ out, uint32_t max_ds, uint32_t* __restrict__ host_nds) {
+                                                            float4* __restrict__ sorted, float4* __restrict__ out, uint32_t max_ds, uint32_t* __restrict__ host_nds,
+                                                            uint32_t launched_passes) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (sd->passthrough) {  // PCL overflow guard: output = input
+        if (blockIdx.x == 0 && tid == 0) host_nds[2] = 0u;
         if (n > max_ds) {
             if (blockIdx.x == 0 && tid == 0) { sd->err |= 1u; sd->n_ds = 0; host_nds[0] = 0; host_nds[1] = 1u; }
             return;
@@ -364,9 +368,13 @@ __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __rest
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         uint32_t err = 0;
         if (run > max_ds) { sd->err |= 1u; run = 0; err = 1u; }
+        // the host launched as many radix passes as the previous scan needed; if this scan's bounding box needs more, the keys
+        // are not fully sorted: say so (bit 2) and let the host run the chain again with all four (rare: the cell count crossed 2^(8k))
+        if (active_passes(sd) > launched_passes) { err |= 2u; run = 0; }
         sd->n_ds = run;
         host_nds[0] = run;  // mapped pinned host words: the host reads them after one stream sync, no copy launch
         host_nds[1] = err;
+        host_nds[2] = active_passes(sd);
     }
 }
 
@@ -459,7 +467,7 @@ __global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt) {
     }
 }
 
-int vg_downsample(lio_scan* s, float leaf) {
+int vg_downsample(lio_scan* s, float leaf, int passes) {
     const uint32_t n = s->n_raw;
     const float inv = 1.0f / leaf;
     hipStream_t st = s->stream;
@@ -469,19 +477,20 @@ int vg_downsample(lio_scan* s, float leaf) {
         hipLaunchKernelGGL(scan_set_nds_kernel, 1, 1, 0, st, s->dev, 0u);
         s->host_nds[0] = 0;
         s->host_nds[1] = 0;
+        s->host_nds[2] = 0;
         return LIO_OK;
     }
     const uint32_t g1 = nblocks < 48 ? nblocks : 48;  // 7 same-line atomics per workgroup: keep the workgroups few
     hipLaunchKernelGGL(vg_bbox_kernel, g1, kThreads, 0, st, s->raw, n, s->dev);
     hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a, s->hist, nblocks);
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < passes; pass++) {  // kernels of a pass the bounding box does not need return at once
         if (pass > 0) hipLaunchKernelGGL(radix_hist_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, pass, s->hist, nblocks, s->dev);
         hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, s->keys_a, s->vals_a, s->keys_b, s->vals_b, n, pass, s->hist, nblocks,
                            s->dev);
     }
     hipLaunchKernelGGL(vg_count_heads_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, s->dev, s->blockcnt);
     hipLaunchKernelGGL(vg_heads_kernel, nblocks, kThreads, 0, st, s->raw, s->keys_a, s->keys_b, s->vals_a, s->vals_b, n, s->dev, s->blockcnt,
-                       s->hpos, s->sorted, s->ds_body, s->max_ds, s->host_nds_dev);
+                       s->hpos, s->sorted, s->ds_body, s->max_ds, s->host_nds_dev, (uint32_t)passes);
     const uint32_t vbound = n < s->max_ds ? n : s->max_ds;
     hipLaunchKernelGGL(vg_centroid_kernel, (vbound + kThreads - 1) / kThreads, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body,
                        s->longlist);

@@ -56,6 +56,28 @@ def test_voxel_downsample_edge_cases(oracle_mod):
     assert s.voxel_downsample(0.5) == 0
 
 
+def test_voxel_downsample_pass_prediction(oracle_mod):
+    """the host launches as many radix passes as the previous scan needed and the device checks: clouds whose bounding boxes need
+    1, 2, 3 and 4 passes in every order on one scan object -- each result bit-exact whether the prediction held or the chain ran twice"""
+    _dev()
+    from lsd_amd import lio
+
+    rng = np.random.default_rng(5)
+    clouds = {}
+    for name, half in (("8 bits", (1.5, 1.5, 1.5)), ("15 bits", (8.0, 8.0, 8.0)), ("22 bits", (60.0, 60.0, 12.0)), ("26 bits", (200.0, 200.0, 25.0))):
+        p = rng.uniform(-1, 1, (30_000, 3)) * np.array(half)
+        clouds[name] = np.c_[p, rng.uniform(0, 255, len(p))].astype(np.float32)
+    ref = {k: oracle_mod.voxel_downsample(v, 0.5) for k, v in clouds.items()}
+    sc = lio.Scan(max_raw=1 << 16, max_ds=1 << 16)
+    order = ["22 bits", "8 bits", "26 bits", "15 bits", "15 bits", "26 bits", "8 bits", "22 bits", "26 bits", "22 bits"]
+    for name in order:
+        sc.upload(clouds[name])
+        n = sc.voxel_downsample(0.5)
+        assert n == len(ref[name]), name
+        assert np.array_equal(sc.get_ds().view(np.uint32), ref[name].view(np.uint32)), name
+    sc.close()
+
+
 def test_map_insert_and_knn_exact(oracle_mod, small_world):
     _dev()
     from lsd_amd import lio
