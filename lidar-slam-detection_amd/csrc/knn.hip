@@ -9,13 +9,15 @@
 // Mapping to the machine: G = 16 lanes (a quarter wave) work on one query, four queries per wave (G = 32 costs the same alone
 // and ~8 % more GPU time with several scans in flight: fewer lanes idle on voxels of ~40 points).
 //   1. each lane probes stencil cells (one 16-B slot load each; two rounds for NEARBY18, five for the 75-cell start-up
-//      stencil), hits are compacted into LDS with ballot + popcount and prefix-summed
-//      with lane shuffles;
-//   2. voxel-major sweep: four voxel descriptors at a time come back from LDS as two ds_read_b128, lane l takes
-//      point l (l+G, ...) of each of the four voxels -- four coalesced 16-B loads in flight, addresses are
+//      stencil); for stencils of at most 2 G cells the hits are compacted into LDS in three buckets of a conservative lower
+//      bound of the voxel's distance to the query (ballot + popcount; group sums by DPP row rotation);
+//   2. voxel-major sweep, nearest bucket first: four voxel descriptors at a time come back from LDS as ds_read_b128, lane l
+//      takes point l (l+G, ...) of each of the four voxels -- four coalesced 16-B loads in flight, addresses are
 //      base + lane -- and keeps its own sorted top-5 as (d2 bits, pool index) pairs: branch-free insertion, five
-//      independent compares, v_min / v_med3 for the distances and two selects per slot for the indices;
-//   3. six rounds of a group-wide 64-bit min (shuffles) pop the global top-5 and the best loser.
+//      independent compares, v_min / v_med3 for the distances and two selects per slot for the indices.  After the first
+//      batch the group bounds its fifth-nearest distance from what the lanes hold and skips every voxel whose lower bound is
+//      strictly above it (exact: sets, ties and in-range counts are unchanged), stopping at the first bucket whose floor is;
+//   3. six rounds of group-wide (d2, index) minima (DPP row rotations, no LDS crossbar) pop the global top-5 and the best loser.
 // Exact d2 ties between different points are the only case where (d2, index) order can differ from the
 // canonical (d2, x, y, z) order.  They are detected on the sorted top-6 and the query is queued for
 // knn_exact_kernel, which redoes it with the full comparison (rare: ~1e-6 per query on float data).
