@@ -362,14 +362,30 @@ int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_
  *                   5 m / 10 deg gate, quaternion hemisphere; returns 1 / 0 = the reference's bool
  *   correct ....... correct(stamp, observation)       :348-360
  *   matrix / get .. matrix(), ukf->mean / cov
- * GNSS fusion (fusion_pose) and the INS state queue (get_timed_pose) are not built; the fitness score is lio_ndt_fitness_score. */
+ *   guess / observe  the two host halves of match() around the alignment (:196-247 / :250-302), with the GNSS observation fused in
+ *                   (fusion_pose :420-433); match_gps = guess -> lio_ndt_align -> observe; match_gps_only = the scan-less match :304-346
+ *   get_timed_pose  get_timed_pose + the INS state queue (:104-141), re-predicted by correct (:366-381); predict_nostate :70-86
+ * The fitness score of the warm-up phase is lio_ndt_fitness_score. */
 typedef struct lio_pose_estimator lio_pose_estimator;
+typedef struct lio_gps_observation {  /* what match() reads of an RTKType: T (map-frame pose, row-major), precision, dimension (2 / 3 / 6) */
+    double T[16];
+    double precision;
+    int32_t dimension;
+} lio_gps_observation;
 lio_pose_estimator* lio_pose_estimator_create(const float imu_ext[16], uint64_t stamp_us, const float pos[3], const float quat_wxyz[4],
                                               double cool_time_duration);
 void lio_pose_estimator_destroy(lio_pose_estimator*);
 int lio_pose_estimator_predict(lio_pose_estimator*, uint64_t stamp_us, const float acc[3], const float gyro[3]);
 int lio_pose_estimator_match(lio_pose_estimator*, lio_ndt* target, lio_scan* source, const lio_ndt_params* params, float observation[7],
                              int* iterations);
+int lio_pose_estimator_match_gps(lio_pose_estimator*, lio_ndt* target, lio_scan* source, const lio_ndt_params* params, const lio_gps_observation* gps,
+                                 float observation[7], float observation_cov[49], int* iterations);
+int lio_pose_estimator_guess(lio_pose_estimator*, const lio_gps_observation* gps, float init_guess[16]);
+int lio_pose_estimator_observe(lio_pose_estimator*, const float init_guess[16], const float aligned[16], int converged, const lio_gps_observation* gps,
+                               float observation[7], float observation_cov[49]);
+int lio_pose_estimator_match_gps_only(lio_pose_estimator*, const lio_gps_observation* gps, float observation[7], float observation_cov[49]);
+int lio_pose_estimator_get_timed_pose(lio_pose_estimator*, uint64_t stamp_us, const double acc_g[3], const double gyro_dps[3], double pose[16]);
+int lio_pose_estimator_predict_nostate(lio_pose_estimator*, uint64_t stamp_us, double pose[16]);
 int lio_pose_estimator_correct(lio_pose_estimator*, uint64_t stamp_us, const float observation[7]);
 int lio_pose_estimator_get(lio_pose_estimator*, float mean23[23], float cov529[529]);
 int lio_pose_estimator_set(lio_pose_estimator*, const float mean23[23], const float cov529[529]);

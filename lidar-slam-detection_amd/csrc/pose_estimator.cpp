@@ -283,13 +283,107 @@ struct Ukf {
 
 }  // namespace
 
+struct InsState {  // one entry of PoseEstimator::state_queue (an RTKType: timestamp, raw IMU sample, predicted state)
+    uint64_t stamp;
+    double acc_g[3], gyro_dps[3];  // as RTKType carries them: g and deg/s, doubles
+    float mean[N];
+};
+
 struct lio_pose_estimator {
     Ukf ukf;
     float process_noise[N * N];
     uint64_t init_stamp = 0, prev_stamp = 0, last_correction_stamp = 0;
     double cool_time_duration = 1.0;
     int bad = 0;  // a Cholesky factorisation failed (covariance not positive definite)
+    std::vector<InsState> state_queue;
 };
+
+namespace {
+
+// PoseEstimator::predict_imu (pose_estimator.cpp:88-102).  `dt_smooth` is a function-local static there: one value shared by every
+// estimator of the process, never reset -- kept that way.
+double g_dt_smooth = 0;
+void predict_imu(lio_pose_estimator* e, uint64_t pre_stamp, uint64_t next_stamp, const float* pre_state, float* next_state, const float acc[3],
+                 const float gyro[3]) {
+    double dt = ((double)next_stamp - (double)pre_stamp) / 1000000.0;
+    dt = std::max(0.0, std::min(1.0, dt));
+    g_dt_smooth = g_dt_smooth * 0.95 + dt * 0.05;
+    e->ukf.system.dt = g_dt_smooth;
+    const float control[6] = {acc[0], acc[1], acc[2], gyro[0], gyro[1], gyro[2]};
+    e->ukf.system.f(pre_state, control, next_state);
+}
+// Vector3f(ins.acc_x * 9.81, ...) and Vector3f(ins.gyro_x / 180.0 * M_PI, ...): double arithmetic on the RTKType's doubles, narrowed
+inline void ins_units(const double acc_g[3], const double gyro_dps[3], float acc[3], float gyr[3]) {
+    for (int i = 0; i < 3; i++) {
+        acc[i] = (float)(acc_g[i] * 9.81);
+        gyr[i] = (float)(gyro_dps[i] / 180.0 * M_PI);
+    }
+}
+inline void pose_of_state(const float* s, double T[16]) {  // Quaternionf(...).normalized() is discarded there: the raw quaternion is used
+    const Quat q{s[6], s[7], s[8], s[9]};
+    float R[9];
+    qtoR(q, R);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[i * 4 + j] = (double)R[i * 3 + j];
+        T[i * 4 + 3] = (double)s[i];
+        T[12 + i] = 0.0;
+    }
+    T[15] = 1.0;
+}
+
+// PoseEstimator::fusion_pose (pose_estimator.cpp:420-433): information-form fusion of two Gaussians over dim x dim blocks, f32
+bool fusion_pose(const float* cov1, const float* cov2, const float* mean1, const float* mean2_in, int n, bool flip_quat, float* fused_cov,
+                 float* fused_mean) {
+    float mean2[K];
+    for (int i = 0; i < n; i++) mean2[i] = mean2_in[i];
+    if (flip_quat) {  // dim == 6 (the default argument): keep the two quaternions on one hemisphere
+        float d = 0.f;
+        for (int i = n - 4; i < n; i++) d += mean1[i] * mean2[i];
+        if ((double)d < 0.0)
+            for (int i = n - 4; i < n; i++) mean2[i] *= -1.0f;
+    }
+    float i1[K * K], i2[K * K], s[K * K];
+    if (!inverse(cov1, n, i1) || !inverse(cov2, n, i2)) return false;
+    for (int i = 0; i < n * n; i++) s[i] = i1[i] + i2[i];
+    if (!inverse(s, n, fused_cov)) return false;
+    // fused_cov * inv_cov1 * mean1 + fused_cov * inv_cov2 * mean2, evaluated left to right
+    float a[K * K], b[K * K];
+    for (int r = 0; r < n; r++)
+        for (int c = 0; c < n; c++) {
+            float x = 0.f, y = 0.f;
+            for (int k = 0; k < n; k++) { x += fused_cov[r * n + k] * i1[k * n + c]; y += fused_cov[r * n + k] * i2[k * n + c]; }
+            a[r * n + c] = x;
+            b[r * n + c] = y;
+        }
+    for (int r = 0; r < n; r++) {
+        float x = 0.f, y = 0.f;
+        for (int k = 0; k < n; k++) { x += a[r * n + k] * mean1[k]; y += b[r * n + k] * mean2[k]; }
+        fused_mean[r] = x + y;
+    }
+    return true;
+}
+
+// the 7 x 7 pose block (position, quaternion) of the filter's 23-state mean / covariance (pose_estimator.cpp:203-211)
+void imu_pose_block(const Ukf& u, float mean7[K], float cov7[K * K]) {
+    static const int idx[K] = {0, 1, 2, 6, 7, 8, 9};
+    for (int i = 0; i < K; i++) {
+        mean7[i] = u.mean[idx[i]];
+        for (int j = 0; j < K; j++) cov7[i * K + j] = u.cov[idx[i] * N + idx[j]];
+    }
+}
+// gps_mean / gps_cov of a GNSS observation (pose_estimator.cpp:219-227); noise_scale = precision, or 10 * precision for the GNSS-only match
+void gps_gaussian(const lio_gps_observation& g, double noise_scale, float mean7[K], float cov7[K * K]) {
+    float R[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = (float)g.T[i * 4 + j];
+    const Quat q = qfromR(R);  // gps_quat.normalized() discards its result: not normalised
+    for (int i = 0; i < 3; i++) mean7[i] = (float)g.T[i * 4 + 3];
+    mean7[3] = q.w; mean7[4] = q.x; mean7[5] = q.y; mean7[6] = q.z;
+    for (int i = 0; i < K * K; i++) cov7[i] = 0.f;
+    for (int i = 0; i < K; i++) cov7[i * K + i] = (i < 3 ? 0.1f : 0.05f) * (float)noise_scale;  // MatrixXf * double: Eigen casts the scalar to float first
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -338,13 +432,73 @@ int lio_pose_estimator_predict(lio_pose_estimator* e, uint64_t stamp_us, const f
     return 1;
 }
 
-// PoseEstimator::correct (pose_estimator.cpp:348-360; the INS state queue is not kept)
+// PoseEstimator::correct (pose_estimator.cpp:348-382): filter update, then the INS state queue is trimmed to the states after the
+// correction and re-predicted from the corrected mean
 int lio_pose_estimator_correct(lio_pose_estimator* e, uint64_t stamp_us, const float observation[7]) {
     if (!e || !observation) return LIO_E_INVALID;
     e->last_correction_stamp = stamp_us;
     e->prev_stamp = stamp_us;
     if (!e->ukf.correct(observation)) { e->bad = 1; return LIO_E_STATE; }
+    auto& q = e->state_queue;
+    size_t drop = 0;
+    while (drop < q.size() && q[drop].stamp <= stamp_us) drop++;
+    q.erase(q.begin(), q.begin() + drop);
+    for (size_t i = 0; i < q.size(); i++) {
+        float acc[3], gyr[3];
+        ins_units(q[i].acc_g, q[i].gyro_dps, acc, gyr);
+        if (i == 0) {
+            predict_imu(e, stamp_us, q[i].stamp, e->ukf.mean, q[i].mean, acc, gyr);
+        } else {
+            float acc0[3], gyr0[3];
+            ins_units(q[i - 1].acc_g, q[i - 1].gyro_dps, acc0, gyr0);
+            for (int k = 0; k < 3; k++) { acc[k] = (acc[k] + acc0[k]) / 2.0f; gyr[k] = (gyr[k] + gyr0[k]) / 2.0f; }  // (Vector3f + Vector3f) / 2.0
+            predict_imu(e, q[i - 1].stamp, q[i].stamp, q[i - 1].mean, q[i].mean, acc, gyr);
+        }
+    }
     return LIO_OK;
+}
+
+// PoseEstimator::predict_nostate (pose_estimator.cpp:70-86): where the filter would be at `stamp`, nothing changed but system.dt
+int lio_pose_estimator_predict_nostate(lio_pose_estimator* e, uint64_t stamp_us, double pose[16]) {
+    if (!e || !pose) return LIO_E_INVALID;
+    const double dt = ((double)stamp_us - (double)e->prev_stamp) / 1000000.0;
+    if (dt <= 0) {
+        float T[16];
+        lio_pose_estimator_matrix(e, T);
+        for (int i = 0; i < 16; i++) pose[i] = (double)T[i];
+        return 0;
+    }
+    e->ukf.system.dt = dt;
+    float ns[N];
+    e->ukf.system.f(e->ukf.mean, nullptr, ns);
+    pose_of_state(ns, pose);
+    return 1;
+}
+
+// PoseEstimator::get_timed_pose (pose_estimator.cpp:104-141): one INS / IMU sample (acceleration in g, rate in deg/s, as RTKType
+// carries them) extends the queue of states predicted past the last correction; returns 1 and the pose at that sample, 0 when it is
+// not newer than the filter / the queue
+int lio_pose_estimator_get_timed_pose(lio_pose_estimator* e, uint64_t stamp_us, const double acc_g[3], const double gyro_dps[3], double pose[16]) {
+    if (!e || !acc_g || !gyro_dps || !pose) return LIO_E_INVALID;
+    if (stamp_us <= e->prev_stamp) return 0;
+    InsState s;
+    s.stamp = stamp_us;
+    float acc[3], gyr[3];
+    for (int i = 0; i < 3; i++) { s.acc_g[i] = acc_g[i]; s.gyro_dps[i] = gyro_dps[i]; }
+    ins_units(s.acc_g, s.gyro_dps, acc, gyr);
+    if (e->state_queue.empty()) {
+        predict_imu(e, e->prev_stamp, stamp_us, e->ukf.mean, s.mean, acc, gyr);
+    } else {
+        const InsState& last = e->state_queue.back();
+        if (stamp_us <= last.stamp) return 0;
+        float acc0[3], gyr0[3];
+        ins_units(last.acc_g, last.gyro_dps, acc0, gyr0);
+        for (int i = 0; i < 3; i++) { acc[i] = (acc[i] + acc0[i]) / 2.0f; gyr[i] = (gyr[i] + gyr0[i]) / 2.0f; }  // (Vector3f + Vector3f) / 2.0
+        predict_imu(e, last.stamp, stamp_us, last.mean, s.mean, acc, gyr);
+    }
+    e->state_queue.push_back(s);
+    pose_of_state(s.mean, pose);
+    return 1;
 }
 
 int lio_pose_estimator_get(lio_pose_estimator* e, float mean23[23], float cov529[529]) {
@@ -375,41 +529,85 @@ int lio_pose_estimator_matrix(lio_pose_estimator* e, float T[16]) {
     return LIO_OK;
 }
 
-// PoseEstimator::match without GNSS (pose_estimator.cpp:188-300): align the downsampled scan from the filter's pose, gate the
-// correction at 5 m / 10 deg, keep the quaternion on the filter's hemisphere.  Returns 1 (use it), 0 (matcher did not converge or
-// the gate fired; the observation is filled all the same, as the reference corrects with it regardless), < 0 on error.
-int lio_pose_estimator_match(lio_pose_estimator* e, lio_ndt* ndt, lio_scan* source, const lio_ndt_params* params, float observation[7],
-                             int* iterations) {
-    if (!e || !ndt || !source || !observation) return LIO_E_INVALID;
-    float Tf[16];
-    lio_pose_estimator_matrix(e, Tf);
-    double guess[16], out[16];
-    for (int i = 0; i < 16; i++) guess[i] = (double)Tf[i];
-    int it = 0, conv = 0;
-    const int rc = lio_ndt_align(ndt, source, guess, params, out, &it, &conv);
-    if (rc < 0) return rc;
-    if (iterations) *iterations = it;
-    int result = conv ? 1 : 0;
-    float M[16];
-    for (int i = 0; i < 16; i++) M[i] = (float)out[i];
-    // delta = init_guess^-1 * observation (rigid inverse in f32)
-    float D[9], dtv[3];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) {
-            float s = 0.f;
-            for (int k = 0; k < 3; k++) s += Tf[k * 4 + i] * M[k * 4 + j];
-            D[i * 3 + j] = s;
+// ---- PoseEstimator::match (pose_estimator.cpp:191-302) in two host halves around the alignment -------------------------------
+// guess: the pose the matcher starts from = the filter's pose, fused with the GNSS observation when there is one (:196-247)
+int lio_pose_estimator_guess(lio_pose_estimator* e, const lio_gps_observation* gps, float init_guess[16]) {
+    if (!e || !init_guess) return LIO_E_INVALID;
+    float fm[K], fc[K * K];
+    imu_pose_block(e->ukf, fm, fc);
+    if (gps) {
+        float gm[K], gc[K * K];
+        gps_gaussian(*gps, gps->precision, gm, gc);
+        gm[2] = fm[2];  // gps_mean(2) = fused_mean(2): the height is the filter's
+        if (gps->dimension == 6) {
+            float oc[K * K], om[K];
+            if (!fusion_pose(fc, gc, fm, gm, K, true, oc, om)) return LIO_E_STATE;
+            memcpy(fm, om, sizeof(om));
+            memcpy(fc, oc, sizeof(oc));
+        } else if (gps->dimension == 2 || gps->dimension == 3) {
+            const float c1[4] = {fc[0], fc[1], fc[K], fc[K + 1]}, c2[4] = {gc[0], gc[1], gc[K], gc[K + 1]};
+            float oc[4], om[2];
+            if (!fusion_pose(c1, c2, fm, gm, 2, false, oc, om)) return LIO_E_STATE;
+            fm[0] = om[0]; fm[1] = om[1];
         }
-    for (int i = 0; i < 3; i++) {
-        float s = 0.f;
-        for (int k = 0; k < 3; k++) s += Tf[k * 4 + i] * (M[k * 4 + 3] - Tf[k * 4 + 3]);
-        dtv[i] = s;
     }
-    const float dx = sqrtf(dtv[0] * dtv[0] + dtv[1] * dtv[1] + dtv[2] * dtv[2]);
-    const Quat qd = qfromR(D);
-    const float vn = sqrtf(qd.x * qd.x + qd.y * qd.y + qd.z * qd.z);
-    const float da = 2.0f * atan2f(vn, fabsf(qd.w)) / (float)M_PI * 180.f;  // Eigen::AngleAxisf(R).angle()
-    if (dx > 5.0f || da > 10.0f) result = 0;
+    const Quat q = qnormalized({fm[3], fm[4], fm[5], fm[6]});
+    float R[9];
+    qtoR(q, R);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) init_guess[i * 4 + j] = R[i * 3 + j];
+        init_guess[i * 4 + 3] = fm[i];
+        init_guess[12 + i] = 0.f;
+    }
+    init_guess[15] = 1.f;
+    return LIO_OK;
+}
+
+// observe: what match() makes of the matcher's answer (:250-302): the 5 m / 10 deg gate (skipped with a GNSS observation), the
+// quaternion hemisphere, the fusion of the observation with the GNSS one; observation_cov is the fused covariance the reference
+// returns (the filter's pose block when there is no GNSS observation).  Returns the reference's bool.
+int lio_pose_estimator_observe(lio_pose_estimator* e, const float init_guess[16], const float aligned[16], int converged, const lio_gps_observation* gps,
+                               float observation[7], float observation_cov[49]) {
+    if (!e || !init_guess || !aligned || !observation) return LIO_E_INVALID;
+    int result = converged ? 1 : 0;
+    const float* Tf = init_guess;
+    const float* M = aligned;
+    float fm[K], fc[K * K];
+    imu_pose_block(e->ukf, fm, fc);
+    float gm[K], gc[K * K];
+    if (gps) {  // the covariance handed back starts as in the first half (:217-241)
+        gps_gaussian(*gps, gps->precision, gm, gc);
+        gm[2] = fm[2];
+        if (gps->dimension == 6) {
+            float oc[K * K], om[K];
+            if (!fusion_pose(fc, gc, fm, gm, K, true, oc, om)) return LIO_E_STATE;
+            memcpy(fc, oc, sizeof(oc));
+        } else if (gps->dimension == 2 || gps->dimension == 3) {
+            const float c1[4] = {fc[0], fc[1], fc[K], fc[K + 1]}, c2[4] = {gc[0], gc[1], gc[K], gc[K + 1]};
+            float oc[4], om[2];
+            if (!fusion_pose(c1, c2, fm, gm, 2, false, oc, om)) return LIO_E_STATE;
+            fc[0] = oc[0]; fc[1] = oc[1]; fc[K] = oc[2]; fc[K + 1] = oc[3];
+        }
+    } else {
+        // delta = init_guess^-1 * observation (general 4 x 4 inverse there; rigid here) and the gate
+        float D[9], dtv[3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                float s = 0.f;
+                for (int k = 0; k < 3; k++) s += Tf[k * 4 + i] * M[k * 4 + j];
+                D[i * 3 + j] = s;
+            }
+        for (int i = 0; i < 3; i++) {
+            float s = 0.f;
+            for (int k = 0; k < 3; k++) s += Tf[k * 4 + i] * (M[k * 4 + 3] - Tf[k * 4 + 3]);
+            dtv[i] = s;
+        }
+        const float dx = sqrtf(dtv[0] * dtv[0] + dtv[1] * dtv[1] + dtv[2] * dtv[2]);
+        const Quat qd = qfromR(D);
+        const float vn = sqrtf(qd.x * qd.x + qd.y * qd.y + qd.z * qd.z);
+        const float da = 2.0f * atan2f(vn, fabsf(qd.w)) / (float)M_PI * 180.f;  // Eigen::AngleAxisf(R).angle()
+        if (dx > 5.0f || da > 10.0f) result = 0;
+    }
     float R[9];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) R[i * 3 + j] = M[i * 4 + j];
@@ -418,7 +616,66 @@ int lio_pose_estimator_match(lio_pose_estimator* e, lio_ndt* ndt, lio_scan* sour
     if (qf.x * q.x + qf.y * q.y + qf.z * q.z + qf.w * q.w < 0.0f) { q.w = -q.w; q.x = -q.x; q.y = -q.y; q.z = -q.z; }
     observation[0] = M[3]; observation[1] = M[7]; observation[2] = M[11];
     observation[3] = q.w; observation[4] = q.x; observation[5] = q.y; observation[6] = q.z;
+    if (gps) {  // :285-299: the matcher's observation (measurement noise) fused with the GNSS one
+        if (gps->dimension == 6) {
+            float oc[K * K], om[K];
+            if (!fusion_pose(e->ukf.measurement_noise, gc, observation, gm, K, true, oc, om)) return LIO_E_STATE;
+            memcpy(observation, om, sizeof(om));
+            memcpy(fc, oc, sizeof(oc));
+        } else if (gps->dimension == 2 || gps->dimension == 3) {
+            const float* mn = e->ukf.measurement_noise;
+            const float c1[4] = {mn[0], mn[1], mn[K], mn[K + 1]}, c2[4] = {gc[0], gc[1], gc[K], gc[K + 1]};
+            float oc[4], om[2];
+            if (!fusion_pose(c1, c2, observation, gm, 2, false, oc, om)) return LIO_E_STATE;
+            observation[0] = om[0]; observation[1] = om[1];
+            fc[0] = oc[0]; fc[1] = oc[1]; fc[K] = oc[2]; fc[K + 1] = oc[3];
+        }
+    }
+    if (observation_cov) memcpy(observation_cov, fc, sizeof(fc));
     return result;
+}
+
+// the GNSS-only match (pose_estimator.cpp:304-346, used while no scan is available): a 6-D GNSS pose fused with the filter's pose block
+// at ten times its stated precision; anything else hands back the filter's pose and 0 (the reference also sleeps 100 ms there)
+int lio_pose_estimator_match_gps_only(lio_pose_estimator* e, const lio_gps_observation* gps, float observation[7], float observation_cov[49]) {
+    if (!e || !observation) return LIO_E_INVALID;
+    float fm[K], fc[K * K];
+    imu_pose_block(e->ukf, fm, fc);
+    if (!gps || gps->dimension != 6) {
+        memcpy(observation, fm, sizeof(fm));
+        return 0;
+    }
+    float gm[K], gc[K * K], oc[K * K], om[K];
+    gps_gaussian(*gps, 10 * gps->precision, gm, gc);
+    if (!fusion_pose(fc, gc, fm, gm, K, true, oc, om)) return LIO_E_STATE;
+    memcpy(observation, om, sizeof(om));
+    if (observation_cov) memcpy(observation_cov, oc, sizeof(oc));
+    return 1;
+}
+
+// PoseEstimator::match with the device matcher in the middle: guess -> lio_ndt_align -> observe.  gps == NULL: no GNSS observation.
+// Returns 1 (use it), 0 (matcher did not converge or the gate fired; the observation is filled all the same, as the reference corrects
+// with it regardless), < 0 on error.
+int lio_pose_estimator_match_gps(lio_pose_estimator* e, lio_ndt* ndt, lio_scan* source, const lio_ndt_params* params, const lio_gps_observation* gps,
+                                 float observation[7], float observation_cov[49], int* iterations) {
+    if (!e || !ndt || !source || !observation) return LIO_E_INVALID;
+    float Tf[16];
+    int rc = lio_pose_estimator_guess(e, gps, Tf);
+    if (rc < 0) return rc;
+    double guess[16], out[16];
+    for (int i = 0; i < 16; i++) guess[i] = (double)Tf[i];
+    int it = 0, conv = 0;
+    rc = lio_ndt_align(ndt, source, guess, params, out, &it, &conv);
+    if (rc < 0) return rc;
+    if (iterations) *iterations = it;
+    float M[16];
+    for (int i = 0; i < 16; i++) M[i] = (float)out[i];
+    return lio_pose_estimator_observe(e, Tf, M, conv, gps, observation, observation_cov);
+}
+
+int lio_pose_estimator_match(lio_pose_estimator* e, lio_ndt* ndt, lio_scan* source, const lio_ndt_params* params, float observation[7],
+                             int* iterations) {
+    return lio_pose_estimator_match_gps(e, ndt, source, params, nullptr, observation, nullptr, iterations);
 }
 
 }  // extern "C"

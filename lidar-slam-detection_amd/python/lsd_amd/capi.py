@@ -29,7 +29,8 @@ SYMBOLS = [
     "lio_state_boxplus", "lio_state_boxminus",
     "lio_localmap_create", "lio_localmap_destroy", "lio_localmap_add_keyframe", "lio_localmap_num_keyframes", "lio_localmap_update",
     "lio_localmap_download",
-    "lio_pose_estimator_create", "lio_pose_estimator_destroy", "lio_pose_estimator_predict", "lio_pose_estimator_match",
+    "lio_pose_estimator_create", "lio_pose_estimator_destroy", "lio_pose_estimator_predict", "lio_pose_estimator_match", "lio_pose_estimator_match_gps", "lio_pose_estimator_guess", "lio_pose_estimator_observe",
+    "lio_pose_estimator_match_gps_only", "lio_pose_estimator_get_timed_pose", "lio_pose_estimator_predict_nostate",
     "lio_pose_estimator_correct", "lio_pose_estimator_get", "lio_pose_estimator_set", "lio_pose_estimator_matrix",
     "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_ins_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
@@ -65,6 +66,10 @@ class ScanJob(C.Structure):
     _fields_ = [("d_raw", C.c_void_p), ("n_raw", C.c_uint32), ("pad", C.c_uint32), ("lidar_beg_time", C.c_double),
                 ("state_in", C.POINTER(C.c_double)), ("cov_in", C.POINTER(C.c_double)), ("state_out", C.POINTER(C.c_double)),
                 ("rc", C.c_int32), ("n_ds", C.c_int32), ("n_pass", C.c_int32), ("n_knn_pass", C.c_int32)]
+
+
+class GpsObservation(C.Structure):  # lio_gps_observation
+    _fields_ = [("T", C.c_double * 16), ("precision", C.c_double), ("dimension", C.c_int32)]
 
 
 class NdtParams(C.Structure):
@@ -162,6 +167,12 @@ def lib():
     sig("lio_pose_estimator_destroy", None, vp)
     sig("lio_pose_estimator_predict", cint, vp, u64, f32p, f32p)
     sig("lio_pose_estimator_match", cint, vp, vp, vp, C.POINTER(NdtParams), f32p, C.POINTER(cint))
+    sig("lio_pose_estimator_match_gps", cint, vp, vp, vp, C.POINTER(NdtParams), C.POINTER(GpsObservation), f32p, f32p, C.POINTER(cint))
+    sig("lio_pose_estimator_guess", cint, vp, C.POINTER(GpsObservation), f32p)
+    sig("lio_pose_estimator_observe", cint, vp, f32p, f32p, cint, C.POINTER(GpsObservation), f32p, f32p)
+    sig("lio_pose_estimator_match_gps_only", cint, vp, C.POINTER(GpsObservation), f32p, f32p)
+    sig("lio_pose_estimator_get_timed_pose", cint, vp, u64, f64p, f64p, f64p)
+    sig("lio_pose_estimator_predict_nostate", cint, vp, u64, f64p)
     sig("lio_pose_estimator_correct", cint, vp, u64, f32p)
     sig("lio_pose_estimator_get", cint, vp, f32p, f32p)
     sig("lio_pose_estimator_set", cint, vp, f32p, f32p)

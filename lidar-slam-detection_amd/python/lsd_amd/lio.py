@@ -571,6 +571,60 @@ class PoseEstimator:
         ok = check(lib().lio_pose_estimator_match(self.h, ndt.h, scan.h, C.byref(p), ptr(obs, C.c_float), C.byref(it)), "match")
         return bool(ok), obs, it.value
 
+    @staticmethod
+    def _gps(gps):
+        """gps: None or (T 4x4, precision, dimension) -> pointer to a lio_gps_observation (kept alive by the caller's frame)"""
+        if gps is None:
+            return None, None
+        g = capi.GpsObservation()
+        T = f64(gps[0]).reshape(16)
+        for i in range(16):
+            g.T[i] = T[i]
+        g.precision, g.dimension = float(gps[1]), int(gps[2])
+        return g, C.byref(g)
+
+    def guess(self, gps=None):
+        """the pose the matcher starts from: the filter's, fused with the GNSS observation when there is one"""
+        keep, gp = self._gps(gps)
+        T = np.zeros(16, np.float32)
+        check(lib().lio_pose_estimator_guess(self.h, gp, ptr(T, C.c_float)), "guess")
+        return T.reshape(4, 4)
+
+    def observe(self, init_guess, aligned, converged=True, gps=None):
+        """what match() makes of the matcher's answer: (ok, observation (7,), observation covariance (7, 7))"""
+        keep, gp = self._gps(gps)
+        a, b = f32(init_guess).reshape(16), f32(aligned).reshape(16)
+        obs, cov = np.zeros(7, np.float32), np.zeros(49, np.float32)
+        ok = check(lib().lio_pose_estimator_observe(self.h, ptr(a, C.c_float), ptr(b, C.c_float), int(converged), gp, ptr(obs, C.c_float), ptr(cov, C.c_float)), "observe")
+        return bool(ok), obs, cov.reshape(7, 7)
+
+    def match_gps(self, ndt, scan, gps, params=None):
+        keep, gp = self._gps(gps)
+        obs, cov, it = np.zeros(7, np.float32), np.zeros(49, np.float32), C.c_int(0)
+        p = params
+        if p is None:
+            p = capi.NdtParams()
+            lib().lio_ndt_default_params(C.byref(p))
+        ok = check(lib().lio_pose_estimator_match_gps(self.h, ndt.h, scan.h, C.byref(p), gp, ptr(obs, C.c_float), ptr(cov, C.c_float), C.byref(it)), "match_gps")
+        return bool(ok), obs, cov.reshape(7, 7), it.value
+
+    def match_gps_only(self, gps):
+        keep, gp = self._gps(gps)
+        obs, cov = np.zeros(7, np.float32), np.zeros(49, np.float32)
+        ok = check(lib().lio_pose_estimator_match_gps_only(self.h, gp, ptr(obs, C.c_float), ptr(cov, C.c_float)), "match_gps_only")
+        return bool(ok), obs, cov.reshape(7, 7)
+
+    def get_timed_pose(self, stamp_us, acc_g, gyro_dps):
+        """one INS sample (g, deg/s) -> (accepted, pose 4x4 at that sample); extends the state queue that correct() re-predicts"""
+        a, g, T = f64(acc_g), f64(gyro_dps), np.zeros(16)
+        ok = check(lib().lio_pose_estimator_get_timed_pose(self.h, int(stamp_us), ptr(a, C.c_double), ptr(g, C.c_double), ptr(T, C.c_double)), "get_timed_pose")
+        return bool(ok), T.reshape(4, 4)
+
+    def predict_nostate(self, stamp_us):
+        T = np.zeros(16)
+        check(lib().lio_pose_estimator_predict_nostate(self.h, int(stamp_us), ptr(T, C.c_double)), "predict_nostate")
+        return T.reshape(4, 4)
+
     def correct(self, stamp_us, observation):
         z = f32(observation)
         check(lib().lio_pose_estimator_correct(self.h, int(stamp_us), ptr(z, C.c_float)), "correct")

@@ -39,6 +39,7 @@ struct RTKType {
     int dimension = 2;
     double precision = 100.0;
     Eigen::Matrix4d T = Eigen::Matrix4d::Identity();
+    Eigen::VectorXf mean;
 };
 
 struct PoseType {

@@ -33,6 +33,8 @@ class Registration {
     void setTransformationEpsilon(double e) { transformation_epsilon_ = e; }
     Matrix4 getFinalTransformation() const { return final_transformation_; }
     bool hasConverged() const { return converged_; }
+    virtual double getFitnessScore(double /*max_range*/) { return 0.0; }  // PCL: kd-tree nearest neighbours of the aligned cloud; mocks override
+    using Ptr = std::shared_ptr<Registration<PointSource, PointTarget, Scalar>>;
     const std::string& getClassName() const { return reg_name_; }
     void align(PointCloudSource& output, const Matrix4& guess = Matrix4::Identity()) {
         converged_ = false;

@@ -1,0 +1,136 @@
+"""The localisation filter AROUND the matcher -- hdl_localization::PoseEstimator: cool time, predict with / without IMU,
+predict_nostate, the INS state queue (get_timed_pose, re-predicted by correct), match with and without a GNSS observation
+(fusion_pose in 6-D and 2-D), the 5 m / 10 deg gate, the quaternion hemisphere, the GNSS-only match -- the product's host C++
+(lio_pose_estimator_*, no GPU needed: guess / observe are the two halves of match() around the alignment) against the reference's
+OWN class compiled whole (oracle/_ref/libref_pose_estimator.so, a mock matcher returning the same prescribed poses on both sides).
+f32 filter on both sides; Eigen's dynamic 7 x 7 / 23 x 23 products sum in another order than the plain loops: tolerances."""
+import numpy as np
+import pytest
+
+import ref_pose_estimator as rp
+
+pytestmark = pytest.mark.skipif(not rp.available(), reason="oracle/_ref/libref_pose_estimator.so not built (needs /root/reference)")
+
+
+def _pose(rng, pos, yaw, jitter_t=0.0, jitter_r=0.0):
+    from lsd_amd import synth
+
+    T = np.eye(4)
+    T[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([rng.normal(0, jitter_r), rng.normal(0, jitter_r), yaw + rng.normal(0, jitter_r)]))
+    T[:3, 3] = np.asarray(pos) + rng.normal(0, jitter_t, 3) if jitter_t else pos
+    return T
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def _state_close(p, r, tol=5e-6):  # measured over the drive: 2.5e-7 (state), 8e-7 (covariance)
+    (mp, cp), (mr, cr) = p.get(), r.get()
+    assert _close(mp, mr, tol), np.abs(mp - mr).max()
+    assert _close(cp, cr, 4 * tol), np.abs(cp - cr).max()
+
+
+def test_filter_loop_with_gnss_and_ins_queue():
+    """a scripted drive: IMU-less and IMU predictions, INS samples between corrections, matcher answers with noise, every GNSS flavour
+    (none / 2-D / 3-D / 6-D, either quaternion hemisphere), a non-converged and a gated alignment"""
+    from lsd_amd import lio, synth
+
+    rng = np.random.default_rng(4)
+    imu_ext = np.eye(4, dtype=np.float32)
+    imu_ext[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0.02, -0.01, 0.3])).astype(np.float32)
+    pos0, q0 = np.array([10.0, -4.0, 1.5], np.float32), synth.quat_from_rotvec([0.0, 0.0, 0.4])
+    q0 = np.array([q0[3], q0[0], q0[1], q0[2]], np.float32)  # (x, y, z, w) -> (w, x, y, z)
+    P = lio.PoseEstimator(pos0, q0, stamp_us=1_000_000, imu_ext=imu_ext, cool_time=0.5)
+    R = rp.RefPoseEstimator(pos0, q0, stamp_us=1_000_000, imu_ext=imu_ext, cool_time=0.5)
+    _state_close(P, R, 0.0)
+    t = 1_000_000
+    yaw, pos, vel = 0.4, pos0.astype(np.float64).copy(), np.array([3.0, 1.0, 0.0])
+    gated = not_conv = 0
+    for k in range(60):
+        t += 100_000
+        yaw += 0.01
+        pos = pos + vel * 0.1
+        acc = np.array([0.3, -0.1, 9.81]) + rng.normal(0, 0.05, 3)
+        gyr = np.array([0.0, 0.0, 0.1]) + rng.normal(0, 0.01, 3)
+        use_imu = k % 5 != 0
+        P.predict(t, acc if use_imu else None, gyr if use_imu else None)
+        R.predict(t, acc if use_imu else None, gyr if use_imu else None)
+        _state_close(P, R)
+        assert _close(P.predict_nostate(t + 30_000), R.predict_nostate(t + 30_000), 2e-5)
+        assert _close(P.predict_nostate(t - 1), R.predict_nostate(t - 1), 2e-5)  # not newer than the filter: its current pose
+        # what the matcher answers
+        aligned = _pose(rng, pos, yaw, 0.03, 0.002)
+        conv = True
+        if k == 17:
+            conv, not_conv = False, not_conv + 1
+        if k == 23:
+            aligned[:3, 3] += [6.0, 0, 0]  # beyond the 5 m gate
+        if k == 31:
+            aligned[:3, :3] = aligned[:3, :3] @ synth.quat_to_R(synth.quat_from_rotvec([0, 0, 0.25]))  # beyond the 10 deg gate
+        gps = None
+        if k % 4 == 1:
+            G = _pose(rng, pos, yaw, 0.3, 0.01)
+            if k % 8 == 5:
+                G[:3, :3] = G[:3, :3] @ synth.quat_to_R(synth.quat_from_rotvec([0, 0, 2 * np.pi - 1e-3]))  # same rotation, the other way round
+            gps = (G, [100.0, 2.0, 0.5][(k // 4) % 3], [2, 3, 6][(k // 4) % 3])
+        ok_r, obs_r, cov_r, guess_r, _ = R.match(t, aligned, conv, gps, fitness=0.123)
+        guess_p = P.guess(gps)
+        assert _close(guess_p, guess_r, 2e-5), (k, np.abs(guess_p - guess_r).max())
+        ok_p, obs_p, cov_p = P.observe(guess_r, aligned, conv, gps)
+        assert ok_p == ok_r, (k, ok_p, ok_r)
+        gated += int(conv and not ok_r)
+        assert _close(obs_p, obs_r, 2e-5), (k, obs_p, obs_r)
+        assert _close(cov_p, cov_r, 1e-4), (k, np.abs(cov_p - cov_r).max())
+        # INS samples after the scan, before the correction arrives (the nodelet's ins callback)
+        for j in range(3):
+            ts = t + 20_000 * (j + 1)
+            a_g, g_dps = acc / 9.81 + rng.normal(0, 0.002, 3), np.degrees(gyr) + rng.normal(0, 0.05, 3)
+            okp, Tp = P.get_timed_pose(ts, a_g, g_dps)
+            okr, Tr = R.get_timed_pose(ts, a_g, g_dps)
+            assert okp == okr and okr and _close(Tp, Tr, 2e-5), (k, j)
+        assert P.get_timed_pose(t, acc / 9.81, np.degrees(gyr))[0] == R.get_timed_pose(t, acc / 9.81, np.degrees(gyr))[0] == False  # stale sample
+        # the correction is applied whatever match() said (the nodelet corrects regardless); queue trimmed + re-predicted
+        P.correct(t + 30_000, obs_r)
+        R.correct(t + 30_000, obs_r)
+        _state_close(P, R)
+        st, means = R.queue()
+        assert list(st) == [t + 40_000, t + 60_000]
+        okp, Tp = P.get_timed_pose(t + 80_000, acc / 9.81, np.degrees(gyr))
+        okr, Tr = R.get_timed_pose(t + 80_000, acc / 9.81, np.degrees(gyr))
+        assert okp and okr and _close(Tp, Tr, 2e-5)
+        assert _close(P.matrix(), R.matrix(), 2e-5)
+    assert gated == 2 and not_conv == 1
+    P.close()
+    R.close()
+
+
+def test_gnss_only_match_and_cool_time():
+    from lsd_amd import lio, synth
+
+    rng = np.random.default_rng(9)
+    pos0, q0 = np.array([0.0, 0.0, 0.0], np.float32), np.array([1.0, 0, 0, 0], np.float32)
+    P = lio.PoseEstimator(pos0, q0, stamp_us=5_000_000, cool_time=1.0)
+    R = rp.RefPoseEstimator(pos0, q0, stamp_us=5_000_000, cool_time=1.0)
+    for t in (5_100_000, 5_500_000, 5_900_000):  # inside the cool time: nothing moves
+        P.predict(t, [0.0, 0.0, 9.81], [0.0, 0.0, 0.2])
+        R.predict(t, [0.0, 0.0, 9.81], [0.0, 0.0, 0.2])
+        _state_close(P, R, 0.0)
+    for t in (6_100_000, 6_200_000, 7_500_000, 7_600_000):  # after it; the 1.3 s gap is refused (dt > 1)
+        P.predict(t, [0.1, 0.0, 9.81], [0.0, 0.0, 0.2])
+        R.predict(t, [0.1, 0.0, 9.81], [0.0, 0.0, 0.2])
+        _state_close(P, R)
+    for dim, expect in ((6, True), (2, False), (3, False)):
+        G = _pose(rng, [0.5, -0.2, 0.1], 0.05, 0.0, 0.0)
+        okp, op, cp = P.match_gps_only((G, 1.5, dim))
+        okr, orr, cr = R.match_gps_only((G, 1.5, dim))
+        assert okp == okr == expect
+        assert _close(op, orr, 2e-5)
+        if expect:
+            assert _close(cp, cr, 1e-4)
+    okp, op, _ = P.match_gps_only(None)
+    okr, orr, _ = R.match_gps_only(None)
+    assert not okp and not okr and _close(op, orr, 1e-6)
+    P.close()
+    R.close()
