@@ -129,7 +129,19 @@ def test_pose_estimator_loop_tracks_a_drive(scene):
         raw, _ = synth.make_scan(scene, tr.pos(tb), tr.quat(tb), seed=k, n_az=900, fov_deg=(-24.8, 2.0))
         scan.upload(raw)
         scan.voxel_downsample(0.2)
-        ok, obs, it = est.match(ndt, scan)
+        if k % 3 == 0:
+            # a GNSS observation of this frame (6-D, then 2-D): match_gps = guess -> lio_ndt_align -> observe, the same three calls by hand
+            Tg = np.eye(4)
+            Tg[:3, :3], Tg[:3, 3] = tr.R(tb), tr.pos(tb) + [0.2, -0.1, 0.0]
+            gps = (Tg, 1.0, 6 if k % 6 == 0 else 2)
+            G = est.guess(gps)
+            Ta, conv, it2 = ndt.align(scan, G.astype(np.float64))
+            ok2, obs2, cov2 = est.observe(G, Ta.astype(np.float32), conv, gps)
+            ok, obs, cov, it = est.match_gps(ndt, scan, gps)
+            assert ok == ok2 and it == it2 and np.array_equal(obs, obs2) and np.array_equal(cov, cov2)
+            assert np.linalg.norm(obs[:3] - tr.pos(tb)) < 0.3
+        else:
+            ok, obs, it = est.match(ndt, scan)
         n_ok += int(ok)
         est.correct(int(round(tb * 1e6)), obs)
         T = est.matrix()
