@@ -1176,7 +1176,7 @@ struct Lio {
     double blind = 0.1;
     V3 Lidar_T{{0, 0, 0}};
     Quat Lidar_R{0, 0, 0, 1};
-    int point_filter_num = 1;
+    int point_filter_num = 1, max_point_num = -1;
     std::vector<P4> feats_undistort;
     State odom_start, odom_end;  // states before / after the scan (fastlio_odometry)
 
@@ -1191,6 +1191,7 @@ struct Lio {
     void pcl_enqueue(const P4* pts, const uint32_t* t_us, int n, double stamp) {
         ScanIn sc;
         sc.beg = stamp;
+        if (max_point_num > 0) point_filter_num = std::max(1, n / max_point_num);  // preprocess.cpp:396-398: overwrites the member
         for (int i = 0; i < n; i++) {
             const P4& p = pts[i];
             if (i % point_filter_num == 0 && (double)(p.x * p.x + p.y * p.y + p.z * p.z) > blind * blind) {
@@ -1714,6 +1715,7 @@ void orc_lio_frontend_config(void* h, const double* extT, const double* extR_xyz
     l->lidar_mean_scantime = scan_period;
     l->undistort_en = undistort != 0;
 }
+void orc_lio_set_max_point_num(void* h, int n) { static_cast<Lio*>(h)->max_point_num = n; }  // p_pre->max_point_num (laserMapping.cpp:1100)
 void orc_lio_ins_enqueue(void* h, double stamp, const double* v) { static_cast<Lio*>(h)->ins_buffer.push_back({stamp, V3{{v[0], v[1], v[2]}}}); }
 int orc_lio_frontend_main(void* h) { return static_cast<Lio*>(h)->frontend_main(); }
 void orc_lio_predict(void* h, double dt, const double* acc, const double* gyro) {

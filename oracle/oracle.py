@@ -85,6 +85,7 @@ def lib():
     L.orc_lio_get_undistorted.restype = C.c_int
     L.orc_lio_get_odometry.argtypes = [C.c_void_p, f64p, f64p]
     L.orc_lio_is_init.argtypes = [C.c_void_p]
+    L.orc_lio_set_max_point_num.argtypes = [C.c_void_p, C.c_int]
     L.orc_undistort_delta.argtypes = [f32p, f32p, C.POINTER(C.c_uint32), C.c_int, C.c_double]
     L.orc_lio_get_ds_world.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_kf_update_cb.argtypes = [f64p, f64p, C.c_double, C.c_int, MEAS_FN, C.c_void_p, C.c_int, f64p, f64p]
@@ -277,9 +278,10 @@ class Lio:
         p, t = _f32(xyzi).reshape(-1, 4), np.ascontiguousarray(t_us, np.uint32)
         lib().orc_lio_pcl_enqueue(self.h, _p(p, C.c_float), _p(t, C.c_uint32), len(p), float(stamp))
 
-    def frontend_config(self, extT=(0, 0, 0), extR_xyzw=(0, 0, 0, 1), filter_num=1, scan_period=0.1, undistort=True):
+    def frontend_config(self, extT=(0, 0, 0), extR_xyzw=(0, 0, 0, 1), filter_num=1, scan_period=0.1, undistort=True, max_point_num=-1):
         t, r = _f64(extT), _f64(extR_xyzw)
         lib().orc_lio_frontend_config(self.h, _p(t, C.c_double), _p(r, C.c_double), filter_num, float(scan_period), int(undistort))
+        lib().orc_lio_set_max_point_num(self.h, int(max_point_num))
 
     def ins_enqueue(self, stamp, vel_imu):
         v = _f64(vel_imu)

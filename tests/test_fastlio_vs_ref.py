@@ -35,15 +35,16 @@ def _sweep(scene, tr, k, distinct):
     return pts, st.astype(np.uint32)
 
 
-def _drive(oracle_mod, scene, n_scans, canonical, distinct=True, on_scan=None):
+def _drive(oracle_mod, scene, n_scans, canonical, distinct=True, on_scan=None, filter_num=1, max_point_num=-1, undistort=True, extT=(0, 0, 0), ext_rotvec=None):
     """the same IMU stream and sweeps into the reference and the oracle; returns per scan (oracle rc, reference state, oracle state)"""
     from lsd_amd import synth
 
     tr = synth.Trajectory()
     imu = synth.imu_stream(tr, 0.0, n_scans * 0.1 + 0.2, rate=200.0)
     L = oracle_mod.Lio()
-    L.frontend_config(scan_period=0.1)
-    R = ref_fastlio.RefFastLio(scan_period=0.1)
+    q_ext = synth.quat_from_rotvec(ext_rotvec) if ext_rotvec is not None else np.array([0, 0, 0, 1.0])
+    L.frontend_config(extT=extT, extR_xyzw=q_ext, filter_num=filter_num, scan_period=0.1, undistort=undistort, max_point_num=max_point_num)
+    R = ref_fastlio.RefFastLio(extT=extT, extR=synth.quat_to_R(q_ext), filter_num=filter_num, max_point_num=max_point_num, scan_period=0.1, undistort=undistort)
     R.set_canonical(canonical)
     ii, out = 0, []
     for k in range(n_scans):
@@ -234,3 +235,26 @@ def test_registration_against_a_static_map(oracle_mod, small_world):
         assert rc == 3 and len(calls) == len(o.pass_logs()) and [c["n_eff"] for c in calls][0] == o.pass_logs()[0]["n_eff"]
         assert np.abs(sr - so).max() < tol_s and np.abs(Pr - Po).max() < tol_P, (canonical, np.abs(sr - so).max(), np.abs(Pr - Po).max())
         assert synth.quat_angle(sr[3:7], so[3:7]) < max(tol_s, 1e-7)
+
+
+@pytest.mark.parametrize("cfg", [dict(filter_num=3), dict(max_point_num=5000), dict(undistort=False), dict(extT=(0.05, -0.02, 0.1), ext_rotvec=(0.01, -0.02, 0.03))])
+def test_front_half_configurations(oracle_mod, scene, cfg):
+    """the knobs of fastlio_init: point decimation by a fixed stride and by a point budget (velodyne_handler), motion compensation off,
+    a lidar -> IMU extrinsic -- same bit-exact agreement through IMU init and the seeding scan, same first update"""
+
+    def on_scan(k, L, R, o):
+        if k <= 6:
+            assert np.array_equal(o["ref"], o["orc"]) and np.array_equal(o["ref_P"], o["orc_P"]), (cfg, k)
+            uo, ur = L.get_undistorted(), R.undistorted()
+            assert len(uo) == len(ur) and np.array_equal(uo, ur[:, :4]), (cfg, k)
+        if k == 6:
+            assert np.array_equal(R.down_body(), L.get_ds()) and R.map_voxels() == L.map_num_voxels
+            n_full = 32 * 600
+            if "filter_num" in cfg:
+                assert len(L.get_undistorted()) <= n_full // 3 + 1
+            if "max_point_num" in cfg:
+                assert len(L.get_undistorted()) <= n_full // (n_full // 5000) + 1
+
+    _, L, R, out = _drive(oracle_mod, scene, 8, canonical=True, on_scan=on_scan, **cfg)
+    assert [o["rc"] for o in out] == [0, 4, 4, 4, 4, 4, 1, 3]
+    assert np.abs(out[7]["ref"] - out[7]["orc"]).max() < 1e-13
