@@ -258,18 +258,6 @@ __device__ inline uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ inline unsigned long long umin64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
-__device__ inline unsigned long long umax64(unsigned long long a, unsigned long long b) { return a < b ? b : a; }
-
-__device__ inline unsigned long long group_min64(unsigned long long v) {
-#pragma unroll
-    for (int off = kG / 2; off > 0; off >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)v, off, kG), hi = __shfl_xor((uint32_t)(v >> 32), off, kG);
-        v = umin64(v, ((unsigned long long)hi << 32) | lo);
-    }
-    return v;
-}
-
 // An upper bound of the squared distance of the query's fifth nearest candidate, from what the lanes hold so far: any lane's own fifth
 // (its five entries are five candidates at most that far), and the fifth smallest of the lanes' nearest (five candidates in five
 // lanes; equal values are counted once, which can only loosen the bound).  0xFFFFFFFF while fewer than five candidates are known.
