@@ -7,9 +7,67 @@ f32 filter on both sides; Eigen's dynamic 7 x 7 / 23 x 23 products sum in anothe
 import numpy as np
 import pytest
 
+import os
+
 import ref_pose_estimator as rp
 
-pytestmark = pytest.mark.skipif(not rp.available(), reason="oracle/_ref/libref_pose_estimator.so not built (needs /root/reference)")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_estimator.npz")
+needs_ref = pytest.mark.skipif(not rp.available(), reason="oracle/_ref/libref_pose_estimator.so not built (needs /root/reference)")
+
+# ---- record / replay of the reference object: the two scripted drives below talk to `R` only through its methods, so the answers of the
+# real class (recorded by tools/make_golden.py into tests/golden/pose_estimator.npz) can stand in for it where /root/reference is absent
+_SHAPES = {"predict": None, "correct": None, "close": None, "predict_nostate": [(4, 4)], "matrix": [(4, 4)], "get": [(23,), (23, 23)],
+           "match": [(), (7,), (7, 7), (4, 4), ()], "get_timed_pose": [(), (4, 4)], "match_gps_only": [(), (7,), (7, 7)], "queue": "queue"}
+
+
+class Recorder:
+    def __init__(self, obj):
+        self.obj, self.log = obj, []
+
+    def __getattr__(self, name):
+        def call(*a, **k):
+            r = getattr(self.obj, name)(*a, **k)
+            if _SHAPES[name] == "queue":
+                self.log.append(np.r_[len(r[0]), np.asarray(r[0], np.float64), np.asarray(r[1], np.float64).reshape(-1)])
+            elif _SHAPES[name] is not None:
+                parts = r if isinstance(r, tuple) else (r,)
+                self.log.append(np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in parts]))
+            return r
+
+        return call
+
+
+class Replayer:
+    def __init__(self, flat, offsets):
+        self.flat, self.off, self.i = flat, offsets, 0
+
+    def __getattr__(self, name):
+        def call(*a, **k):
+            if _SHAPES[name] is None:
+                return None
+            v = self.flat[self.off[self.i]:self.off[self.i + 1]]
+            self.i += 1
+            if _SHAPES[name] == "queue":
+                n = int(v[0])
+                return v[1:1 + n].astype(np.uint64), v[1 + n:].reshape(n, 23).astype(np.float32)
+            out, p = [], 0
+            for sh in _SHAPES[name]:
+                k = int(np.prod(sh)) if sh else 1
+                x = v[p:p + k]
+                out.append(bool(x[0]) if sh == () and name != "match" or (sh == () and len(out) == 0) else (float(x[0]) if sh == () else x.reshape(sh)))
+                p += k
+            return out[0] if len(out) == 1 else tuple(out)
+
+        return call
+
+
+def _make_R(mode, key, *args, **kw):
+    """mode: 'live' (the reference's class), 'record' (same, logging its answers), 'replay' (the recorded answers)"""
+    if mode == "replay":
+        g = np.load(GOLD)
+        return Replayer(g[key + "_flat"], g[key + "_off"])
+    R = rp.RefPoseEstimator(*args, **kw)
+    return Recorder(R) if mode == "record" else R
 
 
 def _pose(rng, pos, yaw, jitter_t=0.0, jitter_r=0.0):
@@ -32,7 +90,7 @@ def _state_close(p, r, tol=5e-6):  # measured over the drive: 2.5e-7 (state), 8e
     assert _close(cp, cr, 4 * tol), np.abs(cp - cr).max()
 
 
-def test_filter_loop_with_gnss_and_ins_queue():
+def drive_filter_loop(mode):
     """a scripted drive: IMU-less and IMU predictions, INS samples between corrections, matcher answers with noise, every GNSS flavour
     (none / 2-D / 3-D / 6-D, either quaternion hemisphere), a non-converged and a gated alignment"""
     from lsd_amd import lio, synth
@@ -43,7 +101,7 @@ def test_filter_loop_with_gnss_and_ins_queue():
     pos0, q0 = np.array([10.0, -4.0, 1.5], np.float32), synth.quat_from_rotvec([0.0, 0.0, 0.4])
     q0 = np.array([q0[3], q0[0], q0[1], q0[2]], np.float32)  # (x, y, z, w) -> (w, x, y, z)
     P = lio.PoseEstimator(pos0, q0, stamp_us=1_000_000, imu_ext=imu_ext, cool_time=0.5)
-    R = rp.RefPoseEstimator(pos0, q0, stamp_us=1_000_000, imu_ext=imu_ext, cool_time=0.5)
+    R = _make_R(mode, "loop", pos0, q0, stamp_us=1_000_000, imu_ext=imu_ext, cool_time=0.5)
     _state_close(P, R, 0.0)
     t = 1_000_000
     yaw, pos, vel = 0.4, pos0.astype(np.float64).copy(), np.array([3.0, 1.0, 0.0])
@@ -104,15 +162,16 @@ def test_filter_loop_with_gnss_and_ins_queue():
     assert gated == 2 and not_conv == 1
     P.close()
     R.close()
+    return R
 
 
-def test_gnss_only_match_and_cool_time():
+def drive_gnss_only(mode):
     from lsd_amd import lio, synth
 
     rng = np.random.default_rng(9)
     pos0, q0 = np.array([0.0, 0.0, 0.0], np.float32), np.array([1.0, 0, 0, 0], np.float32)
     P = lio.PoseEstimator(pos0, q0, stamp_us=5_000_000, cool_time=1.0)
-    R = rp.RefPoseEstimator(pos0, q0, stamp_us=5_000_000, cool_time=1.0)
+    R = _make_R(mode, "gnss", pos0, q0, stamp_us=5_000_000, cool_time=1.0)
     for t in (5_100_000, 5_500_000, 5_900_000):  # inside the cool time: nothing moves
         P.predict(t, [0.0, 0.0, 9.81], [0.0, 0.0, 0.2])
         R.predict(t, [0.0, 0.0, 9.81], [0.0, 0.0, 0.2])
@@ -134,3 +193,28 @@ def test_gnss_only_match_and_cool_time():
     assert not okp and not okr and _close(op, orr, 1e-6)
     P.close()
     R.close()
+    return R
+
+
+@needs_ref
+def test_filter_loop_with_gnss_and_ins_queue():
+    drive_filter_loop("live")
+
+
+@needs_ref
+def test_gnss_only_match_and_cool_time():
+    drive_gnss_only("live")
+
+
+def test_replay_of_the_recorded_reference():
+    """the same two drives against the answers recorded from the reference's class (tests/golden/pose_estimator.npz): runs wherever the
+    repository does, /root/reference or not.  predict_imu's `dt_smooth` is a process-wide static in the reference and here: the replay
+    needs the history of the recording (a fresh process, loop drive first), hence the subprocess."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path[:0] = %r; import test_pose_estimator_vs_ref as t; t.drive_filter_loop('replay'); t.drive_gnss_only('replay'); print('replayed')"
+            % [here, os.path.join(here, "..", "oracle"), os.path.join(here, "..", "lidar-slam-detection_amd", "python")])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "replayed" in r.stdout, r.stderr[-3000:]

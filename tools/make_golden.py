@@ -13,6 +13,7 @@ Provenance of every expected output is recorded in the file ("source" field):
   * ukf.npz ........................... the reference's UKF + pose system (oracle/_ref/libref_ukf.so)
   * fastlio_drive.npz ................. the reference's whole FastLIO translation units (oracle/_ref/libref_fastlio.so)
   * undistort_delta.npz ............... the reference's slam_utils.cpp undistortPoints (oracle/_ref/libref_slam_utils.so)
+  * pose_estimator.npz ................ the reference's hdl_localization::PoseEstimator (oracle/_ref/libref_pose_estimator.so)
 """
 import os
 import sys
@@ -95,8 +96,27 @@ def slam_utils():
                         source="slam/common/slam_utils.cpp:163-191 compiled whole from /root/reference (oracle/ref_slam_utils.cpp); pcl::transformPoint = PCL 1.9.1's one-liner")
 
 
+def pose_estimator():
+    """the answers of the reference's hdl_localization::PoseEstimator (oracle/_ref/libref_pose_estimator.so) to the two scripted drives of
+    tests/test_pose_estimator_vs_ref.py, in call order"""
+    import test_pose_estimator_vs_ref as tp
+
+    if not tp.rp.available():
+        raise SystemExit("oracle/_ref/libref_pose_estimator.so missing: run `make -C oracle ref` where /root/reference is mounted")
+    out = {}
+    for key, fn in (("loop", tp.drive_filter_loop), ("gnss", tp.drive_gnss_only)):  # this order: predict_imu's static dt_smooth carries over
+        rec = fn("record")
+        out[key + "_flat"] = np.concatenate(rec.log)
+        out[key + "_off"] = np.cumsum([0] + [len(v) for v in rec.log])
+    np.savez_compressed(os.path.join(OUT, "pose_estimator.npz"), **out,
+                        source="hdl_localization/src/pose_estimator.cpp compiled whole from /root/reference (oracle/ref_pose_estimator.cpp), mock matcher")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "pose_estimator":
+        pose_estimator()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fastlio":
         fastlio_drive()
         return
@@ -199,6 +219,7 @@ def main():
                         source="kkl/alg/unscented_kalman_filter.hpp + hdl_localization/pose_system.hpp compiled from /root/reference (oracle/ref_ukf.cpp)")
     fastlio_drive()
     slam_utils()
+    pose_estimator()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
