@@ -22,7 +22,8 @@
 // sums run in input order, per-pair terms are f32 as in the reference but summed in f64 in (offset, point) order --
 // and is pinned where real reference code can be compiled: so3.hpp's se3_exp and Eigen's computeDirect / 3x3 inverse
 // through oracle/_ref (tests/test_ndt_oracle_vs_ref.py).  The rest of this file is unpinned on its own; it agrees with the HIP
-// path (tests/test_ndt_gpu.py), which agrees with the reference's kernels to the reference's own run-to-run spread.
+// path (tests/test_ndt_gpu.py), which agrees with the reference's kernels to the reference's own run-to-run spread; and it is held
+// against results recorded from those kernels (tests/golden/ndt_ref_cuda.npz, tests/test_ndt_oracle_vs_ref_golden.py).
 // The 50 ms wall-clock timeout of the reference's LM loop (lsq_registration_impl.hpp:94-104) is not modelled.
 // =============================================================================
 #include <cmath>
