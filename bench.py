@@ -222,9 +222,29 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # the device's own copy rate (report the fraction of the nominal AND of a measured peak): 1 GiB device-to-device copies,
+    # read + write counted, torch events on torch's stream (nothing of the hot path is in flight here)
+    copy_peak = None
+    try:
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_peak = round(2.0 * nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
+    except Exception:
+        copy_peak = None
     roofline = dict(bound="hbm", kernel="knn_kernel<2, 0> (16 lanes per query)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, algorithmic_bytes_per_launch=int(iso_bytes),
                     avg_launch_us=round(iso_us, 2), launches=iso_launches,
+                    measured_copy_peak=copy_peak, frac_of_measured_copy_peak=(round(achieved / copy_peak, 4) if copy_peak else None),
                     timed_region={"avg_launch_us": round(knn_us, 2), "launches": launches, "achieved": round(shared, 1),
                                   "frac": round(shared / HBM_PEAK_GBS, 4), "streams": n_streams},
                     other_kernels_us={"linearize+report": round(kt["linearize_us"] / max(kt["linearize_launches"], 1), 2)})
