@@ -110,6 +110,13 @@ int lio_scan_set_device(lio_scan*, const void* d_body_xyzi, uint32_t n_raw);    
  * device cloud given by lio_scan_set_device is not written).  lio_scan_download_raw returns the point count. */
 int lio_scan_undistort_delta(lio_scan*, const uint32_t* stamp_us, int stamps_on_device, const float delta_pose[16], double scan_period);
 int lio_scan_download_raw(lio_scan*, float* out_xyzi, uint32_t cap);
+/* undistortPoints(std::vector<PoseType>& poses, PointCloudAttrPtr&)   slam/common/slam_utils.cpp:193-228 (graph back end and map export: the
+ * cloud compensated with a LIST of poses, e.g. the IMU poses of a frame): poses[i] = (absolute stamp us, motion T since poses[0], row-major
+ * 4 x 4), i = 0 is the scan start; a point uses the first pose interval, from the one its predecessor used onwards, that ends
+ * (pose_stamp[i] - header_stamp, unsigned) not before its stamp; points past the last pose, and everything after them, are left alone.
+ * The interval ends must not decrease (LIO_E_INVALID otherwise); at most 64 poses. */
+int lio_scan_undistort_poses(lio_scan*, const uint32_t* stamp_us, int stamps_on_device, uint64_t header_stamp_us, const uint64_t* pose_stamp_us,
+                             const double* pose_T, uint32_t n_poses);
 int lio_scan_voxel_downsample(lio_scan*, float leaf, int sync, uint32_t* n_ds);
 /* bypass the filter: use these points as feats_down_body (tests, staged pipelines) */
 int lio_scan_set_ds(lio_scan*, const float* ds_body_xyzi, uint32_t n_ds);

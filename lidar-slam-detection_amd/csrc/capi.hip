@@ -535,6 +535,37 @@ int lio_scan_undistort_delta(lio_scan* s, const uint32_t* stamp_us, int stamps_o
     return LIO_OK;
 }
 
+int lio_scan_undistort_poses(lio_scan* s, const uint32_t* stamp_us, int stamps_on_device, uint64_t header_stamp_us, const uint64_t* pose_stamp_us,
+                             const double* pose_T, uint32_t n_poses) {
+    if (!s || !pose_stamp_us || !pose_T || (!stamp_us && s->n_raw)) return LIO_E_INVALID;
+    if (n_poses > (uint32_t)kMaxPoseList) { set_error("undistort: %u poses (at most %d)", n_poses, kMaxPoseList); return LIO_E_CAPACITY; }
+    if (s->n_raw == 0 || n_poses < 2) return LIO_OK;  // no interval: the reference's loop body never runs
+    PoseListArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n_poses = (int)n_poses;
+    for (uint32_t i = 1; i < n_poses; i++) {
+        A.limit[i] = pose_stamp_us[i] - header_stamp_us;  // unsigned, as there: a pose before the header stamp "never ends"
+        if (i > 1 && A.limit[i] < A.limit[i - 1]) {
+            set_error("undistort: the pose intervals must not end earlier than their predecessors (pose %u)", i);
+            return LIO_E_INVALID;
+        }
+        float D[16];
+        for (int k = 0; k < 16; k++) D[k] = (float)pose_T[16 * (size_t)i + k];  // poses[i].T.cast<float>()
+        delta_pose_args(D, (double)(pose_stamp_us[i] - pose_stamp_us[0]) / 1000000.0, A.d[i]);
+    }
+    hipSetDevice(s->device);
+    const uint32_t* d_stamp = stamp_us;
+    if (!stamps_on_device) {
+        LIO_HIP_TRY(hipMemcpyAsync(s->keys_b, stamp_us, (size_t)s->n_raw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        d_stamp = s->keys_b;
+    }
+    const int rc = undistort_poses_launch(s->stream, s->raw, d_stamp, s->n_raw, s->raw_own, A, s->keys_a);  // keys_a: free until the downsample
+    if (rc != LIO_OK) return rc;
+    s->raw = s->raw_own;
+    if (!stamps_on_device) LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    return LIO_OK;
+}
+
 int lio_scan_download_raw(lio_scan* s, float* out_xyzi, uint32_t cap) {
     if (!s || !out_xyzi) return LIO_E_INVALID;
     if (s->n_raw > cap) { set_error("raw cloud of %u points exceeds cap %u", s->n_raw, cap); return LIO_E_CAPACITY; }

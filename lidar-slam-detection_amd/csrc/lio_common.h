@@ -190,6 +190,14 @@ struct DeltaArgs {  // undistortPoints(delta_pose, ...): delta translation, angl
     float aa[3];
     double scan_period;
 };
+constexpr int kMaxPoseList = 64;
+struct PoseListArgs {  // undistortPoints(poses, points): interval ends (unsigned us since the header stamp) and the motion of every pose since poses[0]
+    int n_poses;
+    unsigned long long limit[kMaxPoseList];
+    DeltaArgs d[kMaxPoseList];
+};
+int undistort_poses_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const PoseListArgs& args,
+                           uint32_t* d_tile_max);
 int undistort_delta_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const DeltaArgs& args);
 int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const ImuPoseDev* d_poses,
                      const UndistortArgs& args, unsigned long long* d_block_min /* ceil(n / 256) words of scratch */);

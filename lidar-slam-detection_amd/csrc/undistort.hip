@@ -196,12 +196,8 @@ __global__ void __launch_bounds__(64) undistort_first_kernel(float4* out, const 
 // slam/common/slam_utils.cpp:163-191.  Everything is f32 as in the reference (Eigen Matrix<float,6,1> / AngleAxisf / Quaternionf /
 // Affine3f, pcl::transformPoint); sums follow Eigen's fixed-size orders x0 + (x1 + x2) and (x0 + x1) + (x2 + x3).  sin / cos of the half angle are evaluated in
 // f64 and rounded to f32, which is what a correctly rounded sinf / cosf returns except within ~1e-8 of a rounding boundary.
-__global__ __launch_bounds__(kThreads) void undistort_delta_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ stamp_us, uint32_t n,
-                                                                   float4* __restrict__ out, DeltaArgs A) {
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = in[i];
-    const float ratio = (float)(((double)stamp_us[i] / 1000000.0) / A.scan_period);  // float t_diff_ratio = (stamp / 1000000.0) / scan_period
+__device__ inline float4 delta_point(const float4 p, uint32_t stamp, const DeltaArgs& A) {
+    const float ratio = (float)(((double)stamp / 1000000.0) / A.scan_period);  // float t_diff_ratio = (stamp / 1000000.0) / scan_period
     const float tx = ratio * A.t[0], ty = ratio * A.t[1], tz = ratio * A.t[2];
     const float wx = ratio * A.aa[0], wy = ratio * A.aa[1], wz = ratio * A.aa[2];
     const float norm = sqrtf(wx * wx + (wy * wy + wz * wz));
@@ -225,7 +221,91 @@ __global__ __launch_bounds__(kThreads) void undistort_delta_kernel(const float4*
     o.x = (r00 * p.x + r01 * p.y) + (r02 * p.z + tx);
     o.y = (r10 * p.x + r11 * p.y) + (r12 * p.z + ty);
     o.z = (r20 * p.x + r21 * p.y) + (r22 * p.z + tz);
-    out[i] = o;
+    return o;
+}
+
+__global__ __launch_bounds__(kThreads) void undistort_delta_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ stamp_us, uint32_t n,
+                                                                   float4* __restrict__ out, DeltaArgs A) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    out[i] = delta_point(in[i], stamp_us[i], A);
+}
+
+// ---- the pose-list variant, undistortPoints(std::vector<PoseType>&, PointCloudAttrPtr&) of slam_utils.cpp:193-228 ---------------------
+// The reference walks the cloud once: a point is compensated with the first pose interval, from the one the previous point used onwards,
+// whose end (poses[i].timestamp - header.stamp, unsigned) is not before its stamp.  With interval ends that do not decrease that is
+// seg(idx) = max over j <= idx of need(j), need(j) = first interval whose end is not before stamp j: a prefix maximum.
+// Kernel 1: maxima of need() per tile of 2048 points.  Kernel 2: prefix over the tiles before, ordered in-tile prefix, transform.
+constexpr int kPoseItems = 8;
+constexpr int kPoseTile = kThreads * kPoseItems;
+
+__device__ inline uint32_t pose_need(uint32_t stamp, const PoseListArgs& A) {
+    uint32_t i = 1;
+    while (i < (uint32_t)A.n_poses && (unsigned long long)stamp > A.limit[i]) i++;
+    return i;  // == n_poses: past the last pose
+}
+
+__global__ __launch_bounds__(kThreads) void undistort_poses_need_kernel(const uint32_t* __restrict__ stamp_us, uint32_t n, PoseListArgs A,
+                                                                        uint32_t* __restrict__ tile_max) {
+    const uint32_t base = blockIdx.x * kPoseTile;
+    uint32_t mx = 0;
+#pragma unroll
+    for (int r = 0; r < kPoseItems; r++) {
+        const uint32_t i = base + r * kThreads + threadIdx.x;
+        if (i < n) mx = max(mx, pose_need(stamp_us[i], A));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    __shared__ uint32_t w[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_max[blockIdx.x] = max(max(w[0], w[1]), max(w[2], w[3]));
+}
+
+__global__ __launch_bounds__(kThreads) void undistort_poses_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ stamp_us, uint32_t n,
+                                                                   float4* __restrict__ out, PoseListArgs A, const uint32_t* __restrict__ tile_max) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // segment reached by the tiles before this one
+    uint32_t pre = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += kThreads) pre = max(pre, tile_max[b]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre = max(pre, __shfl_xor(pre, off));
+    __shared__ uint32_t wred[kThreads / 64], wtot[kThreads / 64];
+    if (lane == 0) wred[wave] = pre;
+    __syncthreads();
+    pre = max(max(wred[0], wred[1]), max(wred[2], wred[3]));
+    // thread t owns kPoseItems CONSECUTIVE points, so that (thread, item) order is the cloud's order
+    const uint32_t base = blockIdx.x * kPoseTile + tid * kPoseItems;
+    uint32_t need[kPoseItems], stamp[kPoseItems], mine = 0;
+#pragma unroll
+    for (int r = 0; r < kPoseItems; r++) {
+        const uint32_t i = base + r;
+        stamp[r] = i < n ? stamp_us[i] : 0u;
+        need[r] = i < n ? pose_need(stamp[r], A) : 0u;
+        mine = max(mine, need[r]);
+    }
+    // exclusive prefix maximum over the threads of the tile: inclusive wave scan, shifted, plus the waves before
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc = max(inc, t);
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t run = __shfl_up(inc, 1);
+    if (lane == 0) run = 0;
+    for (int w = 0; w < wave; w++) run = max(run, wtot[w]);
+    run = max(run, pre);
+#pragma unroll
+    for (int r = 0; r < kPoseItems; r++) {
+        const uint32_t i = base + r;
+        if (i >= n) break;
+        run = max(run, need[r]);
+        float4 p = in[i];
+        if (run < (uint32_t)A.n_poses) p = delta_point(p, stamp[r], A.d[run]);
+        out[i] = p;
+    }
 }
 
 }  // namespace
@@ -233,6 +313,16 @@ __global__ __launch_bounds__(kThreads) void undistort_delta_kernel(const float4*
 int undistort_delta_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const DeltaArgs& args) {
     if (n == 0) return LIO_OK;
     hipLaunchKernelGGL(undistort_delta_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, d_in, d_stamp_us, n, d_out, args);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+int undistort_poses_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_stamp_us, uint32_t n, float4* d_out, const PoseListArgs& args,
+                           uint32_t* d_tile_max /* ceil(n / 2048) words */) {
+    if (n == 0) return LIO_OK;
+    const uint32_t tiles = (n + kPoseTile - 1) / kPoseTile;
+    hipLaunchKernelGGL(undistort_poses_need_kernel, dim3(tiles), dim3(kThreads), 0, stream, d_stamp_us, n, args, d_tile_max);
+    hipLaunchKernelGGL(undistort_poses_kernel, dim3(tiles), dim3(kThreads), 0, stream, d_in, d_stamp_us, n, d_out, args, d_tile_max);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

@@ -151,6 +151,13 @@ class Scan:
             sp = C.c_void_p(self._stamps.ctypes.data)
         check(lib().lio_scan_undistort_delta(self.h, sp, int(on_device), d.ctypes.data_as(C.POINTER(C.c_float)), float(scan_period)), "undistort_delta")
 
+    def undistort_poses(self, stamp_us, header_stamp_us, pose_stamps_us, pose_T):
+        """undistortPoints(poses, points) of slam_utils.cpp:193-228 on the uploaded cloud (host stamps)"""
+        self._stamps = np.ascontiguousarray(stamp_us, np.uint32)
+        ps, pt = np.ascontiguousarray(pose_stamps_us, np.uint64), np.ascontiguousarray(pose_T, np.float64).reshape(-1, 16)
+        check(lib().lio_scan_undistort_poses(self.h, C.c_void_p(self._stamps.ctypes.data), 0, int(header_stamp_us), ps.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             pt.ctypes.data_as(C.POINTER(C.c_double)), len(ps)), "undistort_poses")
+
     def download_raw(self, cap=1 << 18):
         out = np.zeros((cap, 4), np.float32)
         n = lib().lio_scan_download_raw(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), cap)

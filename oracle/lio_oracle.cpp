@@ -1740,7 +1740,10 @@ void orc_lio_get_odometry(void* h, double* s26_start, double* s26_end) {
 // stableNorm below epsilon: StableNorm.h:18-50 on one dynamic 3-segment, summed in sequence).  Per point: r = (stamp / 1e6) / period as float,
 // log = r * [t; angle * axis], rotation = Quaternionf(AngleAxisf(|w|, w / |w|)).toRotationMatrix(), p' = [R t] [p; 1] (Transform * vector is the
 // 3x4 affine part times the homogeneous vector: fixed-size sum of four terms (x0 + x1) + (x2 + x3); pcl::transformPoint of PCL 1.9.1).
-void orc_undistort_delta(const float* D, float* xyzi, const uint32_t* stamp_us, int n, double scan_period) {
+struct DeltaMotion {  // what undistortPoints derives once per delta pose: translation, angle * axis (f32)
+    float tr[3], aa[3];
+};
+static DeltaMotion delta_motion(const float* D) {
     const float m[3][3] = {{D[0], D[1], D[2]}, {D[4], D[5], D[6]}, {D[8], D[9], D[10]}};
     float q[4];
     float t = m[0][0] + (m[1][1] + m[2][2]);
@@ -1773,32 +1776,54 @@ void orc_undistort_delta(const float* D, float* xyzi, const uint32_t* stamp_us, 
         if (q[3] < 0.f) nrm = -nrm;
         for (int i = 0; i < 3; i++) axis[i] = q[i] / nrm;
     }
-    const float tr[3] = {D[3], D[7], D[11]};
-    const float aa[3] = {angle * axis[0], angle * axis[1], angle * axis[2]};
-    for (int i = 0; i < n; i++) {
-        float* p = xyzi + 4 * (size_t)i;
-        const float r = (float)(((double)stamp_us[i] / 1000000.0) / scan_period);
-        const float tx = r * tr[0], ty = r * tr[1], tz = r * tr[2];
-        const float wx = r * aa[0], wy = r * aa[1], wz = r * aa[2];
-        const float norm = std::sqrt(wx * wx + (wy * wy + wz * wz));
-        float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (!((double)norm < 1e-8)) {
-            const float ax = wx / norm, ay = wy / norm, az = wz / norm;
-            const float ha = 0.5f * norm;
-            const float w = std::cos(ha), sh = std::sin(ha);
-            const float x = sh * ax, y = sh * ay, z = sh * az;
-            const float t2x = 2.f * x, t2y = 2.f * y, t2z = 2.f * z;
-            const float twx = t2x * w, twy = t2y * w, twz = t2z * w;
-            const float txx = t2x * x, txy = t2y * x, txz = t2z * x;
-            const float tyy = t2y * y, tyz = t2z * y, tzz = t2z * z;
-            R[0] = 1.f - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
-            R[3] = txy + twz; R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
-            R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.f - (txx + tyy);
+    DeltaMotion M;
+    for (int i = 0; i < 3; i++) { M.tr[i] = D[4 * i + 3]; M.aa[i] = angle * axis[i]; }
+    return M;
+}
+static void undistort_one(const DeltaMotion& M, float* p, uint32_t stamp, double scan_period) {
+    const float r = (float)(((double)stamp / 1000000.0) / scan_period);
+    const float tx = r * M.tr[0], ty = r * M.tr[1], tz = r * M.tr[2];
+    const float wx = r * M.aa[0], wy = r * M.aa[1], wz = r * M.aa[2];
+    const float norm = std::sqrt(wx * wx + (wy * wy + wz * wz));
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (!((double)norm < 1e-8)) {
+        const float ax = wx / norm, ay = wy / norm, az = wz / norm;
+        const float ha = 0.5f * norm;
+        const float w = std::cos(ha), sh = std::sin(ha);
+        const float x = sh * ax, y = sh * ay, z = sh * az;
+        const float t2x = 2.f * x, t2y = 2.f * y, t2z = 2.f * z;
+        const float twx = t2x * w, twy = t2y * w, twz = t2z * w;
+        const float txx = t2x * x, txy = t2y * x, txz = t2z * x;
+        const float tyy = t2y * y, tyz = t2z * y, tzz = t2z * z;
+        R[0] = 1.f - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+        R[3] = txy + twz; R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+        R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.f - (txx + tyy);
+    }
+    const float px = p[0], py = p[1], pz = p[2];
+    p[0] = (R[0] * px + R[1] * py) + (R[2] * pz + tx);
+    p[1] = (R[3] * px + R[4] * py) + (R[5] * pz + ty);
+    p[2] = (R[6] * px + R[7] * py) + (R[8] * pz + tz);
+}
+void orc_undistort_delta(const float* D, float* xyzi, const uint32_t* stamp_us, int n, double scan_period) {
+    const DeltaMotion M = delta_motion(D);
+    for (int i = 0; i < n; i++) undistort_one(M, xyzi + 4 * (size_t)i, stamp_us[i], scan_period);
+}
+// undistortPoints(std::vector<PoseType>& poses, PointCloudAttrPtr&), slam_utils.cpp:193-228: poses[i].T (i >= 1) is the motion since
+// poses[0]; the cloud is walked ONCE, a point belongs to the first pose interval (from the one the previous point used onwards) whose
+// end, poses[i].timestamp - header.stamp in unsigned 64-bit arithmetic, is not before the point's stamp; points past the last pose and
+// everything after them stay as they are
+void orc_undistort_poses(const uint64_t* pose_stamp_us, const double* pose_T16, int n_poses, float* xyzi, const uint32_t* stamp_us, int n,
+                         uint64_t header_us) {
+    int idx = 0;
+    for (int i = 1; i < n_poses; i++) {
+        const double scan_period = (double)(pose_stamp_us[i] - pose_stamp_us[0]) / 1000000.0;
+        float D[16];
+        for (int k = 0; k < 16; k++) D[k] = (float)pose_T16[16 * (size_t)i + k];
+        const DeltaMotion M = delta_motion(D);
+        for (; idx < n; idx++) {
+            if ((uint64_t)stamp_us[idx] > (uint64_t)(pose_stamp_us[i] - header_us)) break;
+            undistort_one(M, xyzi + 4 * (size_t)idx, stamp_us[idx], scan_period);
         }
-        const float px = p[0], py = p[1], pz = p[2];
-        p[0] = (R[0] * px + R[1] * py) + (R[2] * pz + tx);
-        p[1] = (R[3] * px + R[4] * py) + (R[5] * pz + ty);
-        p[2] = (R[6] * px + R[7] * py) + (R[8] * pz + tz);
     }
 }
 

@@ -87,6 +87,7 @@ def lib():
     L.orc_lio_is_init.argtypes = [C.c_void_p]
     L.orc_lio_set_max_point_num.argtypes = [C.c_void_p, C.c_int]
     L.orc_undistort_delta.argtypes = [f32p, f32p, C.POINTER(C.c_uint32), C.c_int, C.c_double]
+    L.orc_undistort_poses.argtypes = [C.POINTER(C.c_uint64), f64p, C.c_int, f32p, C.POINTER(C.c_uint32), C.c_int, C.c_uint64]
     L.orc_lio_get_ds_world.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_kf_update_cb.argtypes = [f64p, f64p, C.c_double, C.c_int, MEAS_FN, C.c_void_p, C.c_int, f64p, f64p]
     L.orc_so3_Exp.argtypes = [f64p, C.c_double, f64p]
@@ -385,6 +386,15 @@ def undistort_delta(xyzi, stamp_us, delta_pose, scan_period=0.1):
     p = np.array(xyzi, np.float32).reshape(-1, 4).copy()
     st, d = np.ascontiguousarray(stamp_us, np.uint32), np.ascontiguousarray(delta_pose, np.float32).reshape(16)
     lib().orc_undistort_delta(_p(d, C.c_float), _p(p, C.c_float), _p(st, C.c_uint32), len(p), float(scan_period))
+    return p
+
+
+def undistort_poses(xyzi, stamp_us, header_us, pose_stamps_us, pose_T):
+    """undistortPoints(poses, points), slam_utils.cpp:193-228"""
+    p = np.array(xyzi, np.float32).reshape(-1, 4).copy()
+    st = np.ascontiguousarray(stamp_us, np.uint32)
+    ps, pt = np.ascontiguousarray(pose_stamps_us, np.uint64), np.ascontiguousarray(pose_T, np.float64).reshape(-1, 16)
+    lib().orc_undistort_poses(_p(ps, C.c_uint64), _p(pt, C.c_double), len(ps), _p(p, C.c_float), _p(st, C.c_uint32), len(p), int(header_us))
     return p
 
 

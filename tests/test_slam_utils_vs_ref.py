@@ -53,6 +53,70 @@ def test_oracle_matches_the_references_slam_utils(oracle_mod):
         assert np.abs(slam_wrapper.get_transform_from_rpyt(*a) - rs.transform_from_rpyt(*a)).max() < 1e-14 * max(1.0, np.abs(a[:3]).max())
 
 
+GOLD_POSES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "undistort_poses.npz")
+
+
+def _pose_cases(g):
+    for k in range(int(g["n_cases"])):
+        yield k, int(g[f"c{k}_header"]), g[f"c{k}_pose_stamps"], g[f"c{k}_pose_T"], g[f"c{k}_stamp_us"], g[f"c{k}_out"]
+
+
+def test_oracle_pose_list_matches_golden(oracle_mod):
+    """undistortPoints(poses, points) (slam_utils.cpp:193-228): the sequential walk over the cloud, against the fixture recorded from the
+    reference's own code -- ordered and unordered clouds, 2 .. 12 poses, a pose before the header stamp, stamps past the last pose"""
+    g = np.load(GOLD_POSES)
+    moved = 0
+    for k, header, ps, Ts, st, ref in _pose_cases(g):
+        out = oracle_mod.undistort_poses(g["points"], st, header, ps, Ts)
+        assert _same(out, ref), k
+        moved += int((np.abs(out[:, :3] - g["points"][:, :3]).max(1) > 0).sum())
+    assert moved > 2500
+
+
+@pytest.mark.skipif(not rs.available(), reason="oracle/_ref/libref_slam_utils.so not built (needs /root/reference)")
+def test_oracle_pose_list_matches_the_references_slam_utils(oracle_mod):
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from make_golden import undistort_poses_cases
+
+    rng = np.random.default_rng(23)
+    for rep in range(3):
+        pts, cases = undistort_poses_cases(rng, n=5000)
+        for c in cases:
+            a = rs.undistort_poses(pts, c["stamp_us"], c["header"], c["pose_stamps"], c["pose_T"])
+            assert _same(oracle_mod.undistort_poses(pts, c["stamp_us"], c["header"], c["pose_stamps"], c["pose_T"]), a)
+
+
+@pytest.mark.gpu
+def test_hip_undistort_poses(oracle_mod):
+    from lsd_amd import capi, lio
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on the GPU box")
+    g = np.load(GOLD_POSES)
+    pts = g["points"]
+    sc = lio.Scan(max_raw=1 << 16, max_ds=1 << 14)
+    refused = 0
+    for k, header, ps, Ts, st, ref in _pose_cases(g):
+        sc.upload(pts)
+        limits = (ps[1:] - np.uint64(header)).astype(np.uint64)  # unsigned wrap-around, as the reference computes them
+        if np.any(np.diff(limits.astype(np.float64)) < 0):
+            with pytest.raises(capi.LioError):  # interval ends that decrease: refused, not guessed
+                sc.undistort_poses(st, header, ps, Ts)
+            refused += 1
+            continue
+        sc.undistort_poses(st, header, ps, Ts)
+        out = sc.download_raw()
+        same_untouched = (ref[:, :3] == pts[:, :3]).all(1)
+        assert np.array_equal(out[same_untouched].view(np.uint32), ref[same_untouched].view(np.uint32)), k  # points the walk never reached
+        d = np.abs(out[:, :3] - ref[:, :3])
+        scale = np.maximum(np.abs(ref[:, :3]).max(axis=1, keepdims=True), 1e-3)
+        assert (d / (scale * 2.0 ** -23)).max() <= 8.0 and (d > 0).mean() < 1e-2, (k, (d / (scale * 2.0 ** -23)).max(), (d > 0).mean())
+    assert refused <= 1
+    sc.close()
+
+
 @pytest.mark.gpu
 def test_hip_undistort_delta(oracle_mod):
     import ctypes as C

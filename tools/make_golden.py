@@ -84,6 +84,30 @@ def undistort_delta_cases(rng, n=3000):
     return pts, st, np.stack(deltas)
 
 
+def undistort_poses_cases(rng, n=3000):
+    """inputs of the pose-list compensation: 2 .. 12 poses, time-ordered and unordered clouds, a first pose at / after the scan start, a pose
+    before the header stamp (its interval 'never ends'), stamps past the last pose"""
+    pts = (rng.normal(size=(n, 4)) * 30).astype(np.float32)
+    cases = []
+    for case in range(8):
+        m = [2, 3, 6, 12][case % 4]
+        header = 1_700_000_000_000_000 + 7 * case
+        ps = (header + np.sort(rng.integers(0, 110000 if case % 2 else 90000, m))).astype(np.uint64)
+        if case % 3 == 0:
+            ps[0] = header
+        if case == 5:
+            ps[1] = header - 5
+        Ts = np.stack([np.eye(4)] * m)
+        for i in range(1, m):
+            Ts[i, :3, :3] = synth.quat_to_R(synth.quat_from_rotvec(rng.normal(size=3) * [1e-1, 1e-3, 0.0][case % 3]))
+            Ts[i, :3, 3] = rng.normal(size=3) * 0.5
+        st = rng.integers(0, 100001, n).astype(np.uint32)
+        if case < 6:
+            st = np.sort(st)
+        cases.append(dict(header=header, pose_stamps=ps, pose_T=Ts, stamp_us=st))
+    return pts, cases
+
+
 def slam_utils():
     """undistortPoints(delta_pose, ...) through the reference's OWN slam_utils.cpp (oracle/_ref/libref_slam_utils.so)"""
     import ref_slam_utils as rs
@@ -94,6 +118,13 @@ def slam_utils():
     out = np.stack([rs.undistort_delta(pts, st, D, 0.1) for D in deltas])
     np.savez_compressed(os.path.join(OUT, "undistort_delta.npz"), points=pts, stamp_us=st, deltas=deltas, scan_period=0.1, out=out,
                         source="slam/common/slam_utils.cpp:163-191 compiled whole from /root/reference (oracle/ref_slam_utils.cpp); pcl::transformPoint = PCL 1.9.1's one-liner")
+    pts, cases = undistort_poses_cases(np.random.default_rng(6), n=1500)
+    rec = dict(points=pts, n_cases=len(cases))
+    for k, c in enumerate(cases):
+        rec[f"c{k}_header"], rec[f"c{k}_pose_stamps"], rec[f"c{k}_pose_T"], rec[f"c{k}_stamp_us"] = np.uint64(c["header"]), c["pose_stamps"], c["pose_T"], c["stamp_us"]
+        rec[f"c{k}_out"] = rs.undistort_poses(pts, c["stamp_us"], c["header"], c["pose_stamps"], c["pose_T"])
+    np.savez_compressed(os.path.join(OUT, "undistort_poses.npz"), **rec,
+                        source="slam/common/slam_utils.cpp:193-228 compiled whole from /root/reference (oracle/ref_slam_utils.cpp)")
 
 
 def pose_estimator():
