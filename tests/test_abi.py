@@ -91,3 +91,47 @@ def test_header_is_plain_c():
         with open(src, "w") as f:
             f.write('#include "lio_hip.h"\nint main(void) { lio_normal_eq ne; lio_ndt_params p; (void)ne; (void)p; return LIO_OK; }\n')
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src])
+
+
+def test_host_only_entry_points_reject_bad_arguments():
+    """entry points that never touch the device answer invalid arguments with LIO_E_INVALID (and NULL handles from *_create), no crash:
+    the C ABI's error contract (negative codes, nothing thrown) can be exercised without a GPU on these"""
+    import ctypes as C
+
+    import numpy as np
+    from lsd_amd import capi
+
+    L = capi.lib()
+    f32p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    assert not L.lio_pose_estimator_create(None, 0, None, None, 1.0)
+    ext, pos, q = np.eye(4, dtype=np.float32).reshape(-1), np.zeros(3, np.float32), np.array([1, 0, 0, 0], np.float32)
+    pe = L.lio_pose_estimator_create(ext.ctypes.data_as(f32p), 0, pos.ctypes.data_as(f32p), q.ctypes.data_as(f32p), 0.0)
+    assert pe
+    acc = np.zeros(3, np.float32)
+    assert L.lio_pose_estimator_predict(None, 1, None, None) == capi.LIO_E_INVALID
+    assert L.lio_pose_estimator_predict(pe, 1, acc.ctypes.data_as(f32p), None) == capi.LIO_E_INVALID  # acc without gyro
+    assert L.lio_pose_estimator_correct(pe, 1, None) == capi.LIO_E_INVALID
+    assert L.lio_pose_estimator_matrix(pe, None) == capi.LIO_E_INVALID
+    assert L.lio_pose_estimator_guess(pe, None, None) == capi.LIO_E_INVALID
+    assert L.lio_pose_estimator_observe(pe, None, None, 1, None, None, None) == capi.LIO_E_INVALID
+    assert L.lio_pose_estimator_get_timed_pose(pe, 5, None, None, None) == capi.LIO_E_INVALID
+    assert L.lio_pose_estimator_predict_nostate(pe, 5, None) == capi.LIO_E_INVALID
+    assert L.lio_pose_estimator_match(pe, None, None, None, None, None) == capi.LIO_E_INVALID
+    obs = np.zeros(7, np.float32)
+    assert L.lio_pose_estimator_match_gps_only(pe, None, obs.ctypes.data_as(f32p), None) == 0  # nothing to fuse: the filter's pose, "false"
+    assert np.allclose(obs, [0, 0, 0, 1, 0, 0, 0])
+    L.lio_pose_estimator_destroy(pe)
+    L.lio_pose_estimator_destroy(None)
+    # null handles on the device-side API: invalid argument, not a crash
+    for name in ("lio_map_destroy", "lio_scan_destroy", "lio_engine_destroy", "lio_ndt_destroy", "lio_localmap_destroy"):
+        getattr(L, name)(None)
+    assert L.lio_scan_upload(None, None, 0) == capi.LIO_E_INVALID
+    assert L.lio_scan_undistort_delta(None, None, 0, None, 0.1) == capi.LIO_E_INVALID
+    assert L.lio_engine_process_scan(None, None, 0, 0.0) < 0
+    assert L.lio_fastlio_main(None) < 0
+    assert L.lio_ndt_align(None, None, None, None, None, None, None) == capi.LIO_E_INVALID
+    s26, d23, out = np.zeros(26), np.zeros(23), np.zeros(26)
+    s26[6] = s26[10] = 1.0
+    s26[23:26] = [0, 0, -9.809]
+    L.lio_state_boxplus(s26.ctypes.data_as(f64p), d23.ctypes.data_as(f64p), out.ctypes.data_as(f64p))
+    assert np.allclose(out, s26)
