@@ -372,7 +372,8 @@ int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_
  *   guess / observe  the two host halves of match() around the alignment (:196-247 / :250-302), with the GNSS observation fused in
  *                   (fusion_pose :420-433); match_gps = guess -> lio_ndt_align -> observe; match_gps_only = the scan-less match :304-346
  *   get_timed_pose  get_timed_pose + the INS state queue (:104-141), re-predicted by correct (:366-381); predict_nostate :70-86
- * The fitness score of the warm-up phase is lio_ndt_fitness_score. */
+ * The fitness score of the warm-up phase is lio_ndt_fitness_score.  predict / predict_nostate / get_timed_pose / correct hold the handle's
+ * mutex, as the reference's data_mutex does (the INS callback thread against the scan thread); the other calls belong to the scan thread. */
 typedef struct lio_pose_estimator lio_pose_estimator;
 typedef struct lio_gps_observation {  /* what match() reads of an RTKType: T (map-frame pose, row-major), precision, dimension (2 / 3 / 6) */
     double T[16];

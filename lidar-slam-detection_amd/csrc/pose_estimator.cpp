@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/lio_hip.h"
@@ -296,6 +297,8 @@ struct lio_pose_estimator {
     double cool_time_duration = 1.0;
     int bad = 0;  // a Cholesky factorisation failed (covariance not positive definite)
     std::vector<InsState> state_queue;
+    std::mutex data_mutex;  // held by predict / predict_nostate / get_timed_pose / correct, as in the reference (the INS callback thread
+                            // calls get_timed_pose while the scan thread predicts and corrects)
 };
 
 namespace {
@@ -417,6 +420,7 @@ void lio_pose_estimator_destroy(lio_pose_estimator* e) { delete e; }
 // PoseEstimator::predict(stamp) / predict(stamp, acc, gyro) (pose_estimator.cpp:142-186); acc, gyro == NULL: no IMU
 int lio_pose_estimator_predict(lio_pose_estimator* e, uint64_t stamp_us, const float acc[3], const float gyro[3]) {
     if (!e || ((acc == nullptr) != (gyro == nullptr))) return LIO_E_INVALID;
+    std::lock_guard<std::mutex> lock(e->data_mutex);
     if ((double)(stamp_us - e->init_stamp) / 1000000.0 < e->cool_time_duration || e->prev_stamp == 0 || e->prev_stamp == stamp_us) {
         e->prev_stamp = stamp_us;
         return 0;
@@ -436,6 +440,7 @@ int lio_pose_estimator_predict(lio_pose_estimator* e, uint64_t stamp_us, const f
 // correction and re-predicted from the corrected mean
 int lio_pose_estimator_correct(lio_pose_estimator* e, uint64_t stamp_us, const float observation[7]) {
     if (!e || !observation) return LIO_E_INVALID;
+    std::lock_guard<std::mutex> lock(e->data_mutex);
     e->last_correction_stamp = stamp_us;
     e->prev_stamp = stamp_us;
     if (!e->ukf.correct(observation)) { e->bad = 1; return LIO_E_STATE; }
@@ -461,6 +466,7 @@ int lio_pose_estimator_correct(lio_pose_estimator* e, uint64_t stamp_us, const f
 // PoseEstimator::predict_nostate (pose_estimator.cpp:70-86): where the filter would be at `stamp`, nothing changed but system.dt
 int lio_pose_estimator_predict_nostate(lio_pose_estimator* e, uint64_t stamp_us, double pose[16]) {
     if (!e || !pose) return LIO_E_INVALID;
+    std::lock_guard<std::mutex> lock(e->data_mutex);
     const double dt = ((double)stamp_us - (double)e->prev_stamp) / 1000000.0;
     if (dt <= 0) {
         float T[16];
@@ -480,6 +486,7 @@ int lio_pose_estimator_predict_nostate(lio_pose_estimator* e, uint64_t stamp_us,
 // not newer than the filter / the queue
 int lio_pose_estimator_get_timed_pose(lio_pose_estimator* e, uint64_t stamp_us, const double acc_g[3], const double gyro_dps[3], double pose[16]) {
     if (!e || !acc_g || !gyro_dps || !pose) return LIO_E_INVALID;
+    std::lock_guard<std::mutex> lock(e->data_mutex);
     if (stamp_us <= e->prev_stamp) return 0;
     InsState s;
     s.stamp = stamp_us;

@@ -218,3 +218,43 @@ def test_replay_of_the_recorded_reference():
             % [here, os.path.join(here, "..", "oracle"), os.path.join(here, "..", "lidar-slam-detection_amd", "python")])
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "replayed" in r.stdout, r.stderr[-3000:]
+
+
+def test_ins_thread_and_scan_thread_share_the_estimator():
+    """the reference guards predict / predict_nostate / get_timed_pose / correct with one mutex because the INS callback thread calls
+    get_timed_pose while the scan thread predicts and corrects; so does the product: two threads hammer one handle, the state stays finite
+    and the queue consistent (ctypes releases the GIL during the calls)"""
+    import threading
+
+    from lsd_amd import lio
+
+    P = lio.PoseEstimator([0, 0, 0], [1, 0, 0, 0], stamp_us=1_000_000, cool_time=0.0)
+    stop, errors, accepted = threading.Event(), [], [0]
+
+    def ins_thread():
+        t = 1_000_000_000  # ahead of the scan thread's clock: every sample is "newer than the filter" and joins the queue
+        try:
+            while not stop.is_set() and accepted[0] < 3000:
+                t += 1_000
+                ok, T = P.get_timed_pose(t, [0.0, 0.0, 1.0], [0.0, 0.0, 1.0])
+                accepted[0] += int(ok)
+                assert np.all(np.isfinite(T))
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = threading.Thread(target=ins_thread)
+    th.start()
+    t = 1_000_000
+    for k in range(300):
+        t += 10_000
+        P.predict(t, [0.0, 0.0, 9.81], [0.0, 0.0, 0.01])
+        P.predict_nostate(t + 5_000)
+        if k % 3 == 0:
+            m, _ = P.get()
+            P.correct(t, np.r_[m[0:3], m[6:10]])
+    stop.set()
+    th.join(timeout=30)
+    assert not th.is_alive() and not errors, errors
+    m, c = P.get()
+    assert np.all(np.isfinite(m)) and np.all(np.isfinite(c)) and accepted[0] > 0
+    P.close()
