@@ -767,6 +767,8 @@ struct Lio {
     bool flg_first_scan = true, flg_EKF_inited = false, is_degenerate = false;
     double res_mean_last = 0.05, total_residual = 0;
     int effct_feat_num = 0;
+    float last_contri[3] = {0, 0, 0}, last_strong[3] = {0, 0, 0};  // test visibility: the sums of laserMapping.cpp:946-964 of the last pass
+    double last_eigval[3] = {0, 0, 0};
 
     std::vector<P4> ds_body, ds_world;
     std::vector<std::vector<P4>> nearest;  // Nearest_Points: persists across scans
@@ -879,6 +881,7 @@ struct Lio {
                     if (dotp > 0.1736f) contri += dotp;
                     if (dotp > 0.7070f) strong += dotp;
                 }
+                last_contri[i] = contri; last_strong[i] = strong; last_eigval[i] = w[i];
                 if (contri < 250.0f && strong < 50.0f) {
                     for (int j = 0; j < 3; j++) V2[i * 3 + j] = 0;
                     is_degenerate = true;
@@ -1701,6 +1704,10 @@ int orc_lio_process_scan(void* h, const float* raw_xyzi, int n_raw, double lidar
 }
 double orc_lio_travel(void* h) { return static_cast<Lio*>(h)->travel; }
 int orc_lio_is_degenerate(void* h) { return static_cast<Lio*>(h)->is_degenerate ? 1 : 0; }
+void orc_lio_last_degeneracy(void* h, float* contri3, float* strong3, double* eigval3) {
+    Lio* l = static_cast<Lio*>(h);
+    for (int i = 0; i < 3; i++) { contri3[i] = l->last_contri[i]; strong3[i] = l->last_strong[i]; eigval3[i] = l->last_eigval[i]; }
+}
 
 // IMU front half
 void orc_lio_imu_enqueue(void* h, double stamp, const double* gyr, const double* acc_ms2) { static_cast<Lio*>(h)->imu_enqueue(stamp, gyr, acc_ms2); }

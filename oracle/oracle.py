@@ -108,6 +108,7 @@ def lib():
     L.orc_lio_travel.restype = C.c_double
     L.orc_lio_is_degenerate.argtypes = [C.c_void_p]
     L.orc_lio_is_degenerate.restype = C.c_int
+    L.orc_lio_last_degeneracy.argtypes = [C.c_void_p, f32p, f32p, f64p]
     L.orc_state_boxplus.argtypes = [f64p, f64p, f64p]
     L.orc_state_boxminus.argtypes = [f64p, f64p, f64p]
     L.orc_A_matrix.argtypes = [f64p, f64p]
@@ -379,6 +380,12 @@ class Lio:
     @property
     def is_degenerate(self):
         return bool(lib().orc_lio_is_degenerate(self.h))
+
+    def last_degeneracy(self):
+        """contri / strong (f32 sums of laserMapping.cpp:946-964) and the eigenvalues of sum n n^T of the last measurement pass"""
+        c, s, w = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(3)
+        lib().orc_lio_last_degeneracy(self.h, _p(c, C.c_float), _p(s, C.c_float), _p(w, C.c_double))
+        return dict(contri=c, strong=s, eigval=w)
 
 
 def undistort_delta(xyzi, stamp_us, delta_pose, scan_period=0.1):

@@ -108,14 +108,23 @@ def test_alignment_against_the_references_registration_object(method):
             G[:3, 3] = T_true[:3, 3] + rng.uniform(-0.4, 0.4, 3)
             G[:3, :3] = T_true[:3, :3] @ synth.quat_to_R(synth.quat_from_rotvec(rng.uniform(-0.03, 0.03, 3)))
         Tr, conv_r, it_r = r.align(G)
-        Tr2, _, _ = r.align(G)  # the reference against itself: its run-to-run spread
+        # the reference against itself: five more runs from the same guess (f32 atomics in its voxel map and Thrust reductions of
+        # unspecified order make every run different); its spread is the resolution at which "the reference's pose" is defined
+        reruns = [r.align(G)[0] for _ in range(5)]
         Tg, conv_g, it_g = g.align(s, G)
         dt, dr = float(np.linalg.norm(Tg[:3, 3] - Tr[:3, 3])), _rot_angle(Tg, Tr)
-        st, sr = float(np.linalg.norm(Tr2[:3, 3] - Tr[:3, 3])), _rot_angle(Tr2, Tr)
-        print("method", method, "guess", k, "conv", conv_r, conv_g, "iters", it_r, it_g, "dpos %.2e drot %.2e" % (dt, dr), "ref spread %.2e %.2e" % (st, sr),
+        st = max(float(np.linalg.norm(T2[:3, 3] - Tr[:3, 3])) for T2 in reruns)
+        sr = max(_rot_angle(T2, Tr) for T2 in reruns)
+        # distance from the HIP pose to the NEAREST of the reference's six answers
+        dt_min = min([dt] + [float(np.linalg.norm(Tg[:3, 3] - T2[:3, 3])) for T2 in reruns])
+        dr_min = min([dr] + [_rot_angle(Tg, T2) for T2 in reruns])
+        print("method", method, "guess", k, "conv", conv_r, conv_g, "iters", it_r, it_g, "dpos %.2e drot %.2e" % (dt, dr), "nearest %.2e %.2e" % (dt_min, dr_min),
+              "ref spread %.2e %.2e" % (st, sr),
               "err vs truth ref %.4f hip %.4f" % (np.linalg.norm(Tr[:3, 3] - T_true[:3, 3]), np.linalg.norm(Tg[:3, 3] - T_true[:3, 3])))
         assert conv_r and conv_g and abs(it_r - it_g) <= 2
+        # the north star's bar (1e-4 m / 1e-5 rad), widened only by what the reference itself moves between runs
+        assert dt <= max(1e-4, 3.0 * st) and dr <= max(1e-5, 3.0 * sr), (k, dt, dr, st, sr)
         worst_t, worst_r = max(worst_t, dt), max(worst_r, dr)
-    assert worst_t < 1e-3 and worst_r < 1e-4, (worst_t, worst_r)  # measured: 1.7e-4 m
+    assert worst_t < 1e-3 and worst_r < 1e-4, (worst_t, worst_r)
     r.close()
     g.close()
