@@ -61,8 +61,9 @@ void lio_map_destroy(lio_map*);
 /* IVox::SetNearByType (used at src/laserMapping.cpp:1241-1243) */
 int lio_map_set_stencil(lio_map*, int stencil);
 /* IVox::AddPoints(points, travel_distance)  (ivox3d.h:231-256).  Points are appended to their voxels;
- * new voxels are stamped with `travel`.  LRU eviction is NOT performed (the reference
- * evicts only above `capacity` voxels; this map reports LIO_E_CAPACITY instead of evicting). */
+ * new voxels are stamped with `travel`.  The LRU list of the reference (least recently touched voxel dropped
+ * above `capacity` voxels once it is older than `max_distance`) is opt-in: lio_map_set_lru below; without it
+ * nothing is ever dropped and exceeding max_points / max_voxels returns LIO_E_CAPACITY. */
 int lio_map_insert(lio_map*, const float* world_xyzi, uint64_t n, double travel);
 int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double travel);
 /* IVox::Options capacity_ / max_distance_ (ivox3d.h:46-52; 100000 voxels / 100 m at src/laserMapping.cpp:1060-1064): turn
@@ -75,6 +76,9 @@ int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double
  * point order drops and re-creates it; here it keeps its points -- the one case where the maps can differ). */
 int lio_map_set_lru(lio_map*, uint64_t capacity_voxels, double max_distance);
 int lio_map_lru_stats(lio_map*, uint64_t* n_evicted, uint64_t* n_interleaved);
+/* capacity planning: slots of the point pool handed out so far by the bump allocator (recycled regions of evicted / outgrown
+ * voxels are re-used first and do not move it) and the pool's size, both in points of 16 B */
+int lio_map_pool_stats(lio_map*, uint64_t* pool_top, uint64_t* pool_cap);
 /* IVox::NumValidGrids (ivox3d.h:173-176) and the total number of stored points */
 int lio_map_stats(lio_map*, uint64_t* n_points, uint64_t* n_voxels);
 /* running total of map points visited by stencil kNN queries (the C-bar * N_ds statistic of the roofline model) */

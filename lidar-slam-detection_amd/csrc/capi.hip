@@ -188,7 +188,7 @@ void lio_map_destroy(lio_map* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->dev);
     hipFree(m->slot_of_point); hipFree(m->tile_sum); hipFree(m->stage);
-    hipFree(m->touch); hipFree(m->prev_touch); hipFree(m->touch2); hipFree(m->prev_touch2); hipFree(m->lru_log); hipFree(m->free_items);
+    hipFree(m->touch); hipFree(m->prev_touch); hipFree(m->touch2); hipFree(m->prev_touch2); hipFree(m->lru_log); hipFree(m->free_items); hipFree(m->free_in);
     hipFree(m->table2); hipFree(m->cap2); hipFree(m->pending2); hipFree(m->created2); hipFree(m->remap);
     if (m->host_dev) hipHostFree(m->host_dev);
     if (m->stream && m->own_stream) hipStreamDestroy(m->stream);
@@ -208,7 +208,7 @@ int lio_map_set_lru(lio_map* m, uint64_t capacity_voxels, double max_distance) {
     m->lru_log_cap = lc;
     m->free_cap = (uint32_t)m->max_voxels;
     bool ok = dev_alloc(&m->touch, cap, &m->bytes) && dev_alloc(&m->prev_touch, cap, &m->bytes) && dev_alloc(&m->touch2, cap, &m->bytes) &&
-              dev_alloc(&m->prev_touch2, cap, &m->bytes) && dev_alloc(&m->lru_log, lc, &m->bytes) && dev_alloc(&m->free_items, (uint64_t)24 * m->free_cap, &m->bytes) &&
+              dev_alloc(&m->prev_touch2, cap, &m->bytes) && dev_alloc(&m->lru_log, lc, &m->bytes) && dev_alloc(&m->free_items, (uint64_t)24 * m->free_cap, &m->bytes) && dev_alloc(&m->free_in, (uint64_t)24 * m->free_cap, &m->bytes) &&
               dev_alloc(&m->table2, cap, &m->bytes) && dev_alloc(&m->cap2, cap, &m->bytes) && dev_alloc(&m->pending2, cap, &m->bytes) &&
               dev_alloc(&m->created2, cap, &m->bytes) && dev_alloc(&m->remap, cap, &m->bytes);
     ok = ok && hipMemsetAsync(m->touch, 0, cap * 8, m->stream) == hipSuccess && hipMemsetAsync(m->prev_touch, 0, cap * 8, m->stream) == hipSuccess &&
@@ -274,6 +274,15 @@ int lio_map_stats(lio_map* m, uint64_t* n_points, uint64_t* n_voxels) {
     const int rc = map_check(m, m->stream);
     if (n_points) *n_points = m->host_dev->n_points;
     if (n_voxels) *n_voxels = m->host_dev->n_voxels;
+    return rc;
+}
+
+int lio_map_pool_stats(lio_map* m, uint64_t* pool_top, uint64_t* pool_cap) {
+    if (!m) return LIO_E_INVALID;
+    hipSetDevice(m->device);
+    const int rc = map_check(m, m->stream);
+    if (pool_top) *pool_top = m->host_dev->pool_top;
+    if (pool_cap) *pool_cap = m->pool_cap;
     return rc;
 }
 

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint3
                                                               float4* pool, unsigned long long pool_cap, unsigned long long n_host,
                                                               const uint32_t* __restrict__ n_dev, MapDev* md,
                                                               const uint32_t* __restrict__ slot_of_point, const uint32_t* __restrict__ free_items,
-                                                              uint32_t free_cap) {
+                                                              uint32_t free_cap, uint32_t* __restrict__ free_in) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint3
         uint32_t ncap = 8;  // leave room: the voxel is on the sensor's path and will be appended to again
         while (ncap < need) ncap <<= 1;
         unsigned long long at = ~0ull;
-        if (free_items) {  // a region an evicted voxel gave back (this kernel only pops, lru_evict_kernel only pushes)
+        if (free_items) {  // a region an evicted or outgrown voxel gave back (this kernel only pops these lists; what it frees itself
+                           // goes to the incoming lists below, which lru_evict_kernel folds in after this kernel has ended)
             const int c = 31 - __clz(ncap);
             // look before popping: the counters share cache lines and same-line atomics serialise (~10 ns each) -- with empty
             // lists (no eviction yet) two atomics per growing voxel cost 50 us per scan
@@ -103,14 +104,24 @@ __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint3
         if (at == ~0ull) {
             at = atomicAdd(&md->pool_top, (unsigned long long)ncap);
             if (at + ncap > pool_cap) {
+                // pool exhausted: the voxel keeps its region; the write kernel stores what still fits and clamps cnt to cap, the
+                // points that do not fit are taken out of the count again (the error bit is sticky, the table stays consistent)
                 atomicOr(&md->err, 2u);
+                const uint32_t room = cap[h] > have ? cap[h] - have : 0u;
+                if (add > room) atomicAdd(&md->n_points, ~(unsigned long long)(add - room) + 1ull);
                 continue;
             }
         }
-        const uint32_t old = table[h].ptr;
+        const uint32_t old = table[h].ptr, old_cap = cap[h];
         for (uint32_t j = 0; j < have; j++) pool[at + j] = pool[old + j];
         table[h].ptr = (uint32_t)at;
         cap[h] = ncap;
+        if (free_in && old_cap >= 8) {  // the outgrown region is recycled (without this an LRU map leaks ~one slot per inserted point)
+            const int oc = 31 - __clz(old_cap);
+            const int pos = atomicAdd(&md->free_in_top[oc], 1);
+            if (pos >= 0 && (uint32_t)pos < free_cap) free_in[(size_t)oc * free_cap + (uint32_t)pos] = old;
+            else atomicSub(&md->free_in_top[oc], 1);
+        }
     }
 }
 
@@ -210,6 +221,7 @@ __global__ void __launch_bounds__(256) map_insert_write_kernel(Slot* table, cons
         const uint32_t h = sp & 0x7FFFFFFFu;
         const uint32_t idx = atomicAdd(&table[h].cnt, 1u);
         if (idx < cap[h]) pool[(unsigned long long)table[h].ptr + idx] = pts[i];
+        else atomicSub(&table[h].cnt, 1u);  // only after a pool overflow (err bit 2): cnt never exceeds cap, readers stay in bounds
     }
 }
 
@@ -294,8 +306,17 @@ __global__ void __launch_bounds__(256) lru_evict_kernel(Slot* table, uint32_t* _
                                                         unsigned long long stamp_base, const LruEntry* __restrict__ log,
                                                         unsigned long long log_mask, uint32_t* __restrict__ free_items, uint32_t free_cap,
                                                         unsigned long long n_host, const uint32_t* __restrict__ n_dev, uint32_t capacity,
-                                                        float travel, float max_distance, MapDev* md) {
+                                                        float travel, float max_distance, MapDev* md, const uint32_t* __restrict__ free_in) {
     const unsigned long long n_add = n_dev ? (unsigned long long)*n_dev : n_host;
+    // regions the grow kernel of this batch freed (voxels that moved to a larger one): fold them into the free lists it pops from
+    for (int c = 3; c < 24; c++) {
+        const int n_in = md->free_in_top[c], top = md->free_top[c];
+        const int room = (int)free_cap - top, take = n_in < room ? n_in : room;
+        for (int j = threadIdx.x; j < take; j += 256) free_items[(size_t)c * free_cap + (uint32_t)(top + j)] = free_in[(size_t)c * free_cap + (uint32_t)j];
+        __syncthreads();
+        if (threadIdx.x == 0 && n_in) { md->free_top[c] = top + (take > 0 ? take : 0); md->free_in_top[c] = 0; }
+        __syncthreads();
+    }
     __shared__ uint32_t wsum[4];
     __shared__ unsigned long long first_young_s, tail_s;
     __shared__ uint32_t want_s, pts_s;
@@ -485,7 +506,7 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
     } else {
         hipLaunchKernelGGL(map_insert_grow_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->cap, m->pending, m->pool,
                            (unsigned long long)m->pool_cap, (unsigned long long)n, d_n, m->dev, m->slot_of_point, lru ? m->free_items : nullptr,
-                           m->free_cap);
+                           m->free_cap, lru ? m->free_in : nullptr);
     }
     hipLaunchKernelGGL(map_insert_write_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->cap, m->pool, d_pts,
                        (unsigned long long)n, d_n, m->slot_of_point);
@@ -494,7 +515,7 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
                            (unsigned long long)(m->lru_log_cap - 1), m->dev);
         hipLaunchKernelGGL(lru_evict_kernel, 1, 256, 0, stream, m->table, m->cap, m->created, m->touch, m->prev_touch, stamp_base, m->lru_log,
                            (unsigned long long)(m->lru_log_cap - 1), m->free_items, m->free_cap, (unsigned long long)n, d_n, (uint32_t)m->lru_capacity,
-                           (float)travel, m->lru_max_distance, m->dev);
+                           (float)travel, m->lru_max_distance, m->dev, m->free_in);
         m->tomb_bound += n;
     }
     LIO_HIP_TRY(hipGetLastError());

@@ -48,6 +48,7 @@ struct MapDev {
     unsigned long long n_evicted;    // voxels evicted so far
     unsigned long long n_lru_interleaved;  // LRU-back voxels that the batch evicting around them also touched (see hashmap.hip)
     int free_top[24];                // recycled pool regions by size class (floor(log2(capacity)))
+    int free_in_top[24];             // regions freed by the grow kernel of the current batch (folded into free_top by lru_evict_kernel)
     unsigned long long knn_cand[64 * 16];  // 64 shards, one 128-B line each (same-line atomics serialise in one L2 channel)
 };
 
@@ -101,6 +102,7 @@ struct lio_map {
     LruEntry* lru_log;           // ring, ordered by stamp
     uint64_t lru_log_cap;        // power of two
     uint32_t* free_items;        // [24][free_cap] recycled region offsets
+    uint32_t* free_in;           // [24][free_cap] regions outgrown during the current batch
     uint32_t free_cap;
     uint64_t tomb_bound;         // evictions possible since the last rebuild (host-side upper bound)
     lio::Slot* table2;           // second set of per-slot arrays: target of a table rebuild, then swapped

@@ -3,8 +3,9 @@
 // (include/kkl/alg/unscented_kalman_filter.hpp:42-262) over the 23-number pose system of include/hdl_localization/
 // pose_system.hpp:14-115 -- predict with or without an IMU sample, scan matching from the predicted pose on the device
 // (lio_ndt_align), the too-large-transform gate, quaternion sign continuity, 7-number observation, correct.
-// Host C++, f32 like the reference (Eigen::MatrixXf there; plain loops here).  GNSS fusion (fusion_pose, get_timed_pose's INS
-// queue) and the fitness score are not part of the path (out of scope).
+// Host C++, f32 like the reference (Eigen::MatrixXf there; plain loops here).  Includes the GNSS fusion (fusion_pose), the
+// GNSS-only match, get_timed_pose with the INS state queue and predict_nostate; the fitness score of the warm-up phase is
+// lio_ndt_fitness_score (ndt.hip).
 #include <math.h>
 #include <string.h>
 

@@ -62,6 +62,11 @@ class Map:
         check(lib().lio_map_lru_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def pool_stats(self):
+        top, cap = C.c_uint64(), C.c_uint64()
+        check(lib().lio_map_pool_stats(self.h, C.byref(top), C.byref(cap)), "pool stats")
+        return top.value, cap.value
+
     def close(self):
         if getattr(self, "h", None) and self._own and lib is not None:  # `lib` is gone at interpreter shutdown
             lib().lio_map_destroy(self.h)

@@ -90,3 +90,40 @@ def test_young_voxels_are_not_evicted(oracle_mod, scene):
         if b == 4:
             assert nvox > 2000  # overshoot
     assert np.array_equal(_rows(m.dump()), _rows(o.dump()))
+
+
+def test_long_lru_run_does_not_leak_the_pool(oracle_mod, scene):
+    """A long drive back and forth with the LRU list on: voxels are created, grow through several region sizes (each move
+    leaves a region behind), are evicted and re-created.  Outgrown and evicted regions are recycled, so the bump allocator must
+    stop moving once the working set is established -- and the map must still equal the oracle's at the end."""
+    from lsd_amd import lio
+
+    rng = np.random.default_rng(12)
+    pts = scene.sample_surface(500_000, seed=13, sigma=0.01)
+    pts = pts[(np.abs(pts[:, 1]) < 20) & (pts[:, 2] < 6)]
+    cap, maxd = 1500, 30.0
+    m = lio.Map(resolution=0.5, stencil=19, max_points=300_000, max_voxels=20000)
+    m.set_lru(cap, maxd)
+    o = oracle_mod.IVox(res=0.5, stencil=19, capacity=cap, max_distance=maxd)
+    legs = list(np.linspace(-70, 70, 36)) + list(np.linspace(70, -70, 36))
+    travel, last, tops = 0.0, legs[0], []
+    n_inserted = 0
+    for lap in range(5):
+        for cx in legs:
+            travel += abs(cx - last) + 0.3
+            last = cx
+            for _ in range(3):  # three batches per stop: the voxels of the window grow 8 -> 16 -> 32 -> ...
+                batch = _batch(pts, cx, rng, 1500)
+                m.add(batch, travel=travel)
+                o.add(batch, travel=travel)
+                n_inserted += len(batch)
+        tops.append(m.pool_stats()[0])
+        npts, nvox = m.stats()
+        assert (nvox, npts) == (o.num_voxels, o.num_points), lap
+    top, pool_cap = m.pool_stats()
+    evicted, _ = m.lru_stats()
+    print("inserted", n_inserted, "evicted voxels", evicted, "pool_top per lap", tops, "pool_cap", pool_cap)
+    assert n_inserted > 1_000_000 and evicted > 10_000
+    assert tops[-1] - tops[1] < 0.1 * tops[1], tops   # after the first laps nothing new is taken from the bump allocator
+    assert top < pool_cap // 2
+    assert np.array_equal(_rows(m.dump()), _rows(o.dump()))
