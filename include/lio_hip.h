@@ -283,6 +283,17 @@ int lio_eskf_update_cb(const double s26[26], const double P[529], double R, int 
                        double P_out[529]);
 int lio_state_predict(const double s26[26], const double P[529], double dt, const double Q[12], const double acc[3], const double gyro[3],
                       double s26_out[26], double P_out[529]);
+/* test visibility, host-only: the DEVICE-resident form of update_iterated_dyn_share_modified (csrc/eskf_dev.h: the filter pass as
+ * data-parallel phases, one workgroup per scan on the GPU; here the same source compiled for the host) driven by caller-supplied sums:
+ *   fn(ctx, state26, converge, acc29) -> valid: acc29 = the 21 upper-triangle entries of J^T J row by row, 6 of J^T h, sum |r|, N_eff
+ *   dfn(ctx, V, cs): the six degeneracy sums (contri[3], strong[3]) against the eigenvectors V (columns of a row-major 3 x 3); called
+ *                    only when the eigenvalue bound does not decide
+ * Returns the number of pass logs written (<= cap_logs); *status = 1 finished, 2 a pass saw N_eff < 23 (the dense branch of
+ * esekfom.hpp:1715-1744 runs on the host: the state is the one BEFORE that pass). */
+typedef int (*lio_sums_fn)(void* ctx, const double* s26, int converge, double* acc29);
+typedef void (*lio_degeneracy_fn)(void* ctx, const double* V9, double* cs6);
+int lio_eskf_update_sums_cb(const double s26[26], const double P[529], double R, int max_iter, int degenerate_detect_en, lio_sums_fn fn,
+                            lio_degeneracy_fn dfn, void* ctx, double s26_out[26], double P_out[529], lio_pass_log* logs, int cap_logs, int* status);
 
 /* Joint registration across GPUs (BASELINE.json config 5: sub-maps one per GPU, all-gather of the per-shard
  * J^T J / J^T r sums).  When a hook is set the engine calls it after every device linearisation with its LOCAL sums and

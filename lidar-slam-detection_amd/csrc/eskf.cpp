@@ -1,5 +1,7 @@
 // eskf.cpp -- see eskf.h.  Plain host C++ (row-major fixed-size arrays; no Eigen, no Boost).
 #include "eskf.h"
+#include "eskf_dev.h"
+#include "../../include/lio_hip.h"
 
 #include <math.h>
 #include <string.h>
@@ -634,3 +636,46 @@ void Eskf::predict(double dt, const double Q[12], const double acc[3], const dou
 }
 
 }  // namespace lio
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host-only: the DEVICE-resident filter loop (eskf_dev.h, here compiled for the host: plain loops instead of workgroup-strided
+// ones) driven by caller-supplied sums -- what step_kernel (p2plane.hip) does once per pass on the GPU.  tests/test_eskf_dev.py
+// holds it against lio_eskf_update_cb (the host filter, itself pinned to the reference's IKFoM code).
+extern "C" int lio_eskf_update_sums_cb(const double s26[26], const double P[529], double R, int max_iter, int degenerate_detect_en,
+                                       lio_sums_fn fn, lio_degeneracy_fn dfn, void* ctx, double s26_out[26], double P_out[529],
+                                       lio_pass_log* logs, int cap_logs, int* status) {
+    using namespace lio;
+    if (!s26 || !P || !fn || !s26_out || !P_out || max_iter < 0 || max_iter + 1 > kEkMaxPass) return LIO_E_INVALID;
+    static_assert(sizeof(EkPassLog) == sizeof(lio_pass_log), "EkPassLog mirrors lio_pass_log");
+    EskfDev* c = new EskfDev();
+    EkWork* w = new EkWork();
+    memset(c, 0, sizeof(*c));
+    memset(w, 0, sizeof(*w));
+    memcpy(c->x, s26, sizeof(double) * 26);
+    memcpy(c->P, P, sizeof(double) * 529);
+    for (int k = 0; k < kEkN; k++) c->limit[k] = 0.001;
+    c->R = R;
+    c->maximum_iter = max_iter;
+    c->degenerate_detect_en = degenerate_detect_en;
+    ek_begin(*c);
+    while (c->status == EK_RUNNING) {
+        const int knn = c->converge;
+        double acc[29];
+        for (int k = 0; k < 29; k++) acc[k] = 0.0;
+        if (!fn(ctx, c->x, knn, acc)) acc[28] = 0.0;
+        ek_measure_head(*c, *w, acc, knn);
+        if (w->flag[1] && dfn) dfn(ctx, w->eigvec, w->cs);
+        ek_measure_tail(*c, *w);
+        if (c->status != EK_RUNNING) break;
+        if (w->flag[0]) ek_step(*c, *w);
+    }
+    memcpy(s26_out, c->x, sizeof(double) * 26);
+    memcpy(P_out, c->P, sizeof(double) * 529);
+    if (status) *status = c->status;
+    const int n = c->n_log;
+    if (logs)
+        for (int k = 0; k < n && k < cap_logs; k++) memcpy(&logs[k], &c->log[k], sizeof(lio_pass_log));
+    delete c;
+    delete w;
+    return n;
+}

@@ -57,14 +57,6 @@ struct Eskf {
     int maximum_iter = 4;  // fastlio_init: NUM_MAX_ITERATIONS 4 (laserMapping.cpp:1026,1116)
 
     Eskf();
-    // esekf::predict (esekfom.hpp:279-383) with get_f / df_dx / df_dw of use-ikfom.hpp:47-88.  Q is the diagonal of the
-    // 12 x 12 process noise (ng, na, nbg, nba).  acc in m/s^2, gyro in rad/s.
-    void predict(double dt, const double Q[12], const double acc[3], const double gyro[3]);
-    // one call of update_iterated_dyn_share_modified; `measure(x, converge, m)` plays h_dyn_share.
-    // Returns the number of measurement evaluations made.
-    template <typename F>
-    int update_iterated(double R, F&& measure, void (*on_pass)(void*, int, bool, const Measurement&, const double*), void* ctx);
-
     struct Work {
         LioState x_prop;
         double P_prop[kDof * kDof];
@@ -72,6 +64,19 @@ struct Eskf {
         double K_h[kDof];
         double dx_new[kDof];
     };
+    // esekf::predict (esekfom.hpp:279-383) with get_f / df_dx / df_dw of use-ikfom.hpp:47-88.  Q is the diagonal of the
+    // 12 x 12 process noise (ng, na, nbg, nba).  acc in m/s^2, gyro in rad/s.
+    void predict(double dt, const double Q[12], const double acc[3], const double gyro[3]);
+    // one call of update_iterated_dyn_share_modified; `measure(x, converge, m)` plays h_dyn_share.
+    // Returns the number of measurement evaluations made.
+    template <typename F>
+    int update_iterated(double R, F&& measure, void (*on_pass)(void*, int, bool, const Measurement&, const double*), void* ctx);
+    // the same loop entered at pass `i` with the loop state (converge, t) and the propagated state / covariance in `w` as an earlier
+    // part of the update left them (the device-resident loop hands over here when a pass needs the N_eff < 23 dense branch)
+    template <typename F>
+    int update_iterated_from(Work& w, int i, bool converge, int t, double R, F&& measure,
+                             void (*on_pass)(void*, int, bool, const Measurement&, const double*), void* ctx);
+
     int step(Work& w, double R, const Measurement& m, int i, bool& converge, int& t, double dx_out[kDof]);
     void begin(Work& w);
 };
@@ -80,9 +85,14 @@ template <typename F>
 int Eskf::update_iterated(double R, F&& measure, void (*on_pass)(void*, int, bool, const Measurement&, const double*), void* ctx) {
     Work w;
     begin(w);
-    bool converge = true;
-    int t = 0, evals = 0;
-    for (int i = -1; i < maximum_iter; i++) {
+    return update_iterated_from(w, -1, true, 0, R, measure, on_pass, ctx);
+}
+
+template <typename F>
+int Eskf::update_iterated_from(Work& w, int i0, bool converge, int t, double R, F&& measure,
+                               void (*on_pass)(void*, int, bool, const Measurement&, const double*), void* ctx) {
+    int evals = 0;
+    for (int i = i0; i < maximum_iter; i++) {
         Measurement m;
         m.valid = true;
         m.rows6 = nullptr;

@@ -34,7 +34,7 @@ SYMBOLS = [
     "lio_pose_estimator_correct", "lio_pose_estimator_get", "lio_pose_estimator_set", "lio_pose_estimator_matrix",
     "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_fastlio_ins_enqueue", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device",
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
-    "lio_state_predict", "lio_eskf_update_cb",
+    "lio_state_predict", "lio_eskf_update_cb", "lio_eskf_update_sums_cb",
     "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_fitness_score", "lio_ndt_overlap_score", "lio_ndt_voxel_at",
     "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align",
 ]
@@ -52,6 +52,8 @@ class PassLog(C.Structure):
                 ("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6), ("dx", C.c_double * 23)]
 
 
+SUMS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+DEG_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 MEAS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
 
 
@@ -192,6 +194,7 @@ def lib():
     sig("lio_fastlio_download_undistorted", cint, vp, f32p, u32, C.POINTER(u32))
     sig("lio_eskf_update_cb", cint, f64p, f64p, dbl, cint, MEAS_FN, vp, cint, f64p, f64p)
     sig("lio_state_predict", cint, f64p, f64p, dbl, f64p, f64p, f64p, f64p, f64p)
+    sig("lio_eskf_update_sums_cb", cint, f64p, f64p, dbl, cint, cint, SUMS_FN, DEG_FN, vp, f64p, f64p, C.POINTER(PassLog), cint, C.POINTER(cint))
     sig("lio_eskf_update_cb", cint, f64p, f64p, dbl, cint, MEAS_FN, vp, cint, f64p, f64p)
     sig("lio_scan_enable_kernel_timing", cint, vp, cint)
     sig("lio_scan_kernel_times", cint, vp, C.POINTER(KernelTimes), cint)

@@ -549,6 +549,47 @@ def eskf_update(s, P, R, model, max_iter=4, cap=4096):
     return so, Po.reshape(23, 23)
 
 
+def sums_of_rows(rows, h):
+    """the 29 numbers a device linearisation hands the filter: J^T J upper triangle row by row, J^T h, sum |r|, N_eff"""
+    rows, h = np.asarray(rows, np.float64).reshape(-1, 6), np.asarray(h, np.float64).ravel()
+    JtJ, Jth = rows.T @ rows, rows.T @ h
+    return np.concatenate([[JtJ[a, b] for a in range(6) for b in range(a, 6)], Jth, [np.abs(h).sum(), float(len(h))]])
+
+
+def eskf_update_sums(s, P, R, model, max_iter=4, degenerate_detect=False):
+    """the DEVICE-resident form of the iterated update (csrc/eskf_dev.h compiled for the host) with a Python model:
+    model(state26, converge) -> (rows (n, 6), h (n,)) or None.  Returns (state26, P, logs, status)."""
+    s, P = f64(s), f64(P).reshape(-1)
+    so, Po = np.zeros(STATE_DIM), np.zeros(529)
+    last = {}
+
+    def _sums(ctx, s26, converge, acc):
+        r = model(np.ctypeslib.as_array(s26, shape=(STATE_DIM,)).copy(), bool(converge))
+        if r is None:
+            return 0
+        last["rows"] = np.asarray(r[0], np.float64).reshape(-1, 6)
+        np.ctypeslib.as_array(acc, shape=(29,))[:] = sums_of_rows(r[0], r[1])
+        return 1
+
+    def _deg(ctx, V, cs):  # laserMapping.cpp:946-964 on the rows of the last evaluation
+        Vm = np.ctypeslib.as_array(V, shape=(9,)).reshape(3, 3)
+        n = last["rows"][:, :3]
+        n = n / np.linalg.norm(n, axis=1, keepdims=True)
+        d = np.abs(n @ Vm).astype(np.float32).astype(np.float64)
+        out = np.ctypeslib.as_array(cs, shape=(6,))
+        out[:3] = np.where(d > np.float32(0.1736), d, 0).sum(0)
+        out[3:] = np.where(d > np.float32(0.7070), d, 0).sum(0)
+
+    f1, f2 = capi.SUMS_FN(_sums), capi.DEG_FN(_deg)
+    logs = (capi.PassLog * 8)()
+    status = C.c_int(0)
+    n = check(lib().lio_eskf_update_sums_cb(ptr(s, C.c_double), ptr(P, C.c_double), float(R), max_iter, int(degenerate_detect), f1, f2, None,
+                                            ptr(so, C.c_double), ptr(Po, C.c_double), logs, 8, C.byref(status)), "eskf_update_sums")
+    out = [dict(knn=l.knn, n_eff=l.n_eff, valid=l.valid, degenerate=l.degenerate, sum_abs_res=l.sum_abs_res, JtJ=np.array(l.JtJ).reshape(6, 6),
+                Jtr=np.array(l.Jtr), dx=np.array(l.dx)) for l in logs[:n]]
+    return so, Po.reshape(23, 23), out, status.value
+
+
 class PoseEstimator:
     """hdl_localization::PoseEstimator over the device matcher: 23-state UKF (host, f32) + lio_ndt_align.
     Stamps in microseconds, quaternions (w, x, y, z), as in the reference."""

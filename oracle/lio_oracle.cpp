@@ -1005,9 +1005,10 @@ struct Lio {
                 Mat Kx15 = mul(Pi15, HTH);
                 K_x = Mat(n, n);
                 for (int a = 0; a < n; a++) for (int b = 0; b < 15; b++) K_x(a, b) = Kx15(a, b);
-                for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) pl.JtJ[a * 6 + b] = HTH(a, b);
-                for (int a = 0; a < 6; a++) { double s = 0; for (int r = 0; r < dof; r++) s += hx(r, a) * dyn.h[r]; pl.Jtr[a] = s; }
             }
+            // test visibility (both branches): the leading 6 x 6 of h_x^T h_x and the first six of h_x^T h, after the degeneracy projection
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { double s = 0; for (int r = 0; r < dof; r++) s += hx(r, a) * hx(r, b); pl.JtJ[a * 6 + b] = s; }
+            for (int a = 0; a < 6; a++) { double s = 0; for (int r = 0; r < dof; r++) s += hx(r, a) * dyn.h[r]; pl.Jtr[a] = s; }
             double dx_[23];
             for (int a = 0; a < n; a++) {
                 double s = K_h[a];

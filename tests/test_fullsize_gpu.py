@@ -36,7 +36,6 @@ def _run(oracle_mod, n_map, seeds, fov_deg, max_range, max_voxels):
     R = None
     if ref_fastlio.available():
         R = ref_fastlio.RefFastLio()
-        R.set_logging(False)
         R.map_add(mp)
         R.set_nearby(18)
     worst = dict(o_dp=0.0, o_da=0.0, r_dp=0.0, r_da=0.0, truth=0.0)

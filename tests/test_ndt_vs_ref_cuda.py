@@ -110,7 +110,10 @@ def test_alignment_against_the_references_registration_object(method):
         Tr, conv_r, it_r = r.align(G)
         # the reference against itself: five more runs from the same guess (f32 atomics in its voxel map and Thrust reductions of
         # unspecified order make every run different); its spread is the resolution at which "the reference's pose" is defined
-        reruns = [r.align(G)[0] for _ in range(5)]
+        reruns = []
+        for _ in range(5):
+            r.set_target(mp)  # the voxel map is where its atomics are: rebuild it, then align again
+            reruns.append(r.align(G)[0])
         Tg, conv_g, it_g = g.align(s, G)
         dt, dr = float(np.linalg.norm(Tg[:3, 3] - Tr[:3, 3])), _rot_angle(Tg, Tr)
         st = max(float(np.linalg.norm(T2[:3, 3] - Tr[:3, 3])) for T2 in reruns)
