@@ -321,6 +321,35 @@ typedef struct lio_scan_job {
     int32_t n_ds, n_pass, n_knn_pass;
 } lio_scan_job;
 int lio_engines_process_batch(lio_engine** engines, int n_engines, lio_scan_job* jobs, int n_jobs);
+/* Throughput mode, batched: B scans per launch.  A batch owns `n_groups` groups of `n_slots` slots (scan buffers + a device-resident
+ * filter each); lio_batch_process hands the jobs to the groups round-robin from ONE host thread: a round = one small upload (states,
+ * covariances, descriptors), the voxel-grid chain and (maximum_iter + 1) x {stencil kNN where the filter asks for it, linearisation,
+ * filter pass} enqueued blind on the group's stream -- every launch serves all slots (blockIdx.y = slot), the iterate loop of
+ * update_iterated_dyn_share_modified (esekfom.hpp:1619-1931) runs on the device (csrc/eskf_dev.h), and the host sees one result record per
+ * scan in mapped memory.  Same job semantics and results as lio_engines_process_batch on engines created with lio_engine_create_shared
+ * (static map: map_incremental is skipped); a pass that needs the N_eff < 23 dense branch of the filter is finished on the host. */
+typedef struct lio_batch lio_batch;
+typedef struct lio_batch_result {
+    double state[26];
+    int32_t status;        /* 1 finished on the device, 2 a pass saw 1 <= N_eff < 23: state / loop_* are those BEFORE that pass */
+    int32_t n_pass, n_knn_pass, n_ds, n_eff, degenerate, radix_passes, err;
+    int32_t loop_i, loop_t, loop_converge, pad;
+    uint32_t seq, pad2;
+} lio_batch_result;
+lio_batch* lio_batch_create(lio_map* shared_map, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds);
+void lio_batch_destroy(lio_batch*);
+int lio_batch_process(lio_batch*, lio_scan_job* jobs, int n_jobs);
+/* live kernel timing of the batched chain with HIP events on the groups' streams (bench.py's roofline leg): per class the summed device
+ * time and the number of timed launches (a "downsample" launch = the whole voxel-grid chain of one round; a kNN / linearise / filter-pass
+ * launch = one kernel serving all slots of a round).  Off by default. */
+typedef struct lio_batch_times {
+    double downsample_us, knn_us, linearize_us, step_us;
+    uint32_t downsample_launches, knn_launches, linearize_launches, step_launches;
+} lio_batch_times;
+int lio_batch_enable_kernel_timing(lio_batch*, int on);
+int lio_batch_kernel_times(lio_batch*, lio_batch_times* out, int reset);
+/* test visibility: the engine behind slot `slot` of group `group` (its scan buffers, pass log of a host continuation) */
+lio_engine* lio_batch_engine(lio_batch*, int group, int slot);
 /* on: process_scan skips map_incremental -- scan-to-map registration against a prebuilt static map
  * (BASELINE.json configs 2 and 4); off (default): the reference's mapping behaviour */
 int lio_engine_set_static_map(lio_engine*, int on);

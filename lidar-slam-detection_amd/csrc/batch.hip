@@ -1,0 +1,333 @@
+// batch.hip -- throughput mode: B scans per launch, iterate loop on the device (lio_batch_* of include/lio_hip.h).
+//
+// What fastlio_main does per scan after IMU processing (/root/reference/slam/mapping/fastlio/src/laserMapping.cpp:1189-1304, static
+// map: no map_incremental) for B independent scans at once.  Round-1's throughput mode ran one engine + host thread + stream per scan
+// in flight: ~25 launches and 4.75 host hand-overs per scan, each launch on a 5-15 us latency floor with a few hundred workgroups.
+// Here a round of B scans is ONE blind submission: every kernel of the chain is launched once with blockIdx.y = slot, the filter
+// lives on the device (eskf_dev.h), and the only host work per scan is filling 9 KB of staging and reading a 300-byte result record.
+#include <sched.h>
+
+#include <chrono>
+#include <deque>
+#include <vector>
+
+#include "eskf.h"
+#include "lio_common.h"
+
+using namespace lio;
+
+int engine_resume_update(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t);  // engine.hip
+void engine_count_passes(lio_engine* e, int* n_pass, int* n_knn);
+
+namespace {
+
+struct Group {
+    hipStream_t stream = nullptr;
+    std::vector<lio_engine*> eng;
+    SlotDesc* d_desc = nullptr;
+    SlotDesc* h_desc = nullptr;          // pinned
+    EskfDev* d_ctrl = nullptr;
+    EskfDev* h_ctrl = nullptr;           // pinned staging
+    lio_batch_result* h_res = nullptr;   // pinned, mapped
+    lio_batch_result* h_res_dev = nullptr;
+    std::vector<int> job_of_slot;
+    int n_active = 0;
+    int launched_passes = 4;
+    uint32_t seq = 0;
+    uint32_t max_n_raw = 0;
+    BatchTimer* bt = nullptr;
+};
+
+}  // namespace
+
+struct lio_batch {
+    lio_map* map = nullptr;
+    int device = 0;
+    int n_slots = 0;
+    uint32_t max_raw = 0, max_ds = 0;
+    int pred_passes = 4;  // radix passes the last rounds needed
+    std::vector<Group> groups;
+};
+
+namespace {
+
+constexpr size_t kCtrlUpload = offsetof(EskfDev, log);  // the logs are written by the device only
+
+void group_free(Group& g) {
+    for (lio_engine* e : g.eng) lio_engine_destroy(e);
+    if (g.d_desc) hipFree(g.d_desc);
+    if (g.h_desc) hipHostFree(g.h_desc);
+    if (g.d_ctrl) hipFree(g.d_ctrl);
+    if (g.h_ctrl) hipHostFree(g.h_ctrl);
+    if (g.h_res) hipHostFree(g.h_res);
+    if (g.stream) hipStreamDestroy(g.stream);
+    if (g.bt) {
+        if (g.bt->created)
+            for (int c = 0; c < BatchTimer::kClasses; c++)
+                for (int i = 0; i < BatchTimer::kPool; i++) { hipEventDestroy(g.bt->ev[c][i][0]); hipEventDestroy(g.bt->ev[c][i][1]); }
+        delete g.bt;
+    }
+}
+
+// one round: jobs[first .. first + n) into the slots of g, everything enqueued on g.stream
+int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int passes) {
+    const int B = b->n_slots;
+    g.seq++;
+    g.n_active = 0;
+    g.max_n_raw = 0;
+    g.launched_passes = passes;
+    for (int s = 0; s < B; s++) {
+        SlotDesc& d = g.h_desc[s];
+        d.active = 0;
+        g.job_of_slot[s] = -1;
+        if (s >= n) continue;
+        lio_scan_job& job = jobs[first + s];
+        g.job_of_slot[s] = first + s;
+        job.rc = LIO_E_INVALID;
+        job.n_ds = job.n_pass = job.n_knn_pass = 0;
+        if (!job.state_in || !job.cov_in || (!job.d_raw && job.n_raw)) continue;
+        if (job.n_raw > b->max_raw) { set_error("scan of %u points exceeds max_raw %u", job.n_raw, b->max_raw); job.rc = LIO_E_CAPACITY; continue; }
+        if (job.n_raw == 0) { job.rc = 2; continue; }  // "FastLio undistort points is empty"
+        d.raw = static_cast<const float4*>(job.d_raw);
+        d.n_raw = job.n_raw;
+        d.nblocks = (job.n_raw + 2047u) / 2048u;
+        d.active = 1;
+        d.seq = g.seq;
+        d.min_ds = 5;  // laserMapping.cpp:1246: fewer than five downsampled points are not registered
+        EskfDev& c = g.h_ctrl[s];
+        memcpy(c.x, job.state_in, sizeof(double) * 26);
+        memcpy(c.P, job.cov_in, sizeof(double) * 529);
+        for (int k = 0; k < kEkN; k++) c.limit[k] = 0.001;
+        c.R = 0.001;  // LASER_POINT_COV
+        c.maximum_iter = 4;
+        c.degenerate_detect_en = 1;
+        c.is_degenerate = 0;
+        ek_begin(c);
+        g.h_res[s].seq = g.seq - 1;
+        g.n_active++;
+        if (job.n_raw > g.max_n_raw) g.max_n_raw = job.n_raw;
+    }
+    if (g.n_active == 0) return LIO_OK;
+    LIO_HIP_TRY(hipMemcpyAsync(g.d_desc, g.h_desc, sizeof(SlotDesc) * (size_t)B, hipMemcpyHostToDevice, g.stream));
+    for (int s = 0; s < B; s++)
+        if (g.h_desc[s].active) LIO_HIP_TRY(hipMemcpyAsync(&g.d_ctrl[s], &g.h_ctrl[s], kCtrlUpload, hipMemcpyHostToDevice, g.stream));
+    if (g.bt) g.bt->begin(0);
+    int rc = vg_downsample_batch(g.stream, g.d_desc, B, g.max_n_raw, b->max_ds, 0.5f, passes);
+    if (g.bt) g.bt->end(0);
+    if (rc != LIO_OK) return rc;
+    const uint32_t ds_bound = g.max_n_raw < b->max_ds ? g.max_n_raw : b->max_ds;
+    return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, g.bt);
+}
+
+int wait_group(Group& g, int B) {
+    for (int s = 0; s < B; s++) {
+        if (!g.h_desc[s].active) continue;
+        volatile uint32_t* seq = &g.h_res[s].seq;
+        for (uint64_t spin = 0; *seq != g.seq; spin++) {
+            __builtin_ia32_pause();
+            if (spin > 2000 && (spin & 31) == 0) sched_yield();
+            if (spin > 40000000ull) {
+                LIO_HIP_TRY(hipStreamSynchronize(g.stream));
+                if (*seq != g.seq) { set_error("batch slot %d did not report (seq %u, expected %u)", s, *seq, g.seq); return LIO_E_DEVICE; }
+                break;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return LIO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds) {
+    if (!map || n_slots < 1 || n_slots > 64 || n_groups < 1 || n_groups > 8 || max_raw == 0 || max_ds == 0) { set_error("lio_batch_create: bad argument"); return nullptr; }
+    if (hipSetDevice(map->device) != hipSuccess) { set_error("lio_batch_create: no HIP device %d", map->device); return nullptr; }
+    lio_batch* b = new lio_batch();
+    b->map = map;
+    b->device = map->device;
+    b->n_slots = n_slots;
+    b->max_raw = max_raw;
+    b->max_ds = max_ds;
+    b->groups.resize(n_groups);
+    bool ok = true;
+    for (Group& g : b->groups) {
+        g.job_of_slot.assign(n_slots, -1);
+        ok = ok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_desc), sizeof(SlotDesc) * n_slots) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_desc), sizeof(SlotDesc) * n_slots, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_ctrl), sizeof(EskfDev) * n_slots) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_ctrl), sizeof(EskfDev) * n_slots, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_res), sizeof(lio_batch_result) * n_slots, hipHostMallocMapped) == hipSuccess;
+        ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&g.h_res_dev), g.h_res, 0) == hipSuccess;
+        if (!ok) break;
+        memset(g.h_desc, 0, sizeof(SlotDesc) * n_slots);
+        memset(g.h_ctrl, 0, sizeof(EskfDev) * n_slots);
+        memset(g.h_res, 0, sizeof(lio_batch_result) * n_slots);
+        ok = hipMemset(g.d_ctrl, 0, sizeof(EskfDev) * n_slots) == hipSuccess;
+        for (int s = 0; s < n_slots && ok; s++) {
+            lio_engine* e = lio_engine_create_shared(map, max_raw, max_ds);
+            if (!e) { ok = false; break; }
+            lio_engine_set_flags(e, 1, 0, 0.0, -10.0);
+            g.eng.push_back(e);
+            lio_scan* sc = lio_engine_scan(e);
+            SlotDesc& d = g.h_desc[s];
+            d.max_ds = sc->max_ds;
+            d.partial_blocks = sc->partial_blocks;
+            d.sd = sc->dev;
+            d.keys_a = sc->keys_a; d.keys_b = sc->keys_b; d.vals_a = sc->vals_a; d.vals_b = sc->vals_b;
+            d.hist = sc->hist; d.blockcnt = sc->blockcnt; d.hpos = sc->hpos; d.longlist = sc->longlist;
+            d.sorted = sc->sorted; d.ds_body = sc->ds_body; d.ds_world = sc->ds_world; d.nn_pts = sc->nn_pts; d.normvec = sc->normvec;
+            d.nn_cnt = sc->nn_cnt; d.selected = sc->selected; d.partial = sc->partial;
+            d.host_nds = sc->host_nds_dev;
+            d.ctrl = &g.d_ctrl[s];
+            d.result = &g.h_res_dev[s];
+        }
+    }
+    if (!ok) {
+        set_error("lio_batch_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
+        lio_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+void lio_batch_destroy(lio_batch* b) {
+    if (!b) return;
+    hipSetDevice(b->device);
+    for (Group& g : b->groups) {
+        if (g.stream) hipStreamSynchronize(g.stream);
+        group_free(g);
+    }
+    delete b;
+}
+
+int lio_batch_enable_kernel_timing(lio_batch* b, int on) {
+    if (!b) return LIO_E_INVALID;
+    hipSetDevice(b->device);
+    for (Group& g : b->groups) {
+        if (!g.bt) { g.bt = new BatchTimer(); g.bt->stream = g.stream; }
+        if (on && !g.bt->created) {
+            for (int c = 0; c < BatchTimer::kClasses; c++)
+                for (int i = 0; i < BatchTimer::kPool; i++) {
+                    LIO_HIP_TRY(hipEventCreate(&g.bt->ev[c][i][0]));
+                    LIO_HIP_TRY(hipEventCreate(&g.bt->ev[c][i][1]));
+                }
+            g.bt->created = true;
+        }
+        g.bt->on = on != 0;
+    }
+    return LIO_OK;
+}
+
+int lio_batch_kernel_times(lio_batch* b, lio_batch_times* out, int reset) {
+    if (!b || !out) return LIO_E_INVALID;
+    memset(out, 0, sizeof(*out));
+    for (Group& g : b->groups) {
+        if (!g.bt) continue;
+        out->downsample_us += g.bt->us[0]; out->knn_us += g.bt->us[1]; out->linearize_us += g.bt->us[2]; out->step_us += g.bt->us[3];
+        out->downsample_launches += g.bt->launches[0]; out->knn_launches += g.bt->launches[1]; out->linearize_launches += g.bt->launches[2];
+        out->step_launches += g.bt->launches[3];
+        if (reset)
+            for (int c = 0; c < BatchTimer::kClasses; c++) { g.bt->us[c] = 0; g.bt->launches[c] = 0; }
+    }
+    return LIO_OK;
+}
+
+lio_engine* lio_batch_engine(lio_batch* b, int group, int slot) {
+    if (!b || group < 0 || group >= (int)b->groups.size() || slot < 0 || slot >= b->n_slots) return nullptr;
+    return b->groups[group].eng[slot];
+}
+
+int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
+    if (!b || (!jobs && n_jobs) || n_jobs < 0) return LIO_E_INVALID;
+    hipSetDevice(b->device);
+    const int B = b->n_slots;
+    int next = 0, first_err = 0;
+    std::deque<int> inflight;
+    std::vector<int> retry;  // jobs whose sort was launched with too few radix passes (the bounding box grew across a power of 256)
+    auto note = [&](int rc) { if (rc < 0 && !first_err) first_err = rc; };
+    auto collect = [&](Group& g) {
+        int need_max = 1;
+        for (int s = 0; s < B; s++) {
+            const int j = g.job_of_slot[s];
+            if (j < 0 || !g.h_desc[s].active) continue;
+            lio_scan_job& job = jobs[j];
+            const lio_batch_result& r = g.h_res[s];
+            if (r.radix_passes > need_max) need_max = r.radix_passes;
+            if (r.radix_passes > g.launched_passes) { retry.push_back(j); continue; }
+            lio_engine* e = g.eng[s];
+            lio_scan* sc = lio_engine_scan(e);
+            sc->have_ds = r.n_ds;
+            sc->n_raw = g.h_desc[s].n_raw;
+            job.n_ds = r.n_ds;
+            job.n_pass = r.n_pass;
+            job.n_knn_pass = r.n_knn_pass;
+            if (r.err & 1) {
+                set_error("downsampled scan exceeds max_ds %u", b->max_ds);
+                hipMemsetAsync(&sc->dev->err, 0, 4, g.stream);
+                job.rc = LIO_E_CAPACITY;
+                note(job.rc);
+                continue;
+            }
+            if (r.status == EK_SKIPPED) { job.rc = 2; continue; }  // fewer than five downsampled points
+            if (r.status == EK_NEEDS_HOST) {
+                // a pass with 1 <= N_eff < 23: the dense gain of esekfom.hpp:1715-1744 needs the rows -- the host filter takes over from
+                // that pass on, through the per-pass path of the slot's engine (same scan buffers, same neighbour cache and gates)
+                const int rc = engine_resume_update(e, r.state, job.state_in, job.cov_in, r.loop_i, r.loop_converge, r.loop_t);
+                if (rc != LIO_OK) { job.rc = rc; note(rc); continue; }
+                int np = 0, nk = 0;
+                engine_count_passes(e, &np, &nk);
+                job.n_pass += np;
+                job.n_knn_pass += nk;
+                if (job.state_out) lio_engine_get_state(e, job.state_out);
+                job.rc = 3;
+                continue;
+            }
+            if (job.state_out) memcpy(job.state_out, r.state, sizeof(double) * 26);
+            job.rc = 3;
+        }
+        if (need_max > 4) need_max = 4;
+        b->pred_passes = need_max;
+    };
+    for (size_t gi = 0; gi < b->groups.size() && next < n_jobs; gi++) {
+        const int n = n_jobs - next < B ? n_jobs - next : B;
+        const int rc = submit(b, b->groups[gi], jobs, next, n, b->pred_passes);
+        if (rc != LIO_OK) return rc;
+        next += n;
+        inflight.push_back((int)gi);
+    }
+    while (!inflight.empty()) {
+        const int gi = inflight.front();
+        inflight.pop_front();
+        Group& g = b->groups[gi];
+        if (g.n_active) {
+            const int rc = wait_group(g, B);
+            if (rc != LIO_OK) return rc;
+        }
+        if (g.bt && g.bt->on) { hipStreamSynchronize(g.stream); g.bt->resolve(); }
+        collect(g);
+        if (next < n_jobs) {
+            const int n = n_jobs - next < B ? n_jobs - next : B;
+            const int rc = submit(b, g, jobs, next, n, b->pred_passes);
+            if (rc != LIO_OK) return rc;
+            next += n;
+            inflight.push_back(gi);
+        }
+    }
+    // the rare re-runs, one by one with all four radix passes
+    const std::vector<int> todo = retry;
+    retry.clear();
+    for (const int j : todo) {
+        Group& g = b->groups[0];
+        int rc = submit(b, g, jobs, j, 1, 4);
+        if (rc == LIO_OK && g.n_active) rc = wait_group(g, B);
+        if (rc != LIO_OK) return rc;
+        collect(g);
+    }
+    for (const int j : retry) { jobs[j].rc = LIO_E_DEVICE; note(LIO_E_DEVICE); }
+    return first_err;
+}
+
+}  // extern "C"

@@ -268,6 +268,8 @@ int run_update(lio_engine* e) {
     bool have_prev = false;
     auto measure = [&](const LioState& x, bool converge, Measurement& m) {
         lio_pass_log pl;
+        memset(&pl, 0, sizeof(pl));
+        if (ctx.rc != LIO_OK) { m.valid = false; return; }  // a device error earlier in this update: no further launches
         const int rc = measure_pass(e, x, converge, m, pl);
         if (rc != LIO_OK) { ctx.rc = rc; m.valid = false; e->log.push_back(pl); return; }
         if (!m.valid && have_prev) {
@@ -291,6 +293,53 @@ int run_update(lio_engine* e) {
 }
 
 }  // namespace
+
+// The device-resident loop (batch.hip) stops before a pass that needs the rows themselves (1 <= N_eff < 23, esekfom.hpp:1715-1744);
+// the host filter continues from exactly there: state at the start of that pass, the propagated state / covariance of the update, the
+// loop counters -- through this engine's per-pass path (same scan buffers, neighbour cache and gate flags the device loop left).
+int engine_resume_update(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t) {
+    if (!e || !x_now26 || !x_prop26 || !P_prop) return LIO_E_INVALID;
+    hipSetDevice(e->scan->device);
+    e->log.clear();
+    memset(&e->tm, 0, sizeof(e->tm));
+    PassCtx ctx{e, LIO_OK};
+    Eskf::Work w;
+    state_from_array(x_prop26, w.x_prop);
+    memcpy(w.P_prop, P_prop, sizeof(w.P_prop));
+    memset(w.K_x, 0, sizeof(w.K_x));
+    memset(w.K_h, 0, sizeof(w.K_h));
+    memset(w.dx_new, 0, sizeof(w.dx_new));
+    state_from_array(x_now26, e->kf.x);
+    memcpy(e->kf.P, P_prop, sizeof(w.P_prop));
+    Measurement prev;
+    std::vector<double> prev_rows, prev_h;
+    bool have_prev = false;
+    auto measure = [&](const LioState& x, bool conv, Measurement& m) {
+        lio_pass_log pl;
+        memset(&pl, 0, sizeof(pl));
+        if (ctx.rc != LIO_OK) { m.valid = false; return; }
+        const int rc = measure_pass(e, x, conv, m, pl);
+        if (rc != LIO_OK) { ctx.rc = rc; m.valid = false; e->log.push_back(pl); return; }
+        if (!m.valid && have_prev) {
+            m = prev;
+            if (prev.rows6) { m.rows6 = prev_rows.data(); m.h = prev_h.data(); }
+            pl.valid = 1;
+            memcpy(pl.JtJ, m.HTH, sizeof(pl.JtJ));
+            memcpy(pl.Jtr, m.HTh, sizeof(pl.Jtr));
+        } else if (m.valid) {
+            prev = m;
+            if (m.rows6) { prev_rows.assign(m.rows6, m.rows6 + (size_t)m.n_rows * 6); prev_h.assign(m.h, m.h + m.n_rows); }
+            have_prev = true;
+        }
+        e->log.push_back(pl);
+    };
+    e->kf.update_iterated_from(w, i, converge != 0, t, e->laser_cov, measure, on_pass, &ctx);
+    return ctx.rc;
+}
+void engine_count_passes(lio_engine* e, int* n_pass, int* n_knn) {
+    *n_pass = e->tm.n_pass;
+    *n_knn = e->tm.n_knn_pass;
+}
 
 extern "C" {
 

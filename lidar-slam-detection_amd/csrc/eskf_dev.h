@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #if defined(__HIP__)  // compiled as HIP: one definition for both passes, the loops differ
+#include <hip/hip_runtime.h>
 #define EK_FN __host__ __device__ inline
 #else
 #define EK_FN inline
@@ -43,7 +44,7 @@ struct EkPassLog {   // = lio_pass_log
     double dx[23];
 };
 
-enum { EK_RUNNING = 0, EK_DONE = 1, EK_NEEDS_HOST = 2 };
+enum { EK_RUNNING = 0, EK_DONE = 1, EK_NEEDS_HOST = 2, EK_SKIPPED = 3 };
 
 // device-resident control block of one scan's iterated update
 struct EskfDev {

@@ -22,6 +22,7 @@
 // canonical (d2, x, y, z) order.  They are detected on the sorted top-6 and the query is queued for
 // knn_exact_kernel, which redoes it with the full comparison (rare: ~1e-6 per query on float data).
 #include "hashgrid.h"
+#include "knn_dev.h"
 #include "lio_common.h"
 
 namespace lio {
@@ -41,25 +42,6 @@ namespace lio {
 constexpr int kG = LIO_KNN_G;          // lanes per query
 constexpr int kU = LIO_KNN_U;          // voxels swept together (loads in flight per lane), multiple of 4
 constexpr int kGPB = 256 / kG;         // queries per workgroup
-
-__device__ inline void body_to_world(const PoseArgs& P, const float4 pb, float4& pw) {
-    // laserMapping.cpp:831-836: p_global = rot * (offset_R_L_I * p_body + offset_T_L_I) + pos, in double, stored float.
-    // Quaternion * vector as Eigen's _transformVector: uv = 2 (q.vec x v); v + w uv + q.vec x uv
-    const double vx = (double)pb.x, vy = (double)pb.y, vz = (double)pb.z;
-    double ux = P.ql[1] * vz - P.ql[2] * vy, uy = P.ql[2] * vx - P.ql[0] * vz, uz = P.ql[0] * vy - P.ql[1] * vx;
-    ux += ux; uy += uy; uz += uz;
-    double cx = P.ql[1] * uz - P.ql[2] * uy, cy = P.ql[2] * ux - P.ql[0] * uz, cz = P.ql[0] * uy - P.ql[1] * ux;
-    const double ix = ((vx + P.ql[3] * ux) + cx) + P.tl[0];
-    const double iy = ((vy + P.ql[3] * uy) + cy) + P.tl[1];
-    const double iz = ((vz + P.ql[3] * uz) + cz) + P.tl[2];
-    ux = P.qw[1] * iz - P.qw[2] * iy; uy = P.qw[2] * ix - P.qw[0] * iz; uz = P.qw[0] * iy - P.qw[1] * ix;
-    ux += ux; uy += uy; uz += uz;
-    cx = P.qw[1] * uz - P.qw[2] * uy; cy = P.qw[2] * ux - P.qw[0] * uz; cz = P.qw[0] * uy - P.qw[1] * ux;
-    pw.x = (float)(((ix + P.qw[3] * ux) + cx) + P.tw[0]);
-    pw.y = (float)(((iy + P.qw[3] * uy) + cy) + P.tw[1]);
-    pw.z = (float)(((iz + P.qw[3] * uz) + cz) + P.tw[2]);
-    pw.w = pb.w;
-}
 
 // Reductions over the kG lanes of a query group.  With kG = 16 a group is exactly one DPP row: four v_min / v_add with a row-rotate
 // modifier (row_ror:8, 4, 2, 1) leave the result in every lane, no LDS crossbar (ds_bpermute) round trips -- the kernel used to issue
@@ -100,18 +82,6 @@ struct __attribute__((aligned(16))) GroupLds {
     uint32_t v_cnt[kMaxStencil + kU + 1];
     uint32_t v_dmin[kMaxStencil + kU + 1];  // bits of a lower bound of the squared distance from the query to any point of the voxel
 };
-
-// A voxel with key c holds points with |p_a * inv_res - c_a| <= 0.5 evaluated in f32 (pos2grid): |p_a - c_a * res| <= res / 2 up to
-// rounding of the product (6e-8 |p_a|).  The bound below shrinks the box side by 0.5 mm + 1e-6 |q_a| per axis (covers that rounding
-// and the one of q_a - c_a * res up to |q| ~ 10 km) and the sum by 1e-5 (covers the f32 evaluation of the candidates' own d2), so it
-// never exceeds the d2 the sweep would compute for a point of that voxel.
-__device__ inline uint32_t cell_min_d2_bits(float qx, float qy, float qz, int cx, int cy, int cz, float res) {
-    const float h = 0.5f * res;
-    const float ax = fmaxf(fabsf(qx - (float)cx * res) - h - (5e-4f + 1e-6f * fabsf(qx)), 0.f);
-    const float ay = fmaxf(fabsf(qy - (float)cy * res) - h - (5e-4f + 1e-6f * fabsf(qy)), 0.f);
-    const float az = fmaxf(fabsf(qz - (float)cz * res) - h - (5e-4f + 1e-6f * fabsf(qz)), 0.f);
-    return __float_as_uint((ax * ax + (ay * ay + az * az)) * 0.99999f);
-}
 
 // probe_stencil for stencils of at most 2 * kG cells (NEARBY6 / 18 / 26) with the hits BUCKETED by that lower bound: bucket 0 below
 // (res / 4)^2, bucket 1 below (res / 2)^2, bucket 2 the rest.  On return the list in g is bucket 0, then 1, then 2 (order inside a

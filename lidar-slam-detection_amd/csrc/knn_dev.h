@@ -1,0 +1,52 @@
+// knn_dev.h -- device inlines shared by the two stencil-kNN kernels (knn.hip: 16 lanes per query, knn_q.hip: 4) and the kernels
+// that read the pose from the device-resident filter state.
+#pragma once
+#include "eskf_dev.h"
+#include "lio_common.h"
+
+namespace lio {
+
+__device__ inline void body_to_world(const PoseArgs& P, const float4 pb, float4& pw) {
+    // laserMapping.cpp:831-836: p_global = rot * (offset_R_L_I * p_body + offset_T_L_I) + pos, in double, stored float.
+    // Quaternion * vector as Eigen's _transformVector: uv = 2 (q.vec x v); v + w uv + q.vec x uv
+    const double vx = (double)pb.x, vy = (double)pb.y, vz = (double)pb.z;
+    double ux = P.ql[1] * vz - P.ql[2] * vy, uy = P.ql[2] * vx - P.ql[0] * vz, uz = P.ql[0] * vy - P.ql[1] * vx;
+    ux += ux; uy += uy; uz += uz;
+    double cx = P.ql[1] * uz - P.ql[2] * uy, cy = P.ql[2] * ux - P.ql[0] * uz, cz = P.ql[0] * uy - P.ql[1] * ux;
+    const double ix = ((vx + P.ql[3] * ux) + cx) + P.tl[0];
+    const double iy = ((vy + P.ql[3] * uy) + cy) + P.tl[1];
+    const double iz = ((vz + P.ql[3] * uz) + cz) + P.tl[2];
+    ux = P.qw[1] * iz - P.qw[2] * iy; uy = P.qw[2] * ix - P.qw[0] * iz; uz = P.qw[0] * iy - P.qw[1] * ix;
+    ux += ux; uy += uy; uz += uz;
+    cx = P.qw[1] * uz - P.qw[2] * uy; cy = P.qw[2] * ux - P.qw[0] * uz; cz = P.qw[0] * uy - P.qw[1] * ux;
+    pw.x = (float)(((ix + P.qw[3] * ux) + cx) + P.tw[0]);
+    pw.y = (float)(((iy + P.qw[3] * uy) + cy) + P.tw[1]);
+    pw.z = (float)(((iz + P.qw[3] * uz) + cz) + P.tw[2]);
+    pw.w = pb.w;
+}
+
+
+// A voxel with key c holds points with |p_a * inv_res - c_a| <= 0.5 evaluated in f32 (pos2grid): |p_a - c_a * res| <= res / 2 up to
+// rounding of the product (6e-8 |p_a|).  The bound below shrinks the box side by 0.5 mm + 1e-6 |q_a| per axis (covers that rounding
+// and the one of q_a - c_a * res up to |q| ~ 10 km) and the sum by 1e-5 (covers the f32 evaluation of the candidates' own d2), so it
+// never exceeds the d2 the sweep would compute for a point of that voxel.
+__device__ inline uint32_t cell_min_d2_bits(float qx, float qy, float qz, int cx, int cy, int cz, float res) {
+    const float h = 0.5f * res;
+    const float ax = fmaxf(fabsf(qx - (float)cx * res) - h - (5e-4f + 1e-6f * fabsf(qx)), 0.f);
+    const float ay = fmaxf(fabsf(qy - (float)cy * res) - h - (5e-4f + 1e-6f * fabsf(qy)), 0.f);
+    const float az = fmaxf(fabsf(qz - (float)cz * res) - h - (5e-4f + 1e-6f * fabsf(qz)), 0.f);
+    return __float_as_uint((ax * ax + (ay * ay + az * az)) * 0.99999f);
+}
+
+
+// the rigid transforms of a 26-number filter state (lio_hip.h layout) as the kernels take them
+__device__ inline PoseArgs pose_from_state(const double* __restrict__ x) {
+    PoseArgs p;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { p.tw[i] = x[i]; p.tl[i] = x[11 + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { p.qw[i] = x[3 + i]; p.ql[i] = x[7 + i]; }
+    return p;
+}
+
+}  // namespace lio

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "../../include/lio_hip.h"
+#include "eskf_dev.h"
 
 namespace lio {
 
@@ -83,6 +84,28 @@ struct ScanDev {
 struct StencilArgs {
     int n;
     signed char off[kMaxStencil][3];
+};
+
+// One scan of a batch (lio_batch_*): everything a kernel needs about it, resident in device memory.  The per-job words are rewritten by
+// the host before every round (one small H2D copy for the whole batch); the rest are the buffers of the slot's lio_scan, fixed.
+// Batch kernels are launched with blockIdx.y = slot and read their arguments from here (uniform scalar loads).
+struct SlotDesc {
+    const float4* raw;       // the job's cloud (device)
+    uint32_t n_raw;
+    uint32_t nblocks;        // ceil(n_raw / 2048): sort tiles of this scan
+    uint32_t active;         // the slot has a job this round
+    uint32_t seq;            // sequence number the result record of this round carries
+    uint32_t max_ds, partial_blocks;
+    uint32_t min_ds, pad;    // scans that downsample to fewer points are not registered (5 in fastlio_main, 0 for a bare filter update)
+    ScanDev* sd;
+    uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *hist, *blockcnt, *hpos, *longlist;
+    float4 *sorted, *ds_body, *ds_world, *nn_pts, *normvec;
+    int32_t* nn_cnt;
+    uint8_t* selected;
+    double* partial;
+    uint32_t* host_nds;      // mapped pinned words {n_ds, err, radix passes needed} of the slot's scan
+    EskfDev* ctrl;           // device-resident filter of the slot
+    lio_batch_result* result;  // mapped pinned host record of the slot
 };
 
 }  // namespace lio
@@ -205,6 +228,32 @@ int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_s
                      const UndistortArgs& args, unsigned long long* d_block_min /* ceil(n / 256) words of scratch */);
 
 int vg_downsample(lio_scan* s, float leaf, int passes /* radix passes to launch, 1..4 */);
+int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes);
+int knn_q_batch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x);
+int knn_q_world(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt);
+// live kernel timing of the batched chain (bench.py's roofline leg): HIP events on the stream the kernels are launched on, per class
+struct BatchTimer {
+    static constexpr int kClasses = 4;  // 0 downsample chain, 1 stencil kNN, 2 linearise, 3 filter pass
+    static constexpr int kPool = 256;
+    hipEvent_t ev[kClasses][kPool][2];
+    int used[kClasses] = {0, 0, 0, 0};
+    double us[kClasses] = {0, 0, 0, 0};
+    uint32_t launches[kClasses] = {0, 0, 0, 0};
+    bool on = false, created = false;
+    hipStream_t stream = nullptr;
+    void begin(int c) { if (on && used[c] < kPool) hipEventRecord(ev[c][used[c]][0], stream); }
+    void end(int c) { if (on && used[c] < kPool) { hipEventRecord(ev[c][used[c]][1], stream); used[c]++; } }
+    void resolve() {  // after the stream was waited for
+        for (int c = 0; c < kClasses; c++) {
+            for (int i = 0; i < used[c]; i++) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev[c][i][0], ev[c][i][1]) == hipSuccess) { us[c] += (double)ms * 1000.0; launches[c]++; }
+            }
+            used[c] = 0;
+        }
+    }
+};
+int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt);
 int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);
 void kt_begin(lio_scan* s, int which);

@@ -18,6 +18,7 @@
 // -ffp-contract=off) in the operation order of Eigen's ColPivHouseholderQR (scalar build: unrolled redux trees for the
 // fixed-size norms, column-oriented triangular solve) so that gates flip exactly where the reference's own
 // esti_plane does (pinned through oracle/_ref, see tests/test_oracle_vs_ref.py).
+#include "knn_dev.h"
 #include "lio_common.h"
 
 namespace lio {
@@ -190,11 +191,11 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, int redo_knn, const ScanDev* __restrict__ sd,
-                                                                const float4* __restrict__ ds_body, float4* __restrict__ ds_world,
-                                                                const float4* __restrict__ nn_pts, uint32_t nn_stride,
-                                                                const int32_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
-                                                                float4* __restrict__ normvec, double* __restrict__ partial) {
+__device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_knn, const ScanDev* __restrict__ sd,
+                                               const float4* __restrict__ ds_body, float4* __restrict__ ds_world,
+                                               const float4* __restrict__ nn_pts, uint32_t nn_stride,
+                                               const int32_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
+                                               float4* __restrict__ normvec, double* __restrict__ partial) {
     const uint32_t n = sd->n_ds;
     if (blockIdx.x * kLinThreads >= n) return;  // finalize only reads the first ceil(n / kLinThreads) partials
     const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
@@ -270,6 +271,23 @@ __global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, i
         }
         partial[(size_t)blockIdx.x * kAcc + threadIdx.x] = s;
     }
+}
+
+__global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, int redo_knn, const ScanDev* __restrict__ sd,
+                                                                const float4* __restrict__ ds_body, float4* __restrict__ ds_world,
+                                                                const float4* __restrict__ nn_pts, uint32_t nn_stride,
+                                                                const int32_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
+                                                                float4* __restrict__ normvec, double* __restrict__ partial) {
+    linearize_body(pose, redo_knn, sd, ds_body, ds_world, nn_pts, nn_stride, nn_cnt, selected, normvec, partial);
+}
+// the scans of a batch: pose and the "redo the neighbour search" flag come from the slot's device-resident filter
+__global__ void __launch_bounds__(kLinThreads) linearize_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;
+    const EskfDev* c = d.ctrl;
+    if (c->status != EK_RUNNING || d.sd->n_ds < d.min_ds) return;
+    const PoseArgs pose = pose_from_state(c->x);
+    linearize_body(pose, c->converge, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, d.selected, d.normvec, d.partial);
 }
 
 // One workgroup folds the per-workgroup partials in a fixed order and writes the 29-number record straight into
@@ -377,6 +395,114 @@ __global__ void __launch_bounds__(256) degeneracy_kernel(const ScanDev* __restri
         const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         if (v != 0.0) atomicAdd(tid < 3 ? &out->contri[tid] : &out->strong[tid - 3], v);
     }
+}
+
+// ---- the device-resident iterate loop: one pass of esekf::update_iterated_dyn_share_modified per launch, one workgroup per scan ----
+// Folds the partial sums of the slot's linearisation exactly as finalize_kernel does (same owner lanes, same order: bit-identical
+// sums), then runs what the host did between two device passes: eigen-decomposition + degeneracy logic (the six sums over the
+// points are evaluated by this workgroup when the eigenvalue bound does not decide), stale-measurement rule, 23-DoF filter step,
+// convergence flags (eskf_dev.h).  A slot that finishes publishes its result record in mapped host memory.
+constexpr int kStepThreads = 1024;
+
+__device__ inline void publish_result(const SlotDesc& d, const EskfDev& c) {
+    lio_batch_result* r = d.result;
+    const int tid = threadIdx.x;
+    if (tid < 26) r->state[tid] = c.x[tid];
+    if (tid == 32) {
+        r->status = c.status; r->n_pass = c.n_pass; r->n_knn_pass = c.n_knn; r->n_ds = (int32_t)d.sd->n_ds;
+        r->n_eff = c.n_eff_last; r->degenerate = c.is_degenerate; r->radix_passes = (int32_t)((d.sd->nbits + 7u) >> 3); r->err = (int32_t)d.sd->err;
+        r->loop_i = c.i; r->loop_t = c.t; r->loop_converge = c.converge; r->pad = 0;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) *reinterpret_cast<volatile uint32_t*>(&r->seq) = d.seq;
+}
+
+__global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.x];
+    if (!d.active) return;
+    EskfDev& c = *d.ctrl;
+    if (c.status != EK_RUNNING) return;  // finished (and published) in an earlier pass
+    __shared__ EkWork w;
+    __shared__ double acc[kAcc];
+    __shared__ double red6[kStepThreads / 64][6];
+    const int tid = threadIdx.x;
+    const uint32_t n = d.sd->n_ds;
+    if ((d.sd->err & 1u) || n < d.min_ds) {  // more voxels than max_ds / too few points (laserMapping.cpp:1246): nothing is registered
+        if (tid == 0) c.status = EK_SKIPPED;
+        __syncthreads();
+        publish_result(d, c);
+        return;
+    }
+    const uint32_t nb = (n + kLinThreads - 1) / kLinThreads;
+    {
+        const int comp = tid >> 5, l = tid & 31;
+        double s = 0.0;
+        if (comp < kAcc)
+            for (uint32_t b = l; b < nb; b += 32) s += d.partial[(size_t)b * kAcc + comp];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (comp < kAcc && l == 0) acc[comp] = s;
+    }
+    __syncthreads();
+    const int knn = c.converge;
+    ek_measure_head(c, w, acc, knn);
+    if (w.flag[1]) {  // the six degeneracy sums (laserMapping.cpp:946-964): every addend is a float in (0.1736, 1] widened to double,
+                      // sums of < 2^17 of them are exact in f64 -> any reduction order gives the same bits
+        double s6[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t i = tid; i < n; i += kStepThreads) {
+            if (!d.selected[i]) continue;
+            const float4 nv = d.normvec[i];
+            double f0 = (double)nv.x, f1 = (double)nv.y, f2 = (double)nv.z;
+            const double nn = sqrt(f0 * f0 + f1 * f1 + f2 * f2);
+            if (nn > 0) { f0 /= nn; f1 /= nn; f2 /= nn; }
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                const float dotp = (float)fabs(f0 * w.eigvec[0 * 3 + e] + f1 * w.eigvec[1 * 3 + e] + f2 * w.eigvec[2 * 3 + e]);
+                if (dotp > 0.1736f) s6[e] += (double)dotp;
+                if (dotp > 0.7070f) s6[3 + e] += (double)dotp;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+            const double v = wave_sum(s6[e]);
+            if ((tid & 63) == 0) red6[tid >> 6][e] = v;
+        }
+        __syncthreads();
+        if (tid < 6) {
+            double v = 0.0;
+            for (int k = 0; k < kStepThreads / 64; k++) v += red6[k][tid];
+            w.cs[tid] = v;
+        }
+        __syncthreads();
+    }
+    ek_measure_tail(c, w);
+    if (c.status == EK_RUNNING && w.flag[0]) ek_step(c, w);
+    __syncthreads();
+    if (c.status != EK_RUNNING) publish_result(d, c);
+}
+
+// the whole iterated update of every slot, enqueued blind: (neighbour search if the filter asks for it, linearisation, filter pass) x
+// (maximum_iter + 1); slots that converge early skip the rest of the launches
+int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt) {
+    uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
+    if (lin_blocks == 0) lin_blocks = 1;
+    uint32_t knn_blocks = (ds_bound + 63) / 64;  // 64 queries per workgroup of knn_q
+    if (knn_blocks > 1024) knn_blocks = 1024;
+    if (knn_blocks == 0) knn_blocks = 8;
+    for (int p = 0; p < n_passes; p++) {
+        if (bt) bt->begin(1);
+        const int rc = knn_q_batch(m, st, d_slots, n_slots, knn_blocks);
+        if (bt) bt->end(1);
+        if (rc != LIO_OK) return rc;
+        if (bt) bt->begin(2);
+        hipLaunchKernelGGL(linearize_batch, dim3(lin_blocks, (uint32_t)n_slots), kLinThreads, 0, st, d_slots);
+        if (bt) { bt->end(2); bt->begin(3); }
+        hipLaunchKernelGGL(step_batch, dim3((uint32_t)n_slots), kStepThreads, 0, st, d_slots);
+        if (bt) bt->end(3);
+    }
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
 }
 
 int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {

@@ -34,7 +34,7 @@ __device__ inline uint32_t f2ord(float f) {
 }
 __device__ inline float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); }
 
-__global__ void __launch_bounds__(kThreads) vg_bbox_kernel(const float4* __restrict__ in, uint32_t n, ScanDev* sd) {
+__device__ __forceinline__ void vg_bbox_body(const float4* __restrict__ in, uint32_t n, ScanDev* sd) {
     float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
     uint32_t cnt = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -114,7 +114,7 @@ __device__ inline VgGrid vg_derive(const ScanDev* sd, float inv) {
 
 // voxel index of every point + the histogram of its lowest digit: one workgroup per sort tile, so the first radix pass needs
 // no histogram launch of its own (the later passes histogram the re-ordered keys)
-__global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
+__device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
                                                            uint32_t nblocks) {
     const VgGrid g = vg_derive(sd, inv);
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restr
 // up in (active & 1 ? b : a)
 __device__ inline uint32_t active_passes(const ScanDev* sd) { return (sd->nbits + 7u) >> 3; }
 
-__global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
+__device__ __forceinline__ void radix_hist_body(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                               int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
     if ((uint32_t)pass >= active_passes(sd)) return;
     const uint32_t* keys = (pass & 1) ? kb : ka;
@@ -189,7 +189,7 @@ __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
     return peers;
 }
 
-__global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
+__device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
                                                                  const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
     if ((uint32_t)pass >= active_passes(sd)) return;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __res
 }
 
 // ---- voxel heads: occupancy flags -> ballot + prefix-sum compaction -> centroid ------------------------
-__global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
+__device__ __forceinline__ void vg_count_heads_body(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                                   const ScanDev* sd, uint32_t* __restrict__ blockcnt) {
     const uint32_t* keys = (active_passes(sd) & 1) ? kb : ka;
     __shared__ uint32_t c;
@@ -301,12 +301,12 @@ __global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t
 }
 
 // compaction of the voxel heads (ballot + prefix sum, fixed order) and the gather of the points into sorted order
-__global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ ka,
+__device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, const uint32_t* __restrict__ ka,
                                                             const uint32_t* __restrict__ kb, const uint32_t* __restrict__ va,
                                                             const uint32_t* __restrict__ vb, uint32_t n, ScanDev* sd,
                                                             const uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ hpos,
                                                             float4* __restrict__ sorted, float4* __restrict__ out, uint32_t max_ds, uint32_t* __restrict__ host_nds,
-                                                            uint32_t launched_passes) {
+                                                            uint32_t launched_passes, uint32_t last_block) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (sd->passthrough) {  // PCL overflow guard: output = input
         if (blockIdx.x == 0 && tid == 0) host_nds[2] = 0u;
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __rest
         run += rtot;
         __syncthreads();
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    if (blockIdx.x == last_block && tid == 0) {
         uint32_t err = 0;
         if (run > max_ds) { sd->err |= 1u; run = 0; err = 1u; }
         // the host launched as many radix passes as the previous scan needed; if this scan's bounding box needs more, the keys
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __rest
 // kernel below, so that their latency is spread over the chip instead of serialising one wave.
 constexpr uint32_t kLongRun = 32;
 
-__global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
+__device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                ScanDev* __restrict__ sd, float4* __restrict__ out,
                                                                uint32_t* __restrict__ longlist) {
     if (sd->passthrough) return;
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __r
 
 // one wave per long run: 64 coalesced loads at a time, then the same sequential additions, fed by
 // v_readlane broadcasts (every lane forms the identical sum; lane 0 stores it)
-__global__ void __launch_bounds__(kThreads) vg_centroid_long_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
+__device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
                                                                     const uint32_t* __restrict__ longlist) {
     if (sd->passthrough) return;
@@ -457,7 +457,7 @@ __global__ void scan_set_nds_kernel(ScanDev* sd, uint32_t n) {
 
 // Nearest_Points.resize(feats_down_size) (laserMapping.cpp:1274): entries beyond the new size are destroyed
 // ... and re-arm the bbox / counters for the next scan's downsample (saves two memset launches per scan)
-__global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt) {
+__device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict__ nn_cnt) {
     const uint32_t lo = sd->n_ds, hi = sd->n_ds_prev;
     for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) nn_cnt[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 3) {
@@ -465,6 +465,95 @@ __global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt) {
         sd->bbox_max[threadIdx.x] = 0u;
         if (threadIdx.x == 0) { sd->n_valid = 0; sd->n_long = 0; }
     }
+}
+
+
+// ---- launchable forms: one scan (arguments by value), or the scans of a batch (blockIdx.y = slot, arguments from the slot's
+// descriptor in device memory; a workgroup beyond the slot's own tile count, or of an idle slot, exits at once) ----------------
+__global__ void __launch_bounds__(kThreads) vg_bbox_kernel(const float4* __restrict__ in, uint32_t n, ScanDev* sd) { vg_bbox_body(in, n, sd); }
+__global__ void __launch_bounds__(kThreads) vg_bbox_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;  // (grid-stride loop over the points: every workgroup of the row takes part)
+    vg_bbox_body(d.raw, d.n_raw, d.sd);
+}
+__global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
+                                                           uint32_t nblocks) {
+    vg_keys_body(in, n, inv, sd, keys, vals, hist, nblocks);
+}
+__global__ void __launch_bounds__(kThreads) vg_keys_batch(const SlotDesc* __restrict__ slots, float inv) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || blockIdx.x >= d.nblocks) return;
+    vg_keys_body(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks);
+}
+__global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
+                                                              int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
+    radix_hist_body(ka, kb, n, pass, hist, nblocks, sd);
+}
+__global__ void __launch_bounds__(kThreads) radix_hist_batch(const SlotDesc* __restrict__ slots, int pass) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || blockIdx.x >= d.nblocks) return;
+    radix_hist_body(d.keys_a, d.keys_b, d.n_raw, pass, d.hist, d.nblocks, d.sd);
+}
+__global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
+                                                                 uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
+                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
+    radix_scatter_body(ka, va, kb, vb, n, pass, hist, nblocks, sd);
+}
+__global__ void __launch_bounds__(kThreads) radix_scatter_batch(const SlotDesc* __restrict__ slots, int pass) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || blockIdx.x >= d.nblocks) return;
+    radix_scatter_body(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd);
+}
+__global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
+                                                                  const ScanDev* sd, uint32_t* __restrict__ blockcnt) {
+    vg_count_heads_body(ka, kb, n, sd, blockcnt);
+}
+__global__ void __launch_bounds__(kThreads) vg_count_heads_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || blockIdx.x >= d.nblocks) return;
+    vg_count_heads_body(d.keys_a, d.keys_b, d.n_raw, d.sd, d.blockcnt);
+}
+__global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ ka,
+                                                            const uint32_t* __restrict__ kb, const uint32_t* __restrict__ va,
+                                                            const uint32_t* __restrict__ vb, uint32_t n, ScanDev* sd,
+                                                            const uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ hpos,
+                                                            float4* __restrict__ sorted, float4* __restrict__ out, uint32_t max_ds, uint32_t* __restrict__ host_nds,
+                                                            uint32_t launched_passes) {
+    vg_heads_body(in, ka, kb, va, vb, n, sd, blockcnt, hpos, sorted, out, max_ds, host_nds, launched_passes, gridDim.x - 1);
+}
+__global__ void __launch_bounds__(kThreads) vg_heads_batch(const SlotDesc* __restrict__ slots, uint32_t launched_passes) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || blockIdx.x >= d.nblocks) return;
+    vg_heads_body(d.raw, d.keys_a, d.keys_b, d.vals_a, d.vals_b, d.n_raw, d.sd, d.blockcnt, d.hpos, d.sorted, d.ds_body, d.max_ds, d.host_nds,
+                  launched_passes, d.nblocks - 1);
+}
+__global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
+                                                               ScanDev* __restrict__ sd, float4* __restrict__ out,
+                                                               uint32_t* __restrict__ longlist) {
+    vg_centroid_body(sorted, hpos, sd, out, longlist);
+}
+__global__ void __launch_bounds__(kThreads) vg_centroid_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;
+    vg_centroid_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist);
+}
+__global__ void __launch_bounds__(kThreads) vg_centroid_long_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
+                                                                    const ScanDev* __restrict__ sd, float4* __restrict__ out,
+                                                                    const uint32_t* __restrict__ longlist) {
+    vg_centroid_long_body(sorted, hpos, sd, out, longlist);
+}
+// + the scan-begin duties (Nearest_Points.resize, re-arming the bbox) of the batch: the long-run kernel is the last of the chain
+__global__ void __launch_bounds__(kThreads) vg_centroid_long_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;
+    vg_centroid_long_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist);
+}
+__global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt) { scan_begin_body(sd, nn_cnt); }
+__global__ void scan_begin_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;
+    scan_begin_body(d.sd, d.nn_cnt);
 }
 
 int vg_downsample(lio_scan* s, float leaf, int passes) {
@@ -495,6 +584,28 @@ int vg_downsample(lio_scan* s, float leaf, int passes) {
     hipLaunchKernelGGL(vg_centroid_kernel, (vbound + kThreads - 1) / kThreads, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body,
                        s->longlist);
     hipLaunchKernelGGL(vg_centroid_long_kernel, 256, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body, s->longlist);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+// the downsample chain for the scans of a batch: every launch serves all slots (grid.y), nothing is read back
+int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes) {
+    const float inv = 1.0f / leaf;
+    const uint32_t nblocks = (max_raw + kTile - 1) / kTile;  // of the largest scan of the batch
+    if (nblocks == 0 || n_slots <= 0) return LIO_OK;
+    const uint32_t B = (uint32_t)n_slots;
+    hipLaunchKernelGGL(vg_bbox_batch, dim3(nblocks < 48 ? nblocks : 48, B), kThreads, 0, st, d_slots);
+    hipLaunchKernelGGL(vg_keys_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, inv);
+    for (int pass = 0; pass < passes; pass++) {
+        if (pass > 0) hipLaunchKernelGGL(radix_hist_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass);
+        hipLaunchKernelGGL(radix_scatter_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass);
+    }
+    hipLaunchKernelGGL(vg_count_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots);
+    hipLaunchKernelGGL(vg_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, (uint32_t)passes);
+    const uint32_t vbound = max_raw < max_ds ? max_raw : max_ds;
+    hipLaunchKernelGGL(vg_centroid_batch, dim3((vbound + kThreads - 1) / kThreads, B), kThreads, 0, st, d_slots);
+    hipLaunchKernelGGL(vg_centroid_long_batch, dim3(64, B), kThreads, 0, st, d_slots);
+    hipLaunchKernelGGL(scan_begin_batch, dim3(16, B), 256, 0, st, d_slots);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

@@ -25,7 +25,7 @@ SYMBOLS = [
     "lio_engine_create", "lio_engine_create_shared", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
     "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
-    "lio_engine_enable_timing", "lio_engines_process_batch", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
+    "lio_engine_enable_timing", "lio_engines_process_batch", "lio_batch_create", "lio_batch_destroy", "lio_batch_process", "lio_batch_engine", "lio_batch_enable_kernel_timing", "lio_batch_kernel_times", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
     "lio_localmap_create", "lio_localmap_destroy", "lio_localmap_add_keyframe", "lio_localmap_num_keyframes", "lio_localmap_update",
     "lio_localmap_download",
@@ -45,6 +45,11 @@ class NormalEq(C.Structure):
                 ("eigval", C.c_double * 3), ("contri", C.c_double * 3), ("strong", C.c_double * 3), ("sum_abs_res", C.c_double),
                 ("n_eff", C.c_uint32), ("n_ds", C.c_uint32), ("n_knn_candidates_lo", C.c_uint32), ("n_knn_candidates_hi", C.c_uint32),
                 ("n_tie", C.c_uint32), ("seq", C.c_uint32)]
+
+
+class BatchTimes(C.Structure):
+    _fields_ = [("downsample_us", C.c_double), ("knn_us", C.c_double), ("linearize_us", C.c_double), ("step_us", C.c_double),
+                ("downsample_launches", C.c_uint32), ("knn_launches", C.c_uint32), ("linearize_launches", C.c_uint32), ("step_launches", C.c_uint32)]
 
 
 class PassLog(C.Structure):
@@ -160,6 +165,12 @@ def lib():
     sig("lio_engine_timings", cint, vp, C.POINTER(Timings))
     sig("lio_engine_enable_timing", cint, vp, cint)
     sig("lio_engines_process_batch", cint, C.POINTER(vp), cint, C.POINTER(ScanJob), cint)
+    sig("lio_batch_create", vp, vp, cint, cint, u32, u32)
+    sig("lio_batch_destroy", None, vp)
+    sig("lio_batch_process", cint, vp, C.POINTER(ScanJob), cint)
+    sig("lio_batch_engine", vp, vp, cint, cint)
+    sig("lio_batch_enable_kernel_timing", cint, vp, cint)
+    sig("lio_batch_kernel_times", cint, vp, C.POINTER(BatchTimes), cint)
     sig("lio_engine_set_static_map", cint, vp, cint)
     sig("lio_localmap_create", vp, cint, u64, u32, u32)
     sig("lio_localmap_destroy", None, vp)

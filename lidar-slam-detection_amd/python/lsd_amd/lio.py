@@ -256,7 +256,7 @@ class Engine:
         self.scan = Scan(max_ds=max_ds, _borrow=lib().lio_engine_scan(self.h))
 
     def close(self):
-        if getattr(self, "h", None) and lib is not None:
+        if getattr(self, "h", None) and getattr(self, "_own", True) and lib is not None:
             lib().lio_engine_destroy(self.h)
         self.h = None
 
@@ -478,8 +478,51 @@ class Ndt:
         return out, bool(conv.value), int(it.value)
 
 
-def process_batch(engines, jobs):
-    """register independent scans concurrently (C++ worker threads, one per engine; see lio_engines_process_batch).
+class Batch:
+    """throughput mode, batched (lio_batch_*): B scans per launch against one resident static map, filter loop on the device"""
+
+    def __init__(self, shared_map, n_slots=8, n_groups=3, max_raw=262144, max_ds=100000):
+        self.map = shared_map
+        self.n_slots, self.n_groups = n_slots, n_groups
+        self.h = lib().lio_batch_create(shared_map.h, n_slots, n_groups, max_raw, max_ds)
+        if not self.h:
+            raise capi.LioError("lio_batch_create failed: " + lib().lio_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().lio_batch_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def enable_kernel_timing(self, on=True):
+        check(lib().lio_batch_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_times(self, reset=True):
+        t = capi.BatchTimes()
+        check(lib().lio_batch_kernel_times(self.h, C.byref(t), int(reset)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def engine(self, group, slot):
+        """the engine behind a slot (borrowed: its scan buffers / neighbour cache, the pass log of a host continuation)"""
+        h = lib().lio_batch_engine(self.h, group, slot)
+        if not h:
+            raise capi.LioError("no such slot")
+        e = Engine.__new__(Engine)
+        e.h = h
+        e._own = False
+        e.map = self.map
+        e.scan = Scan(max_ds=100000, _borrow=lib().lio_engine_scan(h))
+        return e
+
+    def process(self, jobs):
+        """jobs: list of dicts {dptr, n, t, state (26,), cov (23,23)}; returns (rc, list of result dicts) like process_batch"""
+        return process_batch(None, jobs, batch=self)
+
+
+def process_batch(engines, jobs, batch=None):
+    """register independent scans concurrently (C++ worker threads, one per engine; see lio_engines_process_batch) or, with
+    batch=, through the batched device-resident engine (lio_batch_process).
     jobs: list of dicts {dptr, n, t, state (26,), cov (23,23)}; returns (rc, list of result dicts)"""
     n = len(jobs)
     arr = (capi.ScanJob * n)()
@@ -494,8 +537,11 @@ def process_batch(engines, jobs):
         arr[i].state_in = ptr(st, C.c_double)
         arr[i].cov_in = ptr(cv, C.c_double)
         arr[i].state_out = outs[i].ctypes.data_as(C.POINTER(C.c_double))
-    hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
-    rc = lib().lio_engines_process_batch(hs, len(engines), arr, n)
+    if batch is not None:
+        rc = lib().lio_batch_process(batch.h, arr, n)
+    else:
+        hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        rc = lib().lio_engines_process_batch(hs, len(engines), arr, n)
     res = [dict(rc=arr[i].rc, n_ds=arr[i].n_ds, n_pass=arr[i].n_pass, n_knn_pass=arr[i].n_knn_pass, state=outs[i]) for i in range(n)]
     return rc, res
 

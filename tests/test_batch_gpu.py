@@ -1,0 +1,168 @@
+"""The batched, device-resident engine (lio_batch_*: B scans per launch, four-lanes-per-query kNN, the filter loop of
+esekfom.hpp:1619-1931 on the device) against the oracle and against the per-scan engine it replaces in throughput mode."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import scenes  # noqa: E402
+import test_gpu_parity as tgp  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    from lsd_amd import capi
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device")
+
+
+# ---- the four-lanes-per-query kernel answers lio_map_knn: every kNN test of test_gpu_parity.py again ---------------------------
+def test_knn_q_insert_and_knn_exact(oracle_mod, small_world, monkeypatch):
+    monkeypatch.setenv("LIO_KNN_Q", "1")
+    tgp.test_map_insert_and_knn_exact(oracle_mod, small_world)
+
+
+def test_knn_q_ties_and_duplicates(oracle_mod, monkeypatch):
+    monkeypatch.setenv("LIO_KNN_Q", "1")
+    tgp.test_knn_exact_ties_and_duplicates(oracle_mod)
+
+
+def test_knn_q_adversarial(oracle_mod, monkeypatch):
+    monkeypatch.setenv("LIO_KNN_Q", "1")
+    tgp.test_knn_pruned_sweep_adversarial(oracle_mod)
+
+
+# ---- whole registrations ------------------------------------------------------------------------------------------------------
+def _jobs(scene, seeds, dev_tensors, fov=(-25.0, 15.0), max_range=100.0):
+    import torch
+
+    jobs, meta = [], []
+    from lsd_amd import lio
+
+    P0 = lio.init_cov()
+    for k, seed in enumerate(seeds):
+        sc = scenes.config_scan(scene, seed, fov_deg=fov, max_range=max_range)
+        t = torch.from_numpy(sc["raw"]).cuda()
+        dev_tensors.append(t)
+        jobs.append(dict(dptr=t.data_ptr(), n=len(sc["raw"]), t=1.0 + 0.1 * k, state=sc["guess"], cov=P0))
+        meta.append(sc)
+    torch.cuda.synchronize()
+    return jobs, meta
+
+
+def test_batch_matches_oracle_and_per_scan_engine(oracle_mod):
+    """20 scans (more than fit one round of 2 groups x 4 slots, one of them empty, one with three points) through lio_batch_process:
+    same return codes, downsampled sizes, pass counts as the per-scan engine path; poses equal to the oracle's"""
+    _dev()
+    from lsd_amd import lio, synth
+
+    scene = scenes.config_scene()
+    mp = scene.sample_surface(1_000_000, seed=2, sigma=0.01)
+    the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=1_000_000)
+    the_map.add(mp)
+    keep = []
+    jobs, meta = _jobs(scene, range(3000, 3020), keep)
+    jobs[7]["n"] = 0           # "FastLio undistort points is empty"
+    jobs[11]["n"] = 3          # fewer than five downsampled points
+    P0 = lio.init_cov()
+    # the per-scan engine on the same shared map
+    eng = lio.Engine(max_raw=1 << 18, max_ds=100000, shared_map=the_map)
+    eng.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+    rc1, res1 = lio.process_batch([eng], jobs)
+    assert rc1 == 0
+    b = lio.Batch(the_map, n_slots=4, n_groups=2)
+    rc2, res2 = b.process(jobs)
+    assert rc2 == 0
+    o = oracle_mod.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=8)
+    o.map_add(mp)
+    o.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+    worst = 0.0
+    for k, (a, c) in enumerate(zip(res1, res2)):
+        assert (a["rc"], a["n_ds"]) == (c["rc"], c["n_ds"]), (k, a, c)
+        if a["rc"] != 3:
+            assert k in (7, 11) and a["rc"] == 2
+            continue
+        assert (a["n_pass"], a["n_knn_pass"]) == (c["n_pass"], c["n_knn_pass"]), k
+        # the engine's neighbour cache carries over from scan to scan (one engine, 20 scans) while every slot of the batch has its own
+        # history: compare each with the oracle on a fresh cache instead of with each other where that matters
+        sc = meta[k]
+        o.reset_cache()
+        o.set_state(sc["guess"])
+        o.set_cov(P0)
+        o.set_ds(oracle_mod.voxel_downsample(sc["raw"][: jobs[k]["n"]], 0.5))
+        lo = o.update()
+        so = o.get_state()
+        assert len(lo) == c["n_pass"] and sum(p["knn"] for p in lo) == c["n_knn_pass"], k
+        d = float(np.abs(c["state"] - so).max())
+        worst = max(worst, d)
+        assert d < 1e-9, (k, d)
+        assert np.linalg.norm(c["state"][:3] - sc["pos"]) < 0.1
+    print("batch vs oracle: worst |dstate|", worst)
+    # a second call re-uses the slots (their neighbour caches now hold another scan's neighbours: stale entries must not matter
+    # because every first pass searches again) and must give the same answers
+    rc3, res3 = b.process(jobs)
+    assert rc3 == 0
+    for a, c in zip(res2, res3):
+        assert a["rc"] == c["rc"] and (a["rc"] != 3 or np.abs(a["state"] - c["state"]).max() < 1e-9)
+
+
+@pytest.mark.parametrize("name", ["open_ground", "box_12x4"])
+def test_batch_degenerate_scenes(oracle_mod, name):
+    """the degeneracy sums and the projection inside the device-resident loop (step kernel)"""
+    _dev()
+    import torch
+    from lsd_amd import lio
+
+    case = scenes.degenerate_case(name)
+    the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=500_000)
+    the_map.add(case["map"])
+    t = torch.from_numpy(case["raw"]).cuda()
+    torch.cuda.synchronize()
+    P0 = lio.init_cov()
+    b = lio.Batch(the_map, n_slots=2, n_groups=1)
+    rc, res = b.process([dict(dptr=t.data_ptr(), n=len(case["raw"]), t=1.0, state=case["guess"], cov=P0)] * 3)
+    assert rc == 0
+    o = oracle_mod.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=8)
+    o.map_add(case["map"])
+    o.set_state(case["guess"])
+    o.set_cov(P0)
+    o.set_flags(ekf_inited=True, first_scan=False)
+    o.set_ds(oracle_mod.voxel_downsample(case["raw"], 0.5))
+    lo = o.update()
+    so = o.get_state()
+    assert o.is_degenerate
+    for r in res:
+        assert r["rc"] == 3 and r["n_pass"] == len(lo)
+        assert np.abs(r["state"] - so).max() < 1e-8
+
+
+def test_batch_sparse_scans_hand_over_to_the_host_filter(oracle_mod):
+    """1 <= N_eff < 23: the device loop stops before that pass, the slot's engine continues with the dense gain branch"""
+    _dev()
+    import torch
+    from lsd_amd import lio
+
+    P0 = lio.init_cov()
+    for n_az, n_beams in ((6, 8), (8, 6), (10, 4)):
+        case = scenes.degenerate_case("open_ground", n_az=n_az, n_beams=n_beams)
+        the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=500_000)
+        the_map.add(case["map"])
+        t = torch.from_numpy(case["raw"]).cuda()
+        torch.cuda.synchronize()
+        b = lio.Batch(the_map, n_slots=2, n_groups=1)
+        rc, res = b.process([dict(dptr=t.data_ptr(), n=len(case["raw"]), t=1.0, state=case["guess"], cov=P0)])
+        assert rc == 0 and res[0]["rc"] == 3
+        o = oracle_mod.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=8)
+        o.map_add(case["map"])
+        o.set_state(case["guess"])
+        o.set_cov(P0)
+        o.set_flags(ekf_inited=True, first_scan=False)
+        o.set_ds(oracle_mod.voxel_downsample(case["raw"], 0.5))
+        lo = o.update()
+        assert res[0]["n_pass"] == len(lo) and res[0]["n_knn_pass"] == sum(p["knn"] for p in lo), (n_az, n_beams, res[0], len(lo))
+        assert np.abs(res[0]["state"] - o.get_state()).max() < 1e-8
+        del b
