@@ -20,8 +20,15 @@
 #define EK_FN inline
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-#define EK_FOR(i, n) for (int i = (int)threadIdx.x; i < (n); i += (int)blockDim.x)
-#define EK_SYNC() __syncthreads()
+// on the device the filter pass is run by ONE wave (the first of the step kernel's workgroup): loops stride over its 64 lanes, a phase
+// boundary is a wave-level fence on LDS (a wave's LDS operations complete in order) -- no workgroup barrier inside the pass
+#define EK_FOR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
+#define EK_SYNC()                                                  \
+    do {                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+        __builtin_amdgcn_wave_barrier();                           \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+    } while (0)
 #define EK_LANE(k) ((int)threadIdx.x == (k))
 #else
 #define EK_FOR(i, n) for (int i = 0; i < (n); i++)
@@ -348,17 +355,15 @@ EK_FN bool ek_inverse3(const double A[9], double out[9]) {  // mat_inverse(A, 3,
 // ---- phases -------------------------------------------------------------------------------------------------------
 // manifold Jacobians of esekfom.hpp:1661-1699 from (x, x_prop, dx): three independent pieces, one thread each
 EK_FN void ek_jacobians(const double x[26], const double x_prop[26], const double dx[kEkN], EkWork& w) {
-    if (EK_LANE(0)) {
-        double A[9];
-        ek_A_matrix(dx + 3, A);
-        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) w.Jr[a * 3 + b] = A[b * 3 + a];
+    for (int blk = 0; blk < 2; blk++) {
+        if (EK_LANE(blk)) {  // lanes 0 and 1 run the two SO3 blocks side by side
+            double A[9];
+            ek_A_matrix(dx + 3 + 3 * blk, A);
+            double* J = blk == 0 ? w.Jr : w.Jl;
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) J[a * 3 + b] = A[b * 3 + a];
+        }
     }
-    if (EK_LANE(64)) {
-        double A[9];
-        ek_A_matrix(dx + 6, A);
-        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) w.Jl[a * 3 + b] = A[b * 3 + a];
-    }
-    if (EK_LANE(128)) {
+    if (EK_LANE(2)) {
         double Nx[6], Mx[6];
         ek_s2_Nx_yy(x + 23, Nx);
         ek_s2_Mx(x_prop + 23, dx + 21, Mx);
@@ -466,10 +471,22 @@ EK_FN void ek_measure_head(EskfDev& c, EkWork& w, const double acc29[29], int kn
                 double nnT[9];
                 for (int a = 0; a < 3; a++)
                     for (int b = 0; b < 3; b++) nnT[a * 3 + b] = w.HTH[a * 6 + b];
-                ek_eig3_sym(nnT, w.eigval, w.eigvec);
+                // Every eigenvalue is at least the smallest Gershgorin bound a_ii - sum_j |a_ij|: if that already passes the test below,
+                // all three do and the eigen-decomposition (a serial ~2 us on one lane) is not needed -- same decision, well-conditioned
+                // scenes only
+                double gersh = INFINITY;
+                for (int a = 0; a < 3; a++) {
+                    double g = nnT[a * 3 + a];
+                    for (int b = 0; b < 3; b++)
+                        if (b != a) g -= fabs(nnT[a * 3 + b]);
+                    if (g < gersh) gersh = g;
+                }
                 bool need = false;
-                for (int i = 0; i < 3; i++)
-                    if (!(w.eigval[i] * (1.0 - 1e-5) - 0.030138 * (double)n_eff >= 250.0 + 1e-3)) need = true;
+                if (!(gersh * (1.0 - 1e-5) - 0.030138 * (double)n_eff >= 250.0 + 1e-3)) {
+                    ek_eig3_sym(nnT, w.eigval, w.eigvec);
+                    for (int i = 0; i < 3; i++)
+                        if (!(w.eigval[i] * (1.0 - 1e-5) - 0.030138 * (double)n_eff >= 250.0 + 1e-3)) need = true;
+                }
                 if (need) { w.flag[1] = 1; for (int k = 0; k < 6; k++) w.cs[k] = 0.0; }
             }
         }

@@ -404,38 +404,29 @@ __global__ void __launch_bounds__(256) degeneracy_kernel(const ScanDev* __restri
 // convergence flags (eskf_dev.h).  A slot that finishes publishes its result record in mapped host memory.
 constexpr int kStepThreads = 1024;
 
-__device__ inline void publish_result(const SlotDesc& d, const EskfDev& c) {
-    lio_batch_result* r = d.result;
-    const int tid = threadIdx.x;
-    if (tid < 26) r->state[tid] = c.x[tid];
-    if (tid == 32) {
-        r->status = c.status; r->n_pass = c.n_pass; r->n_knn_pass = c.n_knn; r->n_ds = (int32_t)d.sd->n_ds;
-        r->n_eff = c.n_eff_last; r->degenerate = c.is_degenerate; r->radix_passes = (int32_t)((d.sd->nbits + 7u) >> 3); r->err = (int32_t)d.sd->err;
-        r->loop_i = c.i; r->loop_t = c.t; r->loop_converge = c.converge; r->pad = 0;
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) *reinterpret_cast<volatile uint32_t*>(&r->seq) = d.seq;
-}
-
 __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.x];
     if (!d.active) return;
-    EskfDev& c = *d.ctrl;
-    if (c.status != EK_RUNNING) return;  // finished (and published) in an earlier pass
+    EskfDev& cg = *d.ctrl;
+    if (cg.status != EK_RUNNING) return;  // finished (and published) in an earlier pass
+    // the filter (state, covariances, loop state -- everything before the logs) is copied into LDS, worked on by the first wave
+    // with wave-level fences only, and written back; the other fifteen waves fold the partial sums and, in the rare pass that needs
+    // them, the degeneracy sums
+    __shared__ __attribute__((aligned(16))) EskfDev c;
     __shared__ EkWork w;
     __shared__ double acc[kAcc];
     __shared__ double red6[kStepThreads / 64][6];
     const int tid = threadIdx.x;
-    const uint32_t n = d.sd->n_ds;
-    if ((d.sd->err & 1u) || n < d.min_ds) {  // more voxels than max_ds / too few points (laserMapping.cpp:1246): nothing is registered
-        if (tid == 0) c.status = EK_SKIPPED;
-        __syncthreads();
-        publish_result(d, c);
-        return;
-    }
-    const uint32_t nb = (n + kLinThreads - 1) / kLinThreads;
+    constexpr int kCoreWords = (int)(offsetof(EskfDev, log) / 8);
     {
+        const double* src = reinterpret_cast<const double*>(&cg);
+        double* dst = reinterpret_cast<double*>(&c);
+        for (int k = tid; k < kCoreWords; k += kStepThreads) dst[k] = src[k];
+    }
+    const uint32_t n = d.sd->n_ds;
+    const bool skip = (d.sd->err & 1u) || n < d.min_ds;  // more voxels than max_ds / too few points (laserMapping.cpp:1246): nothing is registered
+    const uint32_t nb = (n + kLinThreads - 1) / kLinThreads;
+    if (!skip) {
         const int comp = tid >> 5, l = tid & 31;
         double s = 0.0;
         if (comp < kAcc)
@@ -445,10 +436,15 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         if (comp < kAcc && l == 0) acc[comp] = s;
     }
     __syncthreads();
-    const int knn = c.converge;
-    ek_measure_head(c, w, acc, knn);
-    if (w.flag[1]) {  // the six degeneracy sums (laserMapping.cpp:946-964): every addend is a float in (0.1736, 1] widened to double,
-                      // sums of < 2^17 of them are exact in f64 -> any reduction order gives the same bits
+    const int log0 = c.n_log;
+    if (skip) {
+        if (tid == 0) c.status = EK_SKIPPED;
+    } else if (tid < 64) {
+        ek_measure_head(c, w, acc, c.converge);
+    }
+    __syncthreads();
+    if (!skip && w.flag[1]) {  // the six degeneracy sums (laserMapping.cpp:946-964): every addend is a float in (0.1736, 1] widened to double,
+                               // sums of < 2^17 of them are exact in f64 -> any reduction order gives the same bits
         double s6[6] = {0, 0, 0, 0, 0, 0};
         for (uint32_t i = tid; i < n; i += kStepThreads) {
             if (!d.selected[i]) continue;
@@ -476,10 +472,38 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         }
         __syncthreads();
     }
-    ek_measure_tail(c, w);
-    if (c.status == EK_RUNNING && w.flag[0]) ek_step(c, w);
-    __syncthreads();
-    if (c.status != EK_RUNNING) publish_result(d, c);
+    if (tid >= 64) return;
+    // ---- first wave only from here on ----
+    if (!skip) {
+        ek_measure_tail(c, w);
+        if (c.status == EK_RUNNING && w.flag[0]) ek_step(c, w);
+    }
+    EK_SYNC();
+    {   // write back: the filter, the log entries of this pass
+        const double* src = reinterpret_cast<const double*>(&c);
+        double* dst = reinterpret_cast<double*>(&cg);
+        for (int k = tid; k < kCoreWords; k += 64) dst[k] = src[k];
+        constexpr int kLogWords = (int)(sizeof(EkPassLog) / 8);
+        const int log1 = c.n_log < kEkMaxPass ? c.n_log : kEkMaxPass;
+        // (an aborted pass -- N_eff < 23 hand-over -- leaves its half-written entry behind: the host does not read past n_log)
+        for (int e = log0; e < log1 + (c.status == EK_NEEDS_HOST ? 1 : 0) && e < kEkMaxPass; e++) {
+            const double* ls = reinterpret_cast<const double*>(&c.log[e]);
+            double* ld = reinterpret_cast<double*>(&cg.log[e]);
+            for (int k = tid; k < kLogWords; k += 64) ld[k] = ls[k];
+        }
+    }
+    if (c.status != EK_RUNNING) {
+        lio_batch_result* r = d.result;
+        if (tid < 26) r->state[tid] = c.x[tid];
+        if (tid == 32) {
+            r->status = c.status; r->n_pass = c.n_pass; r->n_knn_pass = c.n_knn; r->n_ds = (int32_t)n;
+            r->n_eff = c.n_eff_last; r->degenerate = c.is_degenerate; r->radix_passes = (int32_t)((d.sd->nbits + 7u) >> 3); r->err = (int32_t)d.sd->err;
+            r->loop_i = c.i; r->loop_t = c.t; r->loop_converge = c.converge; r->pad = 0;
+        }
+        __threadfence_system();
+        EK_SYNC();
+        if (tid == 0) *reinterpret_cast<volatile uint32_t*>(&r->seq) = d.seq;
+    }
 }
 
 // the whole iterated update of every slot, enqueued blind: (neighbour search if the filter asks for it, linearisation, filter pass) x

@@ -48,3 +48,24 @@ def config_scan(scene, seed, fov_deg=(-25.0, 15.0), max_range=100.0):
     raw, _ = synth.make_scan(scene, pos, q, seed=seed, n_az=1875, fov_deg=fov_deg, max_range=max_range)
     gp, gq = synth.perturb_pose(pos, q, seed=seed + 5000, max_t=0.3, max_deg=2.0)
     return dict(raw=raw, pos=pos, q=q, guess=synth.state_from_pose(gp, gq))
+
+
+# ---- device buffers from the HIP runtime the library itself is linked against (torch ships its own copy of the runtime; two in one
+# process do not see each other's devices) --------------------------------------------------------------------------------------------
+_hip_rt = None
+
+
+def to_device(a):
+    """copy a numpy array to the GPU; returns the device address (int).  The allocation lives until the process ends (tests only)."""
+    import ctypes as C
+
+    global _hip_rt
+    if _hip_rt is None:
+        _hip_rt = C.CDLL("libamdhip64.so")
+        _hip_rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        _hip_rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    a = np.ascontiguousarray(a)
+    d = C.c_void_p()
+    assert _hip_rt.hipMalloc(C.byref(d), max(a.nbytes, 16)) == 0
+    assert _hip_rt.hipMemcpy(d, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+    return d.value

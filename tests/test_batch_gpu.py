@@ -38,19 +38,14 @@ def test_knn_q_adversarial(oracle_mod, monkeypatch):
 
 # ---- whole registrations ------------------------------------------------------------------------------------------------------
 def _jobs(scene, seeds, dev_tensors, fov=(-25.0, 15.0), max_range=100.0):
-    import torch
-
     jobs, meta = [], []
     from lsd_amd import lio
 
     P0 = lio.init_cov()
     for k, seed in enumerate(seeds):
         sc = scenes.config_scan(scene, seed, fov_deg=fov, max_range=max_range)
-        t = torch.from_numpy(sc["raw"]).cuda()
-        dev_tensors.append(t)
-        jobs.append(dict(dptr=t.data_ptr(), n=len(sc["raw"]), t=1.0 + 0.1 * k, state=sc["guess"], cov=P0))
+        jobs.append(dict(dptr=scenes.to_device(sc["raw"]), n=len(sc["raw"]), t=1.0 + 0.1 * k, state=sc["guess"], cov=P0))
         meta.append(sc)
-    torch.cuda.synchronize()
     return jobs, meta
 
 
@@ -114,17 +109,15 @@ def test_batch_matches_oracle_and_per_scan_engine(oracle_mod):
 def test_batch_degenerate_scenes(oracle_mod, name):
     """the degeneracy sums and the projection inside the device-resident loop (step kernel)"""
     _dev()
-    import torch
     from lsd_amd import lio
 
     case = scenes.degenerate_case(name)
     the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=500_000)
     the_map.add(case["map"])
-    t = torch.from_numpy(case["raw"]).cuda()
-    torch.cuda.synchronize()
+    dptr = scenes.to_device(case["raw"])
     P0 = lio.init_cov()
     b = lio.Batch(the_map, n_slots=2, n_groups=1)
-    rc, res = b.process([dict(dptr=t.data_ptr(), n=len(case["raw"]), t=1.0, state=case["guess"], cov=P0)] * 3)
+    rc, res = b.process([dict(dptr=dptr, n=len(case["raw"]), t=1.0, state=case["guess"], cov=P0)] * 3)
     assert rc == 0
     o = oracle_mod.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=8)
     o.map_add(case["map"])
@@ -143,7 +136,6 @@ def test_batch_degenerate_scenes(oracle_mod, name):
 def test_batch_sparse_scans_hand_over_to_the_host_filter(oracle_mod):
     """1 <= N_eff < 23: the device loop stops before that pass, the slot's engine continues with the dense gain branch"""
     _dev()
-    import torch
     from lsd_amd import lio
 
     P0 = lio.init_cov()
@@ -151,10 +143,9 @@ def test_batch_sparse_scans_hand_over_to_the_host_filter(oracle_mod):
         case = scenes.degenerate_case("open_ground", n_az=n_az, n_beams=n_beams)
         the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=500_000)
         the_map.add(case["map"])
-        t = torch.from_numpy(case["raw"]).cuda()
-        torch.cuda.synchronize()
+        dptr = scenes.to_device(case["raw"])
         b = lio.Batch(the_map, n_slots=2, n_groups=1)
-        rc, res = b.process([dict(dptr=t.data_ptr(), n=len(case["raw"]), t=1.0, state=case["guess"], cov=P0)])
+        rc, res = b.process([dict(dptr=dptr, n=len(case["raw"]), t=1.0, state=case["guess"], cov=P0)])
         assert rc == 0 and res[0]["rc"] == 3
         o = oracle_mod.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=8)
         o.map_add(case["map"])
