@@ -6,6 +6,7 @@
 // Here a round of B scans is ONE blind submission: every kernel of the chain is launched once with blockIdx.y = slot, the filter
 // lives on the device (eskf_dev.h), and the only host work per scan is filling 9 KB of staging and reading a 300-byte result record.
 #include <sched.h>
+#include <stdlib.h>
 
 #include <chrono>
 #include <deque>
@@ -46,6 +47,7 @@ struct lio_batch {
     int n_slots = 0;
     uint32_t max_raw = 0, max_ds = 0;
     int pred_passes = 4;  // radix passes the last rounds needed
+    int knn_kind = 0;     // LIO_BATCH_KNN=q: the one-lane-per-query kernel (knn_q.hip) instead of knn.hip's sixteen lanes per query
     std::vector<Group> groups;
 };
 
@@ -116,7 +118,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
     if (g.bt) g.bt->end(0);
     if (rc != LIO_OK) return rc;
     const uint32_t ds_bound = g.max_n_raw < b->max_ds ? g.max_n_raw : b->max_ds;
-    return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, g.bt);
+    return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, g.bt, b->knn_kind);
 }
 
 int wait_group(Group& g, int B) {
@@ -151,6 +153,7 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
     b->max_raw = max_raw;
     b->max_ds = max_ds;
     b->groups.resize(n_groups);
+    { const char* k = getenv("LIO_BATCH_KNN"); b->knn_kind = (k && k[0] == 'q') ? 1 : 0; }
     bool ok = true;
     for (Group& g : b->groups) {
         g.job_of_slot.assign(n_slots, -1);
@@ -177,7 +180,7 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
             d.partial_blocks = sc->partial_blocks;
             d.sd = sc->dev;
             d.keys_a = sc->keys_a; d.keys_b = sc->keys_b; d.vals_a = sc->vals_a; d.vals_b = sc->vals_b;
-            d.hist = sc->hist; d.blockcnt = sc->blockcnt; d.hpos = sc->hpos; d.longlist = sc->longlist;
+            d.hist = sc->hist; d.blockcnt = sc->blockcnt; d.hpos = sc->hpos; d.longlist = sc->longlist; d.tie_list = sc->tie_list;
             d.sorted = sc->sorted; d.ds_body = sc->ds_body; d.ds_world = sc->ds_world; d.nn_pts = sc->nn_pts; d.normvec = sc->normvec;
             d.nn_cnt = sc->nn_cnt; d.selected = sc->selected; d.partial = sc->partial;
             d.host_nds = sc->host_nds_dev;

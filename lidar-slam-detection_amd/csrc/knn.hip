@@ -245,11 +245,11 @@ __device__ inline uint32_t fifth_bound(uint32_t d0, uint32_t d4) {
 // MODE 0: queries are body-frame ds points of a scan (transformed here, world point stored);
 // MODE 1: queries are world-frame points (diagnostic lio_map_knn).
 template <int KM, int MODE>
-__global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
-                                                  float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
-                                                  uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
-                                                  float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
-                                                  MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
+__device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                         float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
+                                         uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
+                                         float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
+                                         MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
     __shared__ GroupLds lds[kGPB];
     const int tid = threadIdx.x;
     const int grp = tid / kG, gl = tid % kG;
@@ -409,6 +409,27 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
     }
 }
 
+template <int KM, int MODE>
+__global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                  float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
+                                                  uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
+                                                  float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
+                                                  MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
+    knn_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, md, n_tie, tie_list);
+}
+// the scans of a batch (lio_batch_*): blockIdx.y = slot; pose from the slot's device-resident filter; a slot whose update has finished,
+// or whose filter did not ask for a neighbour search this pass, exits at once
+template <int KM>
+__global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                                       float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;
+    const EskfDev* c = d.ctrl;
+    if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
+    const PoseArgs pose = pose_from_state(c->x);
+    knn_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
+}
+
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
 struct Cand {
     float d2;
@@ -431,10 +452,10 @@ __device__ inline bool cand_less(const Cand& a, const Cand& b, const float4* __r
 }
 
 template <int KM, int MODE>
-__global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
-                                                        float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
-                                                        float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
-                                                        const uint32_t* __restrict__ tie_list) {
+__device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                               float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
+                                               float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
+                                               const uint32_t* __restrict__ tie_list) {
     __shared__ GroupLds lds[kGPB];
     const int tid = threadIdx.x;
     const int grp = tid / kG, gl = tid % kG;
@@ -495,6 +516,46 @@ __global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__
         if (active && gl < 5 && win != kNoIdx) nn_pts[(size_t)gl * nn_stride + q] = pool[win];
         __syncthreads();
     }
+}
+
+template <int KM, int MODE>
+__global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                        float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
+                                                        float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
+                                                        const uint32_t* __restrict__ tie_list) {
+    knn_exact_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, nn_pts, nn_stride, n_tie, tie_list);
+}
+// batch form: the queries the search of this pass queued (usually none: the kernel then ends at once); the queue is re-armed by the
+// filter-pass kernel that follows the linearisation
+template <int KM>
+__global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                              float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || d.sd->n_tie == 0) return;
+    const EskfDev* c = d.ctrl;
+    if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
+    const PoseArgs pose = pose_from_state(c->x);
+    knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list);
+}
+
+int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x) {
+    if (grid_x > 2048) grid_x = 2048;  // grid-stride loop inside: 16 queries per workgroup and round
+    if (grid_x == 0) grid_x = 8;
+    const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
+    const dim3 gridx(64, (uint32_t)n_slots);
+    const int km = (m->stencil.n + kG - 1) / kG;
+#define KNNB_LAUNCH(KM)                                                                                                                         \
+    do {                                                                                                                                        \
+        hipLaunchKernelGGL((knn_batch_kernel<KM>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
+        hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots);  \
+    } while (0)
+    if (km <= 1) KNNB_LAUNCH(1);
+    else if (km <= 2) KNNB_LAUNCH(2);
+    else if (km <= 3) KNNB_LAUNCH(3);
+    else KNNB_LAUNCH((kMaxStencil + kG - 1) / kG);
+#undef KNNB_LAUNCH
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
 }
 
 template <int MODE>

@@ -98,7 +98,7 @@ struct SlotDesc {
     uint32_t max_ds, partial_blocks;
     uint32_t min_ds, pad;    // scans that downsample to fewer points are not registered (5 in fastlio_main, 0 for a bare filter update)
     ScanDev* sd;
-    uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *hist, *blockcnt, *hpos, *longlist;
+    uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *hist, *blockcnt, *hpos, *longlist, *tie_list;
     float4 *sorted, *ds_body, *ds_world, *nn_pts, *normvec;
     int32_t* nn_cnt;
     uint8_t* selected;
@@ -230,6 +230,7 @@ int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_s
 int vg_downsample(lio_scan* s, float leaf, int passes /* radix passes to launch, 1..4 */);
 int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes);
 int knn_q_batch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x);
+int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x);
 int knn_q_world(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt);
 // live kernel timing of the batched chain (bench.py's roofline leg): HIP events on the stream the kernels are launched on, per class
 struct BatchTimer {
@@ -253,7 +254,7 @@ struct BatchTimer {
         }
     }
 };
-int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt);
+int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int knn_kind);
 int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);
 void kt_begin(lio_scan* s, int which);

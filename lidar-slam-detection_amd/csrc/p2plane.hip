@@ -436,6 +436,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         if (comp < kAcc && l == 0) acc[comp] = s;
     }
     __syncthreads();
+    if (tid == 0) d.sd->n_tie = 0;  // the tie queue of this pass's neighbour search has been served (knn_exact_batch_kernel)
     const int log0 = c.n_log;
     if (skip) {
         if (tid == 0) c.status = EK_SKIPPED;
@@ -508,7 +509,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
 
 // the whole iterated update of every slot, enqueued blind: (neighbour search if the filter asks for it, linearisation, filter pass) x
 // (maximum_iter + 1); slots that converge early skip the rest of the launches
-int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt) {
+int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int knn_kind) {
     uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
     if (lin_blocks == 0) lin_blocks = 1;
     uint32_t knn_blocks = (ds_bound + 63) / 64;  // 64 queries per workgroup of knn_q
@@ -516,7 +517,8 @@ int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, in
     if (knn_blocks == 0) knn_blocks = 8;
     for (int p = 0; p < n_passes; p++) {
         if (bt) bt->begin(1);
-        const int rc = knn_q_batch(m, st, d_slots, n_slots, knn_blocks);
+        // knn_kind 0: sixteen lanes per query (knn.hip, + the exact redo of queued ties), 1: one lane per query (knn_q.hip)
+        const int rc = knn_kind == 1 ? knn_q_batch(m, st, d_slots, n_slots, knn_blocks) : knn_batch_launch(m, st, d_slots, n_slots, (ds_bound + 15) / 16);
         if (bt) bt->end(1);
         if (rc != LIO_OK) return rc;
         if (bt) bt->begin(2);

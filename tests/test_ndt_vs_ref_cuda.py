@@ -111,13 +111,14 @@ def test_alignment_against_the_references_registration_object(method):
         # the reference against itself: five more runs from the same guess (f32 atomics in its voxel map and Thrust reductions of
         # unspecified order make every run different); its spread is the resolution at which "the reference's pose" is defined
         reruns = []
-        for _ in range(5):
+        for _ in range(8):
             r.set_target(mp)  # the voxel map is where its atomics are: rebuild it, then align again
             reruns.append(r.align(G)[0])
         Tg, conv_g, it_g = g.align(s, G)
         dt, dr = float(np.linalg.norm(Tg[:3, 3] - Tr[:3, 3])), _rot_angle(Tg, Tr)
-        st = max(float(np.linalg.norm(T2[:3, 3] - Tr[:3, 3])) for T2 in reruns)
-        sr = max(_rot_angle(T2, Tr) for T2 in reruns)
+        runs = [Tr] + reruns  # the diameter of the reference's own answers
+        st = max(float(np.linalg.norm(A[:3, 3] - B[:3, 3])) for A in runs for B in runs)
+        sr = max(_rot_angle(A, B) for A in runs for B in runs)
         # distance from the HIP pose to the NEAREST of the reference's six answers
         dt_min = min([dt] + [float(np.linalg.norm(Tg[:3, 3] - T2[:3, 3])) for T2 in reruns])
         dr_min = min([dr] + [_rot_angle(Tg, T2) for T2 in reruns])
