@@ -352,6 +352,7 @@ lio_engine* lio_engine_create(int device, float resolution, int stencil, uint64_
     lio_engine* e = new lio_engine();
     e->map = m;
     e->scan = s;
+    s->resize_min = 5;
     memset(&e->tm, 0, sizeof(e->tm));
     return e;
 }
@@ -363,6 +364,7 @@ lio_engine* lio_engine_create_shared(lio_map* shared_map, uint32_t max_raw, uint
     lio_engine* e = new lio_engine();
     e->map = shared_map;
     e->scan = s;
+    s->resize_min = 5;
     e->own_map = false;
     e->static_map = true;  // several engines read one map concurrently: nobody inserts
     e->map_seeded = true;

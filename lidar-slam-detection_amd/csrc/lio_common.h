@@ -73,6 +73,7 @@ struct ScanDev {
     uint32_t seq;          // sequence number of the last report
     uint32_t n_ds;         // feats_down_size
     uint32_t n_ds_prev;    // size of the neighbour cache before this scan (Nearest_Points.resize semantics)
+    uint32_t cache_n;      // Nearest_Points.size(): moves only when a scan is registered (>= 5 downsampled points in fastlio_main)
     uint32_t passthrough;  // PCL int32 overflow guard hit: output = input
     uint32_t nbits;        // significant key bits for the radix sort
     uint32_t err;          // bit0: n_ds > max_ds
@@ -194,6 +195,7 @@ struct lio_scan {
     lio_normal_eq* h_result_dev;  // device-side alias of h_result (linearize_kernel's last workgroup writes the record there)
     uint32_t seq_expected;        // sequence number the next report will carry
     int have_ds;
+    uint32_t resize_min;  // scans that downsample to fewer points leave the neighbour cache alone (5 on an engine's scan: laserMapping.cpp:1250-1274)
     uint64_t bytes;
 };
 

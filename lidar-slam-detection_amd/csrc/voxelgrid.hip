@@ -119,7 +119,7 @@ __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint
                                                            uint32_t nblocks) {
     const VgGrid g = vg_derive(sd, inv);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sd->n_ds_prev = sd->n_ds;  // still the previous scan's size: the heads kernel runs later
+        sd->n_ds_prev = sd->cache_n;  // the neighbour cache's size before this scan
         sd->passthrough = g.pass;
         sd->total_cells = g.total;
         sd->nbits = g.total ? (32 - __clz(g.total)) : 0;  // keys 0..total (total = invalid marker) need bits(total)
@@ -451,15 +451,20 @@ __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__
 }
 
 __global__ void scan_set_nds_kernel(ScanDev* sd, uint32_t n) {
-    sd->n_ds_prev = sd->n_ds;
+    sd->n_ds_prev = sd->cache_n;
     sd->n_ds = n;
 }
 
 // Nearest_Points.resize(feats_down_size) (laserMapping.cpp:1274): entries beyond the new size are destroyed
 // ... and re-arm the bbox / counters for the next scan's downsample (saves two memset launches per scan)
-__device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict__ nn_cnt) {
+// -- but only for a scan that is registered: fastlio_main returns on feats_down_size < 5 (laserMapping.cpp:1250-1254) BEFORE that resize,
+// the cache of the previous scan then survives whole (min_ds = 5 on the engines' scans, 0 for a bare lio_scan)
+__device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict__ nn_cnt, uint32_t min_ds) {
     const uint32_t lo = sd->n_ds, hi = sd->n_ds_prev;
-    for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) nn_cnt[i] = 0;
+    if (lo >= min_ds) {
+        for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) nn_cnt[i] = 0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) sd->cache_n = lo;
+    }
     if (blockIdx.x == 0 && threadIdx.x < 3) {
         sd->bbox_min[threadIdx.x] = 0xFFFFFFFFu;
         sd->bbox_max[threadIdx.x] = 0u;
@@ -549,11 +554,11 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_long_batch(const SlotDes
     if (!d.active) return;
     vg_centroid_long_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist);
 }
-__global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt) { scan_begin_body(sd, nn_cnt); }
+__global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt, uint32_t min_ds) { scan_begin_body(sd, nn_cnt, min_ds); }
 __global__ void scan_begin_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    scan_begin_body(d.sd, d.nn_cnt);
+    scan_begin_body(d.sd, d.nn_cnt, d.min_ds);
 }
 
 int vg_downsample(lio_scan* s, float leaf, int passes) {
@@ -611,7 +616,7 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
 }
 
 int scan_begin(lio_scan* s) {
-    hipLaunchKernelGGL(scan_begin_kernel, 64, 256, 0, s->stream, s->dev, s->nn_cnt);
+    hipLaunchKernelGGL(scan_begin_kernel, 64, 256, 0, s->stream, s->dev, s->nn_cnt, s->resize_min);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }
