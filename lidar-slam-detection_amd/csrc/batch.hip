@@ -25,10 +25,14 @@ namespace {
 struct Group {
     hipStream_t stream = nullptr;
     std::vector<lio_engine*> eng;
+    char* d_block = nullptr;             // [SlotDesc x B][EskfDev x B]: one upload per round
+    char* h_block = nullptr;             // pinned staging, same layout
+    size_t block_bytes = 0;
     SlotDesc* d_desc = nullptr;
-    SlotDesc* h_desc = nullptr;          // pinned
+    SlotDesc* h_desc = nullptr;
     EskfDev* d_ctrl = nullptr;
-    EskfDev* h_ctrl = nullptr;           // pinned staging
+    EskfDev* h_ctrl = nullptr;
+    hipGraphExec_t exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the whole round as a graph, per number of radix passes
     lio_batch_result* h_res = nullptr;   // pinned, mapped
     lio_batch_result* h_res_dev = nullptr;
     std::vector<int> job_of_slot;
@@ -47,20 +51,20 @@ struct lio_batch {
     int n_slots = 0;
     uint32_t max_raw = 0, max_ds = 0;
     int pred_passes = 4;  // radix passes the last rounds needed
+    int use_graph = 1;    // LIO_BATCH_GRAPH=0: plain launches instead of one hipGraphLaunch per round
     int knn_kind = 0;     // LIO_BATCH_KNN=q: the one-lane-per-query kernel (knn_q.hip) instead of knn.hip's sixteen lanes per query
     std::vector<Group> groups;
 };
 
 namespace {
 
-constexpr size_t kCtrlUpload = offsetof(EskfDev, log);  // the logs are written by the device only
 
 void group_free(Group& g) {
     for (lio_engine* e : g.eng) lio_engine_destroy(e);
-    if (g.d_desc) hipFree(g.d_desc);
-    if (g.h_desc) hipHostFree(g.h_desc);
-    if (g.d_ctrl) hipFree(g.d_ctrl);
-    if (g.h_ctrl) hipHostFree(g.h_ctrl);
+    for (int k = 0; k < 5; k++)
+        if (g.exec[k]) hipGraphExecDestroy(g.exec[k]);
+    if (g.d_block) hipFree(g.d_block);
+    if (g.h_block) hipHostFree(g.h_block);
     if (g.h_res) hipHostFree(g.h_res);
     if (g.stream) hipStreamDestroy(g.stream);
     if (g.bt) {
@@ -110,15 +114,33 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         if (job.n_raw > g.max_n_raw) g.max_n_raw = job.n_raw;
     }
     if (g.n_active == 0) return LIO_OK;
-    LIO_HIP_TRY(hipMemcpyAsync(g.d_desc, g.h_desc, sizeof(SlotDesc) * (size_t)B, hipMemcpyHostToDevice, g.stream));
-    for (int s = 0; s < B; s++)
-        if (g.h_desc[s].active) LIO_HIP_TRY(hipMemcpyAsync(&g.d_ctrl[s], &g.h_ctrl[s], kCtrlUpload, hipMemcpyHostToDevice, g.stream));
-    if (g.bt) g.bt->begin(0);
-    int rc = vg_downsample_batch(g.stream, g.d_desc, B, g.max_n_raw, b->max_ds, 0.5f, passes);
-    if (g.bt) g.bt->end(0);
-    if (rc != LIO_OK) return rc;
-    const uint32_t ds_bound = g.max_n_raw < b->max_ds ? g.max_n_raw : b->max_ds;
-    return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, g.bt, b->knn_kind);
+    // The round is ONE submission: upload of the staging block, voxel-grid chain, (maximum_iter + 1) x {kNN, linearise, filter pass}.
+    // Every argument is fixed per group (pointers into the group's blocks; what changes from round to round travels in the block), so
+    // the sequence is captured once into a graph and replayed with a single hipGraphLaunch -- ~35 API calls of 5-15 us each otherwise,
+    // which made the one submitting host thread the bottleneck.  Grids are sized for the batch's max_raw (surplus workgroups exit at once).
+    const bool timed = g.bt && g.bt->on;
+    auto enqueue = [&](BatchTimer* bt) -> int {
+        LIO_HIP_TRY(hipMemcpyAsync(g.d_block, g.h_block, g.block_bytes, hipMemcpyHostToDevice, g.stream));
+        if (bt) bt->begin(0);
+        int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes);
+        if (bt) bt->end(0);
+        if (rc != LIO_OK) return rc;
+        const uint32_t ds_bound = b->max_raw < b->max_ds ? b->max_raw : b->max_ds;
+        return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, bt, b->knn_kind);
+    };
+    if (!b->use_graph || timed) return enqueue(timed ? g.bt : nullptr);
+    if (!g.exec[passes]) {
+        hipGraph_t graph = nullptr;
+        LIO_HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue(nullptr);
+        const hipError_t e2 = hipStreamEndCapture(g.stream, &graph);
+        if (rc != LIO_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        LIO_HIP_TRY(e2);
+        LIO_HIP_TRY(hipGraphInstantiate(&g.exec[passes], graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+    }
+    LIO_HIP_TRY(hipGraphLaunch(g.exec[passes], g.stream));
+    return LIO_OK;
 }
 
 int wait_group(Group& g, int B) {
@@ -154,21 +176,26 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
     b->max_ds = max_ds;
     b->groups.resize(n_groups);
     { const char* k = getenv("LIO_BATCH_KNN"); b->knn_kind = (k && k[0] == 'q') ? 1 : 0; }
+    { const char* k = getenv("LIO_BATCH_GRAPH"); b->use_graph = (k && k[0] == '0') ? 0 : 1; }
     bool ok = true;
     for (Group& g : b->groups) {
         g.job_of_slot.assign(n_slots, -1);
         ok = ok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_desc), sizeof(SlotDesc) * n_slots) == hipSuccess;
-        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_desc), sizeof(SlotDesc) * n_slots, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_ctrl), sizeof(EskfDev) * n_slots) == hipSuccess;
-        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_ctrl), sizeof(EskfDev) * n_slots, hipHostMallocDefault) == hipSuccess;
+        g.block_bytes = (sizeof(SlotDesc) + sizeof(EskfDev)) * (size_t)n_slots;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_block), g.block_bytes) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_block), g.block_bytes, hipHostMallocDefault) == hipSuccess;
+        if (ok) {
+            g.d_desc = reinterpret_cast<SlotDesc*>(g.d_block);
+            g.h_desc = reinterpret_cast<SlotDesc*>(g.h_block);
+            g.d_ctrl = reinterpret_cast<EskfDev*>(g.d_block + sizeof(SlotDesc) * n_slots);
+            g.h_ctrl = reinterpret_cast<EskfDev*>(g.h_block + sizeof(SlotDesc) * n_slots);
+        }
         ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_res), sizeof(lio_batch_result) * n_slots, hipHostMallocMapped) == hipSuccess;
         ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&g.h_res_dev), g.h_res, 0) == hipSuccess;
         if (!ok) break;
-        memset(g.h_desc, 0, sizeof(SlotDesc) * n_slots);
-        memset(g.h_ctrl, 0, sizeof(EskfDev) * n_slots);
+        memset(g.h_block, 0, g.block_bytes);
         memset(g.h_res, 0, sizeof(lio_batch_result) * n_slots);
-        ok = hipMemset(g.d_ctrl, 0, sizeof(EskfDev) * n_slots) == hipSuccess;
+        ok = hipMemset(g.d_block, 0, g.block_bytes) == hipSuccess;
         for (int s = 0; s < n_slots && ok; s++) {
             lio_engine* e = lio_engine_create_shared(map, max_raw, max_ds);
             if (!e) { ok = false; break; }

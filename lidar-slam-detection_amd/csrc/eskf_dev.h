@@ -41,7 +41,7 @@ namespace lio {
 constexpr int kEkN = 23;
 constexpr double kEkTol = 1e-11;           // MTK::tolerance<double>()
 constexpr double kEkS2Len = 98090.0 / 10000.0;
-constexpr int kEkMaxPass = 8;              // maximum_iter + 1 passes are logged (5 with the reference's constants)
+constexpr int kEkMaxPass = 6;              // maximum_iter + 1 passes are logged (5 with the reference's constants)
 
 struct EkPassLog {   // = lio_pass_log
     int32_t knn, n_eff, valid, degenerate;

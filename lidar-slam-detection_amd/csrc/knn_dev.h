@@ -39,13 +39,23 @@ __device__ inline uint32_t cell_min_d2_bits(float qx, float qy, float qz, int cx
 }
 
 
+// a double that is the same in every lane, moved to scalar registers (the compiler cannot prove a value loaded through a pointer
+// uniform and would otherwise keep the 14 doubles of a pose in 28 vector registers per lane for the whole kernel: occupancy 4 instead
+// of 6 for the kNN kernel)
+__device__ inline double uniform_double(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // the rigid transforms of a 26-number filter state (lio_hip.h layout) as the kernels take them
 __device__ inline PoseArgs pose_from_state(const double* __restrict__ x) {
     PoseArgs p;
 #pragma unroll
-    for (int i = 0; i < 3; i++) { p.tw[i] = x[i]; p.tl[i] = x[11 + i]; }
+    for (int i = 0; i < 3; i++) { p.tw[i] = uniform_double(x[i]); p.tl[i] = uniform_double(x[11 + i]); }
 #pragma unroll
-    for (int i = 0; i < 4; i++) { p.qw[i] = x[3 + i]; p.ql[i] = x[7 + i]; }
+    for (int i = 0; i < 4; i++) { p.qw[i] = uniform_double(x[3 + i]); p.ql[i] = uniform_double(x[7 + i]); }
     return p;
 }
 
