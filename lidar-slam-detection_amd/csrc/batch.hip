@@ -175,12 +175,14 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
     b->max_raw = max_raw;
     b->max_ds = max_ds;
     b->groups.resize(n_groups);
-    { const char* k = getenv("LIO_BATCH_KNN"); b->knn_kind = (k && k[0] == 'q') ? 1 : 0; }
+    { const char* k = getenv("LIO_BATCH_KNN"); b->knn_kind = (k && k[0] == 'q') ? 1 : ((k && k[0] == 'i') ? 2 : 0); }
     { const char* k = getenv("LIO_BATCH_GRAPH"); b->use_graph = (k && k[0] == '0') ? 0 : 1; }
     bool ok = true;
+    // the groups' streams first: HIP deals streams to its few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) round robin in creation
+    // order -- created after the ~B scan streams of the slots, two groups can land on one queue and their rounds run back to back
+    for (Group& g : b->groups) ok = ok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess;
     for (Group& g : b->groups) {
         g.job_of_slot.assign(n_slots, -1);
-        ok = ok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess;
         g.block_bytes = (sizeof(SlotDesc) + sizeof(EskfDev)) * (size_t)n_slots;
         ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_block), g.block_bytes) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_block), g.block_bytes, hipHostMallocDefault) == hipSuccess;

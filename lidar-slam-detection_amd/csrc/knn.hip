@@ -242,9 +242,70 @@ __device__ inline uint32_t fifth_bound(uint32_t d0, uint32_t d4) {
     return min(t, m);
 }
 
+struct Cand {
+    float d2;
+    uint32_t id;
+};
+
+// strict total order (d2, x, y, z); the coordinate comparison only runs on exact d2 ties
+__device__ __noinline__ bool cand_tie_less(const Cand& a, const Cand& b, const float4* __restrict__ pool) {
+    if (a.id == b.id) return false;
+    if (a.id == kNoIdx || b.id == kNoIdx) return a.id < b.id;
+    const float4 pa = pool[a.id], pb = pool[b.id];
+    if (pa.x != pb.x) return pa.x < pb.x;
+    if (pa.y != pb.y) return pa.y < pb.y;
+    if (pa.z != pb.z) return pa.z < pb.z;
+    return a.id < b.id;
+}
+__device__ inline bool cand_less(const Cand& a, const Cand& b, const float4* __restrict__ pool) {
+    if (a.d2 != b.d2) return a.d2 < b.d2;
+    return cand_tie_less(a, b, pool);
+}
+
+
+// exact redo of ONE query by the kG lanes of its group, from the voxel list the probe left in LDS: every listed voxel, strict total order
+// (d2, x, y, z); winner r comes back in lane r (kNoIdx where fewer than five exist).  Rare (an exact d2 tie among a query's six best).
+__device__ __noinline__ uint32_t group_exact_redo(const GroupLds& g, uint32_t nhit, const float4 pw, const float4* __restrict__ pool, int gl) {
+    Cand e[5];
+    for (int k = 0; k < 5; k++) e[k] = {INFINITY, kNoIdx};
+    for (uint32_t sv = 0; sv < nhit; sv++) {
+        const uint32_t vptr = g.v_ptr[sv], vcnt = g.v_cnt[sv];
+        for (uint32_t i = gl; i < vcnt; i += kG) {
+            const uint32_t id = vptr + i;
+            const float4 p = pool[id];
+            const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
+            const float d2 = dx * dx + (dy * dy + dz * dz);
+            if (d2 < 5.0f) {
+                Cand cd = {d2, id};
+                if (cand_less(cd, e[4], pool)) {
+                    e[4] = cd;
+                    for (int k = 4; k > 0; k--)
+                        if (cand_less(e[k], e[k - 1], pool)) { const Cand t = e[k - 1]; e[k - 1] = e[k]; e[k] = t; }
+                }
+            }
+        }
+    }
+    uint32_t win = kNoIdx;
+    for (int r = 0; r < 5; r++) {
+        Cand best = e[0];
+        for (int off = kG / 2; off > 0; off >>= 1) {
+            Cand o;
+            o.d2 = __shfl_xor(best.d2, off, kG);
+            o.id = __shfl_xor(best.id, off, kG);
+            if (cand_less(o, best, pool)) best = o;
+        }
+        if (gl == r) win = best.id;
+        if (best.id != kNoIdx && e[0].id == best.id) {
+            for (int k = 0; k < 4; k++) e[k] = e[k + 1];
+            e[4] = {INFINITY, kNoIdx};
+        }
+    }
+    return win;
+}
+
 // MODE 0: queries are body-frame ds points of a scan (transformed here, world point stored);
 // MODE 1: queries are world-frame points (diagnostic lio_map_knn).
-template <int KM, int MODE>
+template <int KM, int MODE, bool INLINE_TIE>
 __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                          float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
                                          uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
@@ -391,7 +452,17 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
             if (gl < 5) nn_pts[(size_t)gl * nn_stride + q] = (win != 0xFFFFFFFFu) ? pool[win] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (gl == 0) {
                 nn_cnt[q] = inrange < 5 ? (int32_t)inrange : 5;
-                if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
+                if constexpr (!INLINE_TIE) {
+                    if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
+                }
+            }
+        }
+        if constexpr (INLINE_TIE) {
+            // no tie queue (batch form): the group redoes a tied query exactly right here, from the list it still holds, and overwrites
+            // what it has just stored (the call sits behind the stores so that little is live across it)
+            if (tie && active && inrange > 0) {
+                const uint32_t w2 = group_exact_redo(g, nhit, pw, pool, gl);
+                if (gl < 5 && w2 != kNoIdx) nn_pts[(size_t)gl * nn_stride + q] = pool[w2];
             }
         }
         group_lds_sync();
@@ -415,11 +486,11 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
                                                   uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
                                                   float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
                                                   MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
-    knn_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, md, n_tie, tie_list);
+    knn_body<KM, MODE, false>(table, mask, pool, inv_res, st, pose, queries, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, md, n_tie, tie_list);
 }
 // the scans of a batch (lio_batch_*): blockIdx.y = slot; pose from the slot's device-resident filter; a slot whose update has finished,
 // or whose filter did not ask for a neighbour search this pass, exits at once
-template <int KM>
+template <int KM, bool INLINE_TIE>
 __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                                        float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md) {
     const SlotDesc& d = slots[blockIdx.y];
@@ -427,30 +498,11 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slo
     const EskfDev* c = d.ctrl;
     if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
     const PoseArgs pose = pose_from_state(c->x);
-    knn_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
+    knn_body<KM, 0, INLINE_TIE>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md,
+                                INLINE_TIE ? nullptr : &d.sd->n_tie, INLINE_TIE ? nullptr : d.tie_list);
 }
 
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
-struct Cand {
-    float d2;
-    uint32_t id;
-};
-
-// strict total order (d2, x, y, z); the coordinate comparison only runs on exact d2 ties
-__device__ __noinline__ bool cand_tie_less(const Cand& a, const Cand& b, const float4* __restrict__ pool) {
-    if (a.id == b.id) return false;
-    if (a.id == kNoIdx || b.id == kNoIdx) return a.id < b.id;
-    const float4 pa = pool[a.id], pb = pool[b.id];
-    if (pa.x != pb.x) return pa.x < pb.x;
-    if (pa.y != pb.y) return pa.y < pb.y;
-    if (pa.z != pb.z) return pa.z < pb.z;
-    return a.id < b.id;
-}
-__device__ inline bool cand_less(const Cand& a, const Cand& b, const float4* __restrict__ pool) {
-    if (a.d2 != b.d2) return a.d2 < b.d2;
-    return cand_tie_less(a, b, pool);
-}
-
 template <int KM, int MODE>
 __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
@@ -538,16 +590,22 @@ __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __rest
     knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list);
 }
 
-int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x) {
+// tie_mode 0: tied queries are queued and redone by a second (usually empty) launch; 1: redone in place by their group -- one launch
+// less per pass, at 14 more vector registers (occupancy 5 instead of 6)
+int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode) {
     if (grid_x > 2048) grid_x = 2048;  // grid-stride loop inside: 16 queries per workgroup and round
     if (grid_x == 0) grid_x = 8;
     const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
     const dim3 gridx(64, (uint32_t)n_slots);
     const int km = (m->stencil.n + kG - 1) / kG;
-#define KNNB_LAUNCH(KM)                                                                                                                         \
-    do {                                                                                                                                        \
-        hipLaunchKernelGGL((knn_batch_kernel<KM>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
-        hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots);  \
+#define KNNB_LAUNCH(KM)                                                                                                                              \
+    do {                                                                                                                                             \
+        if (tie_mode == 1) {                                                                                                                         \
+            hipLaunchKernelGGL((knn_batch_kernel<KM, true>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev);  \
+        } else {                                                                                                                                     \
+            hipLaunchKernelGGL((knn_batch_kernel<KM, false>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
+            hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots);       \
+        }                                                                                                                                            \
     } while (0)
     if (km <= 1) KNNB_LAUNCH(1);
     else if (km <= 2) KNNB_LAUNCH(2);

@@ -517,8 +517,9 @@ int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, in
     if (knn_blocks == 0) knn_blocks = 8;
     for (int p = 0; p < n_passes; p++) {
         if (bt) bt->begin(1);
-        // knn_kind 0: sixteen lanes per query (knn.hip, + the exact redo of queued ties), 1: one lane per query (knn_q.hip)
-        const int rc = knn_kind == 1 ? knn_q_batch(m, st, d_slots, n_slots, knn_blocks) : knn_batch_launch(m, st, d_slots, n_slots, (ds_bound + 15) / 16);
+        // knn_kind 0: sixteen lanes per query (knn.hip) + the exact redo of queued ties, 2: the same with ties redone in place,
+        // 1: one lane per query (knn_q.hip)
+        const int rc = knn_kind == 1 ? knn_q_batch(m, st, d_slots, n_slots, knn_blocks) : knn_batch_launch(m, st, d_slots, n_slots, (ds_bound + 15) / 16, knn_kind == 2 ? 1 : 0);
         if (bt) bt->end(1);
         if (rc != LIO_OK) return rc;
         if (bt) bt->begin(2);
