@@ -22,6 +22,10 @@ import time
 
 import numpy as np
 
+# HIP deals streams to hardware queues round robin; with the default of 4 the rounds in flight of the batched engine share queues with
+# idle streams and mostly run back to back (measured: 0.085 -> 0.070 ms per scan with 8).  Must be set before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "lidar-slam-detection_amd", "python"))
 
@@ -55,7 +59,7 @@ def main():
                                                               "each, all reading the one resident map)")
     ap.add_argument("--engine", choices=["batch", "threads"], default="batch",
                     help="batch: B scans per launch, filter loop on the device, one host thread (lio_batch_*); threads: round 1's one engine + thread per scan")
-    ap.add_argument("--slots", type=int, default=8, help="--engine batch: scans per launch")
+    ap.add_argument("--slots", type=int, default=16, help="--engine batch: scans per launch")
     ap.add_argument("--groups", type=int, default=3, help="--engine batch: rounds in flight (one HIP stream each)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="the job list of --steps scans is repeated until the timed region lasts at least this long")
     args = ap.parse_args()

@@ -33,6 +33,8 @@ struct Group {
     EskfDev* d_ctrl = nullptr;
     EskfDev* h_ctrl = nullptr;
     hipGraphExec_t exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the whole round as a graph, per number of radix passes
+    const void* graph_table = nullptr;   // the graphs hold the map's table address and stencil by value: dropped when either changes
+    int graph_stencil = 0;
     lio_batch_result* h_res = nullptr;   // pinned, mapped
     lio_batch_result* h_res_dev = nullptr;
     std::vector<int> job_of_slot;
@@ -58,6 +60,30 @@ struct lio_batch {
 
 namespace {
 
+
+void fill_desc(SlotDesc& d, lio_scan* sc, EskfDev* d_ctrl, lio_batch_result* d_res) {
+    d.max_ds = sc->max_ds;
+    d.partial_blocks = sc->partial_blocks;
+    d.sd = sc->dev;
+    d.keys_a = sc->keys_a; d.keys_b = sc->keys_b; d.vals_a = sc->vals_a; d.vals_b = sc->vals_b;
+    d.hist = sc->hist; d.blockcnt = sc->blockcnt; d.hpos = sc->hpos; d.longlist = sc->longlist; d.tie_list = sc->tie_list;
+    d.sorted = sc->sorted; d.ds_body = sc->ds_body; d.ds_world = sc->ds_world; d.nn_pts = sc->nn_pts; d.normvec = sc->normvec;
+    d.nn_cnt = sc->nn_cnt; d.selected = sc->selected; d.partial = sc->partial;
+    d.host_nds = sc->host_nds_dev;
+    d.ctrl = d_ctrl;
+    d.result = d_res;
+}
+
+void fill_ctrl(EskfDev& c, const double* x26, const double* P529, double R, int max_iter, int degenerate_detect_en) {
+    memcpy(c.x, x26, sizeof(double) * 26);
+    memcpy(c.P, P529, sizeof(double) * 529);
+    for (int k = 0; k < kEkN; k++) c.limit[k] = 0.001;
+    c.R = R;
+    c.maximum_iter = max_iter;
+    c.degenerate_detect_en = degenerate_detect_en;
+    c.is_degenerate = 0;
+    ek_begin(c);
+}
 
 void group_free(Group& g) {
     for (lio_engine* e : g.eng) lio_engine_destroy(e);
@@ -100,15 +126,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         d.active = 1;
         d.seq = g.seq;
         d.min_ds = 5;  // laserMapping.cpp:1246: fewer than five downsampled points are not registered
-        EskfDev& c = g.h_ctrl[s];
-        memcpy(c.x, job.state_in, sizeof(double) * 26);
-        memcpy(c.P, job.cov_in, sizeof(double) * 529);
-        for (int k = 0; k < kEkN; k++) c.limit[k] = 0.001;
-        c.R = 0.001;  // LASER_POINT_COV
-        c.maximum_iter = 4;
-        c.degenerate_detect_en = 1;
-        c.is_degenerate = 0;
-        ek_begin(c);
+        fill_ctrl(g.h_ctrl[s], job.state_in, job.cov_in, 0.001 /* LASER_POINT_COV */, 4, 1);
         g.h_res[s].seq = g.seq - 1;
         g.n_active++;
         if (job.n_raw > g.max_n_raw) g.max_n_raw = job.n_raw;
@@ -129,6 +147,12 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, bt, b->knn_kind);
     };
     if (!b->use_graph || timed) return enqueue(timed ? g.bt : nullptr);
+    if (g.graph_table != b->map->table || g.graph_stencil != b->map->stencil.n) {
+        for (int k = 0; k < 5; k++)
+            if (g.exec[k]) { hipGraphExecDestroy(g.exec[k]); g.exec[k] = nullptr; }
+        g.graph_table = b->map->table;
+        g.graph_stencil = b->map->stencil.n;
+    }
     if (!g.exec[passes]) {
         hipGraph_t graph = nullptr;
         LIO_HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
@@ -203,18 +227,7 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
             if (!e) { ok = false; break; }
             lio_engine_set_flags(e, 1, 0, 0.0, -10.0);
             g.eng.push_back(e);
-            lio_scan* sc = lio_engine_scan(e);
-            SlotDesc& d = g.h_desc[s];
-            d.max_ds = sc->max_ds;
-            d.partial_blocks = sc->partial_blocks;
-            d.sd = sc->dev;
-            d.keys_a = sc->keys_a; d.keys_b = sc->keys_b; d.vals_a = sc->vals_a; d.vals_b = sc->vals_b;
-            d.hist = sc->hist; d.blockcnt = sc->blockcnt; d.hpos = sc->hpos; d.longlist = sc->longlist; d.tie_list = sc->tie_list;
-            d.sorted = sc->sorted; d.ds_body = sc->ds_body; d.ds_world = sc->ds_world; d.nn_pts = sc->nn_pts; d.normvec = sc->normvec;
-            d.nn_cnt = sc->nn_cnt; d.selected = sc->selected; d.partial = sc->partial;
-            d.host_nds = sc->host_nds_dev;
-            d.ctrl = &g.d_ctrl[s];
-            d.result = &g.h_res_dev[s];
+            fill_desc(g.h_desc[s], lio_engine_scan(e), &g.d_ctrl[s], &g.h_res_dev[s]);
         }
     }
     if (!ok) {
@@ -363,3 +376,101 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same device-resident loop for ONE engine (lio_engine_update, the filter update inside lio_engine_process_scan / lio_fastlio_main):
+// one upload, (maximum_iter + 1) x {kNN, linearise, filter pass} on the engine's own stream, one download of the filter (state,
+// covariance, pass logs), one wait -- instead of a host hand-over after every pass.  Falls back to the per-pass host loop for the rest
+// of an update whose pass needs the N_eff < 23 dense branch.
+struct lio_devloop {
+    char* d_block = nullptr;
+    char* h_block = nullptr;  // pinned: [SlotDesc][EskfDev] up, [EskfDev] down
+    size_t block_bytes = 0;
+    SlotDesc* d_desc = nullptr;
+    SlotDesc* h_desc = nullptr;
+    EskfDev* d_ctrl = nullptr;
+    EskfDev* h_ctrl = nullptr;
+    EskfDev* h_back = nullptr;  // pinned download target
+    lio_batch_result* h_res = nullptr;
+    lio_batch_result* h_res_dev = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint32_t seq = 0;
+    int knn_kind = 0;
+    int stencil_n = 0;  // the graph holds the stencil by value and the table's address: re-captured when either changes
+    const void* table = nullptr;  // (an LRU map swaps its table for a rebuilt twin now and then)
+};
+
+void devloop_destroy(lio_devloop* d) {
+    if (!d) return;
+    if (d->exec) hipGraphExecDestroy(d->exec);
+    if (d->d_block) hipFree(d->d_block);
+    if (d->h_block) hipHostFree(d->h_block);
+    if (d->h_back) hipHostFree(d->h_back);
+    if (d->h_res) hipHostFree(d->h_res);
+    delete d;
+}
+
+lio_devloop* devloop_create(lio_scan* sc) {
+    lio_devloop* d = new lio_devloop();
+    d->block_bytes = sizeof(SlotDesc) + sizeof(EskfDev);
+    bool ok = hipMalloc(reinterpret_cast<void**>(&d->d_block), d->block_bytes) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&d->h_block), d->block_bytes, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&d->h_back), sizeof(EskfDev), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&d->h_res), sizeof(lio_batch_result), hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void**>(&d->h_res_dev), d->h_res, 0) == hipSuccess;
+    if (!ok) { devloop_destroy(d); return nullptr; }
+    d->d_desc = reinterpret_cast<SlotDesc*>(d->d_block);
+    d->h_desc = reinterpret_cast<SlotDesc*>(d->h_block);
+    d->d_ctrl = reinterpret_cast<EskfDev*>(d->d_block + sizeof(SlotDesc));
+    d->h_ctrl = reinterpret_cast<EskfDev*>(d->h_block + sizeof(SlotDesc));
+    memset(d->h_block, 0, d->block_bytes);
+    memset(d->h_res, 0, sizeof(lio_batch_result));
+    fill_desc(*d->h_desc, sc, d->d_ctrl, d->h_res_dev);
+    { const char* k = getenv("LIO_BATCH_KNN"); d->knn_kind = (k && k[0] == 'q') ? 1 : ((k && k[0] == 'i') ? 2 : 0); }
+    return d;
+}
+
+// runs the update of the scan's current downsampled points from (x26, P529); on return *out holds the filter as the device left it
+// (status EK_DONE, or EK_NEEDS_HOST with the loop state of the pass the host has to take over)
+int devloop_update(lio_devloop* d, lio_map* m, lio_scan* sc, const double* x26, const double* P529, double R, int max_iter, int degenerate_detect_en,
+                   const EskfDev** out) {
+    SlotDesc& desc = *d->h_desc;
+    desc.active = 1;
+    desc.min_ds = 0;
+    desc.n_raw = sc->n_raw;
+    desc.nblocks = 0;
+    desc.seq = ++d->seq;
+    fill_ctrl(*d->h_ctrl, x26, P529, R, max_iter, degenerate_detect_en);
+    const uint32_t bound = sc->have_ds > 0 ? (uint32_t)sc->have_ds : (sc->n_raw && sc->n_raw < sc->max_ds ? sc->n_raw : sc->max_ds);
+    hipStream_t st = sc->stream;
+    auto enqueue = [&](uint32_t ds_bound) -> int {
+        LIO_HIP_TRY(hipMemcpyAsync(d->d_block, d->h_block, d->block_bytes, hipMemcpyHostToDevice, st));
+        const int rc = p2plane_batch_update(m, st, d->d_desc, 1, ds_bound, max_iter + 1, nullptr, d->knn_kind);
+        if (rc != LIO_OK) return rc;
+        LIO_HIP_TRY(hipMemcpyAsync(d->h_back, d->d_ctrl, sizeof(EskfDev), hipMemcpyDeviceToHost, st));
+        return LIO_OK;
+    };
+    static const bool use_graph = []() { const char* k = getenv("LIO_BATCH_GRAPH"); return !(k && k[0] == '0'); }();
+    if (use_graph && max_iter == 4) {
+        if (d->exec && (d->stencil_n != m->stencil.n || d->table != m->table)) { hipGraphExecDestroy(d->exec); d->exec = nullptr; }
+        if (!d->exec) {
+            hipGraph_t graph = nullptr;
+            LIO_HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue(sc->max_ds);
+            const hipError_t e2 = hipStreamEndCapture(st, &graph);
+            if (rc != LIO_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+            LIO_HIP_TRY(e2);
+            LIO_HIP_TRY(hipGraphInstantiate(&d->exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+            d->stencil_n = m->stencil.n;
+            d->table = m->table;
+        }
+        LIO_HIP_TRY(hipGraphLaunch(d->exec, st));
+    } else {
+        const int rc = enqueue(bound);
+        if (rc != LIO_OK) return rc;
+    }
+    LIO_HIP_TRY(hipStreamSynchronize(st));
+    *out = d->h_back;
+    return LIO_OK;
+}

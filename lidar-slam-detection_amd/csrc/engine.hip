@@ -2,6 +2,8 @@
 // (/root/reference/slam/mapping/fastlio/src/laserMapping.cpp:1189-1304), as host C++ over the kernel-level
 // C ABI.  Constants follow fastlio_init (laserMapping.cpp:1025-1124): 4 (+1) filter passes, leaf 0.5 m for
 // both filters, INIT_TIME 0.1 s, LASER_POINT_COV 0.001, degeneracy detection on, extrinsic estimation off.
+#include <stdlib.h>
+
 #include <atomic>
 #include <chrono>
 #include <array>
@@ -68,8 +70,16 @@ struct Frontend {
     int n_poses = 0;
 };
 
+struct lio_devloop;  // batch.hip: the device-resident filter loop of one engine
+lio_devloop* devloop_create(lio_scan* sc);
+void devloop_destroy(lio_devloop* d);
+int devloop_update(lio_devloop* d, lio_map* m, lio_scan* sc, const double* x26, const double* P529, double R, int max_iter, int degenerate_detect_en,
+                   const lio::EskfDev** out);
+
 struct lio_engine {
     Frontend* fe = nullptr;
+    lio_devloop* dl = nullptr;
+    int device_loop = 1;  // LIO_DEVICE_LOOP=0: the round-1 host loop (one hand-over per pass)
     lio_map* map;
     lio_scan* scan;
     Eskf kf;
@@ -93,6 +103,8 @@ struct lio_engine {
     lio_reduce_fn reduce = nullptr;  // cross-GPU reduction of the normal equations (joint registration)
     void* reduce_ctx = nullptr;
 };
+
+int engine_resume_update_impl(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t, bool keep_log);
 
 namespace {
 
@@ -257,7 +269,48 @@ void on_pass(void* vctx, int, bool, const Measurement&, const double* dx) {
     if (dx && !c->e->log.empty()) memcpy(c->e->log.back().dx, dx, sizeof(double) * kDof);
 }
 
+// the iterated update with the loop on the device (batch.hip, eskf_dev.h): one submission, one wait
+int run_update_device(lio_engine* e) {
+    if (!e->dl) {
+        e->dl = devloop_create(e->scan);
+        if (!e->dl) { set_error("device loop: allocation failed"); return LIO_E_DEVICE; }
+    }
+    double x0[26];
+    state_to_array(e->kf.x, x0);
+    double P0[529];
+    memcpy(P0, e->kf.P, sizeof(P0));
+    const EskfDev* c = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = devloop_update(e->dl, e->map, e->scan, x0, P0, e->laser_cov, e->kf.maximum_iter, e->degenerate_detect_en ? 1 : 0, &c);
+    if (rc != LIO_OK) return rc;
+    e->log.clear();
+    for (int k = 0; k < c->n_log && k < kEkMaxPass; k++) {
+        lio_pass_log pl;
+        static_assert(sizeof(pl) == sizeof(EkPassLog), "EkPassLog mirrors lio_pass_log");
+        memcpy(&pl, &c->log[k], sizeof(pl));
+        e->log.push_back(pl);
+    }
+    e->tm.n_pass = c->n_pass;
+    e->tm.n_knn_pass = c->n_knn;
+    e->tm.n_eff_last = c->n_eff_last;
+    e->tm.n_ds = e->scan->have_ds > 0 ? e->scan->have_ds : e->tm.n_ds;
+    e->is_degenerate = c->is_degenerate != 0;
+    if (c->status == EK_NEEDS_HOST) {  // a pass with 1 <= N_eff < 23: the host filter takes over from that pass (dense gain, esekfom.hpp:1715-1744)
+        const int np = e->tm.n_pass, nk = e->tm.n_knn_pass;
+        const int r2 = engine_resume_update_impl(e, c->x, x0, P0, c->i, c->converge, c->t, true);
+        e->tm.n_pass += np;
+        e->tm.n_knn_pass += nk;
+        if (r2 != LIO_OK) return r2;
+    } else {
+        state_from_array(c->x, e->kf.x);
+        memcpy(e->kf.P, c->P, sizeof(e->kf.P));
+    }
+    e->tm.host_solve_us = (float)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return LIO_OK;
+}
+
 int run_update(lio_engine* e) {
+    if (e->device_loop && !e->reduce && !e->timing && e->kf.maximum_iter + 1 <= kEkMaxPass) return run_update_device(e);
     e->log.clear();
     PassCtx ctx{e, LIO_OK};
     double host_us = 0;
@@ -298,9 +351,12 @@ int run_update(lio_engine* e) {
 // the host filter continues from exactly there: state at the start of that pass, the propagated state / covariance of the update, the
 // loop counters -- through this engine's per-pass path (same scan buffers, neighbour cache and gate flags the device loop left).
 int engine_resume_update(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t) {
+    return engine_resume_update_impl(e, x_now26, x_prop26, P_prop, i, converge, t, false);
+}
+int engine_resume_update_impl(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t, bool keep_log) {
     if (!e || !x_now26 || !x_prop26 || !P_prop) return LIO_E_INVALID;
     hipSetDevice(e->scan->device);
-    e->log.clear();
+    if (!keep_log) e->log.clear();
     memset(&e->tm, 0, sizeof(e->tm));
     PassCtx ctx{e, LIO_OK};
     Eskf::Work w;
@@ -352,6 +408,7 @@ lio_engine* lio_engine_create(int device, float resolution, int stencil, uint64_
     lio_engine* e = new lio_engine();
     e->map = m;
     e->scan = s;
+    { const char* k = getenv("LIO_DEVICE_LOOP"); e->device_loop = (k && k[0] == '0') ? 0 : 1; }
     s->resize_min = 5;
     memset(&e->tm, 0, sizeof(e->tm));
     return e;
@@ -364,6 +421,7 @@ lio_engine* lio_engine_create_shared(lio_map* shared_map, uint32_t max_raw, uint
     lio_engine* e = new lio_engine();
     e->map = shared_map;
     e->scan = s;
+    { const char* k = getenv("LIO_DEVICE_LOOP"); e->device_loop = (k && k[0] == '0') ? 0 : 1; }
     s->resize_min = 5;
     e->own_map = false;
     e->static_map = true;  // several engines read one map concurrently: nobody inserts
@@ -376,6 +434,7 @@ static void frontend_destroy(lio_engine* e);
 void lio_engine_destroy(lio_engine* e) {
     if (!e) return;
     frontend_destroy(e);
+    if (e->dl) { hipStreamSynchronize(e->scan->stream); devloop_destroy(e->dl); }
     lio_scan_destroy(e->scan);
     if (e->own_map) lio_map_destroy(e->map);
     delete e;
