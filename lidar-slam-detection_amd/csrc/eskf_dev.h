@@ -353,6 +353,43 @@ EK_FN bool ek_inverse3(const double A[9], double out[9]) {  // mat_inverse(A, 3,
 }
 
 // ---- phases -------------------------------------------------------------------------------------------------------
+// boxminus / boxplus with their independent pieces on different lanes: the two SO3 blocks on lanes 0 and 1 (one instruction stream),
+// the S2 block on lane 2, the vector parts on lane 3 -- the transcendental functions (atan, sin, cos in f64: hundreds of cycles each on
+// one lane) then cost the time of the slowest piece, not their sum.  On the host the pieces simply run one after the other.
+EK_FN void ek_boxminus_par(const double x[26], const double o[26], double d[kEkN]) {
+    for (int blk = 0; blk < 2; blk++) {
+        if (EK_LANE(blk)) {
+            const int a = 3 + 4 * blk;
+            double c[4], q[4];
+            c[0] = -o[a]; c[1] = -o[a + 1]; c[2] = -o[a + 2]; c[3] = o[a + 3];
+            ek_quat_mul(c, x + a, q);
+            ek_so3_log(q, d + 3 + 3 * blk);
+        }
+    }
+    if (EK_LANE(2)) ek_s2_boxminus(x + 23, o + 23, d + 21);
+    if (EK_LANE(3)) {
+        for (int i = 0; i < 3; i++) {
+            d[i] = x[i] - o[i];
+            d[9 + i] = x[11 + i] - o[11 + i]; d[12 + i] = x[14 + i] - o[14 + i]; d[15 + i] = x[17 + i] - o[17 + i]; d[18 + i] = x[20 + i] - o[20 + i];
+        }
+    }
+}
+EK_FN void ek_boxplus_par(double x[26], const double d[kEkN]) {
+    for (int blk = 0; blk < 2; blk++) {
+        if (EK_LANE(blk)) {
+            const int a = 3 + 4 * blk;
+            double e[4], q[4];
+            ek_so3_exp(d + 3 + 3 * blk, 0.5, e);
+            ek_quat_mul(x + a, e, q);
+            for (int i = 0; i < 4; i++) x[a + i] = q[i];
+        }
+    }
+    if (EK_LANE(2)) ek_s2_boxplus(x + 23, d + 21);
+    if (EK_LANE(3)) {
+        for (int i = 0; i < 3; i++) { x[i] += d[i]; x[11 + i] += d[9 + i]; x[14 + i] += d[12 + i]; x[17 + i] += d[15 + i]; x[20 + i] += d[18 + i]; }
+    }
+}
+
 // manifold Jacobians of esekfom.hpp:1661-1699 from (x, x_prop, dx): three independent pieces, one thread each
 EK_FN void ek_jacobians(const double x[26], const double x_prop[26], const double dx[kEkN], EkWork& w) {
     for (int blk = 0; blk < 2; blk++) {
@@ -587,7 +624,7 @@ EK_FN void ek_measure_tail(EskfDev& c, EkWork& w) {
 EK_FN void ek_step(EskfDev& c, EkWork& w) {
     constexpr int N = kEkN;
     const double R = c.R;
-    if (EK_LANE(0)) ek_boxminus(c.x, c.x_prop, w.dx);
+    ek_boxminus_par(c.x, c.x_prop, w.dx);
     EK_SYNC();
     ek_jacobians(c.x, c.x_prop, w.dx, w);
     EK_FOR(k, N) w.dx_new[k] = w.dx[k];
@@ -646,11 +683,14 @@ EK_FN void ek_step(EskfDev& c, EkWork& w) {
         w.dx_out[a] = s;
     }
     EK_SYNC();
-    if (EK_LANE(0)) {
+    ek_boxplus_par(c.x, w.dx_out);
+    {
         EkPassLog& pl = c.log[c.n_log < kEkMaxPass ? c.n_log : kEkMaxPass - 1];
-        for (int k = 0; k < N; k++) pl.dx[k] = w.dx_out[k];
+        EK_FOR(k, N) pl.dx[k] = w.dx_out[k];
+    }
+    EK_SYNC();
+    if (EK_LANE(0)) {
         c.n_log++;
-        ek_boxplus(c.x, w.dx_out);
         bool converge = true;
         for (int a = 0; a < N; a++)
             if (fabs(w.dx_out[a]) > c.limit[a]) { converge = false; break; }
