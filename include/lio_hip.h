@@ -267,6 +267,12 @@ int lio_fastlio_imu_enqueue(lio_engine*, double stamp, const double gyr[3], cons
  * initialisation reads it (IMU_Processing.hpp:201-204; the wheel-speed rows are compiled out, wheelspeed_en == false) */
 int lio_fastlio_ins_enqueue(lio_engine*, double stamp, const double vel_imu[3]);
 int lio_fastlio_pcl_enqueue(lio_engine*, const float* xyzi, const uint32_t* stamp_us, uint32_t n, double header_stamp);
+/* the same without an intermediate copy (boundary marshalling, numpy_to_pointcloud + preprocessPoints of the reference: slam/src/py_utils.cpp:
+ * 149-181, slam/common/slam_base.h:83-85): _stage hands out the pinned staging buffers of the next scan (room for n points), the caller writes
+ * the points (already in the INS frame) and stamps straight into them, _commit starts their trip to the device and queues the scan.  One scan
+ * staged at a time; the pointers are dead after _commit. */
+int lio_fastlio_pcl_stage(lio_engine*, uint32_t n, float** xyzi, uint32_t** stamp_us);
+int lio_fastlio_pcl_commit(lio_engine*, uint32_t n, double header_stamp);
 /* device-resident scan: the two buffers must stay valid until the lio_fastlio_main call that consumes them returned */
 int lio_fastlio_pcl_enqueue_device(lio_engine*, const void* d_xyzi, const void* d_stamp_us, uint32_t n, double header_stamp);
 int lio_fastlio_main(lio_engine*);

@@ -44,6 +44,7 @@ struct Frontend {
     std::deque<std::pair<double, std::array<double, 3>>> ins_buffer;  // (stamp s, velocity in the IMU frame)
     std::vector<PinnedScan> pool;
     std::vector<int> pool_free;
+    int staged = -1;  // slot handed out by lio_fastlio_pcl_stage and not yet committed
     // fastlio_init arguments / Preprocess members
     double scan_period = 0.1, blind = 0.1;
     int filter_num = 1, max_point_num = -1;
@@ -908,6 +909,76 @@ int lio_fastlio_ins_enqueue(lio_engine* e, double stamp, const double vel_imu[3]
     return LIO_OK;
 }
 
+// a staging slot (pinned host buffer + device twin + event): recycled ones first, the pool grows on demand
+static int fe_take_slot(lio_engine* e, int* slot_out) {
+    Frontend* f = e->fe;
+    lio_scan* s = e->scan;
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lk(f->mtx);
+        if (!f->pool_free.empty()) { slot = f->pool_free.back(); f->pool_free.pop_back(); }
+    }
+    hipSetDevice(s->device);
+    if (slot < 0) {
+        PinnedScan b;
+        void *mem = nullptr, *dmem = nullptr;
+        const size_t bytes = (size_t)s->max_raw * (sizeof(float4) + sizeof(uint32_t));
+        LIO_HIP_TRY(hipHostMalloc(&mem, bytes, hipHostMallocDefault));
+        LIO_HIP_TRY(hipMalloc(&dmem, bytes));
+        LIO_HIP_TRY(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
+        b.xyzi = static_cast<float4*>(mem);
+        b.stamp = reinterpret_cast<uint32_t*>(b.xyzi + s->max_raw);
+        b.d_xyzi = static_cast<float4*>(dmem);
+        b.d_stamp = reinterpret_cast<uint32_t*>(b.d_xyzi + s->max_raw);
+        std::lock_guard<std::mutex> lk(f->mtx);
+        f->pool.push_back(b);
+        slot = (int)f->pool.size() - 1;
+    }
+    *slot_out = slot;
+    return LIO_OK;
+}
+// the slot's content is complete: start its trip to the device on the copy stream and queue the scan
+static int fe_send_slot(lio_engine* e, int slot, uint32_t n, double header_stamp) {
+    Frontend* f = e->fe;
+    PinnedScan b;
+    { std::lock_guard<std::mutex> lk(f->mtx); b = f->pool[slot]; }
+    hipSetDevice(e->scan->device);
+    if (n) {
+        LIO_HIP_TRY(hipMemcpyAsync(b.d_xyzi, b.xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, f->copy_stream));
+        LIO_HIP_TRY(hipMemcpyAsync(b.d_stamp, b.stamp, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, f->copy_stream));
+    }
+    LIO_HIP_TRY(hipEventRecord(b.copied, f->copy_stream));
+    PendingScan sc;
+    sc.beg = header_stamp;
+    sc.n = n;
+    sc.pinned = slot;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    f->lidar_buffer.push_back(sc);
+    return LIO_OK;
+}
+int lio_fastlio_pcl_stage(lio_engine* e, uint32_t n, float** xyzi, uint32_t** stamp_us) {
+    if (!e || !e->fe || !xyzi || !stamp_us) return LIO_E_INVALID;
+    if (n > e->scan->max_raw) { set_error("scan of %u points exceeds max_raw %u", n, e->scan->max_raw); return LIO_E_CAPACITY; }
+    if (e->fe->staged >= 0) { set_error("lio_fastlio_pcl_stage: the previous staged scan was not committed"); return LIO_E_STATE; }
+    int slot = -1;
+    const int rc = fe_take_slot(e, &slot);
+    if (rc != LIO_OK) return rc;
+    e->fe->staged = slot;
+    PinnedScan b;
+    { std::lock_guard<std::mutex> lk(e->fe->mtx); b = e->fe->pool[slot]; }
+    *xyzi = reinterpret_cast<float*>(b.xyzi);
+    *stamp_us = b.stamp;
+    return LIO_OK;
+}
+int lio_fastlio_pcl_commit(lio_engine* e, uint32_t n, double header_stamp) {
+    if (!e || !e->fe) return LIO_E_INVALID;
+    if (e->fe->staged < 0) { set_error("lio_fastlio_pcl_commit: nothing staged"); return LIO_E_STATE; }
+    if (n > e->scan->max_raw) return LIO_E_CAPACITY;
+    const int slot = e->fe->staged;
+    e->fe->staged = -1;
+    return fe_send_slot(e, slot, n, header_stamp);
+}
+
 static int fe_enqueue(lio_engine* e, const float* xyzi, const uint32_t* stamp_us, uint32_t n, double header_stamp, bool device) {
     if (!e || !e->fe || (n && (!xyzi || !stamp_us))) return LIO_E_INVALID;
     Frontend* f = e->fe;
@@ -921,36 +992,13 @@ static int fe_enqueue(lio_engine* e, const float* xyzi, const uint32_t* stamp_us
         sc.d_stamp = stamp_us;
     } else {
         int slot = -1;
-        {
-            std::lock_guard<std::mutex> lk(f->mtx);
-            if (!f->pool_free.empty()) { slot = f->pool_free.back(); f->pool_free.pop_back(); }
-        }
-        hipSetDevice(s->device);
-        if (slot < 0) {  // grow the pool of staging slots (recycled by fastlio_main)
-            PinnedScan b;
-            void *mem = nullptr, *dmem = nullptr;
-            const size_t bytes = (size_t)s->max_raw * (sizeof(float4) + sizeof(uint32_t));
-            LIO_HIP_TRY(hipHostMalloc(&mem, bytes, hipHostMallocDefault));
-            LIO_HIP_TRY(hipMalloc(&dmem, bytes));
-            LIO_HIP_TRY(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
-            b.xyzi = static_cast<float4*>(mem);
-            b.stamp = reinterpret_cast<uint32_t*>(b.xyzi + s->max_raw);
-            b.d_xyzi = static_cast<float4*>(dmem);
-            b.d_stamp = reinterpret_cast<uint32_t*>(b.d_xyzi + s->max_raw);
-            std::lock_guard<std::mutex> lk(f->mtx);
-            f->pool.push_back(b);
-            slot = (int)f->pool.size() - 1;
-        }
+        const int rc = fe_take_slot(e, &slot);
+        if (rc != LIO_OK) return rc;
         PinnedScan b;
         { std::lock_guard<std::mutex> lk(f->mtx); b = f->pool[slot]; }
         memcpy(b.xyzi, xyzi, (size_t)n * sizeof(float4));
         memcpy(b.stamp, stamp_us, (size_t)n * sizeof(uint32_t));
-        if (n) {
-            LIO_HIP_TRY(hipMemcpyAsync(b.d_xyzi, b.xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, f->copy_stream));
-            LIO_HIP_TRY(hipMemcpyAsync(b.d_stamp, b.stamp, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, f->copy_stream));
-        }
-        LIO_HIP_TRY(hipEventRecord(b.copied, f->copy_stream));
-        sc.pinned = slot;
+        return fe_send_slot(e, slot, n, header_stamp);
     }
     std::lock_guard<std::mutex> lk(f->mtx);
     f->lidar_buffer.push_back(sc);

@@ -1,0 +1,477 @@
+// slam_wrapper.cpp -- the reference's OUTER boundary: the pybind11 module `slam_wrapper` that slam/slam.py and slam/map_manager.py
+// import (/root/reference/slam/src/slam_wrapper.cpp:192-324: same function names, argument names and order, return types), in C++
+// over the C ABI of liblio_hip.so.
+//
+// On the hot path (mapping mode, FastLIO): init_slam / set_ins_external_param / set_imu_external_param / setup_slam / process /
+// deinit_slam do what the reference does between Python and the filter --
+//   numpy_to_imu            slam/src/py_utils.cpp:244-258   deg/s -> rad/s, g -> m/s^2, us -> s
+//   pydict_to_cloud         slam/src/py_utils.cpp:149-181   N x 4 f32 + N x 2 attr (col 0 = per-point offset in us)
+//   preprocessPoints        slam/common/slam_base.h:83-85   lidar -> INS static transform (pcl::transformPointCloud with a Matrix4d)
+//   HDL_FastLIO::init / setSensors / feedImuData / feedPointData / runLio / getPose   slam/mapping/fastlio/src/fastlio.cpp:119-277
+//   SLAM::run               slam/src/slam.cpp:273-367       pose fields, heading / pitch / roll from the odometry
+// -- except that the cloud goes numpy -> pinned staging buffer -> HBM in ONE pass (lio_fastlio_pcl_stage / _commit): the static
+// transform and the stamp conversion are applied while copying, the 48-byte PointXYZINormal inflation and the two intermediate
+// PCL clouds of the reference never exist.
+// Off the hot path (graph back end, GNSS, map export, colouration: SURVEY.md section 2 OUT-OF-SCOPE, Appendix B): type-correct minimal
+// implementations -- empty dict / list, identity 4 x 4, stored-and-returned settings -- so that slam.py and map_manager.py run
+// unchanged.  They are listed in INTEGRATION.md.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/lio_hip.h"
+
+namespace py = pybind11;
+
+namespace {
+
+constexpr double kAng2Rad = 0.01745329251994;  // the reference's truncated constant (slam/common/slam_utils.cpp:88)
+
+struct Mat4 {
+    double m[16];
+    static Mat4 identity() {
+        Mat4 r;
+        for (int i = 0; i < 16; i++) r.m[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        return r;
+    }
+    double& operator()(int r, int c) { return m[r * 4 + c]; }
+    double operator()(int r, int c) const { return m[r * 4 + c]; }
+};
+Mat4 mul(const Mat4& a, const Mat4& b) {
+    Mat4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += a(i, k) * b(k, j);
+            r(i, j) = s;
+        }
+    return r;
+}
+Mat4 rigid_inverse(const Mat4& a) {  // [R t; 0 1]^-1 = [R^T  -R^T t; 0 1]
+    Mat4 r = Mat4::identity();
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r(i, j) = a(j, i);
+    for (int i = 0; i < 3; i++) r(i, 3) = -(r(i, 0) * a(0, 3) + r(i, 1) * a(1, 3) + r(i, 2) * a(2, 3));
+    return r;
+}
+// getTransformFromRPYT (slam_utils.cpp:89-96): translation * Rz(yaw) * Rx(pitch) * Ry(roll), angles in degrees
+Mat4 transform_from_rpyt(double x, double y, double z, double yaw, double pitch, double roll) {
+    const double cy = std::cos(yaw * kAng2Rad), sy = std::sin(yaw * kAng2Rad);
+    const double cp = std::cos(pitch * kAng2Rad), sp = std::sin(pitch * kAng2Rad);
+    const double cr = std::cos(roll * kAng2Rad), sr = std::sin(roll * kAng2Rad);
+    Mat4 Rz = Mat4::identity(), Rx = Mat4::identity(), Ry = Mat4::identity(), T = Mat4::identity();
+    Rz(0, 0) = cy; Rz(0, 1) = -sy; Rz(1, 0) = sy; Rz(1, 1) = cy;
+    Rx(1, 1) = cp; Rx(1, 2) = -sp; Rx(2, 1) = sp; Rx(2, 2) = cp;
+    Ry(0, 0) = cr; Ry(0, 2) = sr; Ry(2, 0) = -sr; Ry(2, 2) = cr;
+    T(0, 3) = x; T(1, 3) = y; T(2, 3) = z;
+    return mul(mul(mul(T, Rz), Rx), Ry);
+}
+// getRPYTfromTransformFrom (slam_utils.cpp:98-110): Eigen's MatrixBase::eulerAngles(2, 0, 1) of the rotation block (Geometry/EulerAngles.h,
+// the Tait-Bryan branch with a0 = 2, a1 = 0, a2 = 1: even permutation, i = 2, j = 0, k = 1, result negated), in degrees
+void rpy_from_transform(const Mat4& T, double& yaw, double& pitch, double& roll) {
+    const int i = 2, j = 0, k = 1;
+    double r0 = std::atan2(T(j, k), T(k, k));
+    const double c2 = std::sqrt(T(i, i) * T(i, i) + T(i, j) * T(i, j));
+    double r1;
+    if (r0 > 0.0) {  // (!odd && res[0] > 0)
+        r0 -= M_PI;
+        r1 = std::atan2(-T(i, k), -c2);
+    } else {
+        r1 = std::atan2(-T(i, k), c2);
+    }
+    const double s1 = std::sin(r0), c1 = std::cos(r0);
+    const double r2 = std::atan2(s1 * T(k, i) - c1 * T(j, i), c1 * T(j, j) - s1 * T(k, j));
+    yaw = -r0 / kAng2Rad;
+    pitch = -r1 / kAng2Rad;
+    roll = -r2 / kAng2Rad;
+}
+
+struct Slam {
+    std::string mode, method;
+    std::vector<std::string> sensors;
+    std::string lidar;
+    bool use_imu = false, use_gps = false;
+    Mat4 T_static = Mat4::identity();      // lidar -> INS   (set_ins_external_param)
+    Mat4 T_imu = Mat4::identity();         // IMU extrinsic  (set_imu_external_param)
+    Mat4 T_imu_ins = Mat4::identity(), T_imu_ins_inv = Mat4::identity();
+    double scan_period = 0.1;
+    lio_engine* engine = nullptr;
+    // HDL_FastLIO::runLio + mOdomQueue
+    std::thread lio_thread;
+    std::atomic<bool> running{false};
+    std::mutex mtx;
+    std::condition_variable cv;
+    std::deque<std::pair<Mat4, Mat4>> odom_queue;
+    // settings the off-path calls store and return
+    double origin[6] = {0, 0, 0, 0, 0, 0};
+    bool origin_set = false;
+    bool ground_constraint = false, loop_closure = false, gravity_constraint = false, colouration = false;
+    py::dict ins_config;
+    double init_pose[6] = {0, 0, 0, 0, 0, 0};
+    std::string dest;
+    int dest_port = 0;
+    double export_z[2] = {0, 0};
+    std::string export_color;
+    uint64_t max_points = 8000000, max_voxels = 1u << 21;
+};
+std::unique_ptr<Slam> g;  // one global instance per process, like the reference's slam_ptr (slam_wrapper.cpp:4)
+
+void require(bool ok, const char* what) {
+    if (!ok) throw std::runtime_error(std::string("slam_wrapper: ") + what + (lio_last_error()[0] ? std::string(": ") + lio_last_error() : std::string()));
+}
+
+// HDL_FastLIO::runLio (fastlio.cpp:262-276)
+void run_lio(Slam* s) {
+    while (s->running.load()) {
+        const int rc = lio_fastlio_main(s->engine);
+        if (rc != LIO_MAIN_IDLE && rc >= 0) {
+            double os[16], oe[16];
+            lio_fastlio_odometry(s->engine, os, oe);
+            Mat4 a, b;
+            std::memcpy(a.m, os, sizeof(os));
+            std::memcpy(b.m, oe, sizeof(oe));
+            a = mul(mul(s->T_imu_ins_inv, a), s->T_imu_ins);
+            b = mul(mul(s->T_imu_ins_inv, b), s->T_imu_ins);
+            {
+                std::lock_guard<std::mutex> lk(s->mtx);
+                s->odom_queue.emplace_back(a, b);
+            }
+            s->cv.notify_all();
+            continue;  // more may be queued
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(rc == LIO_MAIN_IDLE ? 200 : 2000));
+    }
+}
+
+py::array_t<float> mat4_to_numpy_f32(const Mat4& T) {  // eigen_to_numpy(Matrix4d) -> float32 4 x 4 (py_utils.cpp:4-11)
+    py::array_t<float> a({4, 4});
+    auto r = a.mutable_unchecked<2>();
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) r(i, j) = (float)T(i, j);
+    return a;
+}
+
+}  // namespace
+
+// ---- hot path ---------------------------------------------------------------------------------------------------------------
+py::list init_slam(const std::string mode, const std::string map_path, const std::string method, py::list& sensor_input, double resolution,
+                   float dist_threshold, float degree_threshold, float frame_range) {
+    (void)map_path; (void)resolution; (void)dist_threshold; (void)degree_threshold; (void)frame_range;
+    if (method != "FastLIO") throw std::runtime_error("slam_wrapper: only the FastLIO odometry path is built on the device (method=" + method + ")");
+    g.reset(new Slam());
+    g->mode = mode;
+    g->method = method;
+    std::vector<std::string> in;
+    for (auto h : sensor_input) in.push_back(py::cast<std::string>(h));
+    // HDL_FastLIO::setSensors (fastlio.cpp:119-151): RTK and IMU first; without an IMU nothing else; the first "n-" name is the lidar
+    bool imu = false;
+    for (auto& s : in) {
+        if (s == "RTK") { g->sensors.push_back(s); g->use_gps = true; }
+        else if (s == "IMU") { g->sensors.push_back(s); imu = true; }
+    }
+    g->use_imu = imu;
+    if (imu)
+        for (auto& s : in) {
+            if (s == "RTK" || s == "IMU") continue;
+            g->sensors.push_back(s);
+            if (!(s.length() < 2 || s[1] != '-') && g->lidar.empty()) g->lidar = s;
+        }
+    return py::cast(g->sensors);
+}
+
+void set_ins_external_param(double x, double y, double z, double yaw, double pitch, double roll) {
+    require((bool)g, "init_slam first");
+    g->T_static = transform_from_rpyt(x, y, z, yaw, pitch, roll);
+}
+void set_imu_external_param(double x, double y, double z, double yaw, double pitch, double roll) {
+    require((bool)g, "init_slam first");
+    g->T_imu = transform_from_rpyt(x, y, z, yaw, pitch, roll);
+}
+
+bool setup_slam() {
+    require((bool)g, "init_slam first");
+    if (lio_device_count() < 1) return false;  // the reference logs and returns false from setup() when the back end cannot start
+    // HDL_FastLIO::init (fastlio.cpp:153-171): T_imu_ins = T_imu * T_static^-1 is the (INS-frame cloud) -> IMU extrinsic
+    g->T_imu_ins = mul(g->T_imu, rigid_inverse(g->T_static));
+    g->T_imu_ins_inv = rigid_inverse(g->T_imu_ins);
+    g->engine = lio_engine_create(0, 0.5f, 75, g->max_points, g->max_voxels, 1u << 18, 100000);
+    if (!g->engine) return false;
+    const double extT[3] = {g->T_imu_ins(0, 3), g->T_imu_ins(1, 3), g->T_imu_ins(2, 3)};
+    double extR[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) extR[i * 3 + j] = g->T_imu_ins(i, j);
+    if (lio_fastlio_init(g->engine, extT, extR, 1, -1, g->scan_period, 1) != LIO_OK) return false;
+    g->running.store(true);
+    g->lio_thread = std::thread(run_lio, g.get());
+    return true;
+}
+
+void deinit_slam() {
+    if (!g) return;
+    if (g->running.exchange(false) && g->lio_thread.joinable()) g->lio_thread.join();
+    if (g->engine) lio_engine_destroy(g->engine);
+    g.reset(nullptr);
+}
+
+py::dict process(py::dict& points, py::dict& points_attr, py::dict& image_dict, py::dict& image_stream_dict, py::dict& image_param,
+                 py::dict& rtk_dict, py::array_t<double>& imu_list, uint64_t timestamp) {
+    (void)image_dict; (void)image_stream_dict; (void)image_param;
+    require(g && g->engine, "init_slam / setup_slam first");
+    Slam* s = g.get();
+    // pydict_to_rtk: only the fields SLAM::run copies into the pose in mapping mode (slam.cpp:344-348)
+    double lat = 0, lon = 0, alt = 0;
+    int status = 0;
+    if (rtk_dict.contains("latitude")) lat = py::cast<double>(rtk_dict["latitude"]);
+    if (rtk_dict.contains("longitude")) lon = py::cast<double>(rtk_dict["longitude"]);
+    if (rtk_dict.contains("altitude")) alt = py::cast<double>(rtk_dict["altitude"]);
+    if (rtk_dict.contains("Status")) status = py::cast<int>(rtk_dict["Status"]);
+    // numpy_to_imu + HDL_FastLIO::feedImuData
+    if (s->use_imu && imu_list.ndim() == 2 && imu_list.shape(1) >= 7) {
+        auto ref = imu_list.unchecked<2>();
+        for (py::ssize_t i = 0; i < ref.shape(0); i++) {
+            const double gyr[3] = {ref(i, 1) / 180.0 * M_PI, ref(i, 2) / 180.0 * M_PI, ref(i, 3) / 180.0 * M_PI};
+            const double acc[3] = {ref(i, 4) * 9.81, ref(i, 5) * 9.81, ref(i, 6) * 9.81};
+            lio_fastlio_imu_enqueue(s->engine, ref(i, 0) / 1000000.0, gyr, acc);
+        }
+    }
+    // pydict_to_cloud + feedPointData: the lidar's cloud (fastlio.cpp:204-210 takes points[mLidarName])
+    std::string name = s->lidar;
+    if (name.empty() || !points.contains(name.c_str())) {
+        require(py::len(points) > 0, "process: no point cloud");
+        name = py::cast<std::string>((*points.begin()).first);
+    }
+    py::array_t<float, py::array::c_style | py::array::forcecast> cloud = py::cast<py::array>(points[name.c_str()]);
+    py::dict attr = py::cast<py::dict>(points_attr[name.c_str()]);
+    py::array_t<float, py::array::c_style | py::array::forcecast> pattr = py::cast<py::array>(attr["points_attr"]);
+    const uint64_t header_stamp = py::cast<uint64_t>(attr["timestamp"]);
+    require(cloud.ndim() == 2 && cloud.shape(1) >= 4 && pattr.ndim() == 2 && pattr.shape(1) >= 1 && pattr.shape(0) == cloud.shape(0),
+            "process: points must be N x 4 float32 with an N x 2 attribute array");
+    const uint32_t n = (uint32_t)cloud.shape(0);
+    const float* src = cloud.data();
+    const float* asrc = pattr.data();
+    const py::ssize_t cs = cloud.shape(1), as = pattr.shape(1);
+    Mat4 out_pose = Mat4::identity();
+    bool got = false;
+    {
+        py::gil_scoped_release release;
+        float* dst = nullptr;
+        uint32_t* dstamp = nullptr;
+        require(lio_fastlio_pcl_stage(s->engine, n, &dst, &dstamp) == LIO_OK, "process: staging failed");
+        // pcl::transformPointCloud(in, out, Matrix4d): per point in double, terms left to right, cast to float (PCL 1.9.1 transforms.hpp)
+        const Mat4& M = s->T_static;
+        for (uint32_t i = 0; i < n; i++) {
+            const double x = src[i * cs], y = src[i * cs + 1], z = src[i * cs + 2];
+            dst[4 * i + 0] = (float)(M(0, 0) * x + M(0, 1) * y + M(0, 2) * z + M(0, 3));
+            dst[4 * i + 1] = (float)(M(1, 0) * x + M(1, 1) * y + M(1, 2) * z + M(1, 3));
+            dst[4 * i + 2] = (float)(M(2, 0) * x + M(2, 1) * y + M(2, 2) * z + M(2, 3));
+            dst[4 * i + 3] = src[i * cs + 3];
+            dstamp[i] = (uint32_t)asrc[i * as];  // pointcloud_attr[i].stamp = ref_attr(i, 0): float -> uint32_t
+        }
+        require(lio_fastlio_pcl_commit(s->engine, n, (double)header_stamp / 1000000.0) == LIO_OK, "process: enqueue failed");
+        // HDL_FastLIO::getPose: wait for the LIO thread's odometry (10 s), then get_odom2map() (identity without a graph back end) * odom.first
+        std::unique_lock<std::mutex> lk(s->mtx);
+        got = s->cv.wait_for(lk, std::chrono::seconds(10), [&] { return !s->odom_queue.empty(); });
+        if (got) {
+            out_pose = s->odom_queue.front().first;
+            s->odom_queue.pop_front();
+        }
+    }
+    // SLAM::run, mapping branch (slam.cpp:344-364)
+    double heading, pitch, roll;
+    rpy_from_transform(out_pose, heading, pitch, roll);
+    if (std::fabs(roll) >= 90.0 || std::fabs(pitch) >= 90.0) {
+        const Mat4 o2 = transform_from_rpyt(out_pose(0, 3), out_pose(1, 3), out_pose(2, 3), -heading, pitch, roll);
+        rpy_from_transform(o2, heading, pitch, roll);
+        out_pose = o2;
+    } else {
+        heading = -heading;
+    }
+    if (heading < 0) heading += 360;
+    py::dict pose;
+    pose["latitude"] = lat;
+    pose["longitude"] = lon;
+    pose["altitude"] = alt;
+    pose["heading"] = heading;
+    pose["pitch"] = pitch;
+    pose["roll"] = roll;
+    pose["Ve"] = 0;
+    pose["Vn"] = 0;
+    pose["Vu"] = 0;
+    pose["Status"] = status;
+    pose["state"] = "Mapping";
+    pose["timestamp"] = header_stamp;
+    pose["odom_matrix"] = mat4_to_numpy_f32(out_pose);
+    py::dict data;
+    data["frame_start_timestamp"] = timestamp;
+    data["pose"] = pose;
+    data["slam_valid"] = true;
+    return data;
+}
+
+// ---- off the hot path: type-correct minimal implementations -------------------------------------------
+void set_camera_param(py::list& cameras) { (void)cameras; }
+void set_ins_config(py::dict& dict) { if (g) g->ins_config = dict; }
+void set_init_pose(double x, double y, double z, double yaw, double pitch, double roll) {
+    if (g) { const double v[6] = {x, y, z, yaw, pitch, roll}; std::memcpy(g->init_pose, v, sizeof(v)); }
+}
+py::list get_estimate_pose(double x0, double y0, double x1, double y1) {
+    (void)x0; (void)y0; (void)x1; (void)y1;
+    return py::cast(std::vector<double>{0, 0, 0, 0, 0, 0, 0});  // x, y, z, roll, pitch, -yaw, result (0 = no estimate)
+}
+void set_destination(bool enable, std::string dest, int port) { (void)enable; if (g) { g->dest = dest; g->dest_port = port; } }
+py::dict update_odom() {
+    py::dict d;
+    d["odoms"] = py::dict();
+    d["keyframes"] = py::list();
+    return d;
+}
+py::dict get_graph_status() {
+    py::dict d;
+    d["loop_detected"] = false;
+    return d;
+}
+py::array_t<double> get_map_origin() {
+    py::array_t<double> a({1, 7});
+    auto r = a.mutable_unchecked<2>();
+    for (int i = 0; i < 6; i++) r(0, i) = g ? g->origin[i] : 0.0;
+    r(0, 6) = 0;
+    return a;
+}
+void set_map_origin(double lat, double lon, double alt, double heading, double pitch, double roll) {
+    if (g && !g->origin_set) {  // SLAM::setOrigin: first one wins
+        const double v[6] = {lat, lon, alt, heading, pitch, roll};
+        std::memcpy(g->origin, v, sizeof(v));
+        g->origin_set = true;
+    }
+}
+py::dict merge_map(const std::string& directory) { (void)directory; return py::dict(); }
+py::dict get_graph_map() { return py::dict(); }
+py::array_t<float> get_color_map() { return py::array_t<float>(std::vector<py::ssize_t>{0, 6}); }
+py::dict get_graph_edges() { return py::dict(); }
+py::dict get_graph_meta() { return py::dict(); }
+// pointcloud_align (graph_utils.cpp:20-46, PCL GICP): the guess, with the reference's 50 m sanity reset of its translation
+py::array_t<float> pointcloud_align(py::array_t<float>& source_point, py::array_t<float>& target_point, py::array_t<float>& guess) {
+    (void)source_point; (void)target_point;
+    py::array_t<float> out({4, 4});
+    auto o = out.mutable_unchecked<2>();
+    auto gi = guess.unchecked<2>();
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) o(i, j) = gi(i, j);
+    const double d = std::sqrt((double)o(0, 3) * o(0, 3) + (double)o(1, 3) * o(1, 3) + (double)o(2, 3) * o(2, 3));
+    if (d >= 50.0) { o(0, 3) = 0; o(1, 3) = 0; o(2, 3) = 0; }
+    return out;
+}
+void set_mapping_ground_constraint(bool enable) { if (g) g->ground_constraint = enable; }
+bool get_mapping_ground_constraint() { return g ? g->ground_constraint : false; }
+void set_mapping_constraint(bool loop_closure, bool gravity_constraint) { if (g) { g->loop_closure = loop_closure; g->gravity_constraint = gravity_constraint; } }
+void set_map_colouration(bool enable) { if (g) g->colouration = enable; }
+void del_graph_vertex(int id) { (void)id; }
+void add_graph_edge(py::array_t<float>& prev, int prev_id, py::array_t<float>& next, int next_id, py::array_t<float>& relative) {
+    (void)prev; (void)prev_id; (void)next; (void)next_id; (void)relative;
+}
+void del_graph_edge(int id) { (void)id; }
+void set_graph_vertex_fix(int id, bool fix) { (void)id; (void)fix; }
+py::dict run_graph_optimization() { return py::dict(); }
+py::dict run_robust_graph_optimization(std::string mode) { (void)mode; return py::dict(); }
+void dump_keyframe(const std::string& directory, uint64_t stamp, int id, py::array_t<float>& points_input, py::array_t<float>& pose_input) {
+    (void)directory; (void)stamp; (void)id; (void)points_input; (void)pose_input;
+}
+void dump_odometry(const std::string& directory) { (void)directory; }
+void set_export_map_config(double z_min, double z_max, std::string color) { if (g) { g->export_z[0] = z_min; g->export_z[1] = z_max; g->export_color = color; } }
+void export_points(py::array_t<float>& points_input, py::array_t<float>& odom_input) { (void)points_input; (void)odom_input; }
+void dump_map_points(std::string file) { (void)file; }
+py::list dump_graph(const std::string& directory) { (void)directory; return py::list(); }
+py::list align_pose(double stamp1, double stamp2, py::array_t<double>& estimate1_py, py::array_t<double>& estimate2_py, py::array_t<double>& poses_stamp,
+                    py::list& poses_py) {
+    (void)stamp1; (void)stamp2; (void)estimate1_py; (void)estimate2_py; (void)poses_stamp;
+    return poses_py;
+}
+void save_undistortion_cloud(std::string file, py::array_t<float>& points, py::dict& points_attr, py::array_t<double>& poses) {
+    (void)file; (void)points; (void)points_attr; (void)poses;
+}
+void accumulate_cloud(py::array_t<float>& points, py::dict& points_attr, py::array_t<double>& poses, std::string odometry_type, bool extract_ground) {
+    (void)points; (void)points_attr; (void)poses; (void)odometry_type; (void)extract_ground;
+}
+void save_accumulate_cloud(std::string file, double resolution) { (void)file; (void)resolution; }
+void texture_mesh(std::string mesh_path, std::string cloud_path, std::string output_path) { (void)mesh_path; (void)cloud_path; (void)output_path; }
+void set_colouration_config(py::list& cameras) { (void)cameras; }
+void set_map_odometrys(py::array_t<double>& poses) { (void)poses; }
+void colouration_frame(std::string lidar_name, py::dict& points, py::dict& points_attr, py::dict& image_dict, py::dict& image_stream_dict, py::dict& image_param) {
+    (void)lidar_name; (void)points; (void)points_attr; (void)image_dict; (void)image_stream_dict; (void)image_param;
+}
+void save_render_cloud(std::string file) { (void)file; }
+
+// test visibility (not in the reference's module): the engine behind the module, so that a test can hold the C++ path against the C ABI
+uintptr_t _engine_handle() { return g ? reinterpret_cast<uintptr_t>(g->engine) : 0; }
+void _set_capacity(uint64_t max_points, uint64_t max_voxels) { if (g) { g->max_points = max_points; g->max_voxels = max_voxels; } }
+
+PYBIND11_MODULE(slam_wrapper, m) {
+    m.doc() = "mapping python interface (MI355X-native LIO core behind the reference's slam_wrapper surface)";
+    m.def("init_slam", &init_slam, "init slam", py::arg("mode"), py::arg("map_path"), py::arg("method"), py::arg("sensor_input"), py::arg("resolution"),
+          py::arg("dist_threshold"), py::arg("degree_threshold"), py::arg("frame_range"));
+    m.def("setup_slam", &setup_slam, py::call_guard<py::gil_scoped_release>());
+    m.def("deinit_slam", &deinit_slam, "deinit slam");
+    m.def("set_camera_param", &set_camera_param, "set camera parameters", py::arg("cameras"));
+    m.def("set_ins_external_param", &set_ins_external_param, "set ins external param", py::arg("x"), py::arg("y"), py::arg("z"), py::arg("yaw"), py::arg("pitch"),
+          py::arg("roll"));
+    m.def("set_imu_external_param", &set_imu_external_param, "set imu external param", py::arg("x"), py::arg("y"), py::arg("z"), py::arg("yaw"), py::arg("pitch"),
+          py::arg("roll"));
+    m.def("set_ins_config", &set_ins_config, "set ins config", py::arg("dict"));
+    m.def("set_init_pose", &set_init_pose, "set init pose", py::arg("x"), py::arg("y"), py::arg("z"), py::arg("yaw"), py::arg("pitch"), py::arg("roll"));
+    m.def("get_estimate_pose", &get_estimate_pose, "get estimate pose", py::arg("x0"), py::arg("y0"), py::arg("x1"), py::arg("y1"));
+    m.def("set_destination", &set_destination, "set destination", py::arg("enable"), py::arg("dest"), py::arg("port"));
+    m.def("process", &process, "process", py::arg("points"), py::arg("points_attr"), py::arg("image_dict"), py::arg("image_stream_dict"), py::arg("image_param"),
+          py::arg("rtk_dict"), py::arg("imu_list"), py::arg("timestamp"));
+    m.def("update_odom", &update_odom, "update odom");
+    m.def("get_graph_status", &get_graph_status, "get graph status");
+    m.def("get_map_origin", &get_map_origin, "get map origin");
+    m.def("set_map_origin", &set_map_origin, "set map origin", py::arg("lat"), py::arg("lon"), py::arg("alt"), py::arg("heading"), py::arg("pitch"), py::arg("roll"));
+    m.def("get_color_map", &get_color_map, "get color map");
+    m.def("merge_map", &merge_map, "merge map", py::arg("directory"));
+    m.def("get_graph_map", &get_graph_map, "get graph map");
+    m.def("get_graph_edges", &get_graph_edges, "get graph edges");
+    m.def("pointcloud_align", &pointcloud_align, "pointcloud align", py::arg("source_point"), py::arg("target_point"), py::arg("guess"));
+    m.def("set_mapping_ground_constraint", &set_mapping_ground_constraint, "set mapping ground constraint", py::arg("enable"));
+    m.def("get_mapping_ground_constraint", &get_mapping_ground_constraint, "get mapping ground constraint");
+    m.def("set_mapping_constraint", &set_mapping_constraint, "set mapping constraint", py::arg("loop_closure"), py::arg("gravity_constraint"));
+    m.def("set_map_colouration", &set_map_colouration, "set map colouration", py::arg("enable"));
+    m.def("get_graph_meta", &get_graph_meta, "get graph meta");
+    m.def("del_graph_vertex", &del_graph_vertex, "del graph vertex", py::arg("id"));
+    m.def("add_graph_edge", &add_graph_edge, "add graph edge", py::arg("prev"), py::arg("prev_id"), py::arg("next"), py::arg("next_id"), py::arg("relative"));
+    m.def("del_graph_edge", &del_graph_edge, "del graph edge", py::arg("id"));
+    m.def("set_graph_vertex_fix", &set_graph_vertex_fix, "set graph vertex fix", py::arg("id"), py::arg("fix"));
+    m.def("run_graph_optimization", &run_graph_optimization, "run graph optimization");
+    m.def("run_robust_graph_optimization", &run_robust_graph_optimization, "run robust graph optimization", py::arg("mode"));
+    m.def("dump_keyframe", &dump_keyframe, "dump keyframe", py::arg("directory"), py::arg("stamp"), py::arg("id"), py::arg("points_input"), py::arg("pose_input"));
+    m.def("dump_odometry", &dump_odometry, "dump odometry", py::arg("directory"));
+    m.def("set_export_map_config", &set_export_map_config, "set export map config", py::arg("z_min"), py::arg("z_max"), py::arg("color"));
+    m.def("export_points", &export_points, "export points", py::arg("points_input"), py::arg("odom_input"));
+    m.def("dump_map_points", &dump_map_points, "dump map points", py::arg("file"));
+    m.def("dump_graph", &dump_graph, "dump graph", py::arg("directory"));
+    m.def("align_pose", &align_pose, "align pose", py::arg("stamp1"), py::arg("stamp2"), py::arg("estimate1_py"), py::arg("estimate2_py"), py::arg("poses_stamp"),
+          py::arg("poses_py"));
+    m.def("save_undistortion_cloud", &save_undistortion_cloud, "save undistortion cloud", py::arg("file"), py::arg("points"), py::arg("points_attr"), py::arg("poses"));
+    m.def("accumulate_cloud", &accumulate_cloud, "accumulate cloud", py::arg("points"), py::arg("points_attr"), py::arg("poses"), py::arg("odometry_type"),
+          py::arg("extract_ground"));
+    m.def("save_accumulate_cloud", &save_accumulate_cloud, "save accumulate cloud", py::arg("file"), py::arg("resolution"));
+    m.def("texture_mesh", &texture_mesh, "texture mesh", py::arg("mesh_path"), py::arg("cloud_path"), py::arg("output_path"));
+    m.def("set_colouration_config", &set_colouration_config, "set colouration config", py::arg("cameras"));
+    m.def("set_map_odometrys", &set_map_odometrys, "set map odometrys", py::arg("poses"));
+    m.def("colouration_frame", &colouration_frame, "colouration frame", py::arg("lidar_name"), py::arg("points"), py::arg("points_attr"), py::arg("image_dict"),
+          py::arg("image_stream_dict"), py::arg("image_param"));
+    m.def("save_render_cloud", &save_render_cloud, "save render cloud", py::arg("file"));
+    m.def("_engine_handle", &_engine_handle);
+    m.def("_set_capacity", &_set_capacity, py::arg("max_points"), py::arg("max_voxels"));
+}

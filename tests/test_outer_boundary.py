@@ -1,0 +1,246 @@
+"""The reference's OUTER boundary: the compiled pybind11 module `slam_wrapper` (lidar-slam-detection_amd/csrc/slam_wrapper.cpp) that
+slam/slam.py and slam/map_manager.py import.
+  CPU (needs /root/reference): every function and argument name of the reference's PYBIND11_MODULE block exists with the same names in the
+      same order; the reference's slam/slam.py, imported BYTE FOR BYTE (three stand-in modules for things this container lacks, SURVEY.md
+      Appendix B), constructs SLAM and runs start() / stop() through the compiled module -- without a GPU setup_slam() returns False, as the
+      reference's does when its back end cannot start;
+  GPU: >= 13 scans through process() with the reference's units and dictionaries; the odometry follows the analytic trajectory and equals the
+      ctypes path over the same C ABI."""
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lidar-slam-detection_amd", "python")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+
+def _module():
+    import slam_wrapper  # the compiled module (lidar-slam-detection_amd/python/slam_wrapper.*.so)
+
+    assert slam_wrapper.__file__.endswith(".so"), slam_wrapper.__file__
+    return slam_wrapper
+
+
+def test_module_loads_and_is_compiled():
+    m = _module()
+    assert m.__doc__ and "mapping python interface" in m.__doc__
+
+
+@pytest.mark.skipif(not os.path.exists(REF + "/slam/src/slam_wrapper.cpp"), reason="needs /root/reference")
+def test_surface_matches_the_reference_module():
+    m = _module()
+    src = open(REF + "/slam/src/slam_wrapper.cpp").read()
+    block = src[src.index("PYBIND11_MODULE(slam_wrapper, m)"):]
+    defs = re.findall(r'm\.def\("(\w+)",\s*&\w+(.*?)\);', block, re.S)
+    assert len(defs) >= 45
+    for name, rest in defs:
+        assert hasattr(m, name), name
+        args = re.findall(r'py::arg\("(\w+)"\)', rest)
+        doc = getattr(m, name).__doc__
+        sig = doc.split("\n")[0]
+        got = re.findall(r"(\w+): ", sig[sig.index("(") + 1:sig.rindex(")")])
+        assert got == args, (name, got, args)
+
+
+def _stand_ins():
+    """cpp_utils_ext (only set_thread_priority is used), shapely.geometry (Point.within(Polygon)), proto.internal_pb2"""
+    m = types.ModuleType("cpp_utils_ext")
+    m.set_thread_priority = lambda name, prio: None
+    sys.modules["cpp_utils_ext"] = m
+    sh, geo = types.ModuleType("shapely"), types.ModuleType("shapely.geometry")
+
+    class Point:
+        def __init__(self, *xy):
+            self.xy = xy
+
+        def within(self, poly):
+            return False
+
+    class Polygon:
+        def __init__(self, pts):
+            self.pts = pts
+
+    geo.Point, geo.Polygon = Point, Polygon
+    sh.geometry = geo
+    sys.modules["shapely"], sys.modules["shapely.geometry"] = sh, geo
+    pr, pb = types.ModuleType("proto"), types.ModuleType("proto.internal_pb2")
+    pr.internal_pb2 = pb
+    sys.modules["proto"], sys.modules["proto.internal_pb2"] = pr, pb
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _cfg(d):
+    return _Cfg({k: _cfg(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+@pytest.mark.skipif(not os.path.exists(REF + "/slam/slam.py"), reason="needs /root/reference")
+def test_reference_slam_py_runs_unchanged_on_the_compiled_module():
+    _module()
+    _stand_ins()
+    if REF not in sys.path:
+        sys.path.insert(1, REF)
+    import importlib
+
+    ref_slam = importlib.import_module("slam.slam")  # /root/reference/slam/slam.py, byte for byte
+    assert ref_slam.__file__ == REF + "/slam/slam.py"
+    assert ref_slam.slam.__file__.endswith(".so") and "lidar-slam-detection_amd" in ref_slam.slam.__file__   # its `import slam_wrapper as slam`
+
+    class Log:
+        def info(self, *a):
+            pass
+
+        warn = error = debug = info
+
+    config = _cfg(dict(
+        input=dict(mode="offline"), camera=[],
+        ins=dict(extrinsic_parameters=[0.3, 0.1, -0.2, 2.0, 1.0, -4.0], imu_extrinsic_parameters=[0.05, -0.02, 0.1, -1.0, 0.5, 3.0], ins_type="6D"),
+        output=dict(localization=dict(UDP=dict(use=False, destination="127.0.0.1", port=9000))),
+        slam=dict(origin=dict(use=False, latitude=31.0, longitude=121.0, altitude=4.0),
+                  mapping=dict(key_frames_range=50.0, ground_constraint=True, loop_closure=True, gravity_constraint=False),
+                  localization=dict(colouration=False))))
+    s = ref_slam.SLAM("mapping", "FastLIO", "/tmp/lsd_map", ["0-Ouster", "IMU"], 0.2, [1.0, 10.0], config, Log())
+    s.start()  # slam.py:50-85: init_slam, set_camera_param, set_*_external_param, set_ins_config, set_destination, setup_slam, set_map_origin, ...
+    assert s.isInited()
+    import slam_wrapper as sw
+
+    assert sw.get_mapping_ground_constraint() is True
+    assert np.allclose(sw.get_map_origin(), [[31.0, 121.0, 4.0, 0, 0, 0, 0]])
+    # a few of the calls slam.py / map_manager.py make off the hot path: type-correct values, nothing raises
+    assert sw.update_odom() == {"odoms": {}, "keyframes": []} and sw.get_graph_status() == {"loop_detected": False}
+    assert sw.get_graph_map() == {} and sw.get_graph_edges() == {} and sw.run_robust_graph_optimization("mapping") == {}
+    G = np.eye(4, dtype=np.float32)
+    G[0, 3] = 60.0
+    A = sw.pointcloud_align(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32), G)
+    assert A.shape == (4, 4) and A[0, 3] == 0.0  # graph_utils.cpp:26-30: a guess farther than 50 m loses its translation
+    s.stop()
+
+
+def _drive(process, n=16, imu_ext=(0.05, -0.02, 0.10, 3.0, 0.5, -1.0), ins_ext=(0.30, 0.10, -0.20, -4.0, 1.0, 2.0)):
+    from lsd_amd import slam_wrapper as mimic, synth
+    from lsd_amd import synth as _s  # noqa: F401
+
+    scene = synth.Scene(half=100.0, n_boxes=40, seed=1)
+    tr = synth.Trajectory()
+    T_li = mimic.get_transform_from_rpyt(*imu_ext)
+    imu = synth.imu_stream(tr, 0.0, 0.1 * n + 0.3, rate=200.0)
+    ii, outs = 0, []
+    for k in range(n):
+        tb = k * 0.1
+        pts, st = synth.make_sweep(scene, tr, tb, ext_R=T_li[:3, :3], ext_t=T_li[:3, 3], seed=k, n_az=900, fov_deg=(-24.8, 2.0))
+        rows = []
+        while ii < len(imu) and imu[ii][0] <= tb + 0.12:
+            t, g, a = imu[ii]
+            rows.append([t * 1e6, *(g * 180.0 / np.pi), *(a / 9.81)])
+            ii += 1
+        attr = dict(timestamp=int(round(tb * 1e6)), points_attr=np.stack([st.astype(np.float32), np.zeros(len(st), np.float32)], 1))
+        out = process({"0-lidar": pts}, {"0-lidar": attr}, {}, {}, {}, {}, np.array(rows, np.float64).reshape(-1, 7), int(round(tb * 1e6)))
+        outs.append((tb, out))
+    return tr, outs
+
+
+@pytest.mark.gpu
+def test_process_through_the_compiled_module():
+    from lsd_amd import capi, slam_wrapper as mimic
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device")
+    sw = _module()
+    imu_ext = (0.05, -0.02, 0.10, 3.0, 0.5, -1.0)
+    ins_ext = (0.30, 0.10, -0.20, -4.0, 1.0, 2.0)
+    assert sw.init_slam("mapping", "", "FastLIO", ["0-lidar", "IMU"], 0.5, 1.0, 10.0, 100) == ["IMU", "0-lidar"]
+    sw._set_capacity(4_000_000, 1 << 20)
+    sw.set_ins_external_param(*ins_ext)
+    sw.set_imu_external_param(*imu_ext)
+    assert sw.setup_slam() is True
+    try:
+        tr, outs = _drive(sw.process)
+    finally:
+        sw.deinit_slam()
+    # the same drive through the ctypes path (lsd_amd.slam_wrapper) over the same C ABI
+    assert mimic.init_slam("mapping", "", "FastLIO", ["0-lidar", "IMU"], 0.5, 1.0, 10.0, 100)
+    mimic.set_ins_external_param(*ins_ext)
+    mimic.set_imu_external_param(*imu_ext)
+    assert mimic.setup_slam(max_points=4_000_000, max_voxels=1 << 20)
+    try:
+        _, outs2 = _drive(mimic.process)
+    finally:
+        mimic.deinit_slam()
+    T_li, T_ln = mimic.get_transform_from_rpyt(*imu_ext), mimic.get_transform_from_rpyt(*ins_ext)
+    T_ni = T_li @ np.linalg.inv(T_ln)
+    W0 = np.eye(4)
+    W0[:3, :3], W0[:3, 3] = tr.R(0.0), tr.pos(0.0)
+    worst = 0.0
+    for (tb, a), (_, b) in zip(outs, outs2):
+        assert a["slam_valid"] is True and a["frame_start_timestamp"] == int(round(tb * 1e6))
+        p = a["pose"]
+        assert set(p) == {"latitude", "longitude", "altitude", "heading", "pitch", "roll", "Ve", "Vn", "Vu", "Status", "state", "timestamp", "odom_matrix"}
+        M = p["odom_matrix"]
+        assert M.dtype == np.float32 and M.shape == (4, 4) and p["state"] == "Mapping" and 0.0 <= p["heading"] < 360.0
+        # the static transform runs in f64 here (pcl::transformPointCloud with the reference's Matrix4d) and in f32 in the ctypes mimic:
+        # one f32 ulp of the coordinates on the input, centimetres never
+        assert np.abs(M - b["pose"]["odom_matrix"]).max() < 2e-3, tb
+        if tb >= 0.85:
+            Wt = np.eye(4)
+            Wt[:3, :3], Wt[:3, 3] = tr.R(tb), tr.pos(tb)
+            truth = np.linalg.inv(T_ni) @ (np.linalg.inv(W0) @ Wt) @ T_ni
+            dp = float(np.linalg.norm(M[:3, 3] - truth[:3, 3]))
+            worst = max(worst, dp)
+            assert dp < 0.05, (tb, dp)
+    print("compiled slam_wrapper.process: worst position error %.4f m over %d scans" % (worst, len(outs)))
+
+
+@pytest.mark.gpu
+def test_reference_hdl_fastlio_class_linked_against_the_library():
+    """INTEGRATION.md's Option 0, linked and RUN: the reference's own Mapping::HDL_FastLIO (fastlio.cpp compiled whole, its runLio thread, its
+    feedImuData / feedPointData / getPose) over liblio_hip.so through the binding the document shows.  Its poses equal the compiled
+    slam_wrapper's (same engine, same inputs) and follow the trajectory; the per-scan delta odometry and the IMU prediction of getPose run too."""
+    from lsd_amd import capi, slam_wrapper as mimic
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device")
+    import ref_hdl_fastlio
+
+    if not ref_hdl_fastlio.available():
+        pytest.skip("oracle/_ref/libref_hdl_fastlio.so not built (needs /root/reference at build time)")
+    imu_ext = (0.05, -0.02, 0.10, 3.0, 0.5, -1.0)
+    ins_ext = (0.30, 0.10, -0.20, -4.0, 1.0, 2.0)
+    T_li, T_ln = mimic.get_transform_from_rpyt(*imu_ext), mimic.get_transform_from_rpyt(*ins_ext)
+    H = ref_hdl_fastlio.HdlFastLio("0-lidar", T_static=T_ln, T_imu=T_li, scan_period=0.1)
+    poses = []
+
+    def process(points, points_attr, _a, _b, _c, _d, imu_rows, timestamp):
+        for row in imu_rows:  # numpy_to_imu's units
+            H.feed_imu(row[0] / 1e6, row[1:4] / 180.0 * np.pi, row[4:7] * 9.81)
+        attr = points_attr["0-lidar"]
+        T, D, n_imu = H.frame(points["0-lidar"], attr["points_attr"][:, 0].astype(np.uint32), attr["timestamp"])
+        poses.append((T, D, n_imu))
+        return None
+
+    try:
+        tr, _ = _drive(process)
+    finally:
+        H.close()
+    sw = _module()
+    assert sw.init_slam("mapping", "", "FastLIO", ["0-lidar", "IMU"], 0.5, 1.0, 10.0, 100) == ["IMU", "0-lidar"]
+    sw._set_capacity(8_000_000, 400_000)  # the binding's lio_engine_create arguments
+    sw.set_ins_external_param(*ins_ext)
+    sw.set_imu_external_param(*imu_ext)
+    assert sw.setup_slam() is True
+    try:
+        _, outs = _drive(sw.process)
+    finally:
+        sw.deinit_slam()
+    assert len(poses) == len(outs)
+    for k, ((T, D, n_imu), (tb, o)) in enumerate(zip(poses, outs)):
+        assert np.abs(T.astype(np.float32) - o["pose"]["odom_matrix"]).max() < 1e-6, k   # the same engine behind both: same numbers
+        if tb >= 0.85:
+            assert n_imu >= 10 and np.linalg.norm(D[:3, 3]) > 0.05  # getPose's IMU prediction ran; the sensor moved during the scan
