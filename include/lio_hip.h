@@ -310,6 +310,26 @@ int lio_eskf_update_sums_cb(const double s26[26], const double P[529], double R,
  * uses the information form (rows live on different GPUs). */
 typedef void (*lio_reduce_fn)(void* ctx, double* buf, int n);
 int lio_engine_set_reduce_hook(lio_engine*, lio_reduce_fn fn, void* ctx);
+/* The same natively, over RCCL (librccl = the ROCm build of NCCL; xGMI between the GPUs of a node), for hosts that are not Python: one process
+ * per GPU.  lio_comm_unique_id: rank 0 makes the 128-byte id and ships it to the other ranks by whatever the application has (MPI, a socket,
+ * torch.distributed's store); lio_comm_init: ncclCommInitRank on `device` (a world of one needs no id and no RCCL).
+ * lio_allgather_normal_eq: DEVICE buffers in and out -- every rank contributes one 32-double record (21 J^T J upper triangle, 6 J^T r, sum |r|,
+ * N_eff, 3 spare), receives all of them rank-major (world x 32) and, if d_sum32 is given, their sum in fixed rank order (a one-wave kernel:
+ * every rank forms the identical bits).  `stream` (a hipStream_t, NULL = the communicator's own) orders it with the caller's kernels.
+ * lio_engine_set_joint: joint registration of ONE scan against sub-maps spread over engines and GPUs -- `e` drives the filter; after every
+ * linearisation its sums are joined, in this order, by those of the `others` (further sub-maps resident on this GPU, each engine with its own
+ * map) and then by the other ranks' through `comm` (NULL = single process).  Replaces a hook set by lio_engine_set_reduce_hook.
+ * lio_engine_joint_register: uploads the cloud to every local engine, runs the registration; prior in, posterior out. */
+typedef struct lio_comm lio_comm;
+int lio_comm_unique_id(uint8_t id[128]);
+lio_comm* lio_comm_init(int device, int rank, int world, const uint8_t id[128]);
+void lio_comm_destroy(lio_comm*);
+int lio_comm_rank(const lio_comm*);
+int lio_comm_world(const lio_comm*);
+int lio_allgather_normal_eq(lio_comm*, const double* d_local32, double* d_gathered, double* d_sum32, void* stream);
+int lio_comm_stats(lio_comm*, uint64_t* n_collectives, double* total_us);  /* collectives issued by joint registrations and their host-observed time */
+int lio_engine_set_joint(lio_engine* e, lio_engine** others, int n_others, lio_comm* comm);
+int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]);
 /* Throughput mode: register a batch of independent scans with `n_engines` engines running concurrently (one host
  * thread + HIP stream per engine, jobs handed out through an atomic counter).  Every job = set_state(state_in) +
  * set_cov(cov_in) + lio_engine_process_scan_device(d_raw, n_raw, lidar_beg_time); outputs are filled per job.

@@ -71,6 +71,7 @@ struct Frontend {
     int n_poses = 0;
 };
 
+struct JointCtx;
 struct lio_devloop;  // batch.hip: the device-resident filter loop of one engine
 lio_devloop* devloop_create(lio_scan* sc);
 void devloop_destroy(lio_devloop* d);
@@ -103,9 +104,24 @@ struct lio_engine {
     std::vector<double> rows6, hvec;
     lio_reduce_fn reduce = nullptr;  // cross-GPU reduction of the normal equations (joint registration)
     void* reduce_ctx = nullptr;
+    JointCtx* joint = nullptr;       // native joint registration (lio_engine_set_joint) behind `reduce`
 };
 
 int engine_resume_update_impl(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t, bool keep_log);
+struct lio_comm;
+int comm_reduce_host(lio_comm* c, double* buf, int n);  // comm.hip
+
+// Joint registration natively (lio_engine_set_joint): this engine drives the filter; after every linearisation its reduce step adds, in
+// order, what the other LOCAL engines (further sub-maps resident on this GPU) see at the same iterate, then all-gathers and sums across
+// the ranks of the communicator (sub-maps on other GPUs).  Same records and order as the generic hook documents.
+struct JointCtx {
+    lio_engine* self = nullptr;
+    std::vector<lio_engine*> others;
+    lio_comm* comm = nullptr;
+    int knn_seen = 0;
+    double nnT[9] = {0};
+    int rc = LIO_OK;
+};
 
 namespace {
 
@@ -436,6 +452,7 @@ void lio_engine_destroy(lio_engine* e) {
     if (!e) return;
     frontend_destroy(e);
     if (e->dl) { hipStreamSynchronize(e->scan->stream); devloop_destroy(e->dl); }
+    delete e->joint;
     lio_scan_destroy(e->scan);
     if (e->own_map) lio_map_destroy(e->map);
     delete e;
@@ -480,6 +497,84 @@ int lio_engine_set_reduce_hook(lio_engine* e, lio_reduce_fn fn, void* ctx) {
     e->reduce_ctx = ctx;
     // with a hook the degeneracy sums are evaluated here, after the reduction, never inside linearize
     return lio_scan_set_degeneracy_mode(e->scan, fn ? 2 : 0);
+}
+
+static void joint_reduce(void* vctx, double* buf, int n) {
+    JointCtx* j = static_cast<JointCtx*>(vctx);
+    lio_engine* e = j->self;
+    if (j->rc != LIO_OK) return;
+    if (n == 29) {
+        const bool redo = e->tm.n_knn_pass > j->knn_seen;  // (already counts the pass being reduced)
+        j->knn_seen = e->tm.n_knn_pass;
+        double pose[7], ext[7];
+        pose_arrays(e->kf.x, pose, ext);
+        for (lio_engine* o : j->others) {
+            lio_normal_eq ne;
+            const int rc = lio_p2plane_linearize(o->map, o->scan, pose, ext, redo ? 1 : 0, &ne);
+            if (rc != LIO_OK) { j->rc = rc; return; }
+            int t = 0;
+            for (int a = 0; a < 6; a++)
+                for (int c = a; c < 6; c++) buf[t++] += ne.JtJ[a * 6 + c];
+            for (int a = 0; a < 6; a++) buf[21 + a] += ne.Jtr[a];
+            buf[27] += ne.sum_abs_res;
+            buf[28] += (double)ne.n_eff;
+        }
+        if (j->comm) { const int rc = comm_reduce_host(j->comm, buf, 29); if (rc != LIO_OK) { j->rc = rc; return; } }
+        double J[36];
+        int t = 0;
+        for (int a = 0; a < 6; a++)
+            for (int c = a; c < 6; c++) { J[a * 6 + c] = buf[t]; J[c * 6 + a] = buf[t]; t++; }
+        for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 3; c++) j->nnT[a * 3 + c] = J[a * 6 + c];
+    } else {  // the six degeneracy sums against the eigenvectors of the GLOBAL sum n n^T (the same decomposition measure_pass made)
+        double w[3], V[9];
+        eig3_sym(j->nnT, w, V);
+        for (lio_engine* o : j->others) {
+            double cs[6];
+            const int rc = lio_p2plane_degeneracy(o->scan, V, cs, cs + 3);
+            if (rc != LIO_OK) { j->rc = rc; return; }
+            for (int k = 0; k < 6; k++) buf[k] += cs[k];
+        }
+        if (j->comm) { const int rc = comm_reduce_host(j->comm, buf, 6); if (rc != LIO_OK) { j->rc = rc; return; } }
+    }
+}
+
+int lio_engine_set_joint(lio_engine* e, lio_engine** others, int n_others, lio_comm* comm) {
+    if (!e || n_others < 0 || (n_others && !others)) return LIO_E_INVALID;
+    delete e->joint;
+    e->joint = nullptr;
+    if (n_others == 0 && !comm) return lio_engine_set_reduce_hook(e, nullptr, nullptr);
+    JointCtx* j = new JointCtx();
+    j->self = e;
+    j->comm = comm;
+    for (int k = 0; k < n_others; k++) {
+        if (!others[k] || others[k] == e) { delete j; return LIO_E_INVALID; }
+        j->others.push_back(others[k]);
+        lio_scan_set_degeneracy_mode(others[k]->scan, 2);  // their degeneracy sums are evaluated after the global reduction
+    }
+    e->joint = j;
+    return lio_engine_set_reduce_hook(e, joint_reduce, j);
+}
+
+// one joint registration: the same cloud to every local engine (each downsamples it into its own scan buffers), then the driving engine's
+// per-scan body with the joint reduce step.  state26 / cov: prior in, posterior out (identical on every rank of the communicator).
+int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]) {
+    if (!e || !e->joint || !state26 || !cov) return LIO_E_INVALID;
+    JointCtx* j = e->joint;
+    j->knn_seen = 0;
+    j->rc = LIO_OK;
+    for (lio_engine* o : j->others) {
+        int rc = lio_scan_upload(o->scan, raw_body_xyzi, n_raw);
+        if (rc == LIO_OK) rc = lio_scan_voxel_downsample(o->scan, o->leaf_surf, 1, nullptr);
+        if (rc != LIO_OK) return rc;
+    }
+    lio_engine_set_state(e, state26);
+    lio_engine_set_cov(e, cov);
+    const int rc = lio_engine_process_scan(e, raw_body_xyzi, n_raw, lidar_beg_time);
+    if (j->rc != LIO_OK) return j->rc;
+    lio_engine_get_state(e, state26);
+    lio_engine_get_cov(e, cov);
+    return rc;
 }
 
 int lio_engine_set_static_map(lio_engine* e, int on) {

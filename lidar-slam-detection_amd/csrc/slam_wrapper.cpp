@@ -292,9 +292,9 @@ py::dict process(py::dict& points, py::dict& points_attr, py::dict& image_dict, 
     double heading, pitch, roll;
     rpy_from_transform(out_pose, heading, pitch, roll);
     if (std::fabs(roll) >= 90.0 || std::fabs(pitch) >= 90.0) {
+        // (the reference rebuilds a LOCAL copy of the odometry here; pose.T was assigned before and keeps the filter's matrix)
         const Mat4 o2 = transform_from_rpyt(out_pose(0, 3), out_pose(1, 3), out_pose(2, 3), -heading, pitch, roll);
         rpy_from_transform(o2, heading, pitch, roll);
-        out_pose = o2;
     } else {
         heading = -heading;
     }

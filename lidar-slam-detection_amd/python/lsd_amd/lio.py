@@ -386,6 +386,20 @@ class Engine:
         self._hook = capi.REDUCE_FN(_cb)  # keep the trampoline alive
         check(lib().lio_engine_set_reduce_hook(self.h, self._hook, None))
 
+    def set_joint(self, others=(), comm=None):
+        """joint registration natively (lio_engine_set_joint): this engine drives the filter, `others` are engines holding further sub-maps on
+        this GPU, `comm` (lio.Comm) joins the ranks that hold the rest"""
+        self._joint_keep = (list(others), comm)
+        hs = (C.c_void_p * max(len(others), 1))(*[o.h for o in others])
+        check(lib().lio_engine_set_joint(self.h, hs, len(others), comm.h if comm is not None else None), "set_joint")
+
+    def joint_register(self, raw, lidar_beg_time, state, cov):
+        r = f32(raw).reshape(-1, 4)
+        s, P = f64(state).copy(), f64(cov).reshape(-1).copy()
+        rc = check(lib().lio_engine_joint_register(self.h, ptr(r, C.c_float), len(r), float(lidar_beg_time), ptr(s, C.c_double), ptr(P, C.c_double)),
+                   "joint_register")
+        return rc, s, P.reshape(23, 23)
+
     def set_static_map(self, on=True):
         check(lib().lio_engine_set_static_map(self.h, int(on)))
 
@@ -476,6 +490,38 @@ class Ndt:
         it, conv = C.c_int(0), C.c_int(0)
         check(lib().lio_ndt_align(self.h, scan.h, ptr(g, C.c_double), C.byref(prm), ptr(out, C.c_double), C.byref(it), C.byref(conv)), "ndt align")
         return out, bool(conv.value), int(it.value)
+
+
+class Comm:
+    """one rank of an RCCL communicator (lio_comm_*): the all-gather of per-rank normal equations for joint registration across GPUs"""
+
+    def __init__(self, rank=0, world=1, device=0, uid=None):
+        u = (C.c_uint8 * 128)(*uid) if uid is not None else None
+        self.h = lib().lio_comm_init(device, rank, world, u)
+        if not self.h:
+            raise capi.LioError("lio_comm_init failed: " + lib().lio_last_error().decode())
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        u = (C.c_uint8 * 128)()
+        check(lib().lio_comm_unique_id(u), "comm unique id")
+        return bytes(u)
+
+    def allgather(self, d_local, d_gathered, d_sum=None, stream=None):
+        check(lib().lio_allgather_normal_eq(self.h, d_local, d_gathered, d_sum, stream), "allgather")
+
+    def stats(self):
+        n, t = C.c_uint64(), C.c_double()
+        check(lib().lio_comm_stats(self.h, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().lio_comm_destroy(self.h)
+        self.h = None
+
+    __del__ = close
 
 
 class Batch:

@@ -94,6 +94,46 @@ def test_joint_registration_two_ranks_one_gpu():
     assert A.process_scan(raw, 1.0) == 3
     assert st["calls"] == int(r0["calls"])
     assert np.array_equal(A.get_state(), r0["state"]) and np.array_equal(A.get_cov(), r0["cov"])
+    # the same natively (lio_engine_set_joint, no Python in the loop): engine A2 drives, engine B2 is the other local sub-map; and once more
+    # through a communicator of one rank (lio_comm_*: the gather is a device copy + the rank-order sum kernel) -- bit for bit the same
+    for use_comm in (False, True):
+        A2 = lio.Engine(stencil=19, max_points=400_000, max_voxels=200_000, max_raw=1 << 17, max_ds=1 << 16)
+        B2 = lio.Engine(stencil=19, max_points=400_000, max_voxels=200_000, max_raw=1 << 17, max_ds=1 << 16)
+        for e, sub in ((A2, subs[0]), (B2, subs[1])):
+            e.map_add(sub)
+            e.set_static_map(True)
+            e.set_flags(ekf_inited=True, first_scan=False, first_lidar_time=-10.0)
+        comm = lio.Comm(rank=0, world=1) if use_comm else None
+        A2.set_joint([B2], comm)
+        rc, s2, P2 = A2.joint_register(raw, 1.0, state, lio.init_cov())
+        assert rc == 3 and np.array_equal(s2, r0["state"]) and np.array_equal(P2, r0["cov"]), use_comm
+        if comm is not None:
+            n_coll, t_us = comm.stats()
+            assert n_coll == int(r0["calls"]) and t_us > 0
     # and the joint solve registers the scan: neither sub-map alone covers it, together they do
     assert np.linalg.norm(r0["state"][:3] - true_pos) < 0.03
     assert synth.quat_angle(r0["state"][3:7], true_q) < 3e-3
+
+
+@pytest.mark.gpu
+def test_native_allgather_device_buffers():
+    """lio_allgather_normal_eq with device pointers in and out (a world of one: the gather is a copy, the sum kernel runs)"""
+    import ctypes as C
+
+    sys.path.insert(0, HERE)
+    import scenes
+    from lsd_amd import lio
+
+    comm = lio.Comm(rank=0, world=1)
+    local = np.arange(32, dtype=np.float64) * 1.5 - 7.0
+    d_local, d_g, d_s = scenes.to_device(local), scenes.to_device(np.zeros(32)), scenes.to_device(np.zeros(32))
+    comm.allgather(d_local, d_g, d_s)
+    hip_rt = C.CDLL("libamdhip64.so")
+    hip_rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip_rt.hipDeviceSynchronize()
+    out = np.zeros(32)
+    assert hip_rt.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(d_s), 256, 2) == 0
+    assert np.array_equal(out, local)
+    g = np.zeros(32)
+    assert hip_rt.hipMemcpy(g.ctypes.data_as(C.c_void_p), C.c_void_p(d_g), 256, 2) == 0
+    assert np.array_equal(g, local)
