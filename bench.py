@@ -61,9 +61,10 @@ def main():
                     help="batch: B scans per launch, filter loop on the device, one host thread (lio_batch_*); threads: round 1's one engine + thread per scan")
     ap.add_argument("--slots", type=int, default=16, help="--engine batch: scans per launch")
     ap.add_argument("--groups", type=int, default=3, help="--engine batch: rounds in flight (one HIP stream each)")
-    ap.add_argument("--config", choices=["metric", "merge"], default="metric",
+    ap.add_argument("--config", choices=["metric", "merge", "stream"], default="metric",
                     help="metric: BASELINE.json's headline (independent 120k-pt scans vs a 1e7-pt map); merge: BASELINE config 5, multi-map merge -- 8 sub-maps "
                          "spread over the GPUs, every key-frame scan registered JOINTLY against all of them (RCCL all-gather of the per-rank J^T J / J^T r)")
+    ap.add_argument("--lru", type=int, default=100000, help="--config stream: iVox capacity in voxels (the reference's 100000, laserMapping.cpp:1063); 0 = never evict")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="the job list of --steps scans is repeated until the timed region lasts at least this long")
     args = ap.parse_args()
 
@@ -88,6 +89,8 @@ def main():
 
     if args.config == "merge":
         return bench_merge(args, torch, dist, world, rank, local_rank, dev)
+    if args.config == "stream":
+        return bench_stream(args, torch, local_rank)
 
     # ---- synthetic workload (SURVEY.md section 8d, config 2 scaled to the metric's 1e7-point map) -------------
     scene = synth.Scene(half=100.0, n_boxes=40, seed=1)
@@ -422,6 +425,77 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _sweep_job(a):
+    from lsd_amd import synth
+
+    k, seed = a
+    scene = synth.Scene(half=500.0, n_boxes=1500, seed=3, box_size=(4.0, 30.0), keep_clear=8.0)
+    tr = synth.FigureEight()
+    return synth.make_sweep(scene, tr, k * 0.1, seed=seed + k, fov_deg=(-24.8, 2.0), max_range=100.0)
+
+
+def bench_stream(args, torch, local_rank):
+    """BASELINE.json config 3 / SURVEY.md 8d ("NCLT replay", stand-in: NCLT is not available): the streaming FastLIO front half -- IMU
+    propagation, motion compensation, downsample, iterated update, map_incremental -- through lio_fastlio_* over a figure-of-eight drive at
+    5 m/s through a 1 km x 1 km scene, --steps scans at 10 Hz; the map grows by map_incremental, with the reference's LRU capacity (--lru 100000)
+    or without eviction (--lru 0, which SURVEY 8d calls the deviation to state).  Clouds come from the host (PCIe inside the timed region)."""
+    import multiprocessing as mp
+
+    from lsd_amd import capi, lio, synth
+
+    n = args.steps
+    t_gen = time.perf_counter()
+    with mp.get_context("fork").Pool(max(1, min(32, usable_cpus()))) as pool:
+        sweeps = pool.map(_sweep_job, [(k, args.seed) for k in range(n)], chunksize=4)
+    t_gen = time.perf_counter() - t_gen
+    tr = synth.FigureEight()
+    evict = args.lru > 0
+    e = lio.Engine(resolution=0.5, stencil=75, max_points=14_000_000, max_voxels=(1 << 21) if evict else 6_000_000, max_raw=1 << 18, max_ds=100000,
+                   device=local_rank)
+    if not evict:
+        e.map.set_lru(5_900_000, 1e9)  # a capacity the drive never reaches: nothing is evicted
+    e.fastlio_init(scan_period=0.1)  # turns on the reference's 100000-voxel / 100 m LRU list unless one was set above
+    imu = synth.imu_stream(tr, 0.0, n * 0.1 + 0.3, rate=100.0, seed=args.seed, gyr_sigma=1e-3, acc_sigma=1e-2)
+    ii, t_main, t_enq, rows, pts = 0, [], [], [], 0
+    for k, (p, st) in enumerate(sweeps):
+        tb = k * 0.1
+        while ii < len(imu) and imu[ii][0] <= tb + 0.12:
+            e.fastlio_imu_enqueue(*imu[ii])
+            ii += 1
+        t0 = time.perf_counter()
+        e.fastlio_pcl_enqueue(p, st, tb)
+        t1 = time.perf_counter()
+        rc = e.fastlio_main()
+        t2 = time.perf_counter()
+        if rc == capi.MAIN_UPDATED and k >= 20:
+            t_enq.append(t1 - t0)
+            t_main.append(t2 - t1)
+            pts += len(p)
+            tm = e.timings()
+            rows.append((tm["n_ds"], tm["n_pass"], tm["n_knn_pass"], tm["n_added"]))
+        elif rc < 0:
+            raise RuntimeError(f"lio_fastlio_main returned {rc} at scan {k}")
+    s = e.get_state()
+    R0, p0 = tr.R(0.0), tr.pos(0.0)
+    err = float(np.linalg.norm(s[0:3] - R0.T @ (tr.pos(n * 0.1) - p0)))
+    map_points, map_voxels = e.map.stats()
+    evicted = e.map.lru_stats()[0]
+    rows = np.array(rows, dtype=np.float64)
+    tot = float(np.sum(t_main) + np.sum(t_enq))
+    out = {"metric": "registered points/sec (streaming LIO front half, incremental map)", "value": round(pts / tot, 1), "unit": "points/s", "n_gpus": 1,
+           "steps": len(t_main), "warmup": 20, "ms_per_step": round(1e3 * tot / len(t_main), 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 per-point geometry / f64 transforms and reductions", "data": "synthetic",
+           "config": {"workload": "BASELINE config 3 stand-in: %d sweeps of 64x1875 rays at 10 Hz along a figure of eight (5 m/s) through a 1 km x 1 km scene, 100 Hz IMU, "
+                                  "lio_fastlio_* (IMU propagation + undistortion + downsample + iterated update + map_incremental), clouds from the host" % n,
+                      "lru_capacity_voxels": args.lru if evict else None, "n_ds_avg": round(float(rows[:, 0].mean()), 1), "passes_avg": round(float(rows[:, 1].mean()), 2),
+                      "knn_passes_avg": round(float(rows[:, 2].mean()), 2), "points_added_per_scan": round(float(rows[:, 3].mean()), 1),
+                      "map_points_end": int(map_points), "map_voxels_end": int(map_voxels), "voxels_evicted": int(evicted),
+                      "main_ms_median": round(1e3 * float(np.median(t_main)), 4), "enqueue_ms_median": round(1e3 * float(np.median(t_enq)), 4),
+                      "main_ms_p99": round(1e3 * float(np.percentile(t_main, 99)), 4), "sweep_generation_s": round(t_gen, 1)},
+           "pose_error_vs_truth_m": err}
+    print(json.dumps(out))
 
 
 def bench_merge(args, torch, dist, world, rank, local_rank, dev):

@@ -547,50 +547,96 @@ int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) 
     return LIO_OK;
 }
 
-// map_incremental (laserMapping.cpp:523-563): which downsampled points enter the map
-__global__ void __launch_bounds__(256) classify_kernel(PoseArgs pose, const ScanDev* __restrict__ sd, const float4* __restrict__ ds_body,
-                                                       float4* __restrict__ ds_world, const float4* __restrict__ nn_pts, uint32_t nn_stride,
-                                                       const int32_t* __restrict__ nn_cnt, float map_leaf, int ekf_inited, int seed_all,
-                                                       float4* __restrict__ stage, MapDev* md) {
+// map_incremental (laserMapping.cpp:523-563): which downsampled points enter the map, and in which order.  The reference fills two lists in
+// point order -- PointToAdd, PointNoNeedDownsample -- and inserts them one after the other (:571-572); the order decides which voxel a scan
+// touches LAST, i.e. the LRU positions, hence the eviction set when the quota cuts inside a scan.  Two launches: classify (flag per point,
+// counts per workgroup), then an ordered scatter (exclusive scan over the workgroup counts, ballot + prefix sums inside) -- the staged
+// batch is PointToAdd in point order followed by PointNoNeedDownsample in point order, independent of wave scheduling.
+constexpr int kClsThreads = 256;
+
+__global__ void __launch_bounds__(kClsThreads) classify_kernel(PoseArgs pose, const ScanDev* __restrict__ sd, const float4* __restrict__ ds_body,
+                                                               float4* __restrict__ ds_world, const float4* __restrict__ nn_pts, uint32_t nn_stride,
+                                                               const int32_t* __restrict__ nn_cnt, float map_leaf, int ekf_inited, int seed_all,
+                                                               uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt /* [2][gridDim.x] */) {
     const uint32_t n = sd->n_ds;
-    const int lane = threadIdx.x & 63;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
-        bool add = false;
-        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n) {
-            double pi[3];
-            body_to_world_d(pose, ds_body[i], pi, pw);
-            ds_world[i] = pw;
-            const int cnt = nn_cnt[i];
-            add = true;
-            if (!seed_all && cnt > 0 && ekf_inited) {
-                const double fs = (double)map_leaf;
-                float4 mid;
-                mid.x = (float)(floor((double)pw.x / fs) * fs + 0.5 * fs);
-                mid.y = (float)(floor((double)pw.y / fs) * fs + 0.5 * fs);
-                mid.z = (float)(floor((double)pw.z / fs) * fs + 0.5 * fs);
-                const float dist = ((pw.x - mid.x) * (pw.x - mid.x) + (pw.y - mid.y) * (pw.y - mid.y)) + (pw.z - mid.z) * (pw.z - mid.z);
-                const double half = 0.5 * fs;
-                const float4 n0 = nn_pts[i];
-                if (fabs((double)(n0.x - mid.x)) > half && fabs((double)(n0.y - mid.y)) > half && fabs((double)(n0.z - mid.z)) > half) {
-                    add = true;  // PointNoNeedDownsample
-                } else if (cnt >= 5) {
+    const uint32_t i = blockIdx.x * kClsThreads + threadIdx.x;
+    int c = 0;  // 0 not added, 1 PointToAdd, 2 PointNoNeedDownsample
+    if (i < n) {
+        double pi[3];
+        float4 pw;
+        body_to_world_d(pose, ds_body[i], pi, pw);
+        ds_world[i] = pw;
+        const int cnt = nn_cnt[i];
+        c = 1;
+        if (!seed_all && cnt > 0 && ekf_inited) {
+            const double fs = (double)map_leaf;
+            float4 mid;
+            mid.x = (float)(floor((double)pw.x / fs) * fs + 0.5 * fs);
+            mid.y = (float)(floor((double)pw.y / fs) * fs + 0.5 * fs);
+            mid.z = (float)(floor((double)pw.z / fs) * fs + 0.5 * fs);
+            const float dist = ((pw.x - mid.x) * (pw.x - mid.x) + (pw.y - mid.y) * (pw.y - mid.y)) + (pw.z - mid.z) * (pw.z - mid.z);
+            const double half = 0.5 * fs;
+            const float4 n0 = nn_pts[i];
+            if (fabs((double)(n0.x - mid.x)) > half && fabs((double)(n0.y - mid.y)) > half && fabs((double)(n0.z - mid.z)) > half) {
+                c = 2;  // PointNoNeedDownsample
+            } else if (cnt >= 5) {
 #pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        const float4 q = nn_pts[(size_t)k * nn_stride + i];
-                        const float dq = ((q.x - mid.x) * (q.x - mid.x) + (q.y - mid.y) * (q.y - mid.y)) + (q.z - mid.z) * (q.z - mid.z);
-                        if (dq < dist) add = false;
-                    }
+                for (int k = 0; k < 5; k++) {
+                    const float4 q = nn_pts[(size_t)k * nn_stride + i];
+                    const float dq = ((q.x - mid.x) * (q.x - mid.x) + (q.y - mid.y) * (q.y - mid.y)) + (q.z - mid.z) * (q.z - mid.z);
+                    if (dq < dist) c = 0;
                 }
             }
         }
-        const unsigned long long m = __ballot(add);
-        uint32_t wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&md->n_add, (uint32_t)__popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (add) stage[wbase + __popcll(m & ((1ull << lane) - 1ull))] = pw;
+        cls[i] = (uint8_t)c;
     }
+    __shared__ uint32_t wc[kClsThreads / 64][2];
+    const unsigned long long m1 = __ballot(c == 1), m2 = __ballot(c == 2);
+    if ((threadIdx.x & 63) == 0) { wc[threadIdx.x >> 6][0] = __popcll(m1); wc[threadIdx.x >> 6][1] = __popcll(m2); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t t = 0;
+        for (int w = 0; w < kClsThreads / 64; w++) t += wc[w][threadIdx.x];
+        blk_cnt[threadIdx.x * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(kClsThreads) classify_scatter_kernel(const ScanDev* __restrict__ sd, const float4* __restrict__ ds_world,
+                                                                       const uint8_t* __restrict__ cls, const uint32_t* __restrict__ blk_cnt,
+                                                                       float4* __restrict__ stage, MapDev* md) {
+    const uint32_t n = sd->n_ds;
+    const uint32_t nb = gridDim.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // exclusive prefix of this workgroup in each list, and the size of the first list (fixed order: deterministic slots)
+    __shared__ uint32_t red[kClsThreads / 64][3];
+    uint32_t preA = 0, preB = 0, totA = 0;
+    for (uint32_t b = tid; b < nb; b += kClsThreads) {
+        const uint32_t a = blk_cnt[b], bb = blk_cnt[nb + b];
+        totA += a;
+        if (b < blockIdx.x) { preA += a; preB += bb; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { preA += __shfl_xor(preA, off); preB += __shfl_xor(preB, off); totA += __shfl_xor(totA, off); }
+    if (lane == 0) { red[wave][0] = preA; red[wave][1] = preB; red[wave][2] = totA; }
+    __syncthreads();
+    preA = preB = totA = 0;
+    for (int w = 0; w < kClsThreads / 64; w++) { preA += red[w][0]; preB += red[w][1]; totA += red[w][2]; }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kClsThreads + tid;
+    const int c = i < n ? (int)cls[i] : 0;
+    const unsigned long long m1 = __ballot(c == 1), m2 = __ballot(c == 2);
+    __shared__ uint32_t wc[kClsThreads / 64][2];
+    if (lane == 0) { wc[wave][0] = __popcll(m1); wc[wave][1] = __popcll(m2); }
+    __syncthreads();
+    uint32_t offA = preA, offB = totA + preB, tb = 0;
+    for (int w = 0; w < kClsThreads / 64; w++) {
+        if (w < wave) { offA += wc[w][0]; offB += wc[w][1]; }
+        tb += wc[w][1];
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (c == 1) stage[offA + __popcll(m1 & below)] = ds_world[i];
+    else if (c == 2) stage[offB + __popcll(m2 & below)] = ds_world[i];
+    if (blockIdx.x == nb - 1 && tid == 0) md->n_add = totA + preB + tb;  // (the last workgroup's exclusive prefix + its own count = the total)
 }
 
 int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float map_leaf, int ekf_inited, int seed_all) {
@@ -599,11 +645,15 @@ int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float ma
         set_error("map_incremental: %u points exceed the staging capacity %llu", bound, (unsigned long long)m->stage_cap);
         return LIO_E_CAPACITY;
     }
-    uint32_t blocks = (bound + 255) / 256;
+    if ((uint64_t)bound > 4ull * s->max_raw) { set_error("map_incremental: %u points exceed the flag scratch", bound); return LIO_E_CAPACITY; }
+    uint32_t blocks = (bound + kClsThreads - 1) / kClsThreads;
     if (blocks == 0) blocks = 1;
-    LIO_HIP_TRY(hipMemsetAsync(&m->dev->n_add, 0, sizeof(uint32_t), s->stream));
-    hipLaunchKernelGGL(classify_kernel, blocks, 256, 0, s->stream, pose, s->dev, s->ds_body, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt,
-                       map_leaf, ekf_inited, seed_all, m->stage, m->dev);
+    // scratch of the downsample that is free by now: the radix histograms (2 x blocks words), a key buffer (one flag byte per point)
+    uint32_t* blk_cnt = s->hist;
+    uint8_t* cls = reinterpret_cast<uint8_t*>(s->keys_a);
+    hipLaunchKernelGGL(classify_kernel, blocks, kClsThreads, 0, s->stream, pose, s->dev, s->ds_body, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt,
+                       map_leaf, ekf_inited, seed_all, cls, blk_cnt);
+    hipLaunchKernelGGL(classify_scatter_kernel, blocks, kClsThreads, 0, s->stream, s->dev, s->ds_world, cls, blk_cnt, m->stage, m->dev);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

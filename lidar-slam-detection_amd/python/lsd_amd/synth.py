@@ -235,6 +235,41 @@ class Trajectory:
         return gyr, R.T @ (acc_w + np.array([0.0, 0.0, g]))
 
 
+class FigureEight(Trajectory):
+    """SURVEY.md 8d config 3 stand-in for a recorded drive: at rest for `t_static` seconds, then a figure of eight (lemniscate of Gerono,
+    x = A sin s, y = B sin s cos s) driven at ~`speed` m/s with the heading along the velocity and small pitch / roll oscillations"""
+
+    def __init__(self, p0=(0.0, 0.0, 1.8), t_static=1.5, speed=5.0, tau=2.0, A=150.0, B=150.0, pitch_amp=0.02, roll_amp=0.03):
+        super().__init__(p0=p0, t_static=t_static, speed=speed, tau=tau)
+        self.A, self.B = A, B
+        self.pitch_amp, self.roll_amp = pitch_amp, roll_amp
+        ss = np.linspace(0, 2 * np.pi, 4001)
+        self.length = float(np.sum(np.hypot(np.diff(A * np.sin(ss)), np.diff(B * np.sin(ss) * np.cos(ss)))))
+
+    def _s(self, t):
+        u = self._u(t)
+        d = self.speed * (u - self.tau * (1.0 - np.exp(-u / self.tau)))  # distance-like parameter, zero velocity at the start
+        return 2 * np.pi * d / self.length
+
+    def pos(self, t):
+        s = self._s(t)
+        u = self._u(t)
+        z = 0.05 * (1.0 - np.cos(1.1 * u))
+        return np.stack([self.p0[0] + self.A * np.sin(s), self.p0[1] + self.B * np.sin(s) * np.cos(s), self.p0[2] + z], -1)
+
+    def R(self, t):
+        s, u = self._s(t), self._u(t)
+        yaw = np.arctan2(self.B * np.cos(2 * s), self.A * np.cos(s))
+        pitch = self.pitch_amp * (1.0 - np.cos(0.9 * u))
+        roll = self.roll_amp * (1.0 - np.cos(0.7 * u))
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        R = np.empty(np.shape(u) + (3, 3))
+        R[..., 0, 0] = cy * cp; R[..., 0, 1] = cy * sp * sr - sy * cr; R[..., 0, 2] = cy * sp * cr + sy * sr
+        R[..., 1, 0] = sy * cp; R[..., 1, 1] = sy * sp * sr + cy * cr; R[..., 1, 2] = sy * sp * cr - cy * sr
+        R[..., 2, 0] = -sp;     R[..., 2, 1] = cp * sr;                R[..., 2, 2] = cp * cr
+        return R
+
+
 def make_sweep(scene, traj, t_beg, scan_period=0.1, ext_R=np.eye(3), ext_t=(0.0, 0.0, 0.0), seed=0, n_beams=64, n_az=1875, sigma=0.02,
                max_range=100.0, fov_deg=(-25.0, 15.0)):
     """one sweep of a MOVING spinning lidar: ray i leaves at t_beg + stamp_i from the pose the trajectory has then.
