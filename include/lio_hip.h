@@ -429,6 +429,30 @@ void lio_ndt_default_params(lio_ndt_params*);
 int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_ndt_params* params, double out[16], int* iterations,
                   int* converged);
 
+/* ---------------------------------------------------------------------------------------------
+ * Generalized-ICP: replaces fast_gicp::FastGICP<PointXYZI, PointXYZI> as select_registration_method("FAST_GICP") configures it
+ * (slam/backend/hdl_graph_slam/src/hdl_graph_slam/registrations.cpp:33-42) -- the fine matcher of the map merge / loop closure tools
+ * (slam/localization/include/overlap_merge.hpp:54-58,158-179: coarse NDT -> fine GICP -> fitness) and, through the same cost function, the
+ * matcher family of slam/thirdparty/fast_gicp/include/fast_gicp/gicp/impl/{fast_gicp_impl.hpp:118-303, fast_vgicp_impl.hpp:72-204}:
+ *   create ......... FastGICP() + setCorrespondenceRandomness(k); grid_resolution = cell size of the search grid (results do not depend on it)
+ *   set_target / set_source  setInputTarget / setInputSource: exact k nearest neighbours of every point, covariance, PLANE regularisation
+ *   linearize ...... update_correspondences (nearest target point within max_corr_dist, Mahalanobis (C_B + R C_A R^T)^-1) + linearize:
+ *                    H = sum J^T M J, b = sum J^T M e, err = sum e^T M e (update_corr = 0: the cached pairs; with_derivatives = 0: compute_error)
+ *   align .......... pcl::Registration::align(guess) -> LsqRegistration's LM loop; params NULL = the reference's FAST_GICP settings
+ *   download / correspondences  test visibility: the clouds in internal (grid) order with their regularised covariances (xx, xy, xz, yy, yz, zz);
+ *                    the target index of every source point (-1 = none), in that order
+ * Transforms are row-major 4 x 4 doubles. */
+typedef struct lio_gicp lio_gicp;
+lio_gicp* lio_gicp_create(int device, float grid_resolution, uint32_t max_points, int k_correspondences);
+void lio_gicp_destroy(lio_gicp*);
+int lio_gicp_set_target(lio_gicp*, const float* xyzi, uint32_t n);
+int lio_gicp_set_source(lio_gicp*, const float* xyzi, uint32_t n);
+int lio_gicp_download(lio_gicp*, int which, float* xyzi, double* cov6, uint32_t cap);
+int lio_gicp_correspondences(lio_gicp*, int32_t* corr, uint32_t cap);
+int lio_gicp_linearize(lio_gicp*, const double T[16], double max_corr_dist, int update_corr, int with_derivatives, double H[36], double b[6], double* err,
+                       uint32_t* n_corr);
+int lio_gicp_align(lio_gicp*, const double guess[16], const lio_ndt_params* params, double max_corr_dist, double out[16], int* iterations, int* converged);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * The localisation loop around the matcher: hdl_localization::PoseEstimator (slam/localization/hdl_localization/src/
  * pose_estimator.cpp) = a 23-state unscented Kalman filter (include/kkl/alg/unscented_kalman_filter.hpp:42-262 over

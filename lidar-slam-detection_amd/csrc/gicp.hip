@@ -1,0 +1,428 @@
+// gicp.hip -- Generalized-ICP on the device: the fine matcher of the reference's map merge / loop closure and the CPU fallback
+// matcher family of its localisation.
+//
+// Replaces fast_gicp::FastGICP<PointXYZI, PointXYZI> as select_registration_method("FAST_GICP") configures it
+// (/root/reference/slam/backend/hdl_graph_slam/src/hdl_graph_slam/registrations.cpp:33-42: 20 neighbours, transformation epsilon 0.01,
+// 64 iterations, max correspondence distance 2.0; overlap_merge.hpp:56-58 tightens it to 0.5 / 0.001 for the fine alignment), i.e.
+//   calculate_covariances   fast_gicp_impl.hpp:244-303   per point: the k nearest neighbours (kd-tree there), their covariance, PLANE
+//                                                        regularisation (SVD, singular values replaced by (1, 1, 1e-3))
+//   update_correspondences  fast_gicp_impl.hpp:118-157   per source point: nearest target point of the transformed point within the
+//                                                        correspondence distance, Mahalanobis matrix (C_B + R C_A R^T)^-1
+//   linearize / compute_error  :159-242                  e = b - T a, J = [ [T a]x | -I ], H = sum J^T M J, b = sum J^T M e, E = sum e^T M e
+//   LsqRegistration         lsq_registration_impl.hpp:71-208   the LM loop on SE(3) shared with the NDT matcher (lsq.h)
+// Mapping to the machine: both clouds live in a hash grid of `grid_resolution` cells (the map's brick-coherent table, the points of a cell
+// contiguous in the pool) -- the exact k-NN and 1-NN searches walk rings of cells around the query's cell and stop once the k-th / best
+// distance is within the radius already covered (after ring r every unseen point is at least r cells away), so they return what an exact
+// kd-tree returns.  One lane per point; the k-NN heap of a lane sits in LDS ([slot][lane]: conflict free).  All sums in f64, folded in a
+// fixed order (run-to-run identical).  The PLANE regularisation needs only the eigenvector of the smallest eigenvalue:
+// U diag(1, 1, 1e-3) V^T = I - (1 - 1e-3) v0 v0^T for a symmetric positive semi-definite covariance.
+#include <sched.h>
+
+#include "hashgrid.h"
+#include "lio_common.h"
+#include "lsq.h"
+
+namespace lio {
+
+constexpr int kGicpThreads = 128;
+constexpr int kGicpMaxK = 32;
+constexpr int kGicpAcc = 29;  // 21 H (upper), 6 b, err, count
+
+struct GicpXform {
+    double R[9], t[3];   // trans (double)
+    float Rf[9], tf[3];  // trans.cast<float>()
+};
+
+__device__ inline bool grid_find(const Slot* __restrict__ table, uint32_t mask, int cx, int cy, int cz, uint32_t& ptr, uint32_t& cnt) {
+    const unsigned long long want = pack_key(cx, cy, cz);
+    BrickProbe bp = brick_probe(cx, cy, cz);
+    for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
+        const Slot sl = table[brick_slot(bp, mask)];
+        if (sl.key == want) { ptr = sl.ptr; cnt = sl.cnt; return cnt > 0; }
+        if (sl.key == kEmptyKey) return false;
+        brick_next(bp);
+    }
+    return false;
+}
+
+// k nearest neighbours of every point of the cloud within the cloud itself (the point is its own nearest), their covariance, PLANE
+// regularisation.  cov6 = (xx, xy, xz, yy, yz, zz) of the regularised matrix, pool order.
+__global__ void __launch_bounds__(kGicpThreads) gicp_cov_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, uint32_t n,
+                                                                float res, int k, double* __restrict__ cov6) {
+    __shared__ float hd[kGicpMaxK][kGicpThreads];
+    __shared__ uint32_t hi[kGicpMaxK][kGicpThreads];
+    const int tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * kGicpThreads + tid;
+    if (i >= n) return;
+    const float4 p = pool[i];
+    int kx, ky, kz;
+    pos2grid_ndt(p.x, p.y, p.z, res, kx, ky, kz);
+    int have = 0;
+    float worst = INFINITY;  // the k-th best once the heap is full
+    for (int r = 0;; r++) {
+        for (int dz = -r; dz <= r; dz++)
+            for (int dy = -r; dy <= r; dy++) {
+                const int step = (abs(dz) == r || abs(dy) == r || r == 0) ? 1 : 2 * r;  // only the shell of the cube
+                for (int dx = -r; dx <= r; dx += step) {
+                    uint32_t ptr, cnt;
+                    if (!grid_find(table, mask, kx + dx, ky + dy, kz + dz, ptr, cnt)) continue;
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        const float4 q = pool[ptr + j];
+                        const float ex = q.x - p.x, ey = q.y - p.y, ez = q.z - p.z;
+                        const float d2 = (ex * ex + ey * ey) + ez * ez;
+                        if (have == k && !(d2 < worst)) continue;
+                        // sorted insertion (ascending): the list is short and insertions become rare quickly
+                        int pos = have < k ? have : k - 1;
+                        while (pos > 0 && hd[pos - 1][tid] > d2) {
+                            hd[pos][tid] = hd[pos - 1][tid];
+                            hi[pos][tid] = hi[pos - 1][tid];
+                            pos--;
+                        }
+                        hd[pos][tid] = d2;
+                        hi[pos][tid] = ptr + j;
+                        if (have < k) have++;
+                        if (have == k) worst = hd[k - 1][tid];
+                    }
+                }
+            }
+        const float reach = (float)r * res;
+        if ((have == k && worst <= reach * reach) || r > 64) break;
+    }
+    // neighbors.colwise() -= neighbors.rowwise().mean(); cov = neighbors * neighbors^T / k   (f64, as the reference casts)
+    double m[3] = {0, 0, 0};
+    for (int j = 0; j < have; j++) {
+        const float4 q = pool[hi[j][tid]];
+        m[0] += (double)q.x; m[1] += (double)q.y; m[2] += (double)q.z;
+    }
+    for (int a = 0; a < 3; a++) m[a] /= (double)k;
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < have; j++) {
+        const float4 q = pool[hi[j][tid]];
+        const double d[3] = {(double)q.x - m[0], (double)q.y - m[1], (double)q.z - m[2]};
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) C[a * 3 + b] += d[a] * d[b];
+    }
+    for (int a = 0; a < 9; a++) C[a] /= (double)k;
+    double w[3], V[9];
+    ek_eig3_sym(C, w, V);  // ascending: column 0 = the direction of least spread (the surface normal)
+    const double v0[3] = {V[0], V[3], V[6]};
+    const double g = 1.0 - 1e-3;
+    double* o = cov6 + (size_t)i * 6;
+    o[0] = 1.0 - g * v0[0] * v0[0];
+    o[1] = -g * v0[0] * v0[1];
+    o[2] = -g * v0[0] * v0[2];
+    o[3] = 1.0 - g * v0[1] * v0[1];
+    o[4] = -g * v0[1] * v0[2];
+    o[5] = 1.0 - g * v0[2] * v0[2];
+}
+
+// update_correspondences: nearest target point of trans_f * a within the correspondence distance, and the Mahalanobis matrix of the pair
+__global__ void __launch_bounds__(kGicpThreads) gicp_corr_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ tpool, float res,
+                                                                 const double* __restrict__ tcov, const float4* __restrict__ spool, const double* __restrict__ scov,
+                                                                 uint32_t n_src, GicpXform X, float max_d2, int32_t* __restrict__ corr, double* __restrict__ maha) {
+    const uint32_t i = blockIdx.x * kGicpThreads + threadIdx.x;
+    if (i >= n_src) return;
+    const float4 a = spool[i];
+    // trans_f * [x y z 1]: Eigen folds the four products of a row pairwise, (r0 x + r1 y) + (r2 z + t) (checked against the reference build)
+    const float tx = (X.Rf[0] * a.x + X.Rf[1] * a.y) + (X.Rf[2] * a.z + X.tf[0]);
+    const float ty = (X.Rf[3] * a.x + X.Rf[4] * a.y) + (X.Rf[5] * a.z + X.tf[1]);
+    const float tz = (X.Rf[6] * a.x + X.Rf[7] * a.y) + (X.Rf[8] * a.z + X.tf[2]);
+    int kx, ky, kz;
+    pos2grid_ndt(tx, ty, tz, res, kx, ky, kz);
+    float best = INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (int r = 0;; r++) {
+        for (int dz = -r; dz <= r; dz++)
+            for (int dy = -r; dy <= r; dy++) {
+                const int step = (abs(dz) == r || abs(dy) == r || r == 0) ? 1 : 2 * r;  // only the shell of the cube
+                for (int dx = -r; dx <= r; dx += step) {
+                    uint32_t ptr, cnt;
+                    if (!grid_find(table, mask, kx + dx, ky + dy, kz + dz, ptr, cnt)) continue;
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        const float4 q = tpool[ptr + j];
+                        const float ex = q.x - tx, ey = q.y - ty, ez = q.z - tz;
+                        const float d2 = (ex * ex + ey * ey) + ez * ez;
+                        if (d2 < best) { best = d2; bi = ptr + j; }
+                    }
+                }
+            }
+        const float reach = (float)r * res;
+        if (best <= reach * reach || reach * reach > max_d2) break;
+    }
+    const bool ok = bi != 0xFFFFFFFFu && best < max_d2;
+    corr[i] = ok ? (int32_t)bi : -1;
+    if (!ok) return;
+    // RCR = cov_B + R cov_A R^T ; mahalanobis = RCR^-1 (3 x 3: the fourth row / column of the reference's 4 x 4 is the unit one)
+    const double* ca = scov + (size_t)i * 6;
+    const double* cb = tcov + (size_t)bi * 6;
+    const double A[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
+    double RA[9], M[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { double s = 0; for (int k2 = 0; k2 < 3; k2++) s += X.R[r * 3 + k2] * A[k2 * 3 + c]; RA[r * 3 + c] = s; }
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { double s = 0; for (int k2 = 0; k2 < 3; k2++) s += RA[r * 3 + k2] * X.R[c * 3 + k2]; M[r * 3 + c] = s; }
+    M[0] += cb[0]; M[1] += cb[1]; M[2] += cb[2]; M[3] += cb[1]; M[4] += cb[3]; M[5] += cb[4]; M[6] += cb[2]; M[7] += cb[4]; M[8] += cb[5];
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+    const double id = 1.0 / det;
+    double* o = maha + (size_t)i * 6;  // symmetric inverse
+    o[0] = c00 * id;
+    o[1] = (M[2] * M[7] - M[1] * M[8]) * id;
+    o[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    o[3] = (M[0] * M[8] - M[2] * M[6]) * id;
+    o[4] = (M[2] * M[3] - M[0] * M[5]) * id;
+    o[5] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+// linearize (DERIV) / compute_error on the cached correspondences and Mahalanobis matrices at transform X
+template <bool DERIV>
+__global__ void __launch_bounds__(kGicpThreads) gicp_cost_kernel(const float4* __restrict__ tpool, const float4* __restrict__ spool, uint32_t n_src,
+                                                                 const int32_t* __restrict__ corr, const double* __restrict__ maha, GicpXform X,
+                                                                 double* __restrict__ partial) {
+    const uint32_t i = blockIdx.x * kGicpThreads + threadIdx.x;
+    double acc[kGicpAcc];
+#pragma unroll
+    for (int a = 0; a < kGicpAcc; a++) acc[a] = 0.0;
+    if (i < n_src && corr[i] >= 0) {
+        const float4 a = spool[i];
+        const float4 b = tpool[corr[i]];
+        const double ax = (double)a.x, ay = (double)a.y, az = (double)a.z;
+        const double ta[3] = {(X.R[0] * ax + X.R[1] * ay) + (X.R[2] * az + X.t[0]), (X.R[3] * ax + X.R[4] * ay) + (X.R[5] * az + X.t[1]),
+                              (X.R[6] * ax + X.R[7] * ay) + (X.R[8] * az + X.t[2])};
+        const double e[3] = {(double)b.x - ta[0], (double)b.y - ta[1], (double)b.z - ta[2]};
+        const double* m = maha + (size_t)i * 6;
+        const double M[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]};
+        double Me[3];
+        for (int r = 0; r < 3; r++) Me[r] = M[r * 3] * e[0] + M[r * 3 + 1] * e[1] + M[r * 3 + 2] * e[2];
+        acc[27] = e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
+        acc[28] = 1.0;
+        if (DERIV) {
+            // J (3 x 6) = [ skew(T a) | -I ]
+            double J[18] = {0, -ta[2], ta[1], -1, 0, 0, ta[2], 0, -ta[0], 0, -1, 0, -ta[1], ta[0], 0, 0, 0, -1};
+            double MJ[18];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 6; c++) MJ[r * 6 + c] = M[r * 3] * J[c] + M[r * 3 + 1] * J[6 + c] + M[r * 3 + 2] * J[12 + c];
+            int t = 0;
+            for (int r = 0; r < 6; r++)
+                for (int c = r; c < 6; c++) acc[t++] = J[r] * MJ[c] + J[6 + r] * MJ[6 + c] + J[12 + r] * MJ[12 + c];
+            for (int r = 0; r < 6; r++) acc[21 + r] = J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2];
+        }
+    }
+    __shared__ double red[kGicpThreads / 64][kGicpAcc];
+#pragma unroll
+    for (int a = 0; a < kGicpAcc; a++) {
+        double v = acc[a];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kGicpAcc) {
+        double v = 0.0;
+        for (int w2 = 0; w2 < kGicpThreads / 64; w2++) v += red[w2][threadIdx.x];
+        partial[(size_t)blockIdx.x * kGicpAcc + threadIdx.x] = v;
+    }
+}
+
+struct GicpReport {
+    double acc[kGicpAcc];
+    uint32_t seq, pad;
+};
+
+__global__ void __launch_bounds__(1024) gicp_report_kernel(const double* __restrict__ partial, uint32_t nb, GicpReport* __restrict__ out, uint32_t seq) {
+    __shared__ double acc[kGicpAcc];
+    const int tid = threadIdx.x, c = tid >> 5, l = tid & 31;
+    double s = 0.0;
+    if (c < kGicpAcc)
+        for (uint32_t b = l; b < nb; b += 32) s += partial[(size_t)b * kGicpAcc + c];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (c < kGicpAcc && l == 0) acc[c] = s;
+    __syncthreads();
+    if (tid < kGicpAcc) out->acc[tid] = acc[tid];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) *reinterpret_cast<volatile uint32_t*>(&out->seq) = seq;
+}
+
+}  // namespace lio
+
+using namespace lio;
+
+struct lio_gicp {
+    int device = 0;
+    float res = 1.0f;
+    int k = 20;
+    uint32_t max_points = 0;
+    lio_map* grid[2] = {nullptr, nullptr};  // 0 target, 1 source: hash grids holding the clouds
+    uint32_t n[2] = {0, 0};
+    double* cov[2] = {nullptr, nullptr};
+    int32_t* corr = nullptr;
+    double* maha = nullptr;
+    double* partial = nullptr;
+    GicpReport* report = nullptr;
+    GicpReport* report_dev = nullptr;
+    uint32_t seq = 0;
+    float4* stage = nullptr;
+};
+
+namespace {
+
+GicpXform to_gx(const double T[16]) {
+    GicpXform x;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) { x.R[i * 3 + j] = T[i * 4 + j]; x.Rf[i * 3 + j] = (float)T[i * 4 + j]; }
+        x.t[i] = T[i * 4 + 3];
+        x.tf[i] = (float)T[i * 4 + 3];
+    }
+    return x;
+}
+
+int gicp_set_cloud(lio_gicp* g, int which, const float* xyzi, uint32_t n) {
+    if (!g || (!xyzi && n)) return LIO_E_INVALID;
+    if (n > g->max_points) { set_error("lio_gicp: cloud of %u points exceeds max_points %u", n, g->max_points); return LIO_E_CAPACITY; }
+    if ((int)n < g->k) { set_error("lio_gicp: a cloud needs at least k = %d points", g->k); return LIO_E_INVALID; }
+    hipSetDevice(g->device);
+    // a fresh grid per cloud: the first batch into an empty map is laid out exactly (cell by cell, contiguous from the start of the pool)
+    if (g->grid[which]) lio_map_destroy(g->grid[which]);
+    g->grid[which] = lio_map_create(g->device, g->res, g->max_points, g->max_points, 1);
+    if (!g->grid[which]) return LIO_E_DEVICE;
+    lio_map* m = g->grid[which];
+    m->key_mode = 1;
+    hipStream_t st = m->stream;
+    LIO_HIP_TRY(hipMemcpyAsync(g->stage, xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, st));
+    int rc = lio_map_insert_device(m, g->stage, n, 0.0);
+    if (rc != LIO_OK) return rc;
+    g->n[which] = n;
+    hipLaunchKernelGGL(gicp_cov_kernel, (n + kGicpThreads - 1) / kGicpThreads, kGicpThreads, 0, st, m->table, m->table_mask, m->pool, n, g->res, g->k, g->cov[which]);
+    LIO_HIP_TRY(hipGetLastError());
+    LIO_HIP_TRY(hipStreamSynchronize(st));
+    return LIO_OK;
+}
+
+int gicp_eval(lio_gicp* g, const double T[16], double max_corr_dist, bool update, bool deriv, double* H, double* b, double* err, uint32_t* n_corr) {
+    if (!g->grid[0] || !g->grid[1]) { set_error("lio_gicp: set target and source first"); return LIO_E_STATE; }
+    hipStream_t st = g->grid[0]->stream;
+    const GicpXform X = to_gx(T);
+    const uint32_t ns = g->n[1];
+    const uint32_t blocks = (ns + kGicpThreads - 1) / kGicpThreads;
+    lio_map* mt = g->grid[0];
+    if (update) {
+        const double d2 = max_corr_dist * max_corr_dist;
+        hipLaunchKernelGGL(gicp_corr_kernel, blocks, kGicpThreads, 0, st, mt->table, mt->table_mask, mt->pool, g->res, g->cov[0], g->grid[1]->pool, g->cov[1], ns, X,
+                           d2 > 3.0e38 ? 3.0e38f : (float)d2, g->corr, g->maha);
+    }
+    if (deriv) hipLaunchKernelGGL(gicp_cost_kernel<true>, blocks, kGicpThreads, 0, st, mt->pool, g->grid[1]->pool, ns, g->corr, g->maha, X, g->partial);
+    else hipLaunchKernelGGL(gicp_cost_kernel<false>, blocks, kGicpThreads, 0, st, mt->pool, g->grid[1]->pool, ns, g->corr, g->maha, X, g->partial);
+    const uint32_t seq = ++g->seq;
+    hipLaunchKernelGGL(gicp_report_kernel, 1, 1024, 0, st, g->partial, blocks, g->report_dev, seq);
+    LIO_HIP_TRY(hipGetLastError());
+    volatile uint32_t* ps = &g->report->seq;
+    for (uint64_t spin = 0; *ps != seq; spin++) {
+        __builtin_ia32_pause();
+        if (spin > 4000 && (spin & 63) == 0) sched_yield();
+        if (spin > 200000000ull) {
+            LIO_HIP_TRY(hipStreamSynchronize(st));
+            if (*ps != seq) { set_error("gicp: the cost kernel did not report"); return LIO_E_DEVICE; }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const double* a = g->report->acc;
+    if (H) {
+        int t = 0;
+        for (int r = 0; r < 6; r++)
+            for (int c = r; c < 6; c++) { H[r * 6 + c] = a[t]; H[c * 6 + r] = a[t]; t++; }
+    }
+    if (b) for (int r = 0; r < 6; r++) b[r] = a[21 + r];
+    if (err) *err = a[27];
+    if (n_corr) *n_corr = (uint32_t)(a[28] + 0.5);
+    return LIO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+lio_gicp* lio_gicp_create(int device, float grid_resolution, uint32_t max_points, int k_correspondences) {
+    if (!(grid_resolution > 0.f) || max_points == 0 || k_correspondences < 3 || k_correspondences > kGicpMaxK) { set_error("lio_gicp_create: bad argument"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("lio_gicp_create: no HIP device %d (this library has no CPU fallback)", device); return nullptr; }
+    lio_gicp* g = new lio_gicp();
+    g->device = device;
+    g->res = grid_resolution;
+    g->k = k_correspondences;
+    g->max_points = max_points;
+    const uint32_t blocks = (max_points + kGicpThreads - 1) / kGicpThreads;
+    bool ok = hipMalloc(reinterpret_cast<void**>(&g->cov[0]), (size_t)max_points * 6 * sizeof(double)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&g->cov[1]), (size_t)max_points * 6 * sizeof(double)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&g->corr), (size_t)max_points * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&g->maha), (size_t)max_points * 6 * sizeof(double)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&g->partial), (size_t)blocks * kGicpAcc * sizeof(double)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&g->stage), (size_t)max_points * sizeof(float4)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&g->report), sizeof(GicpReport), hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void**>(&g->report_dev), g->report, 0) == hipSuccess;
+    if (!ok) { set_error("lio_gicp_create: allocation failed"); lio_gicp_destroy(g); return nullptr; }
+    memset(g->report, 0, sizeof(GicpReport));
+    return g;
+}
+
+void lio_gicp_destroy(lio_gicp* g) {
+    if (!g) return;
+    hipSetDevice(g->device);
+    for (int w = 0; w < 2; w++) {
+        if (g->grid[w]) lio_map_destroy(g->grid[w]);
+        if (g->cov[w]) hipFree(g->cov[w]);
+    }
+    if (g->corr) hipFree(g->corr);
+    if (g->maha) hipFree(g->maha);
+    if (g->partial) hipFree(g->partial);
+    if (g->stage) hipFree(g->stage);
+    if (g->report) hipHostFree(g->report);
+    delete g;
+}
+
+int lio_gicp_set_target(lio_gicp* g, const float* xyzi, uint32_t n) { return gicp_set_cloud(g, 0, xyzi, n); }
+int lio_gicp_set_source(lio_gicp* g, const float* xyzi, uint32_t n) { return gicp_set_cloud(g, 1, xyzi, n); }
+
+int lio_gicp_download(lio_gicp* g, int which, float* xyzi, double* cov6, uint32_t cap) {
+    if (!g || which < 0 || which > 1 || !g->grid[which]) return LIO_E_INVALID;
+    const uint32_t n = g->n[which];
+    if (n > cap) return LIO_E_CAPACITY;
+    hipSetDevice(g->device);
+    if (xyzi) LIO_HIP_TRY(hipMemcpy(xyzi, g->grid[which]->pool, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (cov6) LIO_HIP_TRY(hipMemcpy(cov6, g->cov[which], (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    return (int)n;
+}
+
+int lio_gicp_correspondences(lio_gicp* g, int32_t* corr, uint32_t cap) {
+    if (!g || !corr || !g->grid[1]) return LIO_E_INVALID;
+    if (g->n[1] > cap) return LIO_E_CAPACITY;
+    hipSetDevice(g->device);
+    LIO_HIP_TRY(hipMemcpy(corr, g->corr, (size_t)g->n[1] * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return (int)g->n[1];
+}
+
+int lio_gicp_linearize(lio_gicp* g, const double T[16], double max_corr_dist, int update_corr, int with_derivatives, double H[36], double b[6], double* err,
+                       uint32_t* n_corr) {
+    if (!g || !T) return LIO_E_INVALID;
+    hipSetDevice(g->device);
+    return gicp_eval(g, T, max_corr_dist, update_corr != 0, with_derivatives != 0, H, b, err, n_corr);
+}
+
+int lio_gicp_align(lio_gicp* g, const double guess[16], const lio_ndt_params* prm, double max_corr_dist, double out[16], int* iterations, int* converged) {
+    if (!g || !guess || !out) return LIO_E_INVALID;
+    hipSetDevice(g->device);
+    lio_ndt_params p;
+    if (prm) p = *prm;
+    else {  // select_registration_method("FAST_GICP") (registrations.cpp:33-42) over LsqRegistration's defaults (lsq_registration_impl.hpp:20-35)
+        lio_ndt_default_params(&p);
+        p.rotation_epsilon_deg = 1e-2;
+        p.transformation_epsilon = 0.01;
+        p.max_iterations = 64;
+        p.max_process_time_ms = -1;
+    }
+    auto lin = [&](const double x[16], double H[36], double b[6], double* y) { return gicp_eval(g, x, max_corr_dist, true, true, H, b, y, nullptr); };
+    auto er = [&](const double*, const double x[16], double* y) { return gicp_eval(g, x, max_corr_dist, false, false, nullptr, nullptr, y, nullptr); };
+    return lsq_align(p, guess, lin, er, out, iterations, converged);
+}
+
+}  // extern "C"

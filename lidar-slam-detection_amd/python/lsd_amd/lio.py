@@ -492,6 +492,64 @@ class Ndt:
         return out, bool(conv.value), int(it.value)
 
 
+class Gicp:
+    """fast_gicp::FastGICP on the device (lio_gicp_*): 20-NN covariances with PLANE regularisation, nearest-neighbour correspondences,
+    (C_B + R C_A R^T)^-1 cost, LM on SE(3)"""
+
+    def __init__(self, grid_resolution=1.0, max_points=200_000, k=20, device=0):
+        self.max_points = max_points
+        self.h = lib().lio_gicp_create(device, float(grid_resolution), int(max_points), int(k))
+        if not self.h:
+            raise capi.LioError("lio_gicp_create failed: " + lib().lio_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().lio_gicp_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def set_target(self, pts):
+        p = f32(pts).reshape(-1, 4)
+        check(lib().lio_gicp_set_target(self.h, ptr(p, C.c_float), len(p)), "gicp set_target")
+
+    def set_source(self, pts):
+        p = f32(pts).reshape(-1, 4)
+        check(lib().lio_gicp_set_source(self.h, ptr(p, C.c_float), len(p)), "gicp set_source")
+
+    def download(self, which):
+        """(points (n, 4) in internal order, regularised covariances (n, 3, 3))"""
+        pts, cov = np.zeros((self.max_points, 4), np.float32), np.zeros((self.max_points, 6))
+        n = check(lib().lio_gicp_download(self.h, int(which), ptr(pts, C.c_float), ptr(cov, C.c_double), self.max_points), "gicp download")
+        c = cov[:n]
+        full = np.stack([c[:, 0], c[:, 1], c[:, 2], c[:, 1], c[:, 3], c[:, 4], c[:, 2], c[:, 4], c[:, 5]], 1).reshape(n, 3, 3)
+        return pts[:n].copy(), full
+
+    def correspondences(self):
+        out = np.zeros(self.max_points, np.int32)
+        n = check(lib().lio_gicp_correspondences(self.h, ptr(out, C.c_int32), self.max_points), "gicp correspondences")
+        return out[:n].copy()
+
+    def linearize(self, T, max_corr_dist=2.0, update_corr=True, with_derivatives=True):
+        T = f64(T).reshape(4, 4)
+        H, b, err, nc = np.zeros((6, 6)), np.zeros(6), C.c_double(0), C.c_uint32(0)
+        check(lib().lio_gicp_linearize(self.h, ptr(T, C.c_double), float(max_corr_dist), int(update_corr), int(with_derivatives), ptr(H, C.c_double),
+                                       ptr(b, C.c_double), C.byref(err), C.byref(nc)), "gicp linearize")
+        return dict(H=H, b=b, err=err.value, n_corr=nc.value)
+
+    def align(self, guess, max_corr_dist=2.0, **params):
+        g = f64(guess).reshape(4, 4)
+        prm = capi.NdtParams()
+        lib().lio_ndt_default_params(C.byref(prm))
+        prm.rotation_epsilon_deg, prm.transformation_epsilon, prm.max_iterations, prm.max_process_time_ms = 1e-2, 0.01, 64, -1.0
+        for k, v in params.items():
+            setattr(prm, k, v)
+        out = np.zeros((4, 4))
+        it, conv = C.c_int(0), C.c_int(0)
+        check(lib().lio_gicp_align(self.h, ptr(g, C.c_double), C.byref(prm), float(max_corr_dist), ptr(out, C.c_double), C.byref(it), C.byref(conv)), "gicp align")
+        return out, bool(conv.value), int(it.value)
+
+
 class Comm:
     """one rank of an RCCL communicator (lio_comm_*): the all-gather of per-rank normal equations for joint registration across GPUs"""
 

@@ -31,6 +31,8 @@ struct PointCloud {
     void push_back(const PointT& p) { points.push_back(p); width = (uint32_t)points.size(); height = 1; }
     PointT& operator[](size_t i) { return points[i]; }
     const PointT& operator[](size_t i) const { return points[i]; }
+    PointT& at(size_t i) { return points.at(i); }
+    const PointT& at(size_t i) const { return points.at(i); }
     iterator begin() { return points.begin(); }
     iterator end() { return points.end(); }
     const_iterator begin() const { return points.begin(); }

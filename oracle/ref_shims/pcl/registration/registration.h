@@ -31,6 +31,8 @@ class Registration {
     virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) { target_ = cloud; }
     void setMaximumIterations(int n) { max_iterations_ = n; }
     void setTransformationEpsilon(double e) { transformation_epsilon_ = e; }
+    void setMaxCorrespondenceDistance(double d) { corr_dist_threshold_ = d; }
+    double getMaxCorrespondenceDistance() const { return corr_dist_threshold_; }
     Matrix4 getFinalTransformation() const { return final_transformation_; }
     bool hasConverged() const { return converged_; }
     virtual double getFitnessScore(double /*max_range*/) { return 0.0; }  // PCL: kd-tree nearest neighbours of the aligned cloud; mocks override
