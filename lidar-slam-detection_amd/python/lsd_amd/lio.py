@@ -550,6 +550,89 @@ class Gicp:
         return out, bool(conv.value), int(it.value)
 
 
+def transform_cloud_f32(cloud, M):
+    """pcl::transformPointCloud(in, out, M) for XYZ(I) points as PCL 1.9.1 evaluates it in f32: xyz = M(0..2, 0..3) * [x y z 1], left to right"""
+    c = np.ascontiguousarray(cloud, np.float32).reshape(-1, 4).copy()
+    Mf = np.asarray(M, np.float64).astype(np.float32)
+    x, y, z = c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy()
+    for r in range(3):
+        c[:, r] = ((Mf[r, 0] * x + Mf[r, 1] * y) + Mf[r, 2] * z) + Mf[r, 3]
+    return c
+
+
+class OverlapMatcher:
+    """OverlapDetector::matching of the map-merge / relocalisation tools (slam/localization/include/overlap_merge.hpp:151-211) on the
+    device: per candidate the overlap pre-check and the coarse NDT alignment with its fitness score, then the fine GICP alignment of the
+    new key frame against the best candidate accumulated with its connected frames, then the final fitness test.  Same constants
+    (constructor :45-59): coarse = select_registration_method("NDT_CUDA"), fine = FAST_GICP with max correspondence distance 0.5 and
+    transformation epsilon 0.001."""
+
+    def __init__(self, max_points=400_000, device=0, ndt_resolution=1.0, gicp_grid=1.0):
+        self.fitness_score_max_range = 25.0
+        self.fitness_score_thresh = 1.5
+        self.fitness_inlier_thresh = 0.2
+        self.max_points = max_points
+        self.ndt = Ndt(resolution=ndt_resolution, search_method=7, max_points=max_points, max_voxels=max_points, max_source_points=max_points, device=device)
+        self.gicp = Gicp(grid_resolution=gicp_grid, max_points=max_points, k=20, device=device)
+        self.scan = Scan(max_raw=max_points, max_ds=max_points, device=device)
+
+    def close(self):
+        for o in (self.ndt, self.gicp, self.scan):
+            o.close()
+
+    def calc_fitness_score(self, cloud1, cloud2, relpose, max_range):
+        """calc_fitness_score(cloud1, cloud2, relpose, max_range) (:214-263) -> (score, inlier ratio)"""
+        self.ndt.set_target(overlap_filter(cloud1))
+        self.scan.set_ds(cloud2)
+        return self.ndt.overlap_score(self.scan, np.asarray(relpose, np.float32).astype(np.float64), max_range)
+
+    def matching(self, new_points, new_odom, candidates, connected=()):
+        """new_points / new_odom: the new key frame (cloud, 4 x 4 odometry); candidates: [(points, odom), ...]; connected: frames linked
+        to the candidates, [(candidate index, points, odom), ...].  Returns None (no overlap) or dict(best, relative_pose (4 x 4 f32, new
+        frame -> accumulated candidate frame ... as the reference returns it), score, coarse=[...])"""
+        new_points = f32(new_points).reshape(-1, 4)
+        new_odom = f64(new_odom).reshape(4, 4)
+        best_score, best, rel, coarse = np.inf, None, None, []
+        for ci, (pts, odom) in enumerate(candidates):
+            guess = (np.linalg.inv(new_odom) @ f64(odom).reshape(4, 4)).astype(np.float32)
+            fit = self.calc_fitness_score(new_points, pts, guess, 1.0)
+            if fit[1] < self.fitness_inlier_thresh:
+                coarse.append(dict(candidate=ci, skipped="inlier ratio", ratio=fit[1]))
+                continue
+            self.ndt.set_target(new_points)
+            self.scan.set_ds(pts)
+            T, conv, it = self.ndt.align(self.scan, guess.astype(np.float64))
+            if not conv:
+                coarse.append(dict(candidate=ci, skipped="not converged"))
+                continue
+            Tf = T.astype(np.float32)
+            score, _ = self.ndt.fitness_score(self.scan, Tf.astype(np.float64), self.fitness_score_max_range)
+            coarse.append(dict(candidate=ci, T=Tf, score=score, iterations=it))
+            if score > best_score:
+                continue
+            best_score, best, rel = score, ci, Tf
+        if best is None:
+            return None
+        # finetune: the best candidate plus its connected frames in the candidate's frame
+        bo = f64(candidates[best][1]).reshape(4, 4)
+        accum = [f32(candidates[best][0]).reshape(-1, 4)]
+        for ci, pts, odom in connected:
+            if ci == best:
+                accum.append(transform_cloud_f32(pts, np.linalg.inv(bo) @ f64(odom).reshape(4, 4)))
+        accum = np.concatenate(accum)
+        self.gicp.set_target(accum)
+        self.gicp.set_source(new_points)
+        g = np.linalg.inv(rel.astype(np.float64)).astype(np.float32)  # Eigen::Isometry3f(relative_pose).inverse()
+        T, conv, it = self.gicp.align(g.astype(np.float64), max_corr_dist=0.5, transformation_epsilon=0.001)
+        if not conv:
+            return None
+        relative_pose = T.astype(np.float32)
+        score, _ = self.calc_fitness_score(accum, new_points, relative_pose, self.fitness_score_max_range)
+        if score > self.fitness_score_thresh:
+            return None
+        return dict(best=best, relative_pose=relative_pose, score=score, coarse=coarse, fine_iterations=it)
+
+
 class Comm:
     """one rank of an RCCL communicator (lio_comm_*): the all-gather of per-rank normal equations for joint registration across GPUs"""
 
