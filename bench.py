@@ -241,7 +241,7 @@ def main():
         iso_launches = max(int(kt["knn_launches"]), 1)
         iso_us = kt["knn_us"] / iso_launches
         iso_bytes = knn_total_bytes / iso_launches
-        kernel_name = "knn_q_batch_kernel<4, 5> (4 lanes per query, %d scans per launch)" % args.slots
+        kernel_name = "knn_batch_kernel<2, false> (16 lanes per query, %d scans per launch)" % args.slots
         rounds = max(int(kt["downsample_launches"]), 1)
         others = {"downsample_chain_per_round": round(kt["downsample_us"] / rounds, 2),
                   "linearize_per_launch": round(kt["linearize_us"] / max(int(kt["linearize_launches"]), 1), 2),
@@ -282,7 +282,7 @@ def main():
         kernel_name = "knn_kernel<2, 0> (16 lanes per query)"
     achieved = iso_bytes / (iso_us * 1e-6) / 1e9 if iso_us > 0 else 0.0
     traffic = touched = None
-    tpath = os.path.join(ROOT, "profiles", "knn_q_traffic.json" if batch is not None else "knn_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "knn_batch_traffic.json" if batch is not None else "knn_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))

@@ -361,16 +361,45 @@ py::dict get_graph_map() { return py::dict(); }
 py::array_t<float> get_color_map() { return py::array_t<float>(std::vector<py::ssize_t>{0, 6}); }
 py::dict get_graph_edges() { return py::dict(); }
 py::dict get_graph_meta() { return py::dict(); }
-// pointcloud_align (graph_utils.cpp:20-46, PCL GICP): the guess, with the reference's 50 m sanity reset of its translation
+// pointcloud_align (graph_utils.cpp:20-46): Generalized-ICP of two clouds from a guess, the guess's translation reset when it is 50 m or
+// more.  The reference calls PCL's GeneralizedIterativeClosestPoint (third-party, source not in the tree) with 20 neighbours, 64 iterations,
+// transformation epsilon 1e-2; here the same cost on the device (lio_gicp_*, the FastGICP formulation the reference's other GICP call
+// sites use) with those settings and PCL's default correspondence distance for that class (5 m).  Clouds too small for 20 neighbours, or
+// a failed alignment, return the (sanitised) guess.
 py::array_t<float> pointcloud_align(py::array_t<float>& source_point, py::array_t<float>& target_point, py::array_t<float>& guess) {
-    (void)source_point; (void)target_point;
     py::array_t<float> out({4, 4});
     auto o = out.mutable_unchecked<2>();
     auto gi = guess.unchecked<2>();
+    double G[16];
     for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) o(i, j) = gi(i, j);
-    const double d = std::sqrt((double)o(0, 3) * o(0, 3) + (double)o(1, 3) * o(1, 3) + (double)o(2, 3) * o(2, 3));
-    if (d >= 50.0) { o(0, 3) = 0; o(1, 3) = 0; o(2, 3) = 0; }
+        for (int j = 0; j < 4; j++) G[i * 4 + j] = (double)(float)gi(i, j);
+    const double d = std::sqrt(G[3] * G[3] + G[7] * G[7] + G[11] * G[11]);
+    if (d >= 50.0) { G[3] = 0; G[7] = 0; G[11] = 0; }
+    for (int i = 0; i < 16; i++) o(i / 4, i % 4) = (float)G[i];
+    auto src = py::array_t<float, py::array::c_style | py::array::forcecast>::ensure(source_point);
+    auto tgt = py::array_t<float, py::array::c_style | py::array::forcecast>::ensure(target_point);
+    if (!src || !tgt || src.ndim() != 2 || tgt.ndim() != 2 || src.shape(1) != 4 || tgt.shape(1) != 4 || src.shape(0) < 20 || tgt.shape(0) < 20) return out;
+    const uint32_t ns = (uint32_t)src.shape(0), nt = (uint32_t)tgt.shape(0);
+    lio_gicp* m = lio_gicp_create(0, 1.0f, std::max(ns, nt), 20);
+    if (!m) return out;
+    double T[16];
+    int it = 0, conv = 0;
+    lio_ndt_params prm;
+    lio_ndt_default_params(&prm);
+    prm.transformation_epsilon = 1e-2;
+    prm.rotation_epsilon_deg = 1e-2;
+    prm.max_iterations = 64;
+    prm.max_process_time_ms = -1;
+    int rc;
+    {
+        py::gil_scoped_release nogil;
+        rc = lio_gicp_set_target(m, tgt.data(), nt);
+        if (rc == LIO_OK) rc = lio_gicp_set_source(m, src.data(), ns);
+        if (rc == LIO_OK) rc = lio_gicp_align(m, G, &prm, 5.0, T, &it, &conv);
+        lio_gicp_destroy(m);
+    }
+    if (rc == LIO_OK)
+        for (int i = 0; i < 16; i++) o(i / 4, i % 4) = (float)T[i];
     return out;
 }
 void set_mapping_ground_constraint(bool enable) { if (g) g->ground_constraint = enable; }

@@ -244,3 +244,16 @@ def test_reference_hdl_fastlio_class_linked_against_the_library():
         assert np.abs(T.astype(np.float32) - o["pose"]["odom_matrix"]).max() < 1e-6, k   # the same engine behind both: same numbers
         if tb >= 0.85:
             assert n_imu >= 10 and np.isfinite(D).all()  # getPose's IMU prediction (fastlio.cpp:18-101) ran on the 200 Hz samples of the scan
+
+
+@pytest.mark.gpu
+def test_pointcloud_align_runs_gicp_on_the_device():
+    """slam_wrapper.pointcloud_align (graph_utils.cpp:20-46): Generalized-ICP from a guess -- here lio_gicp_* with the reference's settings"""
+    import gicp_cases
+    import slam_wrapper as sw
+
+    c = gicp_cases.make("room_small")
+    T = sw.pointcloud_align(c["source"], c["target"], c["guess"].astype(np.float32))
+    assert T.dtype == np.float32 and T.shape == (4, 4)
+    assert np.abs(T[:3, 3] - c["truth"][:3, 3]).max() < 0.01 and np.abs(T[:3, :3] - c["truth"][:3, :3]).max() < 2e-3
+    assert np.abs(c["guess"][:3, 3] - c["truth"][:3, 3]).max() > 0.1
