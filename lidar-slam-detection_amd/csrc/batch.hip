@@ -56,6 +56,8 @@ struct lio_batch {
     int use_graph = 1;    // LIO_BATCH_GRAPH=0: plain launches instead of one hipGraphLaunch per round
     int knn_kind = 0;     // LIO_BATCH_KNN=q: the one-lane-per-query kernel (knn_q.hip) instead of knn.hip's sixteen lanes per query
     std::vector<Group> groups;
+    double t_submit = 0, t_wait = 0, t_collect = 0;  // host seconds (LIO_BATCH_PROFILE=1 prints them when the object is destroyed)
+    uint64_t n_rounds = 0;
 };
 
 namespace {
@@ -68,7 +70,7 @@ void fill_desc(SlotDesc& d, lio_scan* sc, EskfDev* d_ctrl, lio_batch_result* d_r
     d.keys_a = sc->keys_a; d.keys_b = sc->keys_b; d.vals_a = sc->vals_a; d.vals_b = sc->vals_b;
     d.hist = sc->hist; d.blockcnt = sc->blockcnt; d.hpos = sc->hpos; d.longlist = sc->longlist; d.tie_list = sc->tie_list;
     d.sorted = sc->sorted; d.ds_body = sc->ds_body; d.ds_world = sc->ds_world; d.nn_pts = sc->nn_pts; d.normvec = sc->normvec;
-    d.nn_cnt = sc->nn_cnt; d.selected = sc->selected; d.partial = sc->partial;
+    d.nn_cnt = sc->nn_cnt; d.nn_meta = sc->nn_meta; d.selected = sc->selected; d.partial = sc->partial;
     d.host_nds = sc->host_nds_dev;
     d.ctrl = d_ctrl;
     d.result = d_res;
@@ -241,6 +243,9 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
 void lio_batch_destroy(lio_batch* b) {
     if (!b) return;
     hipSetDevice(b->device);
+    if (getenv("LIO_BATCH_PROFILE") && b->n_rounds)
+        fprintf(stderr, "lio_batch: %llu rounds of %d slots; host per round: submit %.1f us, wait %.1f us, collect %.1f us\n", (unsigned long long)b->n_rounds,
+                b->n_slots, 1e6 * b->t_submit / b->n_rounds, 1e6 * b->t_wait / b->n_rounds, 1e6 * b->t_collect / b->n_rounds);
     for (Group& g : b->groups) {
         if (g.stream) hipStreamSynchronize(g.stream);
         group_free(g);
@@ -336,9 +341,14 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
         if (need_max > 4) need_max = 4;
         b->pred_passes = need_max;
     };
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point c) { return std::chrono::duration<double>(c - a).count(); };
     for (size_t gi = 0; gi < b->groups.size() && next < n_jobs; gi++) {
         const int n = n_jobs - next < B ? n_jobs - next : B;
+        const auto t0 = clk::now();
         const int rc = submit(b, b->groups[gi], jobs, next, n, b->pred_passes);
+        b->t_submit += secs(t0, clk::now());
+        b->n_rounds++;
         if (rc != LIO_OK) return rc;
         next += n;
         inflight.push_back((int)gi);
@@ -347,15 +357,22 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
         const int gi = inflight.front();
         inflight.pop_front();
         Group& g = b->groups[gi];
+        const auto t0 = clk::now();
         if (g.n_active) {
             const int rc = wait_group(g, B);
             if (rc != LIO_OK) return rc;
         }
         if (g.bt && g.bt->on) { hipStreamSynchronize(g.stream); g.bt->resolve(); }
+        const auto t1 = clk::now();
         collect(g);
+        const auto t2 = clk::now();
+        b->t_wait += secs(t0, t1);
+        b->t_collect += secs(t1, t2);
         if (next < n_jobs) {
             const int n = n_jobs - next < B ? n_jobs - next : B;
             const int rc = submit(b, g, jobs, next, n, b->pred_passes);
+            b->t_submit += secs(t2, clk::now());
+            b->n_rounds++;
             if (rc != LIO_OK) return rc;
             next += n;
             inflight.push_back(gi);

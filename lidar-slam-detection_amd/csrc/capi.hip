@@ -279,6 +279,8 @@ int lio_map_stats(lio_map* m, uint64_t* n_points, uint64_t* n_voxels) {
     return rc;
 }
 
+void lio_debug_knn_reuse(int on) { lio::knn_set_reuse(on); }
+
 int lio_map_pool_stats(lio_map* m, uint64_t* pool_top, uint64_t* pool_cap) {
     if (!m) return LIO_E_INVALID;
     hipSetDevice(m->device);
@@ -373,7 +375,7 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
          dev_alloc(&s->nn_pts, (uint64_t)max_ds * 5, &s->bytes) && dev_alloc(&s->nn_cnt, max_ds, &s->bytes) && dev_alloc(&s->selected, max_ds, &s->bytes) &&
          dev_alloc(&s->normvec, max_ds, &s->bytes) && dev_alloc(&s->keys_a, max_raw, &s->bytes) && dev_alloc(&s->keys_b, max_raw, &s->bytes) &&
          dev_alloc(&s->vals_a, max_raw, &s->bytes) && dev_alloc(&s->vals_b, max_raw, &s->bytes) && dev_alloc(&s->hist, std::max<uint64_t>((uint64_t)256 * nblocks, 2 * (((uint64_t)max_ds + 255) / 256) + 2), &s->bytes) &&
-         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->tie_list, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
+         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->tie_list, max_ds, &s->bytes) && dev_alloc(&s->nn_meta, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
          dev_alloc(&s->dev, 1, &s->bytes) && dev_alloc(&s->d_result, 1, &s->bytes);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&s->host_dev), sizeof(ScanDev)) == hipSuccess &&
          hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(lio_normal_eq), hipHostMallocMapped) == hipSuccess &&
@@ -406,7 +408,7 @@ void lio_scan_destroy(lio_scan* s) {
     if (s->stream) hipStreamSynchronize(s->stream);
     hipFree(s->raw_own); hipFree(s->ds_body); hipFree(s->ds_world); hipFree(s->nn_pts); hipFree(s->nn_cnt); hipFree(s->selected);
     hipFree(s->normvec); hipFree(s->keys_a); hipFree(s->keys_b); hipFree(s->vals_a); hipFree(s->vals_b); hipFree(s->hist);
-    hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->tie_list); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
+    hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->tie_list); hipFree(s->nn_meta); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
     if (s->host_dev) hipHostFree(s->host_dev);
     if (s->h_result) hipHostFree(s->h_result);
     if (s->host_nds) hipHostFree(s->host_nds);

@@ -19,6 +19,10 @@
 #else
 #define EK_FN inline
 #endif
+#if defined(__HIP__) && defined(LIO_STEP_TRACE)
+static __device__ unsigned long long g_ek_trace[64];
+static __device__ unsigned long long g_ek_last;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 // on the device the filter pass is run by ONE wave (the first of the step kernel's workgroup): loops stride over its 64 lanes, a phase
 // boundary is a wave-level fence on LDS (a wave's LDS operations complete in order) -- no workgroup barrier inside the pass
@@ -30,7 +34,21 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
     } while (0)
 #define EK_LANE(k) ((int)threadIdx.x == (k))
+#ifdef LIO_STEP_TRACE  // diagnostic build only: cycle stamps of the filter pass's phases (workgroup 0, lane 0), see tools/experiments/step_trace.py
+#define EK_STAMP(k)                                                                          \
+    do {                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                           \
+            const unsigned long long now_ = __builtin_readcyclecounter();                    \
+            if ((k) > 0) g_ek_trace[(k)] += now_ - g_ek_last;                                \
+            else g_ek_trace[0] += 1;                                                         \
+            g_ek_last = now_;                                                                \
+        }                                                                                    \
+    } while (0)
 #else
+#define EK_STAMP(k) ((void)0)
+#endif
+#else
+#define EK_STAMP(k) ((void)0)
 #define EK_FOR(i, n) for (int i = 0; i < (n); i++)
 #define EK_SYNC() ((void)0)
 #define EK_LANE(k) (true)
@@ -624,12 +642,15 @@ EK_FN void ek_measure_tail(EskfDev& c, EkWork& w) {
 EK_FN void ek_step(EskfDev& c, EkWork& w) {
     constexpr int N = kEkN;
     const double R = c.R;
+    EK_STAMP(10);
     ek_boxminus_par(c.x, c.x_prop, w.dx);
     EK_SYNC();
+    EK_STAMP(11);
     ek_jacobians(c.x, c.x_prop, w.dx, w);
     EK_FOR(k, N) w.dx_new[k] = w.dx[k];
     EK_FOR(k, N * N) w.P[k] = c.P_prop[k];
     EK_SYNC();
+    EK_STAMP(12);
     if (EK_LANE(0)) {
         // the three blocks of dx_new are disjoint: one thread applies them in turn
         double v[3];
@@ -646,6 +667,7 @@ EK_FN void ek_step(EskfDev& c, EkWork& w) {
     ek_cols_mul_T(w.P, N, N, 6, 3, w.Jl); EK_SYNC();
     ek_rows_mul(w.P, N, N, 21, 2, w.Jg); EK_SYNC();
     ek_cols_mul_T(w.P, N, N, 21, 2, w.Jg); EK_SYNC();
+    EK_STAMP(13);
     // information form on the leading 6 x 6 block (see eskf.cpp): P_inv[:, 0:6] = (P / R)[:, 0:6] (I6 + HTH (P / R)_66)^-1
     EK_FOR(e, N * 6) { const int a = e / 6, col = e % 6; w.G[e] = w.P[a * N + col] / R; }
     EK_SYNC();
@@ -656,7 +678,9 @@ EK_FN void ek_step(EskfDev& c, EkWork& w) {
         w.M6[e] = v;
     }
     EK_SYNC();
+    EK_STAMP(14);
     ek_inverse6(w);
+    EK_STAMP(15);
     EK_FOR(e, N * 6) {
         const int a = e / 6, col = e % 6;
         double v = 0;
@@ -683,7 +707,9 @@ EK_FN void ek_step(EskfDev& c, EkWork& w) {
         w.dx_out[a] = s;
     }
     EK_SYNC();
+    EK_STAMP(16);
     ek_boxplus_par(c.x, w.dx_out);
+    EK_STAMP(17);
     {
         EkPassLog& pl = c.log[c.n_log < kEkMaxPass ? c.n_log : kEkMaxPass - 1];
         EK_FOR(k, N) pl.dx[k] = w.dx_out[k];
@@ -701,6 +727,7 @@ EK_FN void ek_step(EskfDev& c, EkWork& w) {
         c.i++;
     }
     EK_SYNC();
+    EK_STAMP(18);
     if (!w.flag[2]) {
         // like the reference's P_ member, the filter's covariance is left as this pass transformed it (it only matters if every
         // later pass turns out invalid; a later valid pass starts from P_prop again)
@@ -736,6 +763,7 @@ EK_FN void ek_step(EskfDev& c, EkWork& w) {
     }
     if (EK_LANE(0)) c.status = EK_DONE;
     EK_SYNC();
+    EK_STAMP(19);
 }
 
 // begin of an update: esekfom.hpp:1623-1634

@@ -36,6 +36,9 @@ namespace lio {
 #ifndef LIO_KNN_WAVES
 #define LIO_KNN_WAVES 1
 #endif
+#ifndef LIO_KNN_WAVES_FIRST
+#define LIO_KNN_WAVES_FIRST 7  // the first search of an update (no re-search code): 72 registers, seven waves per SIMD
+#endif
 #ifndef LIO_KNN_PRUNE
 #define LIO_KNN_PRUNE 1  // distance-ordered sweep with exact pruning of stencil voxels that cannot hold one of the five nearest
 #endif
@@ -59,6 +62,18 @@ __device__ inline uint32_t group_min32(uint32_t v) {
     } else {
 #pragma unroll
         for (int off = kG / 2; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, kG));
+    }
+    return v;
+}
+__device__ inline uint32_t group_max32(uint32_t v) {
+    if constexpr (kG == 16) {
+        v = max(v, dpp_row<0x128>(v));
+        v = max(v, dpp_row<0x124>(v));
+        v = max(v, dpp_row<0x122>(v));
+        v = max(v, dpp_row<0x121>(v));
+    } else {
+#pragma unroll
+        for (int off = kG / 2; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kG));
     }
     return v;
 }
@@ -89,7 +104,7 @@ struct __attribute__((aligned(16))) GroupLds {
 template <int KM>
 __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table, uint32_t mask, const StencilArgs& st, bool active, float4 pw,
                                                   float res, int kx, int ky, int kz, int gl, int lane, unsigned long long gmask, GroupLds& g,
-                                                  uint32_t& nhit_out, uint32_t& n0_out, uint32_t& n01_out) {
+                                                  uint32_t& nhit_out, uint32_t& n0_out, uint32_t& n01_out, uint32_t limit) {
     static_assert(KM <= 2, "bucketed probe: at most 2 cells per lane");
     uint4 raw[KM];
     BrickProbe bp[KM];
@@ -104,10 +119,12 @@ __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table
         dmin[k] = 0xFFFFFFFFu;
         if (active && s < st.n) {
             const int cx = kx + st.off[s][0], cy = ky + st.off[s][1], cz = kz + st.off[s][2];
-            want[k] = pack_key(cx, cy, cz);
-            bp[k] = brick_probe(cx, cy, cz);
-            raw[k] = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[k], mask)]);
             dmin[k] = cell_min_d2_bits(pw.x, pw.y, pw.z, cx, cy, cz, res);
+            if (dmin[k] <= limit) {  // `limit`: a known upper bound of the fifth-nearest distance -- a voxel that cannot reach it is not even probed
+                want[k] = pack_key(cx, cy, cz);
+                bp[k] = brick_probe(cx, cy, cz);
+                raw[k] = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[k], mask)]);
+            }
         }
     }
     const uint32_t b1 = __float_as_uint(0.0625f * res * res), b2 = __float_as_uint(0.25f * res * res);
@@ -305,12 +322,13 @@ __device__ __noinline__ uint32_t group_exact_redo(const GroupLds& g, uint32_t nh
 
 // MODE 0: queries are body-frame ds points of a scan (transformed here, world point stored);
 // MODE 1: queries are world-frame points (diagnostic lio_map_knn).
-template <int KM, int MODE, bool INLINE_TIE>
+template <int KM, int MODE, bool INLINE_TIE, bool REUSE = false>
 __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                          float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
                                          uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
                                          float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
-                                         MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
+                                         MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list,
+                                         uint4* __restrict__ nn_meta = nullptr, bool use_prev = false) {
     __shared__ GroupLds lds[kGPB];
     const int tid = threadIdx.x;
     const int grp = tid / kG, gl = tid % kG;
@@ -318,7 +336,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     GroupLds& g = lds[grp];
     const uint32_t n = sd ? sd->n_ds : n_host;
     const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
-    unsigned long long visited = 0;
+    uint32_t visited = 0;  // this lane's share of the candidate statistic (a few queries' stencils: far below 2^32)
     const float res = 1.0f / inv_res;
     const uint32_t b1_bits = __float_as_uint(0.0625f * res * res), b2_bits = __float_as_uint(0.25f * res * res);
     (void)b1_bits; (void)b2_bits;
@@ -347,8 +365,42 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         uint32_t nhit = 0;
         constexpr bool kPrune = LIO_KNN_PRUNE && KM <= 2;
         uint32_t n0 = 0, n01 = 0, total;
-        if constexpr (kPrune) total = probe_stencil_bucketed<KM>(table, mask, st, active, pw, res, kx, ky, kz, gl, lane, gmask, g, nhit, n0, n01);
+        // Re-search of a later filter pass (use_prev: the scan has been searched in this update, the map has not changed since): the
+        // query moved by centimetres.  If it is still in the voxel of the last full search -- same stencil, same candidate set -- the five
+        // neighbours found then are still candidates, so the largest of their distances to the NEW position bounds the fifth-nearest
+        // distance from above: voxels that cannot reach that bound are not probed at all (usually all but one or two of the nineteen).
+        // Exact: an unprobed voxel's points are strictly farther than five known candidates -- sets, ties and counts are what the full
+        // search returns (the bound must itself be in range, d2 < 5, for the in-range count to stay >= 5).
+        uint32_t limit = 0xFFFFFFFFu, stored_total = 0;
+        bool fast = false;
+        if constexpr (kPrune && MODE == 0 && REUSE) {
+            if (use_prev) {
+                if (active) {
+                    const uint4 mt = nn_meta[q];
+                    const unsigned long long key = pack_key(kx, ky, kz);
+                    fast = mt.w != 0u && mt.x == (uint32_t)key && mt.y == (uint32_t)(key >> 32);
+                    stored_total = mt.z;
+                }
+                uint32_t u = 0;
+                if (fast && gl < 5) {
+                    const float4 p = nn_pts[(size_t)gl * nn_stride + q];
+                    const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
+                    u = __float_as_uint(dx * dx + (dy * dy + dz * dz));
+                }
+                u = group_max32(u);
+                fast = fast && u < __float_as_uint(5.0f);
+                if (fast) limit = u;
+            }
+        }
+        if constexpr (kPrune) total = probe_stencil_bucketed<KM>(table, mask, st, active, pw, res, kx, ky, kz, gl, lane, gmask, g, nhit, n0, n01, limit);
         else total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
+        if (fast) total = stored_total;  // the statistic counts the stencil's residents (the reference algorithm's candidates), probed or not
+        if constexpr (kPrune && MODE == 0) {
+            if (nn_meta && active && !fast && gl == 0) {  // the record of this full search (w: set below once five neighbours are stored)
+                const unsigned long long key = pack_key(kx, ky, kz);
+                nn_meta[q] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), total, 0u);
+            }
+        }
         group_lds_sync();
         // every lane keeps its own ascending top-5 as (d2 bits, pool index) pairs, ordered by d2 alone: candidates with an
         // equal d2 keep their arrival order -- any such pair that reaches the global top-6 is an exact tie and the query
@@ -457,6 +509,9 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                 }
             }
         }
+        if constexpr (kPrune && MODE == 0) {
+            if (nn_meta && active && !fast && gl == 0 && inrange >= 5) nn_meta[q].w = 1u;  // five fresh neighbours: a later pass may start from them
+        }
         if constexpr (INLINE_TIE) {
             // no tie queue (batch form): the group redoes a tied query exactly right here, from the list it still holds, and overwrites
             // what it has just stored (the call sits behind the stores so that little is live across it)
@@ -470,9 +525,10 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     // statistics: one atomic per workgroup, spread over 64 counters that each own a 128-B line (same-line
     // atomics serialise in one L2 channel at ~10 ns apiece -- 9k of them used to cost more than the kernel)
     __shared__ unsigned long long vred[256 / 64];
+    unsigned long long vsum = visited;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) visited += __shfl_xor(visited, off);
-    if (lane == 0) vred[tid >> 6] = visited;
+    for (int off = 32; off > 0; off >>= 1) vsum += __shfl_xor(vsum, off);
+    if (lane == 0) vred[tid >> 6] = vsum;
     __syncthreads();
     if (tid == 0) {
         const unsigned long long v = (vred[0] + vred[1]) + (vred[2] + vred[3]);
@@ -490,16 +546,16 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
 }
 // the scans of a batch (lio_batch_*): blockIdx.y = slot; pose from the slot's device-resident filter; a slot whose update has finished,
 // or whose filter did not ask for a neighbour search this pass, exits at once
-template <int KM, bool INLINE_TIE>
-__global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
-                                                                       float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md) {
+template <int KM, bool INLINE_TIE, bool REUSE>
+__global__ void __launch_bounds__(256, REUSE ? LIO_KNN_WAVES : LIO_KNN_WAVES_FIRST) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                                       float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md, int reuse) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
     const EskfDev* c = d.ctrl;
     if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
     const PoseArgs pose = pose_from_state(c->x);
-    knn_body<KM, 0, INLINE_TIE>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md,
-                                INLINE_TIE ? nullptr : &d.sd->n_tie, INLINE_TIE ? nullptr : d.tie_list);
+    knn_body<KM, 0, INLINE_TIE, REUSE>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md,
+                                INLINE_TIE ? nullptr : &d.sd->n_tie, INLINE_TIE ? nullptr : d.tie_list, d.nn_meta, c->n_knn > 0 && reuse);
 }
 
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
@@ -592,25 +648,36 @@ __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __rest
 
 // tie_mode 0: tied queries are queued and redone by a second (usually empty) launch; 1: redone in place by their group -- one launch
 // less per pass, at 14 more vector registers (occupancy 5 instead of 6)
-int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode) {
+// 0: every search probes the whole stencil (LIO_KNN_REUSE=0 or lio_debug_knn_reuse(0); diagnostic -- the results are identical)
+static int g_knn_reuse = [] { const char* e = getenv("LIO_KNN_REUSE"); return (e && e[0] == '0') ? 0 : 1; }();
+void knn_set_reuse(int on) { g_knn_reuse = on ? 1 : 0; }
+
+int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode, int pass) {
     if (grid_x > 2048) grid_x = 2048;  // grid-stride loop inside: 16 queries per workgroup and round
     if (grid_x == 0) grid_x = 8;
     const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
     const dim3 gridx(64, (uint32_t)n_slots);
     const int km = (m->stencil.n + kG - 1) / kG;
-#define KNNB_LAUNCH(KM)                                                                                                                              \
-    do {                                                                                                                                             \
-        if (tie_mode == 1) {                                                                                                                         \
-            hipLaunchKernelGGL((knn_batch_kernel<KM, true>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev);  \
-        } else {                                                                                                                                     \
-            hipLaunchKernelGGL((knn_batch_kernel<KM, false>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
-            hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots);       \
-        }                                                                                                                                            \
+    const int reuse = g_knn_reuse;
+#define KNNB_LAUNCH1(KM, TIE, RE) \
+    hipLaunchKernelGGL((knn_batch_kernel<KM, TIE, RE>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev, reuse)
+    // pass 0 of an update always searches from scratch: the variant without the re-search code (fewer registers, one more wave per SIMD)
+#define KNNB_LAUNCH(KM)                                                                                                                            \
+    do {                                                                                                                                           \
+        if (tie_mode == 1) {                                                                                                                       \
+            if (pass > 0 && reuse) KNNB_LAUNCH1(KM, true, true);                                                                                   \
+            else KNNB_LAUNCH1(KM, true, false);                                                                                                    \
+        } else {                                                                                                                                   \
+            if (pass > 0 && reuse) KNNB_LAUNCH1(KM, false, true);                                                                                  \
+            else KNNB_LAUNCH1(KM, false, false);                                                                                                   \
+            hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots); \
+        }                                                                                                                                          \
     } while (0)
     if (km <= 1) KNNB_LAUNCH(1);
     else if (km <= 2) KNNB_LAUNCH(2);
     else if (km <= 3) KNNB_LAUNCH(3);
     else KNNB_LAUNCH((kMaxStencil + kG - 1) / kG);
+#undef KNNB_LAUNCH1
 #undef KNNB_LAUNCH
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;

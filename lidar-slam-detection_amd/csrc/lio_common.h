@@ -102,6 +102,7 @@ struct SlotDesc {
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *hist, *blockcnt, *hpos, *longlist, *tie_list;
     float4 *sorted, *ds_body, *ds_world, *nn_pts, *normvec;
     int32_t* nn_cnt;
+    uint4* nn_meta;          // per query: {voxel key lo, hi, stencil candidates, 1 if the search stored five neighbours} of the scan's last full search
     uint8_t* selected;
     double* partial;
     uint32_t* host_nds;      // mapped pinned words {n_ds, err, radix passes needed} of the slot's scan
@@ -182,6 +183,7 @@ struct lio_scan {
     uint32_t* hpos;      // first sorted position of every occupied voxel
     uint32_t* longlist;  // voxels with long runs
     uint32_t* tie_list;  // query indices with exact d2 ties
+    uint4* nn_meta;      // per query record of the scan's last full neighbour search (knn.hip: the re-search of a later filter pass starts from it)
     float4* sorted;      // raw points gathered into (voxel, input index) order
     double* partial;     // per-block partial sums
     uint32_t partial_blocks;
@@ -232,7 +234,8 @@ int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_s
 int vg_downsample(lio_scan* s, float leaf, int passes /* radix passes to launch, 1..4 */);
 int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes);
 int knn_q_batch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x);
-int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode);
+void knn_set_reuse(int on);
+int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode, int pass);
 int knn_q_world(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt);
 // live kernel timing of the batched chain (bench.py's roofline leg): HIP events on the stream the kernels are launched on, per class
 struct BatchTimer {

@@ -418,6 +418,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
     __shared__ double red6[kStepThreads / 64][6];
     const int tid = threadIdx.x;
     constexpr int kCoreWords = (int)(offsetof(EskfDev, log) / 8);
+    EK_STAMP(0);
     {
         const double* src = reinterpret_cast<const double*>(&cg);
         double* dst = reinterpret_cast<double*>(&c);
@@ -436,6 +437,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         if (comp < kAcc && l == 0) acc[comp] = s;
     }
     __syncthreads();
+    EK_STAMP(1);
     if (tid == 0) d.sd->n_tie = 0;  // the tie queue of this pass's neighbour search has been served (knn_exact_batch_kernel)
     const int log0 = c.n_log;
     if (skip) {
@@ -444,6 +446,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         ek_measure_head(c, w, acc, c.converge);
     }
     __syncthreads();
+    EK_STAMP(2);
     if (!skip && w.flag[1]) {  // the six degeneracy sums (laserMapping.cpp:946-964): every addend is a float in (0.1736, 1] widened to double,
                                // sums of < 2^17 of them are exact in f64 -> any reduction order gives the same bits
         double s6[6] = {0, 0, 0, 0, 0, 0};
@@ -474,12 +477,15 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         __syncthreads();
     }
     if (tid >= 64) return;
+    EK_STAMP(3);
     // ---- first wave only from here on ----
     if (!skip) {
         ek_measure_tail(c, w);
+        EK_STAMP(4);
         if (c.status == EK_RUNNING && w.flag[0]) ek_step(c, w);
     }
     EK_SYNC();
+    EK_STAMP(5);
     {   // write back: the filter, the log entries of this pass
         const double* src = reinterpret_cast<const double*>(&c);
         double* dst = reinterpret_cast<double*>(&cg);
@@ -493,6 +499,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
             for (int k = tid; k < kLogWords; k += 64) ld[k] = ls[k];
         }
     }
+    EK_STAMP(6);
     if (c.status != EK_RUNNING) {
         lio_batch_result* r = d.result;
         if (tid < 26) r->state[tid] = c.x[tid];
@@ -505,7 +512,17 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         EK_SYNC();
         if (tid == 0) *reinterpret_cast<volatile uint32_t*>(&r->seq) = d.seq;
     }
+    EK_STAMP(7);
 }
+
+#ifdef LIO_STEP_TRACE
+extern "C" int lio_debug_step_trace(unsigned long long* out64, int reset) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ek_trace), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ek_trace), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 // the whole iterated update of every slot, enqueued blind: (neighbour search if the filter asks for it, linearisation, filter pass) x
 // (maximum_iter + 1); slots that converge early skip the rest of the launches
@@ -519,7 +536,7 @@ int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, in
         if (bt) bt->begin(1);
         // knn_kind 0: sixteen lanes per query (knn.hip) + the exact redo of queued ties, 2: the same with ties redone in place,
         // 1: one lane per query (knn_q.hip)
-        const int rc = knn_kind == 1 ? knn_q_batch(m, st, d_slots, n_slots, knn_blocks) : knn_batch_launch(m, st, d_slots, n_slots, (ds_bound + 15) / 16, knn_kind == 2 ? 1 : 0);
+        const int rc = knn_kind == 1 ? knn_q_batch(m, st, d_slots, n_slots, knn_blocks) : knn_batch_launch(m, st, d_slots, n_slots, (ds_bound + 15) / 16, knn_kind == 2 ? 1 : 0, p);
         if (bt) bt->end(1);
         if (rc != LIO_OK) return rc;
         if (bt) bt->begin(2);

@@ -1,4 +1,4 @@
-"""The batched, device-resident engine (lio_batch_*: B scans per launch, four-lanes-per-query kNN, the filter loop of
+"""The batched, device-resident engine (lio_batch_*: B scans per launch, the batched 16-lanes-per-query kNN (and the selectable one-lane-per-query kernel of knn_q.hip), the filter loop of
 esekfom.hpp:1619-1931 on the device) against the oracle and against the per-scan engine it replaces in throughput mode."""
 import os
 import sys
@@ -165,3 +165,60 @@ def test_batch_sparse_scans_hand_over_to_the_host_filter(oracle_mod):
         assert res[0]["n_pass"] == len(lo) and res[0]["n_knn_pass"] == sum(p["knn"] for p in lo), (n_az, n_beams, res[0], len(lo))
         assert np.abs(res[0]["state"] - o.get_state()).max() < 1e-8
         del b
+
+
+def test_second_search_from_previous_neighbours_is_exact(oracle_mod):
+    """From the second neighbour search of an update on, a query still in the voxel of the last full search is searched only in the voxels
+    that can beat the neighbours found then (knn.hip).  Same scans through fresh Batch objects with the short cut on and off: states,
+    pass / search counts BIT-identical, and the candidate statistic (the stencil's residents, counted or carried over)
+    equal -- on scans whose prior is 0.3 m off (queries change voxel between searches: both paths run) and on sparse-map scans."""
+    _dev()
+    from lsd_amd import capi, lio
+
+    scene = scenes.config_scene()
+    for n_map, seeds in ((1_000_000, range(3100, 3112)), (60_000, range(3200, 3206))):
+        mp = scene.sample_surface(n_map, seed=4, sigma=0.01)
+        the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=1_000_000)
+        the_map.add(mp)
+        keep = []
+        jobs, meta = _jobs(scene, seeds, keep)
+        out = {}
+        for on in (1, 0):
+            capi.lib().lio_debug_knn_reuse(on)
+            try:
+                b = lio.Batch(the_map, n_slots=4, n_groups=2)
+                c0 = the_map.knn_candidates
+                rc, res = b.process(jobs)
+                assert rc == 0
+                out[on] = (res, the_map.knn_candidates - c0)
+                del b
+            finally:
+                capi.lib().lio_debug_knn_reuse(1)
+        (ra, ca), (rb, cb) = out[1], out[0]
+        assert ca == cb, (ca, cb)
+        n_two = 0
+        for a, c in zip(ra, rb):
+            assert (a["rc"], a["n_ds"], a["n_pass"], a["n_knn_pass"]) == (c["rc"], c["n_ds"], c["n_pass"], c["n_knn_pass"])
+            assert np.array_equal(a["state"], c["state"])
+            n_two += a["n_knn_pass"] >= 2
+        assert n_two >= len(ra) // 2  # the short cut had something to do
+    # and through the single-scan engine (device loop)
+    eng = lio.Engine(max_raw=1 << 18, max_ds=100000, shared_map=the_map)
+    eng.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+    states = {}
+    for on in (1, 0):
+        capi.lib().lio_debug_knn_reuse(on)
+        try:
+            e2 = lio.Engine(max_raw=1 << 18, max_ds=100000, shared_map=the_map)
+            e2.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+            st = []
+            for k, j in enumerate(jobs):
+                e2.set_state(j["state"])
+                e2.set_cov(lio.init_cov())
+                assert e2.process_scan_device(j["dptr"], j["n"], 1.0 + 0.1 * k) == 3
+                st.append((e2.get_state(), e2.get_cov()))
+            states[on] = st
+        finally:
+            capi.lib().lio_debug_knn_reuse(1)
+    for (sa, pa), (sb, pb) in zip(states[1], states[0]):
+        assert np.array_equal(sa, sb) and np.array_equal(pa, pb)

@@ -1,7 +1,7 @@
 """The device-resident form of the iterated ESKF update (csrc/eskf_dev.h: the pass as data-parallel phases, one workgroup per scan
 on the GPU) compiled for the HOST and driven by the same Python measurement models as the host filter (lio_eskf_update_cb, which
 tests/test_ikfom_vs_ref.py pins to the reference's own IKFoM code) and, when it is built, as the reference filter itself.
-Same convergence decisions, states and covariances to rounding.  CPU only; the GPU runs this very source (tests/test_device_loop_gpu.py)."""
+Same convergence decisions, states and covariances to rounding.  CPU only; the GPU runs this very source (tests/test_batch_gpu.py, and every -m gpu test that calls lio_engine_update)."""
 import numpy as np
 import pytest
 
