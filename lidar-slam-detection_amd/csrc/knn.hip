@@ -345,9 +345,13 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     // with its own L2.  Consecutive queries are spatial neighbours that share most of their candidate voxels, so
     // every XCD gets one CONTIGUOUS eighth of the queries (gridDim.x is a multiple of 8): the shared voxels are then
     // fetched into one L2 instead of up to eight.  Placement only affects speed, never results.
-    const uint32_t per_xcd = gridDim.x >> 3;
-    const uint32_t vb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    for (uint32_t q0 = vb * kGPB; q0 < n; q0 += gridDim.x * kGPB) {
+    // The eighths are eighths of the QUERIES, not of the grid: a launch sized for the largest scan it may meet (the batched form) must
+    // not leave the XCDs with the high block numbers idle.
+    const uint32_t nblk = (n + kGPB - 1) / kGPB;       // query blocks of this scan
+    const uint32_t per_xcd = (nblk + 7u) >> 3;         // ... per XCD, contiguous
+    const uint32_t wg_per_xcd = gridDim.x >> 3;        // workgroups of this launch on one XCD: they stride over its share
+    for (uint32_t j = blockIdx.x >> 3; j < per_xcd; j += wg_per_xcd) {
+        const uint32_t q0 = ((blockIdx.x & 7u) * per_xcd + j) * kGPB;
         const uint32_t q = q0 + grp;
         const bool active = q < n;
         float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -412,18 +416,25 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         bool drop_tie = false;
         // voxel-major sweep: kU voxel descriptors per batch come back from LDS as ds_read_b128 pairs, lane l takes point l
         // (l+32, ...) of each -- addresses are base + lane (no per-candidate search), kU 16-B loads in flight per lane
+        uint32_t bound5 = 0xFFFFFFFFu;
+        bool need_bound = true;  // group-uniform: a lane of the group has taken a candidate since the bound was last computed
         for (uint32_t s0 = 0; s0 < nhit; s0 += kU) {
             uint32_t ptr4[kU], cnt4[kU];
             uint32_t cmax = 0;
-            uint32_t bound5 = 0xFFFFFFFFu;
+            bool ins = false;
             if constexpr (kPrune) {
                 // exact pruning: a voxel whose nearest possible point is farther than five candidates already seen cannot change the
                 // five nearest (nor tie with the fifth: the comparison is strict); the list is in distance buckets, so once the bound
-                // is below the floor of the bucket the next batch starts in, nothing that follows can matter either
+                // is below the floor of the bucket the next batch starts in, nothing that follows can matter either -- and if none of
+                // the voxels still listed can reach the bound the sweep ends here (the usual case after the first batch: one bound
+                // computation per query instead of one per batch of four listed voxels)
                 if (s0 > 0) {
-                    bound5 = fifth_bound(d0, d4);
+                    if (need_bound) bound5 = fifth_bound(d0, d4);
                     const uint32_t floor_bits = s0 < n0 ? 0u : (s0 < n01 ? b1_bits : b2_bits);
                     if (bound5 < floor_bits) break;
+                    const uint32_t r0 = s0 + gl, r1 = r0 + kG;
+                    const bool mine = (r0 < nhit && g.v_dmin[r0] <= bound5) || (r1 < nhit && g.v_dmin[r1] <= bound5);
+                    if (!(__ballot(mine) & gmask)) break;
                 }
             }
 #pragma unroll
@@ -455,6 +466,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                         inrange++;
                         const uint32_t kd = __float_as_uint(d2);  // d2 >= 0: float order == unsigned order of the bits
                         if (kd < d4) {
+                            ins = true;
                             const uint32_t id = ptr4[u] + i0;
                             const bool c0 = kd < d0, c1 = kd < d1, c2 = kd < dd2, c3 = kd < d3;
                             i4d = c3 ? i3d : id;
@@ -473,6 +485,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                     }
                 }
             }
+            if constexpr (kPrune) need_bound = (__ballot(ins) & gmask) != 0;
         }
         if (gl == 0) visited += total;
         inrange = group_sum32(inrange);

@@ -259,9 +259,12 @@ __device__ __forceinline__ void knn_q_body(const Slot* __restrict__ table, uint3
     const float res = 1.0f / inv_res;
     unsigned long long visited = 0;
     // XCD-aware workgroup -> query mapping (see knn.hip): gridDim.x is a multiple of 8, XCD b % 8 gets one contiguous eighth
-    const uint32_t per_xcd = gridDim.x >> 3;
-    const uint32_t vb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    for (uint32_t q0 = vb * kQWave; q0 < n; q0 += gridDim.x * kQWave) {
+    // (eighths of the queries, not of the grid: the launch is sized for the largest scan it may meet)
+    const uint32_t nblk = (n + kQWave - 1) / kQWave;
+    const uint32_t per_xcd = (nblk + 7u) >> 3;
+    const uint32_t wg_per_xcd = gridDim.x >> 3;
+    for (uint32_t j = blockIdx.x >> 3; j < per_xcd; j += wg_per_xcd) {
+        const uint32_t q0 = ((blockIdx.x & 7u) * per_xcd + j) * kQWave;
         const uint32_t q = q0 + lane;
         const bool active = q < n;
         float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
