@@ -34,7 +34,7 @@ namespace lio {
 #define LIO_KNN_U 4
 #endif
 #ifndef LIO_KNN_WAVES
-#define LIO_KNN_WAVES 1
+#define LIO_KNN_WAVES 7  // 72 registers: seven waves per SIMD (two registers spill in the cold tail; measured 2 % faster than six)
 #endif
 #ifndef LIO_KNN_WAVES_FIRST
 #define LIO_KNN_WAVES_FIRST 7  // the first search of an update (no re-search code): 72 registers, seven waves per SIMD

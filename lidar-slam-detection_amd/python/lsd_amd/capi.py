@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblio_hip.so")
+LIB_PATH = os.environ.get("LIO_HIP_LIB") or os.path.join(_HERE, "liblio_hip.so")  # LIO_HIP_LIB: a variant build (tools/experiments)
 
 LIO_OK, LIO_E_INVALID, LIO_E_CAPACITY, LIO_E_DEVICE, LIO_E_STATE = 0, -1, -2, -3, -4
 MAIN_FIRST_SCAN, MAIN_SEEDED, MAIN_SKIPPED, MAIN_UPDATED, MAIN_IMU_INIT, MAIN_IDLE = 0, 1, 2, 3, 4, 5  # lio_fastlio_main
