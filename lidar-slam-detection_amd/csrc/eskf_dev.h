@@ -24,16 +24,16 @@ static __device__ unsigned long long g_ek_trace[64];
 static __device__ unsigned long long g_ek_last;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-// on the device the filter pass is run by ONE wave (the first of the step kernel's workgroup): loops stride over its 64 lanes, a phase
+// on the device a phase of the filter pass is run by ONE wave of the step kernel's workgroup (any one): loops stride over its 64 lanes, a phase
 // boundary is a wave-level fence on LDS (a wave's LDS operations complete in order) -- no workgroup barrier inside the pass
-#define EK_FOR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
+#define EK_FOR(i, n) for (int i = (int)(threadIdx.x & 63u); i < (n); i += 64)
 #define EK_SYNC()                                                  \
     do {                                                           \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
         __builtin_amdgcn_wave_barrier();                           \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
     } while (0)
-#define EK_LANE(k) ((int)threadIdx.x == (k))
+#define EK_LANE(k) ((int)(threadIdx.x & 63u) == (k))
 #ifdef LIO_STEP_TRACE  // diagnostic build only: cycle stamps of the filter pass's phases (workgroup 0, lane 0), see tools/experiments/step_trace.py
 #define EK_STAMP(k)                                                                          \
     do {                                                                                     \
@@ -637,9 +637,12 @@ EK_FN void ek_measure_tail(EskfDev& c, EkWork& w) {
     EK_SYNC();
 }
 
-// Eskf::step (eskf.cpp): one pass of the iterated update with a valid measurement in w.HTH / w.HTh.  Works on w.xn / w.P
-// (loaded from the control block by the caller) and stores the results back.
-EK_FN void ek_step(EskfDev& c, EkWork& w) {
+// Eskf::step (eskf.cpp): one pass of the iterated update with a valid measurement in w.HTH / w.HTh, in two parts.
+// ek_step_prep is everything that does NOT depend on the measurement -- boxminus of the iterate against the propagated state, the
+// manifold Jacobians, P <- J P_prop J^T, (P / R)[:, 0:6] -- so the step kernel runs it on a second wave WHILE the first one folds the
+// partial sums and decides about the measurement; ek_step_solve is the rest.  ek_step = prep, then solve (the host, and the order of
+// every floating-point operation, are those of the one-piece form).
+EK_FN void ek_step_prep(const EskfDev& c, EkWork& w) {
     constexpr int N = kEkN;
     const double R = c.R;
     EK_STAMP(10);
@@ -668,9 +671,13 @@ EK_FN void ek_step(EskfDev& c, EkWork& w) {
     ek_rows_mul(w.P, N, N, 21, 2, w.Jg); EK_SYNC();
     ek_cols_mul_T(w.P, N, N, 21, 2, w.Jg); EK_SYNC();
     EK_STAMP(13);
-    // information form on the leading 6 x 6 block (see eskf.cpp): P_inv[:, 0:6] = (P / R)[:, 0:6] (I6 + HTH (P / R)_66)^-1
     EK_FOR(e, N * 6) { const int a = e / 6, col = e % 6; w.G[e] = w.P[a * N + col] / R; }
     EK_SYNC();
+}
+
+EK_FN void ek_step_solve(EskfDev& c, EkWork& w) {
+    constexpr int N = kEkN;
+    // information form on the leading 6 x 6 block (see eskf.cpp): P_inv[:, 0:6] = (P / R)[:, 0:6] (I6 + HTH (P / R)_66)^-1  (w.G from the prep)
     EK_FOR(e, 36) {
         const int a = e / 6, col = e % 6;
         double v = (a == col) ? 1.0 : 0.0;
@@ -764,6 +771,11 @@ EK_FN void ek_step(EskfDev& c, EkWork& w) {
     if (EK_LANE(0)) c.status = EK_DONE;
     EK_SYNC();
     EK_STAMP(19);
+}
+
+EK_FN void ek_step(EskfDev& c, EkWork& w) {
+    ek_step_prep(c, w);
+    ek_step_solve(c, w);
 }
 
 // begin of an update: esekfom.hpp:1623-1634

@@ -419,31 +419,43 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
     const int tid = threadIdx.x;
     constexpr int kCoreWords = (int)(offsetof(EskfDev, log) / 8);
     EK_STAMP(0);
-    {
-        const double* src = reinterpret_cast<const double*>(&cg);
-        double* dst = reinterpret_cast<double*>(&c);
-        for (int k = tid; k < kCoreWords; k += kStepThreads) dst[k] = src[k];
-    }
+    // the scan's size first: the loads of the partial sums depend on it, the copy of the filter does not -- both are then in flight together
     const uint32_t n = d.sd->n_ds;
     const bool skip = (d.sd->err & 1u) || n < d.min_ds;  // more voxels than max_ds / too few points (laserMapping.cpp:1246): nothing is registered
     const uint32_t nb = (n + kLinThreads - 1) / kLinThreads;
-    if (!skip) {
-        const int comp = tid >> 5, l = tid & 31;
+    {
+        const double* src = reinterpret_cast<const double*>(&cg);
+        double* dst = reinterpret_cast<double*>(&c);
+        double v0 = 0, v1 = 0;
+        const int k0 = tid, k1 = tid + kStepThreads;
+        if (k0 < kCoreWords) v0 = src[k0];
+        if (k1 < kCoreWords) v1 = src[k1];
+        static_assert(kCoreWords <= 2 * kStepThreads, "filter core: two words per thread");
         double s = 0.0;
-        if (comp < kAcc)
+        const int comp = tid >> 5, l = tid & 31;
+        if (!skip && comp < kAcc)
             for (uint32_t b = l; b < nb; b += 32) s += d.partial[(size_t)b * kAcc + comp];
+        if (k0 < kCoreWords) dst[k0] = v0;
+        if (k1 < kCoreWords) dst[k1] = v1;
+        if (!skip) {
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (comp < kAcc && l == 0) acc[comp] = s;
+            for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (comp < kAcc && l == 0) acc[comp] = s;
+        }
     }
     __syncthreads();
     EK_STAMP(1);
     if (tid == 0) d.sd->n_tie = 0;  // the tie queue of this pass's neighbour search has been served (knn_exact_batch_kernel)
     const int log0 = c.n_log;
+    // Wave 0 decides about the measurement (validity, degeneracy) while wave 1 prepares everything of the filter step that does not
+    // depend on it (boxminus, manifold Jacobians, P <- J P J^T: the transcendental-heavy half of the pass).
     if (skip) {
         if (tid == 0) c.status = EK_SKIPPED;
     } else if (tid < 64) {
         ek_measure_head(c, w, acc, c.converge);
+        if (!w.flag[1]) ek_measure_tail(c, w);  // the usual case: no degeneracy sums needed, everything about the measurement is settled here
+    } else if (tid < 128) {
+        ek_step_prep(c, w);
     }
     __syncthreads();
     EK_STAMP(2);
@@ -475,15 +487,12 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
             w.cs[tid] = v;
         }
         __syncthreads();
+        if (tid < 64) ek_measure_tail(c, w);
     }
     if (tid >= 64) return;
     EK_STAMP(3);
     // ---- first wave only from here on ----
-    if (!skip) {
-        ek_measure_tail(c, w);
-        EK_STAMP(4);
-        if (c.status == EK_RUNNING && w.flag[0]) ek_step(c, w);
-    }
+    if (!skip && c.status == EK_RUNNING && w.flag[0]) ek_step_solve(c, w);
     EK_SYNC();
     EK_STAMP(5);
     {   // write back: the filter, the log entries of this pass
