@@ -452,6 +452,15 @@ lio_gicp* lio_gicp_create(int device, float grid_resolution, uint32_t max_points
 void lio_gicp_destroy(lio_gicp*);
 int lio_gicp_set_target(lio_gicp*, const float* xyzi, uint32_t n);
 int lio_gicp_set_source(lio_gicp*, const float* xyzi, uint32_t n);
+/* The voxelised variant, fast_gicp::FastVGICP (fast_vgicp_impl.hpp:72-204; select_registration_method("FAST_VGICP"), registrations.cpp:56-66:
+ * the reference's matcher on machines without CUDA): voxel_resolution > 0 turns the target into Gaussian voxels (mean position, mean of the
+ * points' regularised 20-NN covariances: ADDITIVE mode, fast_vgicp_voxel.hpp:95-110,129-167) and lio_gicp_linearize / _align into its
+ * update_correspondences / linearize / compute_error: a source point corresponds to the voxel its transformed position falls in
+ * (search_method 1 = DIRECT1, the reference's default; 7, 27: the neighbours too), weight sqrt(points in the voxel); max_corr_dist is not
+ * used.  0 = back to the kd-tree form.  The resolution should be exactly representable in f32 (the reference's 1.0 is). */
+int lio_gicp_set_voxel_mode(lio_gicp*, double voxel_resolution, int search_method);
+/* diagnostic: the Gaussian voxel of the target holding point p -> number of points (0: none), mean[3], covariance (xx, xy, xz, yy, yz, zz) */
+int lio_gicp_voxel_at(lio_gicp*, const float p[3], double mean[3], double cov6[6]);
 int lio_gicp_download(lio_gicp*, int which, float* xyzi, double* cov6, uint32_t cap);
 int lio_gicp_correspondences(lio_gicp*, int32_t* corr, uint32_t cap);
 int lio_gicp_linearize(lio_gicp*, const double T[16], double max_corr_dist, int update_corr, int with_derivatives, double H[36], double b[6], double* err,

@@ -18,6 +18,8 @@
 // U diag(1, 1, 1e-3) V^T = I - (1 - 1e-3) v0 v0^T for a symmetric positive semi-definite covariance.
 #include <sched.h>
 
+#include <vector>
+
 #include "hashgrid.h"
 #include "lio_common.h"
 #include "lsq.h"
@@ -33,16 +35,21 @@ struct GicpXform {
     float Rf[9], tf[3];  // trans.cast<float>()
 };
 
-__device__ inline bool grid_find(const Slot* __restrict__ table, uint32_t mask, int cx, int cy, int cz, uint32_t& ptr, uint32_t& cnt) {
+__device__ inline bool grid_find_slot(const Slot* __restrict__ table, uint32_t mask, int cx, int cy, int cz, uint32_t& ptr, uint32_t& cnt, uint32_t& slot) {
     const unsigned long long want = pack_key(cx, cy, cz);
     BrickProbe bp = brick_probe(cx, cy, cz);
     for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
-        const Slot sl = table[brick_slot(bp, mask)];
-        if (sl.key == want) { ptr = sl.ptr; cnt = sl.cnt; return cnt > 0; }
+        const uint32_t h = brick_slot(bp, mask);
+        const Slot sl = table[h];
+        if (sl.key == want) { ptr = sl.ptr; cnt = sl.cnt; slot = h; return cnt > 0; }
         if (sl.key == kEmptyKey) return false;
         brick_next(bp);
     }
     return false;
+}
+__device__ inline bool grid_find(const Slot* __restrict__ table, uint32_t mask, int cx, int cy, int cz, uint32_t& ptr, uint32_t& cnt) {
+    uint32_t slot;
+    return grid_find_slot(table, mask, cx, cy, cz, ptr, cnt, slot);
 }
 
 // k nearest neighbours of every point of the cloud within the cloud itself (the point is its own nearest), their covariance, PLANE
@@ -224,6 +231,142 @@ __global__ void __launch_bounds__(kGicpThreads) gicp_cost_kernel(const float4* _
     }
 }
 
+
+// ---- the voxelised variant: fast_gicp::FastVGICP (fast_vgicp_impl.hpp:72-204, fast_vgicp_voxel.hpp:125-182) ----------------------------
+// Target = Gaussian voxels of `voxel_resolution` (key floor(x / res - 0.5) in f64): mean of the points' positions and mean of their
+// (regularised, 20-NN) covariances, ADDITIVE mode; a source point corresponds to the voxel(s) its transformed position falls in (DIRECT1:
+// that voxel; DIRECT7 / 27: its neighbours too), weight sqrt(points in the voxel), Mahalanobis matrix (C_voxel + R C_A R^T)^-1.
+struct __attribute__((aligned(16))) VgicpVoxel {
+    double mean[3];
+    double cov[6];
+    double n;
+};
+struct VgicpOffsets {
+    int n;
+    int off[27][3];
+};
+
+// stamp: the voxel map's copy of the target carries the point's index in the k-NN grid's pool order (where its covariance lies)
+__global__ void __launch_bounds__(256) vgicp_stamp_kernel(const float4* __restrict__ in, float4* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    out[i] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
+}
+
+// AdditiveGaussianVoxel::append / finalize: one lane per occupied voxel, its points in pool order
+__global__ void __launch_bounds__(256) vgicp_fold_kernel(const Slot* __restrict__ table, uint32_t table_cap, const float4* __restrict__ pool,
+                                                         const double* __restrict__ tcov, VgicpVoxel* __restrict__ vox) {
+    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    if (h >= table_cap) return;
+    const Slot s = table[h];
+    if (s.key == kEmptyKey || s.cnt == 0) return;
+    double m[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t j = 0; j < s.cnt; j++) {
+        const float4 p = pool[s.ptr + j];
+        m[0] += (double)p.x; m[1] += (double)p.y; m[2] += (double)p.z;
+        const double* pc = tcov + (size_t)__float_as_uint(p.w) * 6;
+#pragma unroll
+        for (int a = 0; a < 6; a++) c[a] += pc[a];
+    }
+    const double n = (double)s.cnt;
+    VgicpVoxel v;
+    for (int a = 0; a < 3; a++) v.mean[a] = m[a] / n;
+    for (int a = 0; a < 6; a++) v.cov[a] = c[a] / n;
+    v.n = n;
+    vox[h] = v;
+}
+
+__device__ inline void gicp_transform_d(const GicpXform& X, const float4 a, double ta[3]) {
+    const double ax = (double)a.x, ay = (double)a.y, az = (double)a.z;
+    ta[0] = (X.R[0] * ax + X.R[1] * ay) + (X.R[2] * az + X.t[0]);
+    ta[1] = (X.R[3] * ax + X.R[4] * ay) + (X.R[5] * az + X.t[1]);
+    ta[2] = (X.R[6] * ax + X.R[7] * ay) + (X.R[8] * az + X.t[2]);
+}
+__device__ inline void gicp_mahalanobis(const double* __restrict__ ca, const double* __restrict__ cb, const GicpXform& X, double* __restrict__ o) {
+    const double A[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
+    double RA[9], M[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { double s = 0; for (int k2 = 0; k2 < 3; k2++) s += X.R[r * 3 + k2] * A[k2 * 3 + c]; RA[r * 3 + c] = s; }
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { double s = 0; for (int k2 = 0; k2 < 3; k2++) s += RA[r * 3 + k2] * X.R[c * 3 + k2]; M[r * 3 + c] = s; }
+    M[0] += cb[0]; M[1] += cb[1]; M[2] += cb[2]; M[3] += cb[1]; M[4] += cb[3]; M[5] += cb[4]; M[6] += cb[2]; M[7] += cb[4]; M[8] += cb[5];
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id;
+    o[1] = (M[2] * M[7] - M[1] * M[8]) * id;
+    o[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    o[3] = (M[0] * M[8] - M[2] * M[6]) * id;
+    o[4] = (M[2] * M[3] - M[0] * M[5]) * id;
+    o[5] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+// update_correspondences (:72-116): one lane per (source point, neighbour offset)
+__global__ void __launch_bounds__(kGicpThreads) vgicp_corr_kernel(const Slot* __restrict__ vtable, uint32_t vmask, const VgicpVoxel* __restrict__ vox, double vres,
+                                                                  const float4* __restrict__ spool, const double* __restrict__ scov, uint32_t n_src,
+                                                                  VgicpOffsets offs, GicpXform X, int32_t* __restrict__ corr, double* __restrict__ maha) {
+    const uint32_t e = blockIdx.x * kGicpThreads + threadIdx.x;
+    if (e >= n_src * (uint32_t)offs.n) return;
+    const uint32_t i = e / (uint32_t)offs.n, o = e % (uint32_t)offs.n;
+    double ta[3];
+    gicp_transform_d(X, spool[i], ta);
+    const int cx = (int)floor(ta[0] / vres - 0.5) + offs.off[o][0], cy = (int)floor(ta[1] / vres - 0.5) + offs.off[o][1],
+              cz = (int)floor(ta[2] / vres - 0.5) + offs.off[o][2];
+    uint32_t ptr, cnt, slot;
+    if (!grid_find_slot(vtable, vmask, cx, cy, cz, ptr, cnt, slot)) { corr[e] = -1; return; }
+    corr[e] = (int32_t)slot;
+    gicp_mahalanobis(scov + (size_t)i * 6, vox[slot].cov, X, maha + (size_t)e * 6);
+}
+
+// linearize (:118-180) / compute_error (:182-204) on the cached voxel correspondences
+template <bool DERIV>
+__global__ void __launch_bounds__(kGicpThreads) vgicp_cost_kernel(const VgicpVoxel* __restrict__ vox, const float4* __restrict__ spool, uint32_t n_src, int n_off,
+                                                                  const int32_t* __restrict__ corr, const double* __restrict__ maha, GicpXform X,
+                                                                  double* __restrict__ partial) {
+    const uint32_t e = blockIdx.x * kGicpThreads + threadIdx.x;
+    double acc[kGicpAcc];
+#pragma unroll
+    for (int a = 0; a < kGicpAcc; a++) acc[a] = 0.0;
+    if (e < n_src * (uint32_t)n_off && corr[e] >= 0) {
+        const VgicpVoxel v = vox[corr[e]];
+        double ta[3];
+        gicp_transform_d(X, spool[e / (uint32_t)n_off], ta);
+        const double er[3] = {v.mean[0] - ta[0], v.mean[1] - ta[1], v.mean[2] - ta[2]};
+        const double* m = maha + (size_t)e * 6;
+        const double M[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]};
+        const double w = sqrt(v.n);
+        double Me[3];
+        for (int r = 0; r < 3; r++) Me[r] = M[r * 3] * er[0] + M[r * 3 + 1] * er[1] + M[r * 3 + 2] * er[2];
+        acc[27] = w * (er[0] * Me[0] + er[1] * Me[1] + er[2] * Me[2]);
+        acc[28] = 1.0;
+        if (DERIV) {
+            double J[18] = {0, -ta[2], ta[1], -1, 0, 0, ta[2], 0, -ta[0], 0, -1, 0, -ta[1], ta[0], 0, 0, 0, -1};
+            double MJ[18];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 6; c++) MJ[r * 6 + c] = M[r * 3] * J[c] + M[r * 3 + 1] * J[6 + c] + M[r * 3 + 2] * J[12 + c];
+            int t = 0;
+            for (int r = 0; r < 6; r++)
+                for (int c = r; c < 6; c++) acc[t++] = w * (J[r] * MJ[c] + J[6 + r] * MJ[6 + c] + J[12 + r] * MJ[12 + c]);
+            for (int r = 0; r < 6; r++) acc[21 + r] = w * (J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2]);
+        }
+    }
+    __shared__ double red[kGicpThreads / 64][kGicpAcc];
+#pragma unroll
+    for (int a = 0; a < kGicpAcc; a++) {
+        double v = acc[a];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kGicpAcc) {
+        double v = 0.0;
+        for (int w2 = 0; w2 < kGicpThreads / 64; w2++) v += red[w2][threadIdx.x];
+        partial[(size_t)blockIdx.x * kGicpAcc + threadIdx.x] = v;
+    }
+}
+
 struct GicpReport {
     double acc[kGicpAcc];
     uint32_t seq, pad;
@@ -264,6 +407,16 @@ struct lio_gicp {
     GicpReport* report_dev = nullptr;
     uint32_t seq = 0;
     float4* stage = nullptr;
+    // voxelised variant (FastVGICP): off while voxel_res == 0
+    double voxel_res = 0.0;
+    VgicpOffsets offs;
+    lio_map* vmap = nullptr;       // the target's Gaussian voxels: hash grid keyed as fast_vgicp_voxel.hpp does
+    VgicpVoxel* vvox = nullptr;    // one record per table slot
+    bool vmap_valid = false;
+    int32_t* vcorr = nullptr;      // [n_src x offsets]
+    double* vmaha = nullptr;
+    double* vpartial = nullptr;
+    uint32_t vblocks = 0;
 };
 
 namespace {
@@ -294,9 +447,33 @@ int gicp_set_cloud(lio_gicp* g, int which, const float* xyzi, uint32_t n) {
     int rc = lio_map_insert_device(m, g->stage, n, 0.0);
     if (rc != LIO_OK) return rc;
     g->n[which] = n;
+    if (which == 0) g->vmap_valid = false;
     hipLaunchKernelGGL(gicp_cov_kernel, (n + kGicpThreads - 1) / kGicpThreads, kGicpThreads, 0, st, m->table, m->table_mask, m->pool, n, g->res, g->k, g->cov[which]);
     LIO_HIP_TRY(hipGetLastError());
     LIO_HIP_TRY(hipStreamSynchronize(st));
+    return LIO_OK;
+}
+
+// create_voxelmap (fast_vgicp_voxel.hpp:129-162) of the current target: built on first use after the target or the mode changed
+int vgicp_build(lio_gicp* g) {
+    lio_map* mt = g->grid[0];
+    hipStream_t st = mt->stream;
+    const uint32_t n = g->n[0];
+    if (g->vmap) { lio_map_destroy(g->vmap); g->vmap = nullptr; }
+    if (g->vvox) { hipFree(g->vvox); g->vvox = nullptr; }
+    g->vmap = lio_map_create(g->device, (float)g->voxel_res, g->max_points, g->max_points, 1);
+    if (!g->vmap) return LIO_E_DEVICE;
+    g->vmap->key_mode = 2;
+    LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->vvox), (size_t)g->vmap->table_cap * sizeof(VgicpVoxel)));
+    hipLaunchKernelGGL(vgicp_stamp_kernel, (n + 255) / 256, 256, 0, st, mt->pool, g->stage, n);
+    LIO_HIP_TRY(hipStreamSynchronize(st));
+    const int rc = lio_map_insert_device(g->vmap, g->stage, n, 0.0);
+    if (rc != LIO_OK) return rc;
+    hipLaunchKernelGGL(vgicp_fold_kernel, (g->vmap->table_cap + 255) / 256, 256, 0, g->vmap->stream, g->vmap->table, g->vmap->table_cap, g->vmap->pool, g->cov[0],
+                       g->vvox);
+    LIO_HIP_TRY(hipGetLastError());
+    LIO_HIP_TRY(hipStreamSynchronize(g->vmap->stream));
+    g->vmap_valid = true;
     return LIO_OK;
 }
 
@@ -305,8 +482,24 @@ int gicp_eval(lio_gicp* g, const double T[16], double max_corr_dist, bool update
     hipStream_t st = g->grid[0]->stream;
     const GicpXform X = to_gx(T);
     const uint32_t ns = g->n[1];
-    const uint32_t blocks = (ns + kGicpThreads - 1) / kGicpThreads;
+    uint32_t blocks = (ns + kGicpThreads - 1) / kGicpThreads;
     lio_map* mt = g->grid[0];
+    const double* partial = g->partial;
+    if (g->voxel_res > 0.0) {  // FastVGICP::linearize / compute_error
+        if (!g->vmap_valid) {
+            const int rc = vgicp_build(g);
+            if (rc != LIO_OK) return rc;
+        }
+        const uint32_t ne = ns * (uint32_t)g->offs.n;
+        blocks = (ne + kGicpThreads - 1) / kGicpThreads;
+        const double vres = (double)(float)g->voxel_res;
+        if (update)
+            hipLaunchKernelGGL(vgicp_corr_kernel, blocks, kGicpThreads, 0, st, g->vmap->table, g->vmap->table_mask, g->vvox, vres, g->grid[1]->pool, g->cov[1], ns, g->offs, X,
+                               g->vcorr, g->vmaha);
+        if (deriv) hipLaunchKernelGGL(vgicp_cost_kernel<true>, blocks, kGicpThreads, 0, st, g->vvox, g->grid[1]->pool, ns, g->offs.n, g->vcorr, g->vmaha, X, g->vpartial);
+        else hipLaunchKernelGGL(vgicp_cost_kernel<false>, blocks, kGicpThreads, 0, st, g->vvox, g->grid[1]->pool, ns, g->offs.n, g->vcorr, g->vmaha, X, g->vpartial);
+        partial = g->vpartial;
+    } else {
     if (update) {
         const double d2 = max_corr_dist * max_corr_dist;
         hipLaunchKernelGGL(gicp_corr_kernel, blocks, kGicpThreads, 0, st, mt->table, mt->table_mask, mt->pool, g->res, g->cov[0], g->grid[1]->pool, g->cov[1], ns, X,
@@ -314,8 +507,9 @@ int gicp_eval(lio_gicp* g, const double T[16], double max_corr_dist, bool update
     }
     if (deriv) hipLaunchKernelGGL(gicp_cost_kernel<true>, blocks, kGicpThreads, 0, st, mt->pool, g->grid[1]->pool, ns, g->corr, g->maha, X, g->partial);
     else hipLaunchKernelGGL(gicp_cost_kernel<false>, blocks, kGicpThreads, 0, st, mt->pool, g->grid[1]->pool, ns, g->corr, g->maha, X, g->partial);
+    }
     const uint32_t seq = ++g->seq;
-    hipLaunchKernelGGL(gicp_report_kernel, 1, 1024, 0, st, g->partial, blocks, g->report_dev, seq);
+    hipLaunchKernelGGL(gicp_report_kernel, 1, 1024, 0, st, partial, blocks, g->report_dev, seq);
     LIO_HIP_TRY(hipGetLastError());
     volatile uint32_t* ps = &g->report->seq;
     for (uint64_t spin = 0; *ps != seq; spin++) {
@@ -372,6 +566,11 @@ void lio_gicp_destroy(lio_gicp* g) {
         if (g->grid[w]) lio_map_destroy(g->grid[w]);
         if (g->cov[w]) hipFree(g->cov[w]);
     }
+    if (g->vmap) lio_map_destroy(g->vmap);
+    if (g->vvox) hipFree(g->vvox);
+    if (g->vcorr) hipFree(g->vcorr);
+    if (g->vmaha) hipFree(g->vmaha);
+    if (g->vpartial) hipFree(g->vpartial);
     if (g->corr) hipFree(g->corr);
     if (g->maha) hipFree(g->maha);
     if (g->partial) hipFree(g->partial);
@@ -382,6 +581,56 @@ void lio_gicp_destroy(lio_gicp* g) {
 
 int lio_gicp_set_target(lio_gicp* g, const float* xyzi, uint32_t n) { return gicp_set_cloud(g, 0, xyzi, n); }
 int lio_gicp_set_source(lio_gicp* g, const float* xyzi, uint32_t n) { return gicp_set_cloud(g, 1, xyzi, n); }
+
+int lio_gicp_set_voxel_mode(lio_gicp* g, double voxel_resolution, int search_method) {
+    if (!g || voxel_resolution < 0.0 || (search_method != 1 && search_method != 7 && search_method != 27)) { set_error("lio_gicp_set_voxel_mode: bad argument"); return LIO_E_INVALID; }
+    hipSetDevice(g->device);
+    if (g->vcorr) { hipFree(g->vcorr); g->vcorr = nullptr; }
+    if (g->vmaha) { hipFree(g->vmaha); g->vmaha = nullptr; }
+    if (g->vpartial) { hipFree(g->vpartial); g->vpartial = nullptr; }
+    g->voxel_res = voxel_resolution;
+    g->vmap_valid = false;
+    if (voxel_resolution == 0.0) return LIO_OK;
+    VgicpOffsets& o = g->offs;  // neighbor_offsets(search_method), fast_vgicp_voxel.hpp:10-43, same order
+    o.n = 0;
+    auto push = [&](int x, int y, int z) { o.off[o.n][0] = x; o.off[o.n][1] = y; o.off[o.n][2] = z; o.n++; };
+    if (search_method == 1) push(0, 0, 0);
+    else if (search_method == 7) { push(0, 0, 0); push(1, 0, 0); push(-1, 0, 0); push(0, 1, 0); push(0, -1, 0); push(0, 0, 1); push(0, 0, -1); }
+    else
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                for (int k = 0; k < 3; k++) push(i - 1, j - 1, k - 1);
+    const size_t ne = (size_t)g->max_points * o.n;
+    g->vblocks = (uint32_t)((ne + kGicpThreads - 1) / kGicpThreads);
+    if (hipMalloc(reinterpret_cast<void**>(&g->vcorr), ne * sizeof(int32_t)) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&g->vmaha), ne * 6 * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&g->vpartial), (size_t)g->vblocks * kGicpAcc * sizeof(double)) != hipSuccess) {
+        set_error("lio_gicp_set_voxel_mode: allocation failed");
+        return LIO_E_DEVICE;
+    }
+    return LIO_OK;
+}
+
+// the Gaussian voxel of the target that holds point p: (points, mean, regularised covariance); 0 = no such voxel
+int lio_gicp_voxel_at(lio_gicp* g, const float p[3], double mean[3], double cov6[6]) {
+    if (!g || !p || g->voxel_res <= 0.0 || !g->grid[0]) return LIO_E_INVALID;
+    hipSetDevice(g->device);
+    if (!g->vmap_valid) { const int rc = vgicp_build(g); if (rc != LIO_OK) return rc; }
+    const double res = (double)(float)g->voxel_res;
+    const int cx = (int)floor((double)p[0] / res - 0.5), cy = (int)floor((double)p[1] / res - 0.5), cz = (int)floor((double)p[2] / res - 0.5);
+    // walk the probe sequence on the host over a copy of the (small) table
+    std::vector<Slot> tab(g->vmap->table_cap);
+    LIO_HIP_TRY(hipMemcpy(tab.data(), g->vmap->table, tab.size() * sizeof(Slot), hipMemcpyDeviceToHost));
+    const unsigned long long want = pack_key(cx, cy, cz);
+    for (uint32_t h = 0; h < g->vmap->table_cap; h++) {
+        if (tab[h].key != want || tab[h].cnt == 0) continue;
+        VgicpVoxel v;
+        LIO_HIP_TRY(hipMemcpy(&v, g->vvox + h, sizeof(v), hipMemcpyDeviceToHost));
+        if (mean) for (int a = 0; a < 3; a++) mean[a] = v.mean[a];
+        if (cov6) for (int a = 0; a < 6; a++) cov6[a] = v.cov[a];
+        return (int)v.n;
+    }
+    return 0;
+}
 
 int lio_gicp_download(lio_gicp* g, int which, float* xyzi, double* cov6, uint32_t cap) {
     if (!g || which < 0 || which > 1 || !g->grid[which]) return LIO_E_INVALID;

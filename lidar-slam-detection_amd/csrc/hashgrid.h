@@ -53,4 +53,12 @@ __device__ inline void pos2grid_ndt(float x, float y, float z, float res, int& k
     kz = (int)floorf(z / res - 0.5f);
 }
 
+// fast_gicp's CPU Gaussian-voxel key (fast_vgicp_voxel.hpp:165-167): (x.array() / voxel_resolution - 0.5).floor() with x and the resolution
+// in DOUBLE (the point cast from f32)
+__device__ inline void pos2grid_vgicp(float x, float y, float z, double res, int& kx, int& ky, int& kz) {
+    kx = (int)floor((double)x / res - 0.5);
+    ky = (int)floor((double)y / res - 0.5);
+    kz = (int)floor((double)z / res - 0.5);
+}
+
 }  // namespace lio

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint
         const float4 p = pts[i];
         int kx, ky, kz;
         if (key_mode == 0) pos2grid(p.x, p.y, p.z, inv_res, kx, ky, kz);
+        else if (key_mode == 2) pos2grid_vgicp(p.x, p.y, p.z, (double)res, kx, ky, kz);
         else pos2grid_ndt(p.x, p.y, p.z, res, kx, ky, kz);
         const unsigned long long key = pack_key(kx, ky, kz);
         BrickProbe bp = brick_probe(kx, ky, kz);

@@ -137,7 +137,7 @@ struct lio_map {
     int device;
     hipStream_t stream;
     float res, inv_res;
-    int key_mode;  // 0: iVox key round(p / res); 1: fast_gicp Gaussian-voxel key floor(p / res - 0.5)
+    int key_mode;  // 0: iVox key round(p / res); 1: fast_gicp Gaussian-voxel key floor(p / res - 0.5) in f32; 2: the same in f64 (its CPU voxel map)
     uint64_t max_points, max_voxels, pool_cap;
     uint32_t table_cap, table_mask;  // power of two
     lio::Slot* table;

@@ -37,7 +37,7 @@ SYMBOLS = [
     "lio_state_predict", "lio_eskf_update_cb", "lio_eskf_update_sums_cb",
     "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_fitness_score", "lio_ndt_overlap_score", "lio_ndt_voxel_at",
     "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align",
-    "lio_gicp_create", "lio_gicp_destroy", "lio_gicp_set_target", "lio_gicp_set_source", "lio_gicp_download", "lio_gicp_correspondences", "lio_gicp_linearize", "lio_gicp_align",
+    "lio_gicp_create", "lio_gicp_destroy", "lio_gicp_set_target", "lio_gicp_set_source", "lio_gicp_set_voxel_mode", "lio_gicp_voxel_at", "lio_gicp_download", "lio_gicp_correspondences", "lio_gicp_linearize", "lio_gicp_align",
 ]
 
 
@@ -235,6 +235,8 @@ def lib():
     sig("lio_gicp_destroy", None, vp)
     sig("lio_gicp_set_target", cint, vp, f32p, u32)
     sig("lio_gicp_set_source", cint, vp, f32p, u32)
+    sig("lio_gicp_set_voxel_mode", cint, vp, C.c_double, cint)
+    sig("lio_gicp_voxel_at", cint, vp, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("lio_gicp_download", cint, vp, cint, f32p, f64p, u32)
     sig("lio_gicp_correspondences", cint, vp, i32p, u32)
     sig("lio_gicp_linearize", cint, vp, f64p, dbl, cint, cint, f64p, f64p, f64p, C.POINTER(u32))

@@ -517,6 +517,17 @@ class Gicp:
         p = f32(pts).reshape(-1, 4)
         check(lib().lio_gicp_set_source(self.h, ptr(p, C.c_float), len(p)), "gicp set_source")
 
+    def set_voxel_mode(self, voxel_resolution=1.0, search_method=1):
+        """fast_gicp::FastVGICP: Gaussian-voxel target of `voxel_resolution` (0 = back to the kd-tree form), DIRECT1 / 7 / 27 lookup"""
+        check(lib().lio_gicp_set_voxel_mode(self.h, float(voxel_resolution), int(search_method)), "gicp set_voxel_mode")
+
+    def voxel_at(self, p):
+        """(points in the target voxel holding p, mean (3,), covariance (3, 3)); 0 points = no such voxel"""
+        p = f32(p)
+        m, c = np.zeros(3), np.zeros(6)
+        n = check(lib().lio_gicp_voxel_at(self.h, ptr(p, C.c_float), ptr(m, C.c_double), ptr(c, C.c_double)), "gicp voxel_at")
+        return n, m, np.array([[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]])
+
     def download(self, which):
         """(points (n, 4) in internal order, regularised covariances (n, 3, 3))"""
         pts, cov = np.zeros((self.max_points, 4), np.float32), np.zeros((self.max_points, 6))

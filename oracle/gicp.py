@@ -6,6 +6,8 @@ Follows /root/reference/slam/thirdparty/fast_gicp/include/fast_gicp/gicp/impl/fa
   correspondences()  update_correspondences  :118-157 (nearest target point of trans_f * a, f32; Mahalanobis (C_B + T C_A T^T)^-1)
   linearize()     linearize / compute_error  :159-242
   align()         LsqRegistration::computeTransformation / step_lm / is_converged  lsq_registration_impl.hpp:71-208, se3_exp of so3.hpp
+  Vgicp           fast_gicp::FastVGICP: fast_vgicp_voxel.hpp:95-110,129-167 (ADDITIVE Gaussian voxels, key floor(x / res - 0.5) in f64),
+                  fast_vgicp_impl.hpp:72-204 (voxel correspondences DIRECT1 / 7 / 27, weight sqrt(points in the voxel))
 Pinned against the reference itself (oracle/_ref/libref_gicp.so, oracle/ref_gicp.cpp) by tests/test_gicp.py and through the vectors that
 harness wrote into tests/golden/gicp_*.npz (tools/make_gicp_golden.py).  Brute-force neighbour search: small clouds only."""
 import numpy as np
@@ -154,3 +156,67 @@ class Gicp:
                 break
             converged = self._converged(delta)
         return x0.astype(np.float32), it, converged
+
+
+OFFSETS = {1: [(0, 0, 0)], 7: [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)],
+           27: [(i - 1, j - 1, k - 1) for i in range(3) for j in range(3) for k in range(3)]}
+
+
+class Vgicp(Gicp):
+    """fast_gicp::FastVGICP<PointXYZI, PointXYZI> (select_registration_method("FAST_VGICP"): resolution 1.0, epsilons 0.1 / 0.1)"""
+
+    def __init__(self, k=20, resolution=1.0, search_method=1, transformation_epsilon=0.1, rotation_epsilon=0.1, max_iterations=64):
+        super().__init__(k=k, max_corr_dist=np.inf, transformation_epsilon=transformation_epsilon, rotation_epsilon=rotation_epsilon, max_iterations=max_iterations)
+        self.res, self.offsets, self.voxels = float(resolution), OFFSETS[search_method], None
+
+    def set_target(self, xyzi):
+        self.voxels = None
+        return super().set_target(xyzi)
+
+    def _coord(self, x):
+        return tuple(np.floor(np.asarray(x, np.float64) / self.res - 0.5).astype(np.int64))
+
+    def _build(self):
+        acc = {}
+        for i in range(len(self.tgt)):  # create_voxelmap: append in input order, then finalize
+            c = self._coord(self.tgt[i, :3].astype(np.float64))
+            v = acc.setdefault(c, [0, np.zeros(3), np.zeros((3, 3))])
+            v[0] += 1
+            v[1] = v[1] + self.tgt[i, :3].astype(np.float64)
+            v[2] = v[2] + self.cov_tgt[i]
+        self.voxels = {c: (n, m / n, C / n) for c, (n, m, C) in acc.items()}
+
+    def voxel_at(self, p):
+        if self.voxels is None:
+            self._build()
+        v = self.voxels.get(self._coord(np.asarray(p, np.float32).astype(np.float64)))
+        return (0, None, None) if v is None else v
+
+    def linearize(self, T, derivatives=True, update=True):
+        if self.voxels is None:
+            self._build()
+        T = np.asarray(T, np.float64)
+        R = T[:3, :3]
+        if update:
+            self.vcorr = []
+            for i in range(len(self.src)):
+                ta = R @ self.src[i, :3].astype(np.float64) + T[:3, 3]
+                c = self._coord(ta)
+                for o in self.offsets:
+                    v = self.voxels.get((c[0] + o[0], c[1] + o[1], c[2] + o[2]))
+                    if v is not None:
+                        self.vcorr.append((i, v, np.linalg.inv(v[2] + R @ self.cov_src[i] @ R.T)))
+        H, b, err = np.zeros((6, 6)), np.zeros(6), 0.0
+        for i, v, M in self.vcorr:
+            ta = R @ self.src[i, :3].astype(np.float64) + T[:3, 3]
+            e = v[1] - ta
+            w = np.sqrt(v[0])
+            err += w * (e @ M @ e)
+            if derivatives:
+                J = np.hstack([_skew(ta), -np.eye(3)])
+                H += w * (J.T @ M @ J)
+                b += w * (J.T @ M @ e)
+        return err, H, b
+
+    def compute_error(self, T):
+        return self.linearize(T, derivatives=False, update=False)[0]

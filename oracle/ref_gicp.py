@@ -31,6 +31,17 @@ def lib():
         L.ref_gicp_compute_error.argtypes = [C.c_void_p, f64p]
         L.ref_gicp_align.argtypes = [C.c_void_p, f32p, f32p, i32p]
         L.ref_gicp_transform_f.argtypes = [f64p, f32p, f32p]
+        L.ref_vgicp_create.restype = C.c_void_p
+        L.ref_vgicp_create.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_float]
+        L.ref_vgicp_destroy.argtypes = [C.c_void_p]
+        L.ref_vgicp_set_target.argtypes = [C.c_void_p, f32p, C.c_int]
+        L.ref_vgicp_set_source.argtypes = [C.c_void_p, f32p, C.c_int]
+        L.ref_vgicp_linearize.restype = C.c_double
+        L.ref_vgicp_linearize.argtypes = [C.c_void_p, f64p, f64p, f64p, i32p]
+        L.ref_vgicp_compute_error.restype = C.c_double
+        L.ref_vgicp_compute_error.argtypes = [C.c_void_p, f64p]
+        L.ref_vgicp_voxel_at.argtypes = [C.c_void_p, f32p, f64p, f64p]
+        L.ref_vgicp_align.argtypes = [C.c_void_p, f32p, f32p, i32p]
         _lib = L
     return _lib
 
@@ -91,4 +102,50 @@ class RefGicp:
         T = np.zeros((4, 4), np.float32)
         it = C.c_int(0)
         conv = lib().ref_gicp_align(self.h, _p(g, C.c_float), _p(T, C.c_float), C.byref(it))
+        return T, it.value, bool(conv)
+
+
+class RefVgicp:
+    """fast_gicp::FastVGICP<PointXYZI, PointXYZI> as select_registration_method("FAST_VGICP") configures it (registrations.cpp:56-66)"""
+
+    def __init__(self, k=20, resolution=1.0, search_method=1, transformation_epsilon=0.1, rotation_epsilon=0.1, max_iterations=64, num_threads=4, kdtree_cell=1.0):
+        self.h = lib().ref_vgicp_create(k, resolution, search_method, transformation_epsilon, rotation_epsilon, max_iterations, num_threads, kdtree_cell)
+
+    def close(self):
+        if self.h:
+            lib().ref_vgicp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_target(self, xyzi):
+        xyzi = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        lib().ref_vgicp_set_target(self.h, _p(xyzi, C.c_float), len(xyzi))
+
+    def set_source(self, xyzi):
+        xyzi = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        lib().ref_vgicp_set_source(self.h, _p(xyzi, C.c_float), len(xyzi))
+
+    def linearize(self, T):
+        T = np.ascontiguousarray(T, np.float64)
+        H, b, nc = np.zeros((6, 6)), np.zeros(6), C.c_int(0)
+        e = lib().ref_vgicp_linearize(self.h, _p(T, C.c_double), _p(H, C.c_double), _p(b, C.c_double), C.byref(nc))
+        return e, H, b, nc.value
+
+    def compute_error(self, T):
+        T = np.ascontiguousarray(T, np.float64)
+        return lib().ref_vgicp_compute_error(self.h, _p(T, C.c_double))
+
+    def voxel_at(self, p):
+        p = np.ascontiguousarray(p, np.float32)
+        m, c = np.zeros(3), np.zeros((3, 3))
+        n = lib().ref_vgicp_voxel_at(self.h, _p(p, C.c_float), _p(m, C.c_double), _p(c, C.c_double))
+        return n, m, c
+
+    def align(self, guess):
+        g = np.ascontiguousarray(guess, np.float32)
+        T = np.zeros((4, 4), np.float32)
+        it = C.c_int(0)
+        conv = lib().ref_vgicp_align(self.h, _p(g, C.c_float), _p(T, C.c_float), C.byref(it))
         return T, it.value, bool(conv)

@@ -81,3 +81,45 @@ def test_kdtree_standin_is_exact():
         g = ref_gicp.RefGicp(k=c["k"], num_threads=1, kdtree_cell=cell)
         covs.append(g.set_target(c["target"]))
     assert np.array_equal(covs[0], covs[1]) and np.array_equal(covs[1], covs[2])
+
+
+VG = [("room_small", 1), ("room_small", 7), ("room_fine", 1), ("room_fine", 27)]
+
+
+@pytest.mark.parametrize("name,sm", [("room_small", 1), ("room_small", 7)])
+def test_oracle_vgicp_vs_reference_vectors(name, sm):
+    """the voxelised variant (fast_gicp::FastVGICP): Gaussian voxels, voxel correspondences, weighted cost -- numpy restatement vs the reference"""
+    c = gicp_cases.make(name)
+    key = f"vgicp/{name}/{sm}/"
+    v = OG.Vgicp(k=c["k"], resolution=1.0, search_method=sm)
+    v.set_target(c["target"])
+    v.set_source(c["source"])
+    for p, n, m, C in zip(GOLD[key + "probe"], GOLD[key + "vox_n"], GOLD[key + "vox_mean"], GOLD[key + "vox_cov"]):
+        n2, m2, C2 = v.voxel_at(p)
+        assert n2 == n and np.abs(m2 - m).max() < 1e-12 and np.abs(C2 - C).max() < 1e-6
+    e, H, b = v.linearize(c["guess"])
+    assert len(v.vcorr) == int(GOLD[key + "n_corr"])
+    assert abs(e - GOLD[key + "err"]) < 1e-6 * abs(GOLD[key + "err"])
+    assert np.abs(H - GOLD[key + "H"]).max() < 1e-6 * np.abs(GOLD[key + "H"]).max()
+    assert np.abs(b - GOLD[key + "b"]).max() < 1e-6 * np.abs(GOLD[key + "b"]).max()
+    T2 = c["guess"].copy()
+    T2[:3, 3] += [0.01, -0.02, 0.005]
+    assert abs(v.compute_error(T2) - GOLD[key + "err2"]) < 1e-6 * abs(GOLD[key + "err2"])
+    if sm == 1:
+        T, it, conv = v.align(c["guess"].astype(np.float32))
+        assert conv == bool(GOLD[key + "converged"]) and it == int(GOLD[key + "iterations"])
+        assert np.abs(T - GOLD[key + "T"]).max() < 1e-5
+
+
+@pytest.mark.skipif(not ref_gicp.available(), reason="oracle/_ref/libref_gicp.so not built")
+@pytest.mark.parametrize("name,sm", VG)
+def test_reference_vgicp_reproduces_vectors(name, sm):
+    c = gicp_cases.make(name)
+    key = f"vgicp/{name}/{sm}/"
+    v = ref_gicp.RefVgicp(k=c["k"], resolution=1.0, search_method=sm, num_threads=1)
+    v.set_target(c["target"])
+    v.set_source(c["source"])
+    e, H, b, nc = v.linearize(c["guess"])
+    assert nc == int(GOLD[key + "n_corr"]) and e == float(GOLD[key + "err"]) and np.array_equal(H, GOLD[key + "H"]) and np.array_equal(b, GOLD[key + "b"])
+    T, it, conv = v.align(c["guess"].astype(np.float32))
+    assert np.array_equal(T, GOLD[key + "T"]) and it == int(GOLD[key + "iterations"])

@@ -97,3 +97,36 @@ def test_gicp_vs_reference_at_merge_size():
     ref.update(T=T, iterations=it, converged=conv)
     assert np.abs(T[:3, 3] - truth[:3, 3]).max() < 0.02
     _check_against(c, ref, 1.0)
+
+
+@pytest.mark.parametrize("name,sm", [("room_small", 1), ("room_small", 7), ("room_fine", 1), ("room_fine", 27)])
+def test_vgicp_vs_reference_vectors(name, sm):
+    """lio_gicp_* in voxel mode = fast_gicp::FastVGICP (fast_vgicp_impl.hpp:72-204): Gaussian voxels of the target, voxel correspondences,
+    weighted cost / H / b, whole alignments -- against the vectors the reference wrote (configured as select_registration_method("FAST_VGICP"))"""
+    c = gicp_cases.make(name)
+    key = f"vgicp/{name}/{sm}/"
+    g = lio.Gicp(grid_resolution=1.0, max_points=max(len(c["target"]), len(c["source"])), k=c["k"])
+    g.set_voxel_mode(1.0, sm)
+    g.set_target(c["target"])
+    g.set_source(c["source"])
+    _, tcov = g.download(0)
+    for p, n, m, C in zip(GOLD[key + "probe"], GOLD[key + "vox_n"], GOLD[key + "vox_mean"], GOLD[key + "vox_cov"]):
+        n2, m2, C2 = g.voxel_at(p)
+        assert n2 == n and np.abs(m2 - m).max() < 1e-12 and np.abs(C2 - C).max() < 1e-6
+    r = g.linearize(c["guess"])
+    assert r["n_corr"] == int(GOLD[key + "n_corr"])
+    assert abs(r["err"] - GOLD[key + "err"]) < 1e-7 * abs(GOLD[key + "err"])
+    assert np.abs(r["H"] - GOLD[key + "H"]).max() < 1e-7 * np.abs(GOLD[key + "H"]).max()
+    assert np.abs(r["b"] - GOLD[key + "b"]).max() < 1e-7 * np.abs(GOLD[key + "b"]).max()
+    T2 = c["guess"].copy()
+    T2[:3, 3] += [0.01, -0.02, 0.005]
+    r2 = g.linearize(T2, update_corr=False, with_derivatives=False)
+    assert abs(r2["err"] - GOLD[key + "err2"]) < 1e-7 * abs(GOLD[key + "err2"])
+    T, conv, it = g.align(c["guess"].astype(np.float32).astype(np.float64), transformation_epsilon=0.1, rotation_epsilon_deg=0.1)
+    assert conv == bool(GOLD[key + "converged"]) and it == int(GOLD[key + "iterations"])
+    assert np.abs(T[:3, 3] - GOLD[key + "T"][:3, 3]).max() < 1e-4 and np.abs(T[:3, :3] - GOLD[key + "T"][:3, :3]).max() < 1e-5
+    # back to the kd-tree form on the same object
+    g.set_voxel_mode(0.0, 1)
+    r3 = g.linearize(c["guess"], max_corr_dist=c["max_corr_dist"])
+    assert abs(r3["err"] - GOLD[name + "/err"]) < 1e-8 * abs(GOLD[name + "/err"])
+    g.close()
