@@ -59,7 +59,7 @@ def main():
                                                               "each, all reading the one resident map)")
     ap.add_argument("--engine", choices=["batch", "threads"], default="batch",
                     help="batch: B scans per launch, filter loop on the device, one host thread (lio_batch_*); threads: round 1's one engine + thread per scan")
-    ap.add_argument("--slots", type=int, default=24, help="--engine batch: scans per launch")
+    ap.add_argument("--slots", type=int, default=32, help="--engine batch: scans per launch")
     ap.add_argument("--groups", type=int, default=3, help="--engine batch: rounds in flight (one HIP stream each)")
     ap.add_argument("--config", choices=["metric", "merge", "stream"], default="metric",
                     help="metric: BASELINE.json's headline (independent 120k-pt scans vs a 1e7-pt map); merge: BASELINE config 5, multi-map merge -- 8 sub-maps "

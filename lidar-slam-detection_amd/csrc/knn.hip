@@ -666,7 +666,15 @@ static int g_knn_reuse = [] { const char* e = getenv("LIO_KNN_REUSE"); return (e
 void knn_set_reuse(int on) { g_knn_reuse = on ? 1 : 0; }
 
 int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode, int pass) {
-    if (grid_x > 2048) grid_x = 2048;  // grid-stride loop inside: 16 queries per workgroup and round
+    // Workgroups per slot: enough of them over all slots to fill the machine a few times (256 CUs x 7 resident workgroups), not more -- a
+    // workgroup that takes several query blocks in turn pays the kernel's prologue and epilogue (~11 % of a single block's instructions)
+    // once.  One slot alone (the single-scan engine) keeps the full 2048; 24 slots get 512 each (measured: 16.9 -> 14.9 us per scan and
+    // search; 256 and fewer lose to the tail).  LIO_KNN_GRID overrides.
+    static const uint32_t forced = [] { const char* e = getenv("LIO_KNN_GRID"); const int v = e ? atoi(e) : 0; return v >= 8 ? (uint32_t)v : 0u; }();
+    uint32_t cap = forced ? forced : (12288u / (uint32_t)(n_slots > 0 ? n_slots : 1));
+    if (cap > 2048u) cap = 2048u;
+    if (cap < 128u) cap = 128u;
+    if (grid_x > cap) grid_x = cap;  // grid-stride loop inside: 16 queries per workgroup and round
     if (grid_x == 0) grid_x = 8;
     const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
     const dim3 gridx(64, (uint32_t)n_slots);
