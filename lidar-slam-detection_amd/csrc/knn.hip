@@ -34,10 +34,10 @@ namespace lio {
 #define LIO_KNN_U 4
 #endif
 #ifndef LIO_KNN_WAVES
-#define LIO_KNN_WAVES 7  // 72 registers: seven waves per SIMD (two registers spill in the cold tail; measured 2 % faster than six)
+#define LIO_KNN_WAVES 6  // <= 80 registers, six waves per SIMD, nothing spills (seven: 72 registers with 9-12 spilled -- 4 % slower once the kernel became VALU bound)
 #endif
 #ifndef LIO_KNN_WAVES_FIRST
-#define LIO_KNN_WAVES_FIRST 7  // the first search of an update (no re-search code): 72 registers, seven waves per SIMD
+#define LIO_KNN_WAVES_FIRST 6  // the first search of an update (the variant without the re-search code)
 #endif
 #ifndef LIO_KNN_PRUNE
 #define LIO_KNN_PRUNE 1  // distance-ordered sweep with exact pruning of stencil voxels that cannot hold one of the five nearest
@@ -350,19 +350,37 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     const uint32_t nblk = (n + kGPB - 1) / kGPB;       // query blocks of this scan
     const uint32_t per_xcd = (nblk + 7u) >> 3;         // ... per XCD, contiguous
     const uint32_t wg_per_xcd = gridDim.x >> 3;        // workgroups of this launch on one XCD: they stride over its share
+    // The body -> world transform (two quaternion rotations in f64, ~140 issue slots) is the same for the sixteen lanes of a query: the
+    // first wave does it once, one lane per query, for the next four query blocks of this workgroup (64 queries), and leaves the world
+    // points in LDS (and in world_out, coalesced).
+    constexpr uint32_t kAhead = 64 / kGPB;
+    __shared__ float4 pw_s[64];
+    uint32_t ahead = kAhead;  // workgroup-uniform: query blocks already taken from the staged chunk
     for (uint32_t j = blockIdx.x >> 3; j < per_xcd; j += wg_per_xcd) {
         const uint32_t q0 = ((blockIdx.x & 7u) * per_xcd + j) * kGPB;
         const uint32_t q = q0 + grp;
         const bool active = q < n;
         float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active) {
-            const float4 pq = queries[q];
-            if (MODE == 0) {
-                body_to_world(pose, pq, pw);
-                if (gl == 0) world_out[q] = pw;
-            } else {
-                pw = pq;
+        if constexpr (MODE == 0) {
+            if (ahead == kAhead) {
+                __syncthreads();
+                if (tid < 64) {
+                    const uint32_t j2 = j + (uint32_t)(tid / kGPB) * wg_per_xcd;
+                    const uint32_t q2 = ((blockIdx.x & 7u) * per_xcd + j2) * kGPB + (uint32_t)(tid % kGPB);
+                    if (j2 < per_xcd && q2 < n) {
+                        float4 w2;
+                        body_to_world(pose, queries[q2], w2);
+                        world_out[q2] = w2;
+                        pw_s[tid] = w2;
+                    }
+                }
+                __syncthreads();
+                ahead = 0;
             }
+            if (active) pw = pw_s[ahead * kGPB + grp];
+            ahead++;
+        } else {
+            if (active) pw = queries[q];
         }
         int kx = 0, ky = 0, kz = 0;
         pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
