@@ -191,6 +191,14 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_knn, const ScanDev* __restrict__ sd,
                                                const float4* __restrict__ ds_body, float4* __restrict__ ds_world,
                                                const float4* __restrict__ nn_pts, uint32_t nn_stride,
@@ -253,18 +261,27 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
         }
         selected[i] = sel ? 1 : 0;
     }
-    // workgroup reduction through LDS, transposed: lane l parks its 29 addends in column l, then 29 lanes each sum
-    // one row in lane order (fixed order -> run-to-run identical).  A butterfly of 29 x 6 64-bit shuffles costs
-    // ~700 ds_bpermute per wave; this is 29 conflict-free ds_write_b64 + 32 ds_read_b128 per summing lane.
-    __shared__ double red[kAcc][kLinThreads];
+    // Workgroup reduction, fixed order (run-to-run identical):
+    //   1. quads: two DPP quad-permute butterflies, (v0 + v1) + (v2 + v3) in every lane of the quad -- no LDS;
+    //   2. one lane per quad parks the 29 quad sums in LDS, transposed [component][quad]: 29 x 16 doubles = 3.6 KB per (one-wave) workgroup
+    //      (the full [29][64] form was 14.5 KB: ten waves per CU by LDS, half of what the registers allow);
+    //   3. 29 lanes each add the quad sums of one component in quad order.
+    constexpr int kQuads = kLinThreads / 4;
+    static_assert(kLinThreads >= kAcc && kQuads % 2 == 0, "one summing lane per component");
+    __shared__ double red[kAcc][kQuads];
 #pragma unroll
-    for (int a = 0; a < kAcc; a++) red[a][threadIdx.x] = acc[a];
+    for (int a = 0; a < kAcc; a++) {
+        double v = acc[a];
+        v += dpp_f64<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+        v += dpp_f64<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+        if ((threadIdx.x & 3) == 0) red[a][threadIdx.x >> 2] = v;
+    }
     __syncthreads();
     if (threadIdx.x < kAcc) {
         const double2* row = reinterpret_cast<const double2*>(&red[threadIdx.x][0]);
         double s = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < kLinThreads / 2; k++) {
+#pragma unroll
+        for (int k = 0; k < kQuads / 2; k++) {
             const double2 v = row[k];
             s += v.x;
             s += v.y;

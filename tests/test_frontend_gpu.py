@@ -80,8 +80,10 @@ def test_drive_matches_oracle(oracle_mod, scene):
         assert np.abs(st[0][14:17] - st[1][14:17]).max() < 1e-3
     frac, mx, mabs = np.array(und_stats).T
     print("undistorted cloud vs oracle: differing coordinates %.2e (max %d ulp, %.2e m)" % (frac.mean(), mx.max(), mabs.max()))
-    # once the two filter states differ in their last bits the clouds do too (the poses are inputs of the compensation)
-    assert frac.max() < 1e-3 and mabs.max() < 1e-5
+    # once the two filter states differ in their last bits the clouds do too (the poses are inputs of the compensation): a few per mille of
+    # the coordinates by an ulp or two -- how many depends on which f64 summation order the reductions use (any fixed order is "the"
+    # answer to 1e-16; the share moved from 0.8e-3 to 1.4e-3 when the linearisation's workgroup reduction went from lane order to quads)
+    assert frac.max() < 5e-3 and mabs.max() < 1e-5
     for k in range(7, n):
         dp, dr = pose_error(tr, res[k][1][0], (k + 1) * 0.1)
         assert dp < 0.03 and dr < 5e-3, (k, dp, dr)
