@@ -244,11 +244,15 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
     for (int w = 0; w < wave; w++) gbase += wsum[w];
 
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // per item: the lanes of this wave holding the same digit (eight ballots), kept as (lanes below me, all of them) for both phases
+    uint32_t below[kItems], total[kItems];
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
         const uint32_t d = (k[r] >> shift) & 255u;
         const unsigned long long peers = match_digit(d, ok[r]);
-        if (ok[r] && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);
+        below[r] = (uint32_t)__popcll(peers & lt);
+        total[r] = (uint32_t)__popcll(peers);
+        if (ok[r] && below[r] == 0) wcnt[wave][d] += total[r];
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -265,11 +269,10 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
         const uint32_t d = (k[r] >> shift) & 255u;
-        const unsigned long long peers = match_digit(d, ok[r]);
         uint32_t pos = 0;
-        if (ok[r]) pos = wcnt[wave][d] + __popcll(peers & lt);
+        if (ok[r]) pos = wcnt[wave][d] + below[r];
         __builtin_amdgcn_wave_barrier();
-        if (ok[r] && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);
+        if (ok[r] && below[r] == 0) wcnt[wave][d] += total[r];
         __builtin_amdgcn_wave_barrier();
         if (ok[r]) { kout[pos] = k[r]; vout[pos] = v[r]; }
     }
