@@ -207,9 +207,9 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
     const uint32_t n = sd->n_ds;
     if (blockIdx.x * kLinThreads >= n) return;  // finalize only reads the first ceil(n / kLinThreads) partials
     const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
-    double acc[kAcc];
-#pragma unroll
-    for (int a = 0; a < kAcc; a++) acc[a] = 0.0;
+    // the point's addends are formed at reduction time from its Jacobian row, residual and |residual| (8 doubles live instead of 29)
+    double row[6] = {0, 0, 0, 0, 0, 0};
+    double h = 0.0, ares = 0.0, one = 0.0;
     if (i < n) {
         const float4 pb = ds_body[i];
         double pi[3];
@@ -241,21 +241,13 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
                     const double cx = (nx + qw * ux) + (qy * uz - qz * uy);
                     const double cy = (ny + qw * uy) + (qz * ux - qx * uz);
                     const double cz = (nz + qw * uz) + (qx * uy - qy * ux);
-                    double row[6];
                     row[0] = nx; row[1] = ny; row[2] = nz;
                     row[3] = pi[1] * cz - pi[2] * cy;  // A = point_crossmat * C = p_imu x C
                     row[4] = pi[2] * cx - pi[0] * cz;
                     row[5] = pi[0] * cy - pi[1] * cx;
-                    const double h = -(double)pd2;
-                    int t = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-#pragma unroll
-                        for (int c = a; c < 6; c++) acc[t++] = row[a] * row[c];
-#pragma unroll
-                    for (int a = 0; a < 6; a++) acc[21 + a] = row[a] * h;
-                    acc[27] = (double)fabsf(pd2);
-                    acc[28] = 1.0;
+                    h = -(double)pd2;
+                    ares = (double)fabsf(pd2);
+                    one = 1.0;
                 }
             }
         }
@@ -269,12 +261,25 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
     constexpr int kQuads = kLinThreads / 4;
     static_assert(kLinThreads >= kAcc && kQuads % 2 == 0, "one summing lane per component");
     __shared__ double red[kAcc][kQuads];
+    {
+        int t = 0;
 #pragma unroll
-    for (int a = 0; a < kAcc; a++) {
-        double v = acc[a];
-        v += dpp_f64<0xB1>(v);  // quad_perm [1, 0, 3, 2]
-        v += dpp_f64<0x4E>(v);  // quad_perm [2, 3, 0, 1]
-        if ((threadIdx.x & 3) == 0) red[a][threadIdx.x >> 2] = v;
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = a; c < 6; c++) {
+                double v = row[a] * row[c];
+                v += dpp_f64<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+                v += dpp_f64<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+                if ((threadIdx.x & 3) == 0) red[t][threadIdx.x >> 2] = v;
+                t++;
+            }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            double v = a < 6 ? row[a] * h : (a == 6 ? ares : one);
+            v += dpp_f64<0xB1>(v);
+            v += dpp_f64<0x4E>(v);
+            if ((threadIdx.x & 3) == 0) red[21 + a][threadIdx.x >> 2] = v;
+        }
     }
     __syncthreads();
     if (threadIdx.x < kAcc) {
