@@ -65,6 +65,8 @@ def main():
                     help="metric: BASELINE.json's headline (independent 120k-pt scans vs a 1e7-pt map); merge: BASELINE config 5, multi-map merge -- 8 sub-maps "
                          "spread over the GPUs, every key-frame scan registered JOINTLY against all of them (RCCL all-gather of the per-rank J^T J / J^T r)")
     ap.add_argument("--lru", type=int, default=100000, help="--config stream: iVox capacity in voxels (the reference's 100000, laserMapping.cpp:1063); 0 = never evict")
+    ap.add_argument("--secondary", type=int, default=1, help="N = 1, --config metric: also run BASELINE config 2 (1e6-pt map) and a short config 3 "
+                                                             "(streaming, map_incremental + LRU) after the timed region and report them under `configs`")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="the job list of --steps scans is repeated until the timed region lasts at least this long")
     args = ap.parse_args()
 
@@ -403,6 +405,45 @@ def main():
                        ms_per_scan=round(1e3 * t_ref / args.ref_scans, 2),
                        gpu_vs_reference_pose={"max_dpos_m": ref_dp, "max_drot_rad": ref_da}, port=port)
 
+    # ---- secondary configurations (BASELINE.json configs 2 and 3), outside the timed region, reported under `configs` ----
+    configs = None
+    if rank == 0 and world == 1 and args.secondary and batch is not None:
+        configs = {}
+        try:
+            # config 2: the same 64 x 1875 scans against a 1e6-point map, through the same batched engine
+            map2_pts = scene.sample_surface(1_000_000, seed=2, sigma=0.01)
+            map2 = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=1_000_000, device=local_rank)
+            d2 = torch.from_numpy(map2_pts).to(dev)
+            torch.cuda.synchronize()
+            map2.add_device(d2.data_ptr(), len(map2_pts))
+            del d2
+            b2 = lio.Batch(map2, n_slots=args.slots, n_groups=args.groups, max_raw=1 << 17, max_ds=100000)
+            j2 = [dict(dptr=d_scans[i % len(scans)].data_ptr(), n=len(scans[i % len(scans)]["raw"]), t=1.0 + 0.1 * i, state=scans[i % len(scans)]["guess"], cov=P0)
+                  for i in range(args.slots * args.groups * 2)]
+            b2.process(j2)
+            prep2 = lio.PreparedJobs(j2 * 20)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            lio.run_prepared(prep2, batch=b2)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter() - t2
+            r2 = prep2.results()
+            pe2 = max(float(np.linalg.norm(r2[i]["state"][:3] - scans[i % len(scans)]["pos"])) for i in range(len(j2)))
+            configs["config2_1e6_map"] = {"workload": "64x%d scans vs 1000000-pt static map, batched engine" % args.n_az, "ms_per_scan": round(1e3 * t2 / prep2.n, 4),
+                                          "points_per_s": round(sum(j["n"] for j in j2) * 20 / t2, 1), "scans_timed": prep2.n,
+                                          "n_ds_avg": round(float(np.mean([r["n_ds"] for r in r2])), 1), "passes_avg": round(float(np.mean([r["n_pass"] for r in r2])), 2),
+                                          "pose_error_vs_truth_m": pe2}
+            del b2, map2
+        except Exception as ex:  # the headline must not depend on the secondary legs
+            configs["config2_1e6_map"] = {"error": repr(ex)}
+        try:
+            s3 = stream_run(300, 100000, args.seed, local_rank)
+            configs["config3_stream_300_sweeps_lru_1e5"] = {"ms_per_scan": s3["ms_per_step"], "points_per_s": s3["value"], **s3["config"],
+                                                            "pose_error_vs_truth_m": s3["pose_error_vs_truth_m"],
+                                                            "note": "short form of `bench.py --config stream --steps 2000` (profiles/r02_bench_stream_*.json)"}
+        except Exception as ex:
+            configs["config3_stream_300_sweeps_lru_1e5"] = {"error": repr(ex)}
+
     if rank == 0:
         value = total_pts / t_max
         out = {
@@ -423,7 +464,7 @@ def main():
             "pose_error_vs_truth": {"max_dpos_m": pose_err, "max_drot_rad": ang_err,
                                     "note": "the reference's algorithm itself: at most four ESKF iterations from a prior 0.3 m / 2 deg off; the GPU pose "
                                             "equals the oracle's and the reference's own (cpu_baseline.gpu_vs_*_pose)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "configs": configs,
         }
         print(json.dumps(out))
     if dist is not None:
@@ -440,6 +481,10 @@ def _sweep_job(a):
 
 
 def bench_stream(args, torch, local_rank):
+    print(json.dumps(stream_run(args.steps, args.lru, args.seed, local_rank)))
+
+
+def stream_run(n, lru, seed, local_rank):
     """BASELINE.json config 3 / SURVEY.md 8d ("NCLT replay", stand-in: NCLT is not available): the streaming FastLIO front half -- IMU
     propagation, motion compensation, downsample, iterated update, map_incremental -- through lio_fastlio_* over a figure-of-eight drive at
     5 m/s through a 1 km x 1 km scene, --steps scans at 10 Hz; the map grows by map_incremental, with the reference's LRU capacity (--lru 100000)
@@ -448,19 +493,18 @@ def bench_stream(args, torch, local_rank):
 
     from lsd_amd import capi, lio, synth
 
-    n = args.steps
     t_gen = time.perf_counter()
     with mp.get_context("fork").Pool(max(1, min(32, usable_cpus()))) as pool:
-        sweeps = pool.map(_sweep_job, [(k, args.seed) for k in range(n)], chunksize=4)
+        sweeps = pool.map(_sweep_job, [(k, seed) for k in range(n)], chunksize=4)
     t_gen = time.perf_counter() - t_gen
     tr = synth.FigureEight()
-    evict = args.lru > 0
+    evict = lru > 0
     e = lio.Engine(resolution=0.5, stencil=75, max_points=14_000_000, max_voxels=(1 << 21) if evict else 6_000_000, max_raw=1 << 18, max_ds=100000,
                    device=local_rank)
     if not evict:
         e.map.set_lru(5_900_000, 1e9)  # a capacity the drive never reaches: nothing is evicted
     e.fastlio_init(scan_period=0.1)  # turns on the reference's 100000-voxel / 100 m LRU list unless one was set above
-    imu = synth.imu_stream(tr, 0.0, n * 0.1 + 0.3, rate=100.0, seed=args.seed, gyr_sigma=1e-3, acc_sigma=1e-2)
+    imu = synth.imu_stream(tr, 0.0, n * 0.1 + 0.3, rate=100.0, seed=seed, gyr_sigma=1e-3, acc_sigma=1e-2)
     ii, t_main, t_enq, rows, pts = 0, [], [], [], 0
     for k, (p, st) in enumerate(sweeps):
         tb = k * 0.1
@@ -492,13 +536,14 @@ def bench_stream(args, torch, local_rank):
            "dtype": "f32 per-point geometry / f64 transforms and reductions", "data": "synthetic",
            "config": {"workload": "BASELINE config 3 stand-in: %d sweeps of 64x1875 rays at 10 Hz along a figure of eight (5 m/s) through a 1 km x 1 km scene, 100 Hz IMU, "
                                   "lio_fastlio_* (IMU propagation + undistortion + downsample + iterated update + map_incremental), clouds from the host" % n,
-                      "lru_capacity_voxels": args.lru if evict else None, "n_ds_avg": round(float(rows[:, 0].mean()), 1), "passes_avg": round(float(rows[:, 1].mean()), 2),
+                      "lru_capacity_voxels": lru if evict else None, "n_ds_avg": round(float(rows[:, 0].mean()), 1), "passes_avg": round(float(rows[:, 1].mean()), 2),
                       "knn_passes_avg": round(float(rows[:, 2].mean()), 2), "points_added_per_scan": round(float(rows[:, 3].mean()), 1),
                       "map_points_end": int(map_points), "map_voxels_end": int(map_voxels), "voxels_evicted": int(evicted),
                       "main_ms_median": round(1e3 * float(np.median(t_main)), 4), "enqueue_ms_median": round(1e3 * float(np.median(t_enq)), 4),
                       "main_ms_p99": round(1e3 * float(np.percentile(t_main, 99)), 4), "sweep_generation_s": round(t_gen, 1)},
            "pose_error_vs_truth_m": err}
-    print(json.dumps(out))
+    e.close()
+    return out
 
 
 def bench_merge(args, torch, dist, world, rank, local_rank, dev):
