@@ -10,8 +10,8 @@ cd $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cut -c1-600 $O/bench.json
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r -- python $R/bench.py --steps 20 --warmup 5 > $O/prof_bench.json 2> $O/prof.err
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- python $R/bench.py --steps 32 --warmup 16 --min-seconds 0 --cpu-scans 0 --groups 1 > /dev/null 2> $O/pmc_fetch.err
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o r -- python $R/bench.py --steps 32 --warmup 16 --min-seconds 0 --cpu-scans 0 --groups 1 > /dev/null 2> $O/pmc_write.err
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- python $R/bench.py --steps 32 --warmup 16 --min-seconds 0 --cpu-scans 0 --ref-scans 0 --secondary 0 --groups 1 > /dev/null 2> $O/pmc_fetch.err
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o r -- python $R/bench.py --steps 32 --warmup 16 --min-seconds 0 --cpu-scans 0 --ref-scans 0 --secondary 0 --groups 1 > /dev/null 2> $O/pmc_write.err
 cd $R
 python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*_results.db" | head -1) $(find $O/pmc_write -name "*_results.db" | head -1) knn_batch_kernel > $O/knn_batch_traffic.json
 timeout 600 python bench.py --config merge --steps 8 --warmup 2 > $O/bench_merge.json 2> $O/bench_merge.err; cut -c1-400 $O/bench_merge.json
