@@ -423,33 +423,47 @@ __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sort
     out[v] = make_float4(sx / c, sy / c, sz / c, sw / c);
 }
 
-// one wave per long run: 64 coalesced loads at a time, then the same sequential additions, fed by
-// v_readlane broadcasts (every lane forms the identical sum; lane 0 stores it)
+// one wave per long run: 64 coalesced loads at a time, parked in LDS by coordinate; lanes 0..3 then each own ONE coordinate and add its
+// 64 values in point order (PCL's sequential f32 sum: a dependent chain by definition -- but four chains side by side in one instruction
+// stream, fed by 16-byte LDS reads: ~5 cycles per point instead of the 32 of four v_readlane + four adds in every lane); the next 64
+// points are in flight while these are summed
 __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
                                                                     const uint32_t* __restrict__ longlist) {
     if (sd->passthrough) return;
     const uint32_t nv = sd->n_ds, nl = sd->n_long;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * kWaves;
-    for (uint32_t w = blockIdx.x * kWaves + (threadIdx.x >> 6); w < nl; w += nwaves) {
+    __shared__ __attribute__((aligned(16))) float park[kWaves][4][64];
+    for (uint32_t w = blockIdx.x * kWaves + wv; w < nl; w += nwaves) {
         const uint32_t v = longlist[w];
         const uint32_t ra = hpos[v];
         const uint32_t rb = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;
-        float tx = 0.f, ty = 0.f, tz = 0.f, tw = 0.f;
+        float t = 0.f;  // lane c < 4: the running sum of coordinate c
+        float4 p = sorted[(ra + lane) < rb ? ra + lane : rb - 1];
         for (uint32_t c = ra; c < rb; c += 64) {
-            const uint32_t j = c + lane;
-            const float4 p = sorted[j < rb ? j : rb - 1];
+            park[wv][0][lane] = p.x; park[wv][1][lane] = p.y; park[wv][2][lane] = p.z; park[wv][3][lane] = p.w;
+            const uint32_t jn = c + 64 + lane;
+            if (c + 64 < rb) p = sorted[jn < rb ? jn : rb - 1];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int m = (rb - c) < 64u ? (int)(rb - c) : 64;
-            for (int k = 0; k < m; k++) {
-                tx = tx + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.x), k));
-                ty = ty + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.y), k));
-                tz = tz + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.z), k));
-                tw = tw + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.w), k));
+            if (lane < 4) {
+                const float* q = park[wv][lane];
+                int k = 0;
+                for (; k + 4 <= m; k += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(q + k);
+                    t = t + a.x; t = t + a.y; t = t + a.z; t = t + a.w;
+                }
+                for (; k < m; k++) t = t + q[k];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         const float cnt = (float)(rb - ra);
-        if (lane == 0) out[v] = make_float4(tx / cnt, ty / cnt, tz / cnt, tw / cnt);
+        if (lane < 4) reinterpret_cast<float*>(&out[v])[lane] = t / cnt;
     }
 }
 
