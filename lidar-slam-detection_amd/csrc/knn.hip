@@ -65,6 +65,17 @@ __device__ inline uint32_t group_min32(uint32_t v) {
     }
     return v;
 }
+// the ballot of a predicate over the kG lanes of this lane's group, as a kG-bit word (bit i = lane i of the group): one select between
+// the two halves of the wave-wide ballot and a bit-field extract -- the 64-bit and / popcount of the wave-wide form cost twice that
+__device__ inline uint32_t group_ballot(bool p, int lane) {
+    const unsigned long long b = __ballot(p);
+    if constexpr (kG == 16) {
+        const uint32_t half = (lane & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+        return (half >> (lane & 16)) & 0xFFFFu;
+    } else {
+        return (uint32_t)((b >> (lane & ~(kG - 1))) & ((1ull << kG) - 1ull));
+    }
+}
 __device__ inline uint32_t group_max32(uint32_t v) {
     if constexpr (kG == 16) {
         v = max(v, dpp_row<0x128>(v));
@@ -128,10 +139,10 @@ __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table
         }
     }
     const uint32_t b1 = __float_as_uint(0.0625f * res * res), b2 = __float_as_uint(0.25f * res * res);
-    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t below = (1u << gl) - 1u;
     uint32_t ptr[KM], cnt[KM], total = 0;
     int bucket[KM];
-    unsigned long long mb[KM][3];
+    uint32_t mb[KM][3];
 #pragma unroll
     for (int k = 0; k < KM; k++) {
         ptr[k] = 0; cnt[k] = 0;
@@ -148,14 +159,14 @@ __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table
         const bool hit = cnt[k] > 0;
         bucket[k] = dmin[k] < b1 ? 0 : (dmin[k] < b2 ? 1 : 2);
 #pragma unroll
-        for (int b = 0; b < 3; b++) mb[k][b] = __ballot(hit && bucket[k] == b) & gmask;
+        for (int b = 0; b < 3; b++) mb[k][b] = group_ballot(hit && bucket[k] == b, lane);
         total += group_sum32(cnt[k]);
     }
     uint32_t nb[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < KM; k++)
 #pragma unroll
-        for (int b = 0; b < 3; b++) nb[b] += __popcll(mb[k][b]);
+        for (int b = 0; b < 3; b++) nb[b] += __popc(mb[k][b]);
     const uint32_t base[3] = {0, nb[0], nb[0] + nb[1]};
     const uint32_t nhit = nb[0] + nb[1] + nb[2];
 #pragma unroll
@@ -163,8 +174,8 @@ __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table
         if (cnt[k] > 0) {
             uint32_t at = base[bucket[k]];
 #pragma unroll
-            for (int kk = 0; kk < k; kk++) at += __popcll(mb[kk][bucket[k]]);
-            at += __popcll(mb[k][bucket[k]] & below);
+            for (int kk = 0; kk < k; kk++) at += __popc(mb[kk][bucket[k]]);
+            at += __popc(mb[k][bucket[k]] & below);
             g.v_ptr[at] = ptr[k];
             g.v_cnt[at] = cnt[k];
             g.v_dmin[at] = dmin[k];
@@ -199,7 +210,7 @@ __device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_
         }
     }
     uint32_t nhit = 0, total = 0;
-    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t below = (1u << gl) - 1u;
 #pragma unroll
     for (int k = 0; k < KM; k++) {
         uint32_t ptr = 0, cnt = 0;
@@ -214,13 +225,13 @@ __device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_
             }
         }
         const bool hit = cnt > 0;
-        const unsigned long long m = __ballot(hit) & gmask;
+        const uint32_t m = group_ballot(hit, lane);
         if (hit) {
-            const uint32_t at = nhit + __popcll(m & below);
+            const uint32_t at = nhit + __popc(m & below);
             g.v_ptr[at] = ptr;
             g.v_cnt[at] = cnt;
         }
-        nhit += __popcll(m);
+        nhit += __popc(m);
         uint32_t sum = cnt;
 #pragma unroll
         for (int off = kG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kG);
@@ -452,7 +463,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                     if (bound5 < floor_bits) break;
                     const uint32_t r0 = s0 + gl, r1 = r0 + kG;
                     const bool mine = (r0 < nhit && g.v_dmin[r0] <= bound5) || (r1 < nhit && g.v_dmin[r1] <= bound5);
-                    if (!(__ballot(mine) & gmask)) break;
+                    if (!group_ballot(mine, lane)) break;
                 }
             }
 #pragma unroll
@@ -503,7 +514,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                     }
                 }
             }
-            if constexpr (kPrune) need_bound = (__ballot(ins) & gmask) != 0;
+            if constexpr (kPrune) need_bound = group_ballot(ins, lane) != 0;
         }
         if (gl == 0) visited += total;
         inrange = group_sum32(inrange);
@@ -528,7 +539,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         // The per-lane lists cannot lose a member of the top-5 (whatever a lane drops is no nearer than its own fifth), but
         // a dropped candidate exactly as far as that fifth would be an undetected tie if all five of the lane's entries
         // are among the six best: redo such a query exactly.
-        if (__ballot(pops >= 5 && drop_tie) & gmask) tie = true;
+        if (group_ballot(pops >= 5 && drop_tie, lane)) tie = true;
         // results.  No in-range candidate at all: GetClosestPoint returns before touching the output
         // (ivox3d.h:152-154), the cached neighbours of an earlier scan survive.
         if (active && inrange > 0) {
