@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(256, REUSE ? LIO_KNN_WAVES : LIO_KNN_WAVES_FIR
     if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
     const PoseArgs pose = pose_from_state(c->x);
     knn_body<KM, 0, INLINE_TIE, REUSE>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md,
-                                INLINE_TIE ? nullptr : &d.sd->n_tie, INLINE_TIE ? nullptr : d.tie_list, d.nn_meta, c->n_knn > 0 && reuse);
+                                INLINE_TIE ? nullptr : &d.sd->n_tie, INLINE_TIE ? nullptr : d.tie_list, d.nn_meta, c->n_knn > 0 && reuse && c->reuse_hint != 0);
 }
 
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------

@@ -175,13 +175,21 @@ def test_second_search_from_previous_neighbours_is_exact(oracle_mod):
     _dev()
     from lsd_amd import capi, lio
 
+    from lsd_amd import synth
+
     scene = scenes.config_scene()
-    for n_map, seeds in ((1_000_000, range(3100, 3112)), (60_000, range(3200, 3206))):
+    # priors 0.3 m off (the iterate leaves the neighbourhood of the first search: the short cut is not even tried), a sparse map, and priors
+    # 3 cm off -- a tracking front end's -- where the second search of most queries takes the short cut
+    for n_map, seeds, near in ((1_000_000, range(3100, 3112), False), (60_000, range(3200, 3206), False), (1_000_000, range(3300, 3312), True)):
         mp = scene.sample_surface(n_map, seed=4, sigma=0.01)
         the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=1_000_000)
         the_map.add(mp)
         keep = []
         jobs, meta = _jobs(scene, seeds, keep)
+        if near:
+            for k, (j, sc) in enumerate(zip(jobs, meta)):
+                gp, gq = synth.perturb_pose(sc["pos"], sc["q"], seed=9000 + k, max_t=0.03, max_deg=0.2)
+                j["state"] = synth.state_from_pose(gp, gq)
         out = {}
         for on in (1, 0):
             capi.lib().lio_debug_knn_reuse(on)
