@@ -65,6 +65,8 @@ def main():
                     help="metric: BASELINE.json's headline (independent 120k-pt scans vs a 1e7-pt map); merge: BASELINE config 5, multi-map merge -- 8 sub-maps "
                          "spread over the GPUs, every key-frame scan registered JOINTLY against all of them (RCCL all-gather of the per-rank J^T J / J^T r)")
     ap.add_argument("--lru", type=int, default=100000, help="--config stream: iVox capacity in voxels (the reference's 100000, laserMapping.cpp:1063); 0 = never evict")
+    ap.add_argument("--prior-t", type=float, default=0.3, help="prior error of a scan, metres (BASELINE: within 0.3 m)")
+    ap.add_argument("--prior-deg", type=float, default=2.0, help="prior error of a scan, degrees (BASELINE: within 2 deg)")
     ap.add_argument("--secondary", type=int, default=1, help="N = 1, --config metric: also run BASELINE config 2 (1e6-pt map) and a short config 3 "
                                                              "(streaming, map_incremental + LRU) after the timed region and report them under `configs`")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="the job list of --steps scans is repeated until the timed region lasts at least this long")
@@ -103,7 +105,7 @@ def main():
         pos = np.array([rng.uniform(-4, 4), rng.uniform(-4, 4), 1.8])
         q = synth.quat_from_rotvec([0, 0, rng.uniform(-np.pi, np.pi)])
         raw, _ = synth.make_scan(scene, pos, q, seed=args.seed + 100 * rank + k, n_az=args.n_az, fov_deg=(-24.8, 2.0), max_range=150.0)
-        gp, gq = synth.perturb_pose(pos, q, seed=args.seed + 7 * k + rank, max_t=0.3, max_deg=2.0)
+        gp, gq = synth.perturb_pose(pos, q, seed=args.seed + 7 * k + rank, max_t=args.prior_t, max_deg=args.prior_deg)
         scans.append(dict(raw=raw, pos=pos, q=q, guess=synth.state_from_pose(gp, gq)))
     n_raw = int(np.mean([len(s["raw"]) for s in scans]))
 

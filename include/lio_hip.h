@@ -76,9 +76,9 @@ int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double
  * point order drops and re-creates it; here it keeps its points -- the one case where the maps can differ). */
 int lio_map_set_lru(lio_map*, uint64_t capacity_voxels, double max_distance);
 int lio_map_lru_stats(lio_map*, uint64_t* n_evicted, uint64_t* n_interleaved);
-/* Diagnostic switch.  From the second neighbour search of an update on, a query that is still in the voxel of the scan's last full search is
- * searched only in the voxels that can beat the neighbours found then (csrc/knn.hip; results identical by construction).  0 turns that off
- * for objects created afterwards (also: environment LIO_KNN_REUSE=0). */
+/* Diagnostic switch.  From the second neighbour search of an update on, a query that is still in the voxel of the scan's last full search can be
+ * searched only in the voxels that can beat the neighbours found then (csrc/knn.hip; results identical by construction, tested).  Off by
+ * default -- measured as no gain (tools/experiments/README.md); 1 turns it on for objects created afterwards (also: LIO_KNN_REUSE=1). */
 void lio_debug_knn_reuse(int on);
 
 /* capacity planning: slots of the point pool handed out so far by the bump allocator (recycled regions of evicted / outgrown

@@ -690,8 +690,11 @@ __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __rest
 
 // tie_mode 0: tied queries are queued and redone by a second (usually empty) launch; 1: redone in place by their group -- one launch
 // less per pass, at 14 more vector registers (occupancy 5 instead of 6)
-// 0: every search probes the whole stencil (LIO_KNN_REUSE=0 or lio_debug_knn_reuse(0); diagnostic -- the results are identical)
-static int g_knn_reuse = [] { const char* e = getenv("LIO_KNN_REUSE"); return (e && e[0] == '0') ? 0 : 1; }();
+// 1: the re-search short cut (LIO_KNN_REUSE=1 or lio_debug_knn_reuse(1); the results are identical either way).  OFF by default: measured
+// on the metric config with the BASELINE priors (0.3 m: the hint never lets it run) and with tracking-size priors (3 cm: nearly every
+// second search takes it) it buys nothing -- 11.55 vs 11.39 us per scan and search -- because the regular sweep already prunes the far
+// voxels after its first batch and the short cut's own two dependent loads (search record, old neighbours) cost what the fewer probes save.
+static int g_knn_reuse = [] { const char* e = getenv("LIO_KNN_REUSE"); return (e && e[0] == '1') ? 1 : 0; }();
 void knn_set_reuse(int on) { g_knn_reuse = on ? 1 : 0; }
 
 int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode, int pass) {

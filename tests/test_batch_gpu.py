@@ -201,7 +201,7 @@ def test_second_search_from_previous_neighbours_is_exact(oracle_mod):
                 out[on] = (res, the_map.knn_candidates - c0)
                 del b
             finally:
-                capi.lib().lio_debug_knn_reuse(1)
+                capi.lib().lio_debug_knn_reuse(0)
         (ra, ca), (rb, cb) = out[1], out[0]
         assert ca == cb, (ca, cb)
         n_two = 0
@@ -227,6 +227,6 @@ def test_second_search_from_previous_neighbours_is_exact(oracle_mod):
                 st.append((e2.get_state(), e2.get_cov()))
             states[on] = st
         finally:
-            capi.lib().lio_debug_knn_reuse(1)
+            capi.lib().lio_debug_knn_reuse(0)
     for (sa, pa), (sb, pb) in zip(states[1], states[0]):
         assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
