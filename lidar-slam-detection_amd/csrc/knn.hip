@@ -54,7 +54,11 @@ __device__ inline uint32_t dpp_row(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
 __device__ inline uint32_t group_min32(uint32_t v) {
-    if constexpr (kG == 16) {
+    if constexpr (kG == 8) {  // half a DPP row: two quad permutes and the half-row mirror
+        v = min(v, dpp_row<0xB1>(v));
+        v = min(v, dpp_row<0x4E>(v));
+        v = min(v, dpp_row<0x141>(v));
+    } else if constexpr (kG == 16) {
         v = min(v, dpp_row<0x128>(v));
         v = min(v, dpp_row<0x124>(v));
         v = min(v, dpp_row<0x122>(v));
@@ -69,15 +73,19 @@ __device__ inline uint32_t group_min32(uint32_t v) {
 // the two halves of the wave-wide ballot and a bit-field extract -- the 64-bit and / popcount of the wave-wide form cost twice that
 __device__ inline uint32_t group_ballot(bool p, int lane) {
     const unsigned long long b = __ballot(p);
-    if constexpr (kG == 16) {
+    if constexpr (kG == 16 || kG == 8) {
         const uint32_t half = (lane & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
-        return (half >> (lane & 16)) & 0xFFFFu;
+        return (half >> (lane & (32 - kG) & 31)) & ((1u << kG) - 1u);
     } else {
         return (uint32_t)((b >> (lane & ~(kG - 1))) & ((1ull << kG) - 1ull));
     }
 }
 __device__ inline uint32_t group_max32(uint32_t v) {
-    if constexpr (kG == 16) {
+    if constexpr (kG == 8) {  // half a DPP row: two quad permutes and the half-row mirror
+        v = max(v, dpp_row<0xB1>(v));
+        v = max(v, dpp_row<0x4E>(v));
+        v = max(v, dpp_row<0x141>(v));
+    } else if constexpr (kG == 16) {
         v = max(v, dpp_row<0x128>(v));
         v = max(v, dpp_row<0x124>(v));
         v = max(v, dpp_row<0x122>(v));
@@ -89,7 +97,11 @@ __device__ inline uint32_t group_max32(uint32_t v) {
     return v;
 }
 __device__ inline uint32_t group_sum32(uint32_t v) {
-    if constexpr (kG == 16) {
+    if constexpr (kG == 8) {
+        v += dpp_row<0xB1>(v);
+        v += dpp_row<0x4E>(v);
+        v += dpp_row<0x141>(v);
+    } else if constexpr (kG == 16) {
         v += dpp_row<0x128>(v);
         v += dpp_row<0x124>(v);
         v += dpp_row<0x122>(v);
@@ -103,10 +115,13 @@ __device__ inline uint32_t group_sum32(uint32_t v) {
 
 // the occupied voxels of one query's stencil, compacted: 16-B aligned so that four descriptors come back from one
 // ds_read_b128; entries nhit .. nhit+3 are zero-filled (count 0) so that batches of four need no bounds test
+#ifndef LIO_KNN_LIST_CAP
+#define LIO_KNN_LIST_CAP kMaxStencil
+#endif
 struct __attribute__((aligned(16))) GroupLds {
-    uint32_t v_ptr[kMaxStencil + kU + 1];
-    uint32_t v_cnt[kMaxStencil + kU + 1];
-    uint32_t v_dmin[kMaxStencil + kU + 1];  // bits of a lower bound of the squared distance from the query to any point of the voxel
+    uint32_t v_ptr[LIO_KNN_LIST_CAP + kU + 1];
+    uint32_t v_cnt[LIO_KNN_LIST_CAP + kU + 1];
+    uint32_t v_dmin[LIO_KNN_LIST_CAP + kU + 1];  // bits of a lower bound of the squared distance from the query to any point of the voxel
 };
 
 // probe_stencil for stencils of at most 2 * kG cells (NEARBY6 / 18 / 26) with the hits BUCKETED by that lower bound: bucket 0 below
@@ -116,7 +131,7 @@ template <int KM>
 __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table, uint32_t mask, const StencilArgs& st, bool active, float4 pw,
                                                   float res, int kx, int ky, int kz, int gl, int lane, unsigned long long gmask, GroupLds& g,
                                                   uint32_t& nhit_out, uint32_t& n0_out, uint32_t& n01_out, uint32_t limit) {
-    static_assert(KM <= 2, "bucketed probe: at most 2 cells per lane");
+    static_assert(KM * kG <= 32, "bucketed probe: stencils of at most 32 cells");
     uint4 raw[KM];
     BrickProbe bp[KM];
     unsigned long long want[KM];
@@ -396,7 +411,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         int kx = 0, ky = 0, kz = 0;
         pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
         uint32_t nhit = 0;
-        constexpr bool kPrune = LIO_KNN_PRUNE && KM <= 2;
+        constexpr bool kPrune = LIO_KNN_PRUNE && KM * kG <= 32;
         uint32_t n0 = 0, n01 = 0, total;
         // Re-search of a later filter pass (use_prev: the scan has been searched in this update, the map has not changed since): the
         // query moved by centimetres.  If it is still in the voxel of the last full search -- same stencil, same candidate set -- the five
@@ -461,8 +476,9 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                     if (need_bound) bound5 = fifth_bound(d0, d4);
                     const uint32_t floor_bits = s0 < n0 ? 0u : (s0 < n01 ? b1_bits : b2_bits);
                     if (bound5 < floor_bits) break;
-                    const uint32_t r0 = s0 + gl, r1 = r0 + kG;
-                    const bool mine = (r0 < nhit && g.v_dmin[r0] <= bound5) || (r1 < nhit && g.v_dmin[r1] <= bound5);
+                    const uint32_t r0 = s0 + gl, r1 = r0 + kG, r2 = r1 + kG, r3 = r2 + kG;  // a pruned stencil has at most 32 cells
+                    const bool mine = (r0 < nhit && g.v_dmin[r0] <= bound5) || (r1 < nhit && g.v_dmin[r1] <= bound5) ||
+                                      (kG < 16 && ((r2 < nhit && g.v_dmin[r2] <= bound5) || (r3 < nhit && g.v_dmin[r3] <= bound5)));
                     if (!group_ballot(mine, lane)) break;
                 }
             }
