@@ -725,7 +725,7 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
     if (grid_x > cap) grid_x = cap;  // grid-stride loop inside: 16 queries per workgroup and round
     if (grid_x == 0) grid_x = 8;
     const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
-    const dim3 gridx(64, (uint32_t)n_slots);
+    const dim3 gridx(n_slots > 8 ? 8 : 64, (uint32_t)n_slots);  // the tie queue of a scan holds a handful of queries at most: a few workgroups per slot (grid-stride inside)
     const int km = (m->stencil.n + kG - 1) / kG;
     const int reuse = g_knn_reuse;
 #define KNNB_LAUNCH1(KM, TIE, RE) \
