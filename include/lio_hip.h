@@ -267,6 +267,12 @@ int lio_fastlio_init(lio_engine*, const double extT[3], const double extR[9], in
                      int undistort);
 int lio_fastlio_is_init(lio_engine*);
 int lio_fastlio_imu_enqueue(lio_engine*, double stamp, const double gyr[3], const double acc_ms2[3]);
+/* Where the iterate loop of lio_engine_update / lio_engine_process_scan / lio_fastlio_main runs.  0 (default): on the host -- one
+ * device linearisation and one hand-over per pass (esekfom.hpp:1619-1931 driven from the CPU, 8 us of host algebra per pass).  1: on the
+ * device (the batched engine's loop for this one scan: one submission, one wait; the calling thread is free meanwhile, the scan takes
+ * ~15 % longer).  Results identical (tests/test_gpu_parity.py).  Environment LIO_DEVICE_LOOP=1 sets the default of new engines. */
+int lio_engine_set_device_loop(lio_engine*, int on);
+
 /* fastlio_ins_enqueue (src/laserMapping.cpp:417-441) after the ENU -> ego -> IMU rotation the reference applies there:
  * vel_imu = Lidar_R_wrt_IMU * Tve^-1 * (Ve, Vn, Vu), third component zeroed by the caller as :436 does.  Only IMU
  * initialisation reads it (IMU_Processing.hpp:201-204; the wheel-speed rows are compiled out, wheelspeed_en == false) */

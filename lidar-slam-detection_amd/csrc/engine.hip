@@ -81,7 +81,9 @@ int devloop_update(lio_devloop* d, lio_map* m, lio_scan* sc, const double* x26, 
 struct lio_engine {
     Frontend* fe = nullptr;
     lio_devloop* dl = nullptr;
-    int device_loop = 1;  // LIO_DEVICE_LOOP=0: the round-1 host loop (one hand-over per pass)
+    int device_loop = 0;  // lio_engine_set_device_loop / LIO_DEVICE_LOOP=1: the iterate loop of ONE scan on the device too (one submission, one
+                          // wait: the host thread is free meanwhile, the scan takes ~15 % longer -- five serial filter kernels and five blind
+                          // tie-queue launches against four to five hand-overs); the batched engine always runs it on the device
     lio_map* map;
     lio_scan* scan;
     Eskf kf;
@@ -425,7 +427,7 @@ lio_engine* lio_engine_create(int device, float resolution, int stencil, uint64_
     lio_engine* e = new lio_engine();
     e->map = m;
     e->scan = s;
-    { const char* k = getenv("LIO_DEVICE_LOOP"); e->device_loop = (k && k[0] == '0') ? 0 : 1; }
+    { const char* k = getenv("LIO_DEVICE_LOOP"); e->device_loop = (k && k[0] == '1') ? 1 : 0; }
     s->resize_min = 5;
     memset(&e->tm, 0, sizeof(e->tm));
     return e;
@@ -438,7 +440,7 @@ lio_engine* lio_engine_create_shared(lio_map* shared_map, uint32_t max_raw, uint
     lio_engine* e = new lio_engine();
     e->map = shared_map;
     e->scan = s;
-    { const char* k = getenv("LIO_DEVICE_LOOP"); e->device_loop = (k && k[0] == '0') ? 0 : 1; }
+    { const char* k = getenv("LIO_DEVICE_LOOP"); e->device_loop = (k && k[0] == '1') ? 1 : 0; }
     s->resize_min = 5;
     e->own_map = false;
     e->static_map = true;  // several engines read one map concurrently: nobody inserts
@@ -997,6 +999,12 @@ int lio_fastlio_imu_enqueue(lio_engine* e, double stamp, const double gyr[3], co
 
 // fastlio_ins_enqueue (laserMapping.cpp:417-441) after its ENU -> ego -> IMU rotation: the caller passes the velocity in the
 // IMU frame (the reference zeroes its third component, :436); consumed by IMU initialisation only (wheelspeed_en == false)
+int lio_engine_set_device_loop(lio_engine* e, int on) {
+    if (!e) return LIO_E_INVALID;
+    e->device_loop = on ? 1 : 0;
+    return LIO_OK;
+}
+
 int lio_fastlio_ins_enqueue(lio_engine* e, double stamp, const double vel_imu[3]) {
     if (!e || !e->fe || !vel_imu) return LIO_E_INVALID;
     std::lock_guard<std::mutex> lk(e->fe->mtx);

@@ -262,6 +262,10 @@ class Engine:
 
     __del__ = close
 
+    def set_device_loop(self, on=True):
+        """run the iterate loop of this engine's updates on the device (one submission, one wait) instead of from the host"""
+        check(lib().lio_engine_set_device_loop(self.h, int(on)), "set_device_loop")
+
     def set_state(self, s):
         s = f64(s)
         assert s.size == STATE_DIM

@@ -40,3 +40,11 @@ def small_world(scene):
     raw, t = synth.make_scan(scene, true_pos, true_q, seed=7, n_az=600)
     g_pos, g_q = synth.perturb_pose(true_pos, true_q, seed=11, max_t=0.2, max_deg=1.5)
     return dict(map=map_pts, raw=raw, true_pos=true_pos, true_q=true_q, guess_pos=g_pos, guess_q=g_q)
+
+
+@pytest.fixture(params=["host_loop", "device_loop"])
+def loop_mode(request, monkeypatch):
+    """where the iterate loop of a single engine's update runs: engines created inside the test take the mode from LIO_DEVICE_LOOP
+    (lio_engine_set_device_loop changes it per engine); the results must not depend on it"""
+    monkeypatch.setenv("LIO_DEVICE_LOOP", "1" if request.param == "device_loop" else "0")
+    return request.param

@@ -218,6 +218,7 @@ def test_second_search_from_previous_neighbours_is_exact(oracle_mod):
         capi.lib().lio_debug_knn_reuse(on)
         try:
             e2 = lio.Engine(max_raw=1 << 18, max_ds=100000, shared_map=the_map)
+            e2.set_device_loop(True)
             e2.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
             st = []
             for k, j in enumerate(jobs):

@@ -125,7 +125,7 @@ def _hip_run(case, ds):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(scenes.DEGENERATE_CASES))
-def test_hip_degenerate_projection_matches_oracle(oracle_mod, name):
+def test_hip_degenerate_projection_matches_oracle(oracle_mod, name, loop_mode):
     _dev()
     from lsd_amd import lio, synth
 
@@ -165,7 +165,7 @@ def test_hip_degenerate_projection_matches_oracle(oracle_mod, name):
 
 
 @pytest.mark.gpu
-def test_hip_sparse_scan_dense_branch_matches_oracle(oracle_mod):
+def test_hip_sparse_scan_dense_branch_matches_oracle(oracle_mod, loop_mode):
     """N_eff < 23: lio_p2plane_rows + the dense gain of esekfom.hpp:1715-1744 on the device path, degeneracy-projected rows"""
     _dev()
     from lsd_amd import synth

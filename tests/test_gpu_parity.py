@@ -232,7 +232,7 @@ def test_linearize_matches_oracle(oracle_mod, small_world):
     assert np.allclose(got2["JtJ"], ref2["JtJ"], rtol=1e-10, atol=1e-9)
 
 
-def test_iterated_update_pose_parity(oracle_mod, small_world):
+def test_iterated_update_pose_parity(oracle_mod, small_world, loop_mode):
     _dev()
     from lsd_amd import synth
 
@@ -259,7 +259,7 @@ def test_iterated_update_pose_parity(oracle_mod, small_world):
     assert e.map.stats() == (o.map_num_points, o.map_num_voxels)
 
 
-def test_process_scan_sequence(oracle_mod, scene):
+def test_process_scan_sequence(oracle_mod, scene, loop_mode):
     _dev()
     from lsd_amd import lio, synth
 
