@@ -277,6 +277,11 @@ int lio_engine_set_device_loop(lio_engine*, int on);
  * vel_imu = Lidar_R_wrt_IMU * Tve^-1 * (Ve, Vn, Vu), third component zeroed by the caller as :436 does.  Only IMU
  * initialisation reads it (IMU_Processing.hpp:201-204; the wheel-speed rows are compiled out, wheelspeed_en == false) */
 int lio_fastlio_ins_enqueue(lio_engine*, double stamp, const double vel_imu[3]);
+/* wheelspeed_en (src/laserMapping.cpp:83, a constant false in the reference: its binaries never take the branch).  When enabled, a scan
+ * whose last INS sample (lio_fastlio_ins_enqueue) is within 10 ms of the scan's end gets the three velocity rows of
+ * h_share_model_wheelspeed (:794-811) appended to its point-to-plane rows in every pass of the update (:994-1012: weight 1e-4, 1e-3 when
+ * degenerate, times the rows before them).  Such updates run the iterate loop from the host. */
+int lio_fastlio_set_wheelspeed(lio_engine*, int enable);
 int lio_fastlio_pcl_enqueue(lio_engine*, const float* xyzi, const uint32_t* stamp_us, uint32_t n, double header_stamp);
 /* the same without an intermediate copy (boundary marshalling, numpy_to_pointcloud + preprocessPoints of the reference: slam/src/py_utils.cpp:
  * 149-181, slam/common/slam_base.h:83-85): _stage hands out the pinned staging buffers of the next scan (room for n points), the caller writes

@@ -98,6 +98,9 @@ struct lio_engine {
     double travel = 0, first_lidar_time = 0;
     double last_pos_lid[3] = {0, 0, 0};
     bool flg_first_scan = true, flg_EKF_inited = false, is_degenerate = false;
+    // wheel-speed rows (laserMapping.cpp:794-811): wheelspeed_en, and Measures.ins.back() / lidar_end_time of the scan being registered
+    bool wheelspeed_en = false, meas_ins_valid = false;
+    double meas_ins_stamp = 0.0, meas_lidar_end = 0.0, meas_ins_vel[3] = {0, 0, 0};
     std::vector<lio_pass_log> log;
     // timing
     bool timing = false;
@@ -328,8 +331,33 @@ int run_update_device(lio_engine* e) {
     return LIO_OK;
 }
 
+// h_share_model's wheel-speed part (laserMapping.cpp:794-811, 994-1012) on top of whatever the point-to-plane part of this pass is -- fresh
+// rows, the previous pass's whole measurement (stale copy), or nothing: three rows dh/dv = I3 with h = (rot * v_ins - vel) * weight,
+// weight = 1e-4 (1e-3 when degenerate) x the rows before them, as a float.
+void append_wheelspeed(lio_engine* e, const LioState& x, Measurement& m) {
+    if (!(e->wheelspeed_en && e->meas_ins_valid && (e->meas_lidar_end - e->meas_ins_stamp) < 0.01)) return;
+    if (!m.valid) {  // no point-to-plane rows at all: the three rows are the measurement (n_terms = 3)
+        m.valid = true;
+        m.n_rows = 0;
+        m.n_geo = 0;
+        m.ws_n = 0;
+        m.rows6 = nullptr;
+        m.h = nullptr;
+        memset(m.HTH, 0, sizeof(m.HTH));
+        memset(m.HTh, 0, sizeof(m.HTh));
+    }
+    if (m.ws_n == 0) m.n_geo = m.n_rows;
+    if (m.ws_n >= 6) return;
+    const float weight = !e->is_degenerate ? (float)(0.0001 * m.n_rows) : (float)(0.001 * m.n_rows);
+    double vel[3];
+    quat_rotate(x.rot, e->meas_ins_vel, vel);
+    for (int a = 0; a < 3; a++) m.ws_h[m.ws_n][a] = (vel[a] - x.vel[a]) * weight;
+    m.ws_n++;
+    m.n_rows += 3;
+}
+
 int run_update(lio_engine* e) {
-    if (e->device_loop && !e->reduce && !e->timing && e->kf.maximum_iter + 1 <= kEkMaxPass) return run_update_device(e);
+    if (e->device_loop && !e->reduce && !e->timing && !e->wheelspeed_en && e->kf.maximum_iter + 1 <= kEkMaxPass) return run_update_device(e);
     e->log.clear();
     PassCtx ctx{e, LIO_OK};
     double host_us = 0;
@@ -350,9 +378,16 @@ int run_update(lio_engine* e) {
             pl.valid = 1;
             memcpy(pl.JtJ, m.HTH, sizeof(pl.JtJ));
             memcpy(pl.Jtr, m.HTh, sizeof(pl.Jtr));
-        } else if (m.valid) {
+        }
+        append_wheelspeed(e, x, m);
+        if (m.valid) {  // what the next pass's copy of the shared struct holds: the whole measurement of this one
+            pl.valid = 1;
+            if (m.rows6 && m.rows6 != prev_rows.data()) {
+                const int ng = m.ws_n > 0 ? m.n_geo : m.n_rows;
+                prev_rows.assign(m.rows6, m.rows6 + (size_t)ng * 6);
+                prev_h.assign(m.h, m.h + ng);
+            }
             prev = m;
-            if (m.rows6) { prev_rows.assign(m.rows6, m.rows6 + (size_t)m.n_rows * 6); prev_h.assign(m.h, m.h + m.n_rows); }
             have_prev = true;
         }
         e->log.push_back(pl);
@@ -401,9 +436,16 @@ int engine_resume_update_impl(lio_engine* e, const double* x_now26, const double
             pl.valid = 1;
             memcpy(pl.JtJ, m.HTH, sizeof(pl.JtJ));
             memcpy(pl.Jtr, m.HTh, sizeof(pl.Jtr));
-        } else if (m.valid) {
+        }
+        append_wheelspeed(e, x, m);
+        if (m.valid) {  // what the next pass's copy of the shared struct holds: the whole measurement of this one
+            pl.valid = 1;
+            if (m.rows6 && m.rows6 != prev_rows.data()) {
+                const int ng = m.ws_n > 0 ? m.n_geo : m.n_rows;
+                prev_rows.assign(m.rows6, m.rows6 + (size_t)ng * 6);
+                prev_h.assign(m.h, m.h + ng);
+            }
             prev = m;
-            if (m.rows6) { prev_rows.assign(m.rows6, m.rows6 + (size_t)m.n_rows * 6); prev_h.assign(m.h, m.h + m.n_rows); }
             have_prev = true;
         }
         e->log.push_back(pl);
@@ -999,6 +1041,12 @@ int lio_fastlio_imu_enqueue(lio_engine* e, double stamp, const double gyr[3], co
 
 // fastlio_ins_enqueue (laserMapping.cpp:417-441) after its ENU -> ego -> IMU rotation: the caller passes the velocity in the
 // IMU frame (the reference zeroes its third component, :436); consumed by IMU initialisation only (wheelspeed_en == false)
+int lio_fastlio_set_wheelspeed(lio_engine* e, int enable) {
+    if (!e) return LIO_E_INVALID;
+    e->wheelspeed_en = enable != 0;
+    return LIO_OK;
+}
+
 int lio_engine_set_device_loop(lio_engine* e, int on) {
     if (!e) return LIO_E_INVALID;
     e->device_loop = on ? 1 : 0;
@@ -1135,9 +1183,13 @@ int lio_fastlio_main(lio_engine* e) {
         }
         while (!f->ins_buffer.empty() && !(f->ins_buffer.front().first > lidar_end)) {  // meas.ins (laserMapping.cpp:495-503)
             for (int i = 0; i < 3; i++) ins_vel[i] = f->ins_buffer.front().second[i];
+            e->meas_ins_stamp = f->ins_buffer.front().first;
             have_ins = true;
             f->ins_buffer.pop_front();
         }
+        e->meas_ins_valid = have_ins;  // meas.ins is rebuilt for every scan
+        for (int i = 0; i < 3; i++) e->meas_ins_vel[i] = ins_vel[i];
+        e->meas_lidar_end = lidar_end;
     }
     hipSetDevice(s->device);
     memset(&e->tm, 0, sizeof(e->tm));

@@ -380,20 +380,25 @@ int Eskf::step(Work& w, double R, const Measurement& m, int i, bool& converge, i
     cols_mul_T(P, N, N, 21, 2, Jg);
 
     memset(w.K_x, 0, sizeof(w.K_x));
-    if (N > m.n_rows && m.rows6) {
-        // K = P H^T (H P H^T / R + I)^-1 / R with H = [rows6 | 0]   (esekfom.hpp:1715-1744)
+    const int ng = m.ws_n > 0 ? m.n_geo : m.n_rows;  // point-to-plane rows; the wheel-speed triples follow them
+    if (N > m.n_rows && (m.rows6 || ng == 0)) {
+        // K = P H^T (H P H^T / R + I)^-1 / R with H = [rows6 | 0] (+ unit rows at columns 12..14 per wheel-speed triple)   (esekfom.hpp:1715-1744)
         const int d = m.n_rows;
-        std::vector<double> PHt((size_t)N * d), S((size_t)d * d), Si((size_t)d * d), K((size_t)N * d);
+        std::vector<double> PHt((size_t)N * d), S((size_t)d * d), Si((size_t)d * d), K((size_t)N * d), hv(d);
+        for (int r = 0; r < ng; r++) hv[r] = m.h[r];
+        for (int r = ng; r < d; r++) hv[r] = m.ws_h[(r - ng) / 3][(r - ng) % 3];
         for (int a = 0; a < N; a++)
             for (int r = 0; r < d; r++) {
                 double s = 0;
-                for (int c = 0; c < 6; c++) s += P[a * N + c] * m.rows6[r * 6 + c];
+                if (r < ng) for (int c = 0; c < 6; c++) s += P[a * N + c] * m.rows6[r * 6 + c];
+                else s = P[a * N + 12 + (r - ng) % 3];
                 PHt[(size_t)a * d + r] = s;
             }
         for (int r = 0; r < d; r++)
             for (int q = 0; q < d; q++) {
                 double s = 0;
-                for (int c = 0; c < 6; c++) s += m.rows6[r * 6 + c] * PHt[(size_t)c * d + q];
+                if (r < ng) for (int c = 0; c < 6; c++) s += m.rows6[r * 6 + c] * PHt[(size_t)c * d + q];
+                else s = PHt[(size_t)(12 + (r - ng) % 3) * d + q];
                 S[(size_t)r * d + q] = s / R + (r == q ? 1.0 : 0.0);
             }
         mat_inverse(S.data(), d, Si.data());
@@ -405,47 +410,61 @@ int Eskf::step(Work& w, double R, const Measurement& m, int i, bool& converge, i
             }
         for (int a = 0; a < N; a++) {
             double s = 0;
-            for (int r = 0; r < d; r++) s += K[(size_t)a * d + r] * m.h[r];
+            for (int r = 0; r < d; r++) s += K[(size_t)a * d + r] * hv[r];
             w.K_h[a] = s;
             for (int c = 0; c < 6; c++) {
                 double v = 0;
-                for (int r = 0; r < d; r++) v += K[(size_t)a * d + r] * m.rows6[r * 6 + c];
+                for (int r = 0; r < ng; r++) v += K[(size_t)a * d + r] * m.rows6[r * 6 + c];
                 w.K_x[a * N + c] = v;
+            }
+            for (int j = 0; j < 3 && m.ws_n > 0; j++) {
+                double v = 0;
+                for (int t2 = 0; t2 < m.ws_n; t2++) v += K[(size_t)a * d + ng + 3 * t2 + j];
+                w.K_x[a * N + 12 + j] = v;
             }
         }
     } else {
         // esekfom.hpp:1782-1809:  P_temp = (P/R)^-1;  P_temp[0:15,0:15] += HTH;  P_inv = P_temp^-1;
         //                         K_h = P_inv[:, 0:15] h_x^T h;  K_x[:, 0:15] = P_inv[:, 0:15] HTH.
-        // HTH is non-zero only in its leading 6x6 block B (extrinsic_est_en == false), so with A = (P/R)^-1,
-        // E = the first six unit columns and the matrix inversion lemma,
-        //   P_inv E = (A + E B E^T)^-1 E = (P/R) E (I6 + B (P/R)_66)^-1 ,
-        // which is all K_h and K_x need: one 6x6 inverse instead of the reference's two 23x23 ones (and no
+        // HTH is non-zero only on the index set S = {0..5} (extrinsic_est_en == false; plus {12, 13, 14} with wheel-speed rows, whose block
+        // is ws_n I3), so with A = (P/R)^-1, E = the unit columns of S, B = HTH_SS and the matrix inversion lemma,
+        //   P_inv E = (A + E B E^T)^-1 E = (P/R) E (I + B (P/R)_SS)^-1 ,
+        // which is all K_h and K_x need: one |S| x |S| inverse instead of the reference's two 23x23 ones (and no
         // inverse of the possibly singular, degeneracy-projected B).  Same quantities, better conditioned.
-        double G[N * 6], M6[36], M6i[36];
+        const int ns = m.ws_n > 0 ? 9 : 6;
+        const int idx[9] = {0, 1, 2, 3, 4, 5, 12, 13, 14};
+        double B[81], Bh[9];
+        for (int a = 0; a < ns; a++) {
+            for (int c = 0; c < ns; c++) B[a * ns + c] = (a < 6 && c < 6) ? m.HTH[a * 6 + c] : ((a == c) ? (double)m.ws_n : 0.0);
+            Bh[a] = a < 6 ? m.HTh[a] : 0.0;
+        }
+        for (int t2 = 0; t2 < m.ws_n; t2++)
+            for (int j = 0; j < 3; j++) Bh[6 + j] += m.ws_h[t2][j];
+        double G[N * 9], Mx[81], Mi[81];
         for (int a = 0; a < N; a++)
-            for (int c = 0; c < 6; c++) G[a * 6 + c] = P[a * N + c] / R;
-        for (int a = 0; a < 6; a++)
-            for (int c = 0; c < 6; c++) {
+            for (int c = 0; c < ns; c++) G[a * ns + c] = P[a * N + idx[c]] / R;
+        for (int a = 0; a < ns; a++)
+            for (int c = 0; c < ns; c++) {
                 double v = (a == c) ? 1.0 : 0.0;
-                for (int k = 0; k < 6; k++) v += m.HTH[a * 6 + k] * G[k * 6 + c];
-                M6[a * 6 + c] = v;
+                for (int k = 0; k < ns; k++) v += B[a * ns + k] * G[idx[k] * ns + c];
+                Mx[a * ns + c] = v;
             }
-        mat_inverse(M6, 6, M6i);
-        double Pi6[N * 6];  // P_inv[:, 0:6]
+        mat_inverse(Mx, ns, Mi);
+        double Pi[N * 9];  // P_inv[:, S]
         for (int a = 0; a < N; a++)
-            for (int c = 0; c < 6; c++) {
+            for (int c = 0; c < ns; c++) {
                 double v = 0;
-                for (int k = 0; k < 6; k++) v += G[a * 6 + k] * M6i[k * 6 + c];
-                Pi6[a * 6 + c] = v;
+                for (int k = 0; k < ns; k++) v += G[a * ns + k] * Mi[k * ns + c];
+                Pi[a * ns + c] = v;
             }
         for (int a = 0; a < N; a++) {
             double s = 0;
-            for (int c = 0; c < 6; c++) s += Pi6[a * 6 + c] * m.HTh[c];
+            for (int c = 0; c < ns; c++) s += Pi[a * ns + c] * Bh[c];
             w.K_h[a] = s;
-            for (int bcol = 0; bcol < 6; bcol++) {
+            for (int bcol = 0; bcol < ns; bcol++) {
                 double v = 0;
-                for (int c = 0; c < 6; c++) v += Pi6[a * 6 + c] * m.HTH[c * 6 + bcol];
-                w.K_x[a * N + bcol] = v;
+                for (int c = 0; c < ns; c++) v += Pi[a * ns + c] * B[c * ns + bcol];
+                w.K_x[a * N + idx[bcol]] = v;
             }
         }
     }

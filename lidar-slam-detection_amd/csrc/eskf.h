@@ -46,8 +46,13 @@ struct Measurement {
     int n_rows;            // dof_Measurement
     double HTH[36];        // top-left 6 x 6 of h_x^T h_x
     double HTh[6];         // first 6 entries of h_x^T h
-    const double* rows6;   // n_rows x 6, only when n_rows < 23 (dense branch, esekfom.hpp:1715-1744)
-    const double* h;       // n_rows
+    const double* rows6;   // n_geo x 6, only when n_rows < 23 (dense branch, esekfom.hpp:1715-1744)
+    const double* h;       // n_geo
+    // wheel-speed rows (laserMapping.cpp:794-811, 994-1012): ws_n triples of rows dh/dv = I3 (state columns 12..14) appended after the
+    // n_geo point-to-plane rows, ws_h their (weighted) residuals; n_rows = n_geo + 3 ws_n.  ws_n == 0 unless the engine enables them.
+    int n_geo = 0;
+    int ws_n = 0;
+    double ws_h[6][3];
 };
 
 struct Eskf {

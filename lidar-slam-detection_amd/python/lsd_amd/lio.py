@@ -337,6 +337,10 @@ class Engine:
         g, a = f64(gyr), f64(acc_ms2)
         check(lib().lio_fastlio_imu_enqueue(self.h, float(stamp), ptr(g, C.c_double), ptr(a, C.c_double)))
 
+    def fastlio_set_wheelspeed(self, on=True):
+        """wheelspeed_en of laserMapping.cpp:83: append the wheel-speed rows (:794-811) when the scan's last INS sample is within 10 ms of its end"""
+        check(lib().lio_fastlio_set_wheelspeed(self.h, int(on)), "set_wheelspeed")
+
     def fastlio_ins_enqueue(self, stamp, vel_imu):
         v = f64(vel_imu)
         check(lib().lio_fastlio_ins_enqueue(self.h, float(stamp), ptr(v, C.c_double)))

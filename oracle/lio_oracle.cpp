@@ -904,6 +904,10 @@ struct Lio {
     // measurement model supplied from outside (tests/test_ikfom_vs_ref.py drives the oracle, the product's host filter and
     // the reference's real esekf with the same rows): fn(ctx, state26, converge, &n, rows n x 6, h n, cap) -> valid
     typedef int (*meas_fn)(void* ctx, const double* s26, int converge, int* n, double* rows6, double* h, int cap);
+    bool wheelspeed_en = false;   // laserMapping.cpp:83
+    bool meas_ins_valid = false;  // Measures.ins.back() of the scan being registered, and its lidar_end_time
+    double meas_ins_stamp = 0.0, meas_lidar_end = 0.0;
+    V3 meas_ins_vel{{0, 0, 0}};
     meas_fn ext_fn = nullptr;
     void* ext_ctx = nullptr;
     int ext_cap = 0;
@@ -920,11 +924,32 @@ struct Lio {
             effct_feat_num = n;
             return;
         }
+        // h_share_model_wheelspeed (laserMapping.cpp:794-811): three rows dh/dv = I, h = rot * v_ins - vel, when wheelspeed_en and the last
+        // INS sample of this scan is within 10 ms of its end.  (wheelspeed_en is a constant false in the reference: dead code there.)
+        bool ws_valid = false;
+        double ws_h[3] = {0, 0, 0};
+        if (wheelspeed_en && meas_ins_valid && (meas_lidar_end - meas_ins_stamp) < 0.01) {
+            const V3 vel = qrot(s.rot, meas_ins_vel);
+            for (int a = 0; a < 3; a++) ws_h[a] = vel[a] - s.vel[a];
+            ws_valid = true;
+        }
         DynShare geo = d;  // copy: stale h_x / h of the previous pass survive an early return
         h_share_model_geometric(s, geo);
-        const int n_terms = (int)geo.h.size();
-        d.h_x = geo.h_x;
-        d.h = geo.h;
+        const int n_geo = (int)geo.h.size();
+        const int n_terms = n_geo + (ws_valid ? 3 : 0);
+        if (ws_valid) {  // :994-1012
+            const float weight = !is_degenerate ? (float)(0.0001 * n_geo) : (float)(0.001 * n_geo);
+            Mat hx(n_terms, 15);
+            for (int r = 0; r < n_geo; r++)
+                for (int c = 0; c < 15; c++) hx(r, c) = geo.h_x(r, c);
+            for (int a = 0; a < 3; a++) hx(n_geo + a, 12 + a) = 1.0;
+            d.h_x = hx;
+            d.h = geo.h;
+            for (int a = 0; a < 3; a++) d.h.push_back(ws_h[a] * weight);
+        } else {
+            d.h_x = geo.h_x;
+            d.h = geo.h;
+        }
         if (n_terms == 0) d.valid = false;
     }
 
@@ -1438,7 +1463,15 @@ struct Lio {
         while (!imu_buffer.empty() && !(imu_buffer.front().stamp > lidar_end)) { meas_imu.push_back(imu_buffer.front()); imu_buffer.pop_front(); }
         bool have_ins = false;
         V3 ins_vel{{0, 0, 0}};
-        while (!ins_buffer.empty() && !(ins_buffer.front().first > lidar_end)) { ins_vel = ins_buffer.front().second; have_ins = true; ins_buffer.pop_front(); }
+        while (!ins_buffer.empty() && !(ins_buffer.front().first > lidar_end)) {
+            ins_vel = ins_buffer.front().second;
+            meas_ins_stamp = ins_buffer.front().first;
+            have_ins = true;
+            ins_buffer.pop_front();
+        }
+        meas_ins_valid = have_ins;  // meas.ins is rebuilt for every scan (laserMapping.cpp:495-503)
+        meas_ins_vel = ins_vel;
+        meas_lidar_end = lidar_end;
         if (flg_first_scan) { first_lidar_time = sc.beg; flg_first_scan = false; return 0; }
         // Process() returns at once when no IMU sample fell into the scan: feats_undistort keeps the PREVIOUS scan's cloud
         // and fastlio_main registers that again (IMU_Processing.hpp:413, laserMapping.cpp:1189-1197)
@@ -1724,6 +1757,7 @@ void orc_lio_frontend_config(void* h, const double* extT, const double* extR_xyz
     l->undistort_en = undistort != 0;
 }
 void orc_lio_set_max_point_num(void* h, int n) { static_cast<Lio*>(h)->max_point_num = n; }  // p_pre->max_point_num (laserMapping.cpp:1100)
+void orc_lio_set_wheelspeed(void* h, int on) { static_cast<Lio*>(h)->wheelspeed_en = on != 0; }
 void orc_lio_ins_enqueue(void* h, double stamp, const double* v) { static_cast<Lio*>(h)->ins_buffer.push_back({stamp, V3{{v[0], v[1], v[2]}}}); }
 int orc_lio_frontend_main(void* h) { return static_cast<Lio*>(h)->frontend_main(); }
 void orc_lio_predict(void* h, double dt, const double* acc, const double* gyro) {

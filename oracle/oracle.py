@@ -78,6 +78,7 @@ def lib():
     L.orc_lio_pcl_enqueue.argtypes = [C.c_void_p, f32p, C.POINTER(C.c_uint32), C.c_int, C.c_double]
     L.orc_lio_frontend_config.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, C.c_int]
     L.orc_lio_ins_enqueue.argtypes = [C.c_void_p, C.c_double, f64p]
+    L.orc_lio_set_wheelspeed.argtypes = [C.c_void_p, C.c_int]
     L.orc_lio_frontend_main.argtypes = [C.c_void_p]
     L.orc_lio_frontend_main.restype = C.c_int
     L.orc_lio_predict.argtypes = [C.c_void_p, C.c_double, f64p, f64p]
@@ -284,6 +285,10 @@ class Lio:
         t, r = _f64(extT), _f64(extR_xyzw)
         lib().orc_lio_frontend_config(self.h, _p(t, C.c_double), _p(r, C.c_double), filter_num, float(scan_period), int(undistort))
         lib().orc_lio_set_max_point_num(self.h, int(max_point_num))
+
+    def set_wheelspeed(self, on):
+        """wheelspeed_en of laserMapping.cpp:83 (a constant false in the reference: its wheel-speed rows, :794-811, are dead code there)"""
+        lib().orc_lio_set_wheelspeed(self.h, int(on))
 
     def ins_enqueue(self, stamp, vel_imu):
         v = _f64(vel_imu)

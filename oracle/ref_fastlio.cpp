@@ -141,6 +141,7 @@ void ref_fl_canonical_neighbours() {
 
 void ref_fl_set_canonical(int on) { g_canonical = on; }
 void ref_fl_set_logging(int on) { g_log = on; }
+void ref_fl_set_wheelspeed(int on) { wheelspeed_en = on != 0; }  // the file-scope constant of laserMapping.cpp:83 (never set by the reference itself)
 
 // ---- the registration step alone, for bench.py's cpu_baseline ("reference") and full-size parity: a static map, a raw cloud, a prior.
 // What runs is the reference's: IVox::AddPoints, SetNearByType, the block of fastlio_main between the downsample and the filter update

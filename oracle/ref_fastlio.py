@@ -65,6 +65,9 @@ class RefFastLio:
         g, a = np.ascontiguousarray(gyr, np.float64), np.ascontiguousarray(acc_ms2, np.float64)
         lib().ref_fl_imu_enqueue(float(stamp), _p(a), _p(g))
 
+    def set_wheelspeed(self, on):
+        lib().ref_fl_set_wheelspeed(int(on))
+
     def ins_enqueue(self, rtk_valid, stamp_us, heading, pitch, roll, Ve, Vn, Vu, sensor="Wheel"):
         lib().ref_fl_ins_enqueue(int(rtk_valid), int(stamp_us), heading, pitch, roll, Ve, Vn, Vu, sensor.encode())
 
