@@ -303,6 +303,10 @@ int lio_fastlio_download_undistorted(lio_engine*, float* out_xyzi, uint32_t cap,
 typedef int (*lio_meas_fn)(void* ctx, const double* s26, int converge, int* n, double* rows6, double* h, int cap);
 int lio_eskf_update_cb(const double s26[26], const double P[529], double R, int max_iter, lio_meas_fn fn, void* ctx, int cap, double s26_out[26],
                        double P_out[529]);
+/* ... with the wheel-speed rows (src/laserMapping.cpp:794-811, 994-1012) appended to the model's rows in every pass: ins_vel = the INS velocity in
+ * the IMU frame (NULL: none), degenerate = the is_degenerate flag the weight depends on */
+int lio_eskf_update_ws_cb(const double s26[26], const double P[529], double R, int max_iter, lio_meas_fn fn, void* ctx, int cap, const double* ins_vel,
+                          int degenerate, double s26_out[26], double P_out[529]);
 int lio_state_predict(const double s26[26], const double P[529], double dt, const double Q[12], const double acc[3], const double gyro[3],
                       double s26_out[26], double P_out[529]);
 /* test visibility, host-only: the DEVICE-resident form of update_iterated_dyn_share_modified (csrc/eskf_dev.h: the filter pass as

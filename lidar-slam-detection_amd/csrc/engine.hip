@@ -1293,6 +1293,12 @@ int lio_state_predict(const double s26[26], const double P[529], double dt, cons
 // by the CPU tests that pin the filter algebra against the reference's own IKFoM code.
 int lio_eskf_update_cb(const double s26[26], const double P[529], double R, int max_iter, lio_meas_fn fn, void* ctx, int cap, double s26_out[26],
                        double P_out[529]) {
+    return lio_eskf_update_ws_cb(s26, P, R, max_iter, fn, ctx, cap, nullptr, 0, s26_out, P_out);
+}
+
+// ... with the wheel-speed rows of laserMapping.cpp:794-811 appended in every pass when ins_vel is given (Measures.ins.back() in the IMU frame)
+int lio_eskf_update_ws_cb(const double s26[26], const double P[529], double R, int max_iter, lio_meas_fn fn, void* ctx, int cap, const double* ins_vel,
+                          int degenerate, double s26_out[26], double P_out[529]) {
     if (!s26 || !P || !fn || !s26_out || !P_out || cap <= 0 || max_iter < 0) return LIO_E_INVALID;
     Eskf kf;
     state_from_array(s26, kf.x);
@@ -1315,6 +1321,15 @@ int lio_eskf_update_cb(const double s26[26], const double P[529], double R, int 
             }
         m.rows6 = rows.data();
         m.h = hv.data();
+        if (ins_vel) {
+            m.n_geo = n;
+            const float weight = !degenerate ? (float)(0.0001 * n) : (float)(0.001 * n);
+            double vel[3];
+            quat_rotate(x.rot, ins_vel, vel);
+            for (int a = 0; a < 3; a++) m.ws_h[0][a] = (vel[a] - x.vel[a]) * weight;
+            m.ws_n = 1;
+            m.n_rows = n + 3;
+        }
     };
     kf.update_iterated(R, measure, nullptr, nullptr);
     state_to_array(kf.x, s26_out);

@@ -34,7 +34,7 @@ SYMBOLS = [
     "lio_pose_estimator_correct", "lio_pose_estimator_get", "lio_pose_estimator_set", "lio_pose_estimator_matrix",
     "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_engine_set_device_loop", "lio_fastlio_ins_enqueue", "lio_fastlio_set_wheelspeed", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device", "lio_fastlio_pcl_stage", "lio_fastlio_pcl_commit",
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
-    "lio_state_predict", "lio_eskf_update_cb", "lio_eskf_update_sums_cb",
+    "lio_state_predict", "lio_eskf_update_cb", "lio_eskf_update_ws_cb", "lio_eskf_update_sums_cb",
     "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_fitness_score", "lio_ndt_overlap_score", "lio_ndt_voxel_at",
     "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align",
     "lio_gicp_create", "lio_gicp_destroy", "lio_gicp_set_target", "lio_gicp_set_source", "lio_gicp_set_voxel_mode", "lio_gicp_voxel_at", "lio_gicp_download", "lio_gicp_correspondences", "lio_gicp_linearize", "lio_gicp_align",
@@ -217,6 +217,7 @@ def lib():
     sig("lio_fastlio_start_state", cint, vp, f64p)
     sig("lio_fastlio_download_undistorted", cint, vp, f32p, u32, C.POINTER(u32))
     sig("lio_eskf_update_cb", cint, f64p, f64p, dbl, cint, MEAS_FN, vp, cint, f64p, f64p)
+    sig("lio_eskf_update_ws_cb", cint, f64p, f64p, dbl, cint, MEAS_FN, vp, cint, f64p, cint, f64p, f64p)
     sig("lio_state_predict", cint, f64p, f64p, dbl, f64p, f64p, f64p, f64p, f64p)
     sig("lio_eskf_update_sums_cb", cint, f64p, f64p, dbl, cint, cint, SUMS_FN, DEG_FN, vp, f64p, f64p, C.POINTER(PassLog), cint, C.POINTER(cint))
     sig("lio_eskf_update_cb", cint, f64p, f64p, dbl, cint, MEAS_FN, vp, cint, f64p, f64p)

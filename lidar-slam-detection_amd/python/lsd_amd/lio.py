@@ -821,6 +821,16 @@ def eskf_update(s, P, R, model, max_iter=4, cap=4096):
     return so, Po.reshape(23, 23)
 
 
+def eskf_update_ws(s, P, R, model, ins_vel, degenerate=False, max_iter=4, cap=4096):
+    """eskf_update with the wheel-speed rows (laserMapping.cpp:794-811) appended to the model's rows in every pass"""
+    s, P, v = f64(s), f64(P).reshape(-1), f64(ins_vel)
+    so, Po = np.zeros(STATE_DIM), np.zeros(529)
+    fn = make_meas_fn(model)
+    check(lib().lio_eskf_update_ws_cb(ptr(s, C.c_double), ptr(P, C.c_double), float(R), max_iter, fn, None, cap, ptr(v, C.c_double), int(degenerate),
+                                      ptr(so, C.c_double), ptr(Po, C.c_double)))
+    return so, Po.reshape(23, 23)
+
+
 def sums_of_rows(rows, h):
     """the 29 numbers a device linearisation hands the filter: J^T J upper triangle row by row, J^T h, sum |r|, N_eff"""
     rows, h = np.asarray(rows, np.float64).reshape(-1, 6), np.asarray(h, np.float64).ravel()

@@ -912,17 +912,17 @@ struct Lio {
     void* ext_ctx = nullptr;
     int ext_cap = 0;
     void h_share_model(const State& s, DynShare& d) {
-        if (ext_fn) {
+        DynShare geo = d;  // copy: stale h_x / h of the previous pass survive an early return
+        if (ext_fn) {  // the point-to-plane part supplied from outside (filter pinning tests); the wheel-speed part below applies to it as well
             double s26[26];
             state_to(s, s26);
             std::vector<double> rows((size_t)ext_cap * 6), hv(ext_cap);
             int n = 0;
             if (!ext_fn(ext_ctx, s26, d.converge ? 1 : 0, &n, rows.data(), hv.data(), ext_cap)) { d.valid = false; return; }
-            d.h_x = Mat(n, 15);
-            d.h.assign(hv.begin(), hv.begin() + n);
-            for (int r = 0; r < n; r++) for (int c = 0; c < 6; c++) d.h_x(r, c) = rows[(size_t)r * 6 + c];
+            geo.h_x = Mat(n, 15);
+            geo.h.assign(hv.begin(), hv.begin() + n);
+            for (int r = 0; r < n; r++) for (int c = 0; c < 6; c++) geo.h_x(r, c) = rows[(size_t)r * 6 + c];
             effct_feat_num = n;
-            return;
         }
         // h_share_model_wheelspeed (laserMapping.cpp:794-811): three rows dh/dv = I, h = rot * v_ins - vel, when wheelspeed_en and the last
         // INS sample of this scan is within 10 ms of its end.  (wheelspeed_en is a constant false in the reference: dead code there.)
@@ -933,8 +933,7 @@ struct Lio {
             for (int a = 0; a < 3; a++) ws_h[a] = vel[a] - s.vel[a];
             ws_valid = true;
         }
-        DynShare geo = d;  // copy: stale h_x / h of the previous pass survive an early return
-        h_share_model_geometric(s, geo);
+        if (!ext_fn) h_share_model_geometric(s, geo);
         const int n_geo = (int)geo.h.size();
         const int n_terms = n_geo + (ws_valid ? 3 : 0);
         if (ws_valid) {  // :994-1012
@@ -1886,6 +1885,24 @@ void orc_kf_update_cb(const double* s26, const double* P, double R, int max_iter
     for (int i = 0; i < 23; i++) for (int j = 0; j < 23; j++) l.P(i, j) = P[i * 23 + j];
     l.max_iter = max_iter;
     l.ext_fn = fn; l.ext_ctx = ctx; l.ext_cap = cap;
+    l.update_iterated(R);
+    state_to(l.x, s26_out);
+    for (int i = 0; i < 23; i++) for (int j = 0; j < 23; j++) P_out[i * 23 + j] = l.P(i, j);
+}
+
+// the same with the wheel-speed rows of laserMapping.cpp:794-811 appended in every pass: ins_vel = Measures.ins.back() in the IMU frame
+void orc_kf_update_ws_cb(const double* s26, const double* P, double R, int max_iter, Lio::meas_fn fn, void* ctx, int cap, const double* ins_vel, int degenerate,
+                         double* s26_out, double* P_out) {
+    Lio l(0.5f, 19, 1000, 100.0);
+    state_from(s26, l.x);
+    for (int i = 0; i < 23; i++) for (int j = 0; j < 23; j++) l.P(i, j) = P[i * 23 + j];
+    l.max_iter = max_iter;
+    l.ext_fn = fn; l.ext_ctx = ctx; l.ext_cap = cap;
+    l.wheelspeed_en = true;
+    l.meas_ins_valid = true;
+    l.meas_ins_stamp = l.meas_lidar_end = 0.0;
+    l.meas_ins_vel = V3{{ins_vel[0], ins_vel[1], ins_vel[2]}};
+    l.is_degenerate = degenerate != 0;
     l.update_iterated(R);
     state_to(l.x, s26_out);
     for (int i = 0; i < 23; i++) for (int j = 0; j < 23; j++) P_out[i * 23 + j] = l.P(i, j);

@@ -91,6 +91,7 @@ def lib():
     L.orc_undistort_poses.argtypes = [C.POINTER(C.c_uint64), f64p, C.c_int, f32p, C.POINTER(C.c_uint32), C.c_int, C.c_uint64]
     L.orc_lio_get_ds_world.argtypes = [C.c_void_p, f32p, C.c_int]
     L.orc_kf_update_cb.argtypes = [f64p, f64p, C.c_double, C.c_int, MEAS_FN, C.c_void_p, C.c_int, f64p, f64p]
+    L.orc_kf_update_ws_cb.argtypes = [f64p, f64p, C.c_double, C.c_int, MEAS_FN, C.c_void_p, C.c_int, f64p, C.c_int, f64p, f64p]
     L.orc_so3_Exp.argtypes = [f64p, C.c_double, f64p]
     L.orc_undistort_point.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_double, f32p, f64p, f64p, f64p, f64p, f32p]
     L.orc_lio_get_ds.argtypes = [C.c_void_p, f32p, C.c_int]
@@ -481,6 +482,15 @@ def undistort_point(R_imu, vel, pos, acc, gyr, dt, p, end_pos, end_rot, ril, til
     out = np.zeros(3, np.float32)
     lib().orc_undistort_point(*[_p(v, C.c_double) for v in a], float(dt), _p(pp, C.c_float), *[_p(v, C.c_double) for v in b], _p(out, C.c_float))
     return out
+
+
+def kf_update_ws(s, P, R, meas_fn, ins_vel, degenerate=False, max_iter=4, cap=4096):
+    """kf_update with the wheel-speed rows (laserMapping.cpp:794-811) appended to the model's rows in every pass"""
+    s, P, v = _f64(s), _f64(P).reshape(-1), _f64(ins_vel)
+    so, Po = np.zeros(STATE_DIM), np.zeros(529)
+    lib().orc_kf_update_ws_cb(_p(s, C.c_double), _p(P, C.c_double), float(R), max_iter, meas_fn, None, cap, _p(v, C.c_double), int(degenerate),
+                              _p(so, C.c_double), _p(Po, C.c_double))
+    return so, Po.reshape(23, 23)
 
 
 def kf_update(s, P, R, meas_fn, max_iter=4, cap=4096):

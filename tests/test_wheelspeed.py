@@ -120,3 +120,30 @@ def test_hip_wheelspeed_rows_match_oracle(oracle_mod, scene):
     assert np.abs(on[7][1] - on[7][2]).max() < 1e-9 and np.abs(on[7][3] - on[7][4]).max() < 1e-8 * max(1.0, np.abs(on[7][4]).max())
     off = drive(False)
     assert np.abs(on[8][1][14:17] - off[8][1][14:17]).max() > 1e-4
+
+
+@pytest.mark.parametrize("n_rows", [400, 20, 19, 10, 3])  # information form (N + 3 >= 23) and the dense gain branch (N + 3 < 23)
+@pytest.mark.parametrize("degenerate", [False, True])
+def test_host_filter_with_wheelspeed_rows_matches_the_oracle_filter(oracle_mod, n_rows, degenerate):
+    """the product's host filter on the active index set {0..5, 12, 13, 14} (csrc/eskf.cpp) against the oracle's dense restatement of
+    esekfom.hpp:1619-1931 (n x 15 Jacobian, two 23 x 23 inverses), both fed the same point-to-plane rows plus the wheel-speed rows"""
+    from lsd_amd import lio
+    from test_ikfom_vs_ref import _close, _cov, _plane_model, _state
+
+    rng = np.random.default_rng(50 + n_rows)
+    for trial in range(4):
+        truth = _state(oracle_mod, rng, 0.2)
+        s0 = oracle_mod.state_boxplus(truth, np.concatenate([rng.normal(size=6) * [0.2, 0.2, 0.2, 0.02, 0.02, 0.02], np.zeros(17)]))
+        P0 = _cov(rng, 1e-3)
+        model, calls = _plane_model(rng, n_rows, truth)
+        v_ins = rng.normal(size=3) * [3.0, 0.5, 0.0]
+        so, Po = oracle_mod.kf_update_ws(s0, P0, 0.001, lio.make_meas_fn(model), v_ins, degenerate, max_iter=4)
+        n_o = len(calls)
+        del calls[:]
+        sp, Pp = lio.eskf_update_ws(s0, P0, 0.001, model, v_ins, degenerate, max_iter=4)
+        assert len(calls) == n_o
+        tol = 1e-9 if n_rows + 3 >= 23 else 1e-8
+        assert _close(sp, so, tol) and _close(Pp, Po, tol * 10), (n_rows, trial, np.abs(sp - so).max(), np.abs(Pp - Po).max())
+        # the rows do something: without them the velocity block of the result differs
+        s_no, _ = lio.eskf_update(s0, P0, 0.001, model, max_iter=4)
+        assert np.abs(s_no[14:17] - sp[14:17]).max() > 1e-9
