@@ -651,6 +651,22 @@ int lio_scan_set_ds(lio_scan* s, const float* ds, uint32_t n) {
     return LIO_OK;
 }
 
+// the downsampled cloud of another scan on the same device (a joint registration downsamples the cloud once and hands it to the scan
+// buffers of the other sub-maps): what lio_scan_set_ds does, from device memory
+int scan_share_ds(lio_scan* dst, lio_scan* src, uint32_t n) {
+    if (!dst || !src || dst->device != src->device) return LIO_E_INVALID;
+    if (n > dst->max_ds) { set_error("%u downsampled points exceed max_ds %u", n, dst->max_ds); return LIO_E_CAPACITY; }
+    hipSetDevice(dst->device);
+    if (n) LIO_HIP_TRY(hipMemcpyAsync(dst->ds_body, src->ds_body, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, dst->stream));
+    int rc = scan_set_nds(dst, n);
+    if (rc != LIO_OK) return rc;
+    rc = scan_begin(dst);
+    if (rc != LIO_OK) return rc;
+    dst->have_ds = (int)n;
+    dst->n_raw = src->n_raw;
+    return LIO_OK;
+}
+
 int lio_scan_num_ds(lio_scan* s) {
     if (!s) return LIO_E_INVALID;
     hipSetDevice(s->device);
@@ -694,8 +710,10 @@ int lio_scan_download_match(lio_scan* s, uint8_t* selected, float* normvec, int3
     return n;
 }
 
-int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn, lio_normal_eq* out) {
-    if (!m || !s || !pose_wi || !ext_il || !out) return LIO_E_INVALID;
+// the launches of one linearisation (neighbour search if asked, linearise + report) without waiting for the record: several scans -- the
+// sub-maps of a joint registration -- are put in flight on their own streams before any of them is waited for
+int p2plane_linearize_begin(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn) {
+    if (!m || !s || !pose_wi || !ext_il) return LIO_E_INVALID;
     if (m->device != s->device) { set_error("map and scan live on different devices"); return LIO_E_INVALID; }
     hipSetDevice(s->device);
     const PoseArgs pose = make_pose(pose_wi, ext_il);
@@ -704,10 +722,22 @@ int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], cons
         rc = map_knn_plane(m, s, pose, redo_knn);
         if (rc != LIO_OK) return rc;
     }
-    rc = p2plane_reduce(m, s, pose, redo_knn);
+    return p2plane_reduce(m, s, pose, redo_knn);
+}
+
+int lio_p2plane_linearize(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn, lio_normal_eq* out) {
+    if (!out) return LIO_E_INVALID;
+    const int rc = p2plane_linearize_begin(m, s, pose_wi, ext_il, redo_knn);
     if (rc != LIO_OK) return rc;
+    return p2plane_linearize_end(m, s, pose_wi, ext_il, redo_knn, out);
+}
+
+int p2plane_linearize_end(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn, lio_normal_eq* out) {
+    if (!m || !s || !pose_wi || !ext_il || !out) return LIO_E_INVALID;
+    hipSetDevice(s->device);
+    const PoseArgs pose = make_pose(pose_wi, ext_il);
     // the reporting workgroup stores the record straight into mapped pinned host memory: no copy launch, no sync call
-    rc = wait_report(s);
+    int rc = wait_report(s);
     if (rc != LIO_OK) return rc;
     if (s->h_result->n_tie) {  // exact d2 ties among some top-6: redo those queries with the canonical comparison
         const uint32_t nt = s->h_result->n_tie;

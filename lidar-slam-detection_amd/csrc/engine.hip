@@ -126,6 +126,8 @@ struct JointCtx {
     int knn_seen = 0;
     double nnT[9] = {0};
     int rc = LIO_OK;
+    bool begun = false;  // the other sub-maps' linearisations of this pass are in flight (started before the driving engine's own)
+    bool share_ds = false;  // this registration hands the driving engine's downsampled cloud to the other sub-maps' scan buffers
 };
 
 namespace {
@@ -155,6 +157,15 @@ int measure_pass(lio_engine* e, const LioState& x, bool converge, Measurement& m
     lio_normal_eq ne;
     hipEvent_t t0, t1;
     if (e->timing) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, e->scan->stream); }
+    if (e->joint && e->joint->rc == LIO_OK) {
+        // joint registration: the other local sub-maps' linearisations of this pass go out first, each on its own scan's stream, so that
+        // they run beside the driving engine's own instead of one after the other behind it
+        e->joint->begun = true;
+        for (lio_engine* o : e->joint->others) {
+            const int r0 = p2plane_linearize_begin(o->map, o->scan, pose, ext, converge ? 1 : 0);
+            if (r0 != LIO_OK) { e->joint->rc = r0; e->joint->begun = false; break; }
+        }
+    }
     const int rc = lio_p2plane_linearize(e->map, e->scan, pose, ext, converge ? 1 : 0, &ne);
     if (e->timing) {
         hipEventRecord(t1, e->scan->stream);
@@ -554,8 +565,9 @@ static void joint_reduce(void* vctx, double* buf, int n) {
         pose_arrays(e->kf.x, pose, ext);
         for (lio_engine* o : j->others) {
             lio_normal_eq ne;
-            const int rc = lio_p2plane_linearize(o->map, o->scan, pose, ext, redo ? 1 : 0, &ne);
-            if (rc != LIO_OK) { j->rc = rc; return; }
+            const int rc = j->begun ? p2plane_linearize_end(o->map, o->scan, pose, ext, redo ? 1 : 0, &ne)
+                                    : lio_p2plane_linearize(o->map, o->scan, pose, ext, redo ? 1 : 0, &ne);
+            if (rc != LIO_OK) { j->rc = rc; j->begun = false; return; }
             int t = 0;
             for (int a = 0; a < 6; a++)
                 for (int c = a; c < 6; c++) buf[t++] += ne.JtJ[a * 6 + c];
@@ -563,6 +575,7 @@ static void joint_reduce(void* vctx, double* buf, int n) {
             buf[27] += ne.sum_abs_res;
             buf[28] += (double)ne.n_eff;
         }
+        j->begun = false;
         if (j->comm) { const int rc = comm_reduce_host(j->comm, buf, 29); if (rc != LIO_OK) { j->rc = rc; return; } }
         double J[36];
         int t = 0;
@@ -607,14 +620,21 @@ int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_
     JointCtx* j = e->joint;
     j->knn_seen = 0;
     j->rc = LIO_OK;
-    for (lio_engine* o : j->others) {
-        int rc = lio_scan_upload(o->scan, raw_body_xyzi, n_raw);
-        if (rc == LIO_OK) rc = lio_scan_voxel_downsample(o->scan, o->leaf_surf, 1, nullptr);
-        if (rc != LIO_OK) return rc;
-    }
+    // the cloud is uploaded and downsampled ONCE, by the driving engine; the other sub-maps' scan buffers receive its downsampled points
+    // device to device right after (process_core) -- same leaf, same input: what each of them would have computed itself
+    j->share_ds = true;
+    for (lio_engine* o : j->others)
+        if (o->leaf_surf != e->leaf_surf || o->scan->device != e->scan->device) j->share_ds = false;
+    if (!j->share_ds)
+        for (lio_engine* o : j->others) {
+            int rc = lio_scan_upload(o->scan, raw_body_xyzi, n_raw);
+            if (rc == LIO_OK) rc = lio_scan_voxel_downsample(o->scan, o->leaf_surf, 1, nullptr);
+            if (rc != LIO_OK) return rc;
+        }
     lio_engine_set_state(e, state26);
     lio_engine_set_cov(e, cov);
     const int rc = lio_engine_process_scan(e, raw_body_xyzi, n_raw, lidar_beg_time);
+    j->share_ds = false;
     if (j->rc != LIO_OK) return j->rc;
     lio_engine_get_state(e, state26);
     lio_engine_get_cov(e, cov);
@@ -657,6 +677,11 @@ static int process_core(lio_engine* e, double lidar_beg_time) {
     }
     if (rc != LIO_OK) return rc;
     e->tm.n_ds = (int)n_ds;
+    if (e->joint && e->joint->share_ds)
+        for (lio_engine* o : e->joint->others) {
+            const int r2 = scan_share_ds(o->scan, s, n_ds);
+            if (r2 != LIO_OK) return r2;
+        }
     double pose[7], ext[7];
     uint64_t nv = 0;
     if (!e->map_seeded) {

@@ -273,3 +273,10 @@ int p2plane_degeneracy(lio_scan* s);
 int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float map_leaf, int ekf_inited, int seed_all);
 PoseArgs make_pose(const double pose_wi[7], const double ext_il[7]);
 }  // namespace lio
+
+// internal entry points defined in capi.hip's extern "C" block (not part of include/lio_hip.h)
+extern "C" {
+int p2plane_linearize_begin(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn);
+int p2plane_linearize_end(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn, lio_normal_eq* out);
+int scan_share_ds(lio_scan* dst, lio_scan* src, uint32_t n);
+}
