@@ -76,11 +76,6 @@ int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double
  * point order drops and re-creates it; here it keeps its points -- the one case where the maps can differ). */
 int lio_map_set_lru(lio_map*, uint64_t capacity_voxels, double max_distance);
 int lio_map_lru_stats(lio_map*, uint64_t* n_evicted, uint64_t* n_interleaved);
-/* Diagnostic switch.  From the second neighbour search of an update on, a query that is still in the voxel of the scan's last full search can be
- * searched only in the voxels that can beat the neighbours found then (csrc/knn.hip; results identical by construction, tested).  Off by
- * default -- measured as no gain (tools/experiments/README.md); 1 turns it on for objects created afterwards (also: LIO_KNN_REUSE=1). */
-void lio_debug_knn_reuse(int on);
-
 /* capacity planning: slots of the point pool handed out so far by the bump allocator (recycled regions of evicted / outgrown
  * voxels are re-used first and do not move it) and the pool's size, both in points of 16 B */
 int lio_map_pool_stats(lio_map*, uint64_t* pool_top, uint64_t* pool_cap);
@@ -88,6 +83,9 @@ int lio_map_pool_stats(lio_map*, uint64_t* pool_top, uint64_t* pool_cap);
 int lio_map_stats(lio_map*, uint64_t* n_points, uint64_t* n_voxels);
 /* running total of map points visited by stencil kNN queries (the C-bar * N_ds statistic of the roofline model) */
 uint64_t lio_map_knn_candidates(lio_map*);
+/* running total of map points whose 16 bytes the kNN sweep actually asked for (it prunes stencil voxels that cannot hold one of the five
+ * nearest, exactly) -- counted only by the diagnostic kernel variant that lio_batch_enable_kernel_timing(b, 2) selects; 0 otherwise */
+uint64_t lio_map_knn_touched(lio_map*);
 /* all stored points, voxel by voxel in unspecified order; returns the count or -(needed) */
 int64_t lio_map_dump(lio_map*, float* out_xyzi, uint64_t cap_points);
 /* IVox::GetClosestPoint(pt, out, 5, 5.0) for a batch of world-frame queries (ivox3d.h:139-171):
@@ -355,10 +353,14 @@ int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_
  * set_cov(cov_in) + lio_engine_process_scan_device(d_raw, n_raw, lidar_beg_time); outputs are filled per job.
  * Intended for engines created with lio_engine_create_shared on one read-only map (independent scans of several
  * sensors / sequences, relocalisation candidates, map-merge alignments). */
+#define LIO_JOB_KEEP_CACHE 1u
 typedef struct lio_scan_job {
     const void* d_raw;          /* device pointer, XYZI float4 */
     uint32_t n_raw;
-    uint32_t pad;
+    uint32_t flags;             /* 0 (default): the jobs are INDEPENDENT scans -- the engine / slot that takes the job first forgets its neighbour
+                                   cache, as fastlio_init does for Nearest_Points (src/laserMapping.cpp:1045-1047), so the result does not depend
+                                   on which scan that engine registered before; LIO_JOB_KEEP_CACHE: a job of a sequence -- the cache of the
+                                   previous scan survives (Nearest_Points across fastlio_main calls, stale where a search finds nothing) */
     double lidar_beg_time;
     const double* state_in;     /* 26 doubles */
     const double* cov_in;       /* 529 doubles */
@@ -392,6 +394,8 @@ typedef struct lio_batch_times {
     double downsample_us, knn_us, linearize_us, step_us;
     uint32_t downsample_launches, knn_launches, linearize_launches, step_launches;
 } lio_batch_times;
+/* on: 0 off, 1 timing, 2 (or 3) timing with the counting variant of the kNN kernel (lio_map_knn_touched) -- times of that variant are not
+ * the product's */
 int lio_batch_enable_kernel_timing(lio_batch*, int on);
 int lio_batch_kernel_times(lio_batch*, lio_batch_times* out, int reset);
 /* test visibility: the engine behind slot `slot` of group `group` (its scan buffers, pass log of a host continuation) */

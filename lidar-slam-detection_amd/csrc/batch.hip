@@ -54,7 +54,7 @@ struct lio_batch {
     uint32_t max_raw = 0, max_ds = 0;
     int pred_passes = 4;  // radix passes the last rounds needed
     int use_graph = 1;    // LIO_BATCH_GRAPH=0: plain launches instead of one hipGraphLaunch per round
-    int knn_kind = 0;     // LIO_BATCH_KNN=q: the one-lane-per-query kernel (knn_q.hip) instead of knn.hip's sixteen lanes per query
+    int count_touched = 0;  // lio_batch_enable_kernel_timing(b, 2): the kNN kernel's diagnostic variant that also counts the points it loads
     std::vector<Group> groups;
     double t_submit = 0, t_wait = 0, t_collect = 0;  // host seconds (LIO_BATCH_PROFILE=1 prints them when the object is destroyed)
     uint64_t n_rounds = 0;
@@ -70,7 +70,7 @@ void fill_desc(SlotDesc& d, lio_scan* sc, EskfDev* d_ctrl, lio_batch_result* d_r
     d.keys_a = sc->keys_a; d.keys_b = sc->keys_b; d.vals_a = sc->vals_a; d.vals_b = sc->vals_b;
     d.hist = sc->hist; d.blockcnt = sc->blockcnt; d.hpos = sc->hpos; d.longlist = sc->longlist; d.tie_list = sc->tie_list;
     d.sorted = sc->sorted; d.ds_body = sc->ds_body; d.ds_world = sc->ds_world; d.nn_pts = sc->nn_pts; d.normvec = sc->normvec;
-    d.nn_cnt = sc->nn_cnt; d.nn_meta = sc->nn_meta; d.selected = sc->selected; d.partial = sc->partial;
+    d.nn_cnt = sc->nn_cnt; d.selected = sc->selected; d.partial = sc->partial;
     d.host_nds = sc->host_nds_dev;
     d.ctrl = d_ctrl;
     d.result = d_res;
@@ -128,6 +128,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         d.active = 1;
         d.seq = g.seq;
         d.min_ds = 5;  // laserMapping.cpp:1246: fewer than five downsampled points are not registered
+        d.reset_cache = (job.flags & LIO_JOB_KEEP_CACHE) ? 0u : 1u;
         fill_ctrl(g.h_ctrl[s], job.state_in, job.cov_in, 0.001 /* LASER_POINT_COV */, 4, 1);
         g.h_res[s].seq = g.seq - 1;
         g.n_active++;
@@ -146,7 +147,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         if (bt) bt->end(0);
         if (rc != LIO_OK) return rc;
         const uint32_t ds_bound = b->max_raw < b->max_ds ? b->max_raw : b->max_ds;
-        return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, bt, b->knn_kind);
+        return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, bt, bt ? b->count_touched : 0);
     };
     if (!b->use_graph || timed) return enqueue(timed ? g.bt : nullptr);
     if (g.graph_table != b->map->table || g.graph_stencil != b->map->stencil.n) {
@@ -189,6 +190,12 @@ int wait_group(Group& g, int B) {
 
 }  // namespace
 
+// HIP deals streams to GPU_MAX_HW_QUEUES hardware queues (4 by default) round robin; with four, the rounds in flight of a batch share queues
+// with the idle per-slot streams and mostly run back to back (measured 0.085 -> 0.070 ms per scan with 8).  The runtime reads the variable
+// when it initialises (the first HIP call of the process), so the library sets it when it is loaded -- unless the application chose a value
+// itself; an application that initialised HIP before loading the library keeps what it had, and lio_batch_create says so (lio_last_error).
+__attribute__((constructor)) static void lio_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" {
 
 lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds) {
@@ -201,7 +208,6 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
     b->max_raw = max_raw;
     b->max_ds = max_ds;
     b->groups.resize(n_groups);
-    { const char* k = getenv("LIO_BATCH_KNN"); b->knn_kind = (k && k[0] == 'q') ? 1 : ((k && k[0] == 'i') ? 2 : 0); }
     { const char* k = getenv("LIO_BATCH_GRAPH"); b->use_graph = (k && k[0] == '0') ? 0 : 1; }
     bool ok = true;
     // the groups' streams first: HIP deals streams to its few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) round robin in creation
@@ -237,6 +243,11 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
         lio_batch_destroy(b);
         return nullptr;
     }
+    {   // not an error: a note for whoever wonders why rounds do not overlap
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        if (n_groups > 1 && q && atoi(q) < 8)
+            set_error("lio_batch_create: GPU_MAX_HW_QUEUES=%s -- with fewer than 8 hardware queues the %d rounds in flight mostly serialise (~20 %% slower)", q, n_groups);
+    }
     return b;
 }
 
@@ -268,6 +279,7 @@ int lio_batch_enable_kernel_timing(lio_batch* b, int on) {
         }
         g.bt->on = on != 0;
     }
+    b->count_touched = (on & 2) ? 1 : 0;
     return LIO_OK;
 }
 
@@ -302,7 +314,8 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
         int need_max = 1;
         for (int s = 0; s < B; s++) {
             const int j = g.job_of_slot[s];
-            if (j < 0 || !g.h_desc[s].active) continue;
+            if (j < 0) continue;
+            if (!g.h_desc[s].active) { note(jobs[j].rc); continue; }  // rejected at submission (bad pointers, more points than max_raw): counted, not lost
             lio_scan_job& job = jobs[j];
             const lio_batch_result& r = g.h_res[s];
             if (r.radix_passes > need_max) need_max = r.radix_passes;
@@ -343,13 +356,20 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
     };
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point c) { return std::chrono::duration<double>(c - a).count(); };
+    // a failed submission / wait: the rounds of the other groups are still in flight and own their pinned blocks and result records --
+    // wait for them before handing the error back (their jobs keep LIO_E_INVALID), so that the next call starts from idle groups
+    auto bail = [&](int rc) {
+        for (const int gi : inflight) hipStreamSynchronize(b->groups[gi].stream);
+        inflight.clear();
+        return rc;
+    };
     for (size_t gi = 0; gi < b->groups.size() && next < n_jobs; gi++) {
         const int n = n_jobs - next < B ? n_jobs - next : B;
         const auto t0 = clk::now();
         const int rc = submit(b, b->groups[gi], jobs, next, n, b->pred_passes);
         b->t_submit += secs(t0, clk::now());
         b->n_rounds++;
-        if (rc != LIO_OK) return rc;
+        if (rc != LIO_OK) return bail(rc);
         next += n;
         inflight.push_back((int)gi);
     }
@@ -360,7 +380,7 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
         const auto t0 = clk::now();
         if (g.n_active) {
             const int rc = wait_group(g, B);
-            if (rc != LIO_OK) return rc;
+            if (rc != LIO_OK) return bail(rc);
         }
         if (g.bt && g.bt->on) { hipStreamSynchronize(g.stream); g.bt->resolve(); }
         const auto t1 = clk::now();
@@ -373,7 +393,7 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
             const int rc = submit(b, g, jobs, next, n, b->pred_passes);
             b->t_submit += secs(t2, clk::now());
             b->n_rounds++;
-            if (rc != LIO_OK) return rc;
+            if (rc != LIO_OK) return bail(rc);
             next += n;
             inflight.push_back(gi);
         }
@@ -412,7 +432,6 @@ struct lio_devloop {
     lio_batch_result* h_res_dev = nullptr;
     hipGraphExec_t exec = nullptr;
     uint32_t seq = 0;
-    int knn_kind = 0;
     int stencil_n = 0;  // the graph holds the stencil by value and the table's address: re-captured when either changes
     const void* table = nullptr;  // (an LRU map swaps its table for a rebuilt twin now and then)
 };
@@ -443,7 +462,6 @@ lio_devloop* devloop_create(lio_scan* sc) {
     memset(d->h_block, 0, d->block_bytes);
     memset(d->h_res, 0, sizeof(lio_batch_result));
     fill_desc(*d->h_desc, sc, d->d_ctrl, d->h_res_dev);
-    { const char* k = getenv("LIO_BATCH_KNN"); d->knn_kind = (k && k[0] == 'q') ? 1 : ((k && k[0] == 'i') ? 2 : 0); }
     return d;
 }
 
@@ -454,6 +472,7 @@ int devloop_update(lio_devloop* d, lio_map* m, lio_scan* sc, const double* x26, 
     SlotDesc& desc = *d->h_desc;
     desc.active = 1;
     desc.min_ds = 0;
+    desc.reset_cache = 0;
     desc.n_raw = sc->n_raw;
     desc.nblocks = 0;
     desc.seq = ++d->seq;
@@ -462,7 +481,7 @@ int devloop_update(lio_devloop* d, lio_map* m, lio_scan* sc, const double* x26, 
     hipStream_t st = sc->stream;
     auto enqueue = [&](uint32_t ds_bound) -> int {
         LIO_HIP_TRY(hipMemcpyAsync(d->d_block, d->h_block, d->block_bytes, hipMemcpyHostToDevice, st));
-        const int rc = p2plane_batch_update(m, st, d->d_desc, 1, ds_bound, max_iter + 1, nullptr, d->knn_kind);
+        const int rc = p2plane_batch_update(m, st, d->d_desc, 1, ds_bound, max_iter + 1, nullptr, 0);
         if (rc != LIO_OK) return rc;
         LIO_HIP_TRY(hipMemcpyAsync(d->h_back, d->d_ctrl, sizeof(EskfDev), hipMemcpyDeviceToHost, st));
         return LIO_OK;

@@ -279,7 +279,6 @@ int lio_map_stats(lio_map* m, uint64_t* n_points, uint64_t* n_voxels) {
     return rc;
 }
 
-void lio_debug_knn_reuse(int on) { lio::knn_set_reuse(on); }
 
 int lio_map_pool_stats(lio_map* m, uint64_t* pool_top, uint64_t* pool_cap) {
     if (!m) return LIO_E_INVALID;
@@ -297,6 +296,16 @@ uint64_t lio_map_knn_candidates(lio_map* m) {
     if (hipMemcpy(&tmp, m->dev, sizeof(MapDev), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     uint64_t s = 0;
     for (int k = 0; k < 64; k++) s += tmp.knn_cand[k * 16];
+    return s;
+}
+
+uint64_t lio_map_knn_touched(lio_map* m) {
+    if (!m) return 0;
+    hipSetDevice(m->device);
+    MapDev tmp;
+    if (hipMemcpy(&tmp, m->dev, sizeof(MapDev), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    uint64_t s = 0;
+    for (int k = 0; k < 64; k++) s += tmp.knn_cand[k * 16 + 1];
     return s;
 }
 
@@ -338,10 +347,7 @@ int lio_map_knn(lio_map* m, const float* q, uint32_t n, float* out_pts, int32_t*
         hipMemsetAsync(dout, 0, (size_t)n * 5 * sizeof(float4), m->stream);
         hipMemsetAsync(dcnt, 0, n * sizeof(int32_t), m->stream);
         hipMemsetAsync(dtie, 0, sizeof(uint32_t), m->stream);
-        // LIO_KNN_Q=1: answer with the four-lanes-per-query kernel of the batched engine (knn_q.hip) instead of knn.hip's
-        // sixteen-lane one -- the tests run their adversarial cases against both
-        const char* q = getenv("LIO_KNN_Q");
-        rc = (q && q[0] == '1') ? knn_q_world(m, dq, n, dout, dcnt) : knn_batch(m, dq, n, dout, dcnt, dtie);
+        rc = knn_batch(m, dq, n, dout, dcnt, dtie);
     }
     if (rc == LIO_OK) {
         std::vector<float4> soa((size_t)n * 5);
@@ -375,7 +381,7 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
          dev_alloc(&s->nn_pts, (uint64_t)max_ds * 5, &s->bytes) && dev_alloc(&s->nn_cnt, max_ds, &s->bytes) && dev_alloc(&s->selected, max_ds, &s->bytes) &&
          dev_alloc(&s->normvec, max_ds, &s->bytes) && dev_alloc(&s->keys_a, max_raw, &s->bytes) && dev_alloc(&s->keys_b, max_raw, &s->bytes) &&
          dev_alloc(&s->vals_a, max_raw, &s->bytes) && dev_alloc(&s->vals_b, max_raw, &s->bytes) && dev_alloc(&s->hist, std::max<uint64_t>((uint64_t)256 * nblocks, 2 * (((uint64_t)max_ds + 255) / 256) + 2), &s->bytes) &&
-         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->tie_list, max_ds, &s->bytes) && dev_alloc(&s->nn_meta, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
+         dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->tie_list, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
          dev_alloc(&s->dev, 1, &s->bytes) && dev_alloc(&s->d_result, 1, &s->bytes);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&s->host_dev), sizeof(ScanDev)) == hipSuccess &&
          hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(lio_normal_eq), hipHostMallocMapped) == hipSuccess &&
@@ -408,7 +414,7 @@ void lio_scan_destroy(lio_scan* s) {
     if (s->stream) hipStreamSynchronize(s->stream);
     hipFree(s->raw_own); hipFree(s->ds_body); hipFree(s->ds_world); hipFree(s->nn_pts); hipFree(s->nn_cnt); hipFree(s->selected);
     hipFree(s->normvec); hipFree(s->keys_a); hipFree(s->keys_b); hipFree(s->vals_a); hipFree(s->vals_b); hipFree(s->hist);
-    hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->tie_list); hipFree(s->nn_meta); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
+    hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->tie_list); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
     if (s->host_dev) hipHostFree(s->host_dev);
     if (s->h_result) hipHostFree(s->h_result);
     if (s->host_nds) hipHostFree(s->host_nds);
@@ -430,6 +436,14 @@ int lio_scan_reset(lio_scan* s) {
     LIO_HIP_TRY(hipMemsetAsync(s->nn_pts, 0, (size_t)s->max_ds * 5 * sizeof(float4), s->stream));
     LIO_HIP_TRY(hipMemsetAsync(&s->dev->cache_n, 0, sizeof(uint32_t), s->stream));
     LIO_HIP_TRY(hipStreamSynchronize(s->stream));
+    return LIO_OK;
+}
+
+// the neighbour cache alone, asynchronously on the scan's stream: what an independent job of lio_engines_process_batch starts from
+int scan_forget_cache(lio_scan* s) {
+    if (!s) return LIO_E_INVALID;
+    LIO_HIP_TRY(hipMemsetAsync(s->nn_cnt, 0, (size_t)s->max_ds * 4, s->stream));
+    LIO_HIP_TRY(hipMemsetAsync(&s->dev->cache_n, 0, sizeof(uint32_t), s->stream));
     return LIO_OK;
 }
 

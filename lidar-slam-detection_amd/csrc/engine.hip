@@ -763,7 +763,8 @@ int lio_engines_process_batch(lio_engine** engines, int n_engines, lio_scan_job*
             if (job.state_in && job.cov_in) {
                 state_from_array(job.state_in, e->kf.x);
                 memcpy(e->kf.P, job.cov_in, sizeof(double) * 529);
-                rc = lio_engine_process_scan_device(e, job.d_raw, job.n_raw, job.lidar_beg_time);
+                rc = (job.flags & LIO_JOB_KEEP_CACHE) ? LIO_OK : scan_forget_cache(e->scan);  // an independent scan: no neighbours of the engine's previous job
+                if (rc == LIO_OK) rc = lio_engine_process_scan_device(e, job.d_raw, job.n_raw, job.lidar_beg_time);
             }
             job.rc = rc;
             job.n_ds = e->tm.n_ds;

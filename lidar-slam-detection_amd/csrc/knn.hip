@@ -36,9 +36,6 @@ namespace lio {
 #ifndef LIO_KNN_WAVES
 #define LIO_KNN_WAVES 6  // <= 80 registers, six waves per SIMD, nothing spills (seven: 72 registers with 9-12 spilled -- 4 % slower once the kernel became VALU bound)
 #endif
-#ifndef LIO_KNN_WAVES_FIRST
-#define LIO_KNN_WAVES_FIRST 6  // the first search of an update (the variant without the re-search code)
-#endif
 #ifndef LIO_KNN_PRUNE
 #define LIO_KNN_PRUNE 1  // distance-ordered sweep with exact pruning of stencil voxels that cannot hold one of the five nearest
 #endif
@@ -306,55 +303,16 @@ __device__ inline bool cand_less(const Cand& a, const Cand& b, const float4* __r
 }
 
 
-// exact redo of ONE query by the kG lanes of its group, from the voxel list the probe left in LDS: every listed voxel, strict total order
-// (d2, x, y, z); winner r comes back in lane r (kNoIdx where fewer than five exist).  Rare (an exact d2 tie among a query's six best).
-__device__ __noinline__ uint32_t group_exact_redo(const GroupLds& g, uint32_t nhit, const float4 pw, const float4* __restrict__ pool, int gl) {
-    Cand e[5];
-    for (int k = 0; k < 5; k++) e[k] = {INFINITY, kNoIdx};
-    for (uint32_t sv = 0; sv < nhit; sv++) {
-        const uint32_t vptr = g.v_ptr[sv], vcnt = g.v_cnt[sv];
-        for (uint32_t i = gl; i < vcnt; i += kG) {
-            const uint32_t id = vptr + i;
-            const float4 p = pool[id];
-            const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
-            const float d2 = dx * dx + (dy * dy + dz * dz);
-            if (d2 < 5.0f) {
-                Cand cd = {d2, id};
-                if (cand_less(cd, e[4], pool)) {
-                    e[4] = cd;
-                    for (int k = 4; k > 0; k--)
-                        if (cand_less(e[k], e[k - 1], pool)) { const Cand t = e[k - 1]; e[k - 1] = e[k]; e[k] = t; }
-                }
-            }
-        }
-    }
-    uint32_t win = kNoIdx;
-    for (int r = 0; r < 5; r++) {
-        Cand best = e[0];
-        for (int off = kG / 2; off > 0; off >>= 1) {
-            Cand o;
-            o.d2 = __shfl_xor(best.d2, off, kG);
-            o.id = __shfl_xor(best.id, off, kG);
-            if (cand_less(o, best, pool)) best = o;
-        }
-        if (gl == r) win = best.id;
-        if (best.id != kNoIdx && e[0].id == best.id) {
-            for (int k = 0; k < 4; k++) e[k] = e[k + 1];
-            e[4] = {INFINITY, kNoIdx};
-        }
-    }
-    return win;
-}
-
 // MODE 0: queries are body-frame ds points of a scan (transformed here, world point stored);
 // MODE 1: queries are world-frame points (diagnostic lio_map_knn).
-template <int KM, int MODE, bool INLINE_TIE, bool REUSE = false>
+// COUNT: a diagnostic build of the same kernel that also counts the candidate points the sweep really loads (`touched`, the second word
+// of a shard of MapDev::knn_cand) beside the stencil's residents -- bench.py's roofline leg wants both; never the timed variant.
+template <int KM, int MODE, bool COUNT = false>
 __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                          float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
                                          uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
                                          float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
-                                         MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list,
-                                         uint4* __restrict__ nn_meta = nullptr, bool use_prev = false) {
+                                         MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
     __shared__ GroupLds lds[kGPB];
     const int tid = threadIdx.x;
     const int grp = tid / kG, gl = tid % kG;
@@ -363,6 +321,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     const uint32_t n = sd ? sd->n_ds : n_host;
     const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
     uint32_t visited = 0;  // this lane's share of the candidate statistic (a few queries' stencils: far below 2^32)
+    uint32_t touched = 0;  // COUNT only: candidate points whose 16 bytes the sweep asked for
     const float res = 1.0f / inv_res;
     const uint32_t b1_bits = __float_as_uint(0.0625f * res * res), b2_bits = __float_as_uint(0.25f * res * res);
     (void)b1_bits; (void)b2_bits;
@@ -413,42 +372,9 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         uint32_t nhit = 0;
         constexpr bool kPrune = LIO_KNN_PRUNE && KM * kG <= 32;
         uint32_t n0 = 0, n01 = 0, total;
-        // Re-search of a later filter pass (use_prev: the scan has been searched in this update, the map has not changed since): the
-        // query moved by centimetres.  If it is still in the voxel of the last full search -- same stencil, same candidate set -- the five
-        // neighbours found then are still candidates, so the largest of their distances to the NEW position bounds the fifth-nearest
-        // distance from above: voxels that cannot reach that bound are not probed at all (usually all but one or two of the nineteen).
-        // Exact: an unprobed voxel's points are strictly farther than five known candidates -- sets, ties and counts are what the full
-        // search returns (the bound must itself be in range, d2 < 5, for the in-range count to stay >= 5).
-        uint32_t limit = 0xFFFFFFFFu, stored_total = 0;
-        bool fast = false;
-        if constexpr (kPrune && MODE == 0 && REUSE) {
-            if (use_prev) {
-                if (active) {
-                    const uint4 mt = nn_meta[q];
-                    const unsigned long long key = pack_key(kx, ky, kz);
-                    fast = mt.w != 0u && mt.x == (uint32_t)key && mt.y == (uint32_t)(key >> 32);
-                    stored_total = mt.z;
-                }
-                uint32_t u = 0;
-                if (fast && gl < 5) {
-                    const float4 p = nn_pts[(size_t)gl * nn_stride + q];
-                    const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
-                    u = __float_as_uint(dx * dx + (dy * dy + dz * dz));
-                }
-                u = group_max32(u);
-                fast = fast && u < __float_as_uint(5.0f);
-                if (fast) limit = u;
-            }
-        }
+        const uint32_t limit = 0xFFFFFFFFu;  // (an upper bound of the fifth-nearest distance known before the probe: none)
         if constexpr (kPrune) total = probe_stencil_bucketed<KM>(table, mask, st, active, pw, res, kx, ky, kz, gl, lane, gmask, g, nhit, n0, n01, limit);
         else total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
-        if (fast) total = stored_total;  // the statistic counts the stencil's residents (the reference algorithm's candidates), probed or not
-        if constexpr (kPrune && MODE == 0) {
-            if (nn_meta && active && !fast && gl == 0) {  // the record of this full search (w: set below once five neighbours are stored)
-                const unsigned long long key = pack_key(kx, ky, kz);
-                nn_meta[q] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), total, 0u);
-            }
-        }
         group_lds_sync();
         // every lane keeps its own ascending top-5 as (d2 bits, pool index) pairs, ordered by d2 alone: candidates with an
         // equal d2 keep their arrival order -- any such pair that reaches the global top-6 is an exact tie and the query
@@ -496,6 +422,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                 ptr4[u] = vp.x; ptr4[u + 1] = vp.y; ptr4[u + 2] = vp.z; ptr4[u + 3] = vp.w;
                 cnt4[u] = vc.x; cnt4[u + 1] = vc.y; cnt4[u + 2] = vc.z; cnt4[u + 3] = vc.w;
                 cmax = max(cmax, max(max(vc.x, vc.y), max(vc.z, vc.w)));
+                if constexpr (COUNT) { if (gl == 0) touched += (vc.x + vc.y) + (vc.z + vc.w); }
             }
             for (uint32_t i0 = gl; i0 < cmax + gl; i0 += kG) {
                 float4 p[kU];
@@ -562,20 +489,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
             if (gl < 5) nn_pts[(size_t)gl * nn_stride + q] = (win != 0xFFFFFFFFu) ? pool[win] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (gl == 0) {
                 nn_cnt[q] = inrange < 5 ? (int32_t)inrange : 5;
-                if constexpr (!INLINE_TIE) {
-                    if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
-                }
-            }
-        }
-        if constexpr (kPrune && MODE == 0) {
-            if (nn_meta && active && !fast && gl == 0 && inrange >= 5) nn_meta[q].w = 1u;  // five fresh neighbours: a later pass may start from them
-        }
-        if constexpr (INLINE_TIE) {
-            // no tie queue (batch form): the group redoes a tied query exactly right here, from the list it still holds, and overwrites
-            // what it has just stored (the call sits behind the stores so that little is live across it)
-            if (tie && active && inrange > 0) {
-                const uint32_t w2 = group_exact_redo(g, nhit, pw, pool, gl);
-                if (gl < 5 && w2 != kNoIdx) nn_pts[(size_t)gl * nn_stride + q] = pool[w2];
+                if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
             }
         }
         group_lds_sync();
@@ -592,6 +506,18 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         const unsigned long long v = (vred[0] + vred[1]) + (vred[2] + vred[3]);
         if (v) atomicAdd(&md->knn_cand[(blockIdx.x & 63) * 16], v);
     }
+    if constexpr (COUNT) {
+        __syncthreads();
+        unsigned long long tsum = touched;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tsum += __shfl_xor(tsum, off);
+        if (lane == 0) vred[tid >> 6] = tsum;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long v = (vred[0] + vred[1]) + (vred[2] + vred[3]);
+            if (v) atomicAdd(&md->knn_cand[(blockIdx.x & 63) * 16 + 1], v);
+        }
+    }
 }
 
 template <int KM, int MODE>
@@ -600,20 +526,19 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
                                                   uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
                                                   float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
                                                   MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
-    knn_body<KM, MODE, false>(table, mask, pool, inv_res, st, pose, queries, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, md, n_tie, tie_list);
+    knn_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, md, n_tie, tie_list);
 }
 // the scans of a batch (lio_batch_*): blockIdx.y = slot; pose from the slot's device-resident filter; a slot whose update has finished,
 // or whose filter did not ask for a neighbour search this pass, exits at once
-template <int KM, bool INLINE_TIE, bool REUSE>
-__global__ void __launch_bounds__(256, REUSE ? LIO_KNN_WAVES : LIO_KNN_WAVES_FIRST) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
-                                                                       float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md, int reuse) {
+template <int KM, bool COUNT>
+__global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                                       float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
     const EskfDev* c = d.ctrl;
     if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
     const PoseArgs pose = pose_from_state(c->x);
-    knn_body<KM, 0, INLINE_TIE, REUSE>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md,
-                                INLINE_TIE ? nullptr : &d.sd->n_tie, INLINE_TIE ? nullptr : d.tie_list, d.nn_meta, c->n_knn > 0 && reuse && c->reuse_hint != 0);
+    knn_body<KM, 0, COUNT>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
 }
 
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
@@ -704,16 +629,10 @@ __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __rest
     knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list);
 }
 
-// tie_mode 0: tied queries are queued and redone by a second (usually empty) launch; 1: redone in place by their group -- one launch
-// less per pass, at 14 more vector registers (occupancy 5 instead of 6)
-// 1: the re-search short cut (LIO_KNN_REUSE=1 or lio_debug_knn_reuse(1); the results are identical either way).  OFF by default: measured
-// on the metric config with the BASELINE priors (0.3 m: the hint never lets it run) and with tracking-size priors (3 cm: nearly every
-// second search takes it) it buys nothing -- 11.55 vs 11.39 us per scan and search -- because the regular sweep already prunes the far
-// voxels after its first batch and the short cut's own two dependent loads (search record, old neighbours) cost what the fewer probes save.
-static int g_knn_reuse = [] { const char* e = getenv("LIO_KNN_REUSE"); return (e && e[0] == '1') ? 1 : 0; }();
-void knn_set_reuse(int on) { g_knn_reuse = on ? 1 : 0; }
-
-int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode, int pass) {
+// Tied queries are queued and redone by a second (usually empty) launch.  (Measured and dropped in round 3: redoing them in place -- one
+// launch less per pass at 14 more registers, slower; the re-search of a later pass from the previous neighbours -- exact, no gain; one lane
+// per query with a flattened sweep -- 2-4 x slower.  tools/experiments/README.md has the numbers.)
+int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int count_touched) {
     // Workgroups per slot: enough of them over all slots to fill the machine a few times (256 CUs x 7 resident workgroups), not more -- a
     // workgroup that takes several query blocks in turn pays the kernel's prologue and epilogue (~11 % of a single block's instructions)
     // once.  One slot alone (the single-scan engine) keeps the full 2048; 24 slots get 512 each (measured: 16.9 -> 14.9 us per scan and
@@ -727,26 +646,16 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
     const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
     const dim3 gridx(n_slots > 8 ? 8 : 64, (uint32_t)n_slots);  // the tie queue of a scan holds a handful of queries at most: a few workgroups per slot (grid-stride inside)
     const int km = (m->stencil.n + kG - 1) / kG;
-    const int reuse = g_knn_reuse;
-#define KNNB_LAUNCH1(KM, TIE, RE) \
-    hipLaunchKernelGGL((knn_batch_kernel<KM, TIE, RE>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev, reuse)
-    // pass 0 of an update always searches from scratch: the variant without the re-search code (fewer registers, one more wave per SIMD)
-#define KNNB_LAUNCH(KM)                                                                                                                            \
-    do {                                                                                                                                           \
-        if (tie_mode == 1) {                                                                                                                       \
-            if (pass > 0 && reuse) KNNB_LAUNCH1(KM, true, true);                                                                                   \
-            else KNNB_LAUNCH1(KM, true, false);                                                                                                    \
-        } else {                                                                                                                                   \
-            if (pass > 0 && reuse) KNNB_LAUNCH1(KM, false, true);                                                                                  \
-            else KNNB_LAUNCH1(KM, false, false);                                                                                                   \
-            hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots); \
-        }                                                                                                                                          \
+#define KNNB_LAUNCH(KM)                                                                                                                              \
+    do {                                                                                                                                             \
+        if (count_touched) hipLaunchKernelGGL((knn_batch_kernel<KM, true>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
+        else hipLaunchKernelGGL((knn_batch_kernel<KM, false>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
+        hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots);       \
     } while (0)
     if (km <= 1) KNNB_LAUNCH(1);
     else if (km <= 2) KNNB_LAUNCH(2);
     else if (km <= 3) KNNB_LAUNCH(3);
     else KNNB_LAUNCH((kMaxStencil + kG - 1) / kG);
-#undef KNNB_LAUNCH1
 #undef KNNB_LAUNCH
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;

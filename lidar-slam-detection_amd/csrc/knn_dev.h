@@ -1,5 +1,5 @@
-// knn_dev.h -- device inlines shared by the two stencil-kNN kernels (knn.hip: 16 lanes per query, knn_q.hip: 4) and the kernels
-// that read the pose from the device-resident filter state.
+// knn_dev.h -- device inlines shared by the stencil-kNN kernel (knn.hip) and the kernels that read the pose from the device-resident
+// filter state.
 #pragma once
 #include "eskf_dev.h"
 #include "lio_common.h"

@@ -50,7 +50,8 @@ struct MapDev {
     unsigned long long n_lru_interleaved;  // LRU-back voxels that the batch evicting around them also touched (see hashmap.hip)
     int free_top[24];                // recycled pool regions by size class (floor(log2(capacity)))
     int free_in_top[24];             // regions freed by the grow kernel of the current batch (folded into free_top by lru_evict_kernel)
-    unsigned long long knn_cand[64 * 16];  // 64 shards, one 128-B line each (same-line atomics serialise in one L2 channel)
+    unsigned long long knn_cand[64 * 16];  // 64 shards, one 128-B line each (same-line atomics serialise in one L2 channel): word 0 = points resident in
+                                           // the probed stencil voxels, word 1 = points the sweep loaded (diagnostic kernel variant only)
 };
 
 // rigid transforms handed to kernels by value (doubles, as the reference computes them)
@@ -97,12 +98,12 @@ struct SlotDesc {
     uint32_t active;         // the slot has a job this round
     uint32_t seq;            // sequence number the result record of this round carries
     uint32_t max_ds, partial_blocks;
-    uint32_t min_ds, pad;    // scans that downsample to fewer points are not registered (5 in fastlio_main, 0 for a bare filter update)
+    uint32_t min_ds;         // scans that downsample to fewer points are not registered (5 in fastlio_main, 0 for a bare filter update)
+    uint32_t reset_cache;    // the job is an independent scan: the slot's neighbour cache is forgotten before it (lio_scan_job.flags)
     ScanDev* sd;
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *hist, *blockcnt, *hpos, *longlist, *tie_list;
     float4 *sorted, *ds_body, *ds_world, *nn_pts, *normvec;
     int32_t* nn_cnt;
-    uint4* nn_meta;          // per query: {voxel key lo, hi, stencil candidates, 1 if the search stored five neighbours} of the scan's last full search
     uint8_t* selected;
     double* partial;
     uint32_t* host_nds;      // mapped pinned words {n_ds, err, radix passes needed} of the slot's scan
@@ -183,7 +184,6 @@ struct lio_scan {
     uint32_t* hpos;      // first sorted position of every occupied voxel
     uint32_t* longlist;  // voxels with long runs
     uint32_t* tie_list;  // query indices with exact d2 ties
-    uint4* nn_meta;      // per query record of the scan's last full neighbour search (knn.hip: the re-search of a later filter pass starts from it)
     float4* sorted;      // raw points gathered into (voxel, input index) order
     double* partial;     // per-block partial sums
     uint32_t partial_blocks;
@@ -233,10 +233,7 @@ int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_s
 
 int vg_downsample(lio_scan* s, float leaf, int passes /* radix passes to launch, 1..4 */);
 int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes);
-int knn_q_batch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x);
-void knn_set_reuse(int on);
-int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int tie_mode, int pass);
-int knn_q_world(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt);
+int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int count_touched);
 // live kernel timing of the batched chain (bench.py's roofline leg): HIP events on the stream the kernels are launched on, per class
 struct BatchTimer {
     static constexpr int kClasses = 4;  // 0 downsample chain, 1 stencil kNN, 2 linearise, 3 filter pass
@@ -259,7 +256,7 @@ struct BatchTimer {
         }
     }
 };
-int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int knn_kind);
+int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int count_touched);
 int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);
 void kt_begin(lio_scan* s, int which);
@@ -279,4 +276,5 @@ extern "C" {
 int p2plane_linearize_begin(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn);
 int p2plane_linearize_end(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn, lio_normal_eq* out);
 int scan_share_ds(lio_scan* dst, lio_scan* src, uint32_t n);
+int scan_forget_cache(lio_scan* s);
 }

@@ -557,17 +557,13 @@ extern "C" int lio_debug_step_trace(unsigned long long* out64, int reset) {
 
 // the whole iterated update of every slot, enqueued blind: (neighbour search if the filter asks for it, linearisation, filter pass) x
 // (maximum_iter + 1); slots that converge early skip the rest of the launches
-int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int knn_kind) {
+int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int count_touched) {
     uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
     if (lin_blocks == 0) lin_blocks = 1;
-    uint32_t knn_blocks = (ds_bound + 63) / 64;  // 64 queries per workgroup of knn_q
-    if (knn_blocks > 1024) knn_blocks = 1024;
-    if (knn_blocks == 0) knn_blocks = 8;
     for (int p = 0; p < n_passes; p++) {
         if (bt) bt->begin(1);
-        // knn_kind 0: sixteen lanes per query (knn.hip) + the exact redo of queued ties, 2: the same with ties redone in place,
-        // 1: one lane per query (knn_q.hip)
-        const int rc = knn_kind == 1 ? knn_q_batch(m, st, d_slots, n_slots, knn_blocks) : knn_batch_launch(m, st, d_slots, n_slots, (ds_bound + 15) / 16, knn_kind == 2 ? 1 : 0, p);
+        // sixteen lanes per query (knn.hip) + the exact redo of queued ties (usually an empty launch)
+        const int rc = knn_batch_launch(m, st, d_slots, n_slots, (ds_bound + 15) / 16, count_touched);
         if (bt) bt->end(1);
         if (rc != LIO_OK) return rc;
         if (bt) bt->begin(2);

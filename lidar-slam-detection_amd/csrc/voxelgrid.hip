@@ -476,11 +476,15 @@ __global__ void scan_set_nds_kernel(ScanDev* sd, uint32_t n) {
 // ... and re-arm the bbox / counters for the next scan's downsample (saves two memset launches per scan)
 // -- but only for a scan that is registered: fastlio_main returns on feats_down_size < 5 (laserMapping.cpp:1250-1254) BEFORE that resize,
 // the cache of the previous scan then survives whole (min_ds = 5 on the engines' scans, 0 for a bare lio_scan)
-__device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict__ nn_cnt, uint32_t min_ds) {
-    const uint32_t lo = sd->n_ds, hi = sd->n_ds_prev;
-    if (lo >= min_ds) {
+// reset (an independent scan, lio_scan_job.flags == 0): the cache is forgotten first -- Nearest_Points as fastlio_init leaves it
+// (laserMapping.cpp:1045-1047) -- i.e. every entry the previous scan left is cleared, not only those beyond the new size (entries
+// beyond cache_n are zero by construction; a search that finds nothing in range leaves an entry alone, so a zero count stays zero)
+__device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict__ nn_cnt, uint32_t min_ds, uint32_t reset) {
+    const uint32_t n = sd->n_ds, hi = sd->n_ds_prev;
+    const uint32_t lo = reset ? 0u : n;
+    if (n >= min_ds) {
         for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) nn_cnt[i] = 0;
-        if (blockIdx.x == 0 && threadIdx.x == 0) sd->cache_n = lo;
+        if (blockIdx.x == 0 && threadIdx.x == 0) sd->cache_n = n;
     }
     if (blockIdx.x == 0 && threadIdx.x < 3) {
         sd->bbox_min[threadIdx.x] = 0xFFFFFFFFu;
@@ -571,11 +575,11 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_long_batch(const SlotDes
     if (!d.active) return;
     vg_centroid_long_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist);
 }
-__global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt, uint32_t min_ds) { scan_begin_body(sd, nn_cnt, min_ds); }
+__global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt, uint32_t min_ds) { scan_begin_body(sd, nn_cnt, min_ds, 0u); }
 __global__ void scan_begin_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    scan_begin_body(d.sd, d.nn_cnt, d.min_ds);
+    scan_begin_body(d.sd, d.nn_cnt, d.min_ds, d.reset_cache);
 }
 
 int vg_downsample(lio_scan* s, float leaf, int passes) {

@@ -105,6 +105,11 @@ class Map:
     def knn_candidates(self):
         return int(lib().lio_map_knn_candidates(self.h))
 
+    @property
+    def knn_touched(self):
+        """points the kNN sweep loaded so far (counted by the diagnostic kernel variant only: Batch.enable_kernel_timing(2))"""
+        return int(lib().lio_map_knn_touched(self.h))
+
     def dump(self):
         n = self.num_points
         out = np.zeros((max(n, 1), 4), np.float32)
@@ -726,6 +731,9 @@ class Batch:
         return process_batch(None, jobs, batch=self)
 
 
+JOB_KEEP_CACHE = 1  # LIO_JOB_KEEP_CACHE of include/lio_hip.h
+
+
 class PreparedJobs:
     """a job list marshalled once into the C ABI's lio_scan_job array (so that a timed region can be the one C call and nothing else)"""
 
@@ -745,6 +753,7 @@ class PreparedJobs:
             a = self.arr[i]
             a.d_raw = j["dptr"]
             a.n_raw = j["n"]
+            a.flags = int(j.get("flags", 0))  # 0: an independent scan (the slot forgets its neighbour cache first); JOB_KEEP_CACHE: one of a sequence
             a.lidar_beg_time = float(j["t"])
             a.state_in = ptr(st, C.c_double)
             a.cov_in = ptr(cv, C.c_double)

@@ -1,7 +1,8 @@
 """BASELINE.json's configurations at their full sizes on the GPU:
   config 2: 1e6-point static map, 64 x 1875 scans, seeds 1000..1099, full iterate-to-converge -- HIP vs the oracle (same passes, same
             effective points, pose <= 1e-9) and vs the reference's own translation units (north-star bar: 1e-4 m / 1e-5 rad);
-  metric config: 1e7-point map, ~120k-point scans, 16 scans, same checks.
+  metric config: 1e7-point map, ~120k-point scans, 16 scans, same checks -- and the batched engine (lio_batch_process, 32 scans per launch,
+            3 rounds in flight: what bench.py's timed region runs) on 208 jobs made of the same scans: poses <= 1e-9 from the oracle's.
 The reference leg runs when oracle/_ref/libref_fastlio.so travelled with the snapshot (it is built where /root/reference exists)."""
 import os
 import sys
@@ -15,7 +16,7 @@ import scenes  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _run(oracle_mod, n_map, seeds, fov_deg, max_range, max_voxels):
+def _run(oracle_mod, n_map, seeds, fov_deg, max_range, max_voxels, batched=None):
     from lsd_amd import capi, lio, synth
 
     if capi.lib().lio_device_count() < 1:
@@ -40,6 +41,7 @@ def _run(oracle_mod, n_map, seeds, fov_deg, max_range, max_voxels):
         R.set_nearby(18)
     worst = dict(o_dp=0.0, o_da=0.0, r_dp=0.0, r_da=0.0, truth=0.0)
     n_raw = []
+    kept = []  # (scan, oracle state, oracle pass count, oracle search count) for the batched leg
     for seed in seeds:
         sc = scenes.config_scan(scene, seed, fov_deg=fov_deg, max_range=max_range)
         n_raw.append(len(sc["raw"]))
@@ -62,12 +64,32 @@ def _run(oracle_mod, n_map, seeds, fov_deg, max_range, max_voxels):
         worst["o_da"] = max(worst["o_da"], float(synth.quat_angle(sg[3:7], so[3:7])))
         worst["truth"] = max(worst["truth"], float(np.linalg.norm(sg[:3] - sc["pos"])))
         assert np.abs(sg - so).max() < 1e-9, seed
+        kept.append((sc, so, len(lo), sum(p["knn"] for p in lo)))
         if R is not None:
             R.reset_cache()
             rc, sr, _ = R.register(sc["raw"], sc["guess"], P0)
             assert rc == 3
             worst["r_dp"] = max(worst["r_dp"], float(np.linalg.norm(sg[:3] - sr[:3])))
             worst["r_da"] = max(worst["r_da"], float(synth.quat_angle(sg[3:7], sr[3:7])))
+    if batched:
+        # the path bench.py times: lio_batch_process with `slots` scans per launch and `groups` rounds in flight (one hipGraphLaunch per
+        # round), the filter loop on the device -- every occurrence of every scan against the oracle's registration of that scan
+        slots, groups, reps = batched
+        b = lio.Batch(e.map, n_slots=slots, n_groups=groups, max_raw=1 << 17, max_ds=100000)
+        dptrs = [scenes.to_device(k[0]["raw"]) for k in kept]
+        jobs = [dict(dptr=dptrs[i % len(kept)], n=len(kept[i % len(kept)][0]["raw"]), t=1.0 + 0.1 * i, state=kept[i % len(kept)][0]["guess"], cov=P0)
+                for i in range(len(kept) * reps)]
+        rc, res = b.process(jobs)
+        assert rc == 0
+        wb = 0.0
+        for i, r in enumerate(res):
+            sc, so, n_pass, n_knn = kept[i % len(kept)]
+            assert (r["rc"], r["n_pass"], r["n_knn_pass"]) == (3, n_pass, n_knn), (i, r)
+            wb = max(wb, float(np.abs(r["state"] - so).max()))
+            assert np.array_equal(r["state"], res[i % len(kept)]["state"]), i  # independent jobs: the slot's history does not matter
+        worst["batch_vs_oracle"] = wb
+        assert wb < 1e-9, wb
+        assert len(jobs) > 2 * slots * groups  # every group ran more than two rounds: slots re-used behind other scans
     print("map", n_map, "scans", len(seeds), "n_raw avg", int(np.mean(n_raw)), worst)
     assert worst["truth"] < 0.1
     if R is not None:  # north-star bar against the reference's own code (untouched neighbour order, Eigen's dense algebra)
@@ -80,4 +102,5 @@ def test_config2_1e6_map_100_scans(oracle_mod):
 
 
 def test_metric_config_1e7_map_16_scans(oracle_mod):
-    _run(oracle_mod, 10_000_000, range(2000, 2016), (-24.8, 2.0), 150.0, 2_500_000)
+    """... and the same 16 scans 13 times over through the batched engine in bench.py's geometry (32 slots x 3 groups)"""
+    _run(oracle_mod, 10_000_000, range(2000, 2016), (-24.8, 2.0), 150.0, 2_500_000, batched=(32, 3, 13))
