@@ -439,6 +439,15 @@ int lio_ndt_fitness_score(lio_ndt*, lio_scan* source, const double T[16], double
  * The reference's constants: xy_range 100.0, min_z 0.5. */
 int lio_ndt_overlap_score(lio_ndt*, lio_scan* source, const double relpose[16], double max_range, double xy_range, double min_z, double* score,
                           double* inlier_ratio);
+/* live timing of the matcher's dominant kernel (ndt_cost_kernel: correspondences + cost [+ H, b] of one evaluation) with HIP events on the
+ * stream it runs on -- bench.py's roofline leg of BASELINE config 4.  Summed over the evaluations since the last reset: device time, launches
+ * (of which with a correspondence update), voxel correspondences evaluated, source points.  Off by default (one event wait per evaluation). */
+typedef struct lio_ndt_times {
+    double cost_us;
+    uint64_t launches, update_launches, pairs, source_points;
+} lio_ndt_times;
+int lio_ndt_enable_kernel_timing(lio_ndt*, int on);
+int lio_ndt_kernel_times(lio_ndt*, lio_ndt_times* out, int reset);
 typedef struct lio_ndt_params {
     int32_t max_iterations;           /* setMaximumIterations (64) */
     int32_t lm_max_iterations;        /* lm_max_iterations_ (10) */

@@ -104,7 +104,7 @@ struct lio_engine {
     std::vector<lio_pass_log> log;
     // timing
     bool timing = false;
-    hipEvent_t ev[8];
+    hipEvent_t ev[2] = {nullptr, nullptr};  // the two timing events, made once by lio_engine_enable_timing (a pair per pass used to be created and destroyed)
     lio_timings tm;
     std::vector<double> rows6, hvec;
     lio_reduce_fn reduce = nullptr;  // cross-GPU reduction of the normal equations (joint registration)
@@ -113,6 +113,7 @@ struct lio_engine {
 };
 
 int engine_resume_update_impl(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t, bool keep_log);
+static void joint_reduce(void* vctx, double* buf, int n);
 struct lio_comm;
 int comm_reduce_host(lio_comm* c, double* buf, int n);  // comm.hip
 
@@ -156,8 +157,8 @@ int measure_pass(lio_engine* e, const LioState& x, bool converge, Measurement& m
     pose_arrays(x, pose, ext);
     lio_normal_eq ne;
     hipEvent_t t0, t1;
-    if (e->timing) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, e->scan->stream); }
-    if (e->joint && e->joint->rc == LIO_OK) {
+    if (e->timing) { t0 = e->ev[0]; t1 = e->ev[1]; hipEventRecord(t0, e->scan->stream); }
+    if (e->joint && e->reduce == joint_reduce && e->joint->rc == LIO_OK) {
         // joint registration: the other local sub-maps' linearisations of this pass go out first, each on its own scan's stream, so that
         // they run beside the driving engine's own instead of one after the other behind it
         e->joint->begun = true;
@@ -172,22 +173,30 @@ int measure_pass(lio_engine* e, const LioState& x, bool converge, Measurement& m
         hipEventSynchronize(t1);
         const float us = ev_us(t0, t1);
         if (converge) e->tm.knn_us += us; else e->tm.linearize_us += us;
-        hipEventDestroy(t0); hipEventDestroy(t1);
     }
     e->tm.n_pass++;
     if (converge) e->tm.n_knn_pass++;
-    if (rc != LIO_OK) return rc;
+    if (rc != LIO_OK && !e->reduce) return rc;
     if (e->reduce) {
         // joint registration: this rank's sums -> global sums (fixed rank order inside the hook), then the
-        // degeneracy logic on the GLOBAL eigen-structure
+        // degeneracy logic on the GLOBAL eigen-structure.
+        // A rank whose own linearisation failed STILL takes part in the collective of this pass -- with a record of NaNs: the sums are then
+        // NaN on every rank, and every rank gives the registration up here, in the same pass, instead of the healthy ones waiting for ever
+        // in an all-gather the failed one never enters.
         double buf[29];
         int t = 0;
-        for (int a = 0; a < 6; a++)
-            for (int c = a; c < 6; c++) buf[t++] = ne.JtJ[a * 6 + c];
-        for (int a = 0; a < 6; a++) buf[21 + a] = ne.Jtr[a];
-        buf[27] = ne.sum_abs_res;
-        buf[28] = (double)ne.n_eff;
+        if (rc == LIO_OK) {
+            for (int a = 0; a < 6; a++)
+                for (int c = a; c < 6; c++) buf[t++] = ne.JtJ[a * 6 + c];
+            for (int a = 0; a < 6; a++) buf[21 + a] = ne.Jtr[a];
+            buf[27] = ne.sum_abs_res;
+            buf[28] = (double)ne.n_eff;
+        } else {
+            for (int a = 0; a < 29; a++) buf[a] = NAN;
+        }
         e->reduce(e->reduce_ctx, buf, 29);
+        if (rc != LIO_OK) return rc;
+        if (!(buf[28] == buf[28])) { set_error("joint registration: a rank (or a local sub-map) reported a failure in this pass"); return LIO_E_DEVICE; }
         t = 0;
         for (int a = 0; a < 6; a++)
             for (int c = a; c < 6; c++) { ne.JtJ[a * 6 + c] = buf[t]; ne.JtJ[c * 6 + a] = buf[t]; t++; }
@@ -200,11 +209,14 @@ int measure_pass(lio_engine* e, const LioState& x, bool converge, Measurement& m
         bool need = false;
         for (int i = 0; i < 3; i++)
             if (!(ne.eigval[i] * (1.0 - 1e-5) - 0.030138 * (double)ne.n_eff >= 250.0 + 1e-3)) need = true;
-        if (need && ne.n_eff > 0) {
+        if (need && ne.n_eff > 0) {  // (a decision made from the GLOBAL sums: the same on every rank)
             double cs[6];
             const int r2 = lio_p2plane_degeneracy(e->scan, ne.eigvec, cs, cs + 3);
-            if (r2 != LIO_OK) return r2;
+            if (r2 != LIO_OK)
+                for (int a = 0; a < 6; a++) cs[a] = NAN;
             e->reduce(e->reduce_ctx, cs, 6);
+            if (r2 != LIO_OK) return r2;
+            if (!(cs[0] == cs[0])) { set_error("joint registration: a rank reported a failure in the degeneracy sums"); return LIO_E_DEVICE; }
             for (int i = 0; i < 3; i++) { ne.contri[i] = cs[i]; ne.strong[i] = cs[3 + i]; }
         } else {
             for (int i = 0; i < 3; i++) { ne.contri[i] = INFINITY; ne.strong[i] = INFINITY; }
@@ -507,7 +519,9 @@ void lio_engine_destroy(lio_engine* e) {
     if (!e) return;
     frontend_destroy(e);
     if (e->dl) { hipStreamSynchronize(e->scan->stream); devloop_destroy(e->dl); }
-    delete e->joint;
+    delete e->joint;  // (the other sub-maps' engines may be gone already: their scans are not touched here -- lio_engine_set_joint(e, NULL, 0, NULL)
+                      // before destroying the driver hands them their own degeneracy evaluation back)
+    if (e->ev[0]) { hipEventDestroy(e->ev[0]); hipEventDestroy(e->ev[1]); }
     lio_scan_destroy(e->scan);
     if (e->own_map) lio_map_destroy(e->map);
     delete e;
@@ -545,9 +559,27 @@ int lio_engine_pass_log(lio_engine* e, int i, lio_pass_log* out) {
     return LIO_OK;
 }
 
-int lio_engine_enable_timing(lio_engine* e, int on) { if (!e) return LIO_E_INVALID; e->timing = on != 0; return LIO_OK; }
+int lio_engine_enable_timing(lio_engine* e, int on) {
+    if (!e) return LIO_E_INVALID;
+    if (on && !e->ev[0]) {
+        hipSetDevice(e->scan->device);
+        LIO_HIP_TRY(hipEventCreate(&e->ev[0]));
+        LIO_HIP_TRY(hipEventCreate(&e->ev[1]));
+    }
+    e->timing = on != 0;
+    return LIO_OK;
+}
+// the joint context goes with its hook: the other sub-maps' scans evaluate their own degeneracy sums again
+static void joint_teardown(lio_engine* e) {
+    if (!e->joint) return;
+    for (lio_engine* o : e->joint->others) lio_scan_set_degeneracy_mode(o->scan, 0);
+    delete e->joint;
+    e->joint = nullptr;
+}
+
 int lio_engine_set_reduce_hook(lio_engine* e, lio_reduce_fn fn, void* ctx) {
     if (!e) return LIO_E_INVALID;
+    if (fn != joint_reduce) joint_teardown(e);  // a caller's hook (or none) replaces a native joint registration
     e->reduce = fn;
     e->reduce_ctx = ctx;
     // with a hook the degeneracy sums are evaluated here, after the reduction, never inside linearize
@@ -557,17 +589,19 @@ int lio_engine_set_reduce_hook(lio_engine* e, lio_reduce_fn fn, void* ctx) {
 static void joint_reduce(void* vctx, double* buf, int n) {
     JointCtx* j = static_cast<JointCtx*>(vctx);
     lio_engine* e = j->self;
-    if (j->rc != LIO_OK) return;
+    // Every call takes part in the collective, whatever happened locally: a failure (here, or in the caller's own linearisation, which then
+    // hands in NaNs) travels as NaN sums, every rank sees them and gives up in the same pass (measure_pass).
+    auto poison = [&]() { for (int k = 0; k < n; k++) buf[k] = NAN; };
     if (n == 29) {
         const bool redo = e->tm.n_knn_pass > j->knn_seen;  // (already counts the pass being reduced)
         j->knn_seen = e->tm.n_knn_pass;
         double pose[7], ext[7];
         pose_arrays(e->kf.x, pose, ext);
-        for (lio_engine* o : j->others) {
+        for (lio_engine* o : j->others) {  // (all of them, also after a failure: what was begun is ended)
             lio_normal_eq ne;
             const int rc = j->begun ? p2plane_linearize_end(o->map, o->scan, pose, ext, redo ? 1 : 0, &ne)
-                                    : lio_p2plane_linearize(o->map, o->scan, pose, ext, redo ? 1 : 0, &ne);
-            if (rc != LIO_OK) { j->rc = rc; j->begun = false; return; }
+                                    : (j->rc == LIO_OK ? lio_p2plane_linearize(o->map, o->scan, pose, ext, redo ? 1 : 0, &ne) : j->rc);
+            if (rc != LIO_OK) { if (j->rc == LIO_OK) j->rc = rc; continue; }
             int t = 0;
             for (int a = 0; a < 6; a++)
                 for (int c = a; c < 6; c++) buf[t++] += ne.JtJ[a * 6 + c];
@@ -576,7 +610,8 @@ static void joint_reduce(void* vctx, double* buf, int n) {
             buf[28] += (double)ne.n_eff;
         }
         j->begun = false;
-        if (j->comm) { const int rc = comm_reduce_host(j->comm, buf, 29); if (rc != LIO_OK) { j->rc = rc; return; } }
+        if (j->rc != LIO_OK) poison();
+        if (j->comm) { const int rc = comm_reduce_host(j->comm, buf, 29); if (rc != LIO_OK) { if (j->rc == LIO_OK) j->rc = rc; poison(); return; } }
         double J[36];
         int t = 0;
         for (int a = 0; a < 6; a++)
@@ -588,18 +623,18 @@ static void joint_reduce(void* vctx, double* buf, int n) {
         eig3_sym(j->nnT, w, V);
         for (lio_engine* o : j->others) {
             double cs[6];
-            const int rc = lio_p2plane_degeneracy(o->scan, V, cs, cs + 3);
-            if (rc != LIO_OK) { j->rc = rc; return; }
+            const int rc = j->rc == LIO_OK ? lio_p2plane_degeneracy(o->scan, V, cs, cs + 3) : j->rc;
+            if (rc != LIO_OK) { if (j->rc == LIO_OK) j->rc = rc; continue; }
             for (int k = 0; k < 6; k++) buf[k] += cs[k];
         }
-        if (j->comm) { const int rc = comm_reduce_host(j->comm, buf, 6); if (rc != LIO_OK) { j->rc = rc; return; } }
+        if (j->rc != LIO_OK) poison();
+        if (j->comm) { const int rc = comm_reduce_host(j->comm, buf, 6); if (rc != LIO_OK) { if (j->rc == LIO_OK) j->rc = rc; poison(); return; } }
     }
 }
 
 int lio_engine_set_joint(lio_engine* e, lio_engine** others, int n_others, lio_comm* comm) {
     if (!e || n_others < 0 || (n_others && !others)) return LIO_E_INVALID;
-    delete e->joint;
-    e->joint = nullptr;
+    joint_teardown(e);
     if (n_others == 0 && !comm) return lio_engine_set_reduce_hook(e, nullptr, nullptr);
     JointCtx* j = new JointCtx();
     j->self = e;
@@ -620,6 +655,12 @@ int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_
     JointCtx* j = e->joint;
     j->knn_seen = 0;
     j->rc = LIO_OK;
+    j->begun = false;
+    // Whether a scan is registered at all must not depend on rank-local state: every rank sees the same cloud (hence the same downsampled
+    // size and the same "too few points" decision), the first-scan latch and the seeding of an empty map (laserMapping.cpp:1171-1177,
+    // 1227-1239) do not apply to a registration against prebuilt sub-maps -- a rank whose sub-map is empty contributes zero rows.
+    e->flg_first_scan = false;
+    e->map_seeded = true;
     // the cloud is uploaded and downsampled ONCE, by the driving engine; the other sub-maps' scan buffers receive its downsampled points
     // device to device right after (process_core) -- same leaf, same input: what each of them would have computed itself
     j->share_ds = true;
@@ -666,14 +707,13 @@ static int process_core(lio_engine* e, double lidar_beg_time) {
     if (s->n_raw == 0) return 2;  // "FastLio undistort points is empty"
     e->flg_EKF_inited = (lidar_beg_time - e->first_lidar_time) < e->init_time ? false : true;
     hipEvent_t t0, t1;
-    if (e->timing) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, s->stream); }
+    if (e->timing) { t0 = e->ev[0]; t1 = e->ev[1]; hipEventRecord(t0, s->stream); }
     uint32_t n_ds = 0;
     int rc = lio_scan_voxel_downsample(s, e->leaf_surf, 1, &n_ds);
     if (e->timing) {
         hipEventRecord(t1, s->stream);
         hipEventSynchronize(t1);
         e->tm.downsample_us = ev_us(t0, t1);
-        hipEventDestroy(t0); hipEventDestroy(t1);
     }
     if (rc != LIO_OK) return rc;
     e->tm.n_ds = (int)n_ds;
@@ -718,13 +758,12 @@ static int process_core(lio_engine* e, double lidar_beg_time) {
         e->tm.total_wall_us = (float)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
         return 3;
     }
-    if (e->timing) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, s->stream); }
+    if (e->timing) { t0 = e->ev[0]; t1 = e->ev[1]; hipEventRecord(t0, s->stream); }
     rc = lio_map_incremental(e->map, s, pose, ext, e->leaf_map, e->flg_EKF_inited ? 1 : 0, e->travel);
     if (e->timing) {
         hipEventRecord(t1, s->stream);
         hipEventSynchronize(t1);
         e->tm.insert_us = ev_us(t0, t1);
-        hipEventDestroy(t0); hipEventDestroy(t1);
     }
     if (rc < 0) return rc;
     e->tm.n_added = rc;
@@ -996,14 +1035,13 @@ static int fe_undistort(lio_engine* e, const PendingScan& sc, const std::vector<
     A.filter_num = f->max_point_num > 0 ? std::max(1, (int)sc.n / f->max_point_num) : f->filter_num;
     A.undistort = f->undistort ? 1 : 0;
     hipEvent_t t0, t1;
-    if (e->timing) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, s->stream); }
+    if (e->timing) { t0 = e->ev[0]; t1 = e->ev[1]; hipEventRecord(t0, s->stream); }
     LIO_HIP_TRY(hipMemcpyAsync(f->d_poses, f->h_poses, sizeof(ImuPoseDev) * (size_t)f->n_poses, hipMemcpyHostToDevice, s->stream));
     rc = undistort_launch(s->stream, d_in, d_stamp, sc.n, s->raw_own, f->d_poses, A, f->d_first);
     if (e->timing) {
         hipEventRecord(t1, s->stream);
         hipEventSynchronize(t1);
         e->tm.undistort_us = ev_us(t0, t1);
-        hipEventDestroy(t0); hipEventDestroy(t1);
     }
     if (rc != LIO_OK) return rc;
     s->raw = s->raw_own;

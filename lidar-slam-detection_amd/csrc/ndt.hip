@@ -523,6 +523,12 @@ struct lio_ndt {
     uint64_t stamp_cap;
     uint64_t max_points;
     int method;
+    // live timing of ndt_cost_kernel (bench.py --config localize): HIP events on the stream it is launched on
+    int timing;
+    hipEvent_t ev[2];
+    double cost_us;
+    uint64_t cost_launches, cost_pairs, cost_points, upd_launches;
+    uint32_t last_corr;
 };
 
 namespace {
@@ -569,6 +575,7 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
     const NdtXform xl = to_xform(x_lin), xx = to_xform(x);
     hipStream_t st = s->stream;
     if (update) LIO_HIP_TRY(hipMemsetAsync(&n->dev->n_corr, 0, 4, st));
+    if (n->timing) hipEventRecord(n->ev[0], st);
 #define NDT_LAUNCH(U, D, NO)                                                                                                                       \
     hipLaunchKernelGGL((ndt_cost_kernel<U, D, NO>), blocks, kNdtThreads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xl, xx, \
                        s->ds_body, s->dev, n->corr, n->max_src, n->partial, n->dev)
@@ -584,6 +591,7 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
     else NDT_DISPATCH(27);
 #undef NDT_DISPATCH
 #undef NDT_LAUNCH
+    if (n->timing) hipEventRecord(n->ev[1], st);
     hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, deriv ? kNdtAcc : 1, n->dev, n->report_dev);
     LIO_HIP_TRY(hipGetLastError());
     n->seq_expected++;
@@ -595,6 +603,17 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
     }
     if (err) *err = n->report->acc[42];
     if (n_corr) *n_corr = n->report->n_corr;
+    if (update) n->last_corr = n->report->n_corr;
+    if (n->timing) {
+        float ms = 0.f;
+        if (hipEventSynchronize(n->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, n->ev[0], n->ev[1]) == hipSuccess) {
+            n->cost_us += (double)ms * 1000.0;
+            n->cost_launches++;
+            n->cost_pairs += n->last_corr;
+            n->cost_points += s->have_ds > 0 ? (uint64_t)s->have_ds : 0ull;
+            if (update) n->upd_launches++;
+        }
+    }
     return LIO_OK;
 }
 
@@ -639,7 +658,30 @@ void lio_ndt_destroy(lio_ndt* n) {
     if (n->map) { hipStreamSynchronize(n->map->stream); lio_map_destroy(n->map); }
     hipFree(n->vox); hipFree(n->corr); hipFree(n->partial); hipFree(n->dev); hipFree(n->stamp); hipFree(n->list); hipFree(n->list_cnt);
     if (n->report) hipHostFree(n->report);
+    if (n->ev[0]) { hipEventDestroy(n->ev[0]); hipEventDestroy(n->ev[1]); }
     delete n;
+}
+
+int lio_ndt_enable_kernel_timing(lio_ndt* n, int on) {
+    if (!n) return LIO_E_INVALID;
+    hipSetDevice(n->device);
+    if (on && !n->ev[0]) {
+        LIO_HIP_TRY(hipEventCreate(&n->ev[0]));
+        LIO_HIP_TRY(hipEventCreate(&n->ev[1]));
+    }
+    n->timing = on != 0;
+    return LIO_OK;
+}
+
+int lio_ndt_kernel_times(lio_ndt* n, lio_ndt_times* out, int reset) {
+    if (!n || !out) return LIO_E_INVALID;
+    out->cost_us = n->cost_us;
+    out->launches = n->cost_launches;
+    out->update_launches = n->upd_launches;
+    out->pairs = n->cost_pairs;
+    out->source_points = n->cost_points;
+    if (reset) { n->cost_us = 0; n->cost_launches = n->cost_pairs = n->cost_points = n->upd_launches = 0; }
+    return LIO_OK;
 }
 
 int lio_ndt_set_target_device(lio_ndt* n, const void* d_xyzi, uint64_t np) {

@@ -453,6 +453,14 @@ class Ndt:
 
     __del__ = close
 
+    def enable_kernel_timing(self, on=True):
+        check(lib().lio_ndt_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_times(self, reset=True):
+        t = capi.NdtTimes()
+        check(lib().lio_ndt_kernel_times(self.h, C.byref(t), int(reset)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
     def set_target(self, pts):
         p = f32(pts).reshape(-1, 4)
         check(lib().lio_ndt_set_target(self.h, ptr(p, C.c_float), len(p)), "ndt set_target")

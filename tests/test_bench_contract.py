@@ -34,3 +34,26 @@ def test_bench_defaults_are_the_drivers_assumptions():
     assert re.search(r'"--gpus", type=int, default=1\b', src)
     assert re.search(r'"--steps", type=int, default=\d+', src) and re.search(r'"--warmup", type=int, default=\d+', src)
     assert "oracle" not in src.split("def main")[0]  # nothing of oracle/ is imported at module level: only the cpu_baseline leg loads it
+
+
+def test_recorded_sweep_loader(tmp_path):
+    """--config stream --bin-dir: KITTI-layout *.bin sweeps (x, y, z, intensity f32; NCLT velodyne_sync converted to it) + optional imu.csv"""
+    import importlib.util
+
+    import numpy as np
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(0)
+    clouds = [rng.normal(size=(n, 4)).astype(np.float32) for n in (100, 57, 3)]
+    for k, c in enumerate(clouds):
+        c.tofile(tmp_path / f"{k:06d}.bin")
+    sweeps, (t, g, a) = bench.load_bin_dir(str(tmp_path))
+    assert len(sweeps) == 3
+    for (p, st), c in zip(sweeps, clouds):
+        assert np.array_equal(p, c) and st.dtype == np.uint32 and len(st) == len(c) and st[0] == 0 and st[-1] < 100000 and np.all(np.diff(st.astype(np.int64)) >= 0)
+    assert np.allclose(a, [0, 0, 9.81]) and np.all(g == 0) and t[-1] >= 0.3 + 0.2  # no imu.csv: a level sensor at rest
+    np.savetxt(tmp_path / "imu.csv", np.array([[0.0, 1, 2, 3, 4, 5, 6], [0.01, 1, 2, 3, 4, 5, 6]]), delimiter=",")
+    _, (t, g, a) = bench.load_bin_dir(str(tmp_path))
+    assert t.tolist() == [0.0, 0.01] and g[1].tolist() == [1, 2, 3] and a[0].tolist() == [4, 5, 6]
