@@ -345,9 +345,13 @@ void lio_comm_destroy(lio_comm*);
 int lio_comm_rank(const lio_comm*);
 int lio_comm_world(const lio_comm*);
 int lio_allgather_normal_eq(lio_comm*, const double* d_local32, double* d_gathered, double* d_sum32, void* stream);
+/* the same for the records of many scans at once (the batched engine's joint mode: one collective per pass for all scans of a round):
+ * n_records x 32 doubles per rank in, world x n_records x 32 out (rank-major), no sum -- the consumer adds the ranks' records in rank order */
+int lio_allgather_records(lio_comm*, const double* d_local, double* d_gathered, uint32_t n_records, void* stream);
 int lio_comm_stats(lio_comm*, uint64_t* n_collectives, double* total_us);  /* collectives issued by joint registrations and their host-observed time */
 int lio_engine_set_joint(lio_engine* e, lio_engine** others, int n_others, lio_comm* comm);
 int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]);
+int lio_engine_joint_register_device(lio_engine* e, const void* d_raw_body_xyzi, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]);
 /* Throughput mode: register a batch of independent scans with `n_engines` engines running concurrently (one host
  * thread + HIP stream per engine, jobs handed out through an atomic counter).  Every job = set_state(state_in) +
  * set_cov(cov_in) + lio_engine_process_scan_device(d_raw, n_raw, lidar_beg_time); outputs are filled per job.
@@ -385,6 +389,16 @@ typedef struct lio_batch_result {
     uint32_t seq, pad2;
 } lio_batch_result;
 lio_batch* lio_batch_create(lio_map* shared_map, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds);
+/* Joint registration, batched (BASELINE.json config 5, the map-merge shape of slam/localization/include/overlap_merge.hpp:46-48,158-179: many key
+ * frames x candidates, each an independent alignment): every job of lio_batch_process is registered against ALL `sub_maps` (resident on this GPU)
+ * and, through `comm` (NULL: single process), against the sub-maps of the other ranks -- every rank calls lio_batch_process with the SAME job list
+ * (same clouds resident on its own GPU, same priors) and receives the same posteriors, bit for bit.  A round of B scans is enqueued blind on the
+ * round's stream: downsample once per scan, then per pass {neighbour search, linearisation} per local sub-map, the rank's B records of 32 doubles,
+ * ONE all-gather of [B x 32] doubles for the whole round (RCCL on that stream, no host in between), the filter pass on the sums taken in rank
+ * order (csrc/eskf_dev.h on the device).  A pass with N_eff < 23 uses the information form (the rows live on several GPUs), a scan whose pass needs
+ * the degeneracy sums (src/laserMapping.cpp:946-964) is redone by the host-driven path (lio_engine_joint_register_device of the slot's engines).
+ * Results equal lio_engine_joint_register's on the same sub-maps, job by job (tests/test_dist.py). */
+lio_batch* lio_batch_create_joint(lio_map** sub_maps, int n_sub_maps, lio_comm* comm, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds);
 void lio_batch_destroy(lio_batch*);
 int lio_batch_process(lio_batch*, lio_scan_job* jobs, int n_jobs);
 /* live kernel timing of the batched chain with HIP events on the groups' streams (bench.py's roofline leg): per class the summed device

@@ -19,13 +19,19 @@ using namespace lio;
 
 int engine_resume_update(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t);  // engine.hip
 void engine_count_passes(lio_engine* e, int* n_pass, int* n_knn);
+int engine_joint_register_device(lio_engine* e, const void* d_raw, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]);
+struct lio_comm;
+extern "C" int lio_comm_world(const lio_comm*);
 
 namespace {
 
 struct Group {
     hipStream_t stream = nullptr;
     std::vector<lio_engine*> eng;
-    char* d_block = nullptr;             // [SlotDesc x B][EskfDev x B]: one upload per round
+    std::vector<lio_engine*> sub_eng;    // joint mode: the scan buffer sets of the further local sub-maps, [(m - 1) * B + slot]
+    double* d_local32 = nullptr;         // joint mode: this rank's record per slot (B x 32), and every rank's (world x B x 32)
+    double* d_gathered = nullptr;
+    char* d_block = nullptr;             // [SlotDesc x B (x sub-maps)][EskfDev x B]: one upload per round
     char* h_block = nullptr;             // pinned staging, same layout
     size_t block_bytes = 0;
     SlotDesc* d_desc = nullptr;
@@ -55,6 +61,12 @@ struct lio_batch {
     int pred_passes = 4;  // radix passes the last rounds needed
     int use_graph = 1;    // LIO_BATCH_GRAPH=0: plain launches instead of one hipGraphLaunch per round
     int count_touched = 0;  // lio_batch_enable_kernel_timing(b, 2): the kNN kernel's diagnostic variant that also counts the points it loads
+    // joint mode (lio_batch_create_joint): every job is registered against all of `maps` (sub-maps on this GPU; maps[0] == map) and, through
+    // `comm`, against the sub-maps of the other ranks
+    std::vector<lio_map*> maps;
+    lio_comm* comm = nullptr;
+    int world = 1;
+    bool joint = false;
     std::vector<Group> groups;
     double t_submit = 0, t_wait = 0, t_collect = 0;  // host seconds (LIO_BATCH_PROFILE=1 prints them when the object is destroyed)
     uint64_t n_rounds = 0;
@@ -76,7 +88,8 @@ void fill_desc(SlotDesc& d, lio_scan* sc, EskfDev* d_ctrl, lio_batch_result* d_r
     d.result = d_res;
 }
 
-void fill_ctrl(EskfDev& c, const double* x26, const double* P529, double R, int max_iter, int degenerate_detect_en) {
+void fill_ctrl(EskfDev& c, const double* x26, const double* P529, double R, int max_iter, int degenerate_detect_en, int joint = 0) {
+    c.joint = joint;
     memcpy(c.x, x26, sizeof(double) * 26);
     memcpy(c.P, P529, sizeof(double) * 529);
     for (int k = 0; k < kEkN; k++) c.limit[k] = 0.001;
@@ -88,7 +101,10 @@ void fill_ctrl(EskfDev& c, const double* x26, const double* P529, double R, int 
 }
 
 void group_free(Group& g) {
-    for (lio_engine* e : g.eng) lio_engine_destroy(e);
+    for (lio_engine* e : g.eng) lio_engine_destroy(e);  // (joint mode: the drivers first -- they hold pointers to the sub-maps' engines)
+    for (lio_engine* e : g.sub_eng) lio_engine_destroy(e);
+    if (g.d_local32) hipFree(g.d_local32);
+    if (g.d_gathered) hipFree(g.d_gathered);
     for (int k = 0; k < 5; k++)
         if (g.exec[k]) hipGraphExecDestroy(g.exec[k]);
     if (g.d_block) hipFree(g.d_block);
@@ -129,11 +145,18 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         d.seq = g.seq;
         d.min_ds = 5;  // laserMapping.cpp:1246: fewer than five downsampled points are not registered
         d.reset_cache = (job.flags & LIO_JOB_KEEP_CACHE) ? 0u : 1u;
-        fill_ctrl(g.h_ctrl[s], job.state_in, job.cov_in, 0.001 /* LASER_POINT_COV */, 4, 1);
+        fill_ctrl(g.h_ctrl[s], job.state_in, job.cov_in, 0.001 /* LASER_POINT_COV */, 4, 1, b->joint ? 1 : 0);
         g.h_res[s].seq = g.seq - 1;
         g.n_active++;
         if (job.n_raw > g.max_n_raw) g.max_n_raw = job.n_raw;
     }
+    const int M = (int)b->maps.size();
+    for (int m = 1; m < M; m++)  // the per-round words of the further sub-maps' rows follow the slot's own
+        for (int s = 0; s < B; s++) {
+            SlotDesc& d = g.h_desc[(size_t)m * B + s];
+            const SlotDesc& p = g.h_desc[s];
+            d.raw = p.raw; d.n_raw = p.n_raw; d.nblocks = p.nblocks; d.active = p.active; d.seq = p.seq; d.min_ds = p.min_ds; d.reset_cache = p.reset_cache;
+        }
     if (g.n_active == 0) return LIO_OK;
     // The round is ONE submission: upload of the staging block, voxel-grid chain, (maximum_iter + 1) x {kNN, linearise, filter pass}.
     // Every argument is fixed per group (pointers into the group's blocks; what changes from round to round travels in the block), so
@@ -147,9 +170,16 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         if (bt) bt->end(0);
         if (rc != LIO_OK) return rc;
         const uint32_t ds_bound = b->max_raw < b->max_ds ? b->max_raw : b->max_ds;
+        if (b->joint) {
+            // the slot's downsampled cloud to the other local sub-maps' scan buffers, their neighbour caches resized / forgotten like the slot's own
+            rc = p2plane_batch_share(g.stream, g.d_desc, B, M, ds_bound);
+            if (rc == LIO_OK) rc = scan_begin_rows(g.stream, g.d_desc + B, B * (M - 1));
+            if (rc != LIO_OK) return rc;
+            return p2plane_batch_update_joint(b->maps.data(), M, b->comm, b->world, g.stream, g.d_desc, B, ds_bound, 5, g.d_local32, g.d_gathered, bt);
+        }
         return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, bt, bt ? b->count_touched : 0);
     };
-    if (!b->use_graph || timed) return enqueue(timed ? g.bt : nullptr);
+    if (!b->use_graph || timed || b->joint) return enqueue(timed ? g.bt : nullptr);
     if (g.graph_table != b->map->table || g.graph_stencil != b->map->stencil.n) {
         for (int k = 0; k < 5; k++)
             if (g.exec[k]) { hipGraphExecDestroy(g.exec[k]); g.exec[k] = nullptr; }
@@ -198,8 +228,11 @@ __attribute__((constructor)) static void lio_default_hw_queues() { setenv("GPU_M
 
 extern "C" {
 
-lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds) {
-    if (!map || n_slots < 1 || n_slots > 64 || n_groups < 1 || n_groups > 8 || max_raw == 0 || max_ds == 0) { set_error("lio_batch_create: bad argument"); return nullptr; }
+static lio_batch* batch_create_impl(lio_map** maps, int n_maps, lio_comm* comm, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds) {
+    lio_map* map = n_maps > 0 && maps ? maps[0] : nullptr;
+    if (!map || n_maps > 64 || n_slots < 1 || n_slots > 64 || n_groups < 1 || n_groups > 8 || max_raw == 0 || max_ds == 0) { set_error("lio_batch_create: bad argument"); return nullptr; }
+    for (int m = 1; m < n_maps; m++)
+        if (!maps[m] || maps[m]->device != map->device) { set_error("lio_batch_create_joint: the sub-maps of a batch live on one device"); return nullptr; }
     if (hipSetDevice(map->device) != hipSuccess) { set_error("lio_batch_create: no HIP device %d", map->device); return nullptr; }
     lio_batch* b = new lio_batch();
     b->map = map;
@@ -207,25 +240,35 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
     b->n_slots = n_slots;
     b->max_raw = max_raw;
     b->max_ds = max_ds;
+    b->maps.assign(maps, maps + n_maps);
+    b->comm = comm;
+    b->world = comm ? lio_comm_world(comm) : 1;
+    b->joint = n_maps > 1 || comm != nullptr;
     b->groups.resize(n_groups);
     { const char* k = getenv("LIO_BATCH_GRAPH"); b->use_graph = (k && k[0] == '0') ? 0 : 1; }
     bool ok = true;
+    const int M = n_maps;
     // the groups' streams first: HIP deals streams to its few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) round robin in creation
     // order -- created after the ~B scan streams of the slots, two groups can land on one queue and their rounds run back to back
     for (Group& g : b->groups) ok = ok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess;
     for (Group& g : b->groups) {
         g.job_of_slot.assign(n_slots, -1);
-        g.block_bytes = (sizeof(SlotDesc) + sizeof(EskfDev)) * (size_t)n_slots;
+        const size_t desc_bytes = sizeof(SlotDesc) * (size_t)n_slots * (size_t)M;
+        g.block_bytes = desc_bytes + sizeof(EskfDev) * (size_t)n_slots;
         ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_block), g.block_bytes) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_block), g.block_bytes, hipHostMallocDefault) == hipSuccess;
         if (ok) {
             g.d_desc = reinterpret_cast<SlotDesc*>(g.d_block);
             g.h_desc = reinterpret_cast<SlotDesc*>(g.h_block);
-            g.d_ctrl = reinterpret_cast<EskfDev*>(g.d_block + sizeof(SlotDesc) * n_slots);
-            g.h_ctrl = reinterpret_cast<EskfDev*>(g.h_block + sizeof(SlotDesc) * n_slots);
+            g.d_ctrl = reinterpret_cast<EskfDev*>(g.d_block + desc_bytes);
+            g.h_ctrl = reinterpret_cast<EskfDev*>(g.h_block + desc_bytes);
         }
         ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_res), sizeof(lio_batch_result) * n_slots, hipHostMallocMapped) == hipSuccess;
         ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&g.h_res_dev), g.h_res, 0) == hipSuccess;
+        if (b->joint) {
+            ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_local32), sizeof(double) * 32 * n_slots) == hipSuccess;
+            ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_gathered), sizeof(double) * 32 * n_slots * (size_t)b->world) == hipSuccess;
+        }
         if (!ok) break;
         memset(g.h_block, 0, g.block_bytes);
         memset(g.h_res, 0, sizeof(lio_batch_result) * n_slots);
@@ -236,6 +279,20 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
             lio_engine_set_flags(e, 1, 0, 0.0, -10.0);
             g.eng.push_back(e);
             fill_desc(g.h_desc[s], lio_engine_scan(e), &g.d_ctrl[s], &g.h_res_dev[s]);
+        }
+        for (int m = 1; m < M && ok; m++)
+            for (int s = 0; s < n_slots && ok; s++) {
+                lio_engine* e = lio_engine_create_shared(maps[m], max_raw, max_ds);
+                if (!e) { ok = false; break; }
+                lio_engine_set_flags(e, 1, 0, 0.0, -10.0);
+                g.sub_eng.push_back(e);
+                fill_desc(g.h_desc[(size_t)m * n_slots + s], lio_engine_scan(e), &g.d_ctrl[s], nullptr);
+            }
+        // the host-driven joint path behind every slot (lio_engine_set_joint): takes over the rare scan whose pass needs the degeneracy sums
+        for (int s = 0; s < n_slots && ok && b->joint; s++) {
+            std::vector<lio_engine*> others;
+            for (int m = 1; m < M; m++) others.push_back(g.sub_eng[(size_t)(m - 1) * n_slots + s]);
+            ok = lio_engine_set_joint(g.eng[s], others.empty() ? nullptr : others.data(), (int)others.size(), comm) == LIO_OK;
         }
     }
     if (!ok) {
@@ -249,6 +306,14 @@ lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t ma
             set_error("lio_batch_create: GPU_MAX_HW_QUEUES=%s -- with fewer than 8 hardware queues the %d rounds in flight mostly serialise (~20 %% slower)", q, n_groups);
     }
     return b;
+}
+
+lio_batch* lio_batch_create(lio_map* map, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds) {
+    return batch_create_impl(&map, map ? 1 : 0, nullptr, n_slots, n_groups, max_raw, max_ds);
+}
+
+lio_batch* lio_batch_create_joint(lio_map** sub_maps, int n_sub_maps, lio_comm* comm, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds) {
+    return batch_create_impl(sub_maps, n_sub_maps, comm, n_slots, n_groups, max_raw, max_ds);
 }
 
 void lio_batch_destroy(lio_batch* b) {
@@ -335,6 +400,24 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
                 continue;
             }
             if (r.status == EK_SKIPPED) { job.rc = 2; continue; }  // fewer than five downsampled points
+            if (r.status == EK_NEEDS_HOST && b->joint) {
+                // a pass of this scan needs the degeneracy sums of laserMapping.cpp:946-964, which live on several sub-maps / ranks: the scan is
+                // registered again by the host-driven joint path of the slot's engines (every rank takes this branch for the same jobs in the
+                // same order: the decision was made from the gathered sums)
+                if (!(job.flags & LIO_JOB_KEEP_CACHE)) {
+                    scan_forget_cache(sc);
+                    for (int m = 1; m < (int)b->maps.size(); m++) scan_forget_cache(lio_engine_scan(g.sub_eng[(size_t)(m - 1) * B + s]));
+                }
+                double st26[26], cov[529];
+                memcpy(st26, job.state_in, sizeof(st26));
+                memcpy(cov, job.cov_in, sizeof(cov));
+                const int rc = engine_joint_register_device(e, job.d_raw, job.n_raw, job.lidar_beg_time, st26, cov);
+                if (rc < 0) { job.rc = rc; note(rc); continue; }
+                engine_count_passes(e, &job.n_pass, &job.n_knn_pass);
+                if (job.state_out) memcpy(job.state_out, st26, sizeof(st26));
+                job.rc = rc;
+                continue;
+            }
             if (r.status == EK_NEEDS_HOST) {
                 // a pass with 1 <= N_eff < 23: the dense gain of esekfom.hpp:1715-1744 needs the rows -- the host filter takes over from
                 // that pass on, through the per-pass path of the slot's engine (same scan buffers, same neighbour cache and gates)

@@ -178,6 +178,12 @@ int lio_comm_stats(lio_comm* c, uint64_t* n_collectives, double* total_us) {
 
 }  // extern "C"
 
+namespace lio {
+int lio_allgather_records_internal(::lio_comm* c, const double* d_local, double* d_gathered, uint32_t n_records, hipStream_t st) {
+    return lio_allgather_records(c, d_local, d_gathered, n_records, st);
+}
+}  // namespace lio
+
 // host records (the host-driven filter loop of a joint registration has its sums on the host): n <= 32 doubles in, the fixed-order sum
 // over ranks out.  A rank that failed locally still takes part (the caller hands in NaNs: every rank then sees NaN sums and gives the
 // registration up in the same pass -- nobody is left waiting in a collective).

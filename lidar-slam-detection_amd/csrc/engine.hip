@@ -476,6 +476,9 @@ int engine_resume_update_impl(lio_engine* e, const double* x_now26, const double
     e->kf.update_iterated_from(w, i, converge != 0, t, e->laser_cov, measure, on_pass, &ctx);
     return ctx.rc;
 }
+int engine_joint_register_device(lio_engine* e, const void* d_raw, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]) {
+    return lio_engine_joint_register_device(e, d_raw, n_raw, lidar_beg_time, state26, cov);
+}
 void engine_count_passes(lio_engine* e, int* n_pass, int* n_knn) {
     *n_pass = e->tm.n_pass;
     *n_knn = e->tm.n_knn_pass;
@@ -650,7 +653,7 @@ int lio_engine_set_joint(lio_engine* e, lio_engine** others, int n_others, lio_c
 
 // one joint registration: the same cloud to every local engine (each downsamples it into its own scan buffers), then the driving engine's
 // per-scan body with the joint reduce step.  state26 / cov: prior in, posterior out (identical on every rank of the communicator).
-int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]) {
+static int joint_register_impl(lio_engine* e, const void* raw, bool on_device, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]) {
     if (!e || !e->joint || !state26 || !cov) return LIO_E_INVALID;
     JointCtx* j = e->joint;
     j->knn_seen = 0;
@@ -668,18 +671,24 @@ int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_
         if (o->leaf_surf != e->leaf_surf || o->scan->device != e->scan->device) j->share_ds = false;
     if (!j->share_ds)
         for (lio_engine* o : j->others) {
-            int rc = lio_scan_upload(o->scan, raw_body_xyzi, n_raw);
+            int rc = on_device ? lio_scan_set_device(o->scan, raw, n_raw) : lio_scan_upload(o->scan, static_cast<const float*>(raw), n_raw);
             if (rc == LIO_OK) rc = lio_scan_voxel_downsample(o->scan, o->leaf_surf, 1, nullptr);
             if (rc != LIO_OK) return rc;
         }
     lio_engine_set_state(e, state26);
     lio_engine_set_cov(e, cov);
-    const int rc = lio_engine_process_scan(e, raw_body_xyzi, n_raw, lidar_beg_time);
+    const int rc = on_device ? lio_engine_process_scan_device(e, raw, n_raw, lidar_beg_time) : lio_engine_process_scan(e, static_cast<const float*>(raw), n_raw, lidar_beg_time);
     j->share_ds = false;
     if (j->rc != LIO_OK) return j->rc;
     lio_engine_get_state(e, state26);
     lio_engine_get_cov(e, cov);
     return rc;
+}
+int lio_engine_joint_register(lio_engine* e, const float* raw_body_xyzi, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]) {
+    return joint_register_impl(e, raw_body_xyzi, false, n_raw, lidar_beg_time, state26, cov);
+}
+int lio_engine_joint_register_device(lio_engine* e, const void* d_raw_body_xyzi, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]) {
+    return joint_register_impl(e, d_raw_body_xyzi, true, n_raw, lidar_beg_time, state26, cov);
 }
 
 int lio_engine_set_static_map(lio_engine* e, int on) {

@@ -93,9 +93,10 @@ struct EskfDev {
     int32_t n_pass, n_knn;  // measurement evaluations so far / of those with a neighbour search
     int32_t n_log;
     int32_t n_eff_last;
-    int32_t reuse_hint;     // the iterate has moved little since the pose of the last neighbour search (knn.hip: worth trying the re-search short cut)
+    int32_t joint;          // the sums handed to the filter are joint ones (several sub-maps / ranks, lio_batch's joint mode): the rows of a pass
+                            // live on different GPUs, so a pass with N_eff < 23 uses the information form too (as the host filter does behind
+                            // a reduce hook) and a pass that needs the degeneracy sums is handed to the host-driven joint path
     double prev_HTH[36], prev_HTh[6];
-    double x_search[7];     // position and attitude the last neighbour search ran at
     EkPassLog log[kEkMaxPass];
 };
 
@@ -514,10 +515,7 @@ EK_FN void ek_measure_head(EskfDev& c, EkWork& w, const double acc29[29], int kn
         for (int k = 0; k < 6; k++) pl.Jtr[k] = 0;
         for (int k = 0; k < 23; k++) pl.dx[k] = 0;
         c.n_pass++;
-        if (knn_this_pass) {
-            c.n_knn++;
-            for (int k = 0; k < 7; k++) c.x_search[k] = c.x[k];
-        }
+        if (knn_this_pass) c.n_knn++;
         c.n_eff_last = n_eff;
         w.flag[0] = 0; w.flag[1] = 0; w.flag[3] = 0; w.flag[4] = n_eff; w.flag[5] = 0;
         if (n_eff >= 1) {
@@ -610,7 +608,7 @@ EK_FN void ek_measure_tail(EskfDev& c, EkWork& w) {
                 }
             }
             w.flag[3] = degenerate ? 1 : 0;
-            if (w.flag[4] < kEkN) {
+            if (w.flag[4] < kEkN && !c.joint) {
                 // the dense branch of the filter (esekfom.hpp:1715-1744) needs the rows themselves: the host takes over from this pass
                 w.flag[5] = 1;
                 c.status = EK_NEEDS_HOST;
@@ -737,13 +735,6 @@ EK_FN void ek_step_solve(EskfDev& c, EkWork& w) {
         c.converge = converge ? 1 : 0;
         w.flag[2] = (c.t > 1 || c.i == c.maximum_iter - 1) ? 1 : 0;
         c.i++;
-        // has the iterate stayed within a fifth of a 0.5 m voxel (position; attitude: at 50 m) of the pose the neighbours were found at?
-        // Only a hint for the next search (its short cut checks every query exactly): far away, no query is worth the check.
-        double dmax = 0.0;
-        for (int k = 0; k < 3; k++) dmax = fmax(dmax, fabs(c.x[k] - c.x_search[k]));
-        double qmax = 0.0;
-        for (int k = 3; k < 7; k++) qmax = fmax(qmax, fabs(c.x[k] - c.x_search[k]));
-        c.reuse_hint = (dmax < 0.1 && qmax < 0.001) ? 1 : 0;
     }
     EK_SYNC();
     EK_STAMP(18);
@@ -796,7 +787,7 @@ EK_FN void ek_begin(EskfDev& c) {
     EK_FOR(k, kEkN * kEkN) c.P_prop[k] = c.P[k];
     if (EK_LANE(0)) {
         c.i = -1; c.t = 0; c.converge = 1; c.status = EK_RUNNING; c.have_prev = 0; c.prev_rows = 0;
-        c.n_pass = 0; c.n_knn = 0; c.n_log = 0; c.n_eff_last = 0; c.reuse_hint = 0;
+        c.n_pass = 0; c.n_knn = 0; c.n_log = 0; c.n_eff_last = 0;
     }
     EK_SYNC();
 }

@@ -426,7 +426,11 @@ __global__ void __launch_bounds__(256) degeneracy_kernel(const ScanDev* __restri
 // convergence flags (eskf_dev.h).  A slot that finishes publishes its result record in mapped host memory.
 constexpr int kStepThreads = 1024;
 
-__global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __restrict__ slots) {
+// JOINT (lio_batch's joint mode): the 29 sums of this pass are not the slot's own -- every rank's record of this slot (its sub-maps' sums,
+// folded by joint_fold_batch, all-gathered) is added in RANK ORDER, the same order on every rank: identical bits, identical filter steps.
+template <bool JOINT>
+__global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __restrict__ slots, const double* __restrict__ gathered, int world,
+                                                           uint32_t n_slots) {
     const SlotDesc& d = slots[blockIdx.x];
     if (!d.active) return;
     EskfDev& cg = *d.ctrl;
@@ -455,11 +459,20 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         static_assert(kCoreWords <= 2 * kStepThreads, "filter core: two words per thread");
         double s = 0.0;
         const int comp = tid >> 5, l = tid & 31;
-        if (!skip && comp < kAcc)
-            for (uint32_t b = l; b < nb; b += 32) s += d.partial[(size_t)b * kAcc + comp];
+        if constexpr (JOINT) {
+            if (!skip && tid < kAcc) {  // sum_ranks_kernel's order (comm.hip): rank 0's record, then + rank 1's, ...
+                s = gathered[(size_t)blockIdx.x * 32 + tid];
+                for (int r = 1; r < world; r++) s += gathered[((size_t)r * n_slots + blockIdx.x) * 32 + tid];
+            }
+        } else {
+            if (!skip && comp < kAcc)
+                for (uint32_t b = l; b < nb; b += 32) s += d.partial[(size_t)b * kAcc + comp];
+        }
         if (k0 < kCoreWords) dst[k0] = v0;
         if (k1 < kCoreWords) dst[k1] = v1;
-        if (!skip) {
+        if constexpr (JOINT) {
+            if (!skip && tid < kAcc) acc[tid] = s;
+        } else if (!skip) {
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
             if (comp < kAcc && l == 0) acc[comp] = s;
@@ -475,13 +488,24 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         if (tid == 0) c.status = EK_SKIPPED;
     } else if (tid < 64) {
         ek_measure_head(c, w, acc, c.converge);
-        if (!w.flag[1]) ek_measure_tail(c, w);  // the usual case: no degeneracy sums needed, everything about the measurement is settled here
+        if constexpr (JOINT) {
+            // the six degeneracy sums of a joint registration live on several sub-maps and ranks: such a pass (rare: the eigenvalue bound of the
+            // GLOBAL sum n n^T did not decide) is left to the host-driven joint path -- every rank reaches this decision from the same bits
+            if (w.flag[1]) {
+                if (tid == 0) { c.status = EK_NEEDS_HOST; c.n_pass--; if (c.converge) c.n_knn--; w.flag[0] = 0; w.flag[5] = 1; }
+                EK_SYNC();
+            } else {
+                ek_measure_tail(c, w);
+            }
+        } else {
+            if (!w.flag[1]) ek_measure_tail(c, w);  // the usual case: no degeneracy sums needed, everything about the measurement is settled here
+        }
     } else if (tid < 128) {
         ek_step_prep(c, w);
     }
     __syncthreads();
     EK_STAMP(2);
-    if (!skip && w.flag[1]) {  // the six degeneracy sums (laserMapping.cpp:946-964): every addend is a float in (0.1736, 1] widened to double,
+    if (!JOINT && !skip && w.flag[1]) {  // the six degeneracy sums (laserMapping.cpp:946-964): every addend is a float in (0.1736, 1] widened to double,
                                // sums of < 2^17 of them are exact in f64 -> any reduction order gives the same bits
         double s6[6] = {0, 0, 0, 0, 0, 0};
         for (uint32_t i = tid; i < n; i += kStepThreads) {
@@ -555,6 +579,101 @@ extern "C" int lio_debug_step_trace(unsigned long long* out64, int reset) {
 }
 #endif
 
+// ---- joint mode of the batched engine: a scan is registered against SEVERAL sub-maps (M on this GPU, more on other ranks) at once ------------
+// Descriptors are laid out [sub-map][slot]; row 0 is the slot's own scan buffers (the cloud is downsampled there), rows 1 .. M-1 are further
+// scan buffer sets (own neighbour cache, gates, partial sums) that share the slot's filter block (pose, loop state).
+
+// the slot's downsampled cloud and size to the other sub-maps' scan buffers (blockIdx.y = (m - 1) * B + slot), device to device
+__global__ void __launch_bounds__(256) share_ds_batch(const SlotDesc* __restrict__ descs, uint32_t n_slots) {
+    const uint32_t slot = blockIdx.y % n_slots, m = 1u + blockIdx.y / n_slots;
+    const SlotDesc& src = descs[slot];
+    const SlotDesc& dst = descs[(size_t)m * n_slots + slot];
+    if (!src.active) return;
+    const uint32_t n = src.sd->n_ds;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst.ds_body[i] = src.ds_body[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        dst.sd->n_ds_prev = dst.sd->cache_n;  // what vg_keys does for the slot's own buffers: the neighbour cache's size before this scan
+        dst.sd->n_ds = n;
+        dst.sd->err = src.sd->err;
+        dst.sd->n_tie = 0;
+    }
+}
+
+// per slot: the partial sums of every local sub-map's linearisation folded exactly as finalize_kernel / step_batch fold them (component c is
+// owned by 32 lanes: stride-32 chunks, fixed xor tree), then added in sub-map order -- what the host-driven joint path (engine.hip:
+// joint_reduce) forms from the sub-maps' reports -- into the rank's 32-double record of the slot; zeros for a slot that is idle or done
+__global__ void __launch_bounds__(1024) joint_fold_batch(const SlotDesc* __restrict__ descs, uint32_t n_slots, int n_maps, double* __restrict__ local32) {
+    const uint32_t slot = blockIdx.x;
+    const SlotDesc& d0 = descs[slot];
+    const int tid = threadIdx.x, comp = tid >> 5, l = tid & 31;
+    double total = 0.0;
+    bool run = d0.active != 0;
+    if (run) {
+        const EskfDev* c = d0.ctrl;
+        const uint32_t n = d0.sd->n_ds;
+        run = c->status == EK_RUNNING && !((d0.sd->err & 1u) || n < d0.min_ds);
+        if (run) {
+            const uint32_t nb = (n + kLinThreads - 1) / kLinThreads;
+            for (int m = 0; m < n_maps; m++) {
+                const SlotDesc& d = descs[(size_t)m * n_slots + slot];
+                double s = 0.0;
+                if (comp < kAcc)
+                    for (uint32_t b = l; b < nb; b += 32) s += d.partial[(size_t)b * kAcc + comp];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                total = m == 0 ? s : total + s;
+                if (m > 0 && tid == 0) d.sd->n_tie = 0;  // this pass's tie queue of the sub-map has been served (step_batch re-arms row 0's)
+            }
+        }
+    }
+    if (comp < 32 && l == 0) local32[(size_t)slot * 32 + comp] = (run && comp < kAcc) ? total : 0.0;
+}
+
+int p2plane_batch_share(hipStream_t st, const SlotDesc* d_descs, int n_slots, int n_maps, uint32_t ds_bound) {
+    if (n_maps <= 1) return LIO_OK;
+    uint32_t bx = (ds_bound + 255u) / 256u;
+    if (bx > 64u) bx = 64u;
+    if (bx == 0) bx = 1;
+    hipLaunchKernelGGL(share_ds_batch, dim3(bx, (uint32_t)(n_slots * (n_maps - 1))), 256, 0, st, d_descs, (uint32_t)n_slots);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+// one pass per loop turn: {neighbour search where the filter asks for it, linearisation} against every local sub-map, the rank's records, the
+// all-gather across ranks (comm.hip; a world of one gathers nothing), the filter pass on the rank-ordered sums.  Enqueued blind, eagerly (no
+// graph: a collective sits in the middle of every pass).
+int lio_allgather_records_internal(::lio_comm* c, const double* d_local, double* d_gathered, uint32_t n_records, hipStream_t st);  // comm.hip
+int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
+                               int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt) {
+    uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
+    if (lin_blocks == 0) lin_blocks = 1;
+    for (int p = 0; p < n_passes; p++) {
+        for (int m = 0; m < n_maps; m++) {
+            const SlotDesc* row = d_descs + (size_t)m * n_slots;
+            if (bt) bt->begin(1);
+            const int rc = knn_batch_launch(maps[m], st, row, n_slots, (ds_bound + 15) / 16, 0);
+            if (bt) bt->end(1);
+            if (rc != LIO_OK) return rc;
+            if (bt) bt->begin(2);
+            hipLaunchKernelGGL(linearize_batch, dim3(lin_blocks, (uint32_t)n_slots), kLinThreads, 0, st, row);
+            if (bt) bt->end(2);
+        }
+        if (bt) bt->begin(3);
+        hipLaunchKernelGGL(joint_fold_batch, dim3((uint32_t)n_slots), 1024, 0, st, d_descs, (uint32_t)n_slots, n_maps, d_local32);
+        LIO_HIP_TRY(hipGetLastError());
+        const double* sums = d_local32;
+        if (comm && world > 1) {
+            const int rc = lio_allgather_records_internal(comm, d_local32, d_gathered, (uint32_t)n_slots, st);
+            if (rc != LIO_OK) return rc;
+            sums = d_gathered;
+        }
+        hipLaunchKernelGGL((step_batch<true>), dim3((uint32_t)n_slots), kStepThreads, 0, st, d_descs, sums, world, (uint32_t)n_slots);
+        if (bt) bt->end(3);
+    }
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
 // the whole iterated update of every slot, enqueued blind: (neighbour search if the filter asks for it, linearisation, filter pass) x
 // (maximum_iter + 1); slots that converge early skip the rest of the launches
 int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int count_touched) {
@@ -569,7 +688,7 @@ int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, in
         if (bt) bt->begin(2);
         hipLaunchKernelGGL(linearize_batch, dim3(lin_blocks, (uint32_t)n_slots), kLinThreads, 0, st, d_slots);
         if (bt) { bt->end(2); bt->begin(3); }
-        hipLaunchKernelGGL(step_batch, dim3((uint32_t)n_slots), kStepThreads, 0, st, d_slots);
+        hipLaunchKernelGGL((step_batch<false>), dim3((uint32_t)n_slots), kStepThreads, 0, st, d_slots, static_cast<const double*>(nullptr), 1, (uint32_t)n_slots);
         if (bt) bt->end(3);
     }
     LIO_HIP_TRY(hipGetLastError());

@@ -636,6 +636,15 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
     return LIO_OK;
 }
 
+// Nearest_Points.resize / forget for the further sub-map rows of a joint batch (their buffers receive the slot's downsampled cloud from
+// share_ds_batch instead of running the chain themselves)
+int scan_begin_rows(hipStream_t st, const SlotDesc* d_descs, int n_rows) {
+    if (n_rows <= 0) return LIO_OK;
+    hipLaunchKernelGGL(scan_begin_batch, dim3(16, (uint32_t)n_rows), 256, 0, st, d_descs);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
 int scan_begin(lio_scan* s) {
     hipLaunchKernelGGL(scan_begin_kernel, 64, 256, 0, s->stream, s->dev, s->nn_cnt, s->resize_min);
     LIO_HIP_TRY(hipGetLastError());

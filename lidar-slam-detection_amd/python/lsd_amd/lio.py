@@ -413,6 +413,13 @@ class Engine:
                    "joint_register")
         return rc, s, P.reshape(23, 23)
 
+    def joint_register_device(self, dptr, n, lidar_beg_time, state, cov):
+        """lio_engine_joint_register_device: the cloud is already resident on the GPU"""
+        s, P = f64(state).copy(), f64(cov).reshape(-1).copy()
+        rc = check(lib().lio_engine_joint_register_device(self.h, C.c_void_p(dptr), n, float(lidar_beg_time), ptr(s, C.c_double), ptr(P, C.c_double)),
+                   "joint_register_device")
+        return rc, s, P.reshape(23, 23)
+
     def set_static_map(self, on=True):
         check(lib().lio_engine_set_static_map(self.h, int(on)))
 
@@ -700,10 +707,18 @@ class Comm:
 class Batch:
     """throughput mode, batched (lio_batch_*): B scans per launch against one resident static map, filter loop on the device"""
 
-    def __init__(self, shared_map, n_slots=8, n_groups=3, max_raw=262144, max_ds=100000):
+    def __init__(self, shared_map, n_slots=8, n_groups=3, max_raw=262144, max_ds=100000, sub_maps=None, comm=None):
+        """sub_maps / comm: the joint mode (lio_batch_create_joint) -- every job is registered against `shared_map` AND the further `sub_maps`
+        resident on this GPU and, through `comm` (lio.Comm), against the sub-maps the other ranks hold; every rank submits the same job list"""
         self.map = shared_map
         self.n_slots, self.n_groups = n_slots, n_groups
-        self.h = lib().lio_batch_create(shared_map.h, n_slots, n_groups, max_raw, max_ds)
+        self._keep = (list(sub_maps or []), comm)
+        if sub_maps or comm is not None:
+            ms = [shared_map] + list(sub_maps or [])
+            hs = (C.c_void_p * len(ms))(*[m.h for m in ms])
+            self.h = lib().lio_batch_create_joint(hs, len(ms), comm.h if comm is not None else None, n_slots, n_groups, max_raw, max_ds)
+        else:
+            self.h = lib().lio_batch_create(shared_map.h, n_slots, n_groups, max_raw, max_ds)
         if not self.h:
             raise capi.LioError("lio_batch_create failed: " + lib().lio_last_error().decode())
 

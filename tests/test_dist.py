@@ -137,3 +137,117 @@ def test_native_allgather_device_buffers():
     g = np.zeros(32)
     assert hip_rt.hipMemcpy(g.ctypes.data_as(C.c_void_p), C.c_void_p(d_g), 256, 2) == 0
     assert np.array_equal(g, local)
+
+
+@pytest.mark.gpu
+def test_batched_joint_registration_equals_single_joint_registrations():
+    """lio_batch's joint mode (B scans per launch, the sub-maps' sums folded on the device, ONE [B x 32]-double gather per pass, filter loop on
+    the device) against B single lio_engine_joint_register calls (host-driven loop, a hand-over per pass) on the same three sub-maps: same
+    pass / search counts, states within the device-vs-host filter bar (1e-9; the two loops share eskf_dev.h, the libm calls differ) -- with
+    and without a communicator of one rank, and bit-identical between those two and between repeated calls."""
+    sys.path.insert(0, HERE)
+    import scenes
+    from _dist_worker import make_world
+    from lsd_amd import lio, synth
+
+    subs, raw0, state0, true_pos, true_q = make_world(3)
+    scene = synth.Scene(half=40.0, n_boxes=12, seed=21)
+    # a few key-frame scans from other poses, each with its own prior
+    scans = [(raw0, state0, true_pos)]
+    for k in range(1, 7):
+        pos = np.array([0.3 + 1.5 * k, 0.8 - 0.7 * k, 1.7])
+        q = synth.quat_from_rotvec([0, 0, 0.2 + 0.3 * k])
+        raw, _ = synth.make_scan(scene, pos, q, seed=230 + k, n_az=300)
+        gp, gq = synth.perturb_pose(pos, q, seed=240 + k, max_t=0.15, max_deg=1.0)
+        scans.append((raw, synth.state_from_pose(gp, gq), pos))
+    P0 = lio.init_cov()
+    maps = []
+    for sub in subs:
+        m = lio.Map(resolution=0.5, stencil=19, max_points=400_000, max_voxels=200_000)
+        m.add(sub)
+        maps.append(m)
+    # the single-scan joint path: engines sharing the three maps
+    engs = [lio.Engine(max_raw=1 << 17, max_ds=1 << 16, shared_map=m) for m in maps]
+    for e in engs:
+        e.set_flags(ekf_inited=True, first_scan=False, first_lidar_time=-10.0)
+    engs[0].set_joint(engs[1:], None)
+    want = []
+    for raw, st, _ in scans:
+        for e in engs:
+            e.scan.reset()
+        rc, s, P = engs[0].joint_register(raw, 1.0, st, P0)
+        assert rc == 3
+        tm = engs[0].timings()
+        want.append((s, tm["n_pass"], tm["n_knn_pass"]))
+    jobs = [dict(dptr=scenes.to_device(raw), n=len(raw), t=1.0, state=st, cov=P0) for raw, st, _ in scans]
+    outs = []
+    for comm in (None, lio.Comm(rank=0, world=1)):
+        b = lio.Batch(maps[0], n_slots=3, n_groups=2, max_raw=1 << 17, max_ds=1 << 16, sub_maps=maps[1:], comm=comm)
+        rc, res = b.process(jobs)
+        assert rc == 0
+        rc2, res2 = b.process(jobs[::-1])  # other slots, other histories: independent jobs
+        assert rc2 == 0
+        for r, r2, (s, n_pass, n_knn), (_, _, pos) in zip(res, res2[::-1], want, scans):
+            assert r["rc"] == 3 and (r["n_pass"], r["n_knn_pass"]) == (n_pass, n_knn), (r, n_pass, n_knn)
+            assert np.abs(r["state"] - s).max() < 1e-9
+            assert np.array_equal(r["state"], r2["state"])
+            assert np.linalg.norm(r["state"][:3] - pos) < 0.05
+        outs.append(res)
+        del b
+    for a, c in zip(*outs):
+        assert np.array_equal(a["state"], c["state"])
+
+
+@pytest.mark.gpu
+def test_batched_joint_registration_degenerate_scene_falls_back_to_the_host_path():
+    """open ground: the eigenvalue bound of the GLOBAL sum n n^T does not decide, the six degeneracy sums are needed -- they live on several
+    sub-maps, so the batched joint mode hands the scan to the host-driven joint path of the slot's engines: the result IS lio_engine_joint_register's"""
+    sys.path.insert(0, HERE)
+    import scenes
+    from lsd_amd import lio
+
+    case = scenes.degenerate_case("open_ground")
+    mp = case["map"]
+    halves = [np.ascontiguousarray(mp[mp[:, 0] < 1.0]), np.ascontiguousarray(mp[mp[:, 0] >= -1.0])]
+    maps = []
+    for sub in halves:
+        m = lio.Map(resolution=0.5, stencil=19, max_points=400_000, max_voxels=200_000)
+        m.add(sub)
+        maps.append(m)
+    P0 = lio.init_cov()
+    engs = [lio.Engine(max_raw=1 << 17, max_ds=1 << 16, shared_map=m) for m in maps]
+    for e in engs:
+        e.set_flags(ekf_inited=True, first_scan=False, first_lidar_time=-10.0)
+    engs[0].set_joint(engs[1:], None)
+    rc, s, P = engs[0].joint_register(case["raw"], 1.0, case["guess"], P0)
+    assert rc == 3 and engs[0].is_degenerate
+    b = lio.Batch(maps[0], n_slots=2, n_groups=1, max_raw=1 << 17, max_ds=1 << 16, sub_maps=maps[1:])
+    rcb, res = b.process([dict(dptr=scenes.to_device(case["raw"]), n=len(case["raw"]), t=1.0, state=case["guess"], cov=P0)] * 3)
+    assert rcb == 0
+    for r in res:
+        assert r["rc"] == 3 and np.array_equal(r["state"], s)
+
+
+@pytest.mark.parametrize("config,world", [("merge", 2), ("merge", 4), ("metric", 2)])
+def test_bench_multi_gpu_launch_dry_run(config, world):
+    """`bench.py --gpus N [--config merge] --dry-run` under torch.distributed.run, as the driver launches it, on the CPU: rendezvous, the sharding
+    of sub-maps / scans over the ranks, the RCCL unique id made by rank 0 (librccl loaded lazily, no device needed) and shipped to the others"""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(31500 + (os.getpid() + world) % 2000), os.path.join(root, "bench.py"), "--gpus", str(world), "--config", config, "--dry-run"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1  # rank 0 alone prints
+    j = json.loads(line[0])
+    assert j["dry_run"] and j["n_gpus"] == world and j["rccl_unique_id_exchanged"] is True and len(j["ranks"]) == world
+    if config == "merge":
+        owned = sorted(k for rk in j["ranks"] for k in rk["sub_maps"])
+        assert owned == list(range(8)) and all(len(rk["sub_maps"]) == 8 // world for rk in j["ranks"])
+        assert len({rk["first_guess_digest"] for rk in j["ranks"]}) == 1  # every rank registers the same key frames from the same priors
+    else:
+        seeds = [tuple(rk["scan_seeds"]) for rk in j["ranks"]]
+        assert len(set(seeds)) == world  # weak scaling: every rank its own scans
