@@ -676,7 +676,7 @@ def stream_run(args, torch, local_rank):
         b_ins = (16.0 * insert_leg["n_ds"] + 32.0 * insert_leg["n_added"]) / ns      # B_ins = 16 N_ds (read) + (16 + 16) N_add
         us = insert_leg["insert_us"] / ns
         ach = b_ins / (us * 1e-6) / 1e9 if us > 0 else 0.0
-        roofline = {"bound": "latency", "kernel": "map_incremental chain (classify_kernel + classify_scatter_kernel + map_insert_* [+ lru_*])", "achieved": round(ach, 2),
+        roofline = {"bound": "hbm", "kernel": "map_incremental chain (classify_kernel + classify_scatter_kernel + map_insert_* [+ lru_*])", "achieved": round(ach, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes_per_launch": int(b_ins),
                     "avg_launch_us": round(us, 2), "launches": ns, "map_points_at_measurement": int(map_points),
                     "stage_us_per_scan": {k2: round(insert_leg[k2] / ns, 2) for k2 in ("undistort_us", "downsample_us", "knn_us", "linearize_us", "insert_us")},
@@ -838,7 +838,7 @@ def bench_localize(args, torch, local_rank):
         cases[name] = {"target_points": npts, "target_voxels": nvox, "target_build_ms": round(1e3 * t_build, 2), "ms_per_scan": round(1e3 * dt / args.steps, 4),
                        "points_per_s": round(n_raw * args.steps / dt, 1), "n_ds_avg": round(float(np.mean(nds)), 1), "lm_iterations_avg": round(float(np.mean(its)), 2),
                        "converged": conv, "pos_err_m_median": float(np.median(errs)), "pos_err_m_max": float(np.max(errs)), "rot_err_rad_median": float(np.median(angs)),
-                       "roofline": {"bound": "latency", "kernel": "ndt_cost_kernel<DIRECT7> (1 lane per source point: 7 voxel probes + P2D cost [+ H, b], f64 block reduce)",
+                       "roofline": {"bound": "hbm", "kernel": "ndt_cost_kernel<DIRECT7> (1 lane per source point: 7 voxel probes + P2D cost [+ H, b], f64 block reduce)",
                                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                                     "algorithmic_bytes_per_launch": int(b_alg), "avg_launch_us": round(us, 2), "launches": L,
                                     "evaluations_per_alignment": round(L / min(args.steps, 64), 2), "pairs_per_launch": round(kt["pairs"] / L, 1)}}

@@ -17,6 +17,7 @@ template <typename PointT>
 class KdTree : public Search<PointT> {
    public:
     using PointCloudConstPtr = typename Search<PointT>::PointCloudConstPtr;
+    using Ptr = std::shared_ptr<KdTree<PointT>>;
     static float& cell_size() { static float c = 1.0f; return c; }  // grid cell of the stand-in (any value gives the same answers)
     void setInputCloud(const PointCloudConstPtr& cloud) override {
         this->input_ = cloud;

@@ -2,8 +2,13 @@
 atan2f (closed-form eigen-solver), which differ in the last bits between libm and the GPU's OCML, so this path is compared
 with tolerances -- tight ones for the sums (the per-pair terms are otherwise the same IEEE operations), the north-star
 1e-4 m / 1e-5 rad for the aligned pose."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -153,63 +158,55 @@ def test_pose_estimator_loop_tracks_a_drive(scene):
     print("pose estimator loop: worst position error %.3f m, %d / 19 matches accepted" % (worst, n_ok))
 
 
-def test_local_map_assembly_on_device(oracle_mod, scene):
-    """Localization::runUpdateLocalMap with the key frames resident in HBM: selection (radius, nearest first, thinning, point
-    cap), VoxelGrid and target build -- the downsampled local map is bit-identical to the oracle's VoxelGrid of the same
-    concatenation, the matcher built from it aligns a scan, and the skip / out-of-map / far-key-frame branches fire"""
+def test_local_map_assembly_on_device(oracle_mod):
+    """Localization::runUpdateLocalMap with the key frames resident in HBM: selection (radius, nearest first, thinning, point cap), VoxelGrid and
+    target build against the REFERENCE'S OWN loop body (localization.cpp:305-312,325-372 cut out and compiled in oracle/ref_localmap.cpp; its
+    results on tests/localmap_cases.py are recorded in tests/golden/localmap.npz): same return code for every pose of the drive -- replaced /
+    nothing to do / replaced / out of map / nearest key frame too far -- and a downsampled local map that is bit-identical to the one the
+    reference's code hands its localizer (live against the harness when it travelled with the snapshot); the matcher built from it aligns a scan"""
+    import localmap_cases as lc
     from lsd_amd import capi, lio, synth
 
     if capi.lib().lio_device_count() < 1:
         pytest.fail("no HIP device visible")
-    rng = np.random.default_rng(3)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "localmap.npz"))
+    scene = lc.scene()
+    frames, poses = lc.key_frames(scene)
     lm = lio.LocalMap(max_total_points=6_000_000, max_local_points=200_000, max_keyframe_points=80_000)
-    frames, poses = [], []
-    for k in range(40):  # key frames every 2 m along x, clouds already in the map frame
-        pos = np.array([-40.0 + 2.0 * k, rng.uniform(-0.5, 0.5), 1.8])
-        q = synth.quat_from_rotvec([0, 0, rng.uniform(-0.2, 0.2)])
-        raw, _ = synth.make_scan(scene, pos, q, seed=100 + k, n_az=600, fov_deg=(-24.8, 2.0))
-        w = raw.copy()
-        w[:, :3] = (raw[:, :3].astype(np.float64) @ synth.quat_to_R(q).T + pos).astype(np.float32)
-        frames.append(w)
-        poses.append(pos.astype(np.float32))
-        assert lm.add_keyframe(w, pos) == k
+    for k, (w, p) in enumerate(zip(frames, poses)):
+        assert lm.add_keyframe(w, p) == k
     ndt = lio.Ndt(resolution=1.0, search_method=7, max_points=400_000, max_voxels=200_000, max_source_points=1 << 17)
-    pose = np.array([3.0, 0.2, 1.8])
-    rc, nk, npts = lm.update(ndt, pose, key_frame_distance=3.0, leaf=0.2)
-    assert rc == 1
-    # the reference's selection, restated: nearest first, skip key frames closer than key_frame_distance (in range) to the last taken
-    d = np.sqrt(((np.array(poses) - pose.astype(np.float32)) ** 2).sum(1).astype(np.float32))
-    order = [i for i in np.argsort(d, kind="stable") if d[i] ** 2 <= 900.0]
-    take, acc, total = [], 0.0, 0
-    for i in order:
-        if total and (d[i] - acc) < 3.0:
-            continue
-        acc = d[i]
-        take.append(i)
-        total += len(frames[i])
-        if total >= 200_000:
-            break
-    assert nk == len(take)
-    want = oracle_mod.voxel_downsample(np.concatenate([frames[i] for i in take]), 0.2)
-    got = lm.download()
-    assert npts == len(want) == len(got) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    # the target built from it localises a fresh scan
-    tq = synth.quat_from_rotvec([0, 0, 0.1])
-    raw, _ = synth.make_scan(scene, pose, tq, seed=999, n_az=900, fov_deg=(-24.8, 2.0))
-    src = lio.Scan(max_raw=1 << 18, max_ds=1 << 17)
-    src.upload(raw)
-    src.voxel_downsample(0.2)
-    T0 = np.eye(4)
-    T0[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0, 0, 0.12]))
-    T0[:3, 3] = pose + [0.15, -0.1, 0.02]
-    T, conv, it = ndt.align(src, T0)
-    assert conv and np.linalg.norm(T[:3, 3] - pose) < 0.05
-    # branches
-    assert lm.update(ndt, pose + [4.0, 0, 0])[0] == 0            # moved less than 10 m: nothing to do
-    assert lm.update(ndt, pose + [12.0, 0, 0], key_frame_distance=3.0)[0] == 1
-    assert lm.update(ndt, np.array([500.0, 0, 0]))[0] == 2        # no key frame within 30 m: out of map, target dropped
-    assert ndt.num_voxels == 0
-    assert lm.update(ndt, np.array([62.0, 0.0, 1.8]))[0] == 3     # nearest key frame 24 m away: target dropped
+    R = None
+    import ref_localmap
+
+    if ref_localmap.available():
+        R = ref_localmap.RefLocalMap(resolution=lc.LEAF, key_frame_distance=lc.KEY_FRAME_DISTANCE)
+        for w, p in zip(frames, poses):
+            R.add_keyframe(w, p)
+    for k, (pose, what) in enumerate(lc.LM_POSES):
+        rc, nk, npts = lm.update(ndt, np.array(pose), key_frame_distance=lc.KEY_FRAME_DISTANCE, leaf=lc.LEAF)
+        assert rc == g["codes"][k], (what, rc)
+        if rc == 1:
+            got = lm.download()
+            assert npts == len(got) and np.array_equal(lc.digest(got), g["digests"][k]), what
+        if rc in (2, 3):
+            assert ndt.num_voxels == 0, what  # the target is dropped (mLocalMap = nullptr handed to the localizer)
+        if R is not None:
+            assert R.update(pose) == rc, what
+            if rc == 1:
+                assert np.array_equal(R.local_map().view(np.uint32), lm.download().view(np.uint32)), what
+        if k == 0:  # the target built from the first local map localises a fresh scan
+            p0 = np.array(pose)
+            tq = synth.quat_from_rotvec([0, 0, 0.1])
+            raw, _ = synth.make_scan(scene, p0, tq, seed=999, n_az=900, fov_deg=(-24.8, 2.0))
+            src = lio.Scan(max_raw=1 << 18, max_ds=1 << 17)
+            src.upload(raw)
+            src.voxel_downsample(0.2)
+            T0 = np.eye(4)
+            T0[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0, 0, 0.12]))
+            T0[:3, 3] = p0 + [0.15, -0.1, 0.02]
+            T, conv, it = ndt.align(src, T0)
+            assert conv and np.linalg.norm(T[:3, 3] - p0) < 0.05
 
 
 def test_fitness_score_exact_nearest_neighbours(scene):
@@ -249,52 +246,42 @@ def test_fitness_score_exact_nearest_neighbours(scene):
     assert n_in == 0 and score > 1e300  # PCL: std::numeric_limits<double>::max()
 
 
-def test_overlap_score_of_the_map_merge_tools(scene):
-    """calc_fitness_score(cloud1, cloud2, relpose, max_range) (overlap_merge.hpp:206-263): both clouds through the range / floor filter
-    (the source AFTER the transform), exact nearest neighbours, mean squared distance of the inliers and their share -- against brute
-    force in the same f32 arithmetic"""
-    from lsd_amd import capi, lio, synth
+def test_overlap_score_of_the_map_merge_tools():
+    """calc_fitness_score(cloud1, cloud2, relpose, max_range): both clouds through the range / floor filter (the source AFTER the transform), exact
+    nearest neighbours, mean squared distance of the inliers and their share -- against the REFERENCE'S OWN filter + calc_fitness_score
+    (overlap_merge.hpp:213-263 cut out and compiled in oracle/ref_localmap.cpp, recorded in tests/golden/localmap.npz; live when the harness
+    travelled with the snapshot)"""
+    import localmap_cases as lc
+    from lsd_amd import capi, lio
 
     if capi.lib().lio_device_count() < 1:
         pytest.fail("no HIP device visible")
-    rng = np.random.default_rng(21)
-    cloud1 = scene.sample_surface(300_000, seed=33, sigma=0.01)
-    cloud1 = cloud1[np.linalg.norm(cloud1[:, :2], axis=1) < 120.0][:60_000]
-    cloud1[:, 2] += 1.0  # part of the cloud below the 0.5 m floor, part above
-    T = np.eye(4)
-    T[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0.0, 0.01, 0.2]))
-    T[:3, 3] = [2.0, -1.0, 0.05]
-    Ti = np.linalg.inv(T)
-    pick = cloud1[rng.choice(len(cloud1), 6000, replace=False)]
-    cloud2 = pick.copy()
-    cloud2[:, :3] = pick[:, :3] @ Ti[:3, :3].T + Ti[:3, 3] + rng.normal(0, 0.1, (6000, 3))
-    cloud2 = np.concatenate([cloud2, np.concatenate([rng.uniform(-150, 150, (800, 2)), rng.uniform(-2, 40, (800, 1)), np.zeros((800, 1))], 1)]).astype(np.float32)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "localmap.npz"))
+    cloud1, cloud2, T = lc.overlap_case()
     target = lio.overlap_filter(cloud1)
     assert 0 < len(target) < len(cloud1)
     ndt = lio.Ndt(resolution=1.0, search_method=7, max_points=len(target) + 1, max_voxels=200_000, max_source_points=1 << 16)
     ndt.set_target(target)
     scan = lio.Scan(max_raw=1 << 16, max_ds=1 << 16)
     scan.set_ds(cloud2)
-    Tf = T.astype(np.float32)
-    tp = np.stack([((Tf[r, 0] * cloud2[:, 0] + Tf[r, 1] * cloud2[:, 1]) + Tf[r, 2] * cloud2[:, 2]) + Tf[r, 3] for r in range(3)], 1)
-    kept = (np.sqrt(tp[:, 0] * tp[:, 0] + tp[:, 1] * tp[:, 1]) < np.float32(100.0)) & (tp[:, 2] > np.float32(0.5))
-    assert 0.3 * len(tp) < kept.sum() < len(tp)
-    tk = tp[kept]
-    best = np.full(len(tk), np.inf, np.float32)
-    for a in range(0, len(tk), 100):
-        d = tk[a:a + 100, None, :] - target[None, :, :3]
-        best[a:a + 100] = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).min(1)
-    for max_range in (1.0, 25.0, 4e-3, 1e-7):
-        inl = best <= np.float32(max_range)
+    import ref_localmap
+
+    n_inl = 0
+    for max_range, (want_score, want_ratio) in zip(g["ranges"], g["fitness"]):
         score, ratio = ndt.overlap_score(scan, T, max_range)
-        if inl.sum() == 0:
-            assert score > 1e300 and ratio == 0.0 and max_range < 1e-3
+        if want_ratio == 0.0:
+            assert score > 1e300 and ratio == 0.0
             continue
-        assert abs(ratio - inl.sum() / kept.sum()) < 1e-15
-        assert abs(score - best[inl].astype(np.float64).mean()) <= 1e-12 * max(1.0, score)
+        n_inl += 1
+        # the reference adds the f32 squared distances one by one in point order, the device in a fixed tree: the mean agrees to rounding
+        assert ratio == want_ratio and abs(score - want_score) <= 1e-12 * max(1.0, want_score), (max_range, score, want_score)
+        if ref_localmap.available():
+            ls, lr = ref_localmap.overlap_fitness(cloud1, cloud2, T, max_range)
+            assert (ls, lr) == (want_score, want_ratio)
+    assert n_inl >= 3
     # nothing survives the filter / nothing within range: (DBL_MAX, 0)
     up = cloud2.copy()
     up[:, 2] -= 100.0
     scan.set_ds(up)
     score, ratio = ndt.overlap_score(scan, T, 1.0)
-    assert score > 1e300 and ratio == 0.0
+    assert score > 1e300 and ratio == 0.0 and g["fitness_none"][0] > 1e300
