@@ -545,6 +545,7 @@ int lio_pose_estimator_match_gps_only(lio_pose_estimator*, const lio_gps_observa
 int lio_pose_estimator_get_timed_pose(lio_pose_estimator*, uint64_t stamp_us, const double acc_g[3], const double gyro_dps[3], double pose[16]);
 int lio_pose_estimator_predict_nostate(lio_pose_estimator*, uint64_t stamp_us, double pose[16]);
 int lio_pose_estimator_correct(lio_pose_estimator*, uint64_t stamp_us, const float observation[7]);
+uint64_t lio_pose_estimator_get_dt(lio_pose_estimator*);  /* get_dt() :389-391, us */
 int lio_pose_estimator_get(lio_pose_estimator*, float mean23[23], float cov529[529]);
 int lio_pose_estimator_set(lio_pose_estimator*, const float mean23[23], const float cov529[529]);
 int lio_pose_estimator_matrix(lio_pose_estimator*, float T[16]);

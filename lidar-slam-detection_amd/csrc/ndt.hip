@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(256) ndt_fitness_kernel(const Slot* __restrict
     uint32_t my_cnt = 0, my_kept = 0;
     bool keep = i < n;
     if (keep && xy_range > 0.f) {
-        // overlap_merge.hpp:196-204 `filter`, applied to the TRANSFORMED source (:237-239): sqrt(x^2 + y^2) < range && z > floor
+        // overlap_merge.hpp:213-223 `filter`, applied to the TRANSFORMED source (:237-239): sqrt(x^2 + y^2) < range && z > floor
         const float4 p = src[i];
         const float tx = ((X.R[0] * p.x + X.R[1] * p.y) + X.R[2] * p.z) + X.t[0];
         const float ty = ((X.R[3] * p.x + X.R[4] * p.y) + X.R[5] * p.z) + X.t[1];

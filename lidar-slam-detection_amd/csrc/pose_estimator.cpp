@@ -437,6 +437,13 @@ int lio_pose_estimator_predict(lio_pose_estimator* e, uint64_t stamp_us, const f
     return 1;
 }
 
+// PoseEstimator::get_dt (pose_estimator.cpp:389-391): the filter's current step, in us (the nodelet compensates the scan's motion over it)
+uint64_t lio_pose_estimator_get_dt(lio_pose_estimator* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lock(e->data_mutex);
+    return (uint64_t)(e->ukf.system.dt * 1000000);
+}
+
 // PoseEstimator::correct (pose_estimator.cpp:348-382): filter update, then the INS state queue is trimmed to the states after the
 // correction and re-predicted from the corrected mean
 int lio_pose_estimator_correct(lio_pose_estimator* e, uint64_t stamp_us, const float observation[7]) {

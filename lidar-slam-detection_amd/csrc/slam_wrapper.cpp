@@ -19,14 +19,21 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <fstream>
+#include <iomanip>
 #include <memory>
 #include <mutex>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -98,7 +105,42 @@ void rpy_from_transform(const Mat4& T, double& yaw, double& pitch, double& roll)
     roll = -r2 / kAng2Rad;
 }
 
+// ---- localisation mode (slam/localization): the state of Locate::Localization + the hdl_localization nodelet, over the C ABI ----
+struct KeyFrameDisk {  // one directory of <map>/graph: `data` (KeyFrame::save, slam/common/keyframe.cpp:118-133) + `cloud.pcd`
+    uint64_t stamp = 0;
+    int id = 0;
+    Mat4 odom = Mat4::identity();
+    std::vector<float> xyzi;   // in the map frame (KeyFrame::mTransfromPoints)
+    std::vector<float> local;  // as stored (KeyFrame::mPoints): what get_graph_map hands to map_manager.py
+};
+struct Loc {
+    std::vector<KeyFrameDisk> frames;
+    lio_localmap* lm = nullptr;
+    lio_ndt* ndt = nullptr;
+    lio_scan* scan = nullptr;
+    lio_pose_estimator* pe = nullptr;
+    lio_ndt_params par;
+    double resolution = 0.2, key_frame_distance = 1.0;
+    bool have_init_pose = false, initialized = false, have_map = false;
+    Mat4 init_pose = Mat4::identity(), last_odom = Mat4::identity();
+    uint64_t init_stamp = 0;
+    int age = 0, failures = 0;          // mLocalizationAge / mFailureCounter (localization.cpp:235-275)
+    std::deque<std::pair<uint64_t, Mat4>> pose_data;  // HdlLocalizationNodelet::pose_data (<= 10)
+    struct Imu { double stamp; float acc[3], gyr[3]; };
+    std::vector<Imu> imu_data;
+    std::vector<uint32_t> stamps;
+    std::vector<float> staged;
+    ~Loc() {
+        if (pe) lio_pose_estimator_destroy(pe);
+        if (lm) lio_localmap_destroy(lm);
+        if (ndt) lio_ndt_destroy(ndt);
+        if (scan) lio_scan_destroy(scan);
+    }
+};
+
 struct Slam {
+    std::unique_ptr<Loc> loc;
+    std::string map_path;
     std::string mode, method;
     std::vector<std::string> sensors;
     std::string lidar;
@@ -119,6 +161,11 @@ struct Slam {
     bool origin_set = false;
     bool ground_constraint = false, loop_closure = false, gravity_constraint = false, colouration = false;
     py::dict ins_config;
+    // SLAM::setInsConfig / preprocessInsData (slam.cpp:196-268): the GNSS status configurations in priority order, the state of the status filter
+    struct InsCfg { std::string name; int status = 0, priority = -1; double stable_time = 0, precision = 0; };
+    std::vector<InsCfg> ins_cfg;
+    int last_ins_priority = -1;
+    double last_ins_timestamp = 0;
     double init_pose[6] = {0, 0, 0, 0, 0, 0};
     std::string dest;
     int dest_port = 0;
@@ -130,6 +177,285 @@ std::unique_ptr<Slam> g;  // one global instance per process, like the reference
 
 void require(bool ok, const char* what) {
     if (!ok) throw std::runtime_error(std::string("slam_wrapper: ") + what + (lio_last_error()[0] ? std::string(": ") + lio_last_error() : std::string()));
+}
+
+
+// ---- the map on disk: <map>/graph/<n>/{data, cloud.pcd} as KeyFrame::save writes them (slam/common/keyframe.cpp:118-133; the cloud through
+// pcl::io::savePCDFileBinary for PointXYZI: FIELDS x y z intensity, 16 bytes per point) -------------------------------------------------
+bool write_pcd_binary(const std::string& path, const float* xyzi, size_t n) {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    f << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH " << n
+      << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA binary\n";
+    f.write(reinterpret_cast<const char*>(xyzi), (std::streamsize)(n * 16));
+    return (bool)f;
+}
+// reads the x, y, z, intensity fields of an ascii or binary PCD (any field order / extra fields of 4-byte scalars)
+bool read_pcd(const std::string& path, std::vector<float>& xyzi) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::vector<std::string> fields;
+    std::vector<int> sizes, counts;
+    size_t points = 0;
+    std::string data_kind, line;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ls(line);
+        std::string key;
+        ls >> key;
+        if (key == "FIELDS") { std::string v; while (ls >> v) fields.push_back(v); }
+        else if (key == "SIZE") { int v; while (ls >> v) sizes.push_back(v); }
+        else if (key == "COUNT") { int v; while (ls >> v) counts.push_back(v); }
+        else if (key == "POINTS") ls >> points;
+        else if (key == "DATA") { ls >> data_kind; break; }
+    }
+    if (fields.empty() || sizes.size() != fields.size()) return false;
+    if (counts.empty()) counts.assign(fields.size(), 1);
+    int off[4] = {-1, -1, -1, -1}, stride = 0, col[4] = {-1, -1, -1, -1}, ncol = 0;
+    for (size_t i = 0; i < fields.size(); i++) {
+        const int k = fields[i] == "x" ? 0 : fields[i] == "y" ? 1 : fields[i] == "z" ? 2 : fields[i] == "intensity" ? 3 : -1;
+        if (k >= 0) { if (sizes[i] != 4) return false; off[k] = stride; col[k] = ncol; }
+        stride += sizes[i] * counts[i];
+        ncol += counts[i];
+    }
+    if (off[0] < 0 || off[1] < 0 || off[2] < 0) return false;
+    xyzi.assign(points * 4, 0.f);
+    if (data_kind == "binary") {
+        std::vector<char> rec(stride);
+        for (size_t i = 0; i < points; i++) {
+            if (!f.read(rec.data(), stride)) return false;
+            for (int k = 0; k < 4; k++)
+                if (off[k] >= 0) std::memcpy(&xyzi[4 * i + k], rec.data() + off[k], 4);
+        }
+    } else if (data_kind == "ascii") {
+        std::vector<double> row(ncol);
+        for (size_t i = 0; i < points; i++) {
+            for (int c = 0; c < ncol; c++) if (!(f >> row[c])) return false;
+            for (int k = 0; k < 4; k++) if (col[k] >= 0) xyzi[4 * i + k] = (float)row[col[k]];
+        }
+    } else {
+        return false;  // (binary_compressed: not written by the reference)
+    }
+    return true;
+}
+bool write_keyframe_data(const std::string& dir, uint64_t stamp_us, int id, const Mat4& odom) {  // KeyFrame::save (keyframe.cpp:122-132)
+    std::ofstream ofs(dir + "/data");
+    if (!ofs) return false;
+    auto mat = [&](std::ostream& o) {
+        for (int r = 0; r < 4; r++) { for (int c = 0; c < 4; c++) o << (c ? " " : "") << odom(r, c); o << "\n"; }  // (Eigen's operator<<: 6 significant digits)
+    };
+    ofs << "stamp " << stamp_us / 1000000ULL << " " << stamp_us % 1000000ULL * 1000 << std::endl;
+    ofs << "estimate" << std::endl; mat(ofs);
+    ofs << "odom " << std::endl; mat(ofs);
+    ofs << "id " << id << std::endl;
+    return (bool)ofs;
+}
+bool read_keyframe_data(const std::string& dir, KeyFrameDisk& kf) {  // KeyFrame::loadOdom, graph form (keyframe.cpp:41-64)
+    std::ifstream ifs(dir + "/data");
+    if (!ifs) return false;
+    bool have = false;
+    while (!ifs.eof()) {
+        std::string token;
+        ifs >> token;
+        if (token == "stamp") { uint64_t sec = 0, nsec = 0; ifs >> sec >> nsec; kf.stamp = sec * 1000000ULL + nsec / 1000ULL; }
+        else if (token == "estimate") { for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) ifs >> kf.odom(i, j); have = true; }
+        else if (token == "id") ifs >> kf.id;
+    }
+    return have;
+}
+// MapLoader::getKeyframeFiles + loadGraphMap (map_loader.cpp:255-300): every sub-directory of <map>/graph holding `data` and `cloud.pcd`, sorted by
+// name, then by id; clouds moved into the map frame by their pose (KeyFrame::transformPoints: pcl::transformPointCloud with a Matrix4d)
+bool load_keyframes(const std::string& map_path, std::vector<KeyFrameDisk>& out) {
+    const std::string graph = map_path + "/graph";
+    DIR* d = opendir(graph.c_str());
+    if (!d) return false;
+    std::vector<std::string> dirs;
+    while (dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name == "." || name == "..") continue;
+        const std::string p = graph + "/" + name;
+        struct stat st;
+        if (stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && stat((p + "/data").c_str(), &st) == 0 && stat((p + "/cloud.pcd").c_str(), &st) == 0) dirs.push_back(p);
+    }
+    closedir(d);
+    std::sort(dirs.begin(), dirs.end());
+    for (const std::string& p : dirs) {
+        KeyFrameDisk kf;
+        if (!read_keyframe_data(p, kf) || !read_pcd(p + "/cloud.pcd", kf.xyzi)) { out.clear(); return false; }
+        kf.local = kf.xyzi;
+        const size_t n = kf.xyzi.size() / 4;
+        for (size_t i = 0; i < n; i++) {
+            const double x = kf.xyzi[4 * i], y = kf.xyzi[4 * i + 1], z = kf.xyzi[4 * i + 2];
+            for (int r = 0; r < 3; r++) kf.xyzi[4 * i + r] = (float)(kf.odom(r, 0) * x + kf.odom(r, 1) * y + kf.odom(r, 2) * z + kf.odom(r, 3));
+        }
+        out.push_back(std::move(kf));
+    }
+    std::stable_sort(out.begin(), out.end(), [](const KeyFrameDisk& a, const KeyFrameDisk& b) { return a.id < b.id; });
+    return !out.empty();
+}
+
+// Localization::init (localization.cpp:91-131) without the graph back end and the global locator: the key frames of the map go to HBM once
+bool loc_setup(Slam* s) {
+    Loc& L = *s->loc;
+    if (!load_keyframes(s->map_path, L.frames)) return false;  // "Map Loader: error to load map"
+    uint64_t total = 0;
+    uint32_t biggest = 0;
+    for (const KeyFrameDisk& kf : L.frames) { total += kf.xyzi.size() / 4; biggest = std::max<uint32_t>(biggest, (uint32_t)(kf.xyzi.size() / 4)); }
+    L.lm = lio_localmap_create(0, total + 16, 200000, std::max<uint32_t>(biggest, 1024));
+    L.ndt = lio_ndt_create(0, 1.0f, 7, 200000ull + biggest + 1024, 400000, 262144);
+    L.scan = lio_scan_create(0, 1u << 18, 1u << 18);
+    if (!L.lm || !L.ndt || !L.scan) return false;
+    lio_ndt_default_params(&L.par);
+    L.par.max_process_time_ms = 50000;  // select_registration_method("NDT_CUDA", 50000) (hdl_localization_nodelet.cpp:47)
+    for (const KeyFrameDisk& kf : L.frames) {
+        const float pos[3] = {(float)kf.odom(0, 3), (float)kf.odom(1, 3), (float)kf.odom(2, 3)};
+        if (lio_localmap_add_keyframe(L.lm, kf.xyzi.data(), (uint32_t)(kf.xyzi.size() / 4), pos) < 0) return false;
+    }
+    return true;
+}
+
+// one loop turn of Localization::runUpdateLocalMap for the pose just located (localization.cpp:303-373) -- synchronous: the key frames are
+// resident in HBM, an update is a millisecond of device-to-device copies + VoxelGrid + target build, not a thread's worth of work
+void loc_update_local_map(Loc& L, const Mat4& pose) {
+    const double p[3] = {pose(0, 3), pose(1, 3), pose(2, 3)};
+    int nk = 0;
+    uint32_t npts = 0;
+    const int rc = lio_localmap_update(L.lm, L.ndt, p, 10.0, 30.0, L.key_frame_distance, (float)std::max(L.resolution, 0.1), &nk, &npts);
+    if (rc == 1) L.have_map = true;
+    else if (rc == 2 || rc == 3) L.have_map = false;  // out of map / nearest key frame too far: the localizer is handed a null map
+}
+
+// HdlLocalizationNodelet::get_timed_pose(stamp) (hdl_localization_nodelet.cpp:108-155) for the two stamps the undistortion asks for
+bool loc_timed_pose(Loc& L, uint64_t stamp, Mat4& out) {
+    if (L.pose_data.empty()) return false;
+    if (stamp < L.pose_data.front().first) return false;
+    if (stamp > L.pose_data.back().first) {
+        if (stamp - L.pose_data.back().first > 1000000) return false;
+        if (!L.pe) return false;
+        return lio_pose_estimator_predict_nostate(L.pe, stamp, out.m) >= 0;
+    }
+    if (L.pose_data.size() < 2) return false;
+    out = L.pose_data.back().second;  // (a stamp inside the stored history: not reached by frame_callback, whose stamps are the newest)
+    return true;
+}
+
+// HdlLocalizationNodelet::frame_callback (hdl_localization_nodelet.cpp:166-275) + Localization::feedPointData's bookkeeping (localization.cpp:235-275).
+// The cloud (INS frame) is in L.staged / L.stamps.  Returns true when the pose is a localised one.
+bool loc_localize(Slam* s, uint32_t n, uint64_t stamp, Mat4& pose_out) {
+    Loc& L = *s->loc;
+    if (!L.initialized) {
+        if (!L.have_init_pose) return false;  // (the global locator -- GNSS / scan-context initial pose -- is out of scope: set_init_pose starts the filter)
+        // Localization::initLocalizer -> initialpose_callback (hdl_localization_nodelet.cpp:304-317): normalised quaternion of the pose, cool time 0.2 s
+        float ext[16];
+        for (int i = 0; i < 16; i++) ext[i] = (float)s->T_imu.m[i];
+        const Mat4& T = L.init_pose;
+        double q[4];  // w x y z, Eigen's matrix -> quaternion
+        {
+            const double t = T(0, 0) + T(1, 1) + T(2, 2);
+            if (t > 0) { const double r = std::sqrt(t + 1.0); q[0] = 0.5 * r; const double k = 0.5 / r; q[1] = (T(2, 1) - T(1, 2)) * k; q[2] = (T(0, 2) - T(2, 0)) * k; q[3] = (T(1, 0) - T(0, 1)) * k; }
+            else {
+                int i = 0;
+                if (T(1, 1) > T(0, 0)) i = 1;
+                if (T(2, 2) > T(i, i)) i = 2;
+                const int j = (i + 1) % 3, k = (j + 1) % 3;
+                const double r = std::sqrt(T(i, i) - T(j, j) - T(k, k) + 1.0);
+                q[1 + i] = 0.5 * r;
+                const double kk = 0.5 / r;
+                q[0] = (T(k, j) - T(j, k)) * kk; q[1 + j] = (T(j, i) + T(i, j)) * kk; q[1 + k] = (T(k, i) + T(i, k)) * kk;
+            }
+            const double nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            for (double& v : q) v /= nq;
+        }
+        const float pos[3] = {(float)T(0, 3), (float)T(1, 3), (float)T(2, 3)};
+        const float qf[4] = {(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+        if (L.pe) lio_pose_estimator_destroy(L.pe);
+        L.pe = lio_pose_estimator_create(ext, stamp, pos, qf, 0.2);
+        if (!L.pe) return false;
+        L.init_stamp = stamp;
+        L.pose_data.clear();
+        L.imu_data.clear();
+        L.last_odom = T;
+        L.initialized = true;
+        L.age = 0;
+        L.failures = 0;
+        lio_localmap_destroy(L.lm);  // a fresh local-map thread state: the first pose always builds a map
+        L.lm = nullptr;
+        uint64_t total = 0;
+        uint32_t biggest = 0;
+        for (const KeyFrameDisk& kf : L.frames) { total += kf.xyzi.size() / 4; biggest = std::max<uint32_t>(biggest, (uint32_t)(kf.xyzi.size() / 4)); }
+        L.lm = lio_localmap_create(0, total + 16, 200000, std::max<uint32_t>(biggest, 1024));
+        if (!L.lm) return false;
+        for (const KeyFrameDisk& kf : L.frames) {
+            const float kp[3] = {(float)kf.odom(0, 3), (float)kf.odom(1, 3), (float)kf.odom(2, 3)};
+            lio_localmap_add_keyframe(L.lm, kf.xyzi.data(), (uint32_t)(kf.xyzi.size() / 4), kp);
+        }
+        loc_update_local_map(L, T);  // mPoseQueue.enqueue(mLastOdom)
+    }
+    if (n == 0) return false;  // "cloud is empty!!"
+    // imu process: mean of the samples up to the frame's stamp
+    float acc[3] = {0, 0, 0}, gyr[3] = {0, 0, 0};
+    size_t used = 0;
+    for (; used < L.imu_data.size(); used++) {
+        if (stamp < (uint64_t)(L.imu_data[used].stamp * 1000000.0)) break;
+        for (int a = 0; a < 3; a++) { acc[a] = acc[a] + L.imu_data[used].acc[a]; gyr[a] = gyr[a] + L.imu_data[used].gyr[a]; }
+    }
+    const bool use_imu = used != 0;
+    if (use_imu) for (int a = 0; a < 3; a++) { acc[a] = acc[a] / (float)(int)used; gyr[a] = gyr[a] / (float)(int)used; }
+    L.imu_data.erase(L.imu_data.begin(), L.imu_data.begin() + used);
+    lio_pose_estimator_predict(L.pe, stamp, use_imu ? acc : nullptr, use_imu ? gyr : nullptr);
+    // undistortion over the filter's step, then the downsample, on the device
+    if (lio_scan_upload(L.scan, L.staged.data(), n) != LIO_OK) return false;
+    Mat4 a, b;
+    if (loc_timed_pose(L, stamp, a) && loc_timed_pose(L, stamp + lio_pose_estimator_get_dt(L.pe), b)) {
+        const Mat4 d = mul(rigid_inverse(a), b);
+        float df[16];
+        for (int i = 0; i < 16; i++) df[i] = (float)d.m[i];
+        lio_scan_undistort_delta(L.scan, L.stamps.data(), 0, df, s->scan_period);
+    }
+    uint32_t n_ds = 0;
+    if (L.resolution >= 0.1) { if (lio_scan_voxel_downsample(L.scan, (float)L.resolution, 1, &n_ds) != LIO_OK) return false; }
+    else { std::vector<float> raw(4 * (size_t)n); lio_scan_download_raw(L.scan, raw.data(), n); lio_scan_set_ds(L.scan, raw.data(), n); }
+    // correct
+    float obs[7], cov[49];
+    bool result = false;
+    double fitness = 0.0;
+    if (L.have_map) {
+        int it = 0;
+        const int rc = lio_pose_estimator_match_gps(L.pe, L.ndt, L.scan, &L.par, nullptr, obs, cov, &it);
+        result = rc == 1;
+        if (stamp - L.init_stamp < 10000000) {  // WARM_UP_TIME: getFitnessScore(25) of the alignment (pose_estimator.cpp:254-264)
+            double T[16] = {0, 0, 0, obs[0], 0, 0, 0, obs[1], 0, 0, 0, obs[2], 0, 0, 0, 1};
+            const double w = obs[3], x = obs[4], y = obs[5], z = obs[6];
+            T[0] = 1 - 2 * (y * y + z * z); T[1] = 2 * (x * y - z * w); T[2] = 2 * (x * z + y * w);
+            T[4] = 2 * (x * y + z * w); T[5] = 1 - 2 * (x * x + z * z); T[6] = 2 * (y * z - x * w);
+            T[8] = 2 * (x * z - y * w); T[9] = 2 * (y * z + x * w); T[10] = 1 - 2 * (x * x + y * y);
+            uint32_t n_in = 0;
+            lio_ndt_fitness_score(L.ndt, L.scan, T, 25.0, &fitness, &n_in);
+        }
+    } else {
+        result = lio_pose_estimator_match_gps_only(L.pe, nullptr, obs, cov) == 1;
+    }
+    lio_pose_estimator_correct(L.pe, stamp, obs);
+    float M[16];
+    lio_pose_estimator_matrix(L.pe, M);
+    for (int i = 0; i < 16; i++) pose_out.m[i] = (double)M[i];
+    while (L.pose_data.size() >= 10) L.pose_data.pop_front();
+    L.pose_data.emplace_back(stamp, pose_out);
+    if (fitness > 1.0) result = false;  // "localization fitness score is too large"
+    L.last_odom = pose_out;
+    // Localization::feedPointData (localization.cpp:252-274)
+    if (result) {
+        L.age++;
+        L.failures = 0;
+        loc_update_local_map(L, pose_out);  // mPoseQueue.enqueue(mLastOdom)
+    } else {
+        L.failures++;
+    }
+    if (L.failures >= 5) {  // "failed to localize, fallback to initializing": back to waiting for an initial pose
+        L.initialized = false;
+        L.have_init_pose = false;
+    }
+    return true;
 }
 
 // HDL_FastLIO::runLio (fastlio.cpp:262-276)
@@ -168,13 +494,32 @@ py::array_t<float> mat4_to_numpy_f32(const Mat4& T) {  // eigen_to_numpy(Matrix4
 // ---- hot path ---------------------------------------------------------------------------------------------------------------
 py::list init_slam(const std::string mode, const std::string map_path, const std::string method, py::list& sensor_input, double resolution,
                    float dist_threshold, float degree_threshold, float frame_range) {
-    (void)map_path; (void)resolution; (void)dist_threshold; (void)degree_threshold; (void)frame_range;
-    if (method != "FastLIO") throw std::runtime_error("slam_wrapper: only the FastLIO odometry path is built on the device (method=" + method + ")");
+    (void)degree_threshold; (void)frame_range;
+    // slam.py hands in method = "Localization" when the mode is not "mapping" (slam/slam.py:12); SLAM::SLAM then builds Locate::Localization
+    const bool localization = mode == "localization" || method == "Localization";
+    if (!localization && method != "FastLIO")
+        throw std::runtime_error("slam_wrapper: only the FastLIO odometry path and the localisation mode are built on the device (method=" + method + ")");
     g.reset(new Slam());
-    g->mode = mode;
+    g->mode = localization ? "localization" : mode;
     g->method = method;
+    g->map_path = map_path;
     std::vector<std::string> in;
     for (auto h : sensor_input) in.push_back(py::cast<std::string>(h));
+    if (localization) {
+        g->loc.reset(new Loc());
+        g->loc->resolution = resolution;
+        g->loc->key_frame_distance = dist_threshold;
+        // Localization::setSensors (localization.cpp:154-182): RTK / IMU as they come, the first "n-" name is the lidar, the first other one the camera
+        bool cam = false;
+        for (auto& s : in) {
+            g->sensors.push_back(s);
+            if (s == "RTK") g->use_gps = true;
+            else if (s == "IMU") g->use_imu = true;
+            else if (s.length() < 2 || s[1] != '-') cam = cam || true;
+            else if (g->lidar.empty()) g->lidar = s;
+        }
+        return py::cast(g->sensors);
+    }
     // HDL_FastLIO::setSensors (fastlio.cpp:119-151): RTK and IMU first; without an IMU nothing else; the first "n-" name is the lidar
     bool imu = false;
     for (auto& s : in) {
@@ -203,6 +548,7 @@ void set_imu_external_param(double x, double y, double z, double yaw, double pit
 bool setup_slam() {
     require((bool)g, "init_slam first");
     if (lio_device_count() < 1) return false;  // the reference logs and returns false from setup() when the back end cannot start
+    if (g->loc) return loc_setup(g.get());
     // HDL_FastLIO::init (fastlio.cpp:153-171): T_imu_ins = T_imu * T_static^-1 is the (INS-frame cloud) -> IMU extrinsic
     g->T_imu_ins = mul(g->T_imu, rigid_inverse(g->T_static));
     g->T_imu_ins_inv = rigid_inverse(g->T_imu_ins);
@@ -222,14 +568,98 @@ void deinit_slam() {
     if (!g) return;
     if (g->running.exchange(false) && g->lio_thread.joinable()) g->lio_thread.join();
     if (g->engine) lio_engine_destroy(g->engine);
+    g->loc.reset(nullptr);
     g.reset(nullptr);
+}
+
+// SLAM::run, localisation branch (slam.cpp:273-367) over Localization::feedImuData / feedPointData / getPose
+py::dict process_localization(Slam* s, py::dict& points, py::dict& points_attr, py::dict& rtk_dict, py::array_t<double>& imu_list, uint64_t timestamp) {
+    Loc& L = *s->loc;
+    int status = 0;
+    if (rtk_dict.contains("Status")) status = py::cast<int>(rtk_dict["Status"]);
+    std::string name = s->lidar;
+    if (name.empty() || !points.contains(name.c_str())) {
+        require(py::len(points) > 0, "process: no point cloud");
+        name = py::cast<std::string>((*points.begin()).first);
+    }
+    py::array_t<float, py::array::c_style | py::array::forcecast> cloud = py::cast<py::array>(points[name.c_str()]);
+    py::dict attr = py::cast<py::dict>(points_attr[name.c_str()]);
+    py::array_t<float, py::array::c_style | py::array::forcecast> pattr = py::cast<py::array>(attr["points_attr"]);
+    const uint64_t header_stamp = py::cast<uint64_t>(attr["timestamp"]);
+    require(cloud.ndim() == 2 && cloud.shape(1) >= 4 && pattr.ndim() == 2 && pattr.shape(1) >= 1 && pattr.shape(0) == cloud.shape(0),
+            "process: points must be N x 4 float32 with an N x 2 attribute array");
+    const uint32_t n = (uint32_t)cloud.shape(0);
+    const float* src = cloud.data();
+    const float* asrc = pattr.data();
+    const py::ssize_t cs = cloud.shape(1), as = pattr.shape(1);
+    std::vector<Loc::Imu> imu_in;
+    if (s->use_imu && imu_list.ndim() == 2 && imu_list.shape(1) >= 7) {  // numpy_to_imu (py_utils.cpp:244-258)
+        auto ref = imu_list.unchecked<2>();
+        for (py::ssize_t i = 0; i < ref.shape(0); i++) {
+            Loc::Imu m;
+            m.stamp = ref(i, 0) / 1000000.0;
+            for (int a = 0; a < 3; a++) { m.gyr[a] = (float)(ref(i, 1 + a) / 180.0 * M_PI); m.acc[a] = (float)(ref(i, 4 + a) * 9.81); }
+            imu_in.push_back(m);
+        }
+    }
+    Mat4 out_pose = Mat4::identity();
+    bool located = false, inited = false;
+    {
+        py::gil_scoped_release release;
+        std::lock_guard<std::mutex> lk(s->mtx);
+        if (L.initialized) L.imu_data.insert(L.imu_data.end(), imu_in.begin(), imu_in.end());  // Localization::feedImuData: dropped while not initialised
+        // preprocessPoints (slam_base.h:83-85) straight into the staging vector
+        L.staged.resize(4 * (size_t)n + 4);
+        L.stamps.resize((size_t)n + 1);
+        const Mat4& M = s->T_static;
+        for (uint32_t i = 0; i < n; i++) {
+            const double x = src[i * cs], y = src[i * cs + 1], z = src[i * cs + 2];
+            L.staged[4 * i + 0] = (float)(M(0, 0) * x + M(0, 1) * y + M(0, 2) * z + M(0, 3));
+            L.staged[4 * i + 1] = (float)(M(1, 0) * x + M(1, 1) * y + M(1, 2) * z + M(1, 3));
+            L.staged[4 * i + 2] = (float)(M(2, 0) * x + M(2, 1) * y + M(2, 2) * z + M(2, 3));
+            L.staged[4 * i + 3] = src[i * cs + 3];
+            L.stamps[i] = (uint32_t)asrc[i * as];
+        }
+        located = loc_localize(s, n, header_stamp, out_pose);
+        if (!located) out_pose = L.last_odom;
+        inited = L.initialized && L.age >= 10;  // Localization::isInited: mInitialized && isStable()
+    }
+    double heading, pitch, roll;
+    rpy_from_transform(out_pose, heading, pitch, roll);
+    if (std::fabs(roll) >= 90.0 || std::fabs(pitch) >= 90.0) {
+        const Mat4 o2 = transform_from_rpyt(out_pose(0, 3), out_pose(1, 3), out_pose(2, 3), -heading, pitch, roll);
+        rpy_from_transform(o2, heading, pitch, roll);
+    } else {
+        heading = -heading;
+    }
+    if (heading < 0) heading += 360;
+    py::dict pose;
+    pose["latitude"] = 0.0;   // (no map origin / UTM projection without the GNSS side: slam.cpp:338-342)
+    pose["longitude"] = 0.0;
+    pose["altitude"] = 0.0;
+    pose["heading"] = heading;
+    pose["pitch"] = pitch;
+    pose["roll"] = roll;
+    pose["Ve"] = 0;
+    pose["Vn"] = 0;
+    pose["Vu"] = 0;
+    pose["Status"] = status;
+    pose["state"] = inited ? "Localizing(L)" : "Initializing";
+    pose["timestamp"] = header_stamp;
+    pose["odom_matrix"] = mat4_to_numpy_f32(out_pose);
+    py::dict data;
+    data["frame_start_timestamp"] = timestamp;
+    data["pose"] = pose;
+    data["slam_valid"] = true;
+    return data;
 }
 
 py::dict process(py::dict& points, py::dict& points_attr, py::dict& image_dict, py::dict& image_stream_dict, py::dict& image_param,
                  py::dict& rtk_dict, py::array_t<double>& imu_list, uint64_t timestamp) {
     (void)image_dict; (void)image_stream_dict; (void)image_param;
-    require(g && g->engine, "init_slam / setup_slam first");
+    require(g && (g->engine || (g->loc && g->loc->scan)), "init_slam / setup_slam first");
     Slam* s = g.get();
+    if (s->loc) return process_localization(s, points, points_attr, rtk_dict, imu_list, timestamp);
     // pydict_to_rtk: only the fields SLAM::run copies into the pose in mapping mode (slam.cpp:344-348)
     double lat = 0, lon = 0, alt = 0;
     int status = 0;
@@ -237,6 +667,46 @@ py::dict process(py::dict& points, py::dict& points_attr, py::dict& image_dict, 
     if (rtk_dict.contains("longitude")) lon = py::cast<double>(rtk_dict["longitude"]);
     if (rtk_dict.contains("altitude")) alt = py::cast<double>(rtk_dict["altitude"]);
     if (rtk_dict.contains("Status")) status = py::cast<int>(rtk_dict["Status"]);
+    // SLAM::run (slam.cpp:283-296): preprocessInsData's validity test, then HDL_FastLIO::feedInsData -> fastlio_ins_enqueue (fastlio.cpp:185-187,
+    // laserMapping.cpp:417-441): the INS velocity, ENU -> ego -> IMU, third component zeroed -- IMU initialisation seeds the state's velocity
+    // from it (IMU_Processing.hpp:201-204), the wheel-speed rows read it
+    if (s->use_gps && rtk_dict.contains("Ve") && rtk_dict.contains("timestamp")) {
+        const uint64_t rtk_stamp = py::cast<uint64_t>(rtk_dict["timestamp"]);
+        const std::string sensor = rtk_dict.contains("Sensor") ? py::cast<std::string>(rtk_dict["Sensor"]) : std::string();
+        bool valid;
+        if (status == 0 && std::fabs(lon) < 1e-4 && std::fabs(lat) < 1e-4) {
+            const double lost = timestamp / 1000000.0 - s->last_ins_timestamp;
+            if (s->last_ins_priority != -1 && lost >= 1.0) s->last_ins_priority = -1;
+            valid = false;
+        } else {
+            const Slam::InsCfg* match = nullptr;
+            for (const auto& c : s->ins_cfg) if (c.status == status) { match = &c; break; }
+            if (!match) for (const auto& c : s->ins_cfg) if (c.status == -1) { match = &c; break; }
+            const int mp = match ? match->priority : -1;
+            int priority = -1;
+            if (mp == s->last_ins_priority) { priority = mp; s->last_ins_timestamp = rtk_stamp / 1000000.0; }
+            else if (mp < s->last_ins_priority) { priority = mp; s->last_ins_priority = mp; s->last_ins_timestamp = rtk_stamp / 1000000.0; }
+            else {
+                const double keep = rtk_stamp / 1000000.0 - s->last_ins_timestamp;
+                if (keep >= match->stable_time) { priority = mp; s->last_ins_priority = mp; s->last_ins_timestamp = rtk_stamp / 1000000.0; }
+                else priority = s->last_ins_priority;
+            }
+            valid = priority >= 0;
+        }
+        if (valid || sensor.find("Wheel") != std::string::npos) {
+            const double hd = rtk_dict.contains("heading") ? py::cast<double>(rtk_dict["heading"]) : 0.0;
+            const double pt = rtk_dict.contains("pitch") ? py::cast<double>(rtk_dict["pitch"]) : 0.0;
+            const double rl = rtk_dict.contains("roll") ? py::cast<double>(rtk_dict["roll"]) : 0.0;
+            const double ve[3] = {py::cast<double>(rtk_dict["Ve"]), rtk_dict.contains("Vn") ? py::cast<double>(rtk_dict["Vn"]) : 0.0,
+                                  rtk_dict.contains("Vu") ? py::cast<double>(rtk_dict["Vu"]) : 0.0};
+            const Mat4 Tve = rigid_inverse(transform_from_rpyt(0, 0, 0, -hd, pt, rl));
+            double ego[3], vi[3];
+            for (int r = 0; r < 3; r++) ego[r] = Tve(r, 0) * ve[0] + Tve(r, 1) * ve[1] + Tve(r, 2) * ve[2];
+            for (int r = 0; r < 3; r++) vi[r] = s->T_imu_ins(r, 0) * ego[0] + s->T_imu_ins(r, 1) * ego[1] + s->T_imu_ins(r, 2) * ego[2];
+            vi[2] = 0.0;  // "body up speed of INS is not accurate"
+            lio_fastlio_ins_enqueue(s->engine, rtk_stamp / 1000000.0, vi);
+        }
+    }
     // numpy_to_imu + HDL_FastLIO::feedImuData
     if (s->use_imu && imu_list.ndim() == 2 && imu_list.shape(1) >= 7) {
         auto ref = imu_list.unchecked<2>();
@@ -322,9 +792,35 @@ py::dict process(py::dict& points, py::dict& points_attr, py::dict& image_dict, 
 
 // ---- off the hot path: type-correct minimal implementations -------------------------------------------
 void set_camera_param(py::list& cameras) { (void)cameras; }
-void set_ins_config(py::dict& dict) { if (g) g->ins_config = dict; }
+// pydict_to_ins_config (py_utils.cpp:295-317): ins_normal / ins_float / ins_fix entries with use, status, stable_time, precision
+void set_ins_config(py::dict& dict) {
+    if (!g) return;
+    g->ins_config = dict;
+    g->ins_cfg.clear();
+    int priority = 0;
+    for (const char* name : {"ins_normal", "ins_float", "ins_fix"}) {
+        if (!dict.contains(name)) continue;
+        py::dict e = py::cast<py::dict>(dict[name]);
+        if (!e.contains("use") || !py::cast<bool>(e["use"])) continue;
+        Slam::InsCfg c;
+        c.name = name;
+        c.status = py::cast<int>(e["status"]);
+        c.stable_time = py::cast<double>(e["stable_time"]);
+        c.precision = py::cast<double>(e["precision"]);
+        c.priority = priority++;
+        g->ins_cfg.push_back(c);
+    }
+}
 void set_init_pose(double x, double y, double z, double yaw, double pitch, double roll) {
-    if (g) { const double v[6] = {x, y, z, yaw, pitch, roll}; std::memcpy(g->init_pose, v, sizeof(v)); }
+    if (!g) return;
+    const double v[6] = {x, y, z, yaw, pitch, roll};
+    std::memcpy(g->init_pose, v, sizeof(v));
+    if (g->loc) {  // SLAM::setInitPose (slam.cpp): getTransformFromRPYT(x, y, z, yaw, pitch, roll) -> Localization::setInitPose: mInitialized = false
+        std::lock_guard<std::mutex> lk(g->mtx);
+        g->loc->init_pose = transform_from_rpyt(x, y, z, yaw, pitch, roll);
+        g->loc->have_init_pose = true;
+        g->loc->initialized = false;
+    }
 }
 py::list get_estimate_pose(double x0, double y0, double x1, double y1) {
     (void)x0; (void)y0; (void)x1; (void)y1;
@@ -357,7 +853,29 @@ void set_map_origin(double lat, double lon, double alt, double heading, double p
     }
 }
 py::dict merge_map(const std::string& directory) { (void)directory; return py::dict(); }
-py::dict get_graph_map() { return py::dict(); }
+// get_graph_map (slam_wrapper.cpp:180-184 -> keyframe_to_pydict, py_utils.cpp:272-293): the key frames of the loaded map in localisation mode
+// (points N x 4 f32 as stored, pose 4 x 4 f32, stamp); empty in mapping mode (the graph back end is out of scope)
+py::dict get_graph_map() {
+    py::dict d;
+    if (!g || !g->loc || g->loc->frames.empty()) return d;
+    py::dict points, images, poses, stamps;
+    for (const KeyFrameDisk& kf : g->loc->frames) {
+        const std::string id = std::to_string(kf.id);
+        const py::ssize_t n = (py::ssize_t)(kf.local.size() / 4);
+        py::array_t<float> a({n, (py::ssize_t)4});
+        auto r = a.mutable_unchecked<2>();
+        for (py::ssize_t i = 0; i < n; i++) { r(i, 0) = kf.local[4 * i]; r(i, 1) = kf.local[4 * i + 1]; r(i, 2) = kf.local[4 * i + 2]; r(i, 3) = kf.local[4 * i + 3]; }
+        points[id.c_str()] = a;
+        poses[id.c_str()] = mat4_to_numpy_f32(kf.odom);
+        stamps[id.c_str()] = kf.stamp;
+        images[id.c_str()] = py::dict();
+    }
+    d["points"] = points;
+    d["images"] = images;
+    d["poses"] = poses;
+    d["stamps"] = stamps;
+    return d;
+}
 py::array_t<float> get_color_map() { return py::array_t<float>(std::vector<py::ssize_t>{0, 6}); }
 py::dict get_graph_edges() { return py::dict(); }
 py::dict get_graph_meta() { return py::dict(); }
@@ -414,8 +932,21 @@ void del_graph_edge(int id) { (void)id; }
 void set_graph_vertex_fix(int id, bool fix) { (void)id; (void)fix; }
 py::dict run_graph_optimization() { return py::dict(); }
 py::dict run_robust_graph_optimization(std::string mode) { (void)mode; return py::dict(); }
+// dump_keyframe (graph_utils.cpp:123-131): KeyFrame(stamp, id, pose, numpy_to_pointcloud(points, 255.0)).save(directory) -- `data` + `cloud.pcd`,
+// the files the localisation mode loads its map from
 void dump_keyframe(const std::string& directory, uint64_t stamp, int id, py::array_t<float>& points_input, py::array_t<float>& pose_input) {
-    (void)directory; (void)stamp; (void)id; (void)points_input; (void)pose_input;
+    auto pts = py::array_t<float, py::array::c_style | py::array::forcecast>::ensure(points_input);
+    auto pose = py::array_t<float, py::array::c_style | py::array::forcecast>::ensure(pose_input);
+    if (!pts || !pose || pts.ndim() != 2 || pts.shape(1) < 4 || pose.size() != 16) return;
+    const size_t n = (size_t)pts.shape(0);
+    std::vector<float> xyzi(4 * n + 4);
+    const float* src = pts.data();
+    const py::ssize_t cs = pts.shape(1);
+    for (size_t i = 0; i < n; i++) { xyzi[4 * i] = src[i * cs]; xyzi[4 * i + 1] = src[i * cs + 1]; xyzi[4 * i + 2] = src[i * cs + 2]; xyzi[4 * i + 3] = src[i * cs + 3] * 255.0f; }
+    Mat4 T;
+    for (int i = 0; i < 16; i++) T.m[i] = (double)pose.data()[i];
+    write_pcd_binary(directory + "/cloud.pcd", xyzi.data(), n);
+    write_keyframe_data(directory, stamp, id, T);
 }
 void dump_odometry(const std::string& directory) { (void)directory; }
 void set_export_map_config(double z_min, double z_max, std::string color) { if (g) { g->export_z[0] = z_min; g->export_z[1] = z_max; g->export_color = color; } }
@@ -444,6 +975,14 @@ void save_render_cloud(std::string file) { (void)file; }
 
 // test visibility (not in the reference's module): the engine behind the module, so that a test can hold the C++ path against the C ABI
 uintptr_t _engine_handle() { return g ? reinterpret_cast<uintptr_t>(g->engine) : 0; }
+py::array_t<double> _transform_from_rpyt(double x, double y, double z, double yaw, double pitch, double roll) {  // the module's getTransformFromRPYT
+    const Mat4 T = transform_from_rpyt(x, y, z, yaw, pitch, roll);
+    py::array_t<double> a({4, 4});
+    auto r = a.mutable_unchecked<2>();
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) r(i, j) = T(i, j);
+    return a;
+}
 void _set_capacity(uint64_t max_points, uint64_t max_voxels) { if (g) { g->max_points = max_points; g->max_voxels = max_voxels; } }
 
 PYBIND11_MODULE(slam_wrapper, m) {
@@ -502,5 +1041,6 @@ PYBIND11_MODULE(slam_wrapper, m) {
           py::arg("image_stream_dict"), py::arg("image_param"));
     m.def("save_render_cloud", &save_render_cloud, "save render cloud", py::arg("file"));
     m.def("_engine_handle", &_engine_handle);
+    m.def("_transform_from_rpyt", &_transform_from_rpyt);
     m.def("_set_capacity", &_set_capacity, py::arg("max_points"), py::arg("max_voxels"));
 }

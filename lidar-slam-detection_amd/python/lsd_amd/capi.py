@@ -31,7 +31,7 @@ SYMBOLS = [
     "lio_localmap_download",
     "lio_pose_estimator_create", "lio_pose_estimator_destroy", "lio_pose_estimator_predict", "lio_pose_estimator_match", "lio_pose_estimator_match_gps", "lio_pose_estimator_guess", "lio_pose_estimator_observe",
     "lio_pose_estimator_match_gps_only", "lio_pose_estimator_get_timed_pose", "lio_pose_estimator_predict_nostate",
-    "lio_pose_estimator_correct", "lio_pose_estimator_get", "lio_pose_estimator_set", "lio_pose_estimator_matrix",
+    "lio_pose_estimator_correct", "lio_pose_estimator_get_dt", "lio_pose_estimator_get", "lio_pose_estimator_set", "lio_pose_estimator_matrix",
     "lio_fastlio_init", "lio_fastlio_is_init", "lio_fastlio_imu_enqueue", "lio_engine_set_device_loop", "lio_fastlio_ins_enqueue", "lio_fastlio_set_wheelspeed", "lio_fastlio_pcl_enqueue", "lio_fastlio_pcl_enqueue_device", "lio_fastlio_pcl_stage", "lio_fastlio_pcl_commit",
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
     "lio_state_predict", "lio_eskf_update_cb", "lio_eskf_update_ws_cb", "lio_eskf_update_sums_cb",
@@ -207,6 +207,7 @@ def lib():
     sig("lio_pose_estimator_get_timed_pose", cint, vp, u64, f64p, f64p, f64p)
     sig("lio_pose_estimator_predict_nostate", cint, vp, u64, f64p)
     sig("lio_pose_estimator_correct", cint, vp, u64, f32p)
+    sig("lio_pose_estimator_get_dt", u64, vp)
     sig("lio_pose_estimator_get", cint, vp, f32p, f32p)
     sig("lio_pose_estimator_set", cint, vp, f32p, f32p)
     sig("lio_pose_estimator_matrix", cint, vp, f32p)

@@ -438,7 +438,7 @@ class Engine:
 
 
 def overlap_filter(cloud, xy_range=100.0, min_z=0.5):
-    """`filter` of overlap_merge.hpp:196-204: keep sqrt(x^2 + y^2) < range && z > floor (f32)"""
+    """`filter` of overlap_merge.hpp:213-223: keep sqrt(x^2 + y^2) < range && z > floor (f32)"""
     c = np.ascontiguousarray(cloud, np.float32).reshape(-1, 4)
     d = np.sqrt(c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1])
     return c[(d < np.float32(xy_range)) & (c[:, 2] > np.float32(min_z))]
@@ -500,7 +500,7 @@ class Ndt:
         return sc.value, ni.value
 
     def overlap_score(self, scan, relpose, max_range=1.0, xy_range=100.0, min_z=0.5):
-        """calc_fitness_score of overlap_merge.hpp:206-263 against this target (filter the target cloud with `overlap_filter` first):
+        """calc_fitness_score of overlap_merge.hpp:225-263 against this target (filter the target cloud with `overlap_filter` first):
         (mean squared nearest-neighbour distance of the inliers, inlier share of the filtered source)"""
         t = f64(relpose).reshape(4, 4)
         sc, ir = C.c_double(0.0), C.c_double(0.0)

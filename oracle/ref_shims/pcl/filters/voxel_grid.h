@@ -4,20 +4,30 @@
 // code -- can be compared with the oracle on equal downsampled clouds.
 #pragma once
 #include <cstring>
+#include <memory>
 #include <vector>
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
 extern "C" int orc_voxel_downsample(const float* in_xyzi, int n, float leaf, float* out_xyzi, int cap);
 namespace pcl {
+// pcl::Filter: the base the localisation nodelet holds its downsample filter through (hdl_localization_nodelet.cpp:357)
 template <typename PointT>
-class VoxelGrid {
+class Filter {
+   public:
+    using Ptr = std::shared_ptr<Filter<PointT>>;
+    virtual ~Filter() {}
+    virtual void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) = 0;
+    virtual void filter(PointCloud<PointT>& out) = 0;
+};
+template <typename PointT>
+class VoxelGrid : public Filter<PointT> {
     float leaf_ = 0.f;
     typename PointCloud<PointT>::ConstPtr in_;
 
    public:
     void setLeafSize(float lx, float, float) { leaf_ = lx; }
-    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { in_ = c; }
-    void filter(PointCloud<PointT>& out) {
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) override { in_ = c; }
+    void filter(PointCloud<PointT>& out) override {
         const size_t n = in_ ? in_->points.size() : 0;
         std::vector<float> a(4 * (n ? n : 1)), b(4 * (n ? n : 1));
         for (size_t i = 0; i < n; i++) {

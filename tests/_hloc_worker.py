@@ -1,0 +1,62 @@
+"""worker for tests/test_localization_boundary.py: one process = one variant of the reference's localisation nodelet (its matcher objects are
+file-scope statics): argv = variant ("hip" | "ref") out.npz.  Drives a 60-scan sequence: IMU samples, motion-distorted sweeps, a GNSS observation
+now and then, a second local map half way (the ping-pong hand-over of globalmap_callback)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "lidar-slam-detection_amd", "python"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+
+
+def drive():
+    from lsd_amd import synth
+
+    scene = synth.Scene(half=100.0, n_boxes=40, seed=1)
+    tr = synth.Trajectory(t_static=0.2, speed=4.0)
+    maps = []
+    for seed in (21, 22):
+        m = scene.sample_surface(1_500_000, seed=seed, sigma=0.01)
+        maps.append(np.ascontiguousarray(m[np.linalg.norm(m[:, :2] - tr.pos(3.0)[:2], axis=1) < 80.0]))
+    imu = synth.imu_stream(tr, 0.0, 6.3, rate=100.0, seed=5, gyr_sigma=1e-3, acc_sigma=1e-2)
+    sweeps = [synth.make_sweep(scene, tr, k * 0.1, seed=300 + k, n_az=900, fov_deg=(-24.8, 2.0)) for k in range(1, 61)]
+    return scene, tr, maps, imu, sweeps
+
+
+def main():
+    variant, out = sys.argv[1], sys.argv[2]
+    import ref_hdl_localization as H
+
+    scene, tr, maps, imu, sweeps = drive()
+    node = H.HdlLocalization(use_reference_matcher=(variant == "ref"), resolution=0.2, scan_period=0.1)
+    node.set_map(maps[0])
+    T0 = np.eye(4)
+    T0[:3, :3], T0[:3, 3] = tr.R(0.1), tr.pos(0.1)
+    node.set_initpose(100000, T0)
+    ii, poses, codes, truth = 0, [], [], []
+    for k, (pts, st) in enumerate(sweeps, start=1):
+        tb = k * 0.1
+        while ii < len(imu) and imu[ii][0] <= tb:
+            node.imu(imu[ii][0], imu[ii][2], imu[ii][1])
+            ii += 1
+        if k == 30:
+            node.set_map(maps[1])  # the next local map: built into the idle matcher object, swapped in by the next frame_callback
+        if k % 7 == 0:  # GNSS samples either side of the frame's stamp (interpolated by the nodelet), 6-D and 2-D
+            for dt in (-0.05, 0.05):
+                Tg = np.eye(4)
+                Tg[:3, :3], Tg[:3, 3] = tr.R(tb + dt), tr.pos(tb + dt) + [0.1, -0.05, 0.0]
+                node.ins(int(round((tb + dt) * 1e6)), Tg, precision=1.0, dimension=6 if k % 14 == 0 else 2)
+        code, T = node.frame(pts, st, int(round(tb * 1e6)))
+        codes.append(code)
+        poses.append(T)
+        Tt = np.eye(4)
+        Tt[:3, :3], Tt[:3, 3] = tr.R(tb), tr.pos(tb)
+        truth.append(Tt)
+    ok, Tq = node.timed_pose(int(round(5.95 * 1e6)))
+    np.savez(out, poses=np.array(poses), codes=np.array(codes), truth=np.array(truth), timed_ok=ok, timed=Tq)
+    node.close()
+
+
+if __name__ == "__main__":
+    main()

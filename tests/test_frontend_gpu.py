@@ -154,59 +154,6 @@ def test_device_resident_enqueue_and_filters(oracle_mod, scene):
         hip_rt.hipFree(d_t)
 
 
-def test_slam_wrapper_process_boundary(scene):
-    """the reference's outer call -- slam_wrapper.process(points, points_attr, ..., imu_list, timestamp) with its units
-    (IMU rows [t us, deg/s x3, g x3], per-point offsets in us, static lidar -> INS and IMU extrinsics) -- drives the device
-    engine; the returned odom_matrix (INS frame, scan start) follows the analytic trajectory"""
-    _dev()
-    from lsd_amd import slam_wrapper as sw, synth
-
-    tr = synth.Trajectory()
-    # lidar -> IMU and lidar -> INS mounting (x, y, z, yaw, pitch, roll; degrees)
-    imu_ext = (0.05, -0.02, 0.10, 3.0, 0.5, -1.0)
-    ins_ext = (0.30, 0.10, -0.20, -4.0, 1.0, 2.0)
-    T_li = sw.get_transform_from_rpyt(*imu_ext)
-    T_ln = sw.get_transform_from_rpyt(*ins_ext)
-    assert sw.init_slam("mapping", "", "FastLIO", ["lidar0", "IMU"], 0.5, 1.0, 10.0, 100) == ["lidar0", "IMU"]
-    sw.set_ins_external_param(*ins_ext)
-    sw.set_imu_external_param(*imu_ext)
-    assert sw.setup_slam(max_points=4_000_000, max_voxels=1 << 20)
-    imu = synth.imu_stream(tr, 0.0, 2.5, rate=200.0)
-    ii, n = 0, 22
-    T_ni = T_li @ np.linalg.inv(T_ln)  # INS -> IMU
-    W0 = np.eye(4)
-    W0[:3, :3], W0[:3, 3] = tr.R(0.0), tr.pos(0.0)
-    worst = 0.0
-    try:
-        for k in range(n):
-            tb = k * 0.1
-            pts, st = synth.make_sweep(scene, tr, tb, ext_R=T_li[:3, :3], ext_t=T_li[:3, 3], seed=k, fov_deg=(-24.8, 2.0))
-            rows = []
-            while ii < len(imu) and imu[ii][0] <= tb + 0.12:
-                t, g, a = imu[ii]
-                rows.append([t * 1e6, *(g * 180.0 / np.pi), *(a / 9.81)])
-                ii += 1
-            attr = dict(timestamp=int(round(tb * 1e6)), points_attr=np.stack([st.astype(np.float32), np.zeros(len(st), np.float32)], 1))
-            out = sw.process({"lidar0": pts}, {"lidar0": attr}, {}, {}, {}, {}, np.array(rows).reshape(-1, 7), int(round(tb * 1e6)))
-            assert out["slam_valid"] and out["frame_start_timestamp"] == int(round(tb * 1e6))
-            M = out["pose"]["odom_matrix"]
-            assert M.dtype == np.float32 and M.shape == (4, 4)
-            if k >= 8:  # registered scans: INS-frame odometry at the scan start vs the trajectory
-                Wt = np.eye(4)
-                Wt[:3, :3], Wt[:3, 3] = tr.R(tb), tr.pos(tb)
-                X = np.linalg.inv(W0) @ Wt                      # IMU pose in the filter's world
-                truth = np.linalg.inv(T_ni) @ X @ T_ni          # fastlio.cpp:269-270
-                dp = np.linalg.norm(M[:3, 3] - truth[:3, 3])
-                dr = np.arccos(min(1.0, (np.trace(M[:3, :3].astype(np.float64).T @ truth[:3, :3]) - 1) / 2))
-                worst = max(worst, dp)
-                assert dp < 0.04 and dr < 6e-3, (k, dp, dr)
-        with pytest.raises(NotImplementedError):
-            sw.get_graph_status()
-    finally:
-        sw.deinit_slam()
-    print("slam_wrapper.process: worst position error %.4f m" % worst)
-
-
 def test_front_half_edge_cases(oracle_mod, scene):
     """empty and all-blind clouds, the max_point_num decimation, an oversized scan, re-initialisation"""
     _dev()

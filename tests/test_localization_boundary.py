@@ -1,0 +1,45 @@
+"""The localisation mode at the reference's boundaries (inner boundary for the localisation half of the path):
+the reference's OWN nodelet loop -- hdl_localization_nodelet.cpp (IMU mean, predict, undistort, downsample, match, correct, ping-pong target
+hand-over) + pose_estimator.cpp, compiled whole -- with select_registration_method("NDT_CUDA") returning the NdtHip class of INTEGRATION.md
+section 3a (extracted from the document), LINKED against liblio_hip.so (oracle/ref_hdl_localization.cpp), driven through a 60-scan sequence on
+the GPU next to the same nodelet over the reference's own fast_gicp::NDTCuda (its CUDA kernels built for gfx950)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+
+
+def _rot_angle(A, B):
+    return float(np.arccos(np.clip((np.trace(A[:3, :3].T @ B[:3, :3]) - 1) / 2, -1, 1)))
+
+
+@pytest.mark.gpu
+def test_reference_localization_nodelet_linked_against_the_library():
+    import ref_hdl_localization as H
+
+    if not H.available():
+        pytest.fail("oracle/_ref/libref_hdl_localization.so did not travel with the snapshot (it is built where /root/reference exists)")
+    with tempfile.TemporaryDirectory() as td:
+        outs = {}
+        for variant in ("hip", "ref"):
+            out = os.path.join(td, variant + ".npz")
+            r = subprocess.run([sys.executable, os.path.join(HERE, "_hloc_worker.py"), variant, out], capture_output=True, text=True, timeout=1200)
+            assert r.returncode == 0, (variant, r.stderr[-3000:])
+            outs[variant] = dict(np.load(out))
+    a, b = outs["hip"], outs["ref"]
+    assert np.array_equal(a["codes"], b["codes"]) and int((a["codes"] == 0).sum()) >= 55  # LocType::OK nearly everywhere, on the same frames
+    dp = np.linalg.norm(a["poses"][:, :3, 3] - b["poses"][:, :3, 3], axis=1)
+    dr = np.array([_rot_angle(x, y) for x, y in zip(a["poses"], b["poses"])])
+    print("nodelet over NdtHip vs over the reference's NDTCuda: max |dp| %.2e m, max rot %.2e rad" % (dp.max(), dr.max()))
+    # the matcher bar of tests/test_ndt_vs_ref_cuda.py (the reference moves by ~1e-4 from run to run: f32 atomics) fed back through the filter
+    assert dp.max() < 2e-3 and dr.max() < 2e-4, (dp.max(), dr.max())
+    # and the loop localises: after the filter's first second (the reference starts its quaternion block at variance 0.1) it stays on the drive
+    et = np.linalg.norm(a["poses"][10:, :3, 3] - a["truth"][10:, :3, 3], axis=1)
+    assert et.max() < 0.15, et.max()  # docs/slam.md: decimetre-level localisation
+    assert bool(a["timed_ok"]) == bool(b["timed_ok"]) and np.abs(a["timed"] - b["timed"]).max() < 2e-3

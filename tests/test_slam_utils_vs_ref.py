@@ -33,7 +33,7 @@ def test_oracle_matches_the_references_slam_utils(oracle_mod):
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     from make_golden import undistort_delta_cases
-    from lsd_amd import slam_wrapper
+    import slam_wrapper  # the compiled module (lidar-slam-detection_amd/python/slam_wrapper.*.so)
 
     rng = np.random.default_rng(11)
     for rep in range(4):
@@ -50,7 +50,7 @@ def test_oracle_matches_the_references_slam_utils(oracle_mod):
     # getTransformFromRPYT (slam_utils.cpp:89-96) as restated for the slam_wrapper boundary
     for _ in range(50):
         a = rng.uniform(-180, 180, 6)
-        assert np.abs(slam_wrapper.get_transform_from_rpyt(*a) - rs.transform_from_rpyt(*a)).max() < 1e-14 * max(1.0, np.abs(a[:3]).max())
+        assert np.abs(slam_wrapper._transform_from_rpyt(*a) - rs.transform_from_rpyt(*a)).max() < 1e-14 * max(1.0, np.abs(a[:3]).max())
 
 
 GOLD_POSES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "undistort_poses.npz")
