@@ -464,7 +464,7 @@ def test_process_forwards_the_ins_velocity_to_the_front_half():
                 if vel is None and capi.lib().lio_fastlio_is_init(C.c_void_p(sw._engine_handle())):
                     s26 = np.zeros(26)
                     capi.lib().lio_fastlio_start_state(C.c_void_p(sw._engine_handle()), s26.ctypes.data_as(C.POINTER(C.c_double)))
-                    vel = s26[17:20].copy()  # pos3 rot4 R_il4 t_il3 vel3
+                    vel = s26[14:17].copy()  # pos3 rot4 R_il4 t_il3 vel3
             seen[label] = vel
         finally:
             sw.deinit_slam()
