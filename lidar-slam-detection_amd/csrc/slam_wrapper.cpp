@@ -160,7 +160,6 @@ struct Slam {
     double origin[6] = {0, 0, 0, 0, 0, 0};
     bool origin_set = false;
     bool ground_constraint = false, loop_closure = false, gravity_constraint = false, colouration = false;
-    py::dict ins_config;
     // SLAM::setInsConfig / preprocessInsData (slam.cpp:196-268): the GNSS status configurations in priority order, the state of the status filter
     struct InsCfg { std::string name; int status = 0, priority = -1; double stable_time = 0, precision = 0; };
     std::vector<InsCfg> ins_cfg;
@@ -795,7 +794,6 @@ void set_camera_param(py::list& cameras) { (void)cameras; }
 // pydict_to_ins_config (py_utils.cpp:295-317): ins_normal / ins_float / ins_fix entries with use, status, stable_time, precision
 void set_ins_config(py::dict& dict) {
     if (!g) return;
-    g->ins_config = dict;
     g->ins_cfg.clear();
     int priority = 0;
     for (const char* name : {"ins_normal", "ins_float", "ins_fix"}) {

@@ -5,7 +5,7 @@
 // with hdl_graph_slam::select_registration_method("NDT_CUDA", t) returning
 //   * NdtHip -- the pcl::Registration subclass INTEGRATION.md section 3a shows a maintainer, extracted from the document at build time
 //     (_ref/obj/ndt_hip.inc) -- or
-//   * RefNdt -- an adapter over the reference's own fast_gicp::NDTCuda object compiled for gfx950 (oracle/_ref/libref_ndt_cuda.so, loaded at
+//   * RefNdtAdapter -- an adapter over the reference's own fast_gicp::NDTCuda object compiled for gfx950 (oracle/_ref/libref_ndt_cuda.so, loaded at
 //     run time: its translation units need hipcc), the baseline the same nodelet is driven over.
 // undistortPoints / interpolateTransform are the reference's slam_utils.cpp (oracle/_ref/libref_slam_utils.so, loaded at run time).
 // tests/test_localization_boundary.py drives both variants through a localisation sequence on the GPU.  Test infrastructure only.
@@ -71,7 +71,7 @@ void undistortPoints(const Eigen::Matrix4f& delta_pose, PointCloudAttrPtr& point
 // ---- the two matchers behind select_registration_method ----
 #include "_ref/obj/ndt_hip.inc"
 
-class RefNdt : public pcl::Registration<pcl::PointXYZI, pcl::PointXYZI, float> {
+class RefNdtAdapter : public pcl::Registration<pcl::PointXYZI, pcl::PointXYZI, float> {
     using PointT = pcl::PointXYZI;
     void* h_;
     static std::vector<float> flat(const pcl::PointCloud<PointT>& c) {
@@ -81,12 +81,12 @@ class RefNdt : public pcl::Registration<pcl::PointXYZI, pcl::PointXYZI, float> {
     }
 
    public:
-    explicit RefNdt(int64_t max_process_time) {
+    explicit RefNdtAdapter(int64_t max_process_time) {
         static auto mk = reinterpret_cast<void* (*)(double, int, double)>(sym("libref_ndt_cuda.so", "ref_ndtreg_create"));
         h_ = mk(1.0, 7, (double)max_process_time);
         reg_name_ = "fast_gicp::NDTCuda (reference, gfx950 build)";
     }
-    ~RefNdt() override {
+    ~RefNdtAdapter() override {
         static auto rm = reinterpret_cast<void (*)(void*)>(sym("libref_ndt_cuda.so", "ref_ndtreg_destroy"));
         rm(h_);
     }
@@ -135,7 +135,7 @@ class RefNdt : public pcl::Registration<pcl::PointXYZI, pcl::PointXYZI, float> {
 static int g_use_reference_matcher = 0;
 namespace hdl_graph_slam {
 pcl::Registration<pcl::PointXYZI, pcl::PointXYZI>::Ptr select_registration_method(std::string, int64_t max_process_time) {
-    if (g_use_reference_matcher) return pcl::Registration<pcl::PointXYZI, pcl::PointXYZI>::Ptr(new RefNdt(max_process_time));
+    if (g_use_reference_matcher) return pcl::Registration<pcl::PointXYZI, pcl::PointXYZI>::Ptr(new RefNdtAdapter(max_process_time));
     return pcl::Registration<pcl::PointXYZI, pcl::PointXYZI>::Ptr(new NdtHip(max_process_time));
 }
 }  // namespace hdl_graph_slam

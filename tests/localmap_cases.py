@@ -35,7 +35,7 @@ def overlap_case(sc=None):
     rng = np.random.default_rng(21)
     cloud1 = sc.sample_surface(300_000, seed=33, sigma=0.01)
     cloud1 = cloud1[np.linalg.norm(cloud1[:, :2], axis=1) < 120.0][:60_000]
-    cloud1[:, 2] += 1.0
+    cloud1[:, 2] += 0.45  # the ground ends up just below the 0.5 m floor of the filter, boxes and walls above it
     T = np.eye(4)
     T[:3, :3] = synth.quat_to_R(synth.quat_from_rotvec([0.0, 0.01, 0.2]))
     T[:3, 3] = [2.0, -1.0, 0.05]

@@ -440,7 +440,7 @@ def test_process_forwards_the_ins_velocity_to_the_front_half():
     imu = synth.imu_stream(tr, 0.0, 1.5, rate=200.0)
     seen = {}
     for label, gnss_status in (("accepted", 4), ("rejected", 1)):
-        assert sw.init_slam("mapping", "", "FastLIO", ["0-lidar", "IMU", "RTK"], 0.5, 1.0, 10.0, 100) == ["RTK", "IMU", "0-lidar"]
+        assert sw.init_slam("mapping", "", "FastLIO", ["0-lidar", "IMU", "RTK"], 0.5, 1.0, 10.0, 100) == ["IMU", "RTK", "0-lidar"]
         sw._set_capacity(2_000_000, 1 << 19)
         sw.set_ins_external_param(0, 0, 0, 0, 0, 0)
         sw.set_imu_external_param(0, 0, 0, 0, 0, 0)
