@@ -846,6 +846,60 @@ def bench_localize(args, torch, local_rank):
             ref_inputs["target"] = cloud.cpu().numpy()
         n.close()
     del dense
+    # ---- the map-merge shape (overlap_merge.hpp:46-48,158-179): 64 new key frames x <= 3 candidate frames, every pair an independent alignment of the
+    # new frame (source) against the candidate (target) -- one lio_ndt_align_batch call against the per-alignment loop ------------------------------
+    merge = None
+    try:
+        n_t = 3
+        tgts = []
+        for k in range(n_t):  # three candidate frames: key-frame clouds (downsampled scans in the map frame) from the local map's neighbourhood
+            kpos = np.array([-6.0 + 6.0 * k, 1.0 - k, 1.8])
+            kq = synth.quat_from_rotvec([0, 0, 0.3 * k])
+            kraw, _ = synth.make_scan(scene, kpos, kq, seed=args.seed + 950 + k, n_az=args.n_az, fov_deg=(-24.8, 2.0), max_range=150.0)
+            s.upload(kraw)
+            s.voxel_downsample(leaf)
+            kds = s.get_ds()
+            kw = kds.copy()
+            kw[:, :3] = (kds[:, :3].astype(np.float64) @ synth.quat_to_R(kq).T + kpos).astype(np.float32)
+            t = lio.Ndt(resolution=1.0, search_method=7, max_points=len(kw) + 16, max_voxels=200_000, max_source_points=200000, device=local_rank)
+            t.set_target(kw)
+            tgts.append(t)
+        srcs = []
+        for w in range(len(pool)):
+            sc = lio.Scan(max_raw=1 << 18, max_ds=200000)
+            sc.set_device(pool[w]["d"].data_ptr(), len(pool[w]["raw"]))
+            sc.voxel_downsample(leaf)
+            srcs.append(sc)
+        jobs_s, jobs_g, jobs_t = [], [], []
+        for kf in range(64):
+            for c in range(n_t):
+                jobs_s.append(srcs[kf % len(srcs)])
+                gi = (kf % len(pool)) + len(pool) * (((kf // len(pool)) * n_t + c) % max(len(guesses) // len(pool), 1))  # a guess made for this source scan
+                jobs_g.append(guesses[gi % len(guesses)])
+                jobs_t.append(tgts[c])
+        prep = tgts[0].prepare_batch(jobs_s, jobs_g, jobs_t)
+        tgts[0].run_batch(prep)  # warm (allocates the slot buffers)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rcb = tgts[0].run_batch(prep)
+        t_batch = time.perf_counter() - t0
+        conv_b = sum(int(a.converged) for a in prep[0])
+        t0 = time.perf_counter()
+        conv_s, dmax = 0, 0.0
+        for i in range(len(jobs_s)):
+            Ta, cv, it = jobs_t[i].align(jobs_s[i], jobs_g[i])
+            conv_s += int(cv)
+            dmax = max(dmax, float(np.abs(Ta - np.array(prep[0][i].out).reshape(4, 4)).max()))
+        t_loop = time.perf_counter() - t0
+        merge = {"alignments": len(jobs_s), "targets": n_t, "batched_call_ms": round(1e3 * t_batch, 3), "per_alignment_loop_ms": round(1e3 * t_loop, 3),
+                 "ms_per_alignment_batched": round(1e3 * t_batch / len(jobs_s), 4), "ms_per_alignment_loop": round(1e3 * t_loop / len(jobs_s), 4),
+                 "converged_batched": conv_b, "converged_loop": conv_s, "max_abs_difference_of_the_results": dmax, "rc": int(rcb),
+                 "what": "overlap_merge.hpp:158-179's workload: 64 key frames x 3 candidate frames = 192 independent NDT alignments (source already downsampled); "
+                         "lio_ndt_align_batch (64 slots per launch, LM loop on the device) vs 192 lio_ndt_align calls"}
+        for t in tgts:
+            t.close()
+    except Exception as ex:
+        merge = {"error": repr(ex)[-300:]}
     # ---- baselines on the reference's semantic (local map), same scans, same guesses -------------------------------------------------------
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
@@ -914,7 +968,7 @@ def bench_localize(args, torch, local_rank):
            "config": {"workload": "BASELINE config 4: %d scans of 64x%d rays (~%d pts), leaf-0.2 VoxelGrid + NDT-P2D (res 1.0, DIRECT7) LM alignment from a guess within "
                                   "0.5 m / 3 deg vs a %d-pt map resident in HBM (map generated on the GPU in %.1f s)" % (args.steps, args.n_az, n_raw, args.dense_points, t_gen),
                       "n_raw": n_raw, "leaf": leaf, "resident_map": {k: v for k, v in head.items() if k != "roofline"},
-                      "local_200k_map": cases["local_200k"], "local_map_key_frames_used": nk_used},
+                      "local_200k_map": cases["local_200k"], "local_map_key_frames_used": nk_used, "merge_candidates_batched": merge},
            "roofline": head["roofline"], "cpu_baseline": cpu, "pose_error_vs_truth_m": head["pos_err_m_max"]}
     print(json.dumps(out))
 

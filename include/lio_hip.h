@@ -476,6 +476,23 @@ void lio_ndt_default_params(lio_ndt_params*);
 int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_ndt_params* params, double out[16], int* iterations,
                   int* converged);
 
+/* Batched alignments: the map-merge / loop-closure / relocalisation tools evaluate several candidates per key frame (slam/localization/include/
+ * overlap_merge.hpp:158-179: 64 key frames x <= 3 candidates, every one an independent registration->align) -- here B of them per launch against
+ * one or several targets: slot = (target, source scan, guess), the Levenberg-Marquardt loop of LsqRegistration (lsq_registration_impl.hpp:71-208) resident on the
+ * device, a round = {cost evaluation of the slots that linearise, of the slots that try a step, LM kernel}, every launch serving all slots; the
+ * host looks at the slots' states every six rounds.  Same schedule, stopping rules and results as lio_ndt_align job by job (to the rounding of
+ * the device's libm); max_process_time_ms does not apply.  Sources: lio_scan objects holding their downsampled clouds (lio_scan_voxel_downsample /
+ * lio_scan_set_ds), at most max_source_points each. */
+typedef struct lio_align_job {
+    lio_ndt* target;         /* NULL: the matcher the call is made on; else another target of the same resolution / search method / device
+                                (a new key frame against each of its candidate frames: setInputTarget per candidate in the reference) */
+    lio_scan* source;
+    const double* guess;     /* row-major 4 x 4 */
+    double out[16];          /* final transformation */
+    int32_t iterations, converged, evaluations, rc;
+} lio_align_job;
+int lio_ndt_align_batch(lio_ndt*, lio_align_job* jobs, int n_jobs, const lio_ndt_params* params);
+
 /* ---------------------------------------------------------------------------------------------
  * Generalized-ICP: replaces fast_gicp::FastGICP<PointXYZI, PointXYZI> as select_registration_method("FAST_GICP") configures it
  * (slam/backend/hdl_graph_slam/src/hdl_graph_slam/registrations.cpp:33-42) -- the fine matcher of the map merge / loop closure tools

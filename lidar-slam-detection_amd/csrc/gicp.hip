@@ -436,12 +436,18 @@ int gicp_set_cloud(lio_gicp* g, int which, const float* xyzi, uint32_t n) {
     if (n > g->max_points) { set_error("lio_gicp: cloud of %u points exceeds max_points %u", n, g->max_points); return LIO_E_CAPACITY; }
     if ((int)n < g->k) { set_error("lio_gicp: a cloud needs at least k = %d points", g->k); return LIO_E_INVALID; }
     hipSetDevice(g->device);
-    // a fresh grid per cloud: the first batch into an empty map is laid out exactly (cell by cell, contiguous from the start of the pool)
-    if (g->grid[which]) lio_map_destroy(g->grid[which]);
-    g->grid[which] = lio_map_create(g->device, g->res, g->max_points, g->max_points, 1);
-    if (!g->grid[which]) return LIO_E_DEVICE;
+    // an EMPTY grid per cloud: the first batch into an empty map is laid out exactly (cell by cell, contiguous from the start of the pool).
+    // The grid object is made once and emptied in place afterwards (map_clear: memsets; a fresh lio_map_create per call was 5-65 ms of
+    // hipMalloc / hipFree, more than the covariances)
+    if (!g->grid[which]) {
+        g->grid[which] = lio_map_create(g->device, g->res, g->max_points, g->max_points, 1);
+        if (!g->grid[which]) return LIO_E_DEVICE;
+        g->grid[which]->key_mode = 1;
+    } else {
+        const int rc0 = map_clear(g->grid[which]);
+        if (rc0 != LIO_OK) return rc0;
+    }
     lio_map* m = g->grid[which];
-    m->key_mode = 1;
     hipStream_t st = m->stream;
     LIO_HIP_TRY(hipMemcpyAsync(g->stage, xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, st));
     int rc = lio_map_insert_device(m, g->stage, n, 0.0);
@@ -459,12 +465,19 @@ int vgicp_build(lio_gicp* g) {
     lio_map* mt = g->grid[0];
     hipStream_t st = mt->stream;
     const uint32_t n = g->n[0];
-    if (g->vmap) { lio_map_destroy(g->vmap); g->vmap = nullptr; }
-    if (g->vvox) { hipFree(g->vvox); g->vvox = nullptr; }
-    g->vmap = lio_map_create(g->device, (float)g->voxel_res, g->max_points, g->max_points, 1);
-    if (!g->vmap) return LIO_E_DEVICE;
-    g->vmap->key_mode = 2;
-    LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->vvox), (size_t)g->vmap->table_cap * sizeof(VgicpVoxel)));
+    if (g->vmap && g->vmap->res != (float)g->voxel_res) {  // another voxel size: another grid
+        lio_map_destroy(g->vmap); g->vmap = nullptr;
+        hipFree(g->vvox); g->vvox = nullptr;
+    }
+    if (!g->vmap) {
+        g->vmap = lio_map_create(g->device, (float)g->voxel_res, g->max_points, g->max_points, 1);
+        if (!g->vmap) return LIO_E_DEVICE;
+        g->vmap->key_mode = 2;
+        LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->vvox), (size_t)g->vmap->table_cap * sizeof(VgicpVoxel)));
+    } else {
+        const int rc0 = map_clear(g->vmap);
+        if (rc0 != LIO_OK) return rc0;
+    }
     hipLaunchKernelGGL(vgicp_stamp_kernel, (n + 255) / 256, 256, 0, st, mt->pool, g->stage, n);
     LIO_HIP_TRY(hipStreamSynchronize(st));
     const int rc = lio_map_insert_device(g->vmap, g->stage, n, 0.0);

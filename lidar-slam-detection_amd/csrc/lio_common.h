@@ -284,4 +284,5 @@ int p2plane_linearize_begin(lio_map* m, lio_scan* s, const double pose_wi[7], co
 int p2plane_linearize_end(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], int redo_knn, lio_normal_eq* out);
 int scan_share_ds(lio_scan* dst, lio_scan* src, uint32_t n);
 int scan_forget_cache(lio_scan* s);
+int map_clear(lio_map* m);
 }

@@ -10,10 +10,16 @@
 
 #include "../../include/lio_hip.h"
 
+#if defined(__HIPCC__)
+#define LSQ_FN __host__ __device__ inline
+#else
+#define LSQ_FN inline
+#endif
+
 namespace lio {
 
-// ---- host side: SE(3) and the LM step (lsq_registration_impl.hpp, so3.hpp), f64 ----------------------------------
-inline void se3_exp_h(const double a[6], double T[16]) {
+// ---- SE(3) and the LM step (lsq_registration_impl.hpp, so3.hpp), f64: host, and device for the batched aligner (ndt.hip) -----------
+LSQ_FN void se3_exp_h(const double a[6], double T[16]) {
     const double wx = a[0], wy = a[1], wz = a[2];
     const double theta_sq = wx * wx + wy * wy + wz * wz;
     double imag, real;
@@ -46,11 +52,11 @@ inline void se3_exp_h(const double a[6], double T[16]) {
         T[i * 4 + 3] = V[i * 3] * a[3] + V[i * 3 + 1] * a[4] + V[i * 3 + 2] * a[5];
     }
 }
-inline void mul44_h(const double A[16], const double B[16], double C[16]) {
+LSQ_FN void mul44_h(const double A[16], const double B[16], double C[16]) {
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j]; C[i * 4 + j] = s; }
 }
-inline double rot_angle_deg_h(const double T[16]) {  // Eigen::AngleAxisd(delta.linear()).angle() / pi * 180 (via the quaternion)
+LSQ_FN double rot_angle_deg_h(const double T[16]) {  // Eigen::AngleAxisd(delta.linear()).angle() / pi * 180 (via the quaternion)
     const double tr = T[0] + T[5] + T[10];
     double w, x, y, z;
     if (tr > 0) {
@@ -73,12 +79,12 @@ inline double rot_angle_deg_h(const double T[16]) {  // Eigen::AngleAxisd(delta.
     return 2.0 * atan2(sqrt(x * x + y * y + z * z), fabs(w)) / M_PI * 180.0;
 }
 // (H + lambda I) d = -b by LDL^T on the lower triangle (the reference: Eigen::LDLT<Matrix<double,6,6>>, same solution)
-inline bool ldlt_solve6(const double A[36], const double rhs[6], double x[6]) {
+LSQ_FN bool ldlt_solve6(const double A[36], const double rhs[6], double x[6]) {
     double L[36] = {0}, D[6];
     for (int j = 0; j < 6; j++) {
         double d = A[j * 6 + j];
         for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k] * D[k];
-        if (d == 0.0 || !std::isfinite(d)) return false;
+        if (d == 0.0 || !(d - d == 0.0)) return false;  // (zero pivot, NaN or infinity)
         D[j] = d;
         L[j * 6 + j] = 1.0;
         for (int i = j + 1; i < 6; i++) {
@@ -93,7 +99,7 @@ inline bool ldlt_solve6(const double A[36], const double rhs[6], double x[6]) {
     for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
     return true;
 }
-inline bool converged_h(const lio_ndt_params& p, const double D[16], double loosen) {
+LSQ_FN bool converged_h(const lio_ndt_params& p, const double D[16], double loosen) {
     const double r_delta = 1.0 / (p.rotation_epsilon_deg * loosen) * rot_angle_deg_h(D);
     double tmax = 0;
     for (int i = 0; i < 3; i++) tmax = fmax(tmax, 1.0 / (p.transformation_epsilon * loosen) * fabs(D[i * 4 + 3]));

@@ -292,12 +292,11 @@ struct NdtReport {  // mapped pinned host memory
 // one cost evaluation.  UPDATE: look the neighbour voxels up at x_lin and cache them (find_voxel_correspondences);
 // DERIV: accumulate H and b besides the error (linearize) -- otherwise the error only (LM trial, compute_error)
 template <bool UPDATE, bool DERIV, int NO>
-__global__ void __launch_bounds__(kNdtThreads) ndt_cost_kernel(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox,
-                                                               float res, NdtOffsets offs, NdtXform x_lin, NdtXform x,
-                                                               const float4* __restrict__ src, const ScanDev* __restrict__ sd,
-                                                               uint32_t* __restrict__ corr, uint32_t corr_stride, double* __restrict__ partial,
-                                                               NdtDev* nd) {
-    const uint32_t n = sd->n_ds;
+__device__ __forceinline__ void ndt_cost_body(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox,
+                                              float res, const NdtOffsets& offs, const NdtXform& x_lin, const NdtXform& x,
+                                              const float4* __restrict__ src, uint32_t n,
+                                              uint32_t* __restrict__ corr, uint32_t corr_stride, double* __restrict__ partial, uint32_t pstride,
+                                              uint32_t* n_corr_counter) {
     if (blockIdx.x * kNdtThreads >= n) return;
     const uint32_t i = blockIdx.x * kNdtThreads + threadIdx.x;
     constexpr int NA = DERIV ? kNdtAcc : 1;
@@ -390,38 +389,168 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_kernel(const Slot* __res
             s += v.x;
             s += v.y;
         }
-        partial[(size_t)blockIdx.x * kNdtAcc + threadIdx.x] = s;
+        partial[(size_t)threadIdx.x * pstride + blockIdx.x] = s;  // [component][workgroup]: the fold reads a component's partials as one contiguous run
     }
     if (UPDATE) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) my_corr += __shfl_xor(my_corr, off);
-        if (threadIdx.x == 0 && my_corr) atomicAdd(&nd->n_corr, my_corr);
+        if (threadIdx.x == 0 && my_corr) atomicAdd(n_corr_counter, my_corr);
     }
 }
 
-__global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial, int na, NdtDev* nd,
+template <bool UPDATE, bool DERIV, int NO>
+__global__ void __launch_bounds__(kNdtThreads) ndt_cost_kernel(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox,
+                                                               float res, NdtOffsets offs, NdtXform x_lin, NdtXform x,
+                                                               const float4* __restrict__ src, const ScanDev* __restrict__ sd,
+                                                               uint32_t* __restrict__ corr, uint32_t corr_stride, double* __restrict__ partial,
+                                                               uint32_t pstride, NdtDev* nd) {
+    ndt_cost_body<UPDATE, DERIV, NO>(table, mask, vox, res, offs, x_lin, x, src, sd->n_ds, corr, corr_stride, partial, pstride, &nd->n_corr);
+}
+
+// ---- batched alignments: slot = one alignment (its own source scan and guess) against the ONE target, the Levenberg-Marquardt loop of
+// LsqRegistration (lsq.h) resident on the device.  A round = {cost kernel for the slots that linearise, cost kernel for the slots that try a
+// step, LM kernel}: every launch serves all slots (blockIdx.y), a slot that is done exits at once.  The map-merge / loop-closure /
+// relocalisation tools evaluate several candidates per key frame (overlap_merge.hpp:158-179): independent alignments against one target.
+struct NdtLmSlot {
+    const Slot* table;     // the slot's target (alignments of one launch may run against different targets of the same resolution)
+    const NdtVoxel* vox;
+    uint32_t mask, pad1;
+    const float4* src;
+    const ScanDev* sd;
+    uint32_t* corr;
+    double* partial;
+    uint32_t corr_stride, active, pstride, pad0;
+    double x0[16], xi[16], delta[16], H[36], b[6], d[6];
+    double y0, lambda, nu;
+    int32_t phase;  // 0: linearise at x0 (correspondences + cost + H + b); 1: cost of the trial xi on the cached pairs; 2: done
+    int32_t it, trial, conv, evals, it_done;
+    uint32_t n_corr, pad;
+};
+struct NdtLmParams {
+    int32_t max_iterations, lm_max_iterations;
+    double rotation_epsilon_deg, transformation_epsilon, lm_init_lambda_factor;
+};
+
+__device__ inline NdtXform xform_of(const double T[16]) {
+    NdtXform x;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) x.R[i * 3 + j] = (float)T[i * 4 + j]; x.t[i] = (float)T[i * 4 + 3]; }
+    return x;
+}
+
+template <bool LIN, int NO>
+__global__ void __launch_bounds__(kNdtThreads) ndt_cost_batch(float res, NdtOffsets offs, NdtLmSlot* __restrict__ slots) {
+    NdtLmSlot& s = slots[blockIdx.y];
+    if (!s.active || s.phase != (LIN ? 0 : 1)) return;
+    const uint32_t n = s.sd->n_ds;
+    const Slot* __restrict__ table = s.table;
+    const NdtVoxel* __restrict__ vox = s.vox;
+    const uint32_t mask = s.mask;
+    if (LIN) {
+        const NdtXform x = xform_of(s.x0);
+        ndt_cost_body<true, true, NO>(table, mask, vox, res, offs, x, x, s.src, n, s.corr, s.corr_stride, s.partial, s.pstride, &s.n_corr);
+    } else {
+        const NdtXform xl = xform_of(s.x0), x = xform_of(s.xi);
+        ndt_cost_body<false, false, NO>(table, mask, vox, res, offs, xl, x, s.src, n, s.corr, s.corr_stride, s.partial, s.pstride, &s.n_corr);
+    }
+}
+
+// the fold of the workgroup partials by a 1024-thread workgroup: wave w takes components w, w + 16, w + 32; lane l adds workgroups l, l + 64, ...
+// (coalesced: the layout is [component][workgroup]), then a fixed xor tree over the wave -- one order, run-to-run identical
+__device__ __forceinline__ void ndt_fold(const double* __restrict__ partial, uint32_t pstride, uint32_t nb, int na, double* acc /* LDS, kNdtAcc */) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wave; c < na; c += 16) {
+        double v = 0.0;
+        for (uint32_t b = lane; b < nb; b += 64) v += partial[(size_t)c * pstride + b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) acc[c] = v;
+    }
+    __syncthreads();
+}
+
+// per slot: the block partials folded in ndt_report_kernel's order, then one lane runs the step of lsq_align (lsq.h) the slot is at
+__global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict__ slots, NdtLmParams P) {
+    NdtLmSlot& s = slots[blockIdx.x];
+    if (!s.active || s.phase == 2) return;
+    __shared__ double acc[kNdtAcc];
+    const int tid = threadIdx.x;
+    const uint32_t nb = (s.sd->n_ds + kNdtThreads - 1) / kNdtThreads;
+    const int na = s.phase == 0 ? kNdtAcc : 1;
+    ndt_fold(s.partial, s.pstride, nb, na, acc);
+    if (tid != 0) return;
+    lio_ndt_params p;
+    p.max_iterations = P.max_iterations; p.lm_max_iterations = P.lm_max_iterations; p.rotation_epsilon_deg = P.rotation_epsilon_deg;
+    p.transformation_epsilon = P.transformation_epsilon; p.lm_init_lambda_factor = P.lm_init_lambda_factor; p.max_process_time_ms = -1;
+    s.evals++;
+    bool make_trial = false, end_iteration = false;
+    if (s.phase == 0) {  // the linearisation at x0 (LsqRegistration::computeTransformation, loop head)
+        for (int k = 0; k < 36; k++) s.H[k] = acc[k];
+        for (int k = 0; k < 6; k++) s.b[k] = acc[36 + k];
+        s.y0 = acc[42];
+        s.it_done = s.it;
+        if (s.lambda < 0.0) {
+            double mx = 0;
+            for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(s.H[i * 7]));
+            s.lambda = p.lm_init_lambda_factor * mx;
+        }
+        s.nu = 2.0;
+        s.trial = 0;
+        make_trial = true;
+    } else {  // the cost of the trial step (step_lm)
+        const double yi = acc[0];
+        double den = 0;
+        for (int k = 0; k < 6; k++) den += s.d[k] * (s.lambda * s.d[k] - s.b[k]);
+        const double rho = (s.y0 - yi) / den;
+        if (rho < 0) {
+            if (converged_h(p, s.delta, 10.0)) {
+                end_iteration = true;
+            } else {
+                s.lambda = s.nu * s.lambda;
+                s.nu = 2 * s.nu;
+                s.trial++;
+                if (s.trial >= p.lm_max_iterations) { s.phase = 2; s.conv = 0; }  // "lm not converged!!"
+                else make_trial = true;
+            }
+        } else {
+            for (int k = 0; k < 16; k++) s.x0[k] = s.xi[k];
+            s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+            end_iteration = true;
+        }
+    }
+    if (make_trial) {
+        double A[36], nb6[6];
+        for (int k = 0; k < 36; k++) A[k] = s.H[k] + ((k % 7 == 0) ? s.lambda : 0.0);
+        for (int k = 0; k < 6; k++) nb6[k] = -s.b[k];
+        if (!ldlt_solve6(A, nb6, s.d)) { s.phase = 2; s.conv = 0; }
+        else {
+            se3_exp_h(s.d, s.delta);
+            mul44_h(s.delta, s.x0, s.xi);
+            s.phase = 1;
+        }
+    }
+    if (end_iteration) {
+        s.conv = converged_h(p, s.delta, 1.0) ? 1 : 0;
+        s.it++;
+        s.phase = (s.conv || s.it >= p.max_iterations) ? 2 : 0;
+        if (s.phase == 0) s.n_corr = 0;  // the next linearisation counts its correspondences afresh
+    }
+}
+
+__global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial, uint32_t pstride, int na, NdtDev* nd,
                                                           NdtReport* __restrict__ out) {
     __shared__ double acc[kNdtAcc];
     const int tid = threadIdx.x;
     const uint32_t nb = (sd->n_ds + kNdtThreads - 1) / kNdtThreads;
-    if (tid < kNdtAcc) acc[tid] = 0.0;
-    __syncthreads();
-    // component c owned by lanes c*16 .. c*16+15 (43 * 16 = 688 lanes): stride-16 chunks, then a fixed xor tree
-    {
-        const int c = tid >> 4, l = tid & 15;
-        double s = 0.0;
-        if (c < na)
-            for (uint32_t b = l; b < nb; b += 16) s += partial[(size_t)b * kNdtAcc + c];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (c < na && l == 0) acc[c] = s;
+    ndt_fold(partial, pstride, nb, na, acc);
+    // the record leaves through 43 lanes at once (a handful of PCIe writes), then one system-scope fence and the sequence word
+    if (tid < 64) {
+        if (na == 1) { if (tid == 0) out->acc[42] = acc[0]; }
+        else if (tid < kNdtAcc) out->acc[tid] = acc[tid];
+        if (tid == 63) out->n_corr = nd->n_corr;
+        __threadfence_system();
     }
     __syncthreads();
     if (tid == 0) {
-        if (na == 1) { out->acc[42] = acc[0]; }
-        else for (int k = 0; k < kNdtAcc; k++) out->acc[k] = acc[k];
-        out->n_corr = nd->n_corr;
-        __threadfence_system();
         const uint32_t seq = nd->seq + 1u;
         nd->seq = seq;
         *reinterpret_cast<volatile uint32_t*>(&out->seq) = seq;
@@ -511,7 +640,7 @@ struct lio_ndt {
     NdtVoxel* vox;
     NdtOffsets offs;
     uint32_t* corr;  // [n_offsets][max_src]
-    uint32_t max_src;
+    uint32_t max_src, pstride;
     double* partial;
     NdtDev* dev;
     NdtReport* report;      // mapped host
@@ -523,6 +652,12 @@ struct lio_ndt {
     uint64_t stamp_cap;
     uint64_t max_points;
     int method;
+    // batched alignments (lio_ndt_align_batch): slot buffers, made on first use
+    struct NdtLmSlot* d_slots;
+    struct NdtLmSlot* h_slots;  // pinned
+    uint32_t* b_corr;
+    double* b_partial;
+    int b_slots;
     // live timing of ndt_cost_kernel (bench.py --config localize): HIP events on the stream it is launched on
     int timing;
     hipEvent_t ev[2];
@@ -578,7 +713,7 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
     if (n->timing) hipEventRecord(n->ev[0], st);
 #define NDT_LAUNCH(U, D, NO)                                                                                                                       \
     hipLaunchKernelGGL((ndt_cost_kernel<U, D, NO>), blocks, kNdtThreads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xl, xx, \
-                       s->ds_body, s->dev, n->corr, n->max_src, n->partial, n->dev)
+                       s->ds_body, s->dev, n->corr, n->max_src, n->partial, n->pstride, n->dev)
 #define NDT_DISPATCH(NO)                            \
     do {                                            \
         if (update && deriv) NDT_LAUNCH(true, true, NO);   \
@@ -592,7 +727,7 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
 #undef NDT_DISPATCH
 #undef NDT_LAUNCH
     if (n->timing) hipEventRecord(n->ev[1], st);
-    hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, deriv ? kNdtAcc : 1, n->dev, n->report_dev);
+    hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, n->pstride, deriv ? kNdtAcc : 1, n->dev, n->report_dev);
     LIO_HIP_TRY(hipGetLastError());
     n->seq_expected++;
     const int rc = ndt_wait(n, st);
@@ -633,6 +768,7 @@ lio_ndt* lio_ndt_create(int device, float resolution, int search_method, uint64_
     n->device = device;
     n->res = resolution;
     n->max_src = max_source_points;
+    n->pstride = (max_source_points + kNdtThreads - 1) / kNdtThreads;
     n->max_points = max_points;
     n->stamp_cap = max_points;
     bool ok = hipMalloc(reinterpret_cast<void**>(&n->vox), (size_t)n->map->table_cap * sizeof(NdtVoxel)) == hipSuccess &&
@@ -658,6 +794,10 @@ void lio_ndt_destroy(lio_ndt* n) {
     if (n->map) { hipStreamSynchronize(n->map->stream); lio_map_destroy(n->map); }
     hipFree(n->vox); hipFree(n->corr); hipFree(n->partial); hipFree(n->dev); hipFree(n->stamp); hipFree(n->list); hipFree(n->list_cnt);
     if (n->report) hipHostFree(n->report);
+    if (n->d_slots) hipFree(n->d_slots);
+    if (n->h_slots) hipHostFree(n->h_slots);
+    if (n->b_corr) hipFree(n->b_corr);
+    if (n->b_partial) hipFree(n->b_partial);
     if (n->ev[0]) { hipEventDestroy(n->ev[0]); hipEventDestroy(n->ev[1]); }
     delete n;
 }
@@ -691,12 +831,7 @@ int lio_ndt_set_target_device(lio_ndt* n, const void* d_xyzi, uint64_t np) {
     lio_map* m = n->map;
     hipStream_t st = m->stream;
     // setInputTarget replaces the target: start from an empty grid
-    LIO_HIP_TRY(hipMemsetAsync(m->table, 0xFF, (size_t)m->table_cap * sizeof(Slot), st));
-    LIO_HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(m->table) + 8, sizeof(Slot), 0, 8, m->table_cap, st));
-    LIO_HIP_TRY(hipMemsetAsync(m->cap, 0, (size_t)m->table_cap * 4, st));
-    LIO_HIP_TRY(hipMemsetAsync(m->pending, 0, (size_t)m->table_cap * 4, st));
-    LIO_HIP_TRY(hipMemsetAsync(m->dev, 0, sizeof(MapDev), st));
-    m->n_batches = 0;
+    { const int rc0 = map_clear(m); if (rc0 != LIO_OK) return rc0; }
     if (np) {
         uint64_t blocks = (np + 255) / 256;
         if (blocks > 8192) blocks = 8192;
@@ -832,6 +967,98 @@ int lio_ndt_align(lio_ndt* n, lio_scan* s, const double guess[16], const lio_ndt
     auto lin = [&](const double x[16], double H[36], double b[6], double* y) { return ndt_eval(n, s, x, x, true, true, H, b, y, nullptr); };
     auto err = [&](const double x_lin[16], const double x[16], double* y) { return ndt_eval(n, s, x_lin, x, false, false, nullptr, nullptr, y, nullptr); };
     return lsq_align(p, guess, lin, err, out, iterations, converged);
+}
+
+// B alignments per launch against this target: see ndt_cost_batch / ndt_lm_step_batch.  Same LM schedule and stopping rules as lio_ndt_align
+// (lsq.h compiled for the device); the wall-clock cut-off (max_process_time_ms) does not apply.
+int lio_ndt_align_batch(lio_ndt* n, lio_align_job* jobs, int n_jobs, const lio_ndt_params* prm) {
+    if (!n || (!jobs && n_jobs) || n_jobs < 0) return LIO_E_INVALID;
+    if (n_jobs == 0) return LIO_OK;
+    hipSetDevice(n->device);
+    lio_ndt_params p;
+    if (prm) p = *prm; else lio_ndt_default_params(&p);
+    constexpr int kSlots = 64;
+    const size_t corr_per = (size_t)n->offs.n * n->max_src, part_per = (size_t)((n->max_src + kNdtThreads - 1) / kNdtThreads) * kNdtAcc;
+    if (!n->d_slots) {
+        bool ok = hipMalloc(reinterpret_cast<void**>(&n->d_slots), sizeof(NdtLmSlot) * kSlots) == hipSuccess &&
+                  hipHostMalloc(reinterpret_cast<void**>(&n->h_slots), sizeof(NdtLmSlot) * kSlots, hipHostMallocDefault) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&n->b_corr), corr_per * 4 * kSlots) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&n->b_partial), part_per * 8 * kSlots) == hipSuccess;
+        if (!ok) { set_error("lio_ndt_align_batch: allocation failed: %s", hipGetErrorString(hipGetLastError())); return LIO_E_DEVICE; }
+        n->b_slots = kSlots;
+    }
+    hipStream_t st = n->map->stream;
+    LIO_HIP_TRY(hipStreamSynchronize(st));
+    NdtLmParams P{p.max_iterations, p.lm_max_iterations, p.rotation_epsilon_deg, p.transformation_epsilon, p.lm_init_lambda_factor};
+    int first_err = LIO_OK;
+    for (int base = 0; base < n_jobs; base += kSlots) {
+        const int B = n_jobs - base < kSlots ? n_jobs - base : kSlots;
+        uint32_t max_n = 0;
+        for (int k = 0; k < B; k++) {
+            lio_align_job& j = jobs[base + k];
+            NdtLmSlot& s = n->h_slots[k];
+            memset(&s, 0, sizeof(s));
+            j.rc = LIO_E_INVALID;
+            j.iterations = j.converged = j.evaluations = 0;
+            if (!j.source || !j.guess || j.source->device != n->device) continue;
+            lio_ndt* tgt = j.target ? j.target : n;
+            if (tgt->device != n->device || tgt->res != n->res || tgt->method != n->method) { set_error("lio_ndt_align_batch: the targets of one call share device, resolution and search method"); continue; }
+            if (tgt != n) LIO_HIP_TRY(hipStreamSynchronize(tgt->map->stream));  // its voxel map is complete
+            LIO_HIP_TRY(hipStreamSynchronize(j.source->stream));  // its downsampled cloud is complete
+            s.table = tgt->map->table;
+            s.mask = tgt->map->table_mask;
+            s.vox = tgt->vox;
+            const uint32_t bound = j.source->have_ds > 0 ? (uint32_t)j.source->have_ds : j.source->max_ds;
+            if (bound > n->max_src) { set_error("source scan of %u points exceeds the matcher's capacity %u", bound, n->max_src); j.rc = LIO_E_CAPACITY; continue; }
+            s.src = j.source->ds_body;
+            s.sd = j.source->dev;
+            s.corr = n->b_corr + corr_per * k;
+            s.partial = n->b_partial + part_per * k;
+            s.corr_stride = n->max_src;
+            s.pstride = n->pstride;
+            s.active = 1;
+            memcpy(s.x0, j.guess, sizeof(s.x0));
+            s.lambda = -1.0;
+            j.rc = LIO_OK;
+            if (bound > max_n) max_n = bound;
+        }
+        if (max_n == 0) continue;
+        LIO_HIP_TRY(hipMemcpyAsync(n->d_slots, n->h_slots, sizeof(NdtLmSlot) * B, hipMemcpyHostToDevice, st));
+        const dim3 grid((max_n + kNdtThreads - 1) / kNdtThreads, (uint32_t)B);
+        const int max_rounds = p.max_iterations * (p.lm_max_iterations + 1) + 2;
+        bool all_done = false;
+        for (int r = 0; r < max_rounds && !all_done;) {
+            for (int k = 0; k < 6 && r < max_rounds; k++, r++) {
+#define NDTB_LAUNCH(NO)                                                                                                                          \
+    do {                                                                                                                                         \
+        hipLaunchKernelGGL((ndt_cost_batch<true, NO>), grid, kNdtThreads, 0, st, n->res, n->offs, n->d_slots);  \
+        hipLaunchKernelGGL((ndt_cost_batch<false, NO>), grid, kNdtThreads, 0, st, n->res, n->offs, n->d_slots); \
+    } while (0)
+                if (n->offs.n == 1) NDTB_LAUNCH(1);
+                else if (n->offs.n == 7) NDTB_LAUNCH(7);
+                else NDTB_LAUNCH(27);
+#undef NDTB_LAUNCH
+                hipLaunchKernelGGL(ndt_lm_step_batch, dim3((uint32_t)B), 1024, 0, st, n->d_slots, P);
+            }
+            LIO_HIP_TRY(hipGetLastError());
+            LIO_HIP_TRY(hipMemcpyAsync(n->h_slots, n->d_slots, sizeof(NdtLmSlot) * B, hipMemcpyDeviceToHost, st));
+            LIO_HIP_TRY(hipStreamSynchronize(st));
+            all_done = true;
+            for (int k = 0; k < B; k++)
+                if (n->h_slots[k].active && n->h_slots[k].phase != 2) all_done = false;
+        }
+        for (int k = 0; k < B; k++) {
+            lio_align_job& j = jobs[base + k];
+            const NdtLmSlot& s = n->h_slots[k];
+            if (!s.active) { if (j.rc < 0 && first_err == LIO_OK) first_err = j.rc; continue; }
+            memcpy(j.out, s.x0, sizeof(j.out));
+            j.iterations = s.it_done;
+            j.converged = s.conv;
+            j.evaluations = s.evals;
+            j.rc = s.phase == 2 ? LIO_OK : LIO_E_STATE;
+        }
+    }
+    return first_err;
 }
 
 }  // extern "C"

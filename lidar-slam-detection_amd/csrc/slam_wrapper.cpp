@@ -296,7 +296,7 @@ bool load_keyframes(const std::string& map_path, std::vector<KeyFrameDisk>& out)
 // Localization::init (localization.cpp:91-131) without the graph back end and the global locator: the key frames of the map go to HBM once
 bool loc_setup(Slam* s) {
     Loc& L = *s->loc;
-    if (!load_keyframes(s->map_path, L.frames)) return false;  // "Map Loader: error to load map"
+    if (L.frames.empty()) return false;  // "Map Loader: error to load map" (setup_slam read the key frames from disk)
     uint64_t total = 0;
     uint32_t biggest = 0;
     for (const KeyFrameDisk& kf : L.frames) { total += kf.xyzi.size() / 4; biggest = std::max<uint32_t>(biggest, (uint32_t)(kf.xyzi.size() / 4)); }
@@ -546,6 +546,7 @@ void set_imu_external_param(double x, double y, double z, double yaw, double pit
 
 bool setup_slam() {
     require((bool)g, "init_slam first");
+    if (g->loc) load_keyframes(g->map_path, g->loc->frames);  // host side of MapLoader: get_graph_map serves the key frames whatever follows
     if (lio_device_count() < 1) return false;  // the reference logs and returns false from setup() when the back end cannot start
     if (g->loc) return loc_setup(g.get());
     // HDL_FastLIO::init (fastlio.cpp:153-171): T_imu_ins = T_imu * T_static^-1 is the (INS-frame cloud) -> IMU extrinsic
@@ -855,9 +856,9 @@ py::dict merge_map(const std::string& directory) { (void)directory; return py::d
 // (points N x 4 f32 as stored, pose 4 x 4 f32, stamp); empty in mapping mode (the graph back end is out of scope)
 py::dict get_graph_map() {
     py::dict d;
-    if (!g || !g->loc || g->loc->frames.empty()) return d;
     py::dict points, images, poses, stamps;
-    for (const KeyFrameDisk& kf : g->loc->frames) {
+    static const std::vector<KeyFrameDisk> none;
+    for (const KeyFrameDisk& kf : (g && g->loc) ? g->loc->frames : none) {
         const std::string id = std::to_string(kf.id);
         const py::ssize_t n = (py::ssize_t)(kf.local.size() / 4);
         py::array_t<float> a({n, (py::ssize_t)4});

@@ -36,7 +36,7 @@ SYMBOLS = [
     "lio_fastlio_main", "lio_fastlio_odometry", "lio_fastlio_state", "lio_fastlio_start_state", "lio_fastlio_download_undistorted",
     "lio_state_predict", "lio_eskf_update_cb", "lio_eskf_update_ws_cb", "lio_eskf_update_sums_cb",
     "lio_ndt_create", "lio_ndt_destroy", "lio_ndt_set_target", "lio_ndt_set_target_device", "lio_ndt_num_voxels", "lio_ndt_fitness_score", "lio_ndt_overlap_score", "lio_ndt_voxel_at",
-    "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align", "lio_ndt_enable_kernel_timing", "lio_ndt_kernel_times",
+    "lio_ndt_linearize", "lio_ndt_default_params", "lio_ndt_align", "lio_ndt_align_batch", "lio_ndt_enable_kernel_timing", "lio_ndt_kernel_times",
     "lio_gicp_create", "lio_gicp_destroy", "lio_gicp_set_target", "lio_gicp_set_source", "lio_gicp_set_voxel_mode", "lio_gicp_voxel_at", "lio_gicp_download", "lio_gicp_correspondences", "lio_gicp_linearize", "lio_gicp_align",
 ]
 
@@ -83,6 +83,11 @@ class GpsObservation(C.Structure):  # lio_gps_observation
 class NdtParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("lm_max_iterations", C.c_int32), ("rotation_epsilon_deg", C.c_double),
                 ("transformation_epsilon", C.c_double), ("lm_init_lambda_factor", C.c_double), ("max_process_time_ms", C.c_double)]
+
+
+class AlignJob(C.Structure):  # lio_align_job
+    _fields_ = [("target", C.c_void_p), ("source", C.c_void_p), ("guess", C.POINTER(C.c_double)), ("out", C.c_double * 16), ("iterations", C.c_int32), ("converged", C.c_int32),
+                ("evaluations", C.c_int32), ("rc", C.c_int32)]
 
 
 class NdtTimes(C.Structure):  # lio_ndt_times
@@ -242,6 +247,7 @@ def lib():
     sig("lio_ndt_linearize", cint, vp, vp, f64p, cint, cint, f64p, f64p, f64p, C.POINTER(u32))
     sig("lio_ndt_default_params", None, C.POINTER(NdtParams))
     sig("lio_ndt_align", cint, vp, vp, f64p, C.POINTER(NdtParams), f64p, C.POINTER(cint), C.POINTER(cint))
+    sig("lio_ndt_align_batch", cint, vp, C.POINTER(AlignJob), cint, C.POINTER(NdtParams))
     sig("lio_ndt_enable_kernel_timing", cint, vp, cint)
     sig("lio_ndt_kernel_times", cint, vp, C.POINTER(NdtTimes), cint)
     sig("lio_gicp_create", vp, cint, flt, u32, cint)

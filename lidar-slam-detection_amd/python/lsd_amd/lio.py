@@ -519,6 +519,33 @@ class Ndt:
         check(lib().lio_ndt_align(self.h, scan.h, ptr(g, C.c_double), C.byref(prm), ptr(out, C.c_double), C.byref(it), C.byref(conv)), "ndt align")
         return out, bool(conv.value), int(it.value)
 
+    def prepare_batch(self, scans, guesses, targets=None):
+        """the job array of lio_ndt_align_batch, marshalled once (so that a timed region can be the one C call); targets: one lio.Ndt per job
+        (None = this one)"""
+        n = len(scans)
+        arr = (capi.AlignJob * n)()
+        keep = [f64(g).reshape(16).copy() for g in guesses]
+        for i in range(n):
+            arr[i].target = targets[i].h if targets is not None and targets[i] is not None else None
+            arr[i].source = scans[i].h
+            arr[i].guess = ptr(keep[i], C.c_double)
+        return arr, keep
+
+    def run_batch(self, prepared, **params):
+        arr, _ = prepared
+        prm = capi.NdtParams()
+        lib().lio_ndt_default_params(C.byref(prm))
+        for k, v in params.items():
+            setattr(prm, k, v)
+        return lib().lio_ndt_align_batch(self.h, arr, len(arr), C.byref(prm))
+
+    def align_batch(self, scans, guesses, targets=None, **params):
+        """B alignments per launch against this target (lio_ndt_align_batch): scans = lio.Scan objects holding their downsampled clouds;
+        returns a list of (T 4 x 4, converged, iterations, evaluations, rc)"""
+        prep = self.prepare_batch(scans, guesses, targets)
+        check(self.run_batch(prep, **params), "ndt align_batch")
+        return [(np.array(a.out).reshape(4, 4), bool(a.converged), int(a.iterations), int(a.evaluations), int(a.rc)) for a in prep[0]]
+
 
 class Gicp:
     """fast_gicp::FastGICP on the device (lio_gicp_*): 20-NN covariances with PLANE regularisation, nearest-neighbour correspondences,
@@ -599,6 +626,17 @@ def transform_cloud_f32(cloud, M):
     return c
 
 
+def transform_cloud_f64(cloud, M):
+    """pcl::transformPointCloud(in, out, M) with an Eigen::Matrix4d (overlap_merge.hpp:190-194: the connected frames are moved by the f64 `relative`):
+    PCL 1.9.1 evaluates that in double, terms left to right, and casts the result to float (csrc/slam_wrapper.cpp does the same for the static transform)"""
+    c = np.ascontiguousarray(cloud, np.float32).reshape(-1, 4).copy()
+    Md = np.asarray(M, np.float64)
+    x, y, z = c[:, 0].astype(np.float64), c[:, 1].astype(np.float64), c[:, 2].astype(np.float64)
+    for r in range(3):
+        c[:, r] = (((Md[r, 0] * x + Md[r, 1] * y) + Md[r, 2] * z) + Md[r, 3]).astype(np.float32)
+    return c
+
+
 class OverlapMatcher:
     """OverlapDetector::matching of the map-merge / relocalisation tools (slam/localization/include/overlap_merge.hpp:151-211) on the
     device: per candidate the overlap pre-check and the coarse NDT alignment with its fitness score, then the fine GICP alignment of the
@@ -657,7 +695,7 @@ class OverlapMatcher:
         accum = [f32(candidates[best][0]).reshape(-1, 4)]
         for ci, pts, odom in connected:
             if ci == best:
-                accum.append(transform_cloud_f32(pts, np.linalg.inv(bo) @ f64(odom).reshape(4, 4)))
+                accum.append(transform_cloud_f64(pts, np.linalg.inv(bo) @ f64(odom).reshape(4, 4)))
         accum = np.concatenate(accum)
         self.gicp.set_target(accum)
         self.gicp.set_source(new_points)

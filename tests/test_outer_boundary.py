@@ -116,7 +116,7 @@ def test_reference_slam_py_runs_unchanged_on_the_compiled_module():
     assert np.allclose(sw.get_map_origin(), [[31.0, 121.0, 4.0, 0, 0, 0, 0]])
     # a few of the calls slam.py / map_manager.py make off the hot path: type-correct values, nothing raises
     assert sw.update_odom() == {"odoms": {}, "keyframes": []} and sw.get_graph_status() == {"loop_detected": False}
-    assert sw.get_graph_map() == {} and sw.get_graph_edges() == {} and sw.run_robust_graph_optimization("mapping") == {}
+    assert sw.get_graph_map() == {"points": {}, "images": {}, "poses": {}, "stamps": {}} and sw.get_graph_edges() == {} and sw.run_robust_graph_optimization("mapping") == {}
     G = np.eye(4, dtype=np.float32)
     G[0, 3] = 60.0
     A = sw.pointcloud_align(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32), G)
@@ -298,16 +298,13 @@ def test_keyframe_files_have_the_reference_layout(tmp_path):
     assert np.array_equal(got[:, :3], pts[:, :3]) and np.array_equal(got[:, 3], pts[:, 3] * 255.0)
 
 
-@pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF + "/slam/slam.py"), reason="needs /root/reference")
-def test_localization_mode_through_the_reference_slam_py(tmp_path):
-    """the reference's slam/slam.py, byte for byte, constructed with mode = "localization" on the compiled module: start() loads the map from disk
-    (key frames -> HBM), hands the key frames to map_manager.py (get_graph_map), set_init_pose starts the filter, and process() returns localised
-    poses along a drive through the mapped area -- VoxelGrid + NDT-P2D + UKF + local-map updates on the device (docs/slam.md: decimetre level)."""
-    from lsd_amd import capi, synth
+def test_reference_slam_py_starts_in_localization_mode(tmp_path):
+    """the reference's slam/slam.py, byte for byte, constructed with mode = "localization" on the compiled module (CPU): start() goes through
+    init_slam / setup_slam (which reads the map's key frames from disk; without a GPU it then returns False as the reference's does when its back
+    end cannot start) and hands the key frames to map_manager.py (slam.py:79-81: get_graph_map -> MapManager.update)"""
+    from lsd_amd import synth
 
-    if capi.lib().lio_device_count() < 1:
-        pytest.fail("no HIP device")
     sw = _module()
     _stand_ins()
     if REF not in sys.path:
@@ -317,7 +314,7 @@ def test_localization_mode_through_the_reference_slam_py(tmp_path):
     ref_slam = importlib.import_module("slam.slam")
     scene = synth.Scene(half=100.0, n_boxes=40, seed=1)
     root = str(tmp_path / "map")
-    frames = _write_map(sw, root, scene)
+    frames = _write_map(sw, root, scene, n_frames=6, n_az=150)
 
     class Log:
         def info(self, *a):
@@ -325,22 +322,51 @@ def test_localization_mode_through_the_reference_slam_py(tmp_path):
 
         warn = error = debug = info
 
-    config = _cfg(dict(
+    s = ref_slam.SLAM("localization", "FastLIO", root, ["0-lidar", "IMU"], 0.2, [1.0, 10.0], _LOC_CONFIG(), Log())
+    assert s.method == "Localization"
+    s.start()
+    try:
+        assert s.isInited()
+        mm = s.map_manager
+        assert sorted(mm.data["stamps"], key=int) == [str(k) for k in range(len(frames))] and mm.vertex_id == len(frames)
+        assert mm.data["stamps"]["2"] == 1_000_000 + 200_000
+        assert np.array_equal(mm.data["points"]["3"][:, :3], frames[3][0][:, :3])
+        assert np.allclose(mm.data["points"]["3"][:, 3], frames[3][0][:, 3], rtol=1e-6)  # / 255 on the way in, * 255 inside dump_keyframe
+        assert np.abs(mm.data["poses"]["3"] - frames[3][1]).max() < 2e-3  # `data` keeps 6 significant digits
+    finally:
+        s.stop()
+
+
+def _LOC_CONFIG():
+    return _cfg(dict(
         input=dict(mode="offline"), camera=[],
         ins=dict(extrinsic_parameters=[0.0, 0.0, 0.0, 0.0, 0.0, 0.0], imu_extrinsic_parameters=[0.0, 0.0, 0.0, 0.0, 0.0, 0.0], ins_type="6D"),
         output=dict(localization=dict(UDP=dict(use=False, destination="127.0.0.1", port=9000))),
         slam=dict(origin=dict(use=True, latitude=0.0, longitude=0.0, altitude=0.0),
                   mapping=dict(key_frames_range=50.0, ground_constraint=False, loop_closure=False, gravity_constraint=False),
                   localization=dict(colouration=False))))
-    s = ref_slam.SLAM("localization", "FastLIO", root, ["0-lidar", "IMU"], 0.2, [1.0, 10.0], config, Log())
-    s.start()
+
+
+@pytest.mark.gpu
+def test_localization_mode_through_the_compiled_module(tmp_path):
+    """the calls slam.py makes in localisation mode (slam.py:50-85, :140-160), on the GPU: init_slam("localization", map_path, "Localization", ...)
+    -> setup_slam loads the map from disk (key frames -> HBM) -> get_graph_map -> set_init_pose starts the filter -> process() returns localised
+    poses along a drive through the mapped area: VoxelGrid + NDT-P2D + UKF + local-map updates on the device (docs/slam.md: decimetre level)"""
+    from lsd_amd import capi, synth
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device")
+    sw = _module()
+    scene = synth.Scene(half=100.0, n_boxes=40, seed=1)
+    root = str(tmp_path / "map")
+    frames = _write_map(sw, root, scene)
+    assert sw.init_slam("offline", root, "Localization", ["0-lidar", "IMU"], 0.2, 1.0, 10.0, 50.0) == ["0-lidar", "IMU"]
+    sw.set_ins_external_param(0, 0, 0, 0, 0, 0)
+    sw.set_imu_external_param(0, 0, 0, 0, 0, 0)
+    assert sw.setup_slam() is True
     try:
-        assert s.isInited() and s.sensor_input == ["0-lidar", "IMU"]
-        # slam.py:79-81: the key frames of the loaded map went to map_manager.py (get_graph_map -> MapManager.update)
-        mm = s.map_manager
-        assert sorted(mm.data["stamps"], key=int) == [str(k) for k in range(len(frames))] and mm.vertex_id == len(frames)
-        assert np.array_equal(mm.data["points"]["3"][:, :3], frames[3][0][:, :3])
-        assert np.abs(mm.data["poses"]["3"] - frames[3][1]).max() < 1e-4 * 20  # `data` keeps 6 significant digits
+        gm = sw.get_graph_map()
+        assert sorted(gm["stamps"], key=int) == [str(k) for k in range(len(frames))] and np.array_equal(gm["points"]["3"][:, :3], frames[3][0][:, :3])
         tr = synth.Trajectory(p0=(-10.0, 0.2, 1.8), t_static=0.2, speed=4.0, heading=0.0, sway=0.3, yaw_amp=0.1)
         imu = synth.imu_stream(tr, 0.0, 4.3, rate=100.0, seed=5, gyr_sigma=1e-3, acc_sigma=1e-2)
         # before an initial pose: "Initializing", identity pose (the global locator is out of scope; slam.set_init_pose supplies the pose)
@@ -370,7 +396,7 @@ def test_localization_mode_through_the_reference_slam_py(tmp_path):
         assert max(errs[10:]) < 0.15 and np.median(errs) < 0.08
         assert states[0] == "Initializing" and states[-1] == "Localizing(L)"  # Localization::isStable: ten good frames
     finally:
-        s.stop()
+        sw.deinit_slam()
 
 
 @pytest.mark.skipif(not os.path.exists(REF + "/slam/map_manager.py"), reason="needs /root/reference")

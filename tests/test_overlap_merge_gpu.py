@@ -76,7 +76,13 @@ def test_overlap_matching_flow_vs_reference_matchers():
     assert [c["candidate"] for c in got["coarse"] if "skipped" not in c] == tried   # the same candidates pass the pre-check and converge
     assert np.abs(coarse["T"][:3, 3] - rel[:3, 3]).max() < 5e-3     # the NDT object of the reference is itself only repeatable to ~1e-3 (test_ndt_vs_ref_cuda)
     assert abs(coarse["score"] - best_score) < 0.02 * best_score
-    accum = np.concatenate([cands[0][0], lio.transform_cloud_f32(linked[0][1], np.linalg.inv(cands[0][1]) @ linked[0][2])])
+    # overlap_merge.hpp:190-194: the connected frame moved by the f64 `relative` (pcl::transformPointCloud with a Matrix4d: double arithmetic, cast
+    # to float) -- restated here independently of the product's helper
+    Mrel = np.linalg.inv(cands[0][1]) @ linked[0][2]
+    moved = linked[0][1].copy()
+    moved[:, :3] = (linked[0][1][:, :3].astype(np.float64) @ Mrel[:3, :3].T + Mrel[:3, 3]).astype(np.float32)
+    assert np.abs(moved[:, :3] - lio.transform_cloud_f64(linked[0][1], Mrel)[:, :3]).max() <= 4e-6 * np.abs(moved[:, :3]).max()  # (summation order: an ulp at most)
+    accum = np.concatenate([cands[0][0], moved])
     fine = ref_gicp.RefGicp(k=20, max_corr_dist=0.5, transformation_epsilon=0.001, num_threads=4)
     fine.set_target(accum)
     fine.set_source(new_pts)

@@ -9,6 +9,7 @@ for stage in "$@"; do
   case "$stage" in
     tests)    timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/tests.log 2>&1 ;;
     tests_all) timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/tests.log 2>&1 ;;
+    tests_fix) timeout 1500 python -m pytest tests/test_localization_boundary.py tests/test_outer_boundary.py tests/test_ndt_gpu.py -m gpu -q -s > gpurun_out/tests_fix.log 2>&1 ;;
     batch)    timeout 900 python -m pytest tests/test_batch_gpu.py tests/test_fullsize_gpu.py -m gpu -x -q -s > gpurun_out/batch.log 2>&1 ;;
     stream)   timeout 900 python bench.py --config stream --grow-to 10000000 --steps 6000 --lru 0 > gpurun_out/stream.json 2> gpurun_out/stream.err ;;
     stream_lru) timeout 600 python bench.py --config stream --steps 300 --lru 100000 --ref-scans 0 > gpurun_out/stream_lru.json 2> gpurun_out/stream_lru.err ;;
