@@ -17,6 +17,7 @@ for stage in "$@"; do
     bench)    timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err ;;
     bench_fast) timeout 900 python bench.py --steps 20 --warmup 5 --secondary 0 > gpurun_out/bench_fast.json 2> gpurun_out/bench_fast.err ;;
     merge)    timeout 600 python bench.py --config merge --steps 40 --warmup 8 > gpurun_out/merge.json 2> gpurun_out/merge.err ;;
+    gicp)     timeout 600 python tools/experiments/gicp_time.py > gpurun_out/gicp_timing.txt 2>&1 ;;
     smoke)    timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 ;;
     *)        if [ -x "tools/r03_stage_$stage.sh" ]; then timeout 1500 "tools/r03_stage_$stage.sh" > "gpurun_out/$stage.log" 2>&1; else echo "unknown stage $stage"; fi ;;
   esac
