@@ -52,82 +52,148 @@ __device__ inline bool grid_find(const Slot* __restrict__ table, uint32_t mask, 
     return grid_find_slot(table, mask, cx, cy, cz, ptr, cnt, slot);
 }
 
+// ---- group search: sixteen lanes (one DPP row) per query --------------------------------------------------------------------------
+// A cloud of a few ten thousand points is 100-200 workgroups with one lane per query: two waves per CU walking hundreds of dependent hash
+// probes each, and a wave waits for its sparsest query (ring r costs 24 r^2 + 2 probes).  With sixteen lanes per query the probes of a
+// shell are made sixteen at a time, the points of a hit cell are split over the lanes, and the launch has sixteen times the waves.
+constexpr int kGrp = 16;
+constexpr int kGrpThreads = 256;  // 16 queries per workgroup
+
+__device__ inline uint32_t grp_ballot(bool p) {
+    const unsigned long long b = __ballot(p);
+    const int lane = threadIdx.x & 63;
+    const uint32_t half = (lane & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+    return (half >> (lane & 16)) & 0xFFFFu;
+}
+
+// cell t of the shell of the (2r + 1)^3 cube around the query's cell: the two z faces, then the perimeter of every layer between them
+__device__ inline int shell_cells(int r) { return r == 0 ? 1 : 2 * (2 * r + 1) * (2 * r + 1) + (2 * r - 1) * 8 * r; }
+__device__ inline void shell_cell(int r, int t, int& dx, int& dy, int& dz) {
+    if (r == 0) { dx = dy = dz = 0; return; }
+    const int s = 2 * r + 1, face = s * s;
+    if (t < 2 * face) {
+        const int f = t >= face, rem = t - f * face, row = rem / s;
+        dz = f ? r : -r;
+        dy = row - r;
+        dx = rem - row * s - r;
+        return;
+    }
+    const int u = t - 2 * face, layer = u / (8 * r), q = u - layer * 8 * r;
+    dz = layer - r + 1;
+    if (q < s) { dy = -r; dx = q - r; }
+    else if (q < 2 * s) { dy = r; dx = q - s - r; }
+    else {
+        const int w = q - 2 * s, side = w >= s - 2;
+        dy = w - side * (s - 2) - r + 1;
+        dx = side ? r : -r;
+    }
+}
+
+// candidate key: f32 bits of the squared distance (non-negative: bit order = numeric order) above the pool index -- ties of exact distance
+// go to the lower index, whatever the order of enumeration
+__device__ inline unsigned long long cand_key(float d2, uint32_t idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | idx; }
+
 // k nearest neighbours of every point of the cloud within the cloud itself (the point is its own nearest), their covariance, PLANE
 // regularisation.  cov6 = (xx, xy, xz, yy, yz, zz) of the regularised matrix, pool order.
-__global__ void __launch_bounds__(kGicpThreads) gicp_cov_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, uint32_t n,
-                                                                float res, int k, double* __restrict__ cov6) {
-    __shared__ float hd[kGicpMaxK][kGicpThreads];
-    __shared__ uint32_t hi[kGicpMaxK][kGicpThreads];
-    const int tid = threadIdx.x;
-    const uint32_t i = blockIdx.x * kGicpThreads + tid;
-    if (i >= n) return;
+// The sorted list of the k <= 32 best lives in two registers per lane (position = lane, 16 + lane); an insertion is one shift by a lane.
+__global__ void __launch_bounds__(kGrpThreads) gicp_cov_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, uint32_t n,
+                                                               float res, int k, double* __restrict__ cov6) {
+    const int lane = threadIdx.x & (kGrp - 1);
+    const uint32_t i = (blockIdx.x * kGrpThreads + threadIdx.x) / kGrp;
+    if (i >= n) return;  // whole groups leave together
     const float4 p = pool[i];
     int kx, ky, kz;
     pos2grid_ndt(p.x, p.y, p.z, res, kx, ky, kz);
-    int have = 0;
-    float worst = INFINITY;  // the k-th best once the heap is full
+    const unsigned long long kNone = ~0ull;
+    unsigned long long e0 = kNone, e1 = kNone, kth = kNone;
     for (int r = 0;; r++) {
-        for (int dz = -r; dz <= r; dz++)
-            for (int dy = -r; dy <= r; dy++) {
-                const int step = (abs(dz) == r || abs(dy) == r || r == 0) ? 1 : 2 * r;  // only the shell of the cube
-                for (int dx = -r; dx <= r; dx += step) {
-                    uint32_t ptr, cnt;
-                    if (!grid_find(table, mask, kx + dx, ky + dy, kz + dz, ptr, cnt)) continue;
-                    for (uint32_t j = 0; j < cnt; j++) {
-                        const float4 q = pool[ptr + j];
+        const int n_cells = shell_cells(r);
+        for (int t0 = 0; t0 < n_cells; t0 += kGrp) {
+            const int t = t0 + lane;
+            uint32_t ptr = 0, cnt = 0;
+            bool found = false;
+            if (t < n_cells) {
+                int dx, dy, dz;
+                shell_cell(r, t, dx, dy, dz);
+                found = grid_find(table, mask, kx + dx, ky + dy, kz + dz, ptr, cnt);
+            }
+            uint32_t hits = grp_ballot(found);
+            while (hits) {
+                const int b = __ffs((int)hits) - 1;
+                hits &= hits - 1;
+                const uint32_t cptr = __shfl(ptr, b, kGrp), ccnt = __shfl(cnt, b, kGrp);
+                for (uint32_t j0 = 0; j0 < ccnt; j0 += kGrp) {
+                    const uint32_t j = j0 + lane;
+                    unsigned long long c = kNone;
+                    if (j < ccnt) {
+                        const float4 q = pool[cptr + j];
                         const float ex = q.x - p.x, ey = q.y - p.y, ez = q.z - p.z;
                         const float d2 = (ex * ex + ey * ey) + ez * ez;
-                        if (have == k && !(d2 < worst)) continue;
-                        // sorted insertion (ascending): the list is short and insertions become rare quickly
-                        int pos = have < k ? have : k - 1;
-                        while (pos > 0 && hd[pos - 1][tid] > d2) {
-                            hd[pos][tid] = hd[pos - 1][tid];
-                            hi[pos][tid] = hi[pos - 1][tid];
-                            pos--;
-                        }
-                        hd[pos][tid] = d2;
-                        hi[pos][tid] = ptr + j;
-                        if (have < k) have++;
-                        if (have == k) worst = hd[k - 1][tid];
+                        if (d2 == d2) c = cand_key(d2, cptr + j);
                     }
+                    uint32_t take = grp_ballot(c < kth);
+                    while (take) {
+                        const int bb = __ffs((int)take) - 1;
+                        take &= take - 1;
+                        const unsigned long long cc = __shfl(c, bb, kGrp);
+                        unsigned long long l0 = __shfl_up(e0, 1, kGrp), l1 = __shfl_up(e1, 1, kGrp);
+                        const unsigned long long carry = __shfl(e0, kGrp - 1, kGrp);
+                        if (lane == 0) { l0 = 0; l1 = carry; }
+                        e0 = e0 <= cc ? e0 : (l0 <= cc ? cc : l0);
+                        e1 = e1 <= cc ? e1 : (l1 <= cc ? cc : l1);
+                    }
+                    kth = k <= kGrp ? __shfl(e0, k - 1, kGrp) : __shfl(e1, k - 1 - kGrp, kGrp);
                 }
             }
+        }
         const float reach = (float)r * res;
-        if ((have == k && worst <= reach * reach) || r > 64) break;
+        if ((kth != kNone && __uint_as_float((uint32_t)(kth >> 32)) <= reach * reach) || r > 64) break;
     }
-    // neighbors.colwise() -= neighbors.rowwise().mean(); cov = neighbors * neighbors^T / k   (f64, as the reference casts)
-    double m[3] = {0, 0, 0};
-    for (int j = 0; j < have; j++) {
-        const float4 q = pool[hi[j][tid]];
-        m[0] += (double)q.x; m[1] += (double)q.y; m[2] += (double)q.z;
-    }
+    // neighbors.colwise() -= neighbors.rowwise().mean(); cov = neighbors * neighbors^T / k   (f64, as the reference casts); the lanes hold
+    // one or two neighbours each, sums by a fixed butterfly over the group
+    const bool v0 = lane < k && e0 != kNone, v1 = kGrp + lane < k && e1 != kNone;
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0;
+    if (v0) q0 = pool[(uint32_t)e0];
+    if (v1) q1 = pool[(uint32_t)e1];
+    double m[3] = {(double)q0.x + (double)q1.x, (double)q0.y + (double)q1.y, (double)q0.z + (double)q1.z};
+#pragma unroll
+    for (int off = kGrp / 2; off > 0; off >>= 1)
+        for (int a = 0; a < 3; a++) m[a] += __shfl_xor(m[a], off, kGrp);
     for (int a = 0; a < 3; a++) m[a] /= (double)k;
-    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < have; j++) {
-        const float4 q = pool[hi[j][tid]];
-        const double d[3] = {(double)q.x - m[0], (double)q.y - m[1], (double)q.z - m[2]};
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) C[a * 3 + b] += d[a] * d[b];
+    double C6[6] = {0, 0, 0, 0, 0, 0};
+    if (v0) {
+        const double d[3] = {(double)q0.x - m[0], (double)q0.y - m[1], (double)q0.z - m[2]};
+        C6[0] += d[0] * d[0]; C6[1] += d[0] * d[1]; C6[2] += d[0] * d[2]; C6[3] += d[1] * d[1]; C6[4] += d[1] * d[2]; C6[5] += d[2] * d[2];
     }
+    if (v1) {
+        const double d[3] = {(double)q1.x - m[0], (double)q1.y - m[1], (double)q1.z - m[2]};
+        C6[0] += d[0] * d[0]; C6[1] += d[0] * d[1]; C6[2] += d[0] * d[2]; C6[3] += d[1] * d[1]; C6[4] += d[1] * d[2]; C6[5] += d[2] * d[2];
+    }
+#pragma unroll
+    for (int off = kGrp / 2; off > 0; off >>= 1)
+        for (int a = 0; a < 6; a++) C6[a] += __shfl_xor(C6[a], off, kGrp);
+    if (lane != 0) return;
+    double C[9] = {C6[0], C6[1], C6[2], C6[1], C6[3], C6[4], C6[2], C6[4], C6[5]};
     for (int a = 0; a < 9; a++) C[a] /= (double)k;
     double w[3], V[9];
     ek_eig3_sym(C, w, V);  // ascending: column 0 = the direction of least spread (the surface normal)
-    const double v0[3] = {V[0], V[3], V[6]};
+    const double n0[3] = {V[0], V[3], V[6]};
     const double g = 1.0 - 1e-3;
     double* o = cov6 + (size_t)i * 6;
-    o[0] = 1.0 - g * v0[0] * v0[0];
-    o[1] = -g * v0[0] * v0[1];
-    o[2] = -g * v0[0] * v0[2];
-    o[3] = 1.0 - g * v0[1] * v0[1];
-    o[4] = -g * v0[1] * v0[2];
-    o[5] = 1.0 - g * v0[2] * v0[2];
+    o[0] = 1.0 - g * n0[0] * n0[0];
+    o[1] = -g * n0[0] * n0[1];
+    o[2] = -g * n0[0] * n0[2];
+    o[3] = 1.0 - g * n0[1] * n0[1];
+    o[4] = -g * n0[1] * n0[2];
+    o[5] = 1.0 - g * n0[2] * n0[2];
 }
 
 // update_correspondences: nearest target point of trans_f * a within the correspondence distance, and the Mahalanobis matrix of the pair
-__global__ void __launch_bounds__(kGicpThreads) gicp_corr_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ tpool, float res,
-                                                                 const double* __restrict__ tcov, const float4* __restrict__ spool, const double* __restrict__ scov,
-                                                                 uint32_t n_src, GicpXform X, float max_d2, int32_t* __restrict__ corr, double* __restrict__ maha) {
-    const uint32_t i = blockIdx.x * kGicpThreads + threadIdx.x;
+__global__ void __launch_bounds__(kGrpThreads) gicp_corr_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ tpool, float res,
+                                                                const double* __restrict__ tcov, const float4* __restrict__ spool, const double* __restrict__ scov,
+                                                                uint32_t n_src, GicpXform X, float max_d2, int32_t* __restrict__ corr, double* __restrict__ maha) {
+    const int lane = threadIdx.x & (kGrp - 1);
+    const uint32_t i = (blockIdx.x * kGrpThreads + threadIdx.x) / kGrp;
     if (i >= n_src) return;
     const float4 a = spool[i];
     // trans_f * [x y z 1]: Eigen folds the four products of a row pairwise, (r0 x + r1 y) + (r2 z + t) (checked against the reference build)
@@ -136,26 +202,40 @@ __global__ void __launch_bounds__(kGicpThreads) gicp_corr_kernel(const Slot* __r
     const float tz = (X.Rf[6] * a.x + X.Rf[7] * a.y) + (X.Rf[8] * a.z + X.tf[2]);
     int kx, ky, kz;
     pos2grid_ndt(tx, ty, tz, res, kx, ky, kz);
-    float best = INFINITY;
-    uint32_t bi = 0xFFFFFFFFu;
+    unsigned long long bk = ~0ull;  // (squared distance, index) of the nearest so far, the same in all lanes of the group after every ring
     for (int r = 0;; r++) {
-        for (int dz = -r; dz <= r; dz++)
-            for (int dy = -r; dy <= r; dy++) {
-                const int step = (abs(dz) == r || abs(dy) == r || r == 0) ? 1 : 2 * r;  // only the shell of the cube
-                for (int dx = -r; dx <= r; dx += step) {
-                    uint32_t ptr, cnt;
-                    if (!grid_find(table, mask, kx + dx, ky + dy, kz + dz, ptr, cnt)) continue;
-                    for (uint32_t j = 0; j < cnt; j++) {
-                        const float4 q = tpool[ptr + j];
-                        const float ex = q.x - tx, ey = q.y - ty, ez = q.z - tz;
-                        const float d2 = (ex * ex + ey * ey) + ez * ez;
-                        if (d2 < best) { best = d2; bi = ptr + j; }
+        const int n_cells = shell_cells(r);
+        for (int t0 = 0; t0 < n_cells; t0 += kGrp) {
+            const int t = t0 + lane;
+            uint32_t ptr = 0, cnt = 0;
+            bool found = false;
+            if (t < n_cells) {
+                int dx, dy, dz;
+                shell_cell(r, t, dx, dy, dz);
+                found = grid_find(table, mask, kx + dx, ky + dy, kz + dz, ptr, cnt);
+            }
+            if (found)
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const float4 q = tpool[ptr + j];
+                    const float ex = q.x - tx, ey = q.y - ty, ez = q.z - tz;
+                    const float d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (d2 == d2) {
+                        const unsigned long long c = cand_key(d2, ptr + j);
+                        if (c < bk) bk = c;
                     }
                 }
-            }
+        }
+#pragma unroll
+        for (int off = kGrp / 2; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(bk, off, kGrp);
+            if (o < bk) bk = o;
+        }
         const float reach = (float)r * res;
-        if (best <= reach * reach || reach * reach > max_d2) break;
+        if ((bk != ~0ull && __uint_as_float((uint32_t)(bk >> 32)) <= reach * reach) || reach * reach > max_d2) break;
     }
+    if (lane != 0) return;
+    const float best = bk != ~0ull ? __uint_as_float((uint32_t)(bk >> 32)) : INFINITY;
+    const uint32_t bi = bk != ~0ull ? (uint32_t)bk : 0xFFFFFFFFu;
     const bool ok = bi != 0xFFFFFFFFu && best < max_d2;
     corr[i] = ok ? (int32_t)bi : -1;
     if (!ok) return;
@@ -454,7 +534,7 @@ int gicp_set_cloud(lio_gicp* g, int which, const float* xyzi, uint32_t n) {
     if (rc != LIO_OK) return rc;
     g->n[which] = n;
     if (which == 0) g->vmap_valid = false;
-    hipLaunchKernelGGL(gicp_cov_kernel, (n + kGicpThreads - 1) / kGicpThreads, kGicpThreads, 0, st, m->table, m->table_mask, m->pool, n, g->res, g->k, g->cov[which]);
+    hipLaunchKernelGGL(gicp_cov_kernel, (uint32_t)(((uint64_t)n * kGrp + kGrpThreads - 1) / kGrpThreads), kGrpThreads, 0, st, m->table, m->table_mask, m->pool, n, g->res, g->k, g->cov[which]);
     LIO_HIP_TRY(hipGetLastError());
     LIO_HIP_TRY(hipStreamSynchronize(st));
     return LIO_OK;
@@ -515,7 +595,7 @@ int gicp_eval(lio_gicp* g, const double T[16], double max_corr_dist, bool update
     } else {
     if (update) {
         const double d2 = max_corr_dist * max_corr_dist;
-        hipLaunchKernelGGL(gicp_corr_kernel, blocks, kGicpThreads, 0, st, mt->table, mt->table_mask, mt->pool, g->res, g->cov[0], g->grid[1]->pool, g->cov[1], ns, X,
+        hipLaunchKernelGGL(gicp_corr_kernel, (uint32_t)(((uint64_t)ns * kGrp + kGrpThreads - 1) / kGrpThreads), kGrpThreads, 0, st, mt->table, mt->table_mask, mt->pool, g->res, g->cov[0], g->grid[1]->pool, g->cov[1], ns, X,
                            d2 > 3.0e38 ? 3.0e38f : (float)d2, g->corr, g->maha);
     }
     if (deriv) hipLaunchKernelGGL(gicp_cost_kernel<true>, blocks, kGicpThreads, 0, st, mt->pool, g->grid[1]->pool, ns, g->corr, g->maha, X, g->partial);

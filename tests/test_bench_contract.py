@@ -7,8 +7,12 @@ import re
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    j = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench.json")).read())
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r02_bench.json", "r03_bench.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    j = json.loads(open(os.path.join(ROOT, "profiles", name)).read())
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
@@ -27,6 +31,28 @@ def test_committed_bench_line_has_the_contract_fields():
     # whole-job value and the per-step time are one measurement
     n_raw = j["config"]["n_raw"]
     assert abs(j["value"] - n_raw / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"]
+
+
+def test_round3_line_carries_the_parity_of_the_timed_path_and_every_config():
+    """what VERDICT r02 asked of the driver-run line: the batched call's own poses against the oracle, configs 3 / 4 as legs, the three
+    fractions of the dominant kernel side by side"""
+    j = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench.json")).read())
+    b = j["cpu_baseline"]["port"]["batch_vs_oracle_pose"]
+    assert b["max_dpos_m"] < 1e-9 and b["max_drot_rad"] < 1e-9 and b["scans_checked"] >= 8
+    assert b["all_timed_results_bit_identical_to_the_checked_ones"] is True and b["timed_results"] >= 32 * 3
+    g = j["cpu_baseline"]["gpu_vs_reference_pose"]
+    assert g["max_dpos_m"] < 1e-4 and g["max_drot_rad"] < 1e-5  # north_star's bar, against the reference's own code
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["traffic"] and 0 < r["frac_hbm_traffic"] < r["frac_touched"] < r["frac"] < 1.0
+    assert abs(r["frac_touched"] - r["touched_bytes_per_launch"] / r["algorithmic_bytes_per_launch"] * r["frac"]) < 1e-3
+    c = j["configs"]
+    assert set(c) >= {"config2_1e6_map", "config3_stream_to_1e7_points", "config3_stream_lru_1e5_300_sweeps", "config4_localize_5e7_map"}
+    assert c["config3_stream_to_1e7_points"]["map_points_end"] >= 10_000_000 and c["config3_stream_to_1e7_points"]["voxels_evicted"] == 0
+    assert c["config3_stream_lru_1e5_300_sweeps"]["voxels_evicted"] > 0
+    assert c["config4_localize_5e7_map"]["resident_map"]["target_points"] == 50_000_000
+    assert c["config4_localize_5e7_map"]["resident_map"]["converged"] == 200
+    m = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_merge.json")).read())
+    assert m["n_gpus"] == 1 and "NOT measured" in m["collective"]["backend"] and m["collective"]["states_identical_on_all_ranks"] is True
 
 
 def test_bench_defaults_are_the_drivers_assumptions():
