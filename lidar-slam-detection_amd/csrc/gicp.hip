@@ -47,51 +47,6 @@ __device__ inline bool grid_find_slot(const Slot* __restrict__ table, uint32_t m
     }
     return false;
 }
-__device__ inline bool grid_find(const Slot* __restrict__ table, uint32_t mask, int cx, int cy, int cz, uint32_t& ptr, uint32_t& cnt) {
-    uint32_t slot;
-    return grid_find_slot(table, mask, cx, cy, cz, ptr, cnt, slot);
-}
-
-// ---- group search: sixteen lanes (one DPP row) per query --------------------------------------------------------------------------
-// A cloud of a few ten thousand points is 100-200 workgroups with one lane per query: two waves per CU walking hundreds of dependent hash
-// probes each, and a wave waits for its sparsest query (ring r costs 24 r^2 + 2 probes).  With sixteen lanes per query the probes of a
-// shell are made sixteen at a time, the points of a hit cell are split over the lanes, and the launch has sixteen times the waves.
-constexpr int kGrp = 16;
-constexpr int kGrpThreads = 256;  // 16 queries per workgroup
-
-__device__ inline uint32_t grp_ballot(bool p) {
-    const unsigned long long b = __ballot(p);
-    const int lane = threadIdx.x & 63;
-    const uint32_t half = (lane & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
-    return (half >> (lane & 16)) & 0xFFFFu;
-}
-
-// cell t of the shell of the (2r + 1)^3 cube around the query's cell: the two z faces, then the perimeter of every layer between them
-__device__ inline int shell_cells(int r) { return r == 0 ? 1 : 2 * (2 * r + 1) * (2 * r + 1) + (2 * r - 1) * 8 * r; }
-__device__ inline void shell_cell(int r, int t, int& dx, int& dy, int& dz) {
-    if (r == 0) { dx = dy = dz = 0; return; }
-    const int s = 2 * r + 1, face = s * s;
-    if (t < 2 * face) {
-        const int f = t >= face, rem = t - f * face, row = rem / s;
-        dz = f ? r : -r;
-        dy = row - r;
-        dx = rem - row * s - r;
-        return;
-    }
-    const int u = t - 2 * face, layer = u / (8 * r), q = u - layer * 8 * r;
-    dz = layer - r + 1;
-    if (q < s) { dy = -r; dx = q - r; }
-    else if (q < 2 * s) { dy = r; dx = q - s - r; }
-    else {
-        const int w = q - 2 * s, side = w >= s - 2;
-        dy = w - side * (s - 2) - r + 1;
-        dx = side ? r : -r;
-    }
-}
-
-// candidate key: f32 bits of the squared distance (non-negative: bit order = numeric order) above the pool index -- ties of exact distance
-// go to the lower index, whatever the order of enumeration
-__device__ inline unsigned long long cand_key(float d2, uint32_t idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | idx; }
 
 // k nearest neighbours of every point of the cloud within the cloud itself (the point is its own nearest), their covariance, PLANE
 // regularisation.  cov6 = (xx, xy, xz, yy, yz, zz) of the regularised matrix, pool order.
@@ -104,6 +59,7 @@ __global__ void __launch_bounds__(kGrpThreads) gicp_cov_kernel(const Slot* __res
     const float4 p = pool[i];
     int kx, ky, kz;
     pos2grid_ndt(p.x, p.y, p.z, res, kx, ky, kz);
+    const float gap = cell_gap3(p.x, p.y, p.z, res, kx, ky, kz);
     const unsigned long long kNone = ~0ull;
     unsigned long long e0 = kNone, e1 = kNone, kth = kNone;
     for (int r = 0;; r++) {
@@ -146,7 +102,7 @@ __global__ void __launch_bounds__(kGrpThreads) gicp_cov_kernel(const Slot* __res
                 }
             }
         }
-        const float reach = (float)r * res;
+        const float reach = (float)r * res + gap;
         if ((kth != kNone && __uint_as_float((uint32_t)(kth >> 32)) <= reach * reach) || r > 64) break;
     }
     // neighbors.colwise() -= neighbors.rowwise().mean(); cov = neighbors * neighbors^T / k   (f64, as the reference casts); the lanes hold
@@ -202,6 +158,7 @@ __global__ void __launch_bounds__(kGrpThreads) gicp_corr_kernel(const Slot* __re
     const float tz = (X.Rf[6] * a.x + X.Rf[7] * a.y) + (X.Rf[8] * a.z + X.tf[2]);
     int kx, ky, kz;
     pos2grid_ndt(tx, ty, tz, res, kx, ky, kz);
+    const float gap = cell_gap3(tx, ty, tz, res, kx, ky, kz);
     unsigned long long bk = ~0ull;  // (squared distance, index) of the nearest so far, the same in all lanes of the group after every ring
     for (int r = 0;; r++) {
         const int n_cells = shell_cells(r);
@@ -230,7 +187,7 @@ __global__ void __launch_bounds__(kGrpThreads) gicp_corr_kernel(const Slot* __re
             const unsigned long long o = __shfl_xor(bk, off, kGrp);
             if (o < bk) bk = o;
         }
-        const float reach = (float)r * res;
+        const float reach = (float)r * res + gap;
         if ((bk != ~0ull && __uint_as_float((uint32_t)(bk >> 32)) <= reach * reach) || reach * reach > max_d2) break;
     }
     if (lane != 0) return;

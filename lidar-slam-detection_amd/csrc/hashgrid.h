@@ -61,4 +61,70 @@ __device__ inline void pos2grid_vgicp(float x, float y, float z, double res, int
     kz = (int)floor((double)z / res - 0.5);
 }
 
+// ---- group search: sixteen lanes (one DPP row) per query --------------------------------------------------------------------------
+// A cloud of a few ten thousand points is 100-200 workgroups with one lane per query: two waves per CU walking hundreds of dependent hash
+// probes each, and a wave waits for its sparsest query (ring r costs 24 r^2 + 2 probes).  With sixteen lanes per query the probes of a
+// shell are made sixteen at a time, the points of a hit cell are split over the lanes, and the launch has sixteen times the waves.
+constexpr int kGrp = 16;
+constexpr int kGrpThreads = 256;  // 16 queries per workgroup
+
+__device__ inline uint32_t grp_ballot(bool p) {
+    const unsigned long long b = __ballot(p);
+    const int lane = threadIdx.x & 63;
+    const uint32_t half = (lane & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+    return (half >> (lane & 16)) & 0xFFFFu;
+}
+
+// cell t of the shell of the (2r + 1)^3 cube around the query's cell: the two z faces, then the perimeter of every layer between them
+__device__ inline int shell_cells(int r) { return r == 0 ? 1 : 2 * (2 * r + 1) * (2 * r + 1) + (2 * r - 1) * 8 * r; }
+__device__ inline void shell_cell(int r, int t, int& dx, int& dy, int& dz) {
+    if (r == 0) { dx = dy = dz = 0; return; }
+    const int s = 2 * r + 1, face = s * s;
+    if (t < 2 * face) {
+        const int f = t >= face, rem = t - f * face, row = rem / s;
+        dz = f ? r : -r;
+        dy = row - r;
+        dx = rem - row * s - r;
+        return;
+    }
+    const int u = t - 2 * face, layer = u / (8 * r), q = u - layer * 8 * r;
+    dz = layer - r + 1;
+    if (q < s) { dy = -r; dx = q - r; }
+    else if (q < 2 * s) { dy = r; dx = q - s - r; }
+    else {
+        const int w = q - 2 * s, side = w >= s - 2;
+        dy = w - side * (s - 2) - r + 1;
+        dx = side ? r : -r;
+    }
+}
+
+// candidate key: f32 bits of the squared distance (non-negative: bit order = numeric order) above the pool index -- ties of exact distance
+// go to the lower index, whatever the order of enumeration
+__device__ inline unsigned long long cand_key(float d2, uint32_t idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | idx; }
+
+
+// distance from x to the nearer face of its own cell along one axis (key floor(x / res - 0.5)), shrunk by the rounding of the key arithmetic:
+// after ring r of a shell search every unseen point is at least r * res + (the smallest gap of the three axes) away
+__device__ inline float cell_gap(float x, float res, int k) {
+    const float f = x / res - 0.5f - (float)k;
+    const float g = fminf(f, 1.0f - f) - 1e-6f * (1.0f + fabsf(x / res));
+    return g > 0.f ? g * res : 0.f;
+}
+__device__ inline float cell_gap3(float x, float y, float z, float res, int kx, int ky, int kz) {
+    return fminf(fminf(cell_gap(x, res, kx), cell_gap(y, res, ky)), cell_gap(z, res, kz));
+}
+
+// exact-key lookup in a hash grid: (ptr, cnt) of the cell's points
+__device__ inline bool grid_find(const Slot* __restrict__ table, uint32_t mask, int cx, int cy, int cz, uint32_t& ptr, uint32_t& cnt) {
+    const unsigned long long want = pack_key(cx, cy, cz);
+    BrickProbe bp = brick_probe(cx, cy, cz);
+    for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
+        const Slot sl = table[brick_slot(bp, mask)];
+        if (sl.key == want) { ptr = sl.ptr; cnt = sl.cnt; return cnt > 0; }
+        if (sl.key == kEmptyKey) return false;
+        brick_next(bp);
+    }
+    return false;
+}
+
 }  // namespace lio

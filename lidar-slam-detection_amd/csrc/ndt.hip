@@ -569,55 +569,59 @@ using namespace lio;
 __global__ void __launch_bounds__(256) ndt_fitness_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, float res,
                                                           NdtXform X, const float4* __restrict__ src, const ScanDev* __restrict__ sd, float max_range_sq,
                                                           float xy_range, float min_z, double* __restrict__ partial) {
+    // sixteen lanes per source point (the probes of a shell sixteen at a time, hashgrid.h), sixteen points per group in turn: a workgroup
+    // still covers 256 points and writes one partial record
     const uint32_t n = sd->n_ds;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & (kGrp - 1), grp = threadIdx.x / kGrp;
     double my_sum = 0.0;
     uint32_t my_cnt = 0, my_kept = 0;
-    bool keep = i < n;
-    if (keep && xy_range > 0.f) {
-        // overlap_merge.hpp:213-223 `filter`, applied to the TRANSFORMED source (:237-239): sqrt(x^2 + y^2) < range && z > floor
-        const float4 p = src[i];
-        const float tx = ((X.R[0] * p.x + X.R[1] * p.y) + X.R[2] * p.z) + X.t[0];
-        const float ty = ((X.R[3] * p.x + X.R[4] * p.y) + X.R[5] * p.z) + X.t[1];
-        const float tz = ((X.R[6] * p.x + X.R[7] * p.y) + X.R[8] * p.z) + X.t[2];
-        keep = sqrtf(tx * tx + ty * ty) < xy_range && tz > min_z;
-    }
-    if (keep) {
-        my_kept = 1;
+    for (int turn = 0; turn < 256 / kGrp; turn++) {
+        const uint32_t i = blockIdx.x * 256u + (uint32_t)turn * kGrp + grp;
+        if (i >= n) break;
         const float4 p = src[i];
         // pcl::transformPointCloud with a Matrix4f: accumulated left to right
         const float tx = ((X.R[0] * p.x + X.R[1] * p.y) + X.R[2] * p.z) + X.t[0];
         const float ty = ((X.R[3] * p.x + X.R[4] * p.y) + X.R[5] * p.z) + X.t[1];
         const float tz = ((X.R[6] * p.x + X.R[7] * p.y) + X.R[8] * p.z) + X.t[2];
+        // overlap_merge.hpp:213-223 `filter`, applied to the TRANSFORMED source (:237-239): sqrt(x^2 + y^2) < range && z > floor
+        if (xy_range > 0.f && !(sqrtf(tx * tx + ty * ty) < xy_range && tz > min_z)) continue;
         int kx, ky, kz;
         pos2grid_ndt(tx, ty, tz, res, kx, ky, kz);
+        const float gap = cell_gap3(tx, ty, tz, res, kx, ky, kz);
         float best = INFINITY;
         for (int r = 0;; r++) {
-            for (int dz = -r; dz <= r; dz++)
-                for (int dy = -r; dy <= r; dy++)
-                    for (int dx = -r; dx <= r; dx++) {
-                        if (max(max(abs(dx), abs(dy)), abs(dz)) != r) continue;
-                        const unsigned long long want = pack_key(kx + dx, ky + dy, kz + dz);
-                        BrickProbe bp = brick_probe(kx + dx, ky + dy, kz + dz);
-                        for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
-                            const Slot sl = table[brick_slot(bp, mask)];
-                            if (sl.key == want) {
-                                for (uint32_t j = 0; j < sl.cnt; j++) {
-                                    const float4 q = pool[sl.ptr + j];
-                                    const float ex = q.x - tx, ey = q.y - ty, ez = q.z - tz;
-                                    const float d2 = (ex * ex + ey * ey) + ez * ez;
-                                    best = fminf(best, d2);
-                                }
-                                break;
-                            }
-                            if (sl.key == kEmptyKey) break;
-                            brick_next(bp);
-                        }
+            const int n_cells = shell_cells(r);
+            for (int t0 = 0; t0 < n_cells; t0 += kGrp) {
+                const int t = t0 + lane;
+                uint32_t ptr = 0, cnt = 0;
+                bool found = false;
+                if (t < n_cells) {
+                    int dx, dy, dz;
+                    shell_cell(r, t, dx, dy, dz);
+                    found = grid_find(table, mask, kx + dx, ky + dy, kz + dz, ptr, cnt);
+                }
+                uint32_t hits = grp_ballot(found);
+                while (hits) {  // the points of a hit cell are split over the lanes (a target voxel holds hundreds)
+                    const int b = __ffs((int)hits) - 1;
+                    hits &= hits - 1;
+                    const uint32_t cptr = __shfl(ptr, b, kGrp), ccnt = __shfl(cnt, b, kGrp);
+                    for (uint32_t j = lane; j < ccnt; j += kGrp) {
+                        const float4 q = pool[cptr + j];
+                        const float ex = q.x - tx, ey = q.y - ty, ez = q.z - tz;
+                        const float d2 = (ex * ex + ey * ey) + ez * ez;
+                        best = fminf(best, d2);
                     }
-            const float reach = (float)r * res;
+                }
+            }
+#pragma unroll
+            for (int off = kGrp / 2; off > 0; off >>= 1) best = fminf(best, __shfl_xor(best, off, kGrp));
+            const float reach = (float)r * res + gap;
             if (best <= reach * reach || reach * reach > max_range_sq) break;
         }
-        if (best <= max_range_sq) { my_sum = (double)best; my_cnt = 1; }
+        if (lane == 0) {
+            my_kept++;
+            if (best <= max_range_sq) { my_sum += (double)best; my_cnt++; }
+        }
     }
     __shared__ double ssum[4];
     __shared__ uint32_t scnt[4], skept[4];
