@@ -219,12 +219,30 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
         // point_selected_surf is re-armed only by a neighbour search (laserMapping.cpp:842-854)
         bool sel = redo_knn ? (nn_cnt[i] >= 5) : (selected[i] != 0);
         if (sel) {
-            float4 near[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) near[k] = nn_pts[(size_t)k * nn_stride + i];
+            // The plane is a function of the five neighbours alone: a pass that does not search (ES:1646-1650 leaves `converge` false) would
+            // fit the plane it fitted last pass -- same inputs, same bits.  It is kept from the pass that searched: (a, b, c) in normvec,
+            // d behind it (plane_d); a point is only evaluated again while it stayed selected, and it stays selected only through passes
+            // that wrote both.  Skips the 80-byte neighbour load and the QR (most of this kernel's instructions) in 2.6 of 4.6 passes.
+            // (An all-zero normal = nothing cached: a bare lio_p2plane_linearize(redo_knn = 0) on a fresh scan takes the long way.)
+            float* plane_d = reinterpret_cast<float*>(normvec + nn_stride);
             float pabcd[4];
+            bool have = false;
+            if (!redo_knn) {
+                const float4 nv = normvec[i];
+                if (nv.x != 0.f || nv.y != 0.f || nv.z != 0.f) {
+                    pabcd[0] = nv.x; pabcd[1] = nv.y; pabcd[2] = nv.z; pabcd[3] = plane_d[i];
+                    have = true;
+                }
+            }
+            if (!have) {
+                float4 near[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) near[k] = nn_pts[(size_t)k * nn_stride + i];
+                have = esti_plane_dev(near, 0.1f, pabcd);
+                if (have) plane_d[i] = pabcd[3];
+            }
             sel = false;
-            if (esti_plane_dev(near, 0.1f, pabcd)) {
+            if (have) {
                 const float pd2 = ((pabcd[0] * pw.x + pabcd[1] * pw.y) + pabcd[2] * pw.z) + pabcd[3];
                 const double pbn = sqrt((double)pb.x * pb.x + ((double)pb.y * pb.y + (double)pb.z * pb.z));  // V3D::norm(): Eigen tree x0 + (x1 + x2)
                 // float s = 1 - 0.9 * fabs(pd2) / sqrt(p_body.norm()); if (s > 0.9)   (laserMapping.cpp:861-863)
