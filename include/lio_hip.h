@@ -220,7 +220,11 @@ typedef struct lio_pass_log {
 } lio_pass_log;
 int lio_engine_pass_log(lio_engine*, int i, lio_pass_log* out);
 /* the per-scan body of fastlio_main: returns 0 first-scan latch, 1 map seeded, 2 too few points,
- * 3 state updated + map_incremental done, < 0 error */
+ * 3 state updated + map_incremental ENQUEUED, < 0 error.  The insert chain (map_incremental's AddPoints + the LRU list) runs on the map's
+ * own stream and is not waited for: the call returns when the state is final, the next scan's upload / motion compensation / downsample
+ * run beside it, and whatever reads the map next (the next neighbour search, any lio_map_* call) is ordered behind it.  A map that
+ * overflowed (LIO_E_CAPACITY) is therefore reported by the NEXT call that touches the map.  With lio_engine_enable_timing(1) the insert
+ * is waited for (its time is one of the stage timings). */
 int lio_engine_process_scan(lio_engine*, const float* raw_body_xyzi, uint32_t n_raw, double lidar_beg_time);
 int lio_engine_process_scan_device(lio_engine*, const void* d_raw_body_xyzi, uint32_t n_raw, double lidar_beg_time);
 /* per-stage device time of the last process_scan in microseconds (hipEvent based; the reference's
@@ -228,7 +232,8 @@ int lio_engine_process_scan_device(lio_engine*, const void* d_raw_body_xyzi, uin
 typedef struct lio_timings {
     float downsample_us, knn_us, linearize_us, insert_us, total_device_us;
     float host_solve_us, total_wall_us;
-    int32_t n_knn_pass, n_pass, n_ds, n_eff_last, n_added;
+    int32_t n_knn_pass, n_pass, n_ds, n_eff_last;
+    int32_t n_added; /* points map_incremental added; while the scan's insert is still running (see above): the count of the last finished one */
     uint64_t knn_candidates; /* in-stencil points visited over all kNN passes (C-bar * N_ds * n_knn) */
     float undistort_us;      /* lio_fastlio_main only: pose upload + point filter + motion compensation kernels */
     float imu_host_us;       /* lio_fastlio_main only: host forward propagation (esekf::predict per IMU sample) */

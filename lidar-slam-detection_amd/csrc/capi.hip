@@ -188,6 +188,7 @@ lio_map* lio_map_create(int device, float resolution, uint64_t max_points, uint6
 // table cost milliseconds, five memsets microseconds); asynchronous on the map's stream.  Not for maps with the LRU list on.
 int map_clear(lio_map* m) {
     if (!m || m->lru_capacity) return LIO_E_INVALID;
+    map_settle(m);
     hipStream_t st = m->stream;
     LIO_HIP_TRY(hipMemsetAsync(m->table, 0xFF, (size_t)m->table_cap * sizeof(Slot), st));
     LIO_HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(m->table) + 8, sizeof(Slot), 0, 8, m->table_cap, st));
@@ -207,6 +208,8 @@ void lio_map_destroy(lio_map* m) {
     hipFree(m->touch); hipFree(m->prev_touch); hipFree(m->touch2); hipFree(m->prev_touch2); hipFree(m->lru_log); hipFree(m->free_items); hipFree(m->free_in);
     hipFree(m->table2); hipFree(m->cap2); hipFree(m->pending2); hipFree(m->created2); hipFree(m->remap);
     if (m->host_dev) hipHostFree(m->host_dev);
+    if (m->ev_classified) hipEventDestroy(m->ev_classified);
+    if (m->ev_inserted) hipEventDestroy(m->ev_inserted);
     if (m->stream && m->own_stream) hipStreamDestroy(m->stream);
     delete m;
 }
@@ -872,7 +875,9 @@ static int incremental_common(lio_map* m, lio_scan* s, const double pose_wi[7], 
     if (m->device != s->device) { set_error("map and scan live on different devices"); return LIO_E_INVALID; }
     hipSetDevice(s->device);
     const PoseArgs pose = make_pose(pose_wi, ext_il);
-    int rc = incremental_classify(m, s, pose, map_leaf, ekf_inited, seed_all);
+    int rc = map_settle(m);
+    if (rc != LIO_OK) return rc;
+    rc = incremental_classify(m, s, pose, map_leaf, ekf_inited, seed_all);
     if (rc != LIO_OK) return rc;
     const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
     rc = map_insert_dev(m, s->stream, m->stage, bound, &m->dev->n_add, travel);
@@ -880,6 +885,42 @@ static int incremental_common(lio_map* m, lio_scan* s, const double pose_wi[7], 
     rc = map_check(m, s->stream);
     if (rc != LIO_OK) return rc;
     return (int)m->host_dev->n_add;
+}
+
+int map_settle(lio_map* m) {
+    if (!m || !m->insert_pending) return LIO_OK;
+    m->insert_pending = false;
+    if (hipEventSynchronize(m->ev_inserted) != hipSuccess) { set_error("map_incremental: %s", hipGetErrorString(hipGetLastError())); return LIO_E_DEVICE; }
+    m->settled_n_add = m->host_dev->n_add;
+    if (m->host_dev->err) {
+        set_error("map capacity exceeded (err bits 0x%x: 1 table full, 2 point pool full, 4 more than max_voxels voxels, 8 LRU log overrun)", m->host_dev->err);
+        return LIO_E_CAPACITY;
+    }
+    return LIO_OK;
+}
+
+int map_incremental_async(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], float map_leaf, int ekf_inited, double travel) {
+    if (!m || !s || !pose_wi || !ext_il) return LIO_E_INVALID;
+    if (m->device != s->device) { set_error("map and scan live on different devices"); return LIO_E_INVALID; }
+    hipSetDevice(s->device);
+    int rc = map_settle(m);
+    if (rc != LIO_OK) return rc;
+    if (!m->ev_classified) {
+        LIO_HIP_TRY(hipEventCreateWithFlags(&m->ev_classified, hipEventDisableTiming));
+        LIO_HIP_TRY(hipEventCreateWithFlags(&m->ev_inserted, hipEventDisableTiming));
+    }
+    const PoseArgs pose = make_pose(pose_wi, ext_il);
+    rc = incremental_classify(m, s, pose, map_leaf, ekf_inited, 0);
+    if (rc != LIO_OK) return rc;
+    const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
+    LIO_HIP_TRY(hipEventRecord(m->ev_classified, s->stream));
+    LIO_HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_classified, 0));
+    rc = map_insert_dev(m, m->stream, m->stage, bound, &m->dev->n_add, travel);
+    if (rc != LIO_OK) return rc;
+    LIO_HIP_TRY(hipMemcpyAsync(m->host_dev, m->dev, sizeof(MapDev), hipMemcpyDeviceToHost, m->stream));
+    LIO_HIP_TRY(hipEventRecord(m->ev_inserted, m->stream));
+    m->insert_pending = true;
+    return LIO_OK;
 }
 
 int lio_map_incremental(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], float map_leaf, int ekf_inited, double travel) {

@@ -94,6 +94,7 @@ struct lio_engine {
     bool static_map = false;
     bool own_map = true;
     bool map_seeded = false;  // NumValidGrids() != 0 observed (a map never becomes empty again)
+    bool n_added_pending = false;  // the last scan's map_incremental runs un-waited on the map's stream: tm.n_added is filled in on demand
     // file-scope state of laserMapping.cpp
     double travel = 0, first_lidar_time = 0;
     double last_pos_lid[3] = {0, 0, 0};
@@ -380,6 +381,11 @@ void append_wheelspeed(lio_engine* e, const LioState& x, Measurement& m) {
 }
 
 int run_update(lio_engine* e) {
+    {   // the previous scan's map_incremental may still be running on the map's stream (process_core does not wait for it): the host looks at
+        // its outcome here, before anything of this update is launched or captured
+        const int rc_settle = map_settle(e->map);
+        if (rc_settle != LIO_OK) return rc_settle;
+    }
     if (e->device_loop && !e->reduce && !e->timing && !e->wheelspeed_en && e->kf.maximum_iter + 1 <= kEkMaxPass) return run_update_device(e);
     e->log.clear();
     PassCtx ctx{e, LIO_OK};
@@ -697,11 +703,25 @@ int lio_engine_set_static_map(lio_engine* e, int on) {
     e->static_map = on != 0;
     return LIO_OK;
 }
-int lio_engine_timings(lio_engine* e, lio_timings* out) { if (!e || !out) return LIO_E_INVALID; *out = e->tm; return LIO_OK; }
+int lio_engine_timings(lio_engine* e, lio_timings* out) {
+    if (!e || !out) return LIO_E_INVALID;
+    if (e->n_added_pending) {  // the last scan's map_incremental was not waited for (process_core), and is not waited for here either:
+        // its count if it has finished, else the count of the last insert that has
+        if (!e->map->insert_pending || hipEventQuery(e->map->ev_inserted) == hipSuccess) {
+            e->n_added_pending = false;
+            const int rc = map_settle(e->map);
+            if (rc != LIO_OK) return rc;
+        }
+        e->tm.n_added = (int)e->map->settled_n_add;
+    }
+    *out = e->tm;
+    return LIO_OK;
+}
 
 static int process_core(lio_engine* e, double lidar_beg_time);
 static int process_common(lio_engine* e, double lidar_beg_time) {
     memset(&e->tm, 0, sizeof(e->tm));
+    e->n_added_pending = false;
     if (e->flg_first_scan) {  // laserMapping.cpp:1171-1177
         e->first_lidar_time = lidar_beg_time;
         e->flg_first_scan = false;
@@ -767,7 +787,17 @@ static int process_core(lio_engine* e, double lidar_beg_time) {
         e->tm.total_wall_us = (float)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
         return 3;
     }
-    if (e->timing) { t0 = e->ev[0]; t1 = e->ev[1]; hipEventRecord(t0, s->stream); }
+    if (!e->timing) {
+        // not waited for: the insert chain runs on the map's stream while this call returns and the next scan is uploaded, undistorted
+        // and downsampled; the next neighbour search (map_knn_plane) looks at its outcome first.  n_added is filled in by lio_engine_timings
+        rc = map_incremental_async(e->map, s, pose, ext, e->leaf_map, e->flg_EKF_inited ? 1 : 0, e->travel);
+        if (rc < 0) return rc;
+        e->n_added_pending = true;
+        e->tm.total_device_us = e->tm.downsample_us + e->tm.knn_us + e->tm.linearize_us;
+        e->tm.total_wall_us = (float)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+        return 3;
+    }
+    t0 = e->ev[0]; t1 = e->ev[1]; hipEventRecord(t0, s->stream);
     rc = lio_map_incremental(e->map, s, pose, ext, e->leaf_map, e->flg_EKF_inited ? 1 : 0, e->travel);
     if (e->timing) {
         hipEventRecord(t1, s->stream);

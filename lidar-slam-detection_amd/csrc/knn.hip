@@ -633,6 +633,7 @@ __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __rest
 // launch less per pass at 14 more registers, slower; the re-search of a later pass from the previous neighbours -- exact, no gain; one lane
 // per query with a flattened sweep -- 2-4 x slower.  tools/experiments/README.md has the numbers.)
 int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int count_touched) {
+    // (may run inside a stream capture: the callers settle a pending insert of the map first -- run_update; batched maps are static)
     // Workgroups per slot: enough of them over all slots to fill the machine a few times (256 CUs x 7 resident workgroups), not more -- a
     // workgroup that takes several query blocks in turn pays the kernel's prologue and epilogue (~11 % of a single block's instructions)
     // once.  One slot alone (the single-scan engine) keeps the full 2048; 24 slots get 512 each (measured: 16.9 -> 14.9 us per scan and
@@ -702,6 +703,7 @@ static int launch_knn_exact(lio_map* m, hipStream_t st, const PoseArgs& pose, co
 }
 
 int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {
+    { const int rc_settle = map_settle(m); if (rc_settle != LIO_OK) return rc_settle; }  // an insert still running on the map's stream
     (void)redo_knn;
     const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
     kt_begin(s, 0);
@@ -717,6 +719,7 @@ int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {
 
 // redo the queued tie queries of the last map_knn_plane exactly (n_tie_host = count read back by the caller)
 int map_knn_exact(lio_map* m, lio_scan* s, const PoseArgs& pose, uint32_t n_tie_host) {
+    { const int rc_settle = map_settle(m); if (rc_settle != LIO_OK) return rc_settle; }  // an insert still running on the map's stream
     return launch_knn_exact<0>(m, s->stream, pose, s->ds_body, s->nn_pts, s->max_ds, n_tie_host, &s->dev->n_tie_done, s->tie_list);
 }
 

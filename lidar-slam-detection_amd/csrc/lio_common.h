@@ -148,6 +148,10 @@ struct lio_map {
     float4* pool;
     lio::MapDev* dev;
     lio::MapDev* host_dev;  // pinned mirror
+    // map_incremental enqueued on the map's own stream and not yet looked at by the host (map_incremental_async / map_settle)
+    hipEvent_t ev_classified = nullptr, ev_inserted = nullptr;
+    bool insert_pending = false;
+    uint32_t settled_n_add = 0;
     unsigned long long* tile_sum;  // prebuilt-map layout scan scratch
     uint32_t* slot_of_point;  // batch insert scratch
     uint64_t slot_of_point_cap;
@@ -285,4 +289,9 @@ int p2plane_linearize_end(lio_map* m, lio_scan* s, const double pose_wi[7], cons
 int scan_share_ds(lio_scan* dst, lio_scan* src, uint32_t n);
 int scan_forget_cache(lio_scan* s);
 int map_clear(lio_map* m);
+// map_incremental without the host wait: the points to add are chosen on the scan's stream (classify), the insert chain (+ LRU) and the
+// status read-back run on the MAP's stream behind an event, and the host looks at the outcome in map_settle -- which everything that reads
+// the map from another stream calls first (the next scan's neighbour search: by then its downsample has run beside the insert)
+int map_incremental_async(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], float map_leaf, int ekf_inited, double travel);
+int map_settle(lio_map* m);
 }
