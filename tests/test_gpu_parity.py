@@ -291,3 +291,27 @@ def test_process_scan_sequence(oracle_mod, scene, loop_mode):
             h.set_cov(P)
     assert rcs[0] == (0, 0) and rcs[1] == (1, 1) and rcs[-1] == (3, 3)
     assert abs(o.travel - e.travel) < 1e-6
+
+
+@pytest.mark.gpu
+def test_map_overflow_is_reported_although_the_insert_is_not_waited_for(scene):
+    """lio_engine_process_scan returns when the state is final; map_incremental runs on the map's stream behind it.  A map that runs out of
+    room must still fail loudly: by the call that overflows it or by the next one that touches the map, never silently."""
+    _dev()
+    from lsd_amd import capi, lio, synth
+
+    e = lio.Engine(resolution=0.5, stencil=19, max_points=12_000, max_voxels=6_000, max_raw=1 << 18, max_ds=100000)
+    e.set_state(synth.state_from_pose([0.0, 0.0, 1.8], [0, 0, 0, 1.0]))
+    pos = np.array([0.0, 0.0, 1.8])
+    raised_at = None
+    for k in range(40):
+        pos = pos + np.array([1.5, 0.3, 0.0])   # new ground every scan: the map keeps growing
+        raw, _ = synth.make_scan(scene, pos, synth.quat_from_rotvec([0, 0, 0.02 * k]), seed=300 + k, n_az=450)
+        try:
+            e.process_scan(raw, 0.1 * k)
+            e.map.stats()
+        except capi.LioError as ex:
+            raised_at = k
+            assert "capacity" in str(ex) or "exceed" in str(ex), str(ex)
+            break
+    assert raised_at is not None and raised_at >= 1
