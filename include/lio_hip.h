@@ -125,6 +125,11 @@ int lio_scan_download_raw(lio_scan*, float* out_xyzi, uint32_t cap);
 int lio_scan_undistort_poses(lio_scan*, const uint32_t* stamp_us, int stamps_on_device, uint64_t header_stamp_us, const uint64_t* pose_stamp_us,
                              const double* pose_T, uint32_t n_poses);
 int lio_scan_voxel_downsample(lio_scan*, float leaf, int sync, uint32_t* n_ds);
+/* the same filter over n scans (each holding its raw cloud: lio_scan_upload / lio_scan_set_device) with ONE set of launches -- the batched
+ * chain of lio_batch, blockIdx.y = scan -- for callers that hold many clouds at once (the candidate key frames of the map-merge tools,
+ * overlap_merge.hpp:158-179; relocalisation; offline re-registration): lio_ndt_align_batch takes the scans as they leave here.  Waits for the
+ * result; n_ds[i] (may be NULL) = points of scan i.  Per scan identical to lio_scan_voxel_downsample */
+int lio_scan_voxel_downsample_batch(lio_scan** scans, int n, float leaf, uint32_t* n_ds);
 /* bypass the filter: use these points as feats_down_body (tests, staged pipelines) */
 int lio_scan_set_ds(lio_scan*, const float* ds_body_xyzi, uint32_t n_ds);
 int lio_scan_num_ds(lio_scan*);                                                   /* syncs the stream */

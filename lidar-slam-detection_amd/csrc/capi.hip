@@ -435,6 +435,8 @@ void lio_scan_destroy(lio_scan* s) {
     if (s->host_dev) hipHostFree(s->host_dev);
     if (s->h_result) hipHostFree(s->h_result);
     if (s->host_nds) hipHostFree(s->host_nds);
+    if (s->d_batch_desc) hipFree(s->d_batch_desc);
+    if (s->h_batch_desc) hipHostFree(s->h_batch_desc);
     if (s->kt) {
         if (s->kt->created)
             for (int w = 0; w < 3; w++)
@@ -666,6 +668,87 @@ int lio_scan_voxel_downsample(lio_scan* s, float leaf, int sync, uint32_t* n_ds)
     s->have_ds = (int)s->host_nds[0];
     if (n_ds) *n_ds = s->host_nds[0];
     return LIO_OK;
+}
+
+// pcl::VoxelGrid of n scans with ONE set of launches: the batched chain of the throughput engine (blockIdx.y = scan), for callers that
+// hold many clouds at once -- the candidate alignments of the map-merge tools, relocalisation, offline re-registration
+// (lio_ndt_align_batch takes the scans as they leave here).  Same result per scan as lio_scan_voxel_downsample.
+int lio_scan_voxel_downsample_batch(lio_scan** scans, int n, float leaf, uint32_t* n_ds) {
+    if (!scans || n <= 0 || n > 4096 || !(leaf > 0.f)) return LIO_E_INVALID;
+    for (int i = 0; i < n; i++) {
+        if (!scans[i] || scans[i]->device != scans[0]->device) { set_error("lio_scan_voxel_downsample_batch: the scans of a call live on one device"); return LIO_E_INVALID; }
+        for (int j = 0; j < i; j++)
+            if (scans[j] == scans[i]) { set_error("lio_scan_voxel_downsample_batch: a scan appears twice"); return LIO_E_INVALID; }
+    }
+    lio_scan* s0 = scans[0];
+    hipSetDevice(s0->device);
+    if (s0->batch_desc_cap < (uint32_t)n) {
+        if (s0->d_batch_desc) hipFree(s0->d_batch_desc);
+        if (s0->h_batch_desc) hipHostFree(s0->h_batch_desc);
+        s0->d_batch_desc = nullptr; s0->h_batch_desc = nullptr; s0->batch_desc_cap = 0;
+        const uint32_t cap = (uint32_t)n < 64u ? 64u : (uint32_t)n;
+        LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s0->d_batch_desc), sizeof(SlotDesc) * cap));
+        LIO_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s0->h_batch_desc), sizeof(SlotDesc) * cap, hipHostMallocDefault));
+        s0->batch_desc_cap = cap;
+    }
+    uint32_t max_raw = 0, max_ds = 0;
+    int passes = 1;
+    for (int i = 0; i < n; i++) {
+        lio_scan* s = scans[i];
+        if (s != s0) LIO_HIP_TRY(hipStreamSynchronize(s->stream));  // its cloud has arrived, nothing of an earlier call still uses its buffers
+        SlotDesc& d = s0->h_batch_desc[i];
+        memset(&d, 0, sizeof(d));
+        d.raw = s->raw;
+        d.n_raw = s->n_raw;
+        d.nblocks = (s->n_raw + 2047u) / 2048u;
+        d.active = s->n_raw ? 1u : 0u;
+        d.max_ds = s->max_ds;
+        d.partial_blocks = s->partial_blocks;
+        d.min_ds = s->resize_min;
+        d.reset_cache = 0;
+        d.sd = s->dev;
+        d.keys_a = s->keys_a; d.keys_b = s->keys_b; d.vals_a = s->vals_a; d.vals_b = s->vals_b;
+        d.hist = s->hist; d.blockcnt = s->blockcnt; d.hpos = s->hpos; d.longlist = s->longlist; d.tie_list = s->tie_list;
+        d.sorted = s->sorted; d.ds_body = s->ds_body; d.ds_world = s->ds_world; d.nn_pts = s->nn_pts; d.normvec = s->normvec;
+        d.nn_cnt = s->nn_cnt; d.selected = s->selected; d.partial = s->partial;
+        d.host_nds = s->host_nds_dev;
+        if (s->n_raw > max_raw) max_raw = s->n_raw;
+        if (s->max_ds > max_ds) max_ds = s->max_ds;
+        if (s->pred_passes > passes) passes = s->pred_passes;
+        s->have_ds = -1;
+        s->host_nds[0] = 0; s->host_nds[1] = 0; s->host_nds[2] = 0;
+    }
+    hipStream_t st = s0->stream;
+    for (;;) {
+        LIO_HIP_TRY(hipMemcpyAsync(s0->d_batch_desc, s0->h_batch_desc, sizeof(SlotDesc) * n, hipMemcpyHostToDevice, st));
+        const int rc = vg_downsample_batch(st, s0->d_batch_desc, n, max_raw, max_ds, leaf, passes);
+        if (rc != LIO_OK) return rc;
+        LIO_HIP_TRY(hipStreamSynchronize(st));
+        bool again = false;
+        for (int i = 0; i < n; i++)
+            if (scans[i]->n_raw && (scans[i]->host_nds[1] & 2u) && passes < 4) again = true;  // an under-launched sort: nothing has consumed it yet
+        if (!again) break;
+        for (int i = 0; i < n; i++) hipMemsetAsync(&scans[i]->dev->err, 0, 4, st);
+        passes = 4;
+    }
+    int first_err = LIO_OK;
+    for (int i = 0; i < n; i++) {
+        lio_scan* s = scans[i];
+        if (!s->n_raw) { s->have_ds = 0; if (n_ds) n_ds[i] = 0; continue; }
+        if (s->host_nds[1] & 1u) {
+            set_error("downsampled scan %d exceeds max_ds %u", i, s->max_ds);
+            hipMemsetAsync(&s->dev->err, 0, 4, st);
+            if (first_err == LIO_OK) first_err = LIO_E_CAPACITY;
+            if (n_ds) n_ds[i] = 0;
+            continue;
+        }
+        const int needed = (int)s->host_nds[2];
+        s->pred_passes = needed >= 1 && needed <= 4 ? needed : 4;
+        s->have_ds = (int)s->host_nds[0];
+        if (n_ds) n_ds[i] = s->host_nds[0];
+    }
+    if (first_err != LIO_OK) LIO_HIP_TRY(hipStreamSynchronize(st));
+    return first_err;
 }
 
 int lio_scan_set_ds(lio_scan* s, const float* ds, uint32_t n) {

@@ -196,6 +196,9 @@ struct lio_scan {
     lio_normal_eq* d_result;
     uint32_t* host_nds;           // pinned, mapped: {n_ds, err, radix passes the scan needed} written by vg_heads_kernel
     int pred_passes;              // radix passes the last waited-for downsample needed (4 until known)
+    lio::SlotDesc* d_batch_desc = nullptr;  // lio_scan_voxel_downsample_batch with this scan first: the descriptor rows of the call
+    lio::SlotDesc* h_batch_desc = nullptr;  // (pinned)
+    uint32_t batch_desc_cap = 0;
     uint32_t* host_nds_dev;
     lio_normal_eq* h_result;      // pinned, mapped
     lio_normal_eq* h_result_dev;  // device-side alias of h_result (linearize_kernel's last workgroup writes the record there)

@@ -180,6 +180,14 @@ class Scan:
         check(lib().lio_scan_voxel_downsample(self.h, float(leaf), int(sync), C.byref(n)), "voxel downsample")
         return int(n.value)
 
+    @staticmethod
+    def voxel_downsample_batch(scans, leaf=0.5):
+        """lio_scan_voxel_downsample_batch: the VoxelGrid of many scans with one set of launches; returns the point counts"""
+        hs = (C.c_void_p * len(scans))(*[s.h for s in scans])
+        n = (C.c_uint32 * len(scans))()
+        check(lib().lio_scan_voxel_downsample_batch(hs, len(scans), float(leaf), n), "voxel downsample batch")
+        return [int(v) for v in n]
+
     def set_ds(self, ds):
         d = f32(ds).reshape(-1, 4)
         check(lib().lio_scan_set_ds(self.h, ptr(d, C.c_float), len(d)), "set_ds")

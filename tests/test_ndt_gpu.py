@@ -345,3 +345,32 @@ def test_batched_alignments_equal_the_single_ones(scene):
     for k, (Tb, cb, itb, evals, rc) in enumerate(mixed):
         Ts, cs, its = (ndt if tg[k] is None else tg[k]).align(scans[k], guesses[k])
         assert rc == 0 and (cb, itb) == (cs, its) and np.abs(Tb - Ts).max() < 1e-9, k
+
+
+def test_batched_voxel_downsample_equals_the_single_scans(scene):
+    """lio_scan_voxel_downsample_batch: one set of launches for n scans -- every scan's output bit-identical (points AND order) to its own
+    lio_scan_voxel_downsample, for clouds of different sizes, a leaf that needs another number of radix passes, and again on re-use"""
+    from lsd_amd import lio, synth
+
+    rng = np.random.default_rng(3)
+    clouds = []
+    for k, n_az in enumerate((450, 1875, 120, 900, 33)):
+        raw, _ = synth.make_scan(scene, np.array([2.0 * k, -1.0 * k, 1.8]), synth.quat_from_rotvec([0, 0, 0.3 * k]), seed=700 + k, n_az=n_az, max_range=150.0)
+        clouds.append(raw[:, :4].astype(np.float32))
+    clouds.append(clouds[0][:7].copy())  # fewer points than one tile
+    single = lio.Scan(max_raw=1 << 18, max_ds=200000)
+    batch = [lio.Scan(max_raw=1 << 18, max_ds=200000) for _ in clouds]
+    for leaf in (0.2, 0.5, 2.0, 0.2):
+        want = []
+        for c in clouds:
+            single.upload(c)
+            single.voxel_downsample(leaf)
+            want.append(single.get_ds())
+        for b, c in zip(batch, clouds):
+            b.upload(c)
+        counts = lio.Scan.voxel_downsample_batch(batch, leaf)
+        for b, w, cnt in zip(batch, want, counts):
+            got = b.get_ds()
+            assert cnt == len(w) == len(got) and np.array_equal(got.view(np.uint32), w.view(np.uint32)), (leaf, cnt, len(w))
+    with pytest.raises(Exception):
+        lio.Scan.voxel_downsample_batch([batch[0], batch[0]], 0.5)
