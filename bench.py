@@ -844,32 +844,40 @@ def bench_localize(args, torch, local_rank):
         # launches (lio_scan_voxel_downsample_batch) + their alignments in one lio_ndt_align_batch call, the LM loop on the device
         batched = None
         try:
-            NB = 32
             if not scans_b:
-                scans_b.extend(lio.Scan(max_raw=1 << 18, max_ds=200000, device=local_rank) for _ in range(NB))
+                scans_b.extend(lio.Scan(max_raw=1 << 18, max_ds=200000, device=local_rank) for _ in range(64))
             sb = scans_b
 
-            def run_batched():
+            def run_batched(NB, split=None):
                 out = []
                 for base in range(0, args.steps, NB):
                     idx = list(range(base, min(base + NB, args.steps)))
+                    c0 = time.perf_counter()
                     for j, i in enumerate(idx):
                         sb[j].set_device(pool[i % len(pool)]["d"].data_ptr(), len(pool[i % len(pool)]["raw"]))
                     lio.Scan.voxel_downsample_batch(sb[:len(idx)], leaf)
+                    c1 = time.perf_counter()
                     out += n.align_batch(sb[:len(idx)], [guesses[i] for i in idx])
+                    if split is not None:
+                        split[0] += c1 - c0
+                        split[1] += time.perf_counter() - c1
                 return out
 
-            run_batched()  # warm (slot buffers of the matcher)
-            torch.cuda.synchronize()
-            tb0 = time.perf_counter()
-            res_b = run_batched()
-            torch.cuda.synchronize()
-            dtb = time.perf_counter() - tb0
-            dmax = max(float(np.abs(rb[0] - ps).max()) for rb, ps in zip(res_b, poses_single))
-            batched = {"ms_per_scan": round(1e3 * dtb / args.steps, 4), "points_per_s": round(n_raw * args.steps / dtb, 1), "scans_per_call": NB,
-                       "converged": int(sum(int(rb[1]) for rb in res_b)), "max_abs_difference_from_the_single_scan_results": dmax,
-                       "what": "the same scans and guesses, 32 at a time: lio_scan_voxel_downsample_batch + lio_ndt_align_batch (independent scans, as in the "
+            batched = {"what": "the same scans and guesses, NB at a time: lio_scan_voxel_downsample_batch + lio_ndt_align_batch (independent scans, as in the "
                                "metric config; a live localisation loop is sequential and takes the per-scan figure)"}
+            for NB in (32, 64):
+                run_batched(NB)  # warm (slot buffers of the matcher)
+                torch.cuda.synchronize()
+                split = [0.0, 0.0]
+                tb0 = time.perf_counter()
+                res_b = run_batched(NB, split)
+                torch.cuda.synchronize()
+                dtb = time.perf_counter() - tb0
+                dmax = max(float(np.abs(rb[0] - ps).max()) for rb, ps in zip(res_b, poses_single))
+                batched[f"{NB}_scans_per_call"] = {"ms_per_scan": round(1e3 * dtb / args.steps, 4), "points_per_s": round(n_raw * args.steps / dtb, 1),
+                                                   "voxelgrid_ms_per_scan": round(1e3 * split[0] / args.steps, 4), "align_ms_per_scan": round(1e3 * split[1] / args.steps, 4),
+                                                   "converged": int(sum(int(rb[1]) for rb in res_b)), "max_abs_difference_from_the_single_scan_results": dmax,
+                                                   "evaluations": int(sum(int(rb[3]) for rb in res_b)), "align_seconds": split[1]}
         except Exception as ex:
             batched = {"error": repr(ex)[-300:]}
         # roofline leg: the same alignments once more with HIP events around every ndt_cost_kernel launch
@@ -887,9 +895,16 @@ def bench_localize(args, torch, local_rank):
         b_alg = (kt["source_points"] / L) * 16.0 + (kt["update_launches"] / L) * (kt["source_points"] / L) * 7 * 16.0 + (kt["pairs"] / L) * 76.0
         us = kt["cost_us"] / L
         ach = b_alg / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        if batched and "error" not in batched:
+            # the batched cost kernel against the same per-evaluation bytes (SURVEY 8d's B_corr + B_der): evaluations x bytes over the align part
+            for key in ("32_scans_per_call", "64_scans_per_call"):
+                bj = batched[key]
+                ach_b = bj.pop("evaluations") * b_alg / max(bj.pop("align_seconds"), 1e-9) / 1e9
+                bj["roofline"] = {"bound": "hbm", "kernel": "ndt_cost_batch<DIRECT7> + ndt_lm_step_batch (whole align part, host checks included)", "achieved": round(ach_b, 1),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 5), "traffic": None}
         cases[name] = {"target_points": npts, "target_voxels": nvox, "target_build_ms": round(1e3 * t_build, 2), "ms_per_scan": round(1e3 * dt / args.steps, 4),
                        "points_per_s": round(n_raw * args.steps / dt, 1), "n_ds_avg": round(float(np.mean(nds)), 1), "lm_iterations_avg": round(float(np.mean(its)), 2),
-                       "converged": conv, "batched_32_scans_per_call": batched, "pos_err_m_median": float(np.median(errs)), "pos_err_m_max": float(np.max(errs)), "rot_err_rad_median": float(np.median(angs)),
+                       "converged": conv, "batched": batched, "pos_err_m_median": float(np.median(errs)), "pos_err_m_max": float(np.max(errs)), "rot_err_rad_median": float(np.median(angs)),
                        "roofline": {"bound": "hbm", "kernel": "ndt_cost_kernel<DIRECT7> (1 lane per source point: 7 voxel probes + P2D cost [+ H, b], f64 block reduce)",
                                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                                     "algorithmic_bytes_per_launch": int(b_alg), "avg_launch_us": round(us, 2), "launches": L,
