@@ -51,6 +51,11 @@ def test_round3_line_carries_the_parity_of_the_timed_path_and_every_config():
     assert c["config3_stream_lru_1e5_300_sweeps"]["voxels_evicted"] > 0
     assert c["config4_localize_5e7_map"]["resident_map"]["target_points"] == 50_000_000
     assert c["config4_localize_5e7_map"]["resident_map"]["converged"] == 200
+    for case in ("resident_map", "local_200k_map"):  # the throughput form of config 4: same poses as the per-scan run, bit for bit
+        for nb in ("32_scans_per_call", "64_scans_per_call"):
+            t = c["config4_localize_5e7_map"][case]["batched"][nb]
+            assert t["max_abs_difference_from_the_single_scan_results"] == 0.0 and t["converged"] == 200
+            assert t["ms_per_scan"] < 0.5 * c["config4_localize_5e7_map"][case]["ms_per_scan"] and 0 < t["roofline"]["frac"] < 1
     m = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_merge.json")).read())
     assert m["n_gpus"] == 1 and "NOT measured" in m["collective"]["backend"] and m["collective"]["states_identical_on_all_ranks"] is True
 
