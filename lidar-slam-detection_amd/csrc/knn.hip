@@ -48,7 +48,9 @@ constexpr int kGPB = 256 / kG;         // queries per workgroup
 // ~100 of those per query, each a dependent ~100-cycle wait.
 template <int CTRL>
 __device__ inline uint32_t dpp_row(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    // old = 0 with bound_ctrl: every lane of a row rotation / quad permutation has a source lane, so `old` is never used -- and in this form the
+    // compiler folds the move into the consuming v_min / v_max / v_add (v_min_u32_dpp ...) instead of a v_mov_b32_dpp + s_nop + op
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 __device__ inline uint32_t group_min32(uint32_t v) {
     if constexpr (kG == 8) {  // half a DPP row: two quad permutes and the half-row mirror
