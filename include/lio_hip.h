@@ -409,6 +409,14 @@ lio_batch* lio_batch_create(lio_map* shared_map, int n_slots, int n_groups, uint
  * the degeneracy sums (src/laserMapping.cpp:946-964) is redone by the host-driven path (lio_engine_joint_register_device of the slot's engines).
  * Results equal lio_engine_joint_register's on the same sub-maps, job by job (tests/test_dist.py). */
 lio_batch* lio_batch_create_joint(lio_map** sub_maps, int n_sub_maps, lio_comm* comm, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds);
+/* the collective of the joint mode through a caller-supplied function instead of RCCL (embedding in a host that has its own transport; and the
+ * way the world > 1 logic is exercised where RCCL cannot be -- two ranks on ONE GPU over gloo, tests/test_dist.py): called on the submitting
+ * thread once per round and pass with this rank's [n_records x 32] doubles in device memory, it must leave every rank's records, rank-major
+ * ([rank][record][32]), in d_gathered before it returns (work already enqueued on `stream` precedes the call; what follows is enqueued after).
+ * For a batch created by lio_batch_create_joint WITHOUT a communicator; a scan that needs the host-driven path (degeneracy sums) fails with
+ * LIO_E_STATE in this mode. */
+typedef int (*lio_gather_fn)(void* ctx, const double* d_local, double* d_gathered, uint32_t n_records, void* stream);
+int lio_batch_set_gather_hook(lio_batch*, lio_gather_fn fn, void* ctx, int rank, int world);
 void lio_batch_destroy(lio_batch*);
 int lio_batch_process(lio_batch*, lio_scan_job* jobs, int n_jobs);
 /* live kernel timing of the batched chain with HIP events on the groups' streams (bench.py's roofline leg): per class the summed device

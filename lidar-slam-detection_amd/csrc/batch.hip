@@ -66,6 +66,8 @@ struct lio_batch {
     std::vector<lio_map*> maps;
     lio_comm* comm = nullptr;
     int world = 1;
+    int (*gather_hook)(void*, const double*, double*, uint32_t, void*) = nullptr;  // lio_batch_set_gather_hook
+    void* gather_ctx = nullptr;
     bool joint = false;
     std::vector<Group> groups;
     double t_submit = 0, t_wait = 0, t_collect = 0;  // host seconds (LIO_BATCH_PROFILE=1 prints them when the object is destroyed)
@@ -175,7 +177,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
             rc = p2plane_batch_share(g.stream, g.d_desc, B, M, ds_bound);
             if (rc == LIO_OK) rc = scan_begin_rows(g.stream, g.d_desc + B, B * (M - 1));
             if (rc != LIO_OK) return rc;
-            return p2plane_batch_update_joint(b->maps.data(), M, b->comm, b->world, g.stream, g.d_desc, B, ds_bound, 5, g.d_local32, g.d_gathered, bt);
+            return p2plane_batch_update_joint(b->maps.data(), M, b->comm, b->world, b->gather_hook, b->gather_ctx, g.stream, g.d_desc, B, ds_bound, 5, g.d_local32, g.d_gathered, bt);
         }
         return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, bt, bt ? b->count_touched : 0);
     };
@@ -316,6 +318,22 @@ lio_batch* lio_batch_create_joint(lio_map** sub_maps, int n_sub_maps, lio_comm* 
     return batch_create_impl(sub_maps, n_sub_maps, comm, n_slots, n_groups, max_raw, max_ds);
 }
 
+int lio_batch_set_gather_hook(lio_batch* b, lio_gather_fn fn, void* ctx, int rank, int world) {
+    if (!b || !fn || world < 1 || rank < 0 || rank >= world) return LIO_E_INVALID;
+    if (!b->joint || b->comm) { set_error("lio_batch_set_gather_hook: for a batch made by lio_batch_create_joint without a communicator"); return LIO_E_STATE; }
+    hipSetDevice(b->map->device);
+    for (auto& g : b->groups) {  // room for every rank's records
+        LIO_HIP_TRY(hipStreamSynchronize(g.stream));
+        if (g.d_gathered) hipFree(g.d_gathered);
+        g.d_gathered = nullptr;
+        LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_gathered), sizeof(double) * 32 * b->n_slots * (size_t)world));
+    }
+    b->gather_hook = fn;
+    b->gather_ctx = ctx;
+    b->world = world;
+    return LIO_OK;
+}
+
 void lio_batch_destroy(lio_batch* b) {
     if (!b) return;
     hipSetDevice(b->device);
@@ -400,6 +418,12 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
                 continue;
             }
             if (r.status == EK_SKIPPED) { job.rc = 2; continue; }  // fewer than five downsampled points
+            if (r.status == EK_NEEDS_HOST && b->joint && b->gather_hook) {
+                set_error("lio_batch (gather hook mode): a scan needs the host-driven joint path, which only exists over a lio_comm");
+                job.rc = LIO_E_STATE;
+                note(job.rc);
+                continue;
+            }
             if (r.status == EK_NEEDS_HOST && b->joint) {
                 // a pass of this scan needs the degeneracy sums of laserMapping.cpp:946-964, which live on several sub-maps / ranks: the scan is
                 // registered again by the host-driven joint path of the slot's engines (every rank takes this branch for the same jobs in the

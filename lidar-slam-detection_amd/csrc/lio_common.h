@@ -268,7 +268,7 @@ int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, in
 struct lio_comm;
 namespace lio {
 int p2plane_batch_share(hipStream_t st, const SlotDesc* d_descs, int n_slots, int n_maps, uint32_t ds_bound);
-int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
+int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, int (*gather_hook)(void*, const double*, double*, uint32_t, void*), void* gather_ctx, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
                                int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt);
 int scan_begin_rows(hipStream_t st, const SlotDesc* d_descs, int n_rows);
 int scan_begin(lio_scan* s);

@@ -661,7 +661,8 @@ int p2plane_batch_share(hipStream_t st, const SlotDesc* d_descs, int n_slots, in
 // all-gather across ranks (comm.hip; a world of one gathers nothing), the filter pass on the rank-ordered sums.  Enqueued blind, eagerly (no
 // graph: a collective sits in the middle of every pass).
 int lio_allgather_records_internal(::lio_comm* c, const double* d_local, double* d_gathered, uint32_t n_records, hipStream_t st);  // comm.hip
-int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
+int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, int (*gather_hook)(void*, const double*, double*, uint32_t, void*),
+                               void* gather_ctx, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
                                int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt) {
     uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
     if (lin_blocks == 0) lin_blocks = 1;
@@ -680,7 +681,11 @@ int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int
         hipLaunchKernelGGL(joint_fold_batch, dim3((uint32_t)n_slots), 1024, 0, st, d_descs, (uint32_t)n_slots, n_maps, d_local32);
         LIO_HIP_TRY(hipGetLastError());
         const double* sums = d_local32;
-        if (comm && world > 1) {
+        if (gather_hook && world > 1) {  // lio_batch_set_gather_hook: the caller's transport instead of RCCL
+            const int rc = gather_hook(gather_ctx, d_local32, d_gathered, (uint32_t)n_slots, st);
+            if (rc != LIO_OK) { set_error("the gather hook returned %d", rc); return rc < 0 ? rc : LIO_E_DEVICE; }
+            sums = d_gathered;
+        } else if (comm && world > 1) {
             const int rc = lio_allgather_records_internal(comm, d_local32, d_gathered, (uint32_t)n_slots, st);
             if (rc != LIO_OK) return rc;
             sums = d_gathered;

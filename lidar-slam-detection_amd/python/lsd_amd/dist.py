@@ -49,6 +49,39 @@ class NormalEqAllGather:
         self.bytes += 8 * n * self.world
 
 
+class RecordsAllGatherHost:
+    """gather hook for lio.Batch.set_gather_hook over a torch.distributed group with HOST tensors (gloo): the round's [n x 32] doubles leave the
+    device, are all-gathered rank-major and come back -- the transport of the tests where RCCL cannot run (two ranks on one GPU); a real
+    multi-GPU job hands lio_batch_create_joint a lio_comm instead (RCCL on the round's stream, no host in the loop)"""
+
+    def __init__(self, group=None):
+        import ctypes
+
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group)
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        self.calls = 0
+
+    def __call__(self, d_local, d_gathered, n, stream):
+        torch = self.torch
+        if self.hip.hipStreamSynchronize(stream) != 0:
+            return -1
+        local = torch.empty(n * 32, dtype=torch.float64)
+        if self.hip.hipMemcpy(local.data_ptr(), d_local, n * 32 * 8, 2) != 0:  # device -> host
+            return -1
+        flat = torch.empty(self.world * n * 32, dtype=torch.float64)  # rank-major: [rank][record][32]
+        self.dist.all_gather_into_tensor(flat, local, group=self.group)
+        if self.hip.hipMemcpy(d_gathered, flat.data_ptr(), self.world * n * 32 * 8, 1) != 0:  # host -> device
+            return -1
+        self.calls += 1
+        return 0
+
+
 def sequential_sum(records):
     """what NormalEqAllGather computes, for a list of per-rank records held in one process (tests, 1-GPU emulation)"""
     acc = np.array(records[0], dtype=np.float64, copy=True)

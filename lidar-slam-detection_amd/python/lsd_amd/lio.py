@@ -775,6 +775,22 @@ class Batch:
 
     __del__ = close
 
+    def set_gather_hook(self, fn, rank, world):
+        """lio_batch_set_gather_hook: fn(d_local: int, d_gathered: int, n_records: int, stream: int) -> int (0 = ok) moves the round's records
+        between the ranks instead of RCCL (lsd_amd.dist.RecordsAllGatherHost: gloo, two ranks on one GPU in the tests)"""
+
+        def _cb(_ctx, d_local, d_gathered, n, stream):
+            try:
+                return int(fn(int(d_local or 0), int(d_gathered or 0), int(n), int(stream or 0)) or 0)
+            except Exception:  # nothing may propagate through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return -1
+
+        self._gather = capi.GATHER_FN(_cb)  # keep the trampoline alive
+        check(lib().lio_batch_set_gather_hook(self.h, self._gather, None, int(rank), int(world)), "set_gather_hook")
+
     def enable_kernel_timing(self, on=True):
         check(lib().lio_batch_enable_kernel_timing(self.h, int(on)))
 

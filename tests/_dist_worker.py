@@ -1,6 +1,8 @@
 """worker for tests/test_dist.py: one rank of a world_size-N gloo job.  argv: mode outdir
 mode "cpu": per-rank normal equations from the CPU oracle on this rank's sub-map, reduced with NormalEqAllGather
-mode "gpu": a full joint registration with lio.Engine + reduce hook on cuda:0 (collective over gloo)"""
+mode "gpu": a full joint registration with lio.Engine + reduce hook on cuda:0 (collective over gloo)
+mode "gpu_batch": the BATCHED joint registration (lio_batch_create_joint) with this rank's share of four sub-maps on cuda:0, the [B x 32]-double
+                  records of a round all-gathered over gloo through lio_batch_set_gather_hook (RCCL refuses two ranks on one device)"""
 import os
 import sys
 
@@ -24,6 +26,41 @@ def make_world(world):
     return subs, raw, synth.state_from_pose(gp, gq), true_pos, true_q
 
 
+def batch_scans():
+    """key-frame scans with their priors, the same on every rank (what test_dist's batched tests register)"""
+    from lsd_amd import synth
+
+    scene = synth.Scene(half=40.0, n_boxes=12, seed=21)
+    out = []
+    for k in range(6):
+        pos = np.array([0.3 + 1.5 * k, 0.8 - 0.7 * k, 1.7])
+        q = synth.quat_from_rotvec([0, 0, 0.2 + 0.3 * k])
+        raw, _ = synth.make_scan(scene, pos, q, seed=230 + k, n_az=300)
+        gp, gq = synth.perturb_pose(pos, q, seed=240 + k, max_t=0.15, max_deg=1.0)
+        out.append((raw, synth.state_from_pose(gp, gq), pos))
+    return out
+
+
+def run_batch(sub_maps_pts, gather=None, rank=0, world=1):
+    """the scans of batch_scans() jointly against `sub_maps_pts` (this process's sub-maps); returns the result dictionaries"""
+    import scenes
+    from lsd_amd import lio
+
+    maps = []
+    for sub in sub_maps_pts:
+        m = lio.Map(resolution=0.5, stencil=19, max_points=400_000, max_voxels=200_000)
+        m.add(sub)
+        maps.append(m)
+    b = lio.Batch(maps[0], n_slots=4, n_groups=2, max_raw=1 << 17, max_ds=1 << 16, sub_maps=maps[1:], comm=None)
+    if gather is not None:
+        b.set_gather_hook(gather, rank, world)
+    P0 = lio.init_cov()
+    jobs = [dict(dptr=scenes.to_device(raw), n=len(raw), t=1.0, state=st, cov=P0) for raw, st, _ in batch_scans()]
+    rc, res = b.process(jobs)
+    assert rc == 0, rc
+    return res
+
+
 def main():
     mode, outdir = sys.argv[1], sys.argv[2]
     import torch.distributed as dist
@@ -32,6 +69,16 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     from lsd_amd import dist as ldist
 
+    if mode == "gpu_batch":
+        subs4 = make_world(4)[0]
+        per = 4 // world
+        gather = ldist.RecordsAllGatherHost()
+        res = run_batch(subs4[rank * per:(rank + 1) * per], gather, rank, world)
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), states=np.array([r["state"] for r in res]), rcs=np.array([r["rc"] for r in res]),
+                 passes=np.array([[r["n_pass"], r["n_knn_pass"]] for r in res]), calls=gather.calls)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     subs, raw, state, _, _ = make_world(world)
     hook = ldist.NormalEqAllGather()
     if mode == "cpu":

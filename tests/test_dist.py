@@ -199,6 +199,28 @@ def test_batched_joint_registration_equals_single_joint_registrations():
 
 
 @pytest.mark.gpu
+def test_batched_joint_registration_two_ranks_one_gpu():
+    """the world > 1 logic of the batched joint mode, for real: two processes on cuda:0, two of four sub-maps each, every round's [B x 32]-double
+    records exchanged rank-major through lio_batch_set_gather_hook (gloo: RCCL refuses two ranks on one device), summed in rank order inside
+    step_batch.  Both ranks must end with bit-identical states, and those must be the one-process result over all four sub-maps up to the
+    order of the f64 additions ((m0 + m1) + (m2 + m3) against ((m0 + m1) + m2) + m3)."""
+    sys.path.insert(0, HERE)
+    from _dist_worker import batch_scans, make_world, run_batch
+
+    with tempfile.TemporaryDirectory() as td:
+        _run("gpu_batch", 2, td)
+        r0, r1 = np.load(os.path.join(td, "rank0.npz")), np.load(os.path.join(td, "rank1.npz"))
+    assert np.array_equal(r0["states"], r1["states"]) and np.array_equal(r0["passes"], r1["passes"])
+    assert np.all(r0["rcs"] == 3) and np.all(r1["rcs"] == 3)
+    assert int(r0["calls"]) == int(r1["calls"]) >= 2  # one exchange per round and pass
+    one = run_batch(make_world(4)[0])
+    for k, (r, (_, _, pos)) in enumerate(zip(one, batch_scans())):
+        assert r["rc"] == 3 and (r["n_pass"], r["n_knn_pass"]) == tuple(r0["passes"][k])
+        assert np.abs(r["state"] - r0["states"][k]).max() < 1e-9, k
+        assert not np.array_equal(r["state"], np.zeros(26)) and np.linalg.norm(r["state"][:3] - pos) < 0.05
+
+
+@pytest.mark.gpu
 def test_batched_joint_registration_degenerate_scene_falls_back_to_the_host_path():
     """open ground: the eigenvalue bound of the GLOBAL sum n n^T does not decide, the six degeneracy sums are needed -- they live on several
     sub-maps, so the batched joint mode hands the scan to the host-driven joint path of the slot's engines: the result IS lio_engine_joint_register's"""
