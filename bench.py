@@ -59,8 +59,8 @@ def main():
                                                               "each, all reading the one resident map)")
     ap.add_argument("--engine", choices=["batch", "threads"], default="batch",
                     help="batch: B scans per launch, filter loop on the device, one host thread (lio_batch_*); threads: round 1's one engine + thread per scan")
-    ap.add_argument("--slots", type=int, default=32, help="--engine batch: scans per launch")
-    ap.add_argument("--groups", type=int, default=3, help="--engine batch: rounds in flight (one HIP stream each)")
+    ap.add_argument("--slots", type=int, default=64, help="--engine batch: scans per launch")
+    ap.add_argument("--groups", type=int, default=4, help="--engine batch: rounds in flight (one HIP stream each)")
     ap.add_argument("--config", choices=["metric", "merge", "stream", "localize"], default="metric",
                     help="metric: BASELINE.json's headline (independent 120k-pt scans vs a 1e7-pt map); merge: BASELINE config 5, multi-map merge -- 8 sub-maps "
                          "spread over the GPUs, every key-frame scan registered JOINTLY against all of them (RCCL all-gather of the per-rank J^T J / J^T r); "
@@ -316,7 +316,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "knn_batch_traffic.json" if batch is not None else "knn_traffic.json")
     if os.path.exists(tpath):  # HBM bytes per launch from the PMC counters (collected by tools/pmc_traffic.py in its own rocprofv3 --pmc passes)
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            if batch is not None and tj.get("slots_per_launch", args.slots) != args.slots:
+                traffic = None  # collected with another number of scans per launch: not this kernel launch's figure
         except Exception:
             traffic = None
     # ---- the whole scan against the roofline, as SURVEY.md 8d defines it: B_scan = B_ds + n_knn B_knn + n_pass B_lin (+ B_ins, none against a
@@ -410,7 +413,7 @@ def main():
             same = all(np.array_equal(results[i]["state"], results[i % args.steps % period]["state"]) for i in range(len(results)))
             batch_vs_oracle = {"max_dpos_m": batch_dp, "max_drot_rad": batch_da, "max_dstate": batch_ds, "scans_checked": batch_checked,
                                "all_timed_results_bit_identical_to_the_checked_ones": bool(same), "timed_results": len(results),
-                               "note": "state_out of the timed lio_batch_process call itself (32 slots x 3 rounds in flight, one hipGraphLaunch per round) against the "
+                               "note": f"state_out of the timed lio_batch_process call itself ({args.slots} slots x {args.groups} rounds in flight, one hipGraphLaunch per round) against the "
                                        "oracle's registration of the same scan; same pass / search counts required"}
             if not same or batch_ds > 1e-9:
                 raise RuntimeError(f"batched engine differs from the oracle on the timed jobs: {batch_vs_oracle}")
@@ -1122,6 +1125,7 @@ def bench_merge(args, torch, dist, world, rank, local_rank, dev):
         box = [lio.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm = lio.Comm(rank=rank, world=world, device=local_rank, uid=box[0])
+    args.slots, args.groups = min(args.slots, 32), min(args.groups, 3)  # every slot carries one scan buffer set PER LOCAL SUB-MAP: 8 x 32 x 3 of them at N = 1
     batch = lio.Batch(maps[0], n_slots=args.slots, n_groups=args.groups, max_raw=1 << 17, max_ds=100000, sub_maps=maps[1:], comm=comm)
     P0 = lio.init_cov()
     scans = []

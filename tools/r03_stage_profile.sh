@@ -23,5 +23,11 @@ rm -rf $O/prof
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- python $R/bench.py --steps 32 --warmup 16 --min-seconds 0 --cpu-scans 0 --ref-scans 0 --secondary 0 --groups 1 > /dev/null 2> $O/pmc_fetch.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o r -- python $R/bench.py --steps 32 --warmup 16 --min-seconds 0 --cpu-scans 0 --ref-scans 0 --secondary 0 --groups 1 > /dev/null 2> $O/pmc_write.err
 python $R/tools/pmc_traffic.py $(find $O/pmc_fetch -name "*_results.db" | head -1) $(find $O/pmc_write -name "*_results.db" | head -1) "knn_batch_kernel<2, false>" > $O/knn_batch_traffic.json
+python - <<P
+import json, re
+j = json.load(open("$O/knn_batch_traffic.json"))
+j["slots_per_launch"] = int(re.search(r'"--slots", type=int, default=(\d+)', open("$R/bench.py").read()).group(1))  # the launches sampled were bench.py's default
+json.dump(j, open("$O/knn_batch_traffic.json", "w"), indent=1)
+P
 rm -rf $O/pmc_fetch $O/pmc_write
 head -12 $O/kernel_stats_stream.csv; cat $O/knn_batch_traffic.json
