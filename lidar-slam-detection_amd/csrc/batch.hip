@@ -232,7 +232,7 @@ extern "C" {
 
 static lio_batch* batch_create_impl(lio_map** maps, int n_maps, lio_comm* comm, int n_slots, int n_groups, uint32_t max_raw, uint32_t max_ds) {
     lio_map* map = n_maps > 0 && maps ? maps[0] : nullptr;
-    if (!map || n_maps > 64 || n_slots < 1 || n_slots > 64 || n_groups < 1 || n_groups > 8 || max_raw == 0 || max_ds == 0) { set_error("lio_batch_create: bad argument"); return nullptr; }
+    if (!map || n_maps > 64 || n_slots < 1 || n_slots > 256 || n_groups < 1 || n_groups > 8 || max_raw == 0 || max_ds == 0) { set_error("lio_batch_create: bad argument"); return nullptr; }
     for (int m = 1; m < n_maps; m++)
         if (!maps[m] || maps[m]->device != map->device) { set_error("lio_batch_create_joint: the sub-maps of a batch live on one device"); return nullptr; }
     if (hipSetDevice(map->device) != hipSuccess) { set_error("lio_batch_create: no HIP device %d", map->device); return nullptr; }

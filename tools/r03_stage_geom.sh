@@ -1,5 +1,5 @@
 #!/bin/bash
-for g in "64 4" "64 3" "56 4" "64 5"; do
+for g in "96 3" "128 2" "128 3" "96 4" "64 4"; do
   set -- $g
   python bench.py --steps 20 --warmup 5 --secondary 0 --cpu-scans 0 --ref-scans 0 --slots $1 --groups $2 --min-seconds 2 2>/dev/null | python -c "
 import json,sys
