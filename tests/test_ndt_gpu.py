@@ -374,3 +374,16 @@ def test_batched_voxel_downsample_equals_the_single_scans(scene):
             assert cnt == len(w) == len(got) and np.array_equal(got.view(np.uint32), w.view(np.uint32)), (leaf, cnt, len(w))
     with pytest.raises(Exception):
         lio.Scan.voxel_downsample_batch([batch[0], batch[0]], 0.5)
+    # an empty scan among the others; a scan whose output does not fit its max_ds fails loudly and leaves the others intact
+    empty = lio.Scan(max_raw=1 << 18, max_ds=200000)
+    small = lio.Scan(max_raw=1 << 18, max_ds=64)
+    batch[0].upload(clouds[0])
+    small.upload(clouds[1])
+    single.upload(clouds[0])
+    single.voxel_downsample(0.5)
+    want0 = single.get_ds()
+    with pytest.raises(Exception, match="max_ds"):
+        lio.Scan.voxel_downsample_batch([batch[0], empty, small], 0.5)
+    assert np.array_equal(batch[0].get_ds().view(np.uint32), want0.view(np.uint32))
+    counts = lio.Scan.voxel_downsample_batch([batch[0], empty], 0.5)
+    assert counts == [len(want0), 0]
