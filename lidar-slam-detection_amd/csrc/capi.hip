@@ -453,6 +453,8 @@ int lio_scan_reset(lio_scan* s) {
     LIO_HIP_TRY(hipMemsetAsync(s->selected, 1, s->max_ds, s->stream));
     LIO_HIP_TRY(hipMemsetAsync(s->nn_cnt, 0, (size_t)s->max_ds * 4, s->stream));
     LIO_HIP_TRY(hipMemsetAsync(s->nn_pts, 0, (size_t)s->max_ds * 5 * sizeof(float4), s->stream));
+    // (the planes a searching pass left for the passes that do not search go with the neighbours they were fitted to: linearize_body)
+    LIO_HIP_TRY(hipMemsetAsync(s->normvec, 0, ((size_t)s->max_ds + (s->max_ds + 3) / 4) * sizeof(float4), s->stream));
     LIO_HIP_TRY(hipMemsetAsync(&s->dev->cache_n, 0, sizeof(uint32_t), s->stream));
     LIO_HIP_TRY(hipStreamSynchronize(s->stream));
     return LIO_OK;
