@@ -16,9 +16,14 @@
 // tests/golden/) and the whole translation units laserMapping.cpp +
 // IMU_Processing.hpp + preprocess.cpp driven end to end
 // (oracle/ref_fastlio.cpp, tests/test_fastlio_vs_ref.py), and this restatement
-// is checked against them.  PCL VoxelGrid is third-party source that is not in
-// the tree: that one stage stays "parity unpinned" (restated from PCL 1.9.1
-// voxel_grid.hpp semantics).
+// is checked against them.  pcl::VoxelGrid itself is third-party source that is
+// not in the tree; the stage is restated from PCL 1.9.1 voxel_grid.hpp semantics
+// and PINNED to the PCL-derived filter the tree does hold -- ndt_omp's
+// pclomp::VoxelGridCovariance::applyFilter, which carries pcl::VoxelGrid's box,
+// overflow guard, keys and per-voxel f32 sums statement for statement
+// (oracle/ref_voxelgrid_cov.cpp, tests/test_voxelgrid_vs_ref.py: bit-exact).  What that
+// cannot pin: the order of the addends inside a voxel after pcl::VoxelGrid's
+// std::sort of its index vector (input order is fixed here).
 //
 // Reference lines followed (paths relative to /root/reference/slam/mapping/fastlio):
 //   voxel downsample ........ PCL 1.9.1 VoxelGrid::applyFilter, called at

@@ -8,7 +8,7 @@
 // (oracle/Makefile `_ref/libref_localmap.so` writes the excerpts with sed; nothing of the reference is copied into this repository.)
 // Around them: the members / types the excerpts name, as plain globals -- key frames with mTransfromPoints, the key-frame position tree
 // (pcl::KdTreeFLANN stand-in: exact, sorted by distance as FLANN returns it), mConfig, mLocalMap, a localizer that records what it is handed.
-// pcl::VoxelGrid is routed to the oracle's restatement (ref_shims/pcl/filters/voxel_grid.h: PCL is not in the tree -- the one unpinned stage),
+// pcl::VoxelGrid is routed to the oracle's restatement (ref_shims/pcl/filters/voxel_grid.h: pcl::VoxelGrid itself is not in the tree; the restatement is pinned by ref_voxelgrid_cov.cpp),
 // pcl::transformPointCloud / pcl::search::KdTree are the stand-ins the GICP harness uses.  Test infrastructure only.
 #include <unistd.h>
 

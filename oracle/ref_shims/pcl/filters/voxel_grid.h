@@ -1,5 +1,5 @@
-// stand-in for <pcl/filters/voxel_grid.h>.  PCL is not installed and its source is not in the reference tree: pcl::VoxelGrid is
-// the ONE stage of the path that stays unpinned.  This shim gives the reference's laserMapping.cpp the SAME restatement the oracle
+// stand-in for <pcl/filters/voxel_grid.h>.  PCL is not installed and pcl::VoxelGrid's own source is not in the reference tree (the
+// restatement is pinned to the PCL-derived pclomp::VoxelGridCovariance the tree does hold: oracle/ref_voxelgrid_cov.cpp).  This shim gives the reference's laserMapping.cpp the SAME restatement the oracle
 // uses (oracle/lio_oracle.cpp voxel_downsample, through liblio_oracle.so), so that everything around it -- the reference's own
 // code -- can be compared with the oracle on equal downsampled clouds.
 #pragma once

@@ -31,6 +31,8 @@ struct PointCloud {
     void push_back(const PointT& p) { points.push_back(p); width = (uint32_t)points.size(); height = 1; }
     PointT& operator[](size_t i) { return points[i]; }
     const PointT& operator[](size_t i) const { return points[i]; }
+    PointT& back() { return points.back(); }
+    const PointT& back() const { return points.back(); }
     PointT& at(size_t i) { return points.at(i); }
     const PointT& at(size_t i) const { return points.at(i); }
     iterator begin() { return points.begin(); }

@@ -1,5 +1,5 @@
-"""A second, independent restatement of pcl::VoxelGrid::applyFilter (PCL 1.9.1 voxel_grid.hpp -- NOT in the reference tree, so the stage is
-"parity unpinned": both restatements come from the published algorithm) written in numpy along another path than oracle/lio_oracle.cpp:
+"""A second, independent restatement of pcl::VoxelGrid::applyFilter (PCL 1.9.1 voxel_grid.hpp -- not in the reference tree; since round 3 the
+oracle is pinned to the PCL-derived filter the tree does hold, tests/test_voxelgrid_vs_ref.py, and this file stays as a cross-check) written in numpy along another path than oracle/lio_oracle.cpp:
 vectorised floor / lexicographic sort by (iz, iy, ix) instead of the linear index, f64 means instead of f32 running sums.  It cross-checks
 what does not depend on summation order: which points share a voxel, the output ORDER (ascending linear index = z-major, then y, then x), the
 point count, the int32 overflow guard, the handling of non-finite points -- and the centroids to 1e-5 m."""
