@@ -44,6 +44,9 @@ typedef struct lio_scan lio_scan;     /* one scan in flight: raw, downsampled, n
 typedef struct lio_engine lio_engine; /* per-scan driver = the body of fastlio_main after IMU processing */
 
 const char* lio_last_error(void);
+/* notes of calls that SUCCEEDED (thread-local, like lio_last_error, which only failures write): e.g. lio_batch_create when GPU_MAX_HW_QUEUES
+ * leaves its rounds in flight sharing hardware queues */
+const char* lio_last_warning(void);
 int lio_device_count(void);
 /* bytes of HBM currently held by a map / scan handle (capacity planning on the 288 GB part) */
 uint64_t lio_map_bytes(const lio_map*);
@@ -228,8 +231,10 @@ int lio_engine_pass_log(lio_engine*, int i, lio_pass_log* out);
  * 3 state updated + map_incremental ENQUEUED, < 0 error.  The insert chain (map_incremental's AddPoints + the LRU list) runs on the map's
  * own stream and is not waited for: the call returns when the state is final, the next scan's upload / motion compensation / downsample
  * run beside it, and whatever reads the map next (the next neighbour search, any lio_map_* call) is ordered behind it.  A map that
- * overflowed (LIO_E_CAPACITY) is therefore reported by the NEXT call that touches the map.  With lio_engine_enable_timing(1) the insert
- * is waited for (its time is one of the stage timings). */
+ * overflowed (LIO_E_CAPACITY) is therefore reported later, ONCE, by whichever call looks first: the next lio_engine_process_scan /
+ * lio_fastlio_main (before it launches anything of its own scan; lio_last_error says the failure is the previous scan's),
+ * lio_engine_timings, or lio_engine_flush -- call lio_engine_flush after the last scan of a run, or the last insert's outcome is never seen.
+ * With lio_engine_enable_timing(1) the insert is waited for (its time is one of the stage timings). */
 int lio_engine_process_scan(lio_engine*, const float* raw_body_xyzi, uint32_t n_raw, double lidar_beg_time);
 int lio_engine_process_scan_device(lio_engine*, const void* d_raw_body_xyzi, uint32_t n_raw, double lidar_beg_time);
 /* per-stage device time of the last process_scan in microseconds (hipEvent based; the reference's
@@ -238,13 +243,17 @@ typedef struct lio_timings {
     float downsample_us, knn_us, linearize_us, insert_us, total_device_us;
     float host_solve_us, total_wall_us;
     int32_t n_knn_pass, n_pass, n_ds, n_eff_last;
-    int32_t n_added; /* points map_incremental added; while the scan's insert is still running (see above): the count of the last finished one */
+    int32_t n_added; /* points map_incremental added; -1 while the scan's insert is still running (see above; lio_engine_flush waits for it) */
     uint64_t knn_candidates; /* in-stencil points visited over all kNN passes (C-bar * N_ds * n_knn) */
     float undistort_us;      /* lio_fastlio_main only: pose upload + point filter + motion compensation kernels */
     float imu_host_us;       /* lio_fastlio_main only: host forward propagation (esekf::predict per IMU sample) */
 } lio_timings;
 int lio_engine_timings(lio_engine*, lio_timings* out);
 int lio_engine_enable_timing(lio_engine*, int on);
+/* waits for the map_incremental the last lio_engine_process_scan / lio_fastlio_main enqueued and returns its outcome (LIO_OK, LIO_E_CAPACITY
+ * when the map overflowed, LIO_E_DEVICE); nothing pending: LIO_OK.  The reference inserts synchronously inside fastlio_main
+ * (laserMapping.cpp:1304): this is where the deferred half of that call ends. */
+int lio_engine_flush(lio_engine*);
 /* ---------------------------------------------------------------------------------------------------------------
  * The IMU front half: the reference's FastLIO entry points, one to one.  After lio_fastlio_init the engine is driven
  * exactly like the reference's module: sensor threads enqueue, the LIO thread calls lio_fastlio_main in a loop
@@ -368,13 +377,17 @@ int lio_engine_joint_register_device(lio_engine* e, const void* d_raw_body_xyzi,
  * Intended for engines created with lio_engine_create_shared on one read-only map (independent scans of several
  * sensors / sequences, relocalisation candidates, map-merge alignments). */
 #define LIO_JOB_KEEP_CACHE 1u
+#define LIO_JOB_FLAGS_KNOWN 1u  /* every other bit must be zero: a job with unknown bits is rejected (rc = LIO_E_INVALID), so that an uninitialised
+                                   word cannot silently pick a behaviour */
 typedef struct lio_scan_job {
     const void* d_raw;          /* device pointer, XYZI float4 */
     uint32_t n_raw;
-    uint32_t flags;             /* 0 (default): the jobs are INDEPENDENT scans -- the engine / slot that takes the job first forgets its neighbour
+    uint32_t flags;             /* ABI note: until round 3 this word was padding and ignored.  ZERO-INITIALISE the job array (memset / = {0}).
+                                   0 (default): the jobs are INDEPENDENT scans -- the engine / slot that takes the job first forgets its neighbour
                                    cache, as fastlio_init does for Nearest_Points (src/laserMapping.cpp:1045-1047), so the result does not depend
                                    on which scan that engine registered before; LIO_JOB_KEEP_CACHE: a job of a sequence -- the cache of the
-                                   previous scan survives (Nearest_Points across fastlio_main calls, stale where a search finds nothing) */
+                                   previous scan survives (Nearest_Points across fastlio_main calls, stale where a search finds nothing): callers that
+                                   feed CONSECUTIVE scans of one sensor through a batch API and want fastlio_main's carry-over must set it */
     double lidar_beg_time;
     const double* state_in;     /* 26 doubles */
     const double* cov_in;       /* 529 doubles */

@@ -138,6 +138,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         job.rc = LIO_E_INVALID;
         job.n_ds = job.n_pass = job.n_knn_pass = 0;
         if (!job.state_in || !job.cov_in || (!job.d_raw && job.n_raw)) continue;
+        if (job.flags & ~LIO_JOB_FLAGS_KNOWN) { set_error("lio_scan_job.flags = 0x%x: unknown bits (a job array that was not zero-initialised?)", job.flags); continue; }
         if (job.n_raw > b->max_raw) { set_error("scan of %u points exceeds max_raw %u", job.n_raw, b->max_raw); job.rc = LIO_E_CAPACITY; continue; }
         if (job.n_raw == 0) { job.rc = 2; continue; }  // "FastLio undistort points is empty"
         d.raw = static_cast<const float4*>(job.d_raw);
@@ -224,9 +225,10 @@ int wait_group(Group& g, int B) {
 
 // HIP deals streams to GPU_MAX_HW_QUEUES hardware queues (4 by default) round robin; with four, the rounds in flight of a batch share queues
 // with the idle per-slot streams and mostly run back to back (measured 0.085 -> 0.070 ms per scan with 8).  The runtime reads the variable
-// when it initialises (the first HIP call of the process), so the library sets it when it is loaded -- unless the application chose a value
-// itself; an application that initialised HIP before loading the library keeps what it had, and lio_batch_create says so (lio_last_error).
-__attribute__((constructor)) static void lio_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// when it initialises (the first HIP call of the process): the APPLICATION exports GPU_MAX_HW_QUEUES=8 before that (bench.py, the tests'
+// conftest and the pybind module's loader do) -- the library does not touch the process environment (until round 3 a load-time constructor
+// called setenv: a process-wide side effect from dlopen, not thread-safe); lio_batch_create leaves a note in lio_last_warning when the value
+// in force is lower.
 
 extern "C" {
 
@@ -304,8 +306,9 @@ static lio_batch* batch_create_impl(lio_map** maps, int n_maps, lio_comm* comm, 
     }
     {   // not an error: a note for whoever wonders why rounds do not overlap
         const char* q = getenv("GPU_MAX_HW_QUEUES");
-        if (n_groups > 1 && q && atoi(q) < 8)
-            set_error("lio_batch_create: GPU_MAX_HW_QUEUES=%s -- with fewer than 8 hardware queues the %d rounds in flight mostly serialise (~20 %% slower)", q, n_groups);
+        if (n_groups > 1 && (!q || atoi(q) < 8))
+            set_warning("lio_batch_create: GPU_MAX_HW_QUEUES=%s -- with fewer than 8 hardware queues the %d rounds in flight mostly serialise (~20 %% slower); "
+                        "export GPU_MAX_HW_QUEUES=8 before the process's first HIP call", q ? q : "(unset: 4)", n_groups);
     }
     return b;
 }

@@ -14,6 +14,14 @@ namespace lio {
 
 static thread_local char g_err[512] = "";
 
+static thread_local char g_warn[512] = "";
+void set_warning(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_warn, sizeof(g_warn), fmt, ap);
+    va_end(ap);
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -129,6 +137,7 @@ using namespace lio;
 extern "C" {
 
 const char* lio_last_error(void) { return g_err; }
+const char* lio_last_warning(void) { return g_warn; }
 
 int lio_device_count(void) {
     int n = 0;
@@ -972,16 +981,27 @@ static int incremental_common(lio_map* m, lio_scan* s, const double pose_wi[7], 
     return (int)m->host_dev->n_add;
 }
 
+// The outcome of an insert that was enqueued and not waited for.  A failed wait leaves the insert pending (the next caller tries again); an
+// overflow found here belongs to the scan that enqueued the insert, not to the caller: it is handed to exactly one caller -- whoever looks
+// first: the next process_scan (before it launches anything), lio_engine_timings or lio_engine_flush -- with a message that says so.
 int map_settle(lio_map* m) {
     if (!m || !m->insert_pending) return LIO_OK;
+    if (hipEventSynchronize(m->ev_inserted) != hipSuccess) { set_error("map_incremental (deferred): %s", hipGetErrorString(hipGetLastError())); return LIO_E_DEVICE; }
     m->insert_pending = false;
-    if (hipEventSynchronize(m->ev_inserted) != hipSuccess) { set_error("map_incremental: %s", hipGetErrorString(hipGetLastError())); return LIO_E_DEVICE; }
     m->settled_n_add = m->host_dev->n_add;
     if (m->host_dev->err) {
-        set_error("map capacity exceeded (err bits 0x%x: 1 table full, 2 point pool full, 4 more than max_voxels voxels, 8 LRU log overrun)", m->host_dev->err);
+        set_error("map capacity exceeded by the map_incremental of the PREVIOUS scan, whose call had already returned (err bits 0x%x: 1 table full, 2 point pool "
+                  "full, 4 more than max_voxels voxels, 8 LRU log overrun)", m->host_dev->err);
         return LIO_E_CAPACITY;
     }
     return LIO_OK;
+}
+
+// the same without waiting: LIO_OK while the insert is still running
+int map_settle_if_done(lio_map* m) {
+    if (!m || !m->insert_pending) return LIO_OK;
+    if (hipEventQuery(m->ev_inserted) != hipSuccess) { (void)hipGetLastError(); return LIO_OK; }
+    return map_settle(m);
 }
 
 int map_incremental_async(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], float map_leaf, int ekf_inited, double travel) {

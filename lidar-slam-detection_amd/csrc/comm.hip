@@ -45,6 +45,7 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = "symbols missing";  // dlerror() of the last dlopen attempt, captured once (a second dlerror() call returns NULL)
 };
 
 Rccl& rccl() {
@@ -54,8 +55,11 @@ Rccl& rccl() {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.so) break;
+            const char* e = dlerror();
+            if (e) snprintf(r.why, sizeof(r.why), "%s", e);
         }
         if (!r.so) return;
+        snprintf(r.why, sizeof(r.why), "symbols missing");
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
@@ -68,7 +72,7 @@ Rccl& rccl() {
 
 bool need_rccl() {
     if (rccl().ok) return true;
-    set_error("librccl could not be loaded (%s): a communicator of more than one rank needs RCCL", dlerror() ? dlerror() : "symbols missing");
+    set_error("librccl could not be loaded (%s): a communicator of more than one rank needs RCCL", rccl().why);
     return false;
 }
 

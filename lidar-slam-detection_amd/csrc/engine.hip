@@ -706,16 +706,25 @@ int lio_engine_set_static_map(lio_engine* e, int on) {
 int lio_engine_timings(lio_engine* e, lio_timings* out) {
     if (!e || !out) return LIO_E_INVALID;
     if (e->n_added_pending) {  // the last scan's map_incremental was not waited for (process_core), and is not waited for here either:
-        // its count if it has finished, else the count of the last insert that has
-        if (!e->map->insert_pending || hipEventQuery(e->map->ev_inserted) == hipSuccess) {
+        // its count if it has finished, else -1 ("still running": lio_engine_flush waits)
+        const int rc = map_settle_if_done(e->map);
+        if (rc != LIO_OK) { e->n_added_pending = false; return rc; }
+        if (!e->map->insert_pending) {
             e->n_added_pending = false;
-            const int rc = map_settle(e->map);
-            if (rc != LIO_OK) return rc;
+            e->tm.n_added = (int)e->map->settled_n_add;
+        } else {
+            e->tm.n_added = -1;
         }
-        e->tm.n_added = (int)e->map->settled_n_add;
     }
     *out = e->tm;
     return LIO_OK;
+}
+int lio_engine_flush(lio_engine* e) {
+    if (!e) return LIO_E_INVALID;
+    hipSetDevice(e->map->device);
+    const int rc = map_settle(e->map);
+    if (rc == LIO_OK && e->n_added_pending) { e->n_added_pending = false; e->tm.n_added = (int)e->map->settled_n_add; }
+    return rc;
 }
 
 static int process_core(lio_engine* e, double lidar_beg_time);
@@ -733,6 +742,11 @@ static int process_common(lio_engine* e, double lidar_beg_time) {
 static int process_core(lio_engine* e, double lidar_beg_time) {
     lio_scan* s = e->scan;
     const auto w0 = std::chrono::steady_clock::now();
+    {   // the previous scan's map_incremental, if it has finished by now (it nearly always has): its failure is reported HERE, before the
+        // registration of this scan launches anything; if it is still running the update looks again (run_update) before it reads the map
+        const int rc_prev = map_settle_if_done(e->map);
+        if (rc_prev != LIO_OK) return rc_prev;
+    }
     if (s->n_raw == 0) return 2;  // "FastLio undistort points is empty"
     e->flg_EKF_inited = (lidar_beg_time - e->first_lidar_time) < e->init_time ? false : true;
     hipEvent_t t0, t1;
@@ -838,7 +852,9 @@ int lio_engines_process_batch(lio_engine** engines, int n_engines, lio_scan_job*
             if (j >= n_jobs) break;
             lio_scan_job& job = jobs[j];
             int rc = LIO_E_INVALID;
-            if (job.state_in && job.cov_in) {
+            if (job.flags & ~LIO_JOB_FLAGS_KNOWN) {
+                set_error("lio_scan_job.flags = 0x%x: unknown bits (a job array that was not zero-initialised?)", job.flags);
+            } else if (job.state_in && job.cov_in) {
                 state_from_array(job.state_in, e->kf.x);
                 memcpy(e->kf.P, job.cov_in, sizeof(double) * 529);
                 rc = (job.flags & LIO_JOB_KEEP_CACHE) ? LIO_OK : scan_forget_cache(e->scan);  // an independent scan: no neighbours of the engine's previous job

@@ -11,7 +11,18 @@
 
 namespace lio {
 
+// a double moved across lanes by one DPP control word (two 32-bit halves): quad_perm 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1] give the quad sums
+// (v0 + v1) + (v2 + v3) in every lane of a quad without LDS -- the first stage of the fixed-order workgroup reductions (p2plane.hip, ndt.hip)
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 void set_error(const char* fmt, ...);
+void set_warning(const char* fmt, ...);  // notes that are not failures (lio_last_warning): never written by a successful call into lio_last_error
 
 #define LIO_HIP_TRY(expr)                                                                         \
     do {                                                                                          \
@@ -297,4 +308,5 @@ int map_clear(lio_map* m);
 // the map from another stream calls first (the next scan's neighbour search: by then its downsample has run beside the insert)
 int map_incremental_async(lio_map* m, lio_scan* s, const double pose_wi[7], const double ext_il[7], float map_leaf, int ekf_inited, double travel);
 int map_settle(lio_map* m);
+int map_settle_if_done(lio_map* m);
 }

@@ -41,8 +41,15 @@ struct __attribute__((aligned(64))) NdtVoxel {
 };
 
 constexpr int kNdtThreads = 64;
-constexpr int kNdtAcc = 43;  // H (36, row-major) + b (6) + err
+// sums of one evaluation: the LOWER triangle of H (21 numbers, packed t = r (r + 1) / 2 + c for c <= r) + b (6) + err.  The reference forms the full 6 x 6
+// in f32 per pair (J^T C^-1 J is not exactly symmetric in f32) and hands it to Eigen::LDLT (lsq_registration_impl.hpp:151,174), which reads the lower
+// triangle only -- as ldlt_solve6 (lsq.h) does: the upper triangle never influences an alignment.  It is not accumulated (43 -> 28 f64 accumulators per
+// lane: 190 -> ~100 VGPRs); H is handed out mirrored.
+constexpr int kNdtAcc = 28;
+constexpr int kNdtOut = 43;  // what the host side sees: H (36, row-major, symmetric) + b (6) + err
+constexpr int kNdtQuads = kNdtThreads / 4;
 constexpr int kNdtMaxOff = 27;
+__device__ __host__ inline int ndt_tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 
 struct NdtOffsets {
     int n;
@@ -284,7 +291,7 @@ struct NdtDev {
     uint32_t seq;
 };
 struct NdtReport {  // mapped pinned host memory
-    double acc[kNdtAcc];
+    double acc[kNdtOut];
     uint32_t n_corr;
     uint32_t seq;
 };
@@ -360,31 +367,65 @@ __device__ __forceinline__ void ndt_cost_body(const Slot* __restrict__ table, ui
             for (int c = 0; c < 3; c++) wc[c] = sum3f(we[0] * ci[c], we[1] * ci[3 + c], we[2] * ci[6 + c]);
             const float err = sum3f(wc[0] * e[0], wc[1] * e[1], wc[2] * e[2]);
             if (DERIV) {
-                const float J[3][6] = {{0.f, -tp[2], tp[1], -1.f, 0.f, 0.f}, {tp[2], 0.f, -tp[0], 0.f, -1.f, 0.f}, {-tp[1], tp[0], 0.f, 0.f, 0.f, -1.f}};
+                // H = J^T (w C^-1) J and b = J^T (w C^-1) e with J = [ -[tp]x | -I ] (ndt_compute_derivatives.cu:63-92), written out.  The reference's generic
+                // f32 products  B_r[c] = (w J0r) ci[c] + ((w J1r) ci[3 + c] + (w J2r) ci[6 + c]),  H[r][c] = B_r[0] J0c + (B_r[1] J1c + B_r[2] J2c)  contain one
+                // exact zero (or two) per sum -- x + (+-0) = x, (w (-t)) c = -((w t) c), a + (-b) = a - b are exact in IEEE arithmetic -- so the forms below
+                // are the SAME f32 numbers (up to the sign of a zero, which no sum sees) at a third of the instructions.
+                const float w0 = w * tp[0], w1 = w * tp[1], w2 = w * tp[2];
+                float Brot[3][3], m[9];
 #pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    float B[3];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) B[c] = sum3f((w * J[0][r]) * ci[c], (w * J[1][r]) * ci[3 + c], (w * J[2][r]) * ci[6 + c]);
-#pragma unroll
-                    for (int c = 0; c < 6; c++) acc[r * 6 + c] += (double)sum3f(B[0] * J[0][c], B[1] * J[1][c], B[2] * J[2][c]);
-                    acc[36 + r] += (double)sum3f(B[0] * e[0], B[1] * e[1], B[2] * e[2]);
+                for (int c = 0; c < 3; c++) {
+                    Brot[0][c] = w2 * ci[3 + c] - w1 * ci[6 + c];
+                    Brot[1][c] = w0 * ci[6 + c] - w2 * ci[c];
+                    Brot[2][c] = w1 * ci[c] - w0 * ci[3 + c];
                 }
-                acc[42] += (double)err;
+#pragma unroll
+                for (int k = 0; k < 9; k++) m[k] = w * ci[k];
+                // rows 0..2 (rotation): columns 0..r of  B_r x (against the columns of -[tp]x): (B[1] tp2 - B[2] tp1, B[2] tp0 - B[0] tp2, B[0] tp1 - B[1] tp0)
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const float h0 = Brot[r][1] * tp[2] - Brot[r][2] * tp[1];
+                    const float h1 = Brot[r][2] * tp[0] - Brot[r][0] * tp[2];
+                    const float h2 = Brot[r][0] * tp[1] - Brot[r][1] * tp[0];
+                    acc[ndt_tri(r, 0)] += (double)h0;
+                    if (r >= 1) acc[ndt_tri(r, 1)] += (double)h1;
+                    if (r >= 2) acc[ndt_tri(r, 2)] += (double)h2;
+                    acc[21 + r] += (double)sum3f(Brot[r][0] * e[0], Brot[r][1] * e[1], Brot[r][2] * e[2]);
+                }
+                // rows 3..5 (translation): B_r = -(w C^-1) row (r - 3): the rotation columns as above, the translation columns -B_r[c] = m
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const float B0 = -m[r * 3], B1 = -m[r * 3 + 1], B2 = -m[r * 3 + 2];
+                    acc[ndt_tri(3 + r, 0)] += (double)(B1 * tp[2] - B2 * tp[1]);
+                    acc[ndt_tri(3 + r, 1)] += (double)(B2 * tp[0] - B0 * tp[2]);
+                    acc[ndt_tri(3 + r, 2)] += (double)(B0 * tp[1] - B1 * tp[0]);
+#pragma unroll
+                    for (int c = 0; c <= r; c++) acc[ndt_tri(3 + r, 3 + c)] += (double)m[r * 3 + c];
+                    acc[24 + r] += (double)sum3f(B0 * e[0], B1 * e[1], B2 * e[2]);
+                }
+                acc[27] += (double)err;
             } else {
                 acc[0] += (double)err;
             }
         }
     }
-    __shared__ double red[NA][kNdtThreads];
+    // Workgroup (= one wave) reduction in a fixed order, as linearize_kernel's: quad sums by two DPP butterflies, one lane per quad parks them in LDS
+    // transposed [component][quad] (28 x 16 doubles = 3.5 KB; the [43][64] form was 22 KB per wave: LDS-limited occupancy), lane c adds the sixteen quad
+    // sums of component c in quad order.
+    __shared__ double red[NA][kNdtQuads];
 #pragma unroll
-    for (int a = 0; a < NA; a++) red[a][threadIdx.x] = acc[a];
+    for (int a = 0; a < NA; a++) {
+        double v = acc[a];
+        v += dpp_f64<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+        v += dpp_f64<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+        if ((threadIdx.x & 3) == 0) red[a][threadIdx.x >> 2] = v;
+    }
     __syncthreads();
     if (threadIdx.x < NA) {
         const double2* row = reinterpret_cast<const double2*>(&red[threadIdx.x][0]);
         double s = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < kNdtThreads / 2; k++) {
+#pragma unroll
+        for (int k = 0; k < kNdtQuads / 2; k++) {
             const double2 v = row[k];
             s += v.x;
             s += v.y;
@@ -484,9 +525,9 @@ __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict_
     s.evals++;
     bool make_trial = false, end_iteration = false;
     if (s.phase == 0) {  // the linearisation at x0 (LsqRegistration::computeTransformation, loop head)
-        for (int k = 0; k < 36; k++) s.H[k] = acc[k];
-        for (int k = 0; k < 6; k++) s.b[k] = acc[36 + k];
-        s.y0 = acc[42];
+        for (int k = 0; k < 36; k++) s.H[k] = acc[ndt_tri(k / 6, k % 6)];
+        for (int k = 0; k < 6; k++) s.b[k] = acc[21 + k];
+        s.y0 = acc[27];
         s.it_done = s.it;
         if (s.lambda < 0.0) {
             double mx = 0;
@@ -495,7 +536,8 @@ __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict_
         }
         s.nu = 2.0;
         s.trial = 0;
-        make_trial = true;
+        if (p.lm_max_iterations > 0) make_trial = true;
+        else { s.phase = 2; s.conv = 0; }  // step_lm's loop does not run: "lm not converged!!", the iteration's x0 stands (lsq_align)
     } else {  // the cost of the trial step (step_lm)
         const double yi = acc[0];
         double den = 0;
@@ -536,16 +578,20 @@ __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict_
     }
 }
 
+// nb_hint: the number of workgroup partials when the host knows the scan's size (it does after a synchronous downsample): saves the dependent load of
+// the size before the fold's loads can be issued; 0 = read it from the scan's device record
 __global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial, uint32_t pstride, int na, NdtDev* nd,
-                                                          NdtReport* __restrict__ out) {
+                                                          NdtReport* __restrict__ out, uint32_t nb_hint) {
     __shared__ double acc[kNdtAcc];
     const int tid = threadIdx.x;
-    const uint32_t nb = (sd->n_ds + kNdtThreads - 1) / kNdtThreads;
+    const uint32_t nb = nb_hint ? nb_hint : (sd->n_ds + kNdtThreads - 1) / kNdtThreads;
     ndt_fold(partial, pstride, nb, na, acc);
-    // the record leaves through 43 lanes at once (a handful of PCIe writes), then one system-scope fence and the sequence word
+    // the record leaves through 43 lanes at once (a handful of PCIe writes; H mirrored from its lower triangle), then one system-scope fence and the
+    // sequence word
     if (tid < 64) {
         if (na == 1) { if (tid == 0) out->acc[42] = acc[0]; }
-        else if (tid < kNdtAcc) out->acc[tid] = acc[tid];
+        else if (tid < 36) out->acc[tid] = acc[ndt_tri(tid / 6, tid % 6)];
+        else if (tid < kNdtOut) out->acc[tid] = acc[21 + (tid - 36)];
         if (tid == 63) out->n_corr = nd->n_corr;
         __threadfence_system();
     }
@@ -731,7 +777,8 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
 #undef NDT_DISPATCH
 #undef NDT_LAUNCH
     if (n->timing) hipEventRecord(n->ev[1], st);
-    hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, n->pstride, deriv ? kNdtAcc : 1, n->dev, n->report_dev);
+    hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, n->pstride, deriv ? kNdtAcc : 1, n->dev, n->report_dev,
+                       s->have_ds > 0 ? blocks : 0u);
     LIO_HIP_TRY(hipGetLastError());
     n->seq_expected++;
     const int rc = ndt_wait(n, st);
@@ -981,16 +1028,38 @@ int lio_ndt_align_batch(lio_ndt* n, lio_align_job* jobs, int n_jobs, const lio_n
     hipSetDevice(n->device);
     lio_ndt_params p;
     if (prm) p = *prm; else lio_ndt_default_params(&p);
-    constexpr int kSlots = 64;
+    if (p.max_iterations <= 0) {  // LsqRegistration::computeTransformation's loop does not run (lsq_align): every alignment returns its guess
+        for (int k = 0; k < n_jobs; k++) {
+            lio_align_job& j = jobs[k];
+            j.iterations = j.converged = j.evaluations = 0;
+            if (!j.source || !j.guess) { j.rc = LIO_E_INVALID; continue; }
+            memcpy(j.out, j.guess, sizeof(j.out));
+            j.rc = LIO_OK;
+        }
+        return LIO_OK;
+    }
     const size_t corr_per = (size_t)n->offs.n * n->max_src, part_per = (size_t)((n->max_src + kNdtThreads - 1) / kNdtThreads) * kNdtAcc;
     if (!n->d_slots) {
-        bool ok = hipMalloc(reinterpret_cast<void**>(&n->d_slots), sizeof(NdtLmSlot) * kSlots) == hipSuccess &&
-                  hipHostMalloc(reinterpret_cast<void**>(&n->h_slots), sizeof(NdtLmSlot) * kSlots, hipHostMallocDefault) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&n->b_corr), corr_per * 4 * kSlots) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&n->b_partial), part_per * 8 * kSlots) == hipSuccess;
-        if (!ok) { set_error("lio_ndt_align_batch: allocation failed: %s", hipGetErrorString(hipGetLastError())); return LIO_E_DEVICE; }
-        n->b_slots = kSlots;
+        // the slots' scratch is offsets x max_source_points x 4 B of correspondences each (7.3 MB at DIRECT7 / 262 144 points, 28 MB at DIRECT27): 64 slots
+        // when that fits, fewer when the device is short of memory (the jobs then go through in more, smaller launches -- same results)
+        int slots = 64;
+        for (; slots >= 1; slots /= 2) {
+            const bool ok = hipMalloc(reinterpret_cast<void**>(&n->d_slots), sizeof(NdtLmSlot) * slots) == hipSuccess &&
+                            hipHostMalloc(reinterpret_cast<void**>(&n->h_slots), sizeof(NdtLmSlot) * slots, hipHostMallocDefault) == hipSuccess &&
+                            hipMalloc(reinterpret_cast<void**>(&n->b_corr), corr_per * 4 * slots) == hipSuccess &&
+                            hipMalloc(reinterpret_cast<void**>(&n->b_partial), part_per * 8 * slots) == hipSuccess;
+            if (ok) break;
+            (void)hipGetLastError();
+            if (n->d_slots) hipFree(n->d_slots);
+            if (n->h_slots) hipHostFree(n->h_slots);
+            if (n->b_corr) hipFree(n->b_corr);
+            if (n->b_partial) hipFree(n->b_partial);
+            n->d_slots = nullptr; n->h_slots = nullptr; n->b_corr = nullptr; n->b_partial = nullptr;
+        }
+        if (slots < 1) { set_error("lio_ndt_align_batch: no room for a single slot's scratch (%zu bytes)", corr_per * 4 + part_per * 8); return LIO_E_DEVICE; }
+        n->b_slots = slots;
     }
+    const int kSlots = n->b_slots;
     hipStream_t st = n->map->stream;
     LIO_HIP_TRY(hipStreamSynchronize(st));
     NdtLmParams P{p.max_iterations, p.lm_max_iterations, p.rotation_epsilon_deg, p.transformation_epsilon, p.lm_init_lambda_factor};
@@ -1026,7 +1095,11 @@ int lio_ndt_align_batch(lio_ndt* n, lio_align_job* jobs, int n_jobs, const lio_n
             j.rc = LIO_OK;
             if (bound > max_n) max_n = bound;
         }
-        if (max_n == 0) continue;
+        if (max_n == 0) {  // no job of this chunk could be submitted: their codes still count
+            for (int k = 0; k < B; k++)
+                if (jobs[base + k].rc < 0 && first_err == LIO_OK) first_err = jobs[base + k].rc;
+            continue;
+        }
         LIO_HIP_TRY(hipMemcpyAsync(n->d_slots, n->h_slots, sizeof(NdtLmSlot) * B, hipMemcpyHostToDevice, st));
         const dim3 grid((max_n + kNdtThreads - 1) / kNdtThreads, (uint32_t)B);
         const int max_rounds = p.max_iterations * (p.lm_max_iterations + 1) + 2;

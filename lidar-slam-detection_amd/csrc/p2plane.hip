@@ -191,14 +191,6 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-template <int CTRL>
-__device__ inline double dpp_f64(double v) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xF, 0xF, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xF, 0xF, false);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_knn, const ScanDev* __restrict__ sd,
                                                const float4* __restrict__ ds_body, float4* __restrict__ ds_world,
                                                const float4* __restrict__ nn_pts, uint32_t nn_stride,

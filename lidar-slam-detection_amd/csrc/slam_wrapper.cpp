@@ -390,7 +390,12 @@ bool loc_localize(Slam* s, uint32_t n, uint64_t stamp, Mat4& pose_out) {
         }
         loc_update_local_map(L, T);  // mPoseQueue.enqueue(mLastOdom)
     }
-    if (n == 0) return false;  // "cloud is empty!!"
+    if (n == 0) {  // "cloud is empty!!": the nodelet returns LocType::OTHER, which Localization::feedPointData counts like any failed frame
+                   // (localization.cpp:245-254)
+        L.failures++;
+        if (L.failures >= 5) { L.initialized = false; L.have_init_pose = false; }
+        return false;
+    }
     // imu process: mean of the samples up to the frame's stamp
     float acc[3] = {0, 0, 0}, gyr[3] = {0, 0, 0};
     size_t used = 0;

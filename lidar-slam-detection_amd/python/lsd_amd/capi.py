@@ -9,6 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# the application's job (the library does not touch the environment): HIP's hardware-queue count, read by the runtime at its first call.  With the
+# default of 4 the rounds in flight of lio_batch share queues and mostly serialise; lio_batch_create notes a lower value in lio_last_warning
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LIB_PATH = os.environ.get("LIO_HIP_LIB") or os.path.join(_HERE, "liblio_hip.so")  # LIO_HIP_LIB: a variant build (tools/experiments)
 
 LIO_OK, LIO_E_INVALID, LIO_E_CAPACITY, LIO_E_DEVICE, LIO_E_STATE = 0, -1, -2, -3, -4
@@ -16,6 +19,7 @@ MAIN_FIRST_SCAN, MAIN_SEEDED, MAIN_SKIPPED, MAIN_UPDATED, MAIN_IMU_INIT, MAIN_ID
 
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
+    "lio_last_warning",
     "lio_last_error", "lio_device_count", "lio_map_bytes",
     "lio_map_create", "lio_map_destroy", "lio_map_set_lru", "lio_map_lru_stats", "lio_map_pool_stats", "lio_map_set_stencil", "lio_map_insert", "lio_map_insert_device", "lio_map_stats",
     "lio_map_dump", "lio_map_knn", "lio_map_knn_candidates", "lio_map_knn_touched",
@@ -24,7 +28,7 @@ SYMBOLS = [
     "lio_p2plane_linearize", "lio_scan_set_degeneracy_mode", "lio_p2plane_degeneracy", "lio_engine_set_reduce_hook", "lio_p2plane_rows", "lio_map_incremental", "lio_map_seed",
     "lio_engine_create", "lio_engine_create_shared", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
     "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
-    "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings",
+    "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings", "lio_engine_flush",
     "lio_engine_enable_timing", "lio_comm_unique_id", "lio_comm_init", "lio_comm_destroy", "lio_comm_rank", "lio_comm_world", "lio_allgather_normal_eq", "lio_comm_stats", "lio_engine_set_joint", "lio_engine_joint_register", "lio_engine_joint_register_device", "lio_allgather_records", "lio_engines_process_batch", "lio_batch_create", "lio_batch_create_joint", "lio_batch_set_gather_hook", "lio_batch_destroy", "lio_batch_process", "lio_batch_engine", "lio_batch_enable_kernel_timing", "lio_batch_kernel_times", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
     "lio_localmap_create", "lio_localmap_destroy", "lio_localmap_add_keyframe", "lio_localmap_num_keyframes", "lio_localmap_update",
@@ -122,6 +126,7 @@ def lib():
         f.argtypes = list(args)
 
     sig("lio_last_error", C.c_char_p)
+    sig("lio_last_warning", C.c_char_p)
     sig("lio_device_count", cint)
     sig("lio_map_bytes", u64, vp)
     sig("lio_map_create", vp, cint, flt, u64, u64, cint)
@@ -176,6 +181,7 @@ def lib():
     sig("lio_engine_process_scan", cint, vp, f32p, u32, dbl)
     sig("lio_engine_process_scan_device", cint, vp, vp, u32, dbl)
     sig("lio_engine_timings", cint, vp, C.POINTER(Timings))
+    sig("lio_engine_flush", cint, vp)
     sig("lio_engine_enable_timing", cint, vp, cint)
     sig("lio_engines_process_batch", cint, C.POINTER(vp), cint, C.POINTER(ScanJob), cint)
     sig("lio_comm_unique_id", cint, C.POINTER(C.c_uint8))

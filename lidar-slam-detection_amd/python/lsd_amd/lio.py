@@ -431,6 +431,10 @@ class Engine:
     def set_static_map(self, on=True):
         check(lib().lio_engine_set_static_map(self.h, int(on)))
 
+    def flush(self):
+        """lio_engine_flush: wait for the map_incremental the last scan enqueued; raises if the map overflowed"""
+        check(lib().lio_engine_flush(self.h), "flush")
+
     def timings(self):
         t = capi.Timings()
         check(lib().lio_engine_timings(self.h, C.byref(t)))

@@ -190,3 +190,40 @@ def imu_stream(traj, t0, t1, rate=100.0, seed=0, gyr_sigma=0.0, acc_sigma=0.0, g
     acc_w = (traj.pos(t + h) - 2 * traj.pos(t) + traj.pos(t - h)) / (h * h)
     acc = np.einsum("nji,nj->ni", R, acc_w + np.array([0.0, 0.0, g]))
     return t, gyr + rng.normal(0, gyr_sigma, gyr.shape), acc + rng.normal(0, acc_sigma, acc.shape)
+
+
+class _Still(synth.Trajectory):
+    """a sensor at rest at (pos, R): the `trajectory` of a static scan"""
+
+    def __init__(self, pos, R):
+        self._p, self._R = np.asarray(pos, np.float64), np.asarray(R, np.float64)
+
+    def pos(self, t):
+        return np.broadcast_to(self._p, np.shape(t) + (3,)).copy()
+
+    def R(self, t):
+        return np.broadcast_to(self._R, np.shape(t) + (3, 3)).copy()
+
+
+class StaticScanner:
+    """synth.make_scan on the device: scans of a sensor at rest (the metric config's scan pool -- 128 scans of 64 x 1875 rays take ~85 s with
+    numpy on one core, a second here).  One Sweeper (ray table, scene boxes on the device) serves every pose."""
+
+    def __init__(self, scene, device, n_beams=64, n_az=1875, fov_deg=(-25.0, 15.0), max_range=100.0, sigma=0.02, blind=0.1):
+        self.sw = Sweeper(scene, _Still(np.zeros(3), np.eye(3)), device, n_beams=n_beams, n_az=n_az, fov_deg=fov_deg, max_range=max_range, sigma=sigma)
+        self.blind = float(blind)
+
+    def scan(self, pos, quat, seed):
+        """body-frame XYZI f32 (n, 4) on the DEVICE (a torch tensor): first hits within max_range, Gaussian range noise, returns closer than
+        `blind` dropped -- what synth.make_scan returns, with torch's random stream (seeded by `seed`)"""
+        sw, torch = self.sw, self.sw.torch
+        sw.traj = _Still(pos, synth.quat_to_R(np.asarray(quat, np.float64)))
+        r = sw.ranges(0.0)
+        sw.gen.manual_seed(int(seed))
+        ok = torch.isfinite(r)
+        r = r + sw.sigma * torch.randn(r.shape, dtype=torch.float64, device=sw.dev, generator=sw.gen)
+        ok &= r > self.blind
+        sel = torch.nonzero(ok).squeeze(1)
+        pts = sw.d_l[sel] * r[sel, None]
+        inten = 255.0 * torch.rand(len(sel), dtype=torch.float64, device=sw.dev, generator=sw.gen)
+        return torch.cat([pts, inten[:, None]], 1).to(torch.float32).contiguous()

@@ -273,3 +273,25 @@ def test_bench_multi_gpu_launch_dry_run(config, world):
     else:
         seeds = [tuple(rk["scan_seeds"]) for rk in j["ranks"]]
         assert len(set(seeds)) == world  # weak scaling: every rank its own scans
+
+
+@pytest.mark.parametrize("config", ["metric", "merge"])
+def test_bench_spawns_its_own_ranks(config):
+    """`python bench.py --gpus 2` WITHOUT a launcher -- the shape of the driver's BENCH command -- must not time one GPU and say so: it re-executes
+    itself under torch.distributed.run with two ranks, and a launcher that started another number of ranks than --gpus is
+    refused"""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--dry-run"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    j = json.loads(line[0])
+    assert j["dry_run"] and j["n_gpus"] == 2 and len(j["ranks"]) == 2 and j["rccl_unique_id_exchanged"] is True
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)

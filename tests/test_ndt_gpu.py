@@ -64,6 +64,8 @@ def test_ndt_matches_oracle(method):
     lg = g.linearize(s, T_guess)
     assert lo["n_corr"] == lg["n_corr"] and lo["n_corr"] > 5000
     assert np.allclose(lg["H"], lo["H"], rtol=1e-3, atol=1e-3 * np.abs(lo["H"]).max())
+    # only the lower triangle of H is accumulated on the device (it is all Eigen::LDLT / ldlt_solve6 read): H comes back mirrored, exactly symmetric
+    assert np.array_equal(lg["H"], lg["H"].T)
     assert np.allclose(lg["b"], lo["b"], rtol=1e-3, atol=1e-3 * np.abs(lo["b"]).max())
     assert abs(lg["err"] - lo["err"]) < 1e-3 * lo["err"]
     # error-only evaluation on the cached pairs at another transform (LM trial)
