@@ -247,13 +247,17 @@ def main():
         return dict(dptr=s["d"].data_ptr(), n=len(s["raw"]), t=1.0 + 0.1 * i, state=s["guess"], cov=P0)
 
     jobs = [job_of(i) for i in range(args.steps)]
-    cal = lio.PreparedJobs([job_of(i) for i in range(8 * args.steps)])
+    # calibration pass: long enough to fill every round in flight several times (a list shorter than slots x groups runs un-pipelined and
+    # over-estimates the time per scan: round 4's first line had a 1.4 s region for --min-seconds 5)
+    n_cal = max(8 * args.steps, 6 * args.slots * args.groups if batch is not None else 8 * n_streams)
+    cal = lio.PreparedJobs([job_of(i) for i in range(n_cal)])
+    lio.run_prepared(cal, engines=engines, batch=batch)  # (once untimed: graphs instantiated, pools grown)
     torch.cuda.synchronize()
     c0 = time.perf_counter()
     lio.run_prepared(cal, engines=engines, batch=batch)
     torch.cuda.synchronize()
-    t_cal = max(time.perf_counter() - c0, 1e-6) / 8
-    repeats = max(1, int(np.ceil(1.05 * args.min_seconds / t_cal)))
+    t_cal = max(time.perf_counter() - c0, 1e-6) * args.steps / n_cal  # seconds per --steps scans
+    repeats = max(1, int(np.ceil(1.1 * args.min_seconds / t_cal)))
     if dist is not None:  # the same R on every rank
         tr = torch.tensor([float(repeats)], device=dev, dtype=torch.float64)
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
@@ -349,13 +353,17 @@ def main():
                 traffic = None
         waves = leg["queries_per_launch"] / 4.0  # sixteen lanes per query: four queries per wave
         issue_us = waves * valu_per_wave / (N_SIMD * CLOCK_GHZ * 1e3 / 4.0)  # a SIMD issues one wave64 VALU instruction per four cycles
+        measured = valu_src.startswith("PMC")
         return dict(bound="valu", kernel="knn_batch_kernel<2, false> (16 lanes per query, %d scans per launch)" % args.slots,
                     achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                     touched_bytes_per_launch=int(leg["touched_bytes"]),
                     frac_touched=round(leg["touched_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
                     frac_hbm_traffic=(round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic and us > 0 else None),
                     valu={"wave_instructions_per_wave": round(valu_per_wave, 1), "source": valu_src, "waves_per_launch": round(waves, 1),
-                          "issue_bound_us": round(issue_us, 2), "frac_of_valu_issue_peak": round(issue_us / us, 4) if us > 0 else None,
+                          "issue_bound_us": round(issue_us, 2),
+                          # (the static count is the metric map's: ~300 candidates per query; a sparser map sweeps fewer voxels per query, so without a
+                          # PMC count of THIS workload the figure is an upper bound and no fraction is formed from it)
+                          "frac_of_valu_issue_peak": (round(issue_us / us, 4) if us > 0 and (measured or abs(leg["candidates_per_query"] - 300.0) < 60.0) else None),
                           "peak": "%d SIMDs x %.1f GHz / 4 cycles per wave64 instruction" % (N_SIMD, CLOCK_GHZ)},
                     algorithmic_bytes_per_launch=int(leg["bytes"]), avg_launch_us=round(us, 2), launches=leg["launches"],
                     candidates_per_query=round(leg["candidates_per_query"], 1),
@@ -980,6 +988,7 @@ def bench_localize(args, torch, local_rank):
     # the resident 5e7-point map is matched from poses all over the scene; the 200 k-point local map (24 key frames along a line through the middle)
     # from poses inside it -- the reference's localisation never leaves its local map
     pools = {"resident": make_pool(args.scan_pool, args.spread, args.seed + 7), "local_200k": make_pool(8, 4.0, args.seed + 7)}
+    pools["resident_one_spot"] = pools["local_200k"]  # round 3's workload against the resident map, beside the spread pool
     pool, guesses = pools["local_200k"]
     n_raw = int(np.mean([len(s["raw"]) for s in pool]))
     leaf = 0.2
@@ -1012,7 +1021,7 @@ def bench_localize(args, torch, local_rank):
     cases = {}
     ref_inputs = {}
     scans_b = []  # the scan buffer sets of the batched leg (made on first use)
-    for name, cloud in (("resident", dense), ("local_200k", near)):
+    for name, cloud in (("resident", dense), ("resident_one_spot", dense), ("local_200k", near)):
         pool, guesses = pools[name]
         npts = int(cloud.shape[0])
         n = lio.Ndt(resolution=1.0, search_method=7, max_points=npts, max_voxels=max(npts // 4, 200_000), max_source_points=200000, device=local_rank)
@@ -1236,7 +1245,9 @@ def bench_localize(args, torch, local_rank):
            "vs_baseline": None, "dtype": "f32 per-point arithmetic / f64 reductions and LM", "data": "synthetic",
            "config": {"workload": "BASELINE config 4: %d scans of 64x%d rays (~%d pts), leaf-0.2 VoxelGrid + NDT-P2D (res 1.0, DIRECT7) LM alignment from a guess within "
                                   "0.5 m / 3 deg vs a %d-pt map resident in HBM (map generated on the GPU in %.1f s)" % (args.steps, args.n_az, n_raw, args.dense_points, t_gen),
-                      "n_raw": n_raw, "leaf": leaf, "resident_map": {k: v for k, v in head.items() if k != "roofline"},
+                      "n_raw": n_raw, "leaf": leaf, "scan_pool": len(pools["resident"][0]), "spread_m": args.spread,
+                      "resident_map": {k: v for k, v in head.items() if k != "roofline"},
+                      "resident_map_one_spot_pool": cases["resident_one_spot"],
                       "local_200k_map": cases["local_200k"], "local_map_key_frames_used": nk_used, "merge_candidates_batched": merge},
            "roofline": head["roofline"], "cpu_baseline": cpu, "pose_error_vs_truth_m": head["pos_err_m_max"]}
     print(json.dumps(out))
@@ -1428,7 +1439,7 @@ def bench_merge(args, torch, dist, world, rank, local_rank, dev):
                         "candidates_per_query": round(cand_pts / max(n_query, 1), 1),
                         "valu": {"wave_instructions_per_wave": KNN_VALU_PER_WAVE_STATIC, "source": "static ISA count at the metric map's trip counts (an upper bound here: "
                                  "the sub-maps hold fewer candidates per query)", "waves_per_launch": round(waves, 1), "issue_bound_us": round(issue_us, 2),
-                                 "frac_of_valu_issue_peak": round(issue_us / us, 4) if us > 0 else None},
+                                 "frac_of_valu_issue_peak": None},
                         "share_of_device_time": round(kt["knn_us"] / max(kt["downsample_us"] + kt["knn_us"] + kt["linearize_us"] + kt["step_us"], 1e-9), 3),
                         "other_kernels_us": {"downsample_chain_per_round": round(kt["downsample_us"] / max(int(kt["downsample_launches"]), 1), 2),
                                              "linearize_per_launch": round(kt["linearize_us"] / max(int(kt["linearize_launches"]), 1), 2),

@@ -540,7 +540,10 @@ struct lio_devloop {
     EskfDev* h_back = nullptr;  // pinned download target
     lio_batch_result* h_res = nullptr;
     lio_batch_result* h_res_dev = nullptr;
-    hipGraphExec_t exec = nullptr;
+    // the loop as a graph, one per size class of the downsampled cloud (bucket k: grids for up to 2048 << k points): a graph captured for max_ds
+    // (100 000) put 1 563 linearisation workgroups on a 7 000-point scan, 1 450 of them surplus
+    static constexpr int kBuckets = 8;
+    hipGraphExec_t exec[kBuckets] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t seq = 0;
     int stencil_n = 0;  // the graph holds the stencil by value and the table's address: re-captured when either changes
     const void* table = nullptr;  // (an LRU map swaps its table for a rebuilt twin now and then)
@@ -548,7 +551,8 @@ struct lio_devloop {
 
 void devloop_destroy(lio_devloop* d) {
     if (!d) return;
-    if (d->exec) hipGraphExecDestroy(d->exec);
+    for (int k = 0; k < lio_devloop::kBuckets; k++)
+        if (d->exec[k]) hipGraphExecDestroy(d->exec[k]);
     if (d->d_block) hipFree(d->d_block);
     if (d->h_block) hipHostFree(d->h_block);
     if (d->h_back) hipHostFree(d->h_back);
@@ -598,20 +602,28 @@ int devloop_update(lio_devloop* d, lio_map* m, lio_scan* sc, const double* x26, 
     };
     static const bool use_graph = []() { const char* k = getenv("LIO_BATCH_GRAPH"); return !(k && k[0] == '0'); }();
     if (use_graph && max_iter == 4) {
-        if (d->exec && (d->stencil_n != m->stencil.n || d->table != m->table)) { hipGraphExecDestroy(d->exec); d->exec = nullptr; }
-        if (!d->exec) {
-            hipGraph_t graph = nullptr;
-            LIO_HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int rc = enqueue(sc->max_ds);
-            const hipError_t e2 = hipStreamEndCapture(st, &graph);
-            if (rc != LIO_OK) { if (graph) hipGraphDestroy(graph); return rc; }
-            LIO_HIP_TRY(e2);
-            LIO_HIP_TRY(hipGraphInstantiate(&d->exec, graph, nullptr, nullptr, 0));
-            hipGraphDestroy(graph);
+        if (d->stencil_n != m->stencil.n || d->table != m->table) {
+            for (int k = 0; k < lio_devloop::kBuckets; k++)
+                if (d->exec[k]) { hipGraphExecDestroy(d->exec[k]); d->exec[k] = nullptr; }
             d->stencil_n = m->stencil.n;
             d->table = m->table;
         }
-        LIO_HIP_TRY(hipGraphLaunch(d->exec, st));
+        int bk = 0;
+        while (bk < lio_devloop::kBuckets - 1 && (2048u << bk) < bound) bk++;
+        uint32_t cap_b = 2048u << bk;
+        if (cap_b > sc->max_ds || bk == lio_devloop::kBuckets - 1) cap_b = sc->max_ds;
+        if (cap_b < bound) cap_b = bound;  // (never: bound <= max_ds)
+        if (!d->exec[bk]) {
+            hipGraph_t graph = nullptr;
+            LIO_HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue(cap_b);
+            const hipError_t e2 = hipStreamEndCapture(st, &graph);
+            if (rc != LIO_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+            LIO_HIP_TRY(e2);
+            LIO_HIP_TRY(hipGraphInstantiate(&d->exec[bk], graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+        }
+        LIO_HIP_TRY(hipGraphLaunch(d->exec[bk], st));
     } else {
         const int rc = enqueue(bound);
         if (rc != LIO_OK) return rc;

@@ -34,15 +34,27 @@ __device__ inline uint32_t f2ord(float f) {
 }
 __device__ inline float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); }
 
-__device__ __forceinline__ void vg_bbox_body(const float4* __restrict__ in, uint32_t n, ScanDev* sd) {
+// bounding box of the finite points, stage 1: one workgroup per sort tile (eight independent 16-byte loads per thread in flight), its box and
+// count stored as ONE 32-byte record {min x, y, z, max x, y, z (order-preserving uint codes), finite points, -}.  vg_keys folds the <= 128 records
+// itself.  (Until round 4: 48 workgroups striding over the cloud with seven same-line atomics each -- 9 us for 120 000 points, all of it the
+// dependent loads of the stride loop and the atomics' serialisation in one L2 channel.)
+__device__ __forceinline__ void vg_bbox_body(const float4* __restrict__ in, uint32_t n, uint32_t* __restrict__ parts) {
     float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
     uint32_t cnt = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 p = in[i];
-        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-            mn0 = fminf(mn0, p.x); mx0 = fmaxf(mx0, p.x);
-            mn1 = fminf(mn1, p.y); mx1 = fmaxf(mx1, p.y);
-            mn2 = fminf(mn2, p.z); mx2 = fmaxf(mx2, p.z);
+    const uint32_t base = blockIdx.x * kTile;
+    float4 p[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        const uint32_t i = base + r * kThreads + threadIdx.x;
+        if (i < n) p[r] = in[i];
+    }
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        const uint32_t i = base + r * kThreads + threadIdx.x;
+        if (i < n && isfinite(p[r].x) && isfinite(p[r].y) && isfinite(p[r].z)) {
+            mn0 = fminf(mn0, p[r].x); mx0 = fmaxf(mx0, p[r].x);
+            mn1 = fminf(mn1, p[r].y); mx1 = fmaxf(mx1, p[r].y);
+            mn2 = fminf(mn2, p[r].z); mx2 = fmaxf(mx2, p[r].z);
             cnt++;
         }
     }
@@ -53,7 +65,6 @@ __device__ __forceinline__ void vg_bbox_body(const float4* __restrict__ in, uint
         mn2 = fminf(mn2, __shfl_xor(mn2, off)); mx2 = fmaxf(mx2, __shfl_xor(mx2, off));
         cnt += __shfl_xor(cnt, off);
     }
-    // one set of atomics per workgroup: the seven words share one L2 line, every atomic on it serialises
     __shared__ float red[kWaves][6];
     __shared__ uint32_t redc[kWaves];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -69,12 +80,10 @@ __device__ __forceinline__ void vg_bbox_body(const float4* __restrict__ in, uint
             mx0 = fmaxf(mx0, red[w][3]); mx1 = fmaxf(mx1, red[w][4]); mx2 = fmaxf(mx2, red[w][5]);
             cnt += redc[w];
         }
-        if (cnt > 0) {
-            atomicMin(&sd->bbox_min[0], f2ord(mn0)); atomicMax(&sd->bbox_max[0], f2ord(mx0));
-            atomicMin(&sd->bbox_min[1], f2ord(mn1)); atomicMax(&sd->bbox_max[1], f2ord(mx1));
-            atomicMin(&sd->bbox_min[2], f2ord(mn2)); atomicMax(&sd->bbox_max[2], f2ord(mx2));
-            atomicAdd(&sd->n_valid, cnt);
-        }
+        // a tile without a finite point: the neutral codes (min = code(+inf), max = code(-inf)) and count 0
+        uint4* out = reinterpret_cast<uint4*>(parts + 8u * blockIdx.x);
+        out[0] = make_uint4(f2ord(mn0), f2ord(mn1), f2ord(mn2), f2ord(mx0));
+        out[1] = make_uint4(f2ord(mx1), f2ord(mx2), cnt, 0u);
     }
 }
 
@@ -85,17 +94,17 @@ struct VgGrid {
     uint32_t pass;
 };
 
-__device__ inline VgGrid vg_derive(const ScanDev* sd, float inv) {
+__device__ inline VgGrid vg_derive(const uint32_t bmin[3], const uint32_t bmax[3], uint32_t n_valid, float inv) {
     VgGrid g;
     g.pass = 0;
-    if (sd->n_valid == 0) {
+    if (n_valid == 0) {
         g.minb[0] = g.minb[1] = g.minb[2] = 0;
         g.mul1 = g.mul2 = 0;
         g.total = 0;
         return g;
     }
     float mn[3], mx[3];
-    for (int a = 0; a < 3; a++) { mn[a] = ord2f(sd->bbox_min[a]); mx[a] = ord2f(sd->bbox_max[a]); }
+    for (int a = 0; a < 3; a++) { mn[a] = ord2f(bmin[a]); mx[a] = ord2f(bmax[a]); }
     const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1;
     const long long dy = (long long)((mx[1] - mn[1]) * inv) + 1;
     const long long dz = (long long)((mx[2] - mn[2]) * inv) + 1;
@@ -116,25 +125,57 @@ __device__ inline VgGrid vg_derive(const ScanDev* sd, float inv) {
 // no histogram launch of its own (the later passes histogram the re-ordered keys)
 __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
-                                                           uint32_t nblocks) {
-    const VgGrid g = vg_derive(sd, inv);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sd->n_ds_prev = sd->cache_n;  // the neighbour cache's size before this scan
-        sd->passthrough = g.pass;
-        sd->total_cells = g.total;
-        sd->nbits = g.total ? (32 - __clz(g.total)) : 0;  // keys 0..total (total = invalid marker) need bits(total)
-        sd->minb[0] = g.minb[0]; sd->minb[1] = g.minb[1]; sd->minb[2] = g.minb[2];
-        sd->mul1 = g.mul1; sd->mul2 = g.mul2;
-    }
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
+                                                           uint32_t nblocks, const uint32_t* __restrict__ parts) {
+    // the cloud's points first (they do not depend on the box), then the fold of the tiles' box records: every workgroup forms the same box
     const uint32_t base = blockIdx.x * kTile;
     float4 p[kItems];
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
         const uint32_t i = base + r * kThreads + threadIdx.x;
         if (i < n) p[r] = in[i];
+    }
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t sbox[kWaves][8];
+    h[threadIdx.x] = 0;
+    uint32_t bmin[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bmax[3] = {0u, 0u, 0u}, n_valid = 0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += kThreads) {
+        const uint4 r0 = reinterpret_cast<const uint4*>(parts)[2 * b], r1 = reinterpret_cast<const uint4*>(parts)[2 * b + 1];
+        if (r1.z) {  // (a tile without finite points carries the codes of +-inf, which no finite point's code beats: skipped anyway)
+            bmin[0] = min(bmin[0], r0.x); bmin[1] = min(bmin[1], r0.y); bmin[2] = min(bmin[2], r0.z);
+            bmax[0] = max(bmax[0], r0.w); bmax[1] = max(bmax[1], r1.x); bmax[2] = max(bmax[2], r1.y);
+            n_valid += r1.z;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { bmin[a] = min(bmin[a], (uint32_t)__shfl_xor((int)bmin[a], off)); bmax[a] = max(bmax[a], (uint32_t)__shfl_xor((int)bmax[a], off)); }
+        n_valid += (uint32_t)__shfl_xor((int)n_valid, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t* o = sbox[threadIdx.x >> 6];
+        o[0] = bmin[0]; o[1] = bmin[1]; o[2] = bmin[2]; o[3] = bmax[0]; o[4] = bmax[1]; o[5] = bmax[2]; o[6] = n_valid;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; a++) { bmin[a] = 0xFFFFFFFFu; bmax[a] = 0u; }
+    n_valid = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { bmin[a] = min(bmin[a], sbox[w][a]); bmax[a] = max(bmax[a], sbox[w][3 + a]); }
+        n_valid += sbox[w][6];
+    }
+    const VgGrid g = vg_derive(bmin, bmax, n_valid, inv);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int a = 0; a < 3; a++) { sd->bbox_min[a] = bmin[a]; sd->bbox_max[a] = bmax[a]; }
+        sd->n_valid = n_valid;
+        sd->n_ds_prev = sd->cache_n;  // the neighbour cache's size before this scan
+        sd->passthrough = g.pass;
+        sd->total_cells = g.total;
+        sd->nbits = g.total ? (32 - __clz(g.total)) : 0;  // keys 0..total (total = invalid marker) need bits(total)
+        sd->minb[0] = g.minb[0]; sd->minb[1] = g.minb[1]; sd->minb[2] = g.minb[2];
+        sd->mul1 = g.mul1; sd->mul2 = g.mul2;
     }
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
@@ -220,6 +261,18 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
         // of a load in a different cache line, 64 transactions per instruction)
         const uint32_t* col = hist + tid;
         uint32_t b = 0;
+        // sixteen rows in flight (the rows are L2 hits of ~0.5 us each: four at a time made the 59 rows of a 120 000-point scan fifteen dependent
+        // round trips -- most of this kernel's 10 us)
+        for (; b + 16 <= nblocks; b += 16) {
+            uint32_t hv[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) hv[k] = col[(size_t)(b + k) * 256u];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                tot += hv[k];
+                pre += (b + k < blockIdx.x) ? hv[k] : 0u;
+            }
+        }
         for (; b + 4 <= nblocks; b += 4) {
             const uint32_t h0 = col[(size_t)b * 256u], h1 = col[(size_t)(b + 1) * 256u], h2 = col[(size_t)(b + 2) * 256u], h3 = col[(size_t)(b + 3) * 256u];
             tot += (h0 + h1) + (h2 + h3);
@@ -328,6 +381,34 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
     const bool odd = active_passes(sd) & 1;
     const uint32_t* keys = odd ? kb : ka;
     const uint32_t* vals = odd ? vb : va;
+    const uint32_t total = sd->total_cells;
+    const uint32_t base = blockIdx.x * kTile;
+    // everything this tile reads is requested up front -- keys, the key before each, the sort's index, then the eight gathers through it -- so that the
+    // eight rounds of ballots below run on registers (they used to issue their dependent loads one round at a time: 8 x 2 round trips, most of
+    // the kernel's 11 us)
+    uint32_t key_r[kItems], val_r[kItems];
+    bool head_r[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        const uint32_t i = base + r * kThreads + tid;
+        key_r[r] = i < n ? keys[i] : 0xFFFFFFFFu;
+        val_r[r] = i < n ? vals[i] : 0u;
+        const uint32_t before = (i < n && i > 0) ? keys[i - 1] : 0xFFFFFFFFu;
+        head_r[r] = i < n && key_r[r] < total && (i == 0 || before != key_r[r]);
+    }
+    {
+        float4 pt[kItems];
+#pragma unroll
+        for (int r = 0; r < kItems; r++) {
+            const uint32_t i = base + r * kThreads + tid;
+            if (i < n) pt[r] = in[val_r[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < kItems; r++) {
+            const uint32_t i = base + r * kThreads + tid;
+            if (i < n) sorted[i] = pt[r];
+        }
+    }
     __shared__ uint32_t red[kWaves];
     __shared__ uint32_t wtot[kWaves];
     // exclusive prefix of the tiles before this one (fixed order -> deterministic output slots)
@@ -341,17 +422,11 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
     for (int w = 0; w < kWaves; w++) run += red[w];
     __syncthreads();
 
-    const uint32_t total = sd->total_cells;
-    const uint32_t base = blockIdx.x * kTile;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
     for (int r = 0; r < kItems; r++) {
         const uint32_t i = base + r * kThreads + tid;
-        bool head = false;
-        if (i < n) {
-            const uint32_t key = keys[i];
-            head = key < total && (i == 0 || keys[i - 1] != key);
-            sorted[i] = in[vals[i]];
-        }
+        const bool head = head_r[r];
         const unsigned long long m = __ballot(head);
         if (lane == 0) wtot[wave] = __popcll(m);
         __syncthreads();
@@ -496,21 +571,22 @@ __device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict
 
 // ---- launchable forms: one scan (arguments by value), or the scans of a batch (blockIdx.y = slot, arguments from the slot's
 // descriptor in device memory; a workgroup beyond the slot's own tile count, or of an idle slot, exits at once) ----------------
-__global__ void __launch_bounds__(kThreads) vg_bbox_kernel(const float4* __restrict__ in, uint32_t n, ScanDev* sd) { vg_bbox_body(in, n, sd); }
+// the tiles' box records live in the head of the `sorted` buffer (free until vg_heads fills it): 32 bytes per tile
+__global__ void __launch_bounds__(kThreads) vg_bbox_kernel(const float4* __restrict__ in, uint32_t n, uint32_t* __restrict__ parts) { vg_bbox_body(in, n, parts); }
 __global__ void __launch_bounds__(kThreads) vg_bbox_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active) return;  // (grid-stride loop over the points: every workgroup of the row takes part)
-    vg_bbox_body(d.raw, d.n_raw, d.sd);
+    if (!d.active || blockIdx.x >= d.nblocks) return;
+    vg_bbox_body(d.raw, d.n_raw, reinterpret_cast<uint32_t*>(d.sorted));
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
-                                                           uint32_t nblocks) {
-    vg_keys_body(in, n, inv, sd, keys, vals, hist, nblocks);
+                                                           uint32_t nblocks, const uint32_t* __restrict__ parts) {
+    vg_keys_body(in, n, inv, sd, keys, vals, hist, nblocks, parts);
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_batch(const SlotDesc* __restrict__ slots, float inv) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || blockIdx.x >= d.nblocks) return;
-    vg_keys_body(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks);
+    vg_keys_body(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, reinterpret_cast<const uint32_t*>(d.sorted));
 }
 __global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                               int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
@@ -595,9 +671,9 @@ int vg_downsample(lio_scan* s, float leaf, int passes) {
         s->host_nds[2] = 0;
         return LIO_OK;
     }
-    const uint32_t g1 = nblocks < 48 ? nblocks : 48;  // 7 same-line atomics per workgroup: keep the workgroups few
-    hipLaunchKernelGGL(vg_bbox_kernel, g1, kThreads, 0, st, s->raw, n, s->dev);
-    hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a, s->hist, nblocks);
+    uint32_t* parts = reinterpret_cast<uint32_t*>(s->sorted);
+    hipLaunchKernelGGL(vg_bbox_kernel, nblocks, kThreads, 0, st, s->raw, n, parts);
+    hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a, s->hist, nblocks, parts);
     for (int pass = 0; pass < passes; pass++) {  // kernels of a pass the bounding box does not need return at once
         if (pass > 0) hipLaunchKernelGGL(radix_hist_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, pass, s->hist, nblocks, s->dev);
         hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, s->keys_a, s->vals_a, s->keys_b, s->vals_b, n, pass, s->hist, nblocks,
@@ -620,7 +696,7 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
     const uint32_t nblocks = (max_raw + kTile - 1) / kTile;  // of the largest scan of the batch
     if (nblocks == 0 || n_slots <= 0) return LIO_OK;
     const uint32_t B = (uint32_t)n_slots;
-    hipLaunchKernelGGL(vg_bbox_batch, dim3(nblocks < 48 ? nblocks : 48, B), kThreads, 0, st, d_slots);
+    hipLaunchKernelGGL(vg_bbox_batch, dim3(nblocks, B), kThreads, 0, st, d_slots);
     hipLaunchKernelGGL(vg_keys_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, inv);
     for (int pass = 0; pass < passes; pass++) {
         if (pass > 0) hipLaunchKernelGGL(radix_hist_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass);
