@@ -358,8 +358,7 @@ int run_update_device(lio_engine* e) {
 // h_share_model's wheel-speed part (laserMapping.cpp:794-811, 994-1012) on top of whatever the point-to-plane part of this pass is -- fresh
 // rows, the previous pass's whole measurement (stale copy), or nothing: three rows dh/dv = I3 with h = (rot * v_ins - vel) * weight,
 // weight = 1e-4 (1e-3 when degenerate) x the rows before them, as a float.
-void append_wheelspeed(lio_engine* e, const LioState& x, Measurement& m) {
-    if (!(e->wheelspeed_en && e->meas_ins_valid && (e->meas_lidar_end - e->meas_ins_stamp) < 0.01)) return;
+void append_wheelspeed_rows(bool is_degenerate, const double ins_vel[3], const LioState& x, Measurement& m) {
     if (!m.valid) {  // no point-to-plane rows at all: the three rows are the measurement (n_terms = 3)
         m.valid = true;
         m.n_rows = 0;
@@ -372,13 +371,44 @@ void append_wheelspeed(lio_engine* e, const LioState& x, Measurement& m) {
     }
     if (m.ws_n == 0) m.n_geo = m.n_rows;
     if (m.ws_n >= 6) return;
-    const float weight = !e->is_degenerate ? (float)(0.0001 * m.n_rows) : (float)(0.001 * m.n_rows);
+    const float weight = !is_degenerate ? (float)(0.0001 * m.n_rows) : (float)(0.001 * m.n_rows);
     double vel[3];
-    quat_rotate(x.rot, e->meas_ins_vel, vel);
+    quat_rotate(x.rot, ins_vel, vel);
     for (int a = 0; a < 3; a++) m.ws_h[m.ws_n][a] = (vel[a] - x.vel[a]) * weight;
     m.ws_n++;
     m.n_rows += 3;
 }
+void append_wheelspeed(lio_engine* e, const LioState& x, Measurement& m) {
+    if (!(e->wheelspeed_en && e->meas_ins_valid && (e->meas_lidar_end - e->meas_ins_stamp) < 0.01)) return;
+    append_wheelspeed_rows(e->is_degenerate, e->meas_ins_vel, x, m);
+}
+
+// ekfom_data_geo is a COPY of the shared struct (laserMapping.cpp:991): when a later pass finds no effective point, the rows of the previous
+// pass -- its point-to-plane rows AND the wheel-speed rows that pass appended -- survive in it and the filter re-uses them (n_terms != 0).
+// One keeper serves run_update, the resumed update and the filter-level harness (lio_eskf_update_ws_cb).
+struct StaleRows {
+    Measurement prev;
+    std::vector<double> rows, h;
+    bool have = false;
+    // a pass without effective points takes over the previous pass's whole measurement; returns whether it did
+    bool take_over(Measurement& m) {
+        if (m.valid || !have) return false;
+        m = prev;
+        if (prev.rows6) { m.rows6 = rows.data(); m.h = h.data(); }
+        return true;
+    }
+    // what the next pass's copy of the shared struct holds: the whole measurement of this one
+    void remember(const Measurement& m) {
+        if (!m.valid) return;
+        if (m.rows6 && m.rows6 != rows.data()) {
+            const int ng = m.ws_n > 0 ? m.n_geo : m.n_rows;
+            rows.assign(m.rows6, m.rows6 + (size_t)ng * 6);
+            h.assign(m.h, m.h + ng);
+        }
+        prev = m;
+        have = true;
+    }
+};
 
 int run_update(lio_engine* e) {
     {   // the previous scan's map_incremental may still be running on the map's stream (process_core does not wait for it): the host looks at
@@ -392,33 +422,21 @@ int run_update(lio_engine* e) {
     double host_us = 0;
     // ekfom_data_geo is a COPY of the shared struct (laserMapping.cpp:991): when a later pass finds no
     // effective point, the rows of the previous pass survive in it and the filter re-uses them (n_terms != 0).
-    Measurement prev;
-    std::vector<double> prev_rows, prev_h;
-    bool have_prev = false;
+    StaleRows stale;
     auto measure = [&](const LioState& x, bool converge, Measurement& m) {
         lio_pass_log pl;
         memset(&pl, 0, sizeof(pl));
         if (ctx.rc != LIO_OK) { m.valid = false; return; }  // a device error earlier in this update: no further launches
         const int rc = measure_pass(e, x, converge, m, pl);
         if (rc != LIO_OK) { ctx.rc = rc; m.valid = false; e->log.push_back(pl); return; }
-        if (!m.valid && have_prev) {
-            m = prev;
-            if (prev.rows6) { m.rows6 = prev_rows.data(); m.h = prev_h.data(); }
+        if (stale.take_over(m)) {
             pl.valid = 1;
             memcpy(pl.JtJ, m.HTH, sizeof(pl.JtJ));
             memcpy(pl.Jtr, m.HTh, sizeof(pl.Jtr));
         }
         append_wheelspeed(e, x, m);
-        if (m.valid) {  // what the next pass's copy of the shared struct holds: the whole measurement of this one
-            pl.valid = 1;
-            if (m.rows6 && m.rows6 != prev_rows.data()) {
-                const int ng = m.ws_n > 0 ? m.n_geo : m.n_rows;
-                prev_rows.assign(m.rows6, m.rows6 + (size_t)ng * 6);
-                prev_h.assign(m.h, m.h + ng);
-            }
-            prev = m;
-            have_prev = true;
-        }
+        if (m.valid) pl.valid = 1;
+        stale.remember(m);
         e->log.push_back(pl);
     };
     const auto t0 = std::chrono::steady_clock::now();
@@ -450,33 +468,21 @@ int engine_resume_update_impl(lio_engine* e, const double* x_now26, const double
     memset(w.dx_new, 0, sizeof(w.dx_new));
     state_from_array(x_now26, e->kf.x);
     memcpy(e->kf.P, P_prop, sizeof(w.P_prop));
-    Measurement prev;
-    std::vector<double> prev_rows, prev_h;
-    bool have_prev = false;
+    StaleRows stale;
     auto measure = [&](const LioState& x, bool conv, Measurement& m) {
         lio_pass_log pl;
         memset(&pl, 0, sizeof(pl));
         if (ctx.rc != LIO_OK) { m.valid = false; return; }
         const int rc = measure_pass(e, x, conv, m, pl);
         if (rc != LIO_OK) { ctx.rc = rc; m.valid = false; e->log.push_back(pl); return; }
-        if (!m.valid && have_prev) {
-            m = prev;
-            if (prev.rows6) { m.rows6 = prev_rows.data(); m.h = prev_h.data(); }
+        if (stale.take_over(m)) {
             pl.valid = 1;
             memcpy(pl.JtJ, m.HTH, sizeof(pl.JtJ));
             memcpy(pl.Jtr, m.HTh, sizeof(pl.Jtr));
         }
         append_wheelspeed(e, x, m);
-        if (m.valid) {  // what the next pass's copy of the shared struct holds: the whole measurement of this one
-            pl.valid = 1;
-            if (m.rows6 && m.rows6 != prev_rows.data()) {
-                const int ng = m.ws_n > 0 ? m.n_geo : m.n_rows;
-                prev_rows.assign(m.rows6, m.rows6 + (size_t)ng * 6);
-                prev_h.assign(m.h, m.h + ng);
-            }
-            prev = m;
-            have_prev = true;
-        }
+        if (m.valid) pl.valid = 1;
+        stale.remember(m);
         e->log.push_back(pl);
     };
     e->kf.update_iterated_from(w, i, converge != 0, t, e->laser_cov, measure, on_pass, &ctx);
@@ -1424,31 +1430,39 @@ int lio_eskf_update_ws_cb(const double s26[26], const double P[529], double R, i
     memcpy(kf.P, P, sizeof(double) * 529);
     kf.maximum_iter = max_iter;
     std::vector<double> rows((size_t)cap * 6), hv(cap);
+    StaleRows stale;  // the keeper run_update uses: a model that reports "no effective points" (return value 2) gets the previous pass's rows back
     auto measure = [&](const LioState& x, bool converge, Measurement& m) {
         double st[26];
         state_to_array(x, st);
         int n = 0;
-        if (!fn(ctx, st, converge ? 1 : 0, &n, rows.data(), hv.data(), cap) || n <= 0 || n > cap) { m.valid = false; return; }
-        m.valid = true;
-        m.n_rows = n;
-        for (int a = 0; a < 36; a++) m.HTH[a] = 0;
-        for (int a = 0; a < 6; a++) m.HTh[a] = 0;
-        for (int r = 0; r < n; r++)
-            for (int a = 0; a < 6; a++) {
-                for (int b = 0; b < 6; b++) m.HTH[a * 6 + b] += rows[(size_t)r * 6 + a] * rows[(size_t)r * 6 + b];
-                m.HTh[a] += rows[(size_t)r * 6 + a] * hv[r];
-            }
-        m.rows6 = rows.data();
-        m.h = hv.data();
-        if (ins_vel) {
-            m.n_geo = n;
-            const float weight = !degenerate ? (float)(0.0001 * n) : (float)(0.001 * n);
-            double vel[3];
-            quat_rotate(x.rot, ins_vel, vel);
-            for (int a = 0; a < 3; a++) m.ws_h[0][a] = (vel[a] - x.vel[a]) * weight;
-            m.ws_n = 1;
-            m.n_rows = n + 3;
+        const int rc = fn(ctx, st, converge ? 1 : 0, &n, rows.data(), hv.data(), cap);
+        m.valid = false;
+        m.n_rows = 0;
+        m.n_geo = 0;
+        m.ws_n = 0;
+        m.rows6 = nullptr;
+        m.h = nullptr;
+        if (rc == 2) {
+            // h_share_model_geometric returned early ("No Effective Points", laserMapping.cpp:888-893): the copy of the shared struct keeps what
+            // the previous pass left in it
+            stale.take_over(m);
+        } else if (rc && n > 0 && n <= cap) {
+            m.valid = true;
+            m.n_rows = n;
+            for (int a = 0; a < 36; a++) m.HTH[a] = 0;
+            for (int a = 0; a < 6; a++) m.HTh[a] = 0;
+            for (int r = 0; r < n; r++)
+                for (int a = 0; a < 6; a++) {
+                    for (int b = 0; b < 6; b++) m.HTH[a * 6 + b] += rows[(size_t)r * 6 + a] * rows[(size_t)r * 6 + b];
+                    m.HTh[a] += rows[(size_t)r * 6 + a] * hv[r];
+                }
+            m.rows6 = rows.data();
+            m.h = hv.data();
+        } else {
+            return;  // the model reports the whole pass invalid
         }
+        if (ins_vel) append_wheelspeed_rows(degenerate != 0, ins_vel, x, m);
+        stale.remember(m);
     };
     kf.update_iterated(R, measure, nullptr, nullptr);
     state_to_array(kf.x, s26_out);

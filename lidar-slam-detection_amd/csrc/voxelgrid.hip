@@ -125,7 +125,13 @@ __device__ inline VgGrid vg_derive(const uint32_t bmin[3], const uint32_t bmax[3
 // no histogram launch of its own (the later passes histogram the re-ordered keys)
 __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
-                                                           uint32_t nblocks, const uint32_t* __restrict__ parts) {
+                                                           uint32_t nblocks, const uint32_t* __restrict__ parts, uint32_t hist_stride) {
+    // hist_stride != 0 (one scan at a time): the histograms of passes 1..3 are built by the scatter of the pass before them (atomics into their own
+    // sections of `hist`, hist_stride words apart); this tile clears its rows of those sections
+    if (hist_stride) {
+#pragma unroll
+        for (uint32_t sct = 1; sct < 4; sct++) hist[(size_t)sct * hist_stride + blockIdx.x * 256u + threadIdx.x] = 0u;
+    }
     // the cloud's points first (they do not depend on the box), then the fold of the tiles' box records: every workgroup forms the same box
     const uint32_t base = blockIdx.x * kTile;
     float4 p[kItems];
@@ -230,10 +236,16 @@ __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
     return peers;
 }
 
+// FUSE: this pass also builds the NEXT pass's per-tile histogram -- one atomic per key into the row of the tile the key lands in -- so that a scan
+// registered alone needs no histogram launch between its scatters (two launches of ~5 us + their boundaries per scan; with 64 scans per launch the
+// 7.7 M atomics per pass would cost what the histogram kernel does: the batched chain keeps it)
+template <bool FUSE>
 __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
-                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
+                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd,
+                                                                 uint32_t* __restrict__ hist_next) {
     if ((uint32_t)pass >= active_passes(sd)) return;
+    const bool feed_next = FUSE && (uint32_t)(pass + 1) < active_passes(sd);
     const uint32_t* kin = (pass & 1) ? kb : ka;
     const uint32_t* vin = (pass & 1) ? vb : va;
     uint32_t* kout = (pass & 1) ? ka : kb;
@@ -327,7 +339,10 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
         __builtin_amdgcn_wave_barrier();
         if (ok[r] && below[r] == 0) wcnt[wave][d] += total[r];
         __builtin_amdgcn_wave_barrier();
-        if (ok[r]) { kout[pos] = k[r]; vout[pos] = v[r]; }
+        if (ok[r]) {
+            kout[pos] = k[r]; vout[pos] = v[r];
+            if (FUSE && feed_next) atomicAdd(&hist_next[(size_t)(pos / (uint32_t)kTile) * 256u + ((k[r] >> (shift + 8)) & 255u)], 1u);
+        }
     }
 }
 
@@ -356,7 +371,9 @@ __device__ __forceinline__ void vg_count_heads_body(const uint32_t* __restrict__
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = c;
 }
 
-// compaction of the voxel heads (ballot + prefix sum, fixed order) and the gather of the points into sorted order
+// compaction of the voxel heads (ballot + prefix sum, fixed order) and the gather of the points into sorted order.
+// (Measured in round 4 and not kept: every load of the tile requested up front, the ballot rounds on registers -- 11.4 -> 13.8 us for one scan,
+// 42 -> 79 us for a batched round: the eight gathers through the sort's permutation then leave together and queue behind each other.)
 __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, const uint32_t* __restrict__ ka,
                                                             const uint32_t* __restrict__ kb, const uint32_t* __restrict__ va,
                                                             const uint32_t* __restrict__ vb, uint32_t n, ScanDev* sd,
@@ -381,34 +398,6 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
     const bool odd = active_passes(sd) & 1;
     const uint32_t* keys = odd ? kb : ka;
     const uint32_t* vals = odd ? vb : va;
-    const uint32_t total = sd->total_cells;
-    const uint32_t base = blockIdx.x * kTile;
-    // everything this tile reads is requested up front -- keys, the key before each, the sort's index, then the eight gathers through it -- so that the
-    // eight rounds of ballots below run on registers (they used to issue their dependent loads one round at a time: 8 x 2 round trips, most of
-    // the kernel's 11 us)
-    uint32_t key_r[kItems], val_r[kItems];
-    bool head_r[kItems];
-#pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        const uint32_t i = base + r * kThreads + tid;
-        key_r[r] = i < n ? keys[i] : 0xFFFFFFFFu;
-        val_r[r] = i < n ? vals[i] : 0u;
-        const uint32_t before = (i < n && i > 0) ? keys[i - 1] : 0xFFFFFFFFu;
-        head_r[r] = i < n && key_r[r] < total && (i == 0 || before != key_r[r]);
-    }
-    {
-        float4 pt[kItems];
-#pragma unroll
-        for (int r = 0; r < kItems; r++) {
-            const uint32_t i = base + r * kThreads + tid;
-            if (i < n) pt[r] = in[val_r[r]];
-        }
-#pragma unroll
-        for (int r = 0; r < kItems; r++) {
-            const uint32_t i = base + r * kThreads + tid;
-            if (i < n) sorted[i] = pt[r];
-        }
-    }
     __shared__ uint32_t red[kWaves];
     __shared__ uint32_t wtot[kWaves];
     // exclusive prefix of the tiles before this one (fixed order -> deterministic output slots)
@@ -422,11 +411,17 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
     for (int w = 0; w < kWaves; w++) run += red[w];
     __syncthreads();
 
+    const uint32_t total = sd->total_cells;
+    const uint32_t base = blockIdx.x * kTile;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
     for (int r = 0; r < kItems; r++) {
         const uint32_t i = base + r * kThreads + tid;
-        const bool head = head_r[r];
+        bool head = false;
+        if (i < n) {
+            const uint32_t key = keys[i];
+            head = key < total && (i == 0 || keys[i - 1] != key);
+            sorted[i] = in[vals[i]];
+        }
         const unsigned long long m = __ballot(head);
         if (lane == 0) wtot[wave] = __popcll(m);
         __syncthreads();
@@ -498,10 +493,14 @@ __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sort
     out[v] = make_float4(sx / c, sy / c, sz / c, sw / c);
 }
 
-// one wave per long run: 64 coalesced loads at a time, parked in LDS by coordinate; lanes 0..3 then each own ONE coordinate and add its
-// 64 values in point order (PCL's sequential f32 sum: a dependent chain by definition -- but four chains side by side in one instruction
-// stream, fed by 16-byte LDS reads: ~5 cycles per point instead of the 32 of four v_readlane + four adds in every lane); the next 64
-// points are in flight while these are summed
+// one wave per long run.  The sum itself is PCL's sequential f32 sum -- a dependent chain by definition -- run as four chains side by side (lanes
+// 0..3 own one coordinate each) over values parked in LDS by coordinate, ~5 cycles per point.  What the chain must never do is wait for memory:
+// a chunk of 512 points (eight coalesced 16-byte loads per lane) is requested one chunk AHEAD of the one being summed.  (Until round 4 one
+// 64-point batch was in flight: 0.15 us of adds behind every ~0.8 us load -- 36 us on average in the streaming configuration, 0.6 ms for the
+// worst voxel.)
+constexpr int kLongChunk = 512;
+constexpr int kLongLoads = kLongChunk / 64;
+
 __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
                                                                     const uint32_t* __restrict__ longlist) {
@@ -509,21 +508,34 @@ __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__
     const uint32_t nv = sd->n_ds, nl = sd->n_long;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * kWaves;
-    __shared__ __attribute__((aligned(16))) float park[kWaves][4][64];
+    __shared__ __attribute__((aligned(16))) float park[kWaves][4][kLongChunk];
     for (uint32_t w = blockIdx.x * kWaves + wv; w < nl; w += nwaves) {
         const uint32_t v = longlist[w];
         const uint32_t ra = hpos[v];
         const uint32_t rb = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;
         float t = 0.f;  // lane c < 4: the running sum of coordinate c
-        float4 p = sorted[(ra + lane) < rb ? ra + lane : rb - 1];
-        for (uint32_t c = ra; c < rb; c += 64) {
-            park[wv][0][lane] = p.x; park[wv][1][lane] = p.y; park[wv][2][lane] = p.z; park[wv][3][lane] = p.w;
-            const uint32_t jn = c + 64 + lane;
-            if (c + 64 < rb) p = sorted[jn < rb ? jn : rb - 1];
+        float4 p[kLongLoads];
+#pragma unroll
+        for (int k = 0; k < kLongLoads; k++) {
+            const uint32_t j = ra + k * 64 + lane;
+            p[k] = sorted[j < rb ? j : rb - 1];
+        }
+        for (uint32_t c = ra; c < rb; c += kLongChunk) {
+#pragma unroll
+            for (int k = 0; k < kLongLoads; k++) {
+                park[wv][0][k * 64 + lane] = p[k].x; park[wv][1][k * 64 + lane] = p[k].y; park[wv][2][k * 64 + lane] = p[k].z; park[wv][3][k * 64 + lane] = p[k].w;
+            }
+            if (c + kLongChunk < rb) {  // the next chunk's loads leave before this one is summed
+#pragma unroll
+                for (int k = 0; k < kLongLoads; k++) {
+                    const uint32_t j = c + kLongChunk + k * 64 + lane;
+                    p[k] = sorted[j < rb ? j : rb - 1];
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int m = (rb - c) < 64u ? (int)(rb - c) : 64;
+            const int m = (rb - c) < (uint32_t)kLongChunk ? (int)(rb - c) : kLongChunk;
             if (lane < 4) {
                 const float* q = park[wv][lane];
                 int k = 0;
@@ -580,13 +592,13 @@ __global__ void __launch_bounds__(kThreads) vg_bbox_batch(const SlotDesc* __rest
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
-                                                           uint32_t nblocks, const uint32_t* __restrict__ parts) {
-    vg_keys_body(in, n, inv, sd, keys, vals, hist, nblocks, parts);
+                                                           uint32_t nblocks, const uint32_t* __restrict__ parts, uint32_t hist_stride) {
+    vg_keys_body(in, n, inv, sd, keys, vals, hist, nblocks, parts, hist_stride);
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_batch(const SlotDesc* __restrict__ slots, float inv) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || blockIdx.x >= d.nblocks) return;
-    vg_keys_body(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, reinterpret_cast<const uint32_t*>(d.sorted));
+    vg_keys_body(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, reinterpret_cast<const uint32_t*>(d.sorted), 0u);
 }
 __global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                               int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
@@ -599,13 +611,13 @@ __global__ void __launch_bounds__(kThreads) radix_hist_batch(const SlotDesc* __r
 }
 __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
-                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
-    radix_scatter_body(ka, va, kb, vb, n, pass, hist, nblocks, sd);
+                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd, uint32_t* __restrict__ hist_next) {
+    radix_scatter_body<true>(ka, va, kb, vb, n, pass, hist, nblocks, sd, hist_next);
 }
 __global__ void __launch_bounds__(kThreads) radix_scatter_batch(const SlotDesc* __restrict__ slots, int pass) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || blockIdx.x >= d.nblocks) return;
-    radix_scatter_body(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd);
+    radix_scatter_body<false>(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd, nullptr);
 }
 __global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                                   const ScanDev* sd, uint32_t* __restrict__ blockcnt) {
@@ -673,12 +685,13 @@ int vg_downsample(lio_scan* s, float leaf, int passes) {
     }
     uint32_t* parts = reinterpret_cast<uint32_t*>(s->sorted);
     hipLaunchKernelGGL(vg_bbox_kernel, nblocks, kThreads, 0, st, s->raw, n, parts);
-    hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a, s->hist, nblocks, parts);
-    for (int pass = 0; pass < passes; pass++) {  // kernels of a pass the bounding box does not need return at once
-        if (pass > 0) hipLaunchKernelGGL(radix_hist_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, pass, s->hist, nblocks, s->dev);
-        hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, s->keys_a, s->vals_a, s->keys_b, s->vals_b, n, pass, s->hist, nblocks,
-                           s->dev);
-    }
+    // the four passes' histograms live in four sections of `hist` (lio_scan_create sizes it for them): pass 0's is built by vg_keys, pass p + 1's by the
+    // scatter of pass p
+    const uint32_t hstride = s->hist_stride;
+    hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a, s->hist, nblocks, parts, hstride);
+    for (int pass = 0; pass < passes; pass++)  // kernels of a pass the bounding box does not need return at once
+        hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, s->keys_a, s->vals_a, s->keys_b, s->vals_b, n, pass,
+                           s->hist + (size_t)pass * hstride, nblocks, s->dev, s->hist + (size_t)(pass + 1 < 4 ? pass + 1 : 3) * hstride);
     hipLaunchKernelGGL(vg_count_heads_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, s->dev, s->blockcnt);
     hipLaunchKernelGGL(vg_heads_kernel, nblocks, kThreads, 0, st, s->raw, s->keys_a, s->keys_b, s->vals_a, s->vals_b, n, s->dev, s->blockcnt,
                        s->hpos, s->sorted, s->ds_body, s->max_ds, s->host_nds_dev, (uint32_t)passes);

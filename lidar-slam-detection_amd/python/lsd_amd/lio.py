@@ -894,12 +894,19 @@ def state_predict(s, P, dt, Q12, acc, gyro):
     return so, Po.reshape(23, 23)
 
 
+NO_EFFECTIVE_POINTS = "no effective points"  # a model's answer for a pass in which h_share_model_geometric returns early (laserMapping.cpp:888-893)
+
+
 def make_meas_fn(model):
-    """wrap model(state26, converge) -> (rows (n, 6), h (n,)) or None as the C measurement callback of lio_eskf_update_cb"""
+    """wrap model(state26, converge) -> (rows (n, 6), h (n,)), None (the pass is invalid) or NO_EFFECTIVE_POINTS (the point-to-plane part found
+    nothing: the rows of the previous pass survive in the copied struct, laserMapping.cpp:991) as the C measurement callback of lio_eskf_update_cb"""
     def _cb(ctx, s26, converge, n_out, rows, h, cap):
         r = model(np.ctypeslib.as_array(s26, shape=(STATE_DIM,)).copy(), bool(converge))
         if r is None:
             return 0
+        if isinstance(r, str) and r == NO_EFFECTIVE_POINTS:
+            n_out[0] = 0
+            return 2
         R, H = np.asarray(r[0], np.float64).reshape(-1, 6), np.asarray(r[1], np.float64).ravel()
         n = len(H)
         assert n <= cap and len(R) == n

@@ -923,11 +923,18 @@ struct Lio {
             state_to(s, s26);
             std::vector<double> rows((size_t)ext_cap * 6), hv(ext_cap);
             int n = 0;
-            if (!ext_fn(ext_ctx, s26, d.converge ? 1 : 0, &n, rows.data(), hv.data(), ext_cap)) { d.valid = false; return; }
-            geo.h_x = Mat(n, 15);
-            geo.h.assign(hv.begin(), hv.begin() + n);
-            for (int r = 0; r < n; r++) for (int c = 0; c < 6; c++) geo.h_x(r, c) = rows[(size_t)r * 6 + c];
-            effct_feat_num = n;
+            const int rc_ext = ext_fn(ext_ctx, s26, d.converge ? 1 : 0, &n, rows.data(), hv.data(), ext_cap);
+            if (!rc_ext) { d.valid = false; return; }
+            if (rc_ext == 2) {
+                // "No Effective Points" (laserMapping.cpp:888-893): h_share_model_geometric sets valid = false on the COPY and returns -- geo keeps
+                // the h_x / h the previous pass left in the shared struct (its point-to-plane rows and the wheel-speed rows appended to them)
+                effct_feat_num = 0;
+            } else {
+                geo.h_x = Mat(n, 15);
+                geo.h.assign(hv.begin(), hv.begin() + n);
+                for (int r = 0; r < n; r++) for (int c = 0; c < 6; c++) geo.h_x(r, c) = rows[(size_t)r * 6 + c];
+                effct_feat_num = n;
+            }
         }
         // h_share_model_wheelspeed (laserMapping.cpp:794-811): three rows dh/dv = I, h = rot * v_ins - vel, when wheelspeed_en and the last
         // INS sample of this scan is within 10 ms of its end.  (wheelspeed_en is a constant false in the reference: dead code there.)

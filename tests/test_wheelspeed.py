@@ -147,3 +147,51 @@ def test_host_filter_with_wheelspeed_rows_matches_the_oracle_filter(oracle_mod, 
         # the rows do something: without them the velocity block of the result differs
         s_no, _ = lio.eskf_update(s0, P0, 0.001, model, max_iter=4)
         assert np.abs(s_no[14:17] - sp[14:17]).max() > 1e-9
+
+
+@pytest.mark.parametrize("n_rows", [400, 10])          # information form, and the dense gain branch (rows + 3 (+ 3) < 23)
+@pytest.mark.parametrize("empty_passes", [(1,), (1, 2), (0,), (2, 3)])
+@pytest.mark.parametrize("wheel", [True, False])
+def test_stale_rows_of_a_pass_without_effective_points_with_wheel_rows(oracle_mod, n_rows, empty_passes, wheel):
+    """laserMapping.cpp:991: `ekfom_data_geo = ekfom_data` copies the shared struct, so a pass in which h_share_model_geometric finds no
+    effective point (:888-893) re-uses the rows the PREVIOUS pass left there -- its point-to-plane rows and, with wheelspeed_en, the three
+    wheel-speed rows that pass appended -- and appends this pass's wheel rows behind them (the weight then counts the stale wheel rows too).
+    The product's keeper of those rows (StaleRows in csrc/engine.hip: run_update, the resumed update and this harness share it) against the
+    oracle's dense restatement, scripted through the filter-level harnesses: the model reports NO_EFFECTIVE_POINTS in the given passes (pass 0 =
+    nothing to fall back on: with wheel rows the three rows alone are the measurement, without them the pass is invalid)."""
+    from lsd_amd import lio
+    from test_ikfom_vs_ref import _close, _cov, _plane_model, _state
+
+    rng = np.random.default_rng(900 + n_rows + 10 * sum(empty_passes) + wheel)
+    for trial in range(3):
+        truth = _state(oracle_mod, rng, 0.2)
+        s0 = oracle_mod.state_boxplus(truth, np.concatenate([rng.normal(size=6) * [0.2, 0.2, 0.2, 0.02, 0.02, 0.02], np.zeros(17)]))
+        P0 = _cov(rng, 1e-3)
+        base, calls = _plane_model(rng, n_rows, truth)
+        seen = []
+
+        def model(s, converge):
+            k = len(seen)
+            seen.append(k)
+            if k in empty_passes:
+                return lio.NO_EFFECTIVE_POINTS
+            return base(s, converge)
+
+        v_ins = rng.normal(size=3) * [3.0, 0.5, 0.0]
+        if wheel:
+            so, Po = oracle_mod.kf_update_ws(s0, P0, 0.001, lio.make_meas_fn(model), v_ins, False, max_iter=4)
+        else:
+            so, Po = oracle_mod.kf_update(s0, P0, 0.001, lio.make_meas_fn(model), max_iter=4)
+        n_o = len(seen)
+        del seen[:]
+        if wheel:
+            sp, Pp = lio.eskf_update_ws(s0, P0, 0.001, model, v_ins, False, max_iter=4)
+        else:
+            sp, Pp = lio.eskf_update(s0, P0, 0.001, model, max_iter=4)
+        assert len(seen) == n_o and n_o >= max(empty_passes) + 1, (n_o, len(seen))
+        tol = 1e-9 if n_rows >= 23 else 1e-8
+        assert _close(sp, so, tol) and _close(Pp, Po, tol * 10), (n_rows, empty_passes, wheel, trial, np.abs(sp - so).max(), np.abs(Pp - Po).max())
+        # the scripted passes matter: the same update with every pass measured ends elsewhere
+        del seen[:]
+        s_all, _ = (lio.eskf_update_ws(s0, P0, 0.001, base, v_ins, False, max_iter=4) if wheel else lio.eskf_update(s0, P0, 0.001, base, max_iter=4))
+        assert np.abs(s_all - sp).max() > 1e-12
