@@ -167,4 +167,77 @@ int lsq_align(const lio_ndt_params& p, const double guess[16], Lin&& linearize, 
     return LIO_OK;
 }
 
+// The same driver with the trial evaluation and the linearisation that follows an accepted step fetched TOGETHER: spec(x_lin, xi, H', b', &y', &yi)
+// returns the cost yi at xi on the pairs cached at x_lin (what error() returns) and, for the pairs refreshed at xi, cost / H / b (what the
+// next iteration's linearize(xi) returns); commit() tells the matcher that xi was accepted (its refreshed pairs become the cached ones).
+// Decisions, poses and iteration counts are those of lsq_align: the numbers are the same, they only arrive one hand-over earlier.
+template <typename Lin, typename Spec, typename Commit>
+int lsq_align_spec(const lio_ndt_params& p, const double guess[16], Lin&& linearize, Spec&& spec, Commit&& commit, double out[16], int* iterations,
+                   int* converged) {
+    double x0[16];
+    memcpy(x0, guess, sizeof(x0));
+    double lambda = -1.0;
+    bool conv = false, have_next = false;
+    int it_done = 0;
+    double Hn[36], bn[6], yn = 0;
+    const auto clock0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < p.max_iterations && !conv; it++) {
+        it_done = it;
+        double H[36], b[6], delta[16], y0 = 0;
+        if (have_next) {
+            memcpy(H, Hn, sizeof(H));
+            memcpy(b, bn, sizeof(b));
+            y0 = yn;
+            have_next = false;
+        } else {
+            const int rc = linearize(x0, H, b, &y0);
+            if (rc != LIO_OK) return rc;
+        }
+        if (lambda < 0.0) {
+            double mx = 0;
+            for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(H[i * 7]));
+            lambda = p.lm_init_lambda_factor * mx;
+        }
+        double nu = 2.0;
+        bool ok = false;
+        for (int i = 0; i < p.lm_max_iterations; i++) {  // step_lm
+            double A[36], nb[6], d[6];
+            for (int k = 0; k < 36; k++) A[k] = H[k] + ((k % 7 == 0) ? lambda : 0.0);
+            for (int k = 0; k < 6; k++) nb[k] = -b[k];
+            if (!ldlt_solve6(A, nb, d)) break;
+            se3_exp_h(d, delta);
+            double xi[16], yi = 0;
+            mul44_h(delta, x0, xi);
+            const int rc = spec(x0, xi, Hn, bn, &yn, &yi);
+            if (rc != LIO_OK) return rc;
+            double den = 0;
+            for (int k = 0; k < 6; k++) den += d[k] * (lambda * d[k] - b[k]);
+            const double rho = (y0 - yi) / den;
+            if (rho < 0) {
+                if (converged_h(p, delta, 10.0)) { ok = true; break; }
+                lambda = nu * lambda;
+                nu = 2 * nu;
+                continue;
+            }
+            memcpy(x0, xi, sizeof(x0));
+            lambda = lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+            ok = true;
+            have_next = true;
+            commit();
+            break;
+        }
+        if (!ok) break;  // "lm not converged!!"
+        conv = converged_h(p, delta, 1.0);
+        if (p.max_process_time_ms > 0) {  // lsq_registration_impl.hpp:94-104
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clock0).count();
+            if (ms > p.max_process_time_ms && converged_h(p, delta, 10.0)) { conv = true; break; }
+            else if (ms > 1.5 * p.max_process_time_ms) break;
+        }
+    }
+    memcpy(out, x0, sizeof(x0));
+    if (iterations) *iterations = it_done;
+    if (converged) *converged = conv ? 1 : 0;
+    return LIO_OK;
+}
+
 }  // namespace lio

@@ -292,6 +292,7 @@ struct NdtDev {
 };
 struct NdtReport {  // mapped pinned host memory
     double acc[kNdtOut];
+    double err_trial;  // speculative evaluation only: the cost at x on the pairs cached at the linearisation point (compute_error)
     uint32_t n_corr;
     uint32_t seq;
 };
@@ -448,6 +449,159 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_kernel(const Slot* __res
     ndt_cost_body<UPDATE, DERIV, NO>(table, mask, vox, res, offs, x_lin, x, src, sd->n_ds, corr, corr_stride, partial, pstride, &nd->n_corr);
 }
 
+// ---- speculative evaluation (lio_ndt_align, one alignment at a time) -----------------------------------------------------------------------------
+// LsqRegistration::step_lm evaluates a trial pose xi with compute_error -- on the pairs cached at the linearisation point x0 -- and, when the step
+// is accepted (nearly always on the first trial), the next iteration begins by linearising at that very pose (update_correspondences + derivatives at
+// x0 := xi).  Both are functions of xi alone, so ONE launch computes them together: the trial cost on the old pairs (acc[28]) and, into the OTHER
+// correspondence buffer, the pairs at xi with their cost / H / b (acc[0..27]).  An accepted step finds its next linearisation already reported -- one
+// kernel, one report and one host hand-over per LM iteration instead of two; a rejected step discards it (the pairs of x0 were not touched).  Same
+// statements, same per-lane accumulation order, same reduction as the two separate kernels: the results are the same bits.
+template <int NO>
+__global__ void __launch_bounds__(kNdtThreads) ndt_cost_spec_kernel(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox, float res,
+                                                                    NdtOffsets offs, NdtXform x, const float4* __restrict__ src, const ScanDev* __restrict__ sd,
+                                                                    const uint32_t* __restrict__ corr_old, uint32_t* __restrict__ corr_new, uint32_t corr_stride,
+                                                                    double* __restrict__ partial, uint32_t pstride, NdtDev* nd) {
+    const uint32_t n = sd->n_ds;
+    if (blockIdx.x * kNdtThreads >= n) return;
+    const uint32_t i = blockIdx.x * kNdtThreads + threadIdx.x;
+    constexpr int NA = kNdtAcc + 1;
+    double acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) acc[a] = 0.0;
+    uint32_t my_corr = 0;
+    if (i < n) {
+        const float4 p = src[i];
+        uint32_t s_old[NO], slot[NO];
+#pragma unroll
+        for (int o = 0; o < NO; o++) s_old[o] = corr_old[(size_t)o * corr_stride + i];
+        float tp[3];
+        xform_dev(x, p, tp);  // (the linearisation point of the new pairs IS x: find_voxel_correspondences' transform and the cost's are one)
+        {
+            int kx, ky, kz;
+            pos2grid_ndt(tp[0], tp[1], tp[2], res, kx, ky, kz);
+            uint4 raw[NO];
+            BrickProbe bp[NO];
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                bp[o] = brick_probe(kx + offs.off[o][0], ky + offs.off[o][1], kz + offs.off[o][2]);
+                raw[o] = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[o], mask)]);
+            }
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                const unsigned long long want = pack_key(kx + offs.off[o][0], ky + offs.off[o][1], kz + offs.off[o][2]);
+                uint4 r = raw[o];
+                uint32_t found = kNoIdx;
+                for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
+                    const unsigned long long kk = ((unsigned long long)r.y << 32) | r.x;
+                    if (kk == want) { found = r.w > 0 ? brick_slot(bp[o], mask) : kNoIdx; break; }
+                    if (kk == kEmptyKey) break;
+                    brick_next(bp[o]);
+                    r = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[o], mask)]);
+                }
+                slot[o] = found;
+                corr_new[(size_t)o * corr_stride + i] = found;
+                if (found != kNoIdx) my_corr++;
+            }
+        }
+        const float ksq = res * res;
+#pragma unroll
+        for (int o = 0; o < NO; o++) {
+            // the pair of the new correspondences: cost + H + b (the DERIV branch of ndt_cost_body, statement for statement)
+            float err_new = 0.f;
+            bool have_new = false;
+            if (slot[o] != kNoIdx) {
+                const float4* rec = reinterpret_cast<const float4*>(&vox[slot[o]]);
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                if (__float_as_int(r0.w) > 6) {
+                    const float ci[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
+                    const float e[3] = {r0.x - tp[0], r0.y - tp[1], r0.z - tp[2]};
+                    const float nrm = sqrtf(sqn3_dev(e));
+                    const float w = ksq / (ksq + nrm * nrm);
+                    const float we[3] = {w * e[0], w * e[1], w * e[2]};
+                    float wc[3];
+                    for (int c = 0; c < 3; c++) wc[c] = sum3f(we[0] * ci[c], we[1] * ci[3 + c], we[2] * ci[6 + c]);
+                    err_new = sum3f(wc[0] * e[0], wc[1] * e[1], wc[2] * e[2]);
+                    have_new = true;
+                    const float w0 = w * tp[0], w1 = w * tp[1], w2 = w * tp[2];
+                    float Brot[3][3], m[9];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        Brot[0][c] = w2 * ci[3 + c] - w1 * ci[6 + c];
+                        Brot[1][c] = w0 * ci[6 + c] - w2 * ci[c];
+                        Brot[2][c] = w1 * ci[c] - w0 * ci[3 + c];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 9; k++) m[k] = w * ci[k];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const float h0 = Brot[r][1] * tp[2] - Brot[r][2] * tp[1];
+                        const float h1 = Brot[r][2] * tp[0] - Brot[r][0] * tp[2];
+                        const float h2 = Brot[r][0] * tp[1] - Brot[r][1] * tp[0];
+                        acc[ndt_tri(r, 0)] += (double)h0;
+                        if (r >= 1) acc[ndt_tri(r, 1)] += (double)h1;
+                        if (r >= 2) acc[ndt_tri(r, 2)] += (double)h2;
+                        acc[21 + r] += (double)sum3f(Brot[r][0] * e[0], Brot[r][1] * e[1], Brot[r][2] * e[2]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const float B0 = -m[r * 3], B1 = -m[r * 3 + 1], B2 = -m[r * 3 + 2];
+                        acc[ndt_tri(3 + r, 0)] += (double)(B1 * tp[2] - B2 * tp[1]);
+                        acc[ndt_tri(3 + r, 1)] += (double)(B2 * tp[0] - B0 * tp[2]);
+                        acc[ndt_tri(3 + r, 2)] += (double)(B0 * tp[1] - B1 * tp[0]);
+#pragma unroll
+                        for (int c = 0; c <= r; c++) acc[ndt_tri(3 + r, 3 + c)] += (double)m[r * 3 + c];
+                        acc[24 + r] += (double)sum3f(B0 * e[0], B1 * e[1], B2 * e[2]);
+                    }
+                    acc[27] += (double)err_new;
+                }
+            }
+            // the pair the linearisation at x0 cached for this offset: its cost at x (compute_error).  Usually the same voxel: the same record and the
+            // same transformed point give the same f32 number
+            if (s_old[o] != kNoIdx) {
+                if (s_old[o] == slot[o]) {
+                    if (have_new) acc[28] += (double)err_new;
+                } else {
+                    const float4* rec = reinterpret_cast<const float4*>(&vox[s_old[o]]);
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                    if (__float_as_int(r0.w) > 6) {
+                        const float ci[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
+                        const float e[3] = {r0.x - tp[0], r0.y - tp[1], r0.z - tp[2]};
+                        const float nrm = sqrtf(sqn3_dev(e));
+                        const float w = ksq / (ksq + nrm * nrm);
+                        const float we[3] = {w * e[0], w * e[1], w * e[2]};
+                        float wc[3];
+                        for (int c = 0; c < 3; c++) wc[c] = sum3f(we[0] * ci[c], we[1] * ci[3 + c], we[2] * ci[6 + c]);
+                        acc[28] += (double)sum3f(wc[0] * e[0], wc[1] * e[1], wc[2] * e[2]);
+                    }
+                }
+            }
+        }
+    }
+    __shared__ double red[NA][kNdtQuads];
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        double v = acc[a];
+        v += dpp_f64<0xB1>(v);
+        v += dpp_f64<0x4E>(v);
+        if ((threadIdx.x & 3) == 0) red[a][threadIdx.x >> 2] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NA) {
+        const double2* row = reinterpret_cast<const double2*>(&red[threadIdx.x][0]);
+        double sm = 0.0;
+#pragma unroll
+        for (int k = 0; k < kNdtQuads / 2; k++) {
+            const double2 v = row[k];
+            sm += v.x;
+            sm += v.y;
+        }
+        partial[(size_t)threadIdx.x * pstride + blockIdx.x] = sm;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_corr += __shfl_xor(my_corr, off);
+    if (threadIdx.x == 0 && my_corr) atomicAdd(&nd->n_corr, my_corr);
+}
+
 // ---- batched alignments: slot = one alignment (its own source scan and guess) against the ONE target, the Levenberg-Marquardt loop of
 // LsqRegistration (lsq.h) resident on the device.  A round = {cost kernel for the slots that linearise, cost kernel for the slots that try a
 // step, LM kernel}: every launch serves all slots (blockIdx.y), a slot that is done exits at once.  The map-merge / loop-closure /
@@ -582,7 +736,7 @@ __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict_
 // the size before the fold's loads can be issued; 0 = read it from the scan's device record
 __global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial, uint32_t pstride, int na, NdtDev* nd,
                                                           NdtReport* __restrict__ out, uint32_t nb_hint) {
-    __shared__ double acc[kNdtAcc];
+    __shared__ double acc[kNdtAcc + 1];
     const int tid = threadIdx.x;
     const uint32_t nb = nb_hint ? nb_hint : (sd->n_ds + kNdtThreads - 1) / kNdtThreads;
     ndt_fold(partial, pstride, nb, na, acc);
@@ -592,6 +746,7 @@ __global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restr
         if (na == 1) { if (tid == 0) out->acc[42] = acc[0]; }
         else if (tid < 36) out->acc[tid] = acc[ndt_tri(tid / 6, tid % 6)];
         else if (tid < kNdtOut) out->acc[tid] = acc[21 + (tid - 36)];
+        else if (tid == kNdtOut && na > kNdtAcc) out->err_trial = acc[kNdtAcc];
         if (tid == 63) out->n_corr = nd->n_corr;
         __threadfence_system();
     }
@@ -689,7 +844,9 @@ struct lio_ndt {
     lio_map* map;  // hash grid with the Gaussian-voxel key; owns the stream used for builds
     NdtVoxel* vox;
     NdtOffsets offs;
-    uint32_t* corr;  // [n_offsets][max_src]
+    uint32_t* corr;  // [n_offsets][max_src]: the pairs of the last linearisation
+    uint32_t* corr2; // the other buffer of the speculative evaluation (lio_ndt_align): the pairs at the trial pose, swapped in when the step is accepted
+    int spec;        // 1: lio_ndt_align evaluates a trial pose and the linearisation that follows an accepted step in one launch (LIO_NDT_SPEC=0: two)
     uint32_t max_src, pstride;
     double* partial;
     NdtDev* dev;
@@ -712,8 +869,8 @@ struct lio_ndt {
     int timing;
     hipEvent_t ev[2];
     double cost_us;
-    uint64_t cost_launches, cost_pairs, cost_points, upd_launches;
-    uint32_t last_corr;
+    uint64_t cost_launches, cost_pairs, cost_points, upd_launches, spec_launches;
+    uint32_t last_corr, spec_corr;
 };
 
 namespace {
@@ -803,6 +960,48 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
     return LIO_OK;
 }
 
+// the speculative evaluation at the trial pose x: trial cost on the cached pairs (n->corr), the pairs at x (into n->corr2) with their cost / H / b
+int ndt_eval_spec(lio_ndt* n, lio_scan* s, const double x[16], double* H, double* b, double* y_new, double* y_trial) {
+    const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
+    if (bound > n->max_src) { set_error("source scan of %u points exceeds the matcher's capacity %u", bound, n->max_src); return LIO_E_CAPACITY; }
+    uint32_t blocks = (bound + kNdtThreads - 1) / kNdtThreads;
+    if (blocks == 0) blocks = 1;
+    const NdtXform xx = to_xform(x);
+    hipStream_t st = s->stream;
+    LIO_HIP_TRY(hipMemsetAsync(&n->dev->n_corr, 0, 4, st));
+    if (n->timing) hipEventRecord(n->ev[0], st);
+#define NDT_SPEC(NO)                                                                                                                                    \
+    hipLaunchKernelGGL((ndt_cost_spec_kernel<NO>), blocks, kNdtThreads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xx, s->ds_body, \
+                       s->dev, n->corr, n->corr2, n->max_src, n->partial, n->pstride, n->dev)
+    if (n->offs.n == 1) NDT_SPEC(1);
+    else if (n->offs.n == 7) NDT_SPEC(7);
+    else NDT_SPEC(27);
+#undef NDT_SPEC
+    if (n->timing) hipEventRecord(n->ev[1], st);
+    hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, n->pstride, kNdtAcc + 1, n->dev, n->report_dev, s->have_ds > 0 ? blocks : 0u);
+    LIO_HIP_TRY(hipGetLastError());
+    n->seq_expected++;
+    const int rc = ndt_wait(n, st);
+    if (rc != LIO_OK) return rc;
+    for (int k = 0; k < 36; k++) H[k] = n->report->acc[k];
+    for (int k = 0; k < 6; k++) b[k] = n->report->acc[36 + k];
+    *y_new = n->report->acc[42];
+    *y_trial = n->report->err_trial;
+    n->spec_corr = n->report->n_corr;  // becomes last_corr when the step is accepted
+    if (n->timing) {
+        float ms = 0.f;
+        if (hipEventSynchronize(n->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, n->ev[0], n->ev[1]) == hipSuccess) {
+            n->cost_us += (double)ms * 1000.0;
+            n->cost_launches++;
+            n->cost_pairs += n->spec_corr;
+            n->cost_points += s->have_ds > 0 ? (uint64_t)s->have_ds : 0ull;
+            n->upd_launches++;
+            n->spec_launches++;
+        }
+    }
+    return LIO_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -822,9 +1021,11 @@ lio_ndt* lio_ndt_create(int device, float resolution, int search_method, uint64_
     n->pstride = (max_source_points + kNdtThreads - 1) / kNdtThreads;
     n->max_points = max_points;
     n->stamp_cap = max_points;
+    { const char* k = getenv("LIO_NDT_SPEC"); n->spec = (k && k[0] == '0') ? 0 : 1; }
     bool ok = hipMalloc(reinterpret_cast<void**>(&n->vox), (size_t)n->map->table_cap * sizeof(NdtVoxel)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->corr), (size_t)kNdtMaxOff * max_source_points * 4) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&n->partial), (size_t)((max_source_points + kNdtThreads - 1) / kNdtThreads) * kNdtAcc * 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->corr2), (size_t)n->offs.n * max_source_points * 4) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->partial), (size_t)((max_source_points + kNdtThreads - 1) / kNdtThreads) * (kNdtAcc + 1) * 8) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->dev), sizeof(NdtDev)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->stamp), (size_t)n->stamp_cap * sizeof(float4)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->list), (size_t)n->map->table_cap * 4) == hipSuccess &&
@@ -843,7 +1044,7 @@ void lio_ndt_destroy(lio_ndt* n) {
     if (!n) return;
     hipSetDevice(n->device);
     if (n->map) { hipStreamSynchronize(n->map->stream); lio_map_destroy(n->map); }
-    hipFree(n->vox); hipFree(n->corr); hipFree(n->partial); hipFree(n->dev); hipFree(n->stamp); hipFree(n->list); hipFree(n->list_cnt);
+    hipFree(n->vox); hipFree(n->corr); hipFree(n->corr2); hipFree(n->partial); hipFree(n->dev); hipFree(n->stamp); hipFree(n->list); hipFree(n->list_cnt);
     if (n->report) hipHostFree(n->report);
     if (n->d_slots) hipFree(n->d_slots);
     if (n->h_slots) hipHostFree(n->h_slots);
@@ -1017,7 +1218,13 @@ int lio_ndt_align(lio_ndt* n, lio_scan* s, const double guess[16], const lio_ndt
     // compute_error (on the cached pairs): lsq.h
     auto lin = [&](const double x[16], double H[36], double b[6], double* y) { return ndt_eval(n, s, x, x, true, true, H, b, y, nullptr); };
     auto err = [&](const double x_lin[16], const double x[16], double* y) { return ndt_eval(n, s, x_lin, x, false, false, nullptr, nullptr, y, nullptr); };
-    return lsq_align(p, guess, lin, err, out, iterations, converged);
+    if (!n->spec) return lsq_align(p, guess, lin, err, out, iterations, converged);
+    // one launch per LM trial: the trial's cost on the cached pairs AND the linearisation an accepted step continues from (ndt_cost_spec_kernel)
+    auto spec = [&](const double /*x_lin*/[16], const double xi[16], double H[36], double b[6], double* y_new, double* y_trial) {
+        return ndt_eval_spec(n, s, xi, H, b, y_new, y_trial);
+    };
+    auto commit = [&]() { std::swap(n->corr, n->corr2); n->last_corr = n->spec_corr; };  // the step was accepted: the pairs at xi are the cached ones now
+    return lsq_align_spec(p, guess, lin, spec, commit, out, iterations, converged);
 }
 
 // B alignments per launch against this target: see ndt_cost_batch / ndt_lm_step_batch.  Same LM schedule and stopping rules as lio_ndt_align

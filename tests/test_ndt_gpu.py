@@ -389,3 +389,45 @@ def test_batched_voxel_downsample_equals_the_single_scans(scene):
     assert np.array_equal(batch[0].get_ds().view(np.uint32), want0.view(np.uint32))
     counts = lio.Scan.voxel_downsample_batch([batch[0], empty], 0.5)
     assert counts == [len(want0), 0]
+
+
+def test_speculative_trial_evaluation_is_bit_identical(scene, monkeypatch):
+    """lio_ndt_align fetches a trial pose's cost (on the pairs cached at the linearisation point) and the linearisation an accepted step continues
+    from in ONE launch (ndt_cost_spec_kernel + lsq_align_spec); LIO_NDT_SPEC=0 keeps LsqRegistration's two evaluations per iteration.  Same
+    statements, same accumulation order: poses, convergence flags and iteration counts are the same BITS -- accepted steps, rejected trials (a
+    hopeless guess), one-offset and 27-offset neighbourhoods"""
+    from lsd_amd import capi, lio, synth
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    target = scene.sample_surface(1_500_000, seed=43, sigma=0.01)
+    target = np.ascontiguousarray(target[np.linalg.norm(target[:, :2], axis=1) < 80.0])
+    rng = np.random.default_rng(11)
+    cases = []
+    for k in range(10):
+        pos = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), 1.8])
+        q = synth.quat_from_rotvec([0, 0, rng.uniform(-np.pi, np.pi)])
+        raw, _ = synth.make_scan(scene, pos, q, seed=900 + k, n_az=400, fov_deg=(-24.8, 2.0))
+        gp, gq = synth.perturb_pose(pos, q, seed=950 + k, max_t=0.5, max_deg=3.0)
+        if k == 4:
+            gp = gp + [20.0, 15.0, 0.0]  # far off: rejected trials, lambda growing, gives up
+        G = np.eye(4)
+        G[:3, :3], G[:3, 3] = synth.quat_to_R(gq), gp
+        cases.append((raw, G))
+    for method in (7, 1, 27):
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("LIO_NDT_SPEC", flag)  # read by lio_ndt_create
+            ndt = lio.Ndt(resolution=1.0, search_method=method, max_points=len(target) + 1, max_voxels=400_000, max_source_points=1 << 16)
+            ndt.set_target(target)
+            sc = lio.Scan(max_raw=1 << 17, max_ds=1 << 16)
+            out = []
+            for raw, G in cases:
+                sc.upload(raw)
+                sc.voxel_downsample(0.3)
+                out.append(ndt.align(sc, G))
+            res[flag] = out
+            ndt.close()
+        for k, ((Ta, ca, ia), (Tb, cb, ib)) in enumerate(zip(res["1"], res["0"])):
+            assert (ca, ia) == (cb, ib) and np.array_equal(Ta, Tb), (method, k, ca, cb, ia, ib, np.abs(Ta - Tb).max())
+        assert sum(int(c) for _, c, _ in res["1"]) >= 8
