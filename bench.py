@@ -630,7 +630,7 @@ def main():
         import subprocess
 
         for key, extra in (("config3_stream_to_1e7_points", ["--config", "stream", "--grow-to", "10000000", "--steps", "6000", "--lru", "0"]),
-                           ("config3_stream_lru_1e5_300_sweeps", ["--config", "stream", "--steps", "300", "--lru", "100000", "--ref-scans", "0"]),
+                           ("config3_stream_lru_1e5_300_sweeps", ["--config", "stream", "--steps", "300", "--lru", "100000", "--ref-scans", "300"]),
                            ("config4_localize_5e7_map", ["--config", "localize", "--steps", "200", "--scan-pool", "32"]),
                            ("config5_merge_8_submaps_1_gpu", ["--config", "merge", "--steps", "256", "--warmup", "64", "--scan-pool", "64", "--min-seconds", "2"])):
             try:
@@ -901,6 +901,7 @@ def stream_run(args, torch, local_rank):
                 R.set_logging(False)
                 m_ref = min(args.ref_scans, k_done)
                 jj, t_ref, n_ref, pts_ref = 0, 0.0, 0, 0
+                t_full, n_full = 0.0, 0  # ... of those, the sweeps registered while the reference's iVox holds its full 100000 voxels (LRU evicting)
                 for k in range(m_ref):
                     p, st = get_sweep(k)
                     tb = k * 0.1
@@ -915,6 +916,9 @@ def stream_run(args, torch, local_rank):
                         t_ref += c1 - c0
                         n_ref += 1
                         pts_ref += len(p)
+                        if R.map_voxels() >= 100000:
+                            t_full += c1 - c0
+                            n_full += 1
                 gpu_same = float(np.mean((np.array(t_main) + np.array(t_enq))[: max(n_ref, 1)]))
                 ref_err = None
                 if tr is not None and m_ref > 0:
@@ -922,8 +926,11 @@ def stream_run(args, torch, local_rank):
                 cpu = dict(value=round(pts_ref / t_ref, 1), unit="points/s", cores=min(8, usable_cpus()), host_cpus=usable_cpus(), kind="reference",
                            sample=f"sweeps 20..{m_ref - 1} of the same drive through the reference's own fastlio_imu_enqueue / fastlio_pcl_enqueue / fastlio_main "
                                   f"(IMU propagation, undistortion, VoxelGrid [the oracle's restatement], iVox kNN on MP_PROC_NUM=8 threads, esekfom update, "
-                                  f"map_incremental with its 100000-voxel LRU), {t_ref:.1f} s; the map is still small there",
+                                  f"map_incremental with its 100000-voxel LRU), {t_ref:.1f} s; its map is capped at 100000 voxels by its LRU "
+                                  f"(sweeps_with_the_reference_map_at_capacity says for how many of these sweeps it was full)",
                            ms_per_scan=round(1e3 * t_ref / max(n_ref, 1), 3), gpu_ms_per_scan_same_sweeps=round(1e3 * gpu_same, 4),
+                           sweeps_with_the_reference_map_at_capacity=n_full, ms_per_scan_at_capacity=(round(1e3 * t_full / n_full, 3) if n_full else None),
+                           reference_map_voxels_end=int(R.map_voxels()),
                            pose_error_vs_truth_m=ref_err, at_sweep=m_ref)
         except Exception as ex:
             cpu = {"error": repr(ex)[-300:]}

@@ -503,7 +503,9 @@ typedef struct lio_ndt_params {
 } lio_ndt_params;
 void lio_ndt_default_params(lio_ndt_params*);
 /* pcl::Registration::align(guess) -> LsqRegistration::computeTransformation with step_lm
- * (lsq_registration_impl.hpp:71-109,163-208); out = final transformation, *converged = hasConverged() */
+ * (lsq_registration_impl.hpp:71-109,163-208); out = final transformation, *converged = hasConverged().  step_lm's compute_error(xi) and the
+ * linearize(xi) that follows an accepted step are fetched in one launch (see lio_ndt_align_batch): identical results, one device hand-over per
+ * LM iteration instead of two. */
 int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_ndt_params* params, double out[16], int* iterations,
                   int* converged);
 
@@ -511,8 +513,11 @@ int lio_ndt_align(lio_ndt*, lio_scan* source, const double guess[16], const lio_
  * overlap_merge.hpp:158-179: 64 key frames x <= 3 candidates, every one an independent registration->align) -- here B of them per launch against
  * one or several targets: slot = (target, source scan, guess), the Levenberg-Marquardt loop of LsqRegistration (lsq_registration_impl.hpp:71-208) resident on the
  * device, a round = {cost evaluation of the slots that linearise, of the slots that try a step, LM kernel}, every launch serving all slots; the
- * host looks at the slots' states every six rounds.  Same schedule, stopping rules and results as lio_ndt_align job by job (to the rounding of
- * the device's libm); max_process_time_ms does not apply.  Sources: lio_scan objects holding their downsampled clouds (lio_scan_voxel_downsample /
+ * host looks at the slots' states every six rounds.  A trial evaluation is speculative (round 4): one launch computes the trial's cost on the
+ * pairs cached at the linearisation point AND the linearisation at the trial pose, which an accepted step continues from -- one round per LM
+ * iteration instead of two, the same numbers (lio_ndt_align does the same, LIO_NDT_SPEC=0 turns it off there).  Same schedule, stopping rules
+ * and results as lio_ndt_align job by job (to the rounding of the device's libm); max_process_time_ms does not apply.  `evaluations` counts
+ * launches that served the job (1 + the LM trials).  Sources: lio_scan objects holding their downsampled clouds (lio_scan_voxel_downsample /
  * lio_scan_set_ds), at most max_source_points each. */
 typedef struct lio_align_job {
     lio_ndt* target;         /* NULL: the matcher the call is made on; else another target of the same resolution / search method / device

@@ -194,8 +194,7 @@ struct lio_scan {
     uint8_t* selected;
     float4* normvec;
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b;
-    uint32_t* hist;      // radix histograms [nblocks][256], four sections (one per pass) hist_stride words apart
-    uint32_t hist_stride;
+    uint32_t* hist;      // radix histograms [nblocks][256]
     uint32_t* blockcnt;  // head counts per tile
     uint32_t* hpos;      // first sorted position of every occupied voxel
     uint32_t* longlist;  // voxels with long runs

@@ -457,11 +457,10 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_kernel(const Slot* __res
 // kernel, one report and one host hand-over per LM iteration instead of two; a rejected step discards it (the pairs of x0 were not touched).  Same
 // statements, same per-lane accumulation order, same reduction as the two separate kernels: the results are the same bits.
 template <int NO>
-__global__ void __launch_bounds__(kNdtThreads) ndt_cost_spec_kernel(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox, float res,
-                                                                    NdtOffsets offs, NdtXform x, const float4* __restrict__ src, const ScanDev* __restrict__ sd,
-                                                                    const uint32_t* __restrict__ corr_old, uint32_t* __restrict__ corr_new, uint32_t corr_stride,
-                                                                    double* __restrict__ partial, uint32_t pstride, NdtDev* nd) {
-    const uint32_t n = sd->n_ds;
+__device__ __forceinline__ void ndt_spec_body(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox, float res,
+                                              const NdtOffsets& offs, const NdtXform& x, const float4* __restrict__ src, uint32_t n,
+                                              const uint32_t* __restrict__ corr_old, uint32_t* __restrict__ corr_new, uint32_t corr_stride,
+                                              double* __restrict__ partial, uint32_t pstride, uint32_t* n_corr_counter) {
     if (blockIdx.x * kNdtThreads >= n) return;
     const uint32_t i = blockIdx.x * kNdtThreads + threadIdx.x;
     constexpr int NA = kNdtAcc + 1;
@@ -599,7 +598,15 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_spec_kernel(const Slot* 
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) my_corr += __shfl_xor(my_corr, off);
-    if (threadIdx.x == 0 && my_corr) atomicAdd(&nd->n_corr, my_corr);
+    if (threadIdx.x == 0 && my_corr) atomicAdd(n_corr_counter, my_corr);
+}
+
+template <int NO>
+__global__ void __launch_bounds__(kNdtThreads) ndt_cost_spec_kernel(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox, float res,
+                                                                    NdtOffsets offs, NdtXform x, const float4* __restrict__ src, const ScanDev* __restrict__ sd,
+                                                                    const uint32_t* __restrict__ corr_old, uint32_t* __restrict__ corr_new, uint32_t corr_stride,
+                                                                    double* __restrict__ partial, uint32_t pstride, NdtDev* nd) {
+    ndt_spec_body<NO>(table, mask, vox, res, offs, x, src, sd->n_ds, corr_old, corr_new, corr_stride, partial, pstride, &nd->n_corr);
 }
 
 // ---- batched alignments: slot = one alignment (its own source scan and guess) against the ONE target, the Levenberg-Marquardt loop of
@@ -612,12 +619,13 @@ struct NdtLmSlot {
     uint32_t mask, pad1;
     const float4* src;
     const ScanDev* sd;
-    uint32_t* corr;
+    uint32_t* corr;        // the pairs cached at x0
+    uint32_t* corr2;       // the pairs at the trial pose (speculative evaluation): swapped with `corr` when the step is accepted
     double* partial;
     uint32_t corr_stride, active, pstride, pad0;
     double x0[16], xi[16], delta[16], H[36], b[6], d[6];
     double y0, lambda, nu;
-    int32_t phase;  // 0: linearise at x0 (correspondences + cost + H + b); 1: cost of the trial xi on the cached pairs; 2: done
+    int32_t phase;  // 0: linearise at x0 (correspondences + cost + H + b); 1: the trial xi -- its cost on the cached pairs AND the linearisation at xi; 2: done
     int32_t it, trial, conv, evals, it_done;
     uint32_t n_corr, pad;
 };
@@ -644,8 +652,9 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_batch(float res, NdtOffs
         const NdtXform x = xform_of(s.x0);
         ndt_cost_body<true, true, NO>(table, mask, vox, res, offs, x, x, s.src, n, s.corr, s.corr_stride, s.partial, s.pstride, &s.n_corr);
     } else {
-        const NdtXform xl = xform_of(s.x0), x = xform_of(s.xi);
-        ndt_cost_body<false, false, NO>(table, mask, vox, res, offs, xl, x, s.src, n, s.corr, s.corr_stride, s.partial, s.pstride, &s.n_corr);
+        // the trial pose: speculative evaluation (ndt_cost_spec_kernel's body) -- cost on the pairs of x0, pairs + cost + H + b at xi into the other buffer
+        const NdtXform x = xform_of(s.xi);
+        ndt_spec_body<NO>(table, mask, vox, res, offs, x, s.src, n, s.corr, s.corr2, s.corr_stride, s.partial, s.pstride, &s.n_corr);
     }
 }
 
@@ -667,21 +676,58 @@ __device__ __forceinline__ void ndt_fold(const double* __restrict__ partial, uin
 __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict__ slots, NdtLmParams P) {
     NdtLmSlot& s = slots[blockIdx.x];
     if (!s.active || s.phase == 2) return;
-    __shared__ double acc[kNdtAcc];
+    __shared__ double acc[kNdtAcc + 1];
     const int tid = threadIdx.x;
     const uint32_t nb = (s.sd->n_ds + kNdtThreads - 1) / kNdtThreads;
-    const int na = s.phase == 0 ? kNdtAcc : 1;
+    const int na = s.phase == 0 ? kNdtAcc : kNdtAcc + 1;
     ndt_fold(s.partial, s.pstride, nb, na, acc);
     if (tid != 0) return;
     lio_ndt_params p;
     p.max_iterations = P.max_iterations; p.lm_max_iterations = P.lm_max_iterations; p.rotation_epsilon_deg = P.rotation_epsilon_deg;
     p.transformation_epsilon = P.transformation_epsilon; p.lm_init_lambda_factor = P.lm_init_lambda_factor; p.max_process_time_ms = -1;
     s.evals++;
-    bool make_trial = false, end_iteration = false;
+    // lsq_align_spec (lsq.h) as a state machine: phase 0 delivers the linearisation at x0, phase 1 the trial xi -- its cost on x0's pairs (acc[28]) and
+    // the linearisation at xi (acc[0..27], pairs in corr2) that an accepted step continues from without another launch
+    bool begin_iteration = false, make_trial = false, end_iteration = false;
     if (s.phase == 0) {  // the linearisation at x0 (LsqRegistration::computeTransformation, loop head)
         for (int k = 0; k < 36; k++) s.H[k] = acc[ndt_tri(k / 6, k % 6)];
         for (int k = 0; k < 6; k++) s.b[k] = acc[21 + k];
         s.y0 = acc[27];
+        begin_iteration = true;
+    } else {  // the trial step (step_lm)
+        const double yi = acc[kNdtAcc];
+        double den = 0;
+        for (int k = 0; k < 6; k++) den += s.d[k] * (s.lambda * s.d[k] - s.b[k]);
+        const double rho = (s.y0 - yi) / den;
+        if (rho < 0) {
+            if (converged_h(p, s.delta, 10.0)) {
+                // the iteration ends without a step: x0 and its pairs stand, and so does their linearisation (H, b, y0 are functions of x0 alone:
+                // the reference computes them again, to the same bits)
+                end_iteration = true;
+            } else {
+                s.lambda = s.nu * s.lambda;
+                s.nu = 2 * s.nu;
+                s.trial++;
+                if (s.trial >= p.lm_max_iterations) { s.phase = 2; s.conv = 0; }  // "lm not converged!!"
+                else make_trial = true;
+            }
+        } else {  // accepted: xi becomes x0, its pairs the cached ones, its linearisation the next iteration's
+            for (int k = 0; k < 16; k++) s.x0[k] = s.xi[k];
+            s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+            uint32_t* t = s.corr; s.corr = s.corr2; s.corr2 = t;
+            for (int k = 0; k < 36; k++) s.H[k] = acc[ndt_tri(k / 6, k % 6)];
+            for (int k = 0; k < 6; k++) s.b[k] = acc[21 + k];
+            s.y0 = acc[27];
+            end_iteration = true;
+        }
+    }
+    if (end_iteration) {
+        s.conv = converged_h(p, s.delta, 1.0) ? 1 : 0;
+        s.it++;
+        if (s.conv || s.it >= p.max_iterations) s.phase = 2;
+        else begin_iteration = true;
+    }
+    if (begin_iteration) {
         s.it_done = s.it;
         if (s.lambda < 0.0) {
             double mx = 0;
@@ -692,26 +738,6 @@ __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict_
         s.trial = 0;
         if (p.lm_max_iterations > 0) make_trial = true;
         else { s.phase = 2; s.conv = 0; }  // step_lm's loop does not run: "lm not converged!!", the iteration's x0 stands (lsq_align)
-    } else {  // the cost of the trial step (step_lm)
-        const double yi = acc[0];
-        double den = 0;
-        for (int k = 0; k < 6; k++) den += s.d[k] * (s.lambda * s.d[k] - s.b[k]);
-        const double rho = (s.y0 - yi) / den;
-        if (rho < 0) {
-            if (converged_h(p, s.delta, 10.0)) {
-                end_iteration = true;
-            } else {
-                s.lambda = s.nu * s.lambda;
-                s.nu = 2 * s.nu;
-                s.trial++;
-                if (s.trial >= p.lm_max_iterations) { s.phase = 2; s.conv = 0; }  // "lm not converged!!"
-                else make_trial = true;
-            }
-        } else {
-            for (int k = 0; k < 16; k++) s.x0[k] = s.xi[k];
-            s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
-            end_iteration = true;
-        }
     }
     if (make_trial) {
         double A[36], nb6[6];
@@ -722,13 +748,8 @@ __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict_
             se3_exp_h(s.d, s.delta);
             mul44_h(s.delta, s.x0, s.xi);
             s.phase = 1;
+            s.n_corr = 0;  // the trial's pairs are counted afresh
         }
-    }
-    if (end_iteration) {
-        s.conv = converged_h(p, s.delta, 1.0) ? 1 : 0;
-        s.it++;
-        s.phase = (s.conv || s.it >= p.max_iterations) ? 2 : 0;
-        if (s.phase == 0) s.n_corr = 0;  // the next linearisation counts its correspondences afresh
     }
 }
 
@@ -1245,15 +1266,15 @@ int lio_ndt_align_batch(lio_ndt* n, lio_align_job* jobs, int n_jobs, const lio_n
         }
         return LIO_OK;
     }
-    const size_t corr_per = (size_t)n->offs.n * n->max_src, part_per = (size_t)((n->max_src + kNdtThreads - 1) / kNdtThreads) * kNdtAcc;
+    const size_t corr_per = (size_t)n->offs.n * n->max_src, part_per = (size_t)((n->max_src + kNdtThreads - 1) / kNdtThreads) * (kNdtAcc + 1);
     if (!n->d_slots) {
-        // the slots' scratch is offsets x max_source_points x 4 B of correspondences each (7.3 MB at DIRECT7 / 262 144 points, 28 MB at DIRECT27): 64 slots
+        // the slots' scratch is 2 x offsets x max_source_points x 4 B of correspondences each (15 MB at DIRECT7 / 262 144 points, 57 MB at DIRECT27): 64 slots
         // when that fits, fewer when the device is short of memory (the jobs then go through in more, smaller launches -- same results)
         int slots = 64;
         for (; slots >= 1; slots /= 2) {
             const bool ok = hipMalloc(reinterpret_cast<void**>(&n->d_slots), sizeof(NdtLmSlot) * slots) == hipSuccess &&
                             hipHostMalloc(reinterpret_cast<void**>(&n->h_slots), sizeof(NdtLmSlot) * slots, hipHostMallocDefault) == hipSuccess &&
-                            hipMalloc(reinterpret_cast<void**>(&n->b_corr), corr_per * 4 * slots) == hipSuccess &&
+                            hipMalloc(reinterpret_cast<void**>(&n->b_corr), corr_per * 4 * 2 * slots) == hipSuccess &&  /* two pair buffers per slot */
                             hipMalloc(reinterpret_cast<void**>(&n->b_partial), part_per * 8 * slots) == hipSuccess;
             if (ok) break;
             (void)hipGetLastError();
@@ -1263,7 +1284,7 @@ int lio_ndt_align_batch(lio_ndt* n, lio_align_job* jobs, int n_jobs, const lio_n
             if (n->b_partial) hipFree(n->b_partial);
             n->d_slots = nullptr; n->h_slots = nullptr; n->b_corr = nullptr; n->b_partial = nullptr;
         }
-        if (slots < 1) { set_error("lio_ndt_align_batch: no room for a single slot's scratch (%zu bytes)", corr_per * 4 + part_per * 8); return LIO_E_DEVICE; }
+        if (slots < 1) { set_error("lio_ndt_align_batch: no room for a single slot's scratch (%zu bytes)", corr_per * 8 + part_per * 8); return LIO_E_DEVICE; }
         n->b_slots = slots;
     }
     const int kSlots = n->b_slots;
@@ -1292,7 +1313,8 @@ int lio_ndt_align_batch(lio_ndt* n, lio_align_job* jobs, int n_jobs, const lio_n
             if (bound > n->max_src) { set_error("source scan of %u points exceeds the matcher's capacity %u", bound, n->max_src); j.rc = LIO_E_CAPACITY; continue; }
             s.src = j.source->ds_body;
             s.sd = j.source->dev;
-            s.corr = n->b_corr + corr_per * k;
+            s.corr = n->b_corr + corr_per * 2 * k;
+            s.corr2 = s.corr + corr_per;
             s.partial = n->b_partial + part_per * k;
             s.corr_stride = n->max_src;
             s.pstride = n->pstride;

@@ -125,13 +125,7 @@ __device__ inline VgGrid vg_derive(const uint32_t bmin[3], const uint32_t bmax[3
 // no histogram launch of its own (the later passes histogram the re-ordered keys)
 __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
-                                                           uint32_t nblocks, const uint32_t* __restrict__ parts, uint32_t hist_stride) {
-    // hist_stride != 0 (one scan at a time): the histograms of passes 1..3 are built by the scatter of the pass before them (atomics into their own
-    // sections of `hist`, hist_stride words apart); this tile clears its rows of those sections
-    if (hist_stride) {
-#pragma unroll
-        for (uint32_t sct = 1; sct < 4; sct++) hist[(size_t)sct * hist_stride + blockIdx.x * 256u + threadIdx.x] = 0u;
-    }
+                                                           uint32_t nblocks, const uint32_t* __restrict__ parts) {
     // the cloud's points first (they do not depend on the box), then the fold of the tiles' box records: every workgroup forms the same box
     const uint32_t base = blockIdx.x * kTile;
     float4 p[kItems];
@@ -236,16 +230,13 @@ __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
     return peers;
 }
 
-// FUSE: this pass also builds the NEXT pass's per-tile histogram -- one atomic per key into the row of the tile the key lands in -- so that a scan
-// registered alone needs no histogram launch between its scatters (two launches of ~5 us + their boundaries per scan; with 64 scans per launch the
-// 7.7 M atomics per pass would cost what the histogram kernel does: the batched chain keeps it)
-template <bool FUSE>
+// (Measured in round 4 and not kept: this pass also building the NEXT pass's per-tile histogram -- one global atomic per key into the row of the
+// tile the key lands in -- so that a scan registered alone would need no histogram launch between its scatters: 120 000 scattered atomics cost
+// 17 us per pass, 8.5 -> 25.3 us for this kernel, against the 4.8 + 1.5 us of the launch they replace.)
 __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
-                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd,
-                                                                 uint32_t* __restrict__ hist_next) {
+                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
     if ((uint32_t)pass >= active_passes(sd)) return;
-    const bool feed_next = FUSE && (uint32_t)(pass + 1) < active_passes(sd);
     const uint32_t* kin = (pass & 1) ? kb : ka;
     const uint32_t* vin = (pass & 1) ? vb : va;
     uint32_t* kout = (pass & 1) ? ka : kb;
@@ -339,10 +330,7 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
         __builtin_amdgcn_wave_barrier();
         if (ok[r] && below[r] == 0) wcnt[wave][d] += total[r];
         __builtin_amdgcn_wave_barrier();
-        if (ok[r]) {
-            kout[pos] = k[r]; vout[pos] = v[r];
-            if (FUSE && feed_next) atomicAdd(&hist_next[(size_t)(pos / (uint32_t)kTile) * 256u + ((k[r] >> (shift + 8)) & 255u)], 1u);
-        }
+        if (ok[r]) { kout[pos] = k[r]; vout[pos] = v[r]; }
     }
 }
 
@@ -592,13 +580,13 @@ __global__ void __launch_bounds__(kThreads) vg_bbox_batch(const SlotDesc* __rest
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
-                                                           uint32_t nblocks, const uint32_t* __restrict__ parts, uint32_t hist_stride) {
-    vg_keys_body(in, n, inv, sd, keys, vals, hist, nblocks, parts, hist_stride);
+                                                           uint32_t nblocks, const uint32_t* __restrict__ parts) {
+    vg_keys_body(in, n, inv, sd, keys, vals, hist, nblocks, parts);
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_batch(const SlotDesc* __restrict__ slots, float inv) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || blockIdx.x >= d.nblocks) return;
-    vg_keys_body(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, reinterpret_cast<const uint32_t*>(d.sorted), 0u);
+    vg_keys_body(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, reinterpret_cast<const uint32_t*>(d.sorted));
 }
 __global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                               int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
@@ -611,13 +599,13 @@ __global__ void __launch_bounds__(kThreads) radix_hist_batch(const SlotDesc* __r
 }
 __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
-                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd, uint32_t* __restrict__ hist_next) {
-    radix_scatter_body<true>(ka, va, kb, vb, n, pass, hist, nblocks, sd, hist_next);
+                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
+    radix_scatter_body(ka, va, kb, vb, n, pass, hist, nblocks, sd);
 }
 __global__ void __launch_bounds__(kThreads) radix_scatter_batch(const SlotDesc* __restrict__ slots, int pass) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || blockIdx.x >= d.nblocks) return;
-    radix_scatter_body<false>(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd, nullptr);
+    radix_scatter_body(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd);
 }
 __global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                                   const ScanDev* sd, uint32_t* __restrict__ blockcnt) {
@@ -685,13 +673,12 @@ int vg_downsample(lio_scan* s, float leaf, int passes) {
     }
     uint32_t* parts = reinterpret_cast<uint32_t*>(s->sorted);
     hipLaunchKernelGGL(vg_bbox_kernel, nblocks, kThreads, 0, st, s->raw, n, parts);
-    // the four passes' histograms live in four sections of `hist` (lio_scan_create sizes it for them): pass 0's is built by vg_keys, pass p + 1's by the
-    // scatter of pass p
-    const uint32_t hstride = s->hist_stride;
-    hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a, s->hist, nblocks, parts, hstride);
-    for (int pass = 0; pass < passes; pass++)  // kernels of a pass the bounding box does not need return at once
-        hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, s->keys_a, s->vals_a, s->keys_b, s->vals_b, n, pass,
-                           s->hist + (size_t)pass * hstride, nblocks, s->dev, s->hist + (size_t)(pass + 1 < 4 ? pass + 1 : 3) * hstride);
+    hipLaunchKernelGGL(vg_keys_kernel, nblocks, kThreads, 0, st, s->raw, n, inv, s->dev, s->keys_a, s->vals_a, s->hist, nblocks, parts);
+    for (int pass = 0; pass < passes; pass++) {  // kernels of a pass the bounding box does not need return at once
+        if (pass > 0) hipLaunchKernelGGL(radix_hist_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, pass, s->hist, nblocks, s->dev);
+        hipLaunchKernelGGL(radix_scatter_kernel, nblocks, kThreads, 0, st, s->keys_a, s->vals_a, s->keys_b, s->vals_b, n, pass, s->hist, nblocks,
+                           s->dev);
+    }
     hipLaunchKernelGGL(vg_count_heads_kernel, nblocks, kThreads, 0, st, s->keys_a, s->keys_b, n, s->dev, s->blockcnt);
     hipLaunchKernelGGL(vg_heads_kernel, nblocks, kThreads, 0, st, s->raw, s->keys_a, s->keys_b, s->vals_a, s->vals_b, n, s->dev, s->blockcnt,
                        s->hpos, s->sorted, s->ds_body, s->max_ds, s->host_nds_dev, (uint32_t)passes);
