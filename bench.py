@@ -341,25 +341,30 @@ def main():
         us = leg["us"]
         ach = leg["bytes"] / (us * 1e-6) / 1e9 if us > 0 else 0.0
         traffic, valu_per_wave, valu_src = None, KNN_VALU_PER_WAVE_STATIC, "static ISA count (llvm-objdump of knn.o, loop body at the average trip counts)"
+        valu_per_launch = None
         tpath = os.path.join(ROOT, "profiles", traffic_file)
         if os.path.exists(tpath):  # HBM bytes per launch + VALU instructions per wave from the PMC passes (tools/pmc_traffic.py, its own rocprofv3 --pmc runs)
             try:
                 tj = json.load(open(tpath))
                 if tj.get("slots_per_launch", args.slots) == args.slots and tj.get("scan_pool", args.scan_pool) == args.scan_pool:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    if tj.get("valu_insts_per_wave"):
-                        valu_per_wave, valu_src = float(tj["valu_insts_per_wave"]), "PMC: SQ_INSTS_VALU / SQ_WAVES of the same launches (%s)" % traffic_file
+                    if tj.get("valu_wave_instructions_per_launch"):
+                        valu_per_launch = float(tj["valu_wave_instructions_per_launch"])
+                        valu_src = "PMC: SQ_INSTS_VALU per launch of this kernel on the same workload (profiles/%s, its own rocprofv3 --pmc pass)" % traffic_file
             except Exception:
                 traffic = None
-        waves = leg["queries_per_launch"] / 4.0  # sixteen lanes per query: four queries per wave
-        issue_us = waves * valu_per_wave / (N_SIMD * CLOCK_GHZ * 1e3 / 4.0)  # a SIMD issues one wave64 VALU instruction per four cycles
+        waves = leg["queries_per_launch"] / 4.0  # sixteen lanes per query: four queries per wave-pass (a launched wave takes several in turn)
+        if valu_per_launch is None:
+            valu_per_launch = waves * valu_per_wave
+        issue_us = valu_per_launch / (N_SIMD * CLOCK_GHZ * 1e3 / 4.0)  # a SIMD issues one wave64 VALU instruction per four cycles
         measured = valu_src.startswith("PMC")
         return dict(bound="valu", kernel="knn_batch_kernel<2, false> (16 lanes per query, %d scans per launch)" % args.slots,
                     achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                     touched_bytes_per_launch=int(leg["touched_bytes"]),
                     frac_touched=round(leg["touched_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
                     frac_hbm_traffic=(round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic and us > 0 else None),
-                    valu={"wave_instructions_per_wave": round(valu_per_wave, 1), "source": valu_src, "waves_per_launch": round(waves, 1),
+                    valu={"wave_instructions_per_launch": round(valu_per_launch, 0), "per_four_queries": round(valu_per_launch / max(waves, 1.0), 1),
+                          "source": valu_src, "four_query_units_per_launch": round(waves, 1),
                           "issue_bound_us": round(issue_us, 2),
                           # (the static count is the metric map's: ~300 candidates per query; a sparser map sweeps fewer voxels per query, so without a
                           # PMC count of THIS workload the figure is an upper bound and no fraction is formed from it)
