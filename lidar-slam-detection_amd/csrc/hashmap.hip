@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint
         const unsigned long long key = pack_key(kx, ky, kz);
         BrickProbe bp = brick_probe(kx, ky, kz);
         uint32_t found = kNoIdx;
+        bool made = false;
         for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
             const uint32_t h = brick_slot(bp, mask);
             unsigned long long k = *reinterpret_cast<volatile unsigned long long*>(&table[h].key);
@@ -50,13 +51,22 @@ __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint
                 k = atomicCAS(&table[h].key, kEmptyKey, key);
                 if (k == kEmptyKey) {  // this thread created the voxel
                     created[h] = travel;
-                    const uint32_t nv = atomicAdd(&md->n_voxels, 1u) + 1u;
-                    if (nv > max_voxels) atomicOr(&md->err, 4u);
+                    made = true;
                     k = key;
                 }
             }
             if (k == key) { found = h; break; }
             brick_next(bp);
+        }
+        {   // the voxel count: one atomic per wave for the voxels its lanes created (one each serialised a few hundred same-address atomics per scan)
+            const unsigned long long mm = __ballot(made);
+            if (mm) {
+                const int lane = threadIdx.x & 63, leader = __ffsll((long long)mm) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&md->n_voxels, (uint32_t)__popcll(mm));
+                base = __shfl(base, leader);
+                if (made && base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)) + 1u > max_voxels) atomicOr(&md->err, 4u);
+            }
         }
         if (found == kNoIdx) {
             atomicOr(&md->err, 1u);
@@ -79,14 +89,18 @@ __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint3
                                                               const uint32_t* __restrict__ slot_of_point, const uint32_t* __restrict__ free_items,
                                                               uint32_t free_cap, uint32_t* __restrict__ free_in) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
-    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
-         i += (unsigned long long)gridDim.x * blockDim.x) {
+    // the map's point count: one atomic per wave (the leaders' additions summed by shuffles first) -- one per touched voxel serialised ~1 000 same-address
+    // atomics per scan at ~12 ns each, most of this kernel's 14 us (round 4)
+    unsigned long long added = 0;
+    for (unsigned long long i0 = blockIdx.x * (unsigned long long)blockDim.x; i0 < n; i0 += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long i = i0 + threadIdx.x;
+        if (i >= n) continue;
         const uint32_t sp = slot_of_point[i];
         if (sp == kNoIdx || !(sp & 0x80000000u)) continue;
         const uint32_t h = sp & 0x7FFFFFFFu;
         const uint32_t have = table[h].cnt, add = pending[h], need = have + add;
         pending[h] = 0;
-        atomicAdd(&md->n_points, (unsigned long long)add);
+        added += add;
         if (need <= cap[h]) continue;
         uint32_t ncap = 8;  // leave room: the voxel is on the sensor's path and will be appended to again
         while (ncap < need) ncap <<= 1;
@@ -124,6 +138,9 @@ __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint3
             else atomicSub(&md->free_in_top[oc], 1);
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) added += __shfl_xor(added, off);
+    if ((threadIdx.x & 63) == 0 && added) atomicAdd(&md->n_points, added);
 }
 
 // prebuilt-map layout: exclusive scan of the per-slot point counts in table order (three launches)
@@ -309,15 +326,23 @@ __global__ void __launch_bounds__(256) lru_evict_kernel(Slot* table, uint32_t* _
                                                         unsigned long long n_host, const uint32_t* __restrict__ n_dev, uint32_t capacity,
                                                         float travel, float max_distance, MapDev* md, const uint32_t* __restrict__ free_in) {
     const unsigned long long n_add = n_dev ? (unsigned long long)*n_dev : n_host;
-    // regions the grow kernel of this batch freed (voxels that moved to a larger one): fold them into the free lists it pops from
+    // regions the grow kernel of this batch freed (voxels that moved to a larger one): fold them into the free lists it pops from.  The 21 size
+    // classes' counters are read in one go (they used to be read class by class between two barriers: 21 dependent round trips, ~10 us of this
+    // kernel's 16), the classes that received something -- usually two or three -- are then copied in turn
+    __shared__ int fin_s[24], ftop_s[24];
+    if (threadIdx.x < 24) {
+        fin_s[threadIdx.x] = threadIdx.x >= 3 ? md->free_in_top[threadIdx.x] : 0;
+        ftop_s[threadIdx.x] = threadIdx.x >= 3 ? md->free_top[threadIdx.x] : 0;
+    }
+    __syncthreads();
     for (int c = 3; c < 24; c++) {
-        const int n_in = md->free_in_top[c], top = md->free_top[c];
+        const int n_in = fin_s[c], top = ftop_s[c];
+        if (n_in == 0) continue;  // (uniform: every thread reads the same shared words)
         const int room = (int)free_cap - top, take = n_in < room ? n_in : room;
         for (int j = threadIdx.x; j < take; j += 256) free_items[(size_t)c * free_cap + (uint32_t)(top + j)] = free_in[(size_t)c * free_cap + (uint32_t)j];
-        __syncthreads();
-        if (threadIdx.x == 0 && n_in) { md->free_top[c] = top + (take > 0 ? take : 0); md->free_in_top[c] = 0; }
-        __syncthreads();
+        if (threadIdx.x == 0) { md->free_top[c] = top + (take > 0 ? take : 0); md->free_in_top[c] = 0; }
     }
+    __syncthreads();
     __shared__ uint32_t wsum[4];
     __shared__ unsigned long long first_young_s, tail_s;
     __shared__ uint32_t want_s, pts_s;

@@ -34,6 +34,53 @@ __device__ inline uint32_t f2ord(float f) {
 }
 __device__ inline float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); }
 
+// the batched chain's form (64 scans per launch: the grid is full either way): 48 workgroups per scan striding over the cloud, one set of
+// ordered-uint atomics per workgroup into the scan's device record, which vg_keys reads.  (The per-tile records below cost the batched vg_keys
+// 20 -> 35 us per round: 3 776 workgroups folding 59 records each; the atomics' serialisation is hidden there by the other scans' work.)
+__device__ __forceinline__ void vg_bbox_atomic_body(const float4* __restrict__ in, uint32_t n, ScanDev* sd) {
+    float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
+    uint32_t cnt = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = in[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            mn0 = fminf(mn0, p.x); mx0 = fmaxf(mx0, p.x);
+            mn1 = fminf(mn1, p.y); mx1 = fmaxf(mx1, p.y);
+            mn2 = fminf(mn2, p.z); mx2 = fmaxf(mx2, p.z);
+            cnt++;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn0 = fminf(mn0, __shfl_xor(mn0, off)); mx0 = fmaxf(mx0, __shfl_xor(mx0, off));
+        mn1 = fminf(mn1, __shfl_xor(mn1, off)); mx1 = fmaxf(mx1, __shfl_xor(mx1, off));
+        mn2 = fminf(mn2, __shfl_xor(mn2, off)); mx2 = fmaxf(mx2, __shfl_xor(mx2, off));
+        cnt += __shfl_xor(cnt, off);
+    }
+    // one set of atomics per workgroup: the seven words share one L2 line, every atomic on it serialises
+    __shared__ float red[kWaves][6];
+    __shared__ uint32_t redc[kWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave][0] = mn0; red[wave][1] = mn1; red[wave][2] = mn2;
+        red[wave][3] = mx0; red[wave][4] = mx1; red[wave][5] = mx2;
+        redc[wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWaves; w++) {
+            mn0 = fminf(mn0, red[w][0]); mn1 = fminf(mn1, red[w][1]); mn2 = fminf(mn2, red[w][2]);
+            mx0 = fmaxf(mx0, red[w][3]); mx1 = fmaxf(mx1, red[w][4]); mx2 = fmaxf(mx2, red[w][5]);
+            cnt += redc[w];
+        }
+        if (cnt > 0) {
+            atomicMin(&sd->bbox_min[0], f2ord(mn0)); atomicMax(&sd->bbox_max[0], f2ord(mx0));
+            atomicMin(&sd->bbox_min[1], f2ord(mn1)); atomicMax(&sd->bbox_max[1], f2ord(mx1));
+            atomicMin(&sd->bbox_min[2], f2ord(mn2)); atomicMax(&sd->bbox_max[2], f2ord(mx2));
+            atomicAdd(&sd->n_valid, cnt);
+        }
+    }
+}
+
 // bounding box of the finite points, stage 1: one workgroup per sort tile (eight independent 16-byte loads per thread in flight), its box and
 // count stored as ONE 32-byte record {min x, y, z, max x, y, z (order-preserving uint codes), finite points, -}.  vg_keys folds the <= 128 records
 // itself.  (Until round 4: 48 workgroups striding over the cloud with seven same-line atomics each -- 9 us for 120 000 points, all of it the
@@ -123,6 +170,7 @@ __device__ inline VgGrid vg_derive(const uint32_t bmin[3], const uint32_t bmax[3
 
 // voxel index of every point + the histogram of its lowest digit: one workgroup per sort tile, so the first radix pass needs
 // no histogram launch of its own (the later passes histogram the re-ordered keys)
+template <bool FOLD>
 __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
                                                            uint32_t nblocks, const uint32_t* __restrict__ parts) {
@@ -138,6 +186,11 @@ __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint
     __shared__ uint32_t sbox[kWaves][8];
     h[threadIdx.x] = 0;
     uint32_t bmin[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bmax[3] = {0u, 0u, 0u}, n_valid = 0;
+    if (!FOLD) {  // the batched chain: vg_bbox_atomic_body left the box in the scan's record
+        for (int a = 0; a < 3; a++) { bmin[a] = sd->bbox_min[a]; bmax[a] = sd->bbox_max[a]; }
+        n_valid = sd->n_valid;
+        __syncthreads();  // (h[] cleared before the atomics below)
+    } else {
     for (uint32_t b = threadIdx.x; b < nblocks; b += kThreads) {
         const uint4 r0 = reinterpret_cast<const uint4*>(parts)[2 * b], r1 = reinterpret_cast<const uint4*>(parts)[2 * b + 1];
         if (r1.z) {  // (a tile without finite points carries the codes of +-inf, which no finite point's code beats: skipped anyway)
@@ -166,10 +219,13 @@ __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint
         for (int a = 0; a < 3; a++) { bmin[a] = min(bmin[a], sbox[w][a]); bmax[a] = max(bmax[a], sbox[w][3 + a]); }
         n_valid += sbox[w][6];
     }
+    }
     const VgGrid g = vg_derive(bmin, bmax, n_valid, inv);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int a = 0; a < 3; a++) { sd->bbox_min[a] = bmin[a]; sd->bbox_max[a] = bmax[a]; }
-        sd->n_valid = n_valid;
+        if (FOLD) {
+            for (int a = 0; a < 3; a++) { sd->bbox_min[a] = bmin[a]; sd->bbox_max[a] = bmax[a]; }
+            sd->n_valid = n_valid;
+        }
         sd->n_ds_prev = sd->cache_n;  // the neighbour cache's size before this scan
         sd->passthrough = g.pass;
         sd->total_cells = g.total;
@@ -482,13 +538,11 @@ __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sort
 }
 
 // one wave per long run.  The sum itself is PCL's sequential f32 sum -- a dependent chain by definition -- run as four chains side by side (lanes
-// 0..3 own one coordinate each) over values parked in LDS by coordinate, ~5 cycles per point.  What the chain must never do is wait for memory:
-// a chunk of 512 points (eight coalesced 16-byte loads per lane) is requested one chunk AHEAD of the one being summed.  (Until round 4 one
-// 64-point batch was in flight: 0.15 us of adds behind every ~0.8 us load -- 36 us on average in the streaming configuration, 0.6 ms for the
-// worst voxel.)
-constexpr int kLongChunk = 512;
-constexpr int kLongLoads = kLongChunk / 64;
-
+// 0..3 own one coordinate each) over 64 values parked in LDS by coordinate, ~5 cycles per point.  What the chain should not do is wait for
+// memory: FOUR batches of 64 points are in flight ahead of the one being summed (a ring of four registers per lane; a batch beyond the run's
+// end is not requested, so a 40-point run costs one load).  Until round 4 one batch was in flight: ~0.15 us of adds behind every ~0.8 us load for
+// the voxels that hold thousands of points (a wall a metre from the sensor).  (Also measured in round 4 and not kept: 512 points parked per
+// step -- 32 KB of LDS per workgroup and eight loads per lane even for a 40-point run: 31 -> 83 us per batched round.)
 __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
                                                                     const uint32_t* __restrict__ longlist) {
@@ -496,46 +550,44 @@ __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__
     const uint32_t nv = sd->n_ds, nl = sd->n_long;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * kWaves;
-    __shared__ __attribute__((aligned(16))) float park[kWaves][4][kLongChunk];
+    __shared__ __attribute__((aligned(16))) float park[kWaves][4][64];
+    constexpr int kAhead = 4;
     for (uint32_t w = blockIdx.x * kWaves + wv; w < nl; w += nwaves) {
         const uint32_t v = longlist[w];
         const uint32_t ra = hpos[v];
         const uint32_t rb = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;
         float t = 0.f;  // lane c < 4: the running sum of coordinate c
-        float4 p[kLongLoads];
+        float4 p[kAhead];
 #pragma unroll
-        for (int k = 0; k < kLongLoads; k++) {
-            const uint32_t j = ra + k * 64 + lane;
-            p[k] = sorted[j < rb ? j : rb - 1];
+        for (int k = 0; k < kAhead; k++) {
+            const uint32_t c0 = ra + (uint32_t)k * 64u;
+            if (c0 < rb) p[k] = sorted[(c0 + lane) < rb ? c0 + lane : rb - 1];
         }
-        for (uint32_t c = ra; c < rb; c += kLongChunk) {
+        for (uint32_t c = ra; c < rb; c += 64u * kAhead) {
 #pragma unroll
-            for (int k = 0; k < kLongLoads; k++) {
-                park[wv][0][k * 64 + lane] = p[k].x; park[wv][1][k * 64 + lane] = p[k].y; park[wv][2][k * 64 + lane] = p[k].z; park[wv][3][k * 64 + lane] = p[k].w;
-            }
-            if (c + kLongChunk < rb) {  // the next chunk's loads leave before this one is summed
-#pragma unroll
-                for (int k = 0; k < kLongLoads; k++) {
-                    const uint32_t j = c + kLongChunk + k * 64 + lane;
-                    p[k] = sorted[j < rb ? j : rb - 1];
+            for (int k = 0; k < kAhead; k++) {
+                const uint32_t c0 = c + (uint32_t)k * 64u;
+                if (c0 >= rb) break;  // (uniform over the wave)
+                park[wv][0][lane] = p[k].x; park[wv][1][lane] = p[k].y; park[wv][2][lane] = p[k].z; park[wv][3][lane] = p[k].w;
+                const uint32_t cn = c0 + 64u * kAhead;  // this register's next batch: four batches ahead
+                if (cn < rb) p[k] = sorted[(cn + lane) < rb ? cn + lane : rb - 1];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int m = (rb - c0) < 64u ? (int)(rb - c0) : 64;
+                if (lane < 4) {
+                    const float* q = park[wv][lane];
+                    int j = 0;
+                    for (; j + 4 <= m; j += 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(q + j);
+                        t = t + a.x; t = t + a.y; t = t + a.z; t = t + a.w;
+                    }
+                    for (; j < m; j++) t = t + q[j];
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int m = (rb - c) < (uint32_t)kLongChunk ? (int)(rb - c) : kLongChunk;
-            if (lane < 4) {
-                const float* q = park[wv][lane];
-                int k = 0;
-                for (; k + 4 <= m; k += 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(q + k);
-                    t = t + a.x; t = t + a.y; t = t + a.z; t = t + a.w;
-                }
-                for (; k < m; k++) t = t + q[k];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         const float cnt = (float)(rb - ra);
         if (lane < 4) reinterpret_cast<float*>(&out[v])[lane] = t / cnt;
@@ -575,18 +627,18 @@ __device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict
 __global__ void __launch_bounds__(kThreads) vg_bbox_kernel(const float4* __restrict__ in, uint32_t n, uint32_t* __restrict__ parts) { vg_bbox_body(in, n, parts); }
 __global__ void __launch_bounds__(kThreads) vg_bbox_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || blockIdx.x >= d.nblocks) return;
-    vg_bbox_body(d.raw, d.n_raw, reinterpret_cast<uint32_t*>(d.sorted));
+    if (!d.active) return;  // (grid-stride loop over the points: every workgroup of the row takes part)
+    vg_bbox_atomic_body(d.raw, d.n_raw, d.sd);
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
                                                            uint32_t nblocks, const uint32_t* __restrict__ parts) {
-    vg_keys_body(in, n, inv, sd, keys, vals, hist, nblocks, parts);
+    vg_keys_body<true>(in, n, inv, sd, keys, vals, hist, nblocks, parts);
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_batch(const SlotDesc* __restrict__ slots, float inv) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || blockIdx.x >= d.nblocks) return;
-    vg_keys_body(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, reinterpret_cast<const uint32_t*>(d.sorted));
+    vg_keys_body<false>(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, nullptr);
 }
 __global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                               int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
@@ -696,7 +748,7 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
     const uint32_t nblocks = (max_raw + kTile - 1) / kTile;  // of the largest scan of the batch
     if (nblocks == 0 || n_slots <= 0) return LIO_OK;
     const uint32_t B = (uint32_t)n_slots;
-    hipLaunchKernelGGL(vg_bbox_batch, dim3(nblocks, B), kThreads, 0, st, d_slots);
+    hipLaunchKernelGGL(vg_bbox_batch, dim3(nblocks < 48 ? nblocks : 48, B), kThreads, 0, st, d_slots);
     hipLaunchKernelGGL(vg_keys_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, inv);
     for (int pass = 0; pass < passes; pass++) {
         if (pass > 0) hipLaunchKernelGGL(radix_hist_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass);

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4, stage e: parity (full gpu suite); kernel statistics with one round in flight and of the streaming leg after the batched chain went back
+# to the atomic bounding box, the long-run centroids got their four-batch ring and the insert kernels their aggregated atomics; the driver's command
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r04e
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+timeout 1300 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc $?" | tee -a $O/pytest.log
+tail -6 $O/pytest.log
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r -- python $R/bench.py --steps 20 --warmup 5 --secondary 0 --groups 1 --min-seconds 1 --cpu-scans 0 --ref-scans 0 > $O/one_round_under_rocprof.json 2> $O/prof.err
+find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_one_round_in_flight.csv \;
+rm -rf $O/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r -- python $R/bench.py --config stream --steps 400 --lru 100000 --ref-scans 0 > $O/stream_under_rocprof.json 2>> $O/prof.err
+find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_stream.csv \;
+rm -rf $O/prof
+cd $R
+( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
+tail -c 300 $O/bench.err
+head -c 400 $O/bench.json
