@@ -81,7 +81,7 @@ def main():
                     help="batch: B scans per launch, filter loop on the device, one host thread (lio_batch_*); threads: round 1's one engine + thread per scan")
     ap.add_argument("--slots", type=int, default=64, help="--engine batch: scans per launch")
     ap.add_argument("--groups", type=int, default=4, help="--engine batch: rounds in flight (one HIP stream each)")
-    ap.add_argument("--config", choices=["metric", "merge", "stream", "localize"], default="metric",
+    ap.add_argument("--config", choices=["metric", "merge", "stream", "localize", "refparity"], default="metric",
                     help="metric: BASELINE.json's headline (independent 120k-pt scans vs a 1e7-pt map); merge: BASELINE config 5, multi-map merge -- 8 sub-maps "
                          "spread over the GPUs, every key-frame scan registered JOINTLY against all of them (RCCL all-gather of the per-rank J^T J / J^T r); "
                          "stream: BASELINE config 3 (streaming front half, incremental map); localize: BASELINE config 4 (NDT scan-to-map vs a 5e7-pt resident map)")
@@ -99,9 +99,14 @@ def main():
                                                              "(streaming, map_incremental + LRU) after the timed region and report them under `configs`")
     ap.add_argument("--dry-run", action="store_true", help="everything up to the first HIP call, on the CPU: arguments, the torch.distributed rendezvous (gloo), the "
                                                            "sharding of the work over the ranks, the RCCL unique id exchange -- a launch check for multi-GPU runs on a box without GPUs")
+    ap.add_argument("--parity-scans", type=int, default=128, help="scans of the pool registered by the PINNED build of the reference (scalar Eigen, oracle/_ref/libref_fastlio.so) in a "
+                                                                  "child process for cpu_baseline.gpu_vs_reference_pose.pinned_build")
+    ap.add_argument("--parity-dir", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--min-seconds", type=float, default=5.0, help="the job list of --steps scans is repeated until the timed region lasts at least this long")
     args = ap.parse_args()
 
+    if args.config == "refparity":  # child process of the metric config's parity leg: CPU only
+        return ref_parity_leg(args.parity_dir)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher -- one process per GPU under torch.distributed.run (RCCL / gloo
         # rendezvous on 127.0.0.1), this process only waits for them and hands their exit code back
@@ -522,6 +527,7 @@ def main():
             R.map_add(map_pts)
             R.set_nearby(18)
             t_ref, pts_ref, ref_dp, ref_da = 0.0, 0, 0.0, 0.0
+            per_scan = []  # (|dpos|, |drot|, GPU state) against the reference's own code, scan by scan
             for i in range(args.ref_scans):
                 s = scans[i % len(scans)]
                 parity = i < len(scans)
@@ -539,12 +545,46 @@ def main():
                     sg = eng.get_state()
                     ref_dp = max(ref_dp, float(np.linalg.norm(sg[:3] - sr[:3])))
                     ref_da = max(ref_da, float(synth.quat_angle(sg[3:7], sr[3:7])))
+                    per_scan.append((float(np.linalg.norm(sg[:3] - sr[:3])), float(synth.quat_angle(sg[3:7], sr[3:7])), sg.copy()))
+            # `R` is the reference's code built with ITS flags (-O3 -DNDEBUG: Eigen vectorised, the compiler free to contract) -- the build that is
+            # timed.  The build the path is PINNED to is the other one (oracle/_ref/libref_fastlio.so: scalar Eigen, no contraction -- DESIGN.md
+            # section 4: Eigen's operation order depends on the build, and esti_plane's 5 x 3 QR is ill-conditioned for planes through the map
+            # frame's origin, which this scene's ground z = 0 is).  One build per process (both define the reference's file-scope globals): the
+            # pinned build registers the same scans in a child process, once as it is (neighbours 1..4 in std::nth_element's order) and once with
+            # every search's lists sorted into the oracle's canonical order (ref_fl_set_canonical).
+            gvr = {"build": "the reference's own flags (-O3 -DNDEBUG, vectorised Eigen): the build that is timed", "max_dpos_m": ref_dp, "max_drot_rad": ref_da,
+                   "scans": len(per_scan)}
+            if per_scan:
+                dps, das = np.array([p[0] for p in per_scan]), np.array([p[1] for p in per_scan])
+                w = int(np.argmax(dps))
+                gvr.update(median_dpos_m=float(np.median(dps)), p90_dpos_m=float(np.percentile(dps, 90)),
+                           scans_beyond_1e_4_m_or_1e_5_rad=int(np.count_nonzero((dps > 1e-4) | (das > 1e-5))),
+                           worst_scan={"index": w, "seed": scans[w]["seed"], "dpos_m": float(dps[w]), "drot_rad": float(das[w]),
+                                       "pose_error_vs_truth_m": float(np.linalg.norm(per_scan[w][2][:3] - scans[w]["pos"]))})
+                try:
+                    import subprocess
+                    import tempfile
+
+                    del R
+                    m_par = min(len(per_scan), args.parity_scans)
+                    with tempfile.TemporaryDirectory(prefix="lio_bench_parity_") as td:
+                        np.save(os.path.join(td, "map.npy"), map_pts)
+                        np.savez(os.path.join(td, "scans.npz"), P0=P0, n=m_par, **{f"raw{i}": scans[i]["raw"] for i in range(m_par)},
+                                 **{f"guess{i}": scans[i]["guess"] for i in range(m_par)}, **{f"gpu{i}": per_scan[i][2] for i in range(m_par)})
+                        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "refparity", "--parity-dir", td], capture_output=True, text=True,
+                                            timeout=600)
+                    line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                    if pr.returncode != 0 or not line:
+                        raise RuntimeError((pr.stderr or pr.stdout)[-300:])
+                    gvr["pinned_build"] = json.loads(line[-1])
+                except Exception as ex:
+                    gvr["pinned_build"] = {"error": repr(ex)[-300:]}
             cpu = dict(value=round(pts_ref / t_ref, 1), unit="points/s", cores=min(8, usable_cpus()), host_cpus=usable_cpus(), kind="reference",
                        sample=f"{args.ref_scans} scans of the same workload through the reference's own laserMapping.cpp h_share_model + iVox + esekfom "
                               f"update_iterated_dyn_share_modified (oracle/_ref/libref_fastlio_release.so: -O3 -DNDEBUG, MP_EN with MP_PROC_NUM=8 as its "
                               f"CMakeLists.txt sets on x86_64; pcl::VoxelGrid replaced by the oracle's restatement), {t_ref:.1f} s",
                        ms_per_scan=round(1e3 * t_ref / args.ref_scans, 2),
-                       gpu_vs_reference_pose={"max_dpos_m": ref_dp, "max_drot_rad": ref_da}, port=port)
+                       gpu_vs_reference_pose=gvr, port=port)
 
     # ---- secondary configurations (BASELINE.json configs 2 and 3), outside the timed region, reported under `configs` ----
     configs = None
@@ -646,7 +686,7 @@ def main():
                 j = json.loads(line[-1])
                 configs[key] = {"ms_per_scan": j["ms_per_step"], "points_per_s": j["value"], **j["config"],
                                 "roofline": j.get("roofline"), "cpu_baseline": j.get("cpu_baseline"), "pose_error_vs_truth_m": j.get("pose_error_vs_truth_m")}
-                for extra_key in ("drift", "collective", "latency"):
+                for extra_key in ("drift", "collective", "latency", "knn_on_this_map"):
                     if j.get(extra_key):
                         configs[key][extra_key] = j[extra_key]
             except Exception as ex:  # the headline must not depend on the secondary legs
@@ -687,6 +727,43 @@ def main():
             sys.stdout.flush()
             os._exit(0)
         dist.destroy_process_group()
+
+
+def ref_parity_leg(td):
+    """the scans of <td>/scans.npz registered by the PINNED build of the reference's own code (oracle/_ref/libref_fastlio.so) against <td>/map.npy: the
+    poses the GPU path returned for them against the reference's, with its neighbour lists as std::nth_element leaves them and in canonical order.
+    One JSON line.  Test infrastructure (oracle/) used as the checker, on the host, outside every timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_fastlio
+    from lsd_amd import synth
+
+    if not ref_fastlio.available():
+        print(json.dumps({"error": "oracle/_ref/libref_fastlio.so is not there"}))
+        return
+    d = np.load(os.path.join(td, "scans.npz"))
+    R = ref_fastlio.RefFastLio()
+    R.set_logging(False)
+    R.map_add(np.load(os.path.join(td, "map.npy")))
+    R.set_nearby(18)
+    P0, n = d["P0"], int(d["n"])
+    out = {}
+    for mode in ("neighbour_lists_as_nth_element_leaves_them", "neighbour_lists_in_canonical_order"):
+        R.set_canonical(mode.endswith("canonical_order"))
+        dp, da = [], []
+        for i in range(n):
+            R.reset_cache()
+            rc, sr, _ = R.register(d[f"raw{i}"], d[f"guess{i}"], P0)
+            if rc != 3:
+                continue
+            g = d[f"gpu{i}"]
+            dp.append(float(np.linalg.norm(g[:3] - sr[:3])))
+            da.append(float(synth.quat_angle(g[3:7], sr[3:7])))
+        dp, da = np.array(dp), np.array(da)
+        out[mode] = {"scans": int(len(dp)), "max_dpos_m": float(dp.max()), "max_drot_rad": float(da.max()), "median_dpos_m": float(np.median(dp)),
+                     "scans_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((dp > 1e-4) | (da > 1e-5)))}
+    R.set_canonical(False)
+    out["build"] = "oracle/_ref/libref_fastlio.so: the reference's translation units with scalar Eigen and no FMA contraction -- the build the path is pinned to"
+    print(json.dumps(out))
 
 
 def rccl_probe(torch, dist, lio, rank, world, local_rank, dev, n_records=64, iters=200, timeout_s=90.0):
@@ -862,6 +939,58 @@ def stream_run(args, torch, local_rank):
             insert_leg = dict(downsample_us=0.0, knn_us=0.0, linearize_us=0.0, insert_us=0.0, undistort_us=0.0, n_ds=0, n_added=0, scans=0)
             timing_left = 100
     e.enable_timing(False)
+    # ---- the stencil search on THIS map (grown by map_incremental: a few points per voxel, not the 39 of the metric config's pre-built one): the last
+    # sweeps once more as independent jobs of a 16-slot batch against the engine's map, HIP events per kernel class, then the counting variant
+    knn_grown = None
+    if tr is not None and k_done > 40:
+        try:
+            e.flush()
+            S = 19
+            d_sw, jb = [], []
+            P0 = lio.init_cov()
+            R0, p0 = tr.R(0.0), tr.pos(0.0)
+            for k in range(k_done - 32, k_done):
+                p, _ = get_sweep(k)
+                d = torch.from_numpy(p).to(dev)
+                d_sw.append(d)
+                tm_ = k * 0.1 + 0.05  # the pose half-way through the sweep, in the frame of the first pose (the engine's map frame)
+                Rk, pk = R0.T @ tr.R(tm_), R0.T @ (tr.pos(tm_) - p0)
+                qw = np.sqrt(max(0.0, 1.0 + Rk[0, 0] + Rk[1, 1] + Rk[2, 2])) / 2
+                qk = np.array([(Rk[2, 1] - Rk[1, 2]) / (4 * qw), (Rk[0, 2] - Rk[2, 0]) / (4 * qw), (Rk[1, 0] - Rk[0, 1]) / (4 * qw), qw])
+                jb.append(dict(dptr=d.data_ptr(), n=len(p), t=1.0 + 0.1 * k, state=synth.state_from_pose(pk, qk), cov=P0))
+            torch.cuda.synchronize()
+            solo = lio.Batch(e.map, n_slots=16, n_groups=1, max_raw=1 << 18, max_ds=100000)
+            solo.process(jb[:16])
+            solo.enable_kernel_timing(True)
+            solo.kernel_times(reset=True)
+            c1 = e.map.knn_candidates
+            _, res_s = solo.process(jb)
+            kt = solo.kernel_times(reset=True)
+            n_q = sum(r["n_ds"] * r["n_knn_pass"] for r in res_s)
+            cand_pts = e.map.knn_candidates - c1
+            solo.enable_kernel_timing(2)
+            solo.kernel_times(reset=True)
+            t0c = e.map.knn_touched
+            solo.process(jb)
+            solo.kernel_times(reset=True)
+            touched = e.map.knn_touched - t0c
+            solo.enable_kernel_timing(False)
+            del solo
+            L = max(int(kt["knn_launches"]), 1)
+            us = kt["knn_us"] / L
+            b_alg = (n_q * (16 + 16 * S) + 16.0 * cand_pts) / L
+            b_tch = (n_q * (16 + 16 * S) + 16.0 * touched) / L
+            knn_grown = {"what": "knn_batch_kernel on the map this drive grew: the last 32 sweeps as independent jobs, 16 per launch, one round in flight",
+                         "map_points": int(e.map.stats()[0]), "map_voxels": int(e.map.stats()[1]),
+                         "candidates_per_query": round(cand_pts / max(n_q, 1), 1), "touched_per_query": round(touched / max(n_q, 1), 1),
+                         "queries": int(n_q), "searches": int(sum(r["n_knn_pass"] for r in res_s)), "registered": int(sum(1 for r in res_s if r["rc"] == 3)),
+                         "us_per_scan_and_search": round(kt["knn_us"] / max(sum(r["n_knn_pass"] for r in res_s), 1), 2),
+                         "avg_launch_us": round(us, 2), "launches": L,
+                         "frac": round(b_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
+                         "frac_touched": round(b_tch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
+                         "algorithmic_bytes_per_launch": int(b_alg), "touched_bytes_per_launch": int(b_tch), "traffic": None}
+        except Exception as ex:
+            knn_grown = {"error": repr(ex)[-300:]}
     s = e.get_state()
     err = None
     if tr is not None:
@@ -951,7 +1080,7 @@ def stream_run(args, torch, local_rank):
                       "main_ms_median": round(1e3 * float(np.median(t_main)), 4), "enqueue_ms_median": round(1e3 * float(np.median(t_enq)), 4),
                       "main_ms_p99": round(1e3 * float(np.percentile(t_main, 99)), 4), "main_ms_median_by_map_size_Mpts": curve,
                       "sweep_generation_s": round(t_gen, 1)},
-           "roofline": roofline, "cpu_baseline": cpu, "pose_error_vs_truth_m": err,
+           "roofline": roofline, "knn_on_this_map": knn_grown, "cpu_baseline": cpu, "pose_error_vs_truth_m": err,
            "drift": {"metres_driven__position_error_m__its_vertical_part_m": err_curve,
                      "note": "pure odometry (no loop closure, no GNSS on this path): drift against the generating trajectory, mostly vertical on this flat "
                              "synthetic ground; the reference's own FastLIO build drifts the same way on the same sweeps (cpu_baseline.pose_error_vs_truth_m "
