@@ -46,6 +46,24 @@ def usable_cpus():
     return n
 
 
+def quat_from_R(R):
+    """rotation matrix -> (x, y, z, w), the branch with the largest pivot (a heading of 180 degrees has w = 0)"""
+    t = np.trace(R)
+    if t > 0:
+        w = np.sqrt(1.0 + t) / 2
+        q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+    else:
+        i = int(np.argmax([R[0, 0], R[1, 1], R[2, 2]]))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        r = np.sqrt(max(0.0, 1.0 + R[i, i] - R[j, j] - R[k, k])) / 2
+        q = np.zeros(4)
+        q[i] = r
+        q[j] = (R[j, i] + R[i, j]) / (4 * r)
+        q[k] = (R[k, i] + R[i, k]) / (4 * r)
+        q[3] = (R[k, j] - R[j, k]) / (4 * r)
+    return q / np.linalg.norm(q)
+
+
 def spawn_ranks(n):
     """re-run this command line as `n` ranks of torch.distributed.run on this node (what the docstring's second form does by hand)"""
     import socket
@@ -99,7 +117,7 @@ def main():
                                                              "(streaming, map_incremental + LRU) after the timed region and report them under `configs`")
     ap.add_argument("--dry-run", action="store_true", help="everything up to the first HIP call, on the CPU: arguments, the torch.distributed rendezvous (gloo), the "
                                                            "sharding of the work over the ranks, the RCCL unique id exchange -- a launch check for multi-GPU runs on a box without GPUs")
-    ap.add_argument("--parity-scans", type=int, default=128, help="scans of the pool registered by the PINNED build of the reference (scalar Eigen, oracle/_ref/libref_fastlio.so) in a "
+    ap.add_argument("--parity-scans", type=int, default=32, help="scans of the pool registered by the PINNED build of the reference (scalar Eigen, oracle/_ref/libref_fastlio.so) in a "
                                                                   "child process for cpu_baseline.gpu_vs_reference_pose.pinned_build")
     ap.add_argument("--parity-dir", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--min-seconds", type=float, default=5.0, help="the job list of --steps scans is repeated until the timed region lasts at least this long")
@@ -747,6 +765,7 @@ def ref_parity_leg(td):
     R.set_nearby(18)
     P0, n = d["P0"], int(d["n"])
     out = {}
+    out_dp_canonical = np.zeros(0)
     for mode in ("neighbour_lists_as_nth_element_leaves_them", "neighbour_lists_in_canonical_order"):
         R.set_canonical(mode.endswith("canonical_order"))
         dp, da = [], []
@@ -759,10 +778,51 @@ def ref_parity_leg(td):
             dp.append(float(np.linalg.norm(g[:3] - sr[:3])))
             da.append(float(synth.quat_angle(g[3:7], sr[3:7])))
         dp, da = np.array(dp), np.array(da)
+        if mode.endswith("canonical_order"):
+            out_dp_canonical = dp
         out[mode] = {"scans": int(len(dp)), "max_dpos_m": float(dp.max()), "max_drot_rad": float(da.max()), "median_dpos_m": float(np.median(dp)),
                      "scans_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((dp > 1e-4) | (da > 1e-5)))}
     R.set_canonical(False)
     out["build"] = "oracle/_ref/libref_fastlio.so: the reference's translation units with scalar Eigen and no FMA contraction -- the build the path is pinned to"
+    # What is left in canonical order: queries whose FIFTH-nearest candidate ties with the sixth in f32 squared distance.  The reference keeps whichever
+    # std::nth_element leaves (ivox3d_node.hpp:107-127, ivox3d.h:159-164: implementation-defined), oracle and kernels break the tie by (d2, x, y, z):
+    # another neighbour SET, which no ordering of the lists repairs.  Shown on the scan that differs most: the first search of the update, oracle
+    # (= the GPU path, bit for bit) against the reference, query by query.
+    try:
+        import oracle
+
+        worst = int(np.argmax(out_dp_canonical)) if len(out_dp_canonical) else -1
+        if worst >= 0 and out_dp_canonical[worst] > 1e-9:
+            raw, g = d[f"raw{worst}"], d[f"guess{worst}"]
+            o = oracle.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=8)
+            o.map_add(np.load(os.path.join(td, "map.npy")))
+            o.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+            o.set_state(g)
+            o.set_cov(P0)
+            o.set_ds(oracle.voxel_downsample(raw, 0.5))
+            lo = o.linearize(True)
+            wpts = o.get_ds_world()
+            R.reset_cache()
+            R.register(raw, g, P0)
+            R.reset_cache()
+            hr = R.h_share(g, converge=2)
+            ties = []
+            for q in np.nonzero(np.abs(lo["nn"] - hr["nn"]).reshape(len(wpts), -1).max(1) > 0)[0]:
+                a = {tuple(r) for r in lo["nn"][q][: lo["nn_cnt"][q], :3].tolist()}
+                b = {tuple(r) for r in hr["nn"][q][: hr["nn_cnt"][q], :3].tolist()}
+                w = wpts[q].astype(np.float32)
+
+                def d2(pt):
+                    e = np.asarray(pt, np.float32) - w[:3]
+                    return float(np.float32(e[0] * e[0]) + np.float32(np.float32(e[1] * e[1]) + np.float32(e[2] * e[2])))
+
+                ties.append({"query": int(q), "only_in_oracle_d2": [d2(x) for x in a - b], "only_in_reference_d2": [d2(x) for x in b - a]})
+            out["what_is_left_in_canonical_order"] = {
+                "scan": worst, "dpos_m": float(out_dp_canonical[worst]), "queries_with_another_neighbour_set_in_the_first_search": len(ties), "their_members": ties[:8],
+                "note": "equal f32 squared distances on both sides = a tie at the fifth-nearest boundary, resolved by std::nth_element in the reference "
+                        "(implementation-defined) and by the total order (d2, x, y, z) in the oracle and the kernels"}
+    except Exception as ex:
+        out["what_is_left_in_canonical_order"] = {"error": repr(ex)[-300:]}
     print(json.dumps(out))
 
 
@@ -955,8 +1015,7 @@ def stream_run(args, torch, local_rank):
                 d_sw.append(d)
                 tm_ = k * 0.1 + 0.05  # the pose half-way through the sweep, in the frame of the first pose (the engine's map frame)
                 Rk, pk = R0.T @ tr.R(tm_), R0.T @ (tr.pos(tm_) - p0)
-                qw = np.sqrt(max(0.0, 1.0 + Rk[0, 0] + Rk[1, 1] + Rk[2, 2])) / 2
-                qk = np.array([(Rk[2, 1] - Rk[1, 2]) / (4 * qw), (Rk[0, 2] - Rk[2, 0]) / (4 * qw), (Rk[1, 0] - Rk[0, 1]) / (4 * qw), qw])
+                qk = quat_from_R(Rk)
                 jb.append(dict(dptr=d.data_ptr(), n=len(p), t=1.0 + 0.1 * k, state=synth.state_from_pose(pk, qk), cov=P0))
             torch.cuda.synchronize()
             solo = lio.Batch(e.map, n_slots=16, n_groups=1, max_raw=1 << 18, max_ds=100000)
