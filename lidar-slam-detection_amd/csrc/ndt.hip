@@ -47,6 +47,11 @@ constexpr int kNdtThreads = 64;
 // lane: 190 -> ~100 VGPRs); H is handed out mirrored.
 constexpr int kNdtAcc = 28;
 constexpr int kNdtOut = 43;  // what the host side sees: H (36, row-major, symmetric) + b (6) + err
+// component 29 of the workgroups' partial records: the number of pairs the workgroup found (an evaluation that refreshes the pairs).  It used to be
+// one atomicAdd per workgroup on ONE device word: 782 same-address atomics serialise at ~12 ns each -- 9 us of a 17 us kernel (round 4: found when the
+// eight-lanes-per-point variant, with eight times the waves, took 75 us for the same work)
+constexpr int kNdtCnt = kNdtAcc + 1;
+constexpr int kNdtComps = kNdtAcc + 2;  // 28 sums, the speculative evaluation's trial cost, the pair count
 constexpr int kNdtQuads = kNdtThreads / 4;
 constexpr int kNdtMaxOff = 27;
 __device__ __host__ inline int ndt_tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
@@ -436,8 +441,9 @@ __device__ __forceinline__ void ndt_cost_body(const Slot* __restrict__ table, ui
     if (UPDATE) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) my_corr += __shfl_xor(my_corr, off);
-        if (threadIdx.x == 0 && my_corr) atomicAdd(n_corr_counter, my_corr);
+        if (threadIdx.x == 0) partial[(size_t)kNdtCnt * pstride + blockIdx.x] = (double)my_corr;
     }
+    (void)n_corr_counter;
 }
 
 template <bool UPDATE, bool DERIV, int NO>
@@ -598,7 +604,8 @@ __device__ __forceinline__ void ndt_spec_body(const Slot* __restrict__ table, ui
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) my_corr += __shfl_xor(my_corr, off);
-    if (threadIdx.x == 0 && my_corr) atomicAdd(n_corr_counter, my_corr);
+    if (threadIdx.x == 0) partial[(size_t)kNdtCnt * pstride + blockIdx.x] = (double)my_corr;
+    (void)n_corr_counter;
 }
 
 template <int NO>
@@ -759,9 +766,17 @@ __global__ void __launch_bounds__(kL8Threads) ndt_cost_l8_kernel(const Slot* __r
         }
         partial[(size_t)tid * pstride + blockIdx.x] = sm;
     }
-    // the number of pairs of this evaluation (diagnostic / timing bookkeeping)
+    // the number of pairs of this evaluation: the block's count as one more component of its partial record
+    __shared__ uint32_t wcnt[kL8Threads / 64];
     const unsigned long long fm = __ballot(found != kNoIdx);
-    if ((tid & 63) == 0 && fm) atomicAdd(&nd->n_corr, (uint32_t)__popcll(fm));
+    if ((tid & 63) == 0) wcnt[tid >> 6] = (uint32_t)__popcll(fm);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0;
+        for (int w = 0; w < kL8Threads / 64; w++) c += wcnt[w];
+        partial[(size_t)kNdtCnt * pstride + blockIdx.x] = (double)c;
+    }
+    (void)nd;
 }
 
 // ---- batched alignments: slot = one alignment (its own source scan and guess) against the ONE target, the Levenberg-Marquardt loop of
@@ -815,8 +830,16 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_batch(float res, NdtOffs
 
 // the fold of the workgroup partials by a 1024-thread workgroup: wave w takes components w, w + 16, w + 32; lane l adds workgroups l, l + 64, ...
 // (coalesced: the layout is [component][workgroup]), then a fixed xor tree over the wave -- one order, run-to-run identical
-__device__ __forceinline__ void ndt_fold(const double* __restrict__ partial, uint32_t pstride, uint32_t nb, int na, double* acc /* LDS, kNdtAcc */) {
+// with_count: also component kNdtCnt (the pair count: integers, exact in any order) into acc[kNdtCnt]
+__device__ __forceinline__ void ndt_fold(const double* __restrict__ partial, uint32_t pstride, uint32_t nb, int na, double* acc /* LDS, kNdtComps */, bool with_count) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (with_count && wave == 15) {
+        double v = 0.0;
+        for (uint32_t b = lane; b < nb; b += 64) v += partial[(size_t)kNdtCnt * pstride + b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) acc[kNdtCnt] = v;
+    }
     for (int c = wave; c < na; c += 16) {
         double v = 0.0;
         for (uint32_t b = lane; b < nb; b += 64) v += partial[(size_t)c * pstride + b];
@@ -831,12 +854,13 @@ __device__ __forceinline__ void ndt_fold(const double* __restrict__ partial, uin
 __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict__ slots, NdtLmParams P) {
     NdtLmSlot& s = slots[blockIdx.x];
     if (!s.active || s.phase == 2) return;
-    __shared__ double acc[kNdtAcc + 1];
+    __shared__ double acc[kNdtComps];
     const int tid = threadIdx.x;
     const uint32_t nb = (s.sd->n_ds + kNdtThreads - 1) / kNdtThreads;
     const int na = s.phase == 0 ? kNdtAcc : kNdtAcc + 1;
-    ndt_fold(s.partial, s.pstride, nb, na, acc);
+    ndt_fold(s.partial, s.pstride, nb, na, acc, true);
     if (tid != 0) return;
+    s.n_corr = (uint32_t)(acc[kNdtCnt] + 0.5);
     lio_ndt_params p;
     p.max_iterations = P.max_iterations; p.lm_max_iterations = P.lm_max_iterations; p.rotation_epsilon_deg = P.rotation_epsilon_deg;
     p.transformation_epsilon = P.transformation_epsilon; p.lm_init_lambda_factor = P.lm_init_lambda_factor; p.max_process_time_ms = -1;
@@ -903,7 +927,6 @@ __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict_
             se3_exp_h(s.d, s.delta);
             mul44_h(s.delta, s.x0, s.xi);
             s.phase = 1;
-            s.n_corr = 0;  // the trial's pairs are counted afresh
         }
     }
 }
@@ -911,11 +934,12 @@ __global__ void __launch_bounds__(1024) ndt_lm_step_batch(NdtLmSlot* __restrict_
 // nb_hint: the number of workgroup partials when the host knows the scan's size (it does after a synchronous downsample): saves the dependent load of
 // the size before the fold's loads can be issued; 0 = read it from the scan's device record
 __global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restrict__ sd, const double* __restrict__ partial, uint32_t pstride, int na, NdtDev* nd,
-                                                          NdtReport* __restrict__ out, uint32_t nb_hint) {
-    __shared__ double acc[kNdtAcc + 1];
+                                                          NdtReport* __restrict__ out, uint32_t nb_hint, int with_count) {
+    __shared__ double acc[kNdtComps];
     const int tid = threadIdx.x;
     const uint32_t nb = nb_hint ? nb_hint : (sd->n_ds + kNdtThreads - 1) / kNdtThreads;
-    ndt_fold(partial, pstride, nb, na, acc);
+    const bool counted = with_count != 0;
+    ndt_fold(partial, pstride, nb, na, acc, counted);
     // the record leaves through 43 lanes at once (a handful of PCIe writes; H mirrored from its lower triangle), then one system-scope fence and the
     // sequence word
     if (tid < 64) {
@@ -923,7 +947,10 @@ __global__ void __launch_bounds__(1024) ndt_report_kernel(const ScanDev* __restr
         else if (tid < 36) out->acc[tid] = acc[ndt_tri(tid / 6, tid % 6)];
         else if (tid < kNdtOut) out->acc[tid] = acc[21 + (tid - 36)];
         else if (tid == kNdtOut && na > kNdtAcc) out->err_trial = acc[kNdtAcc];
-        if (tid == 63) out->n_corr = nd->n_corr;
+        if (tid == 63) {  // an evaluation that refreshed the pairs counted them; an error-only one leaves the last count
+            if (counted) nd->n_corr = (uint32_t)(acc[kNdtCnt] + 0.5);
+            out->n_corr = nd->n_corr;
+        }
         __threadfence_system();
     }
     __syncthreads();
@@ -1093,7 +1120,6 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
     if (blocks == 0) blocks = 1;
     const NdtXform xl = to_xform(x_lin), xx = to_xform(x);
     hipStream_t st = s->stream;
-    if (update) LIO_HIP_TRY(hipMemsetAsync(&n->dev->n_corr, 0, 4, st));
     if (n->timing) hipEventRecord(n->ev[0], st);
 #define NDT_LAUNCH(U, D, NO)                                                                                                                       \
     hipLaunchKernelGGL((ndt_cost_kernel<U, D, NO>), blocks, kNdtThreads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xl, xx, \
@@ -1115,7 +1141,7 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
 #undef NDT_LAUNCH
     if (n->timing) hipEventRecord(n->ev[1], st);
     hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, n->pstride, deriv ? kNdtAcc : 1, n->dev, n->report_dev,
-                       s->have_ds > 0 ? blocks : 0u);
+                       s->have_ds > 0 ? blocks : 0u, update ? 1 : 0);
     LIO_HIP_TRY(hipGetLastError());
     n->seq_expected++;
     const int rc = ndt_wait(n, st);
@@ -1148,7 +1174,6 @@ int ndt_eval_spec(lio_ndt* n, lio_scan* s, const double x[16], double* H, double
     if (blocks == 0) blocks = 1;
     const NdtXform xx = to_xform(x);
     hipStream_t st = s->stream;
-    LIO_HIP_TRY(hipMemsetAsync(&n->dev->n_corr, 0, 4, st));
     if (n->timing) hipEventRecord(n->ev[0], st);
 #define NDT_SPEC(NO)                                                                                                                                    \
     hipLaunchKernelGGL((ndt_cost_spec_kernel<NO>), blocks, kNdtThreads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xx, s->ds_body, \
@@ -1161,7 +1186,7 @@ int ndt_eval_spec(lio_ndt* n, lio_scan* s, const double x[16], double* H, double
     else NDT_SPEC(27);
 #undef NDT_SPEC
     if (n->timing) hipEventRecord(n->ev[1], st);
-    hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, n->pstride, kNdtAcc + 1, n->dev, n->report_dev, s->have_ds > 0 ? blocks : 0u);
+    hipLaunchKernelGGL(ndt_report_kernel, 1, 1024, 0, st, s->dev, n->partial, n->pstride, kNdtAcc + 1, n->dev, n->report_dev, s->have_ds > 0 ? blocks : 0u, 1);
     LIO_HIP_TRY(hipGetLastError());
     n->seq_expected++;
     const int rc = ndt_wait(n, st);
@@ -1209,7 +1234,7 @@ lio_ndt* lio_ndt_create(int device, float resolution, int search_method, uint64_
     bool ok = hipMalloc(reinterpret_cast<void**>(&n->vox), (size_t)n->map->table_cap * sizeof(NdtVoxel)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->corr), (size_t)kNdtMaxOff * max_source_points * 4) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->corr2), (size_t)n->offs.n * max_source_points * 4) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&n->partial), (size_t)((max_source_points + kNdtThreads - 1) / kNdtThreads) * (kNdtAcc + 1) * 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&n->partial), (size_t)((max_source_points + kNdtThreads - 1) / kNdtThreads) * kNdtComps * 8) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->dev), sizeof(NdtDev)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->stamp), (size_t)n->stamp_cap * sizeof(float4)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->list), (size_t)n->map->table_cap * 4) == hipSuccess &&
@@ -1429,7 +1454,7 @@ int lio_ndt_align_batch(lio_ndt* n, lio_align_job* jobs, int n_jobs, const lio_n
         }
         return LIO_OK;
     }
-    const size_t corr_per = (size_t)n->offs.n * n->max_src, part_per = (size_t)((n->max_src + kNdtThreads - 1) / kNdtThreads) * (kNdtAcc + 1);
+    const size_t corr_per = (size_t)n->offs.n * n->max_src, part_per = (size_t)((n->max_src + kNdtThreads - 1) / kNdtThreads) * kNdtComps;
     if (!n->d_slots) {
         // the slots' scratch is 2 x offsets x max_source_points x 4 B of correspondences each (15 MB at DIRECT7 / 262 144 points, 57 MB at DIRECT27): 64 slots
         // when that fits, fewer when the device is short of memory (the jobs then go through in more, smaller launches -- same results)
