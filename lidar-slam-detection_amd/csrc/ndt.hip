@@ -616,168 +616,9 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_spec_kernel(const Slot* 
     ndt_spec_body<NO>(table, mask, vox, res, offs, x, src, sd->n_ds, corr_old, corr_new, corr_stride, partial, pstride, &nd->n_corr);
 }
 
-// ---- one alignment at a time: EIGHT LANES PER SOURCE POINT (DIRECT7) ---------------------------------------------------------------------------------
-// A single alignment is 50 000 source points = 782 waves of the one-lane-per-point kernel on 1 024 SIMDs: every wave walks its dependent chain
-// (point -> seven probes -> seven 64-byte records -> 7 x 28 terms -> reduction) alone, 17-19 us whatever the occupancy allows.  Here lane (point, o)
-// takes ONE of the seven offsets (the eighth lane of a point idles): eight times the waves, a chain of one probe and one record.  The sums are
-// formed in the order of the one-lane kernel, so the bits are the same and the batched path (one lane per point: it has the waves) and this one
-// stay interchangeable:
-//   per point    s = 0; s += t_o for o = 0..6        (an absent pair contributes +0.0: x + 0.0 = x, and s never holds -0.0)
-//   per quad     (P0 + P1) + (P2 + P3)               over four consecutive points (the DPP butterflies of the one-lane kernel)
-//   per block    the sixteen quad sums of 64 points in quad order -> partial[component][block]: the blocks of the one-lane kernel
-// Components travel through LDS eight at a time ([point][offset][8] doubles, 32 KB): lane (point, cc) adds the seven offsets of component cc.
-constexpr int kL8Threads = 512;  // 64 points x 8 lanes
-
-template <bool SPEC>
-__global__ void __launch_bounds__(kL8Threads) ndt_cost_l8_kernel(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox, float res,
-                                                                 NdtOffsets offs, NdtXform x, const float4* __restrict__ src, const ScanDev* __restrict__ sd,
-                                                                 const uint32_t* __restrict__ corr_old, uint32_t* __restrict__ corr_new, uint32_t corr_stride,
-                                                                 double* __restrict__ partial, uint32_t pstride, NdtDev* nd) {
-    const uint32_t n = sd->n_ds;
-    if (blockIdx.x * 64u >= n) return;
-    constexpr int NA = SPEC ? kNdtAcc + 1 : kNdtAcc;
-    const int tid = threadIdx.x, pt = tid >> 3, o = tid & 7;
-    const uint32_t i = blockIdx.x * 64u + (uint32_t)pt;
-    double v[32];
-#pragma unroll
-    for (int c = 0; c < 32; c++) v[c] = 0.0;
-    uint32_t found = kNoIdx;
-    if (i < n && o < 7) {
-        const float4 p = src[i];
-        float tp[3];
-        xform_dev(x, p, tp);
-        int kx, ky, kz;
-        pos2grid_ndt(tp[0], tp[1], tp[2], res, kx, ky, kz);
-        kx += offs.off[o][0]; ky += offs.off[o][1]; kz += offs.off[o][2];
-        uint32_t s_old = kNoIdx;
-        if (SPEC) s_old = corr_old[(size_t)o * corr_stride + i];
-        {
-            const unsigned long long want = pack_key(kx, ky, kz);
-            BrickProbe bp = brick_probe(kx, ky, kz);
-            uint4 r = *reinterpret_cast<const uint4*>(&table[brick_slot(bp, mask)]);
-            for (uint32_t probe = 0; probe <= (mask >> 6); probe++) {
-                const unsigned long long kk = ((unsigned long long)r.y << 32) | r.x;
-                if (kk == want) { found = r.w > 0 ? brick_slot(bp, mask) : kNoIdx; break; }
-                if (kk == kEmptyKey) break;
-                brick_next(bp);
-                r = *reinterpret_cast<const uint4*>(&table[brick_slot(bp, mask)]);
-            }
-            corr_new[(size_t)o * corr_stride + i] = found;
-        }
-        const float ksq = res * res;
-        float err_new = 0.f;
-        bool have_new = false;
-        if (found != kNoIdx) {
-            const float4* rec = reinterpret_cast<const float4*>(&vox[found]);
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-            if (__float_as_int(r0.w) > 6) {  // ndt_compute_derivatives.cu:61
-                const float ci[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
-                const float e[3] = {r0.x - tp[0], r0.y - tp[1], r0.z - tp[2]};
-                const float nrm = sqrtf(sqn3_dev(e));
-                const float w = ksq / (ksq + nrm * nrm);
-                const float we[3] = {w * e[0], w * e[1], w * e[2]};
-                float wc[3];
-                for (int c = 0; c < 3; c++) wc[c] = sum3f(we[0] * ci[c], we[1] * ci[3 + c], we[2] * ci[6 + c]);
-                err_new = sum3f(wc[0] * e[0], wc[1] * e[1], wc[2] * e[2]);
-                have_new = true;
-                // the DERIV branch of ndt_cost_body, statement for statement (one pair: the terms themselves, not sums)
-                const float w0 = w * tp[0], w1 = w * tp[1], w2 = w * tp[2];
-                float Brot[3][3], m[9];
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    Brot[0][c] = w2 * ci[3 + c] - w1 * ci[6 + c];
-                    Brot[1][c] = w0 * ci[6 + c] - w2 * ci[c];
-                    Brot[2][c] = w1 * ci[c] - w0 * ci[3 + c];
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) m[k] = w * ci[k];
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const float h0 = Brot[r][1] * tp[2] - Brot[r][2] * tp[1];
-                    const float h1 = Brot[r][2] * tp[0] - Brot[r][0] * tp[2];
-                    const float h2 = Brot[r][0] * tp[1] - Brot[r][1] * tp[0];
-                    v[ndt_tri(r, 0)] = (double)h0;
-                    if (r >= 1) v[ndt_tri(r, 1)] = (double)h1;
-                    if (r >= 2) v[ndt_tri(r, 2)] = (double)h2;
-                    v[21 + r] = (double)sum3f(Brot[r][0] * e[0], Brot[r][1] * e[1], Brot[r][2] * e[2]);
-                }
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const float B0 = -m[r * 3], B1 = -m[r * 3 + 1], B2 = -m[r * 3 + 2];
-                    v[ndt_tri(3 + r, 0)] = (double)(B1 * tp[2] - B2 * tp[1]);
-                    v[ndt_tri(3 + r, 1)] = (double)(B2 * tp[0] - B0 * tp[2]);
-                    v[ndt_tri(3 + r, 2)] = (double)(B0 * tp[1] - B1 * tp[0]);
-#pragma unroll
-                    for (int c = 0; c <= r; c++) v[ndt_tri(3 + r, 3 + c)] = (double)m[r * 3 + c];
-                    v[24 + r] = (double)sum3f(B0 * e[0], B1 * e[1], B2 * e[2]);
-                }
-                v[27] = (double)err_new;
-            }
-        }
-        if (SPEC && s_old != kNoIdx) {  // the pair cached at the linearisation point: its cost at x (compute_error)
-            if (s_old == found) {
-                if (have_new) v[28] = (double)err_new;
-            } else {
-                const float4* rec = reinterpret_cast<const float4*>(&vox[s_old]);
-                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                if (__float_as_int(r0.w) > 6) {
-                    const float ci[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
-                    const float e[3] = {r0.x - tp[0], r0.y - tp[1], r0.z - tp[2]};
-                    const float nrm = sqrtf(sqn3_dev(e));
-                    const float w = ksq / (ksq + nrm * nrm);
-                    const float we[3] = {w * e[0], w * e[1], w * e[2]};
-                    float wc[3];
-                    for (int c = 0; c < 3; c++) wc[c] = sum3f(we[0] * ci[c], we[1] * ci[3 + c], we[2] * ci[6 + c]);
-                    v[28] = (double)sum3f(wc[0] * e[0], wc[1] * e[1], wc[2] * e[2]);
-                }
-            }
-        }
-    }
-    __shared__ __attribute__((aligned(16))) double stage[64][8][8];  // [point][offset][component of the chunk]
-    __shared__ __attribute__((aligned(16))) double red[NA][16];
-#pragma unroll
-    for (int ch = 0; ch < 4; ch++) {
-        if (ch * 8 >= NA) break;
-        {
-            double2* dst = reinterpret_cast<double2*>(&stage[pt][o][0]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) dst[k] = make_double2(v[ch * 8 + 2 * k], v[ch * 8 + 2 * k + 1]);
-        }
-        __syncthreads();
-        // lane (pt, cc = o): component ch * 8 + cc of this point, its seven offsets in offset order
-        double sp = 0.0;
-#pragma unroll
-        for (int oo = 0; oo < 7; oo++) sp += stage[pt][oo][o];
-        // the quad of four consecutive points: (P0 + P1) + (P2 + P3); their lanes sit 8 and 16 apart
-        sp += __shfl_xor(sp, 8);
-        sp += __shfl_xor(sp, 16);
-        const int comp = ch * 8 + o;
-        if ((pt & 3) == 0 && comp < NA) red[comp][pt >> 2] = sp;
-        __syncthreads();
-    }
-    if (tid < NA) {
-        const double2* row = reinterpret_cast<const double2*>(&red[tid][0]);
-        double sm = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const double2 q2 = row[k];
-            sm += q2.x;
-            sm += q2.y;
-        }
-        partial[(size_t)tid * pstride + blockIdx.x] = sm;
-    }
-    // the number of pairs of this evaluation: the block's count as one more component of its partial record
-    __shared__ uint32_t wcnt[kL8Threads / 64];
-    const unsigned long long fm = __ballot(found != kNoIdx);
-    if ((tid & 63) == 0) wcnt[tid >> 6] = (uint32_t)__popcll(fm);
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t c = 0;
-        for (int w = 0; w < kL8Threads / 64; w++) c += wcnt[w];
-        partial[(size_t)kNdtCnt * pstride + blockIdx.x] = (double)c;
-    }
-    (void)nd;
-}
+// (Measured in round 4 and not kept: EIGHT LANES PER SOURCE POINT for the single alignment -- lane (point, offset), the sums re-formed in this kernel's
+// order through LDS, bit-identical -- eight times the waves, a chain of one probe and one record per lane: 17.0 / 16.3 us per launch against 15-17 here.
+// The 782 waves of a 50 000-point source are not what bounds the kernel; tools/experiments/README.md has the numbers.)
 
 // ---- batched alignments: slot = one alignment (its own source scan and guess) against the ONE target, the Levenberg-Marquardt loop of
 // LsqRegistration (lsq.h) resident on the device.  A round = {cost kernel for the slots that linearise, cost kernel for the slots that try a
@@ -1049,7 +890,6 @@ struct lio_ndt {
     NdtOffsets offs;
     uint32_t* corr;  // [n_offsets][max_src]: the pairs of the last linearisation
     uint32_t* corr2; // the other buffer of the speculative evaluation (lio_ndt_align): the pairs at the trial pose, swapped in when the step is accepted
-    int l8;          // 1: single evaluations with DIRECT7 run eight lanes per source point (ndt_cost_l8_kernel; LIO_NDT_L8=0: one lane per point)
     int spec;        // 1: lio_ndt_align evaluates a trial pose and the linearisation that follows an accepted step in one launch (LIO_NDT_SPEC=0: two)
     uint32_t max_src, pstride;
     double* partial;
@@ -1131,10 +971,7 @@ int ndt_eval(lio_ndt* n, lio_scan* s, const double x_lin[16], const double x[16]
         else if (deriv) NDT_LAUNCH(false, true, NO);       \
         else NDT_LAUNCH(false, false, NO);                 \
     } while (0)
-    if (n->offs.n == 7 && n->l8 && update && deriv && memcmp(x_lin, x, sizeof(double) * 16) == 0)
-        hipLaunchKernelGGL((ndt_cost_l8_kernel<false>), blocks, kL8Threads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xx, s->ds_body, s->dev,
-                           static_cast<const uint32_t*>(nullptr), n->corr, n->max_src, n->partial, n->pstride, n->dev);
-    else if (n->offs.n == 1) NDT_DISPATCH(1);
+    if (n->offs.n == 1) NDT_DISPATCH(1);
     else if (n->offs.n == 7) NDT_DISPATCH(7);
     else NDT_DISPATCH(27);
 #undef NDT_DISPATCH
@@ -1178,10 +1015,7 @@ int ndt_eval_spec(lio_ndt* n, lio_scan* s, const double x[16], double* H, double
 #define NDT_SPEC(NO)                                                                                                                                    \
     hipLaunchKernelGGL((ndt_cost_spec_kernel<NO>), blocks, kNdtThreads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xx, s->ds_body, \
                        s->dev, n->corr, n->corr2, n->max_src, n->partial, n->pstride, n->dev)
-    if (n->offs.n == 7 && n->l8)
-        hipLaunchKernelGGL((ndt_cost_l8_kernel<true>), blocks, kL8Threads, 0, st, n->map->table, n->map->table_mask, n->vox, n->res, n->offs, xx, s->ds_body, s->dev,
-                           n->corr, n->corr2, n->max_src, n->partial, n->pstride, n->dev);
-    else if (n->offs.n == 1) NDT_SPEC(1);
+    if (n->offs.n == 1) NDT_SPEC(1);
     else if (n->offs.n == 7) NDT_SPEC(7);
     else NDT_SPEC(27);
 #undef NDT_SPEC
@@ -1230,7 +1064,6 @@ lio_ndt* lio_ndt_create(int device, float resolution, int search_method, uint64_
     n->max_points = max_points;
     n->stamp_cap = max_points;
     { const char* k = getenv("LIO_NDT_SPEC"); n->spec = (k && k[0] == '0') ? 0 : 1; }
-    { const char* k = getenv("LIO_NDT_L8"); n->l8 = (k && k[0] == '0') ? 0 : 1; }
     bool ok = hipMalloc(reinterpret_cast<void**>(&n->vox), (size_t)n->map->table_cap * sizeof(NdtVoxel)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->corr), (size_t)kNdtMaxOff * max_source_points * 4) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&n->corr2), (size_t)n->offs.n * max_source_points * 4) == hipSuccess &&
