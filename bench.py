@@ -46,24 +46,6 @@ def usable_cpus():
     return n
 
 
-def quat_from_R(R):
-    """rotation matrix -> (x, y, z, w), the branch with the largest pivot (a heading of 180 degrees has w = 0)"""
-    t = np.trace(R)
-    if t > 0:
-        w = np.sqrt(1.0 + t) / 2
-        q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
-    else:
-        i = int(np.argmax([R[0, 0], R[1, 1], R[2, 2]]))
-        j, k = (i + 1) % 3, (i + 2) % 3
-        r = np.sqrt(max(0.0, 1.0 + R[i, i] - R[j, j] - R[k, k])) / 2
-        q = np.zeros(4)
-        q[i] = r
-        q[j] = (R[j, i] + R[i, j]) / (4 * r)
-        q[k] = (R[k, i] + R[i, k]) / (4 * r)
-        q[3] = (R[k, j] - R[j, k]) / (4 * r)
-    return q / np.linalg.norm(q)
-
-
 def spawn_ranks(n):
     """re-run this command line as `n` ranks of torch.distributed.run on this node (what the docstring's second form does by hand)"""
     import socket
@@ -948,6 +930,7 @@ def stream_run(args, torch, local_rank):
     k_done = 0
     insert_leg = None
     timing_left = -1
+    last_states = []
     err_curve = []  # (metres driven, position error against the generating trajectory): odometry drift, no loop closure on this path
     for k in range(n):
         g0 = time.perf_counter()
@@ -972,6 +955,9 @@ def stream_run(args, torch, local_rank):
             dk = sk[0:3] - tr.R(0.0).T @ (tr.pos(tk) - tr.pos(0.0))
             err_curve.append([None if driven is None else round(driven, 1), round(float(np.linalg.norm(dk)), 3), round(float(dk[2]), 3)])
         e.flush()  # after the clock: the scan's map_incremental was enqueued, not waited for (its count, and an overflow, are read here)
+        last_states.append((k, e.get_state()))  # (the engine's own poses of the last sweeps: the priors of the kNN leg on the grown map)
+        if len(last_states) > 32:
+            last_states.pop(0)
         if timing_left > 0:  # the insert-side roofline leg: per-stage HIP events on (these sweeps are not in the ms/scan figure)
             if rc == capi.MAIN_UPDATED:
                 tm = e.timings()
@@ -1002,21 +988,17 @@ def stream_run(args, torch, local_rank):
     # ---- the stencil search on THIS map (grown by map_incremental: a few points per voxel, not the 39 of the metric config's pre-built one): the last
     # sweeps once more as independent jobs of a 16-slot batch against the engine's map, HIP events per kernel class, then the counting variant
     knn_grown = None
-    if tr is not None and k_done > 40:
+    if len(last_states) >= 16:
         try:
             e.flush()
             S = 19
             d_sw, jb = [], []
             P0 = lio.init_cov()
-            R0, p0 = tr.R(0.0), tr.pos(0.0)
-            for k in range(k_done - 32, k_done):
+            for k, st_k in last_states:  # the prior of a job: the engine's own state after that sweep (the map lives in ITS frame, drift included)
                 p, _ = get_sweep(k)
                 d = torch.from_numpy(p).to(dev)
                 d_sw.append(d)
-                tm_ = k * 0.1 + 0.05  # the pose half-way through the sweep, in the frame of the first pose (the engine's map frame)
-                Rk, pk = R0.T @ tr.R(tm_), R0.T @ (tr.pos(tm_) - p0)
-                qk = quat_from_R(Rk)
-                jb.append(dict(dptr=d.data_ptr(), n=len(p), t=1.0 + 0.1 * k, state=synth.state_from_pose(pk, qk), cov=P0))
+                jb.append(dict(dptr=d.data_ptr(), n=len(p), t=1.0 + 0.1 * k, state=st_k, cov=P0))
             torch.cuda.synchronize()
             solo = lio.Batch(e.map, n_slots=16, n_groups=1, max_raw=1 << 18, max_ds=100000)
             solo.process(jb[:16])
