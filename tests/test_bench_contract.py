@@ -10,7 +10,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r02_bench.json", "r03_bench.json"])
+@pytest.mark.parametrize("name", ["r02_bench.json", "r03_bench.json", "r04_bench.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     j = json.loads(open(os.path.join(ROOT, "profiles", name)).read())
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
@@ -58,6 +58,45 @@ def test_round3_line_carries_the_parity_of_the_timed_path_and_every_config():
             assert t["ms_per_scan"] < 0.5 * c["config4_localize_5e7_map"][case]["ms_per_scan"] and 0 < t["roofline"]["frac"] < 1
     m = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_merge.json")).read())
     assert m["n_gpus"] == 1 and "NOT measured" in m["collective"]["backend"] and m["collective"]["states_identical_on_all_ranks"] is True
+
+
+def test_round4_line_is_measured_on_varied_inputs_and_says_what_bounds_the_kernel():
+    """what VERDICT r03 asked of the driver-run line: a pool of >= 128 scans spread over the map with round 3's pool beside it, the dominant kernel
+    labelled by what bounds it (VALU issue) with the PMC instruction count, timed_region, configs 2 and 5 with their own roofline + baseline,
+    the kNN figures on the map config 3 grows, the pooled scans against the reference's pinned build"""
+    j = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read())
+    assert j["config"]["scan_pool"] >= 128 and j["config"]["spread_m"] >= 90.0
+    assert j["rccl_ranks"] == j["n_gpus"] == 1 and j["collective"] is None
+    r = j["roofline"]
+    assert r["bound"] == "valu" and abs(r["timed_region"] - j["timed_seconds"]) < 1e-9 and r["timed_region"] > 3.0
+    v = r["valu"]
+    assert v["source"].startswith("PMC") and 0.3 < v["frac_of_valu_issue_peak"] < 1.0
+    assert abs(v["frac_of_valu_issue_peak"] - v["issue_bound_us"] / r["avg_launch_us"]) < 2e-3
+    assert r["traffic"] and r["frac_hbm_traffic"] < r["frac_touched"] < r["frac"]
+    assert r["whole_scan"]["terms"]["B_ins"] == 0
+    b = j["batch_vs_oracle_pose"]
+    assert b["scans_checked"] == 128 and b["parity_ok"] and b["all_timed_results_bit_identical_to_the_checked_ones"] and b["max_dpos_m"] < 1e-9
+    g = j["cpu_baseline"]["gpu_vs_reference_pose"]
+    pinned = g["pinned_build"]["neighbour_lists_in_canonical_order"]
+    assert pinned["median_dpos_m"] < 1e-12  # the same bits as the reference's own code, except ...
+    left = g["pinned_build"]["what_is_left_in_canonical_order"]
+    # ... where the reference breaks an exact f32 tie at the fifth-nearest boundary its own (implementation-defined) way: reported, with the tie
+    for m in left["their_members"]:
+        assert m["only_in_oracle_d2"] == m["only_in_reference_d2"]
+    assert pinned["scans_beyond_1e_4_m_or_1e_5_rad"] == len({left["scan"]}) == 1
+    c = j["configs"]
+    p8 = c["pool8_one_spot"]
+    assert p8["roofline"]["bound"] == "valu" and p8["ms_per_scan"] > j["ms_per_step"] * 0.8
+    for k in ("config2_1e6_map", "config5_merge_8_submaps_1_gpu"):
+        assert c[k]["roofline"]["bound"] == "valu" and c[k]["roofline"]["frac"] > 0 and c[k]["cpu_baseline"]["kind"] == "reference", k
+        assert c[k]["cpu_baseline"]["value"] > 0 and c[k]["cpu_baseline"]["unit"] == "points/s"
+    for k in ("config3_stream_to_1e7_points", "config3_stream_lru_1e5_300_sweeps"):
+        kk = c[k]["knn_on_this_map"]
+        assert kk["candidates_per_query"] > 5 and kk["touched_per_query"] <= kk["candidates_per_query"] and kk["registered"] >= 16, k
+        assert c[k]["cpu_baseline"]["kind"] == "reference" and c[k]["cpu_baseline"]["ms_per_scan"] > 10 * c[k]["ms_per_scan"]
+    assert c["config3_stream_lru_1e5_300_sweeps"]["cpu_baseline"]["sweeps_with_the_reference_map_at_capacity"] > 50
+    c4 = c["config4_localize_5e7_map"]
+    assert c4["scan_pool"] >= 32 and c4["local_200k_map"]["ms_per_scan"] < 0.3
 
 
 def test_bench_defaults_are_the_drivers_assumptions():
