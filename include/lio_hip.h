@@ -377,7 +377,8 @@ int lio_engine_joint_register_device(lio_engine* e, const void* d_raw_body_xyzi,
  * Intended for engines created with lio_engine_create_shared on one read-only map (independent scans of several
  * sensors / sequences, relocalisation candidates, map-merge alignments). */
 #define LIO_JOB_KEEP_CACHE 1u
-#define LIO_JOB_FLAGS_KNOWN 1u  /* every other bit must be zero: a job with unknown bits is rejected (rc = LIO_E_INVALID), so that an uninitialised
+#define LIO_JOB_IDLE 2u         /* lio_batch_sequences_step: the session of this job has no scan this round (rc = 0, nothing else is looked at) */
+#define LIO_JOB_FLAGS_KNOWN 3u  /* every other bit must be zero: a job with unknown bits is rejected (rc = LIO_E_INVALID), so that an uninitialised
                                    word cannot silently pick a behaviour */
 typedef struct lio_scan_job {
     const void* d_raw;          /* device pointer, XYZI float4 */
@@ -430,6 +431,23 @@ lio_batch* lio_batch_create_joint(lio_map** sub_maps, int n_sub_maps, lio_comm* 
  * LIO_E_STATE in this mode. */
 typedef int (*lio_gather_fn)(void* ctx, const double* d_local, double* d_gathered, uint32_t n_records, void* stream);
 int lio_batch_set_gather_hook(lio_batch*, lio_gather_fn fn, void* ctx, int rank, int world);
+/* Sequence mode: throughput WITH map_incremental.  n_groups x n_slots independent SLAM sessions (replay of recorded drives, offline mapping of many
+ * sequences), one per slot, each with ITS OWN map (lio_engine_create's arguments, per session).  lio_batch_sequences_step takes exactly one job per
+ * session -- job j is the NEXT scan of session j = (group j / n_slots, slot j % n_slots): state_in / cov_in the propagated prior as for every
+ * lio_scan_job, LIO_JOB_IDLE for a session without a scan this round -- and runs, per group, fastlio_main from the downsample to map_incremental
+ * (src/laserMapping.cpp:1193-1304) as ONE blind submission: voxel-grid chain, (maximum_iter + 1) x {stencil kNN against the slot's own map,
+ * linearisation, filter pass on the device}, then for every slot whose update finished classify + IVox::AddPoints (+ the LRU list) -- every launch
+ * serves all slots (blockIdx.y = slot).  SURVEY 8d's B_ins, which the static batch leaves out, is inside the round.  The file-scope state of
+ * laserMapping.cpp (first_lidar_time, flg_EKF_inited, travel, the stencil switch at 10 x INIT_TIME) lives in the slot's engine
+ * (lio_batch_engine(b, group, slot); its map: lio_engine_map).  Scans a round cannot take go through that engine's own code -- a session's first
+ * scan (only its time is kept, rc 0) and its map seed (rc 1), a scan whose pass needs the dense N_eff < 23 branch, a bounding box that needs more
+ * radix passes than were launched -- so a session driven here and the same scans pushed one by one through lio_engine_set_state / set_cov /
+ * lio_engine_process_scan_device on an engine with lio_engine_set_device_loop(e, 1) give the same bits (tests/test_sequence_batch_gpu.py).
+ * rc per job as lio_engine_process_scan; state_out and cov_out[j * 529 ..] (may be NULL) receive the posterior (the prior where nothing was
+ * registered).  The pass logs of a scan registered inside a round stay on the device (lio_engine_pass_log of the slot's engine is empty). */
+lio_batch* lio_batch_create_sequences(int device, float resolution, int stencil, uint64_t max_points, uint64_t max_voxels, int n_slots, int n_groups,
+                                      uint32_t max_raw, uint32_t max_ds);
+int lio_batch_sequences_step(lio_batch*, lio_scan_job* jobs, int n_jobs, double* cov_out);
 void lio_batch_destroy(lio_batch*);
 int lio_batch_process(lio_batch*, lio_scan_job* jobs, int n_jobs);
 /* live kernel timing of the batched chain with HIP events on the groups' streams (bench.py's roofline leg): per class the summed device
@@ -438,6 +456,8 @@ int lio_batch_process(lio_batch*, lio_scan_job* jobs, int n_jobs);
 typedef struct lio_batch_times {
     double downsample_us, knn_us, linearize_us, step_us;
     uint32_t downsample_launches, knn_launches, linearize_launches, step_launches;
+    double insert_us;            /* sequence mode: the map_incremental half of a round (classify + AddPoints + LRU + read-back records); appended in round 4 */
+    uint32_t insert_launches, pad;
 } lio_batch_times;
 /* on: 0 off, 1 timing, 2 (or 3) timing with the counting variant of the kNN kernel (lio_map_knn_touched) -- times of that variant are not
  * the product's */

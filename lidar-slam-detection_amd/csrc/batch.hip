@@ -22,6 +22,15 @@ void engine_count_passes(lio_engine* e, int* n_pass, int* n_knn);
 int engine_joint_register_device(lio_engine* e, const void* d_raw, uint32_t n_raw, double lidar_beg_time, double state26[26], double cov[529]);
 struct lio_comm;
 extern "C" int lio_comm_world(const lio_comm*);
+extern "C" {  // engine.hip: the host half of fastlio_main around a sequence round
+int engine_seq_prepare(lio_engine* e, uint32_t n_raw, double lidar_beg_time, int* ekf_inited);
+void engine_seq_params(lio_engine* e, double* laser_cov, int* maximum_iter, int* degenerate_detect_en, float* leaf_surf, float* leaf_map, int* static_map,
+                       double* travel, double last_pos_lid[3]);
+int engine_seq_finish(lio_engine* e, const double x26[26], const double P529[529], int n_ds, int n_pass, int n_knn, int n_eff, int degenerate, int inserted,
+                      uint32_t n_add, uint32_t map_err, uint32_t bound);
+int engine_seq_resume(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t);
+int engine_seq_has_lru(lio_engine* e);
+}
 
 namespace {
 
@@ -44,6 +53,13 @@ struct Group {
     lio_batch_result* h_res = nullptr;   // pinned, mapped
     lio_batch_result* h_res_dev = nullptr;
     std::vector<int> job_of_slot;
+    // sequence mode: the slots' own maps as the kernels see them (part of the uploaded block), the insert half's records (device + pinned copy)
+    MapRef* d_maps = nullptr;
+    MapRef* h_maps = nullptr;
+    SeqDev* d_seq = nullptr;
+    SeqDev* h_seq = nullptr;
+    std::vector<int> seq_path;           // per slot, this round: what engine_seq_prepare said (0, 2, 10, 11) or < 0
+    int any_lru = 0;
     int n_active = 0;
     int launched_passes = 4;
     uint32_t seq = 0;
@@ -69,6 +85,7 @@ struct lio_batch {
     int (*gather_hook)(void*, const double*, double*, uint32_t, void*) = nullptr;  // lio_batch_set_gather_hook
     void* gather_ctx = nullptr;
     bool joint = false;
+    bool sequences = false;  // lio_batch_create_sequences: every slot is a SLAM session with its own map (the slot's engine owns it)
     std::vector<Group> groups;
     double t_submit = 0, t_wait = 0, t_collect = 0;  // host seconds (LIO_BATCH_PROFILE=1 prints them when the object is destroyed)
     uint64_t n_rounds = 0;
@@ -111,6 +128,8 @@ void group_free(Group& g) {
         if (g.exec[k]) hipGraphExecDestroy(g.exec[k]);
     if (g.d_block) hipFree(g.d_block);
     if (g.h_block) hipHostFree(g.h_block);
+    if (g.d_seq) hipFree(g.d_seq);
+    if (g.h_seq) hipHostFree(g.h_seq);
     if (g.h_res) hipHostFree(g.h_res);
     if (g.stream) hipStreamDestroy(g.stream);
     if (g.bt) {
@@ -137,6 +156,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         g.job_of_slot[s] = first + s;
         job.rc = LIO_E_INVALID;
         job.n_ds = job.n_pass = job.n_knn_pass = 0;
+        if (job.flags & LIO_JOB_IDLE) { job.rc = 0; g.job_of_slot[s] = -1; continue; }  // (a session without a scan, sequence mode's marker: nothing to do here either)
         if (!job.state_in || !job.cov_in || (!job.d_raw && job.n_raw)) continue;
         if (job.flags & ~LIO_JOB_FLAGS_KNOWN) { set_error("lio_scan_job.flags = 0x%x: unknown bits (a job array that was not zero-initialised?)", job.flags); continue; }
         if (job.n_raw > b->max_raw) { set_error("scan of %u points exceeds max_raw %u", job.n_raw, b->max_raw); job.rc = LIO_E_CAPACITY; continue; }
@@ -377,6 +397,8 @@ int lio_batch_kernel_times(lio_batch* b, lio_batch_times* out, int reset) {
         out->downsample_us += g.bt->us[0]; out->knn_us += g.bt->us[1]; out->linearize_us += g.bt->us[2]; out->step_us += g.bt->us[3];
         out->downsample_launches += g.bt->launches[0]; out->knn_launches += g.bt->launches[1]; out->linearize_launches += g.bt->launches[2];
         out->step_launches += g.bt->launches[3];
+        out->insert_us += g.bt->us[4];
+        out->insert_launches += g.bt->launches[4];
         if (reset)
             for (int c = 0; c < BatchTimer::kClasses; c++) { g.bt->us[c] = 0; g.bt->launches[c] = 0; }
     }
@@ -390,6 +412,7 @@ lio_engine* lio_batch_engine(lio_batch* b, int group, int slot) {
 
 int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
     if (!b || (!jobs && n_jobs) || n_jobs < 0) return LIO_E_INVALID;
+    if (b->sequences) { set_error("lio_batch_process: a sequence batch is driven by lio_batch_sequences_step"); return LIO_E_STATE; }
     hipSetDevice(b->device);
     const int B = b->n_slots;
     int next = 0, first_err = 0;
@@ -519,6 +542,262 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
         collect(g);
     }
     for (const int j : retry) { jobs[j].rc = LIO_E_DEVICE; note(LIO_E_DEVICE); }
+    return first_err;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sequence mode: B x G independent SLAM sessions, one per slot, each with ITS OWN map (the slot's engine owns it).  A step registers the next
+// scan of every session and inserts it into the session's map -- fastlio_main from the downsample to map_incremental (laserMapping.cpp:
+// 1193-1304) -- as one blind submission per group: the voxel-grid chain, (maximum_iter + 1) x {stencil kNN against the slot's own map,
+// linearisation, filter pass}, then classify + AddPoints (+ LRU) for every slot whose update finished, all with blockIdx.y = slot.  What the
+// static batch leaves out (SURVEY 8d's B_ins) is inside the round here.  Scans the round cannot take -- a session's first scans (time origin,
+// map seed), a scan whose update needs the host filter (1 <= N_eff < 23), a bounding box that needs more radix passes than were launched --
+// go through the slot's engine, i.e. through lio_engine_process_scan_device's own code: a session driven here and one driven scan by scan
+// through an engine with the device loop on (lio_engine_set_device_loop) run the same kernels on the same data.
+static void fill_mapref(MapRef& r, const lio_map* m) {
+    r.table = m->table; r.cap = m->cap; r.pending = m->pending; r.created = m->created; r.pool = m->pool; r.md = m->dev;
+    r.slot_of_point = m->slot_of_point; r.stage = m->stage; r.pool_cap = m->pool_cap;
+    r.touch = m->touch; r.prev_touch = m->prev_touch; r.lru_log = m->lru_log; r.log_mask = m->lru_log_cap ? m->lru_log_cap - 1 : 0;
+    r.free_items = m->free_items; r.free_in = m->free_in; r.free_cap = m->free_cap;
+    r.lru_capacity = (uint32_t)m->lru_capacity; r.lru_max_distance = m->lru_max_distance;
+    r.mask = m->table_mask; r.inv_res = m->inv_res; r.res = m->res; r.key_mode = m->key_mode; r.max_voxels = (uint32_t)m->max_voxels;
+    r.stencil_id = m->stencil_id;
+}
+
+lio_batch* lio_batch_create_sequences(int device, float resolution, int stencil, uint64_t max_points, uint64_t max_voxels, int n_slots, int n_groups,
+                                      uint32_t max_raw, uint32_t max_ds) {
+    if (n_slots < 1 || n_slots > 256 || n_groups < 1 || n_groups > 8 || max_raw == 0 || max_ds == 0 || max_points == 0 || max_voxels == 0) {
+        set_error("lio_batch_create_sequences: bad argument");
+        return nullptr;
+    }
+    const uint32_t ds_bound = max_raw < max_ds ? max_raw : max_ds;
+    if (ds_bound > max_points || ds_bound > (1u << 20)) { set_error("lio_batch_create_sequences: a scan's %u downsampled points exceed the maps' insert scratch", ds_bound); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("lio_batch_create_sequences: no HIP device %d", device); return nullptr; }
+    lio_batch* b = new lio_batch();
+    b->device = device;
+    b->n_slots = n_slots;
+    b->max_raw = max_raw;
+    b->max_ds = max_ds;
+    b->sequences = true;
+    b->groups.resize(n_groups);
+    bool ok = true;
+    for (Group& g : b->groups) ok = ok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess;
+    for (Group& g : b->groups) {
+        g.job_of_slot.assign(n_slots, -1);
+        g.seq_path.assign(n_slots, 0);
+        const size_t desc_bytes = sizeof(SlotDesc) * (size_t)n_slots, ctrl_bytes = sizeof(EskfDev) * (size_t)n_slots;
+        g.block_bytes = desc_bytes + ctrl_bytes + sizeof(MapRef) * (size_t)n_slots;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_block), g.block_bytes) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_block), g.block_bytes, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&g.d_seq), sizeof(SeqDev) * (size_t)n_slots) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_seq), sizeof(SeqDev) * (size_t)n_slots, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g.h_res), sizeof(lio_batch_result) * n_slots, hipHostMallocMapped) == hipSuccess;
+        ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&g.h_res_dev), g.h_res, 0) == hipSuccess;
+        if (!ok) break;
+        g.d_desc = reinterpret_cast<SlotDesc*>(g.d_block);
+        g.h_desc = reinterpret_cast<SlotDesc*>(g.h_block);
+        g.d_ctrl = reinterpret_cast<EskfDev*>(g.d_block + desc_bytes);
+        g.h_ctrl = reinterpret_cast<EskfDev*>(g.h_block + desc_bytes);
+        g.d_maps = reinterpret_cast<MapRef*>(g.d_block + desc_bytes + ctrl_bytes);
+        g.h_maps = reinterpret_cast<MapRef*>(g.h_block + desc_bytes + ctrl_bytes);
+        memset(g.h_block, 0, g.block_bytes);
+        memset(g.h_res, 0, sizeof(lio_batch_result) * n_slots);
+        memset(g.h_seq, 0, sizeof(SeqDev) * (size_t)n_slots);
+        ok = hipMemset(g.d_block, 0, g.block_bytes) == hipSuccess && hipMemset(g.d_seq, 0, sizeof(SeqDev) * (size_t)n_slots) == hipSuccess;
+        for (int s = 0; s < n_slots && ok; s++) {
+            lio_engine* e = lio_engine_create(device, resolution, stencil, max_points, max_voxels, max_raw, max_ds);
+            if (!e) { ok = false; break; }
+            lio_engine_set_device_loop(e, 1);  // the scans the round cannot take run the same filter kernels
+            g.eng.push_back(e);
+            fill_desc(g.h_desc[s], lio_engine_scan(e), &g.d_ctrl[s], &g.h_res_dev[s]);
+        }
+    }
+    if (!ok) {
+        set_error("lio_batch_create_sequences: device setup failed: %s", hipGetErrorString(hipGetLastError()));
+        lio_batch_destroy(b);
+        return nullptr;
+    }
+    b->map = lio_engine_map(b->groups[0].eng[0]);  // (what the accessors of the static batch expect to be non-null)
+    return b;
+}
+
+int lio_batch_sequences_step(lio_batch* b, lio_scan_job* jobs, int n_jobs, double* cov_out) {
+    if (!b || !jobs) return LIO_E_INVALID;
+    if (!b->sequences) { set_error("lio_batch_sequences_step: for a batch made by lio_batch_create_sequences"); return LIO_E_STATE; }
+    const int B = b->n_slots, G = (int)b->groups.size();
+    if (n_jobs != B * G) { set_error("lio_batch_sequences_step: %d jobs for %d sessions (job j is the next scan of session j; LIO_JOB_IDLE marks a session without one)", n_jobs, B * G); return LIO_E_INVALID; }
+    hipSetDevice(b->device);
+    int first_err = 0;
+    auto note = [&](int rc) { if (rc < 0 && !first_err) first_err = rc; };
+    const uint32_t ds_bound = b->max_raw < b->max_ds ? b->max_raw : b->max_ds;
+    const int passes = b->pred_passes;
+    // ---- submit: one round per group ----
+    for (int gi = 0; gi < G; gi++) {
+        Group& g = b->groups[gi];
+        g.seq++;
+        g.n_active = 0;
+        g.max_n_raw = 0;
+        g.launched_passes = passes;
+        g.any_lru = 0;
+        StencilArgs stencils[4];
+        int stencil_ids[4], n_st = 0;
+        for (int s = 0; s < B; s++) {
+            SlotDesc& d = g.h_desc[s];
+            d.active = 0;
+            g.job_of_slot[s] = gi * B + s;
+            g.seq_path[s] = -1000;
+            lio_scan_job& job = jobs[gi * B + s];
+            job.n_ds = job.n_pass = job.n_knn_pass = 0;
+            if (job.flags & LIO_JOB_IDLE) { job.rc = 0; g.job_of_slot[s] = -1; continue; }
+            job.rc = LIO_E_INVALID;
+            if (!job.state_in || !job.cov_in || (!job.d_raw && job.n_raw)) { note(job.rc); continue; }
+            if (job.flags & ~LIO_JOB_FLAGS_KNOWN) { set_error("lio_scan_job.flags = 0x%x: unknown bits (a job array that was not zero-initialised?)", job.flags); note(job.rc); continue; }
+            if (job.n_raw > b->max_raw) { set_error("scan of %u points exceeds max_raw %u", job.n_raw, b->max_raw); job.rc = LIO_E_CAPACITY; note(job.rc); continue; }
+            lio_engine* e = g.eng[s];
+            int ekf_inited = 0;
+            const int path = engine_seq_prepare(e, job.n_raw, job.lidar_beg_time, &ekf_inited);
+            g.seq_path[s] = path;
+            if (path < 0) { job.rc = path; note(path); continue; }
+            if (path == 0 || path == 2) { job.rc = path; if (job.state_out) memcpy(job.state_out, job.state_in, sizeof(double) * 26); if (cov_out) memcpy(cov_out + (size_t)(gi * B + s) * 529, job.cov_in, sizeof(double) * 529); continue; }
+            if (path == 10) {  // the engine's own path: downsample + map seed (nothing is registered yet)
+                lio_engine_set_state(e, job.state_in);
+                lio_engine_set_cov(e, job.cov_in);
+                const int rc = lio_engine_process_scan_device(e, job.d_raw, job.n_raw, job.lidar_beg_time);
+                job.rc = rc;
+                note(rc);
+                if (rc >= 0) {
+                    lio_timings tm;
+                    lio_engine_timings(e, &tm);
+                    job.n_ds = tm.n_ds; job.n_pass = tm.n_pass; job.n_knn_pass = tm.n_knn_pass;
+                    if (job.state_out) lio_engine_get_state(e, job.state_out);
+                    if (cov_out) lio_engine_get_cov(e, cov_out + (size_t)(gi * B + s) * 529);
+                }
+                continue;
+            }
+            // path 11: a slot of the round
+            lio_map* m = lio_engine_map(e);
+            double laser_cov = 0.001, travel = 0, last_pos_lid[3];
+            int maximum_iter = 4, deg_en = 1, static_map = 0;
+            float leaf_surf = 0.5f, leaf_map = 0.5f;
+            engine_seq_params(e, &laser_cov, &maximum_iter, &deg_en, &leaf_surf, &leaf_map, &static_map, &travel, last_pos_lid);
+            if (leaf_surf != 0.5f || maximum_iter != 4) { set_error("sequence batch: the round is built for filter_size_surf 0.5 and NUM_MAX_ITERATIONS 4"); job.rc = LIO_E_STATE; note(job.rc); g.seq_path[s] = LIO_E_STATE; continue; }
+            if (m->lru_capacity && m->tomb_bound > m->table_cap / 4) {  // (map_insert_dev's rule) tombstones of evicted voxels: rebuild the table first
+                const int rc = map_rebuild(m, g.stream);
+                if (rc != LIO_OK) { job.rc = rc; note(rc); g.seq_path[s] = rc; continue; }
+            }
+            d.raw = static_cast<const float4*>(job.d_raw);
+            d.n_raw = job.n_raw;
+            d.nblocks = (job.n_raw + 2047u) / 2048u;
+            d.active = 1;
+            d.seq = g.seq;
+            d.min_ds = 5;
+            d.reset_cache = 0;  // a session: Nearest_Points survives from scan to scan
+            fill_ctrl(g.h_ctrl[s], job.state_in, job.cov_in, laser_cov, maximum_iter, deg_en, 0);
+            MapRef& r = g.h_maps[s];
+            fill_mapref(r, m);
+            r.stamp_base = (unsigned long long)(m->n_batches + 1) << kStampIdxBits;
+            r.do_insert = static_map ? 0u : 1u;
+            r.ekf_inited = (uint32_t)ekf_inited;
+            r.map_leaf = leaf_map;
+            r.travel_prev = travel;
+            for (int i = 0; i < 3; i++) r.last_pos_lid[i] = last_pos_lid[i];
+            if (m->lru_capacity) g.any_lru = 1;
+            int k = 0;
+            while (k < n_st && stencil_ids[k] != m->stencil_id) k++;
+            if (k == n_st && n_st < 4) { stencils[n_st] = m->stencil; stencil_ids[n_st] = m->stencil_id; n_st++; }
+            else if (k == n_st) { set_error("sequence batch: more than four different stencils in one round"); job.rc = LIO_E_STATE; note(job.rc); d.active = 0; g.seq_path[s] = LIO_E_STATE; continue; }
+            g.h_res[s].seq = g.seq - 1;
+            g.n_active++;
+            if (job.n_raw > g.max_n_raw) g.max_n_raw = job.n_raw;
+        }
+        if (g.n_active == 0) continue;
+        const bool timed = g.bt && g.bt->on;
+        BatchTimer* bt = timed ? g.bt : nullptr;
+        LIO_HIP_TRY(hipMemcpyAsync(g.d_block, g.h_block, g.block_bytes, hipMemcpyHostToDevice, g.stream));
+        if (bt) bt->begin(0);
+        int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes);
+        if (bt) bt->end(0);
+        if (rc == LIO_OK) rc = p2plane_seq_update(g.stream, g.d_maps, g.d_desc, B, ds_bound, 5, stencils, stencil_ids, n_st, bt);
+        if (bt) bt->begin(4);
+        if (rc == LIO_OK) rc = p2plane_seq_insert(g.stream, g.d_maps, g.d_desc, g.d_seq, B, ds_bound, g.any_lru);
+        if (bt) bt->end(4);
+        if (rc != LIO_OK) { for (int k = 0; k <= gi; k++) hipStreamSynchronize(b->groups[k].stream); return rc; }
+        LIO_HIP_TRY(hipMemcpyAsync(g.h_seq, g.d_seq, sizeof(SeqDev) * (size_t)B, hipMemcpyDeviceToHost, g.stream));
+        b->n_rounds++;
+    }
+    // ---- collect ----
+    int need_max = 1;
+    for (int gi = 0; gi < G; gi++) {
+        Group& g = b->groups[gi];
+        if (g.n_active == 0) continue;
+        LIO_HIP_TRY(hipStreamSynchronize(g.stream));
+        if (g.bt && g.bt->on) g.bt->resolve();
+        for (int s = 0; s < B; s++) {
+            if (!g.h_desc[s].active) continue;
+            lio_scan_job& job = jobs[gi * B + s];
+            const lio_batch_result& r = g.h_res[s];
+            const SeqDev& q = g.h_seq[s];
+            lio_engine* e = g.eng[s];
+            lio_scan* sc = lio_engine_scan(e);
+            double* cov_dst = cov_out ? cov_out + (size_t)(gi * B + s) * 529 : nullptr;
+            if (r.seq != g.seq) { set_error("sequence batch: slot %d did not report", s); job.rc = LIO_E_DEVICE; note(job.rc); continue; }
+            if (r.radix_passes > need_max) need_max = r.radix_passes;
+            if (r.radix_passes > g.launched_passes) {
+                // the bounding box needs more radix passes than the round launched: nothing was registered or inserted (the chain reports an empty
+                // cloud); the scan goes through the engine's own path, which launches what it needs
+                lio_engine_set_state(e, job.state_in);
+                lio_engine_set_cov(e, job.cov_in);
+                const int rc = lio_engine_process_scan_device(e, job.d_raw, job.n_raw, job.lidar_beg_time);
+                job.rc = rc;
+                note(rc);
+                if (rc >= 0) {
+                    lio_timings tm;
+                    lio_engine_timings(e, &tm);
+                    job.n_ds = tm.n_ds; job.n_pass = tm.n_pass; job.n_knn_pass = tm.n_knn_pass;
+                    if (job.state_out) lio_engine_get_state(e, job.state_out);
+                    if (cov_dst) lio_engine_get_cov(e, cov_dst);
+                }
+                continue;
+            }
+            sc->have_ds = r.n_ds;
+            sc->n_raw = g.h_desc[s].n_raw;
+            job.n_ds = r.n_ds;
+            job.n_pass = r.n_pass;
+            job.n_knn_pass = r.n_knn_pass;
+            if (r.err & 1) {
+                set_error("downsampled scan exceeds max_ds %u", b->max_ds);
+                hipMemsetAsync(&sc->dev->err, 0, 4, g.stream);
+                job.rc = LIO_E_CAPACITY;
+                note(job.rc);
+                continue;
+            }
+            if (r.status == EK_SKIPPED) {  // fewer than five downsampled points: nothing is registered (laserMapping.cpp:1246)
+                job.rc = 2;
+                if (job.state_out) memcpy(job.state_out, job.state_in, sizeof(double) * 26);
+                if (cov_dst) memcpy(cov_dst, job.cov_in, sizeof(double) * 529);
+                continue;
+            }
+            if (r.status == EK_NEEDS_HOST) {
+                const int rc = engine_seq_resume(e, r.state, job.state_in, job.cov_in, r.loop_i, r.loop_converge, r.loop_t);
+                if (rc < 0) { job.rc = rc; note(rc); continue; }
+                int np = 0, nk = 0;
+                engine_count_passes(e, &np, &nk);
+                job.n_pass += np;
+                job.n_knn_pass += nk;
+                if (job.state_out) lio_engine_get_state(e, job.state_out);
+                if (cov_dst) lio_engine_get_cov(e, cov_dst);
+                job.rc = rc;
+                continue;
+            }
+            const int rc = engine_seq_finish(e, r.state, q.P, r.n_ds, r.n_pass, r.n_knn_pass, r.n_eff, r.degenerate, (int)q.go, q.n_add, q.go ? q.map_err : 0u, (uint32_t)r.n_ds /* map_insert_dev's n on the engine's own path */);
+            if (job.state_out) memcpy(job.state_out, r.state, sizeof(double) * 26);
+            if (cov_dst) memcpy(cov_dst, q.P, sizeof(double) * 529);
+            job.rc = rc;
+            note(rc);
+        }
+    }
+    if (need_max > 4) need_max = 4;
+    b->pred_passes = need_max;
     return first_err;
 }
 

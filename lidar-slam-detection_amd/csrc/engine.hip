@@ -734,6 +734,7 @@ int lio_engine_flush(lio_engine* e) {
 }
 
 static int process_core(lio_engine* e, double lidar_beg_time);
+static int after_update(lio_engine* e, std::chrono::steady_clock::time_point w0);
 static int process_common(lio_engine* e, double lidar_beg_time) {
     memset(&e->tm, 0, sizeof(e->tm));
     e->n_added_pending = false;
@@ -790,6 +791,14 @@ static int process_core(lio_engine* e, double lidar_beg_time) {
     if (n_ds < 5) return 2;
     rc = run_update(e);
     if (rc != LIO_OK) return rc;
+    return after_update(e, w0);
+}
+// fastlio_main after the filter update (laserMapping.cpp:1288-1304): travel distance of the lidar origin, map_incremental
+static int after_update(lio_engine* e, std::chrono::steady_clock::time_point w0) {
+    lio_scan* s = e->scan;
+    double pose[7], ext[7];
+    int rc = LIO_OK;
+    hipEvent_t t0, t1;
     // travel distance of the lidar origin (laserMapping.cpp:1288-1291)
     double off[3];
     quat_rotate(e->kf.x.rot, e->kf.x.til, off);
@@ -831,6 +840,98 @@ static int process_core(lio_engine* e, double lidar_beg_time) {
     return 3;
 }
 
+// ---- sequence mode of the batched engine (batch.hip: lio_batch_create_sequences): the host half of fastlio_main around a round.  Internal (not in
+// include/lio_hip.h).  A slot's engine owns the session's map and its file-scope state (first_lidar_time, travel, flags); the round does on the
+// device what process_core does between the downsample and map_incremental, for B sessions at once. ---------------------------------------------
+// Before the round: process_common + process_core up to the update.  Returns < 0 on error, 0 = the session's first scan (only its time is kept:
+// laserMapping.cpp:1171-1177), 2 = empty scan, 10 = this scan goes through the engine's own path (the map is not seeded yet: downsample + seed),
+// 11 = the scan takes a slot of the round (ekf_inited / the map's stencil are settled here).
+int engine_seq_prepare(lio_engine* e, uint32_t n_raw, double lidar_beg_time, int* ekf_inited) {
+    if (!e) return LIO_E_INVALID;
+    if (e->reduce || e->joint || e->timing || e->wheelspeed_en || e->kf.maximum_iter + 1 > kEkMaxPass) {
+        set_error("sequence batch: an engine with a reduce hook, joint registration, per-scan timing or wheel-speed rows runs on its own path only");
+        return LIO_E_STATE;
+    }
+    const int rc_prev = map_settle(e->map);  // an insert this engine's own path left running on the map's stream (the scan before this one went that way)
+    if (rc_prev != LIO_OK) return rc_prev;
+    if (e->flg_first_scan) {
+        memset(&e->tm, 0, sizeof(e->tm));
+        e->n_added_pending = false;
+        e->first_lidar_time = lidar_beg_time;
+        e->flg_first_scan = false;
+        return 0;
+    }
+    if (n_raw == 0) { memset(&e->tm, 0, sizeof(e->tm)); e->n_added_pending = false; return 2; }
+    if (!e->map_seeded) {
+        uint64_t nv = 0;
+        const int rc = lio_map_stats(e->map, nullptr, &nv);
+        if (rc != LIO_OK) return rc;
+        e->map_seeded = nv != 0;
+    }
+    if (!e->map_seeded || e->map->n_batches == 0) return 10;
+    memset(&e->tm, 0, sizeof(e->tm));
+    e->n_added_pending = false;
+    e->flg_EKF_inited = (lidar_beg_time - e->first_lidar_time) < e->init_time ? false : true;
+    if (e->map->stencil_id != 19 && (lidar_beg_time - e->first_lidar_time) > 10 * e->init_time) lio_map_set_stencil(e->map, 19);  // :1241-1243
+    *ekf_inited = e->flg_EKF_inited ? 1 : 0;
+    return 11;
+}
+// the filter constants and the state of laserMapping.cpp's file scope the round needs
+void engine_seq_params(lio_engine* e, double* laser_cov, int* maximum_iter, int* degenerate_detect_en, float* leaf_surf, float* leaf_map, int* static_map,
+                       double* travel, double last_pos_lid[3]) {
+    *laser_cov = e->laser_cov;
+    *maximum_iter = e->kf.maximum_iter;
+    *degenerate_detect_en = e->degenerate_detect_en ? 1 : 0;
+    *leaf_surf = e->leaf_surf;
+    *leaf_map = e->leaf_map;
+    *static_map = e->static_map ? 1 : 0;
+    *travel = e->travel;
+    for (int i = 0; i < 3; i++) last_pos_lid[i] = e->last_pos_lid[i];
+}
+// After the round, for a slot whose update finished on the device: the posterior into the engine's filter, the travel distance (the additions the
+// device made for its own copy), the bookkeeping of the insert the round ran (map_insert_dev's host side).  Returns 3 like process_core.
+int engine_seq_finish(lio_engine* e, const double x26[26], const double P529[529], int n_ds, int n_pass, int n_knn, int n_eff, int degenerate, int inserted,
+                      uint32_t n_add, uint32_t map_err, uint32_t bound) {
+    state_from_array(x26, e->kf.x);
+    memcpy(e->kf.P, P529, sizeof(e->kf.P));
+    e->log.clear();  // (the pass logs stay on the device in this mode)
+    e->tm.n_ds = n_ds;
+    e->tm.n_pass = n_pass;
+    e->tm.n_knn_pass = n_knn;
+    e->tm.n_eff_last = n_eff;
+    e->is_degenerate = degenerate != 0;
+    double off[3];
+    quat_rotate(e->kf.x.rot, e->kf.x.til, off);
+    double d2 = 0;
+    for (int i = 0; i < 3; i++) {
+        const double pl = e->kf.x.pos[i] + off[i];
+        const double d = pl - e->last_pos_lid[i];
+        d2 += d * d;
+        e->last_pos_lid[i] = pl;
+    }
+    e->travel = e->travel + sqrt(d2);
+    if (inserted) {
+        lio_map* m = e->map;
+        m->n_batches++;
+        if (m->lru_capacity) m->tomb_bound += bound;
+        e->tm.n_added = (int)n_add;
+        if (map_err) {
+            set_error("map capacity exceeded by map_incremental (err bits 0x%x: 1 table full, 2 point pool full, 4 more than max_voxels voxels, 8 LRU log overrun)", map_err);
+            return LIO_E_CAPACITY;
+        }
+    }
+    return 3;
+}
+// ... and for a slot whose update the device handed over (a pass with 1 <= N_eff < 23): the host filter finishes it through the engine's per-pass
+// path, then travel + map_incremental on the engine's own path (not waited for, as process_core leaves it)
+int engine_seq_resume(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t) {
+    const auto w0 = std::chrono::steady_clock::now();
+    const int rc = engine_resume_update_impl(e, x_now26, x_prop26, P_prop, i, converge, t, false);
+    if (rc != LIO_OK) return rc;
+    return after_update(e, w0);
+}
+int engine_seq_has_lru(lio_engine* e) { return e->map->lru_capacity != 0 ? 1 : 0; }
+
 int lio_engine_process_scan(lio_engine* e, const float* raw, uint32_t n_raw, double lidar_beg_time) {
     if (!e) return LIO_E_INVALID;
     const int rc = lio_scan_upload(e->scan, raw, n_raw);
@@ -860,6 +961,8 @@ int lio_engines_process_batch(lio_engine** engines, int n_engines, lio_scan_job*
             int rc = LIO_E_INVALID;
             if (job.flags & ~LIO_JOB_FLAGS_KNOWN) {
                 set_error("lio_scan_job.flags = 0x%x: unknown bits (a job array that was not zero-initialised?)", job.flags);
+            } else if (job.flags & LIO_JOB_IDLE) {
+                rc = 0;  // (sequence mode's marker for a session without a scan: nothing to do)
             } else if (job.state_in && job.cov_in) {
                 state_from_array(job.state_in, e->kf.x);
                 memcpy(e->kf.P, job.cov_in, sizeof(double) * 529);

@@ -25,7 +25,7 @@ namespace lio {
 // ---------------------------------------------------------------------------------------------------
 // batch insert = IVox::AddPoints (ivox3d.h:231-256); the LRU list is further down
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint32_t mask, uint32_t* __restrict__ pending,
+__device__ __forceinline__ void map_insert_claim_body(Slot* table, uint32_t mask, uint32_t* __restrict__ pending,
                                                                float* __restrict__ created, const float4* __restrict__ pts,
                                                                unsigned long long n_host, const uint32_t* __restrict__ n_dev,
                                                                float inv_res, float res, int key_mode, float travel, uint32_t max_voxels,
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint
     }
 }
 
-__global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint32_t* __restrict__ cap, uint32_t* __restrict__ pending,
+__device__ __forceinline__ void map_insert_grow_body(Slot* table, uint32_t* __restrict__ cap, uint32_t* __restrict__ pending,
                                                               float4* pool, unsigned long long pool_cap, unsigned long long n_host,
                                                               const uint32_t* __restrict__ n_dev, MapDev* md,
                                                               const uint32_t* __restrict__ slot_of_point, const uint32_t* __restrict__ free_items,
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) map_layout_assign_kernel(Slot* table, uin
     }
 }
 
-__global__ void __launch_bounds__(256) map_insert_write_kernel(Slot* table, const uint32_t* __restrict__ cap, float4* pool,
+__device__ __forceinline__ void map_insert_write_body(Slot* table, const uint32_t* __restrict__ cap, float4* pool,
                                                                const float4* __restrict__ pts, unsigned long long n_host,
                                                                const uint32_t* __restrict__ n_dev,
                                                                const uint32_t* __restrict__ slot_of_point) {
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) map_insert_write_kernel(Slot* table, cons
 // SAME batch would be re-created by the reference; that needs capacity < one scan's footprint and is reported as an
 // error instead (err bit 4).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) lru_append_kernel(const uint32_t* __restrict__ slot_of_point, const unsigned long long* __restrict__ touch,
+__device__ __forceinline__ void lru_append_body(const uint32_t* __restrict__ slot_of_point, const unsigned long long* __restrict__ touch,
                                                           unsigned long long n_host, const uint32_t* __restrict__ n_dev, unsigned long long stamp_base,
                                                           LruEntry* __restrict__ log, unsigned long long log_mask, MapDev* md) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(1024) lru_append_kernel(const uint32_t* __rest
     }
 }
 
-__global__ void __launch_bounds__(256) lru_evict_kernel(Slot* table, uint32_t* __restrict__ cap, const float* __restrict__ created,
+__device__ __forceinline__ void lru_evict_body(Slot* table, uint32_t* __restrict__ cap, const float* __restrict__ created,
                                                         unsigned long long* __restrict__ touch, const unsigned long long* __restrict__ prev_touch,
                                                         unsigned long long stamp_base, const LruEntry* __restrict__ log,
                                                         unsigned long long log_mask, uint32_t* __restrict__ free_items, uint32_t free_cap,
@@ -439,6 +439,70 @@ __global__ void __launch_bounds__(256) lru_evict_kernel(Slot* table, uint32_t* _
     }
 }
 
+// ---- launchable forms: one map (arguments by value), or the maps of a sequence batch (blockIdx.y = slot, arguments from the slot's MapRef in
+// device memory; a slot whose scan does not enter its map this round -- SeqDev::go == 0 -- exits at once) -----------------------------------------
+__global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint32_t mask, uint32_t* __restrict__ pending, float* __restrict__ created,
+                                                               const float4* __restrict__ pts, unsigned long long n_host, const uint32_t* __restrict__ n_dev,
+                                                               float inv_res, float res, int key_mode, float travel, uint32_t max_voxels, MapDev* md,
+                                                               uint32_t* __restrict__ slot_of_point, unsigned long long* __restrict__ touch,
+                                                               unsigned long long* __restrict__ prev_touch, unsigned long long stamp_base) {
+    map_insert_claim_body(table, mask, pending, created, pts, n_host, n_dev, inv_res, res, key_mode, travel, max_voxels, md, slot_of_point, touch, prev_touch,
+                          stamp_base);
+}
+__global__ void __launch_bounds__(256) map_insert_claim_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
+    if (!seq[blockIdx.y].go) return;
+    const MapRef& r = maps[blockIdx.y];
+    map_insert_claim_body(r.table, r.mask, r.pending, r.created, r.stage, 0ull, &r.md->n_add, r.inv_res, r.res, r.key_mode, (float)seq[blockIdx.y].travel,
+                          r.max_voxels, r.md, r.slot_of_point, r.lru_capacity ? r.touch : nullptr, r.prev_touch, r.stamp_base);
+}
+__global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint32_t* __restrict__ cap, uint32_t* __restrict__ pending, float4* pool,
+                                                              unsigned long long pool_cap, unsigned long long n_host, const uint32_t* __restrict__ n_dev,
+                                                              MapDev* md, const uint32_t* __restrict__ slot_of_point, const uint32_t* __restrict__ free_items,
+                                                              uint32_t free_cap, uint32_t* __restrict__ free_in) {
+    map_insert_grow_body(table, cap, pending, pool, pool_cap, n_host, n_dev, md, slot_of_point, free_items, free_cap, free_in);
+}
+__global__ void __launch_bounds__(256) map_insert_grow_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
+    if (!seq[blockIdx.y].go) return;
+    const MapRef& r = maps[blockIdx.y];
+    map_insert_grow_body(r.table, r.cap, r.pending, r.pool, r.pool_cap, 0ull, &r.md->n_add, r.md, r.slot_of_point, r.lru_capacity ? r.free_items : nullptr,
+                         r.free_cap, r.lru_capacity ? r.free_in : nullptr);
+}
+__global__ void __launch_bounds__(256) map_insert_write_kernel(Slot* table, const uint32_t* __restrict__ cap, float4* pool, const float4* __restrict__ pts,
+                                                               unsigned long long n_host, const uint32_t* __restrict__ n_dev,
+                                                               const uint32_t* __restrict__ slot_of_point) {
+    map_insert_write_body(table, cap, pool, pts, n_host, n_dev, slot_of_point);
+}
+__global__ void __launch_bounds__(256) map_insert_write_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
+    if (!seq[blockIdx.y].go) return;
+    const MapRef& r = maps[blockIdx.y];
+    map_insert_write_body(r.table, r.cap, r.pool, r.stage, 0ull, &r.md->n_add, r.slot_of_point);
+}
+__global__ void __launch_bounds__(1024) lru_append_kernel(const uint32_t* __restrict__ slot_of_point, const unsigned long long* __restrict__ touch,
+                                                          unsigned long long n_host, const uint32_t* __restrict__ n_dev, unsigned long long stamp_base,
+                                                          LruEntry* __restrict__ log, unsigned long long log_mask, MapDev* md) {
+    lru_append_body(slot_of_point, touch, n_host, n_dev, stamp_base, log, log_mask, md);
+}
+__global__ void __launch_bounds__(1024) lru_append_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
+    const MapRef& r = maps[blockIdx.y];
+    if (!seq[blockIdx.y].go || !r.lru_capacity) return;
+    lru_append_body(r.slot_of_point, r.touch, 0ull, &r.md->n_add, r.stamp_base, r.lru_log, r.log_mask, r.md);
+}
+__global__ void __launch_bounds__(256) lru_evict_kernel(Slot* table, uint32_t* __restrict__ cap, const float* __restrict__ created,
+                                                        unsigned long long* __restrict__ touch, const unsigned long long* __restrict__ prev_touch,
+                                                        unsigned long long stamp_base, const LruEntry* __restrict__ log, unsigned long long log_mask,
+                                                        uint32_t* __restrict__ free_items, uint32_t free_cap, unsigned long long n_host,
+                                                        const uint32_t* __restrict__ n_dev, uint32_t capacity, float travel, float max_distance, MapDev* md,
+                                                        const uint32_t* __restrict__ free_in) {
+    lru_evict_body(table, cap, created, touch, prev_touch, stamp_base, log, log_mask, free_items, free_cap, n_host, n_dev, capacity, travel, max_distance, md,
+                   free_in);
+}
+__global__ void __launch_bounds__(256) lru_evict_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
+    const MapRef& r = maps[blockIdx.y];
+    if (!seq[blockIdx.y].go || !r.lru_capacity) return;
+    lru_evict_body(r.table, r.cap, r.created, r.touch, r.prev_touch, r.stamp_base, r.lru_log, r.log_mask, r.free_items, r.free_cap, 0ull, &r.md->n_add,
+                   r.lru_capacity, (float)seq[blockIdx.y].travel, r.lru_max_distance, r.md, r.free_in);
+}
+
 // table rebuild: live slots are re-inserted into the twin table (no tombstones), the touch log is re-pointed
 __global__ void __launch_bounds__(256) rebuild_insert_kernel(const Slot* __restrict__ told, const uint32_t* __restrict__ cap_old,
                                                              const float* __restrict__ created_old, const unsigned long long* __restrict__ touch_old,
@@ -543,6 +607,26 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
                            (unsigned long long)(m->lru_log_cap - 1), m->free_items, m->free_cap, (unsigned long long)n, d_n, (uint32_t)m->lru_capacity,
                            (float)travel, m->lru_max_distance, m->dev, m->free_in);
         m->tomb_bound += n;
+    }
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+// IVox::AddPoints for the maps of a sequence batch: the staged points of every slot whose scan enters its map this round (SeqDev::go; the count
+// is the map's own MapDev::n_add, left by the batched classify), one launch per step of map_insert_dev's chain with blockIdx.y = slot.  Never the
+// prebuilt-map layout: a session's first batch (the seed) goes through its engine's own path.  `bound` = upper bound of a slot's staged points.
+int map_insert_seq(hipStream_t st, const MapRef* d_maps, const SeqDev* d_seq, int n_slots, uint32_t bound, int any_lru) {
+    if (bound == 0 || n_slots <= 0) return LIO_OK;
+    uint32_t blocks = (bound + 255u) / 256u;
+    // the points a scan adds are a fraction of its downsampled cloud (~2 000 of 7-12 k): a grid-stride loop over a fraction of the bound
+    if (blocks > 64u) blocks = 64u;
+    const dim3 grid(blocks, (uint32_t)n_slots);
+    hipLaunchKernelGGL(map_insert_claim_seq, grid, 256, 0, st, d_maps, d_seq);
+    hipLaunchKernelGGL(map_insert_grow_seq, grid, 256, 0, st, d_maps, d_seq);
+    hipLaunchKernelGGL(map_insert_write_seq, grid, 256, 0, st, d_maps, d_seq);
+    if (any_lru) {
+        hipLaunchKernelGGL(lru_append_seq, dim3(1, (uint32_t)n_slots), 1024, 0, st, d_maps, d_seq);
+        hipLaunchKernelGGL(lru_evict_seq, dim3(1, (uint32_t)n_slots), 256, 0, st, d_maps, d_seq);
     }
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;

@@ -664,6 +664,60 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
     return LIO_OK;
 }
 
+// sequence mode (lio_batch_create_sequences): every slot searches ITS OWN map -- table, pool and counters come from the slot's MapRef instead of
+// the kernel arguments.  The stencil travels by value, so one launch serves the slots whose map uses that stencil (normally all of them: 19).
+template <int KM>
+__global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id,
+                                                                     const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;
+    const MapRef& r = maps[blockIdx.y];
+    if (r.stencil_id != stencil_id) return;
+    const EskfDev* c = d.ctrl;
+    if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
+    const PoseArgs pose = pose_from_state(c->x);
+    knn_body<KM, 0, false>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, r.md, &d.sd->n_tie, d.tie_list);
+}
+template <int KM>
+__global__ void __launch_bounds__(256) knn_exact_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id, const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || d.sd->n_tie == 0) return;
+    const MapRef& r = maps[blockIdx.y];
+    if (r.stencil_id != stencil_id) return;
+    const EskfDev* c = d.ctrl;
+    if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
+    const PoseArgs pose = pose_from_state(c->x);
+    knn_exact_body<KM, 0>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list);
+}
+
+int knn_seq_launch(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, const StencilArgs* stencils, const int* stencil_ids,
+                   int n_stencils) {
+    static const uint32_t forced = [] { const char* e = getenv("LIO_KNN_GRID"); const int v = e ? atoi(e) : 0; return v >= 8 ? (uint32_t)v : 0u; }();
+    uint32_t cap = forced ? forced : (12288u / (uint32_t)(n_slots > 0 ? n_slots : 1));
+    if (cap > 2048u) cap = 2048u;
+    if (cap < 128u) cap = 128u;
+    if (grid_x > cap) grid_x = cap;
+    if (grid_x == 0) grid_x = 8;
+    const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
+    const dim3 gridx(n_slots > 8 ? 8 : 64, (uint32_t)n_slots);
+    for (int k = 0; k < n_stencils; k++) {
+        const StencilArgs& sa = stencils[k];
+        const int km = (sa.n + kG - 1) / kG;
+#define KNNS_LAUNCH(KM)                                                                                                  \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL((knn_seq_kernel<KM>), grid, 256, 0, st, d_maps, sa, stencil_ids[k], d_slots);                 \
+        hipLaunchKernelGGL((knn_exact_seq_kernel<KM>), gridx, 256, 0, st, d_maps, sa, stencil_ids[k], d_slots);          \
+    } while (0)
+        if (km <= 1) KNNS_LAUNCH(1);
+        else if (km <= 2) KNNS_LAUNCH(2);
+        else if (km <= 3) KNNS_LAUNCH(3);
+        else KNNS_LAUNCH((kMaxStencil + kG - 1) / kG);
+#undef KNNS_LAUNCH
+    }
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
 template <int MODE>
 static int launch_knn(lio_map* m, hipStream_t st, const PoseArgs& pose, const float4* q, uint32_t n_host, const ScanDev* sd,
                       float4* world_out, float4* nn_pts, uint32_t nn_stride, int32_t* nn_cnt, uint32_t n_bound, uint32_t* n_tie,

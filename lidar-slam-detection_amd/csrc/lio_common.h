@@ -9,6 +9,8 @@
 #include "../../include/lio_hip.h"
 #include "eskf_dev.h"
 
+struct LruEntry;
+
 namespace lio {
 
 // a double moved across lanes by one DPP control word (two 32-bit halves): quad_perm 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1] give the quad sums
@@ -120,6 +122,53 @@ struct SlotDesc {
     uint32_t* host_nds;      // mapped pinned words {n_ds, err, radix passes needed} of the slot's scan
     EskfDev* ctrl;           // device-resident filter of the slot
     lio_batch_result* result;  // mapped pinned host record of the slot
+};
+
+// Sequence mode of the batched engine (lio_batch_create_sequences): every slot is ONE SLAM session with its own map.  What the batched kernels
+// need of slot s's map, and the per-round words of its map_incremental; uploaded with the descriptors before every round.
+struct MapRef {
+    Slot* table;
+    uint32_t* cap;
+    uint32_t* pending;
+    float* created;
+    float4* pool;
+    MapDev* md;
+    uint32_t* slot_of_point;
+    float4* stage;
+    unsigned long long pool_cap;
+    unsigned long long stamp_base;   // (n_batches + 1) << kStampIdxBits of the insert this round would be
+    // LRU (null / 0 while the map has none)
+    unsigned long long* touch;
+    unsigned long long* prev_touch;
+    struct ::LruEntry* lru_log;
+    unsigned long long log_mask;
+    uint32_t* free_items;
+    uint32_t* free_in;
+    uint32_t free_cap;
+    uint32_t lru_capacity;
+    float lru_max_distance;
+    uint32_t mask;
+    float inv_res, res;
+    int key_mode;
+    uint32_t max_voxels;
+    int stencil_id;                  // the map's stencil this round (a launch of the neighbour search serves the slots of one stencil)
+    uint32_t do_insert;              // the round's scan enters the map when its update finishes on the device (map_incremental, laserMapping.cpp:1304)
+    uint32_t ekf_inited;             // flg_EKF_inited of this scan (laserMapping.cpp:1201)
+    float map_leaf;                  // filter_size_map_min
+    // travel distance of the lidar origin before this scan (laserMapping.cpp:1288-1291); the round adds this scan's step on the device
+    double travel_prev;
+    double last_pos_lid[3];
+};
+
+// what the insert half of a sequence round decides / leaves per slot (device-resident; the tail is read back by the host)
+struct SeqDev {
+    double travel;       // travel after this scan (what AddPoints stamps new voxels with)
+    uint32_t go;         // the update finished on the device (EK_DONE) and the scan enters the map this round
+    uint32_t map_err;    // MapDev::err after the insert
+    uint32_t n_add;      // points handed to AddPoints
+    uint32_t n_voxels;
+    unsigned long long n_points;
+    double P[kEkN * kEkN];  // the posterior covariance (the result record in mapped memory carries the state only)
 };
 
 }  // namespace lio
@@ -254,12 +303,12 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
 int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int count_touched);
 // live kernel timing of the batched chain (bench.py's roofline leg): HIP events on the stream the kernels are launched on, per class
 struct BatchTimer {
-    static constexpr int kClasses = 4;  // 0 downsample chain, 1 stencil kNN, 2 linearise, 3 filter pass
+    static constexpr int kClasses = 5;  // 0 downsample chain, 1 stencil kNN, 2 linearise, 3 filter pass, 4 map_incremental (sequence mode)
     static constexpr int kPool = 256;
     hipEvent_t ev[kClasses][kPool][2];
-    int used[kClasses] = {0, 0, 0, 0};
-    double us[kClasses] = {0, 0, 0, 0};
-    uint32_t launches[kClasses] = {0, 0, 0, 0};
+    int used[kClasses] = {0, 0, 0, 0, 0};
+    double us[kClasses] = {0, 0, 0, 0, 0};
+    uint32_t launches[kClasses] = {0, 0, 0, 0, 0};
     bool on = false, created = false;
     hipStream_t stream = nullptr;
     void begin(int c) { if (on && used[c] < kPool) hipEventRecord(ev[c][used[c]][0], stream); }
@@ -275,6 +324,15 @@ struct BatchTimer {
     }
 };
 int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int count_touched);
+// sequence mode: the same loop with every slot's neighbour search against ITS map (one launch per stencil among `stencils`), then the
+// map_incremental of every slot whose update finished on the device, then the read-back records
+int knn_seq_launch(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, const StencilArgs* stencils, const int* stencil_ids,
+                   int n_stencils);
+int p2plane_seq_update(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, const StencilArgs* stencils,
+                       const int* stencil_ids, int n_stencils, BatchTimer* bt);
+int p2plane_seq_insert(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, SeqDev* d_seq, int n_slots, uint32_t ds_bound, int any_lru);
+int map_insert_seq(hipStream_t st, const MapRef* d_maps, const SeqDev* d_seq, int n_slots, uint32_t bound, int any_lru);
+int map_rebuild(lio_map* m, hipStream_t stream);
 }
 struct lio_comm;
 namespace lio {

@@ -710,6 +710,26 @@ int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, in
     return LIO_OK;
 }
 
+// sequence mode: the same blind loop, every slot against its own map
+int p2plane_seq_update(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, const StencilArgs* stencils,
+                       const int* stencil_ids, int n_stencils, BatchTimer* bt) {
+    uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
+    if (lin_blocks == 0) lin_blocks = 1;
+    for (int p = 0; p < n_passes; p++) {
+        if (bt) bt->begin(1);
+        const int rc = knn_seq_launch(st, d_maps, d_slots, n_slots, (ds_bound + 15) / 16, stencils, stencil_ids, n_stencils);
+        if (bt) bt->end(1);
+        if (rc != LIO_OK) return rc;
+        if (bt) bt->begin(2);
+        hipLaunchKernelGGL(linearize_batch, dim3(lin_blocks, (uint32_t)n_slots), kLinThreads, 0, st, d_slots);
+        if (bt) { bt->end(2); bt->begin(3); }
+        hipLaunchKernelGGL((step_batch<false>), dim3((uint32_t)n_slots), kStepThreads, 0, st, d_slots, static_cast<const double*>(nullptr), 1, (uint32_t)n_slots);
+        if (bt) bt->end(3);
+    }
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
 int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {
     const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
     uint32_t blocks = (bound + kLinThreads - 1) / kLinThreads;
@@ -732,10 +752,10 @@ int p2plane_reduce(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) 
 // batch is PointToAdd in point order followed by PointNoNeedDownsample in point order, independent of wave scheduling.
 constexpr int kClsThreads = 256;
 
-__global__ void __launch_bounds__(kClsThreads) classify_kernel(PoseArgs pose, const ScanDev* __restrict__ sd, const float4* __restrict__ ds_body,
-                                                               float4* __restrict__ ds_world, const float4* __restrict__ nn_pts, uint32_t nn_stride,
-                                                               const int32_t* __restrict__ nn_cnt, float map_leaf, int ekf_inited, int seed_all,
-                                                               uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt /* [2][gridDim.x] */) {
+__device__ __forceinline__ void classify_body(const PoseArgs& pose, const ScanDev* __restrict__ sd, const float4* __restrict__ ds_body,
+                                              float4* __restrict__ ds_world, const float4* __restrict__ nn_pts, uint32_t nn_stride,
+                                              const int32_t* __restrict__ nn_cnt, float map_leaf, int ekf_inited, int seed_all,
+                                              uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt /* [2][gridDim.x] */) {
     const uint32_t n = sd->n_ds;
     const uint32_t i = blockIdx.x * kClsThreads + threadIdx.x;
     int c = 0;  // 0 not added, 1 PointToAdd, 2 PointNoNeedDownsample
@@ -779,9 +799,9 @@ __global__ void __launch_bounds__(kClsThreads) classify_kernel(PoseArgs pose, co
     }
 }
 
-__global__ void __launch_bounds__(kClsThreads) classify_scatter_kernel(const ScanDev* __restrict__ sd, const float4* __restrict__ ds_world,
-                                                                       const uint8_t* __restrict__ cls, const uint32_t* __restrict__ blk_cnt,
-                                                                       float4* __restrict__ stage, MapDev* md) {
+__device__ __forceinline__ void classify_scatter_body(const ScanDev* __restrict__ sd, const float4* __restrict__ ds_world,
+                                                      const uint8_t* __restrict__ cls, const uint32_t* __restrict__ blk_cnt,
+                                                      float4* __restrict__ stage, MapDev* md) {
     const uint32_t n = sd->n_ds;
     const uint32_t nb = gridDim.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -817,6 +837,78 @@ __global__ void __launch_bounds__(kClsThreads) classify_scatter_kernel(const Sca
     if (blockIdx.x == nb - 1 && tid == 0) md->n_add = totA + preB + tb;  // (the last workgroup's exclusive prefix + its own count = the total)
 }
 
+__global__ void __launch_bounds__(kClsThreads) classify_kernel(PoseArgs pose, const ScanDev* __restrict__ sd, const float4* __restrict__ ds_body,
+                                                               float4* __restrict__ ds_world, const float4* __restrict__ nn_pts, uint32_t nn_stride,
+                                                               const int32_t* __restrict__ nn_cnt, float map_leaf, int ekf_inited, int seed_all,
+                                                               uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt) {
+    classify_body(pose, sd, ds_body, ds_world, nn_pts, nn_stride, nn_cnt, map_leaf, ekf_inited, seed_all, cls, blk_cnt);
+}
+__global__ void __launch_bounds__(kClsThreads) classify_scatter_kernel(const ScanDev* __restrict__ sd, const float4* __restrict__ ds_world,
+                                                                       const uint8_t* __restrict__ cls, const uint32_t* __restrict__ blk_cnt,
+                                                                       float4* __restrict__ stage, MapDev* md) {
+    classify_scatter_body(sd, ds_world, cls, blk_cnt, stage, md);
+}
+
+// ---- sequence mode (lio_batch_create_sequences): map_incremental of every slot inside the round -----------------------------------------------
+// One small workgroup per slot after the last filter pass: does this round's scan enter its map (the update finished on the device -- a scan
+// handed to the host, skipped or over capacity is finished and inserted by the slot's engine afterwards), and the travel distance of the lidar
+// origin after it (laserMapping.cpp:1288-1291: what AddPoints stamps new voxels with; the host repeats the same additions for its own copy).
+__global__ void __launch_bounds__(64) seq_begin_insert_kernel(const MapRef* __restrict__ maps, const SlotDesc* __restrict__ slots, SeqDev* __restrict__ seq) {
+    const SlotDesc& d = slots[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    SeqDev& q = seq[blockIdx.x];
+    q.go = 0;
+    q.map_err = 0;
+    q.n_add = 0;
+    if (!d.active) return;
+    const MapRef& r = maps[blockIdx.x];
+    const EskfDev* c = d.ctrl;
+    double travel = r.travel_prev;
+    if (c->status == EK_DONE && !(d.sd->err & 1u)) {
+        // pos_lid = pos + rot * offset_T_L_I, in the operation order of quat_rotate (eskf.cpp)
+        const double* x = c->x;
+        const double qx = x[3], qy = x[4], qz = x[5], qw = x[6];
+        const double v[3] = {x[11], x[12], x[13]};
+        const double t0 = 2.0 * (qy * v[2] - qz * v[1]), t1 = 2.0 * (qz * v[0] - qx * v[2]), t2 = 2.0 * (qx * v[1] - qy * v[0]);
+        const double o0 = v[0] + qw * t0 + (qy * t2 - qz * t1), o1 = v[1] + qw * t1 + (qz * t0 - qx * t2), o2 = v[2] + qw * t2 + (qx * t1 - qy * t0);
+        const double p[3] = {x[0] + o0, x[1] + o1, x[2] + o2};
+        double d2 = 0;
+        for (int i = 0; i < 3; i++) { const double dd = p[i] - r.last_pos_lid[i]; d2 += dd * dd; }
+        travel = travel + sqrt(d2);
+        q.go = r.do_insert ? 1u : 0u;
+    }
+    q.travel = travel;
+}
+__global__ void __launch_bounds__(kClsThreads) classify_seq(const MapRef* __restrict__ maps, const SlotDesc* __restrict__ slots, const SeqDev* __restrict__ seq) {
+    if (!seq[blockIdx.y].go) return;
+    const SlotDesc& d = slots[blockIdx.y];
+    const MapRef& r = maps[blockIdx.y];
+    const PoseArgs pose = pose_from_state(d.ctrl->x);
+    classify_body(pose, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, r.map_leaf, (int)r.ekf_inited, 0, reinterpret_cast<uint8_t*>(d.keys_a), d.hist);
+}
+__global__ void __launch_bounds__(kClsThreads) classify_scatter_seq(const MapRef* __restrict__ maps, const SlotDesc* __restrict__ slots,
+                                                                    const SeqDev* __restrict__ seq) {
+    if (!seq[blockIdx.y].go) return;
+    const SlotDesc& d = slots[blockIdx.y];
+    const MapRef& r = maps[blockIdx.y];
+    classify_scatter_body(d.sd, d.ds_world, reinterpret_cast<const uint8_t*>(d.keys_a), d.hist, r.stage, r.md);
+}
+// the read-back record of every slot: the posterior covariance and what the insert left in the map's counters
+__global__ void __launch_bounds__(256) seq_finish_kernel(const MapRef* __restrict__ maps, const SlotDesc* __restrict__ slots, SeqDev* __restrict__ seq) {
+    const SlotDesc& d = slots[blockIdx.x];
+    if (!d.active) return;
+    SeqDev& q = seq[blockIdx.x];
+    const EskfDev* c = d.ctrl;
+    for (int k = threadIdx.x; k < kEkN * kEkN; k += 256) q.P[k] = c->P[k];
+    if (threadIdx.x == 0) {
+        const MapDev* md = maps[blockIdx.x].md;
+        q.map_err = md->err;
+        q.n_add = q.go ? md->n_add : 0u;
+        q.n_voxels = md->n_voxels;
+        q.n_points = md->n_points;
+    }
+}
+
 int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float map_leaf, int ekf_inited, int seed_all) {
     const uint32_t bound = s->have_ds > 0 ? (uint32_t)s->have_ds : (s->n_raw && s->n_raw < s->max_ds ? s->n_raw : s->max_ds);
     if (bound > m->stage_cap) {
@@ -832,6 +924,21 @@ int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float ma
     hipLaunchKernelGGL(classify_kernel, blocks, kClsThreads, 0, s->stream, pose, s->dev, s->ds_body, s->ds_world, s->nn_pts, s->max_ds, s->nn_cnt,
                        map_leaf, ekf_inited, seed_all, cls, blk_cnt);
     hipLaunchKernelGGL(classify_scatter_kernel, blocks, kClsThreads, 0, s->stream, s->dev, s->ds_world, cls, blk_cnt, m->stage, m->dev);
+    LIO_HIP_TRY(hipGetLastError());
+    return LIO_OK;
+}
+
+// map_incremental (laserMapping.cpp:523-576) of every slot whose update finished, against its own map, then the read-back records
+int p2plane_seq_insert(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, SeqDev* d_seq, int n_slots, uint32_t ds_bound, int any_lru) {
+    uint32_t blocks = (ds_bound + kClsThreads - 1) / kClsThreads;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(seq_begin_insert_kernel, dim3((uint32_t)n_slots), 64, 0, st, d_maps, d_slots, d_seq);
+    hipLaunchKernelGGL(classify_seq, dim3(blocks, (uint32_t)n_slots), kClsThreads, 0, st, d_maps, d_slots, d_seq);
+    hipLaunchKernelGGL(classify_scatter_seq, dim3(blocks, (uint32_t)n_slots), kClsThreads, 0, st, d_maps, d_slots, d_seq);
+    LIO_HIP_TRY(hipGetLastError());
+    const int rc = map_insert_seq(st, d_maps, d_seq, n_slots, ds_bound, any_lru);
+    if (rc != LIO_OK) return rc;
+    hipLaunchKernelGGL(seq_finish_kernel, dim3((uint32_t)n_slots), 256, 0, st, d_maps, d_slots, d_seq);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }

@@ -821,6 +821,86 @@ class Batch:
 
 
 JOB_KEEP_CACHE = 1  # LIO_JOB_KEEP_CACHE of include/lio_hip.h
+JOB_IDLE = 2        # LIO_JOB_IDLE: the session has no scan this round (lio_batch_sequences_step)
+
+
+class SequenceBatch:
+    """throughput mode WITH map_incremental (lio_batch_create_sequences): n_groups x n_slots independent SLAM sessions, one per slot, each with its
+    own map; step() registers the next scan of every session and inserts it into the session's map in one submission per group"""
+
+    def __init__(self, n_slots=8, n_groups=1, resolution=0.5, stencil=19, max_points=2_000_000, max_voxels=1_000_000, max_raw=262144, max_ds=100000, device=0):
+        self.n_slots, self.n_groups = n_slots, n_groups
+        self.n = n_slots * n_groups
+        self.h = lib().lio_batch_create_sequences(device, resolution, stencil, max_points, max_voxels, n_slots, n_groups, max_raw, max_ds)
+        if not self.h:
+            raise capi.LioError("lio_batch_create_sequences failed: " + lib().lio_last_error().decode())
+        self.arr = (capi.ScanJob * self.n)()
+        self.states_in = np.zeros((self.n, STATE_DIM))
+        self.covs_in = np.zeros((self.n, 23 * 23))
+        self.states_out = np.zeros((self.n, STATE_DIM))
+        self.covs_out = np.zeros((self.n, 23 * 23))
+        for i in range(self.n):
+            a = self.arr[i]
+            a.state_in = self.states_in[i].ctypes.data_as(C.POINTER(C.c_double))
+            a.cov_in = self.covs_in[i].ctypes.data_as(C.POINTER(C.c_double))
+            a.state_out = self.states_out[i].ctypes.data_as(C.POINTER(C.c_double))
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().lio_batch_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def engine(self, session):
+        """the engine that owns session `session`'s map and file-scope state (borrowed)"""
+        h = lib().lio_batch_engine(self.h, session // self.n_slots, session % self.n_slots)
+        if not h:
+            raise capi.LioError("no such session")
+        e = Engine.__new__(Engine)
+        e.h = h
+        e._own = False
+        e.map = Map(_borrow=lib().lio_engine_map(h))
+        e.scan = Scan(max_ds=100000, _borrow=lib().lio_engine_scan(h))
+        return e
+
+    def enable_kernel_timing(self, on=True):
+        check(lib().lio_batch_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_times(self, reset=True):
+        t = capi.BatchTimes()
+        check(lib().lio_batch_kernel_times(self.h, C.byref(t), int(reset)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def load(self, jobs):
+        """jobs: one entry per session -- None (idle this round) or a dict {dptr, n, t, state (26,), cov (23,23)}"""
+        assert len(jobs) == self.n
+        for i, j in enumerate(jobs):
+            a = self.arr[i]
+            if j is None:
+                a.flags = JOB_IDLE
+                a.d_raw, a.n_raw = None, 0
+                continue
+            a.flags = 0
+            a.d_raw = j["dptr"]
+            a.n_raw = j["n"]
+            a.lidar_beg_time = float(j["t"])
+            self.states_in[i] = f64(j["state"])
+            self.covs_in[i] = f64(j["cov"]).reshape(-1)
+
+    def run(self):
+        """the C call alone (on what load() marshalled)"""
+        return lib().lio_batch_sequences_step(self.h, self.arr, self.n, self.covs_out.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def step(self, jobs):
+        """returns (rc, list of result dicts -- None for an idle session)"""
+        self.load(jobs)
+        rc = self.run()
+        a = self.arr
+        res = [None if jobs[i] is None else dict(rc=a[i].rc, n_ds=a[i].n_ds, n_pass=a[i].n_pass, n_knn_pass=a[i].n_knn_pass, state=self.states_out[i].copy(),
+                                                  cov=self.covs_out[i].reshape(23, 23).copy()) for i in range(self.n)]
+        return rc, res
+
 
 
 class PreparedJobs:

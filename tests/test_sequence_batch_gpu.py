@@ -1,0 +1,151 @@
+"""Sequence mode of the batched engine (lio_batch_create_sequences / lio_batch_sequences_step): B independent SLAM sessions, each with its own
+map, registered AND inserted (map_incremental, laserMapping.cpp:523-576,1304) inside one blind submission per round -- against the same scans
+pushed one by one through a per-session engine (lio_engine_process_scan_device with the device loop on): same return codes, the same posterior
+bits scan after scan, the same maps."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import scenes  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(a):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1, 4)
+    return a[np.lexsort((a[:, 3], a[:, 2], a[:, 1], a[:, 0]))]
+
+
+def _drive_plan(scene, session, n_scans, n_az=300):
+    """the scans of one session: a short drive of its own (start, heading, seeds), starting at its own time and round"""
+    from lsd_amd import synth
+
+    rng = np.random.default_rng(100 + session)
+    start = np.array([rng.uniform(-40, 40), rng.uniform(-40, 40), 1.8])
+    heading = rng.uniform(0, 2 * np.pi)
+    step = 0.6 * np.array([np.cos(heading), np.sin(heading), 0.0])
+    t0 = 5.0 * session  # its own time origin
+    scans = []
+    for k in range(n_scans):
+        pos = start + k * step
+        q = synth.quat_mul(synth.quat_from_rotvec([0, 0, heading]), synth.quat_from_rotvec([0, 0, 0.01 * k]))
+        raw, _ = synth.make_scan(scene, pos, q, seed=1000 * session + k, n_az=n_az, max_range=40.0)
+        scans.append(dict(raw=raw, dptr=scenes.to_device(raw), n=len(raw), t=t0 + 0.1 * k, pos=pos, quat=q))
+    s0 = synth.state_from_pose(start, synth.quat_from_rotvec([0, 0, heading]))
+    return scans, s0
+
+
+def _next_prior(res, P_add=1e-2):
+    P = res["cov"].copy()
+    P[:6, :6] += np.eye(6) * P_add
+    return res["state"].copy(), P
+
+
+@pytest.mark.parametrize("lru", [False, True])
+def test_sessions_in_a_batch_equal_sessions_on_their_own(scene, lru):
+    from lsd_amd import capi, lio
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device")
+    n_slots, n_groups = 3, 2
+    n_sess = n_slots * n_groups
+    n_scans = 16
+    first_round = [0, 0, 2, 0, 5, 1]  # the round a session's first scan arrives in: the slots of a round are at different stages
+    plans = [_drive_plan(scene, s, n_scans) for s in range(n_sess)]
+    P0 = lio.init_cov()
+    # with the LRU list: a table small enough to be rebuilt (tombstones of evicted voxels) in the middle of the drives
+    kw = dict(resolution=0.5, stencil=75, max_points=600_000, max_voxels=40_000 if lru else 100_000, max_raw=1 << 17, max_ds=60000)
+    cap_lru, maxd_lru = 6000, 1.0
+
+    # ---- every session on its own engine, scan by scan ----
+    solo = []
+    for s in range(n_sess):
+        e = lio.Engine(**kw)
+        e.set_device_loop(True)
+        if lru:
+            e.map.set_lru(cap_lru, maxd_lru)
+        scans, s0 = plans[s]
+        st, P = s0.copy(), P0.copy()
+        out = []
+        for k, sc in enumerate(scans):
+            if k == 9:
+                sc_n = 0  # an empty scan in the middle of every drive ("FastLio undistort points is empty")
+            else:
+                sc_n = sc["n"]
+            e.set_state(st)
+            e.set_cov(P)
+            rc = e.process_scan_device(sc["dptr"], sc_n, sc["t"])
+            res = dict(rc=rc, state=e.get_state(), cov=e.get_cov(), n_ds=e.timings()["n_ds"])
+            out.append(res)
+            if rc == 3:
+                st, P = _next_prior(res)
+        e.flush()
+        npts, nvox = e.map.stats()
+        solo.append(dict(out=out, npts=npts, nvox=nvox, dump=_rows(e.map.dump()), travel=e.travel, evicted=e.map.lru_stats()[0] if lru else 0))
+        e.close()
+
+    # ---- the same sessions as slots of a sequence batch ----
+    b = lio.SequenceBatch(n_slots=n_slots, n_groups=n_groups, **kw)
+    if lru:
+        for s in range(n_sess):
+            b.engine(s).map.set_lru(cap_lru, maxd_lru)
+    priors = [(plans[s][1].copy(), P0.copy()) for s in range(n_sess)]
+    got = [[] for _ in range(n_sess)]
+    n_rounds = n_scans + max(first_round)
+    in_round = 0
+    for r in range(n_rounds):
+        jobs = []
+        for s in range(n_sess):
+            k = r - first_round[s]
+            if k < 0 or k >= n_scans:
+                jobs.append(None)
+                continue
+            sc = plans[s][0][k]
+            jobs.append(dict(dptr=sc["dptr"], n=0 if k == 9 else sc["n"], t=sc["t"], state=priors[s][0], cov=priors[s][1]))
+        rc, res = b.step(jobs)
+        assert rc == 0, (r, capi.lib().lio_last_error().decode())
+        for s in range(n_sess):
+            if res[s] is None:
+                continue
+            got[s].append(res[s])
+            if res[s]["rc"] == 3:
+                priors[s] = _next_prior(res[s])
+                in_round += 1
+    assert in_round >= n_sess * (n_scans - 4)
+    for s in range(n_sess):
+        assert len(got[s]) == n_scans
+        for k, (a, c) in enumerate(zip(solo[s]["out"], got[s])):
+            assert a["rc"] == c["rc"], (s, k, a["rc"], c["rc"])
+            if a["rc"] == 3:
+                assert a["n_ds"] == c["n_ds"], (s, k)
+                assert np.array_equal(a["state"], c["state"]), (s, k, np.abs(a["state"] - c["state"]).max())
+                assert np.array_equal(a["cov"], c["cov"]), (s, k, np.abs(a["cov"] - c["cov"]).max())
+        rcs = [c["rc"] for c in got[s]]
+        assert rcs[0] == 0 and rcs[1] == 1 and rcs[9] == 2 and rcs.count(3) == n_scans - 3, rcs
+        e = b.engine(s)
+        npts, nvox = e.map.stats()
+        assert (npts, nvox) == (solo[s]["npts"], solo[s]["nvox"]), (s, npts, nvox, solo[s]["npts"], solo[s]["nvox"])
+        assert np.array_equal(_rows(e.map.dump()), solo[s]["dump"]), s
+        assert e.travel == solo[s]["travel"], s
+        if lru:
+            assert e.map.lru_stats()[0] == solo[s]["evicted"], s
+    if lru:
+        assert sum(x["evicted"] for x in solo) > 500
+    # the sessions really moved and mapped
+    assert all(x["npts"] > 5000 for x in solo)
+    b.close()
+
+
+def test_sequence_batch_rejects_what_it_cannot_run(scene):
+    from lsd_amd import capi, lio
+
+    b = lio.SequenceBatch(n_slots=2, n_groups=1, max_points=200_000, max_voxels=50_000, max_raw=1 << 16, max_ds=30000)
+    arr = (capi.ScanJob * 1)()
+    assert capi.lib().lio_batch_sequences_step(b.h, arr, 1, None) < 0  # one job per session
+    assert capi.lib().lio_batch_process(b.h, b.arr, 2) < 0            # the static batch's entry point
+    rc, res = b.step([None, None])
+    assert rc == 0 and res == [None, None]
+    b.close()
