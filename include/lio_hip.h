@@ -448,6 +448,14 @@ int lio_batch_set_gather_hook(lio_batch*, lio_gather_fn fn, void* ctx, int rank,
 lio_batch* lio_batch_create_sequences(int device, float resolution, int stencil, uint64_t max_points, uint64_t max_voxels, int n_slots, int n_groups,
                                       uint32_t max_raw, uint32_t max_ds);
 int lio_batch_sequences_step(lio_batch*, lio_scan_job* jobs, int n_jobs, double* cov_out);
+/* lio_fastlio_main (= fastlio_main, src/laserMapping.cpp:1160-1310) for every session of a sequence batch at once: replay of many recorded drives
+ * through the reference's own entry points.  Each session's engine carries the front half -- lio_fastlio_init(lio_batch_engine(b, g, s), ...), then
+ * lio_fastlio_imu_enqueue / lio_fastlio_ins_enqueue / lio_fastlio_pcl_enqueue[_device] on it as for a single engine.  One call = one fastlio_main per
+ * session: sync_packages, IMU initialisation, forward propagation and undistortion per session as lio_fastlio_main does them, ONE sequence round for
+ * the scans that reach registration, the back half per session.  rc_out[j] (n_groups x n_slots entries) = what lio_fastlio_main would have returned
+ * for session j (LIO_MAIN_IDLE without a complete package); lio_fastlio_odometry / _state of the session's engine read the result.  Same bits as
+ * lio_fastlio_main on a per-session engine with the device loop on (tests/test_sequence_batch_gpu.py). */
+int lio_batch_fastlio_main(lio_batch*, int* rc_out);
 void lio_batch_destroy(lio_batch*);
 int lio_batch_process(lio_batch*, lio_scan_job* jobs, int n_jobs);
 /* live kernel timing of the batched chain with HIP events on the groups' streams (bench.py's roofline leg): per class the summed device

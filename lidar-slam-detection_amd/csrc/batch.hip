@@ -30,6 +30,8 @@ int engine_seq_finish(lio_engine* e, const double x26[26], const double P529[529
                       uint32_t n_add, uint32_t map_err, uint32_t bound);
 int engine_seq_resume(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t);
 int engine_seq_has_lru(lio_engine* e);
+int engine_fastlio_front(lio_engine* e, const void** d_raw, uint32_t* n_raw, double* beg, double state26[26], double cov529[529]);
+void engine_fastlio_back(lio_engine* e);
 }
 
 namespace {
@@ -86,6 +88,8 @@ struct lio_batch {
     void* gather_ctx = nullptr;
     bool joint = false;
     bool sequences = false;  // lio_batch_create_sequences: every slot is a SLAM session with its own map (the slot's engine owns it)
+    std::vector<lio_scan_job> fl_jobs;   // lio_batch_fastlio_main: the round's jobs and their priors / posteriors
+    std::vector<double> fl_state, fl_cov;
     std::vector<Group> groups;
     double t_submit = 0, t_wait = 0, t_collect = 0;  // host seconds (LIO_BATCH_PROFILE=1 prints them when the object is destroyed)
     uint64_t n_rounds = 0;
@@ -802,6 +806,54 @@ int lio_batch_sequences_step(lio_batch* b, lio_scan_job* jobs, int n_jobs, doubl
 }
 
 }  // extern "C"
+
+// fastlio_main for every session of a sequence batch at once: the sessions' engines carry the reference's front half (lio_fastlio_init on
+// lio_batch_engine(b, g, s), then lio_fastlio_imu_enqueue / lio_fastlio_pcl_enqueue* as for a single engine).  Per session: sync_packages, IMU
+// initialisation, forward propagation + undistortion exactly as lio_fastlio_main does them (engine.hip: fastlio_front); the scans that reach
+// registration form ONE sequence round (lio_batch_sequences_step); then the back half.  rc_out[j]: what lio_fastlio_main would have returned
+// for session j (LIO_MAIN_IDLE for a session without a complete package).
+int lio_batch_fastlio_main(lio_batch* b, int* rc_out) {
+    if (!b || !rc_out) return LIO_E_INVALID;
+    if (!b->sequences) { set_error("lio_batch_fastlio_main: for a batch made by lio_batch_create_sequences"); return LIO_E_STATE; }
+    const int B = b->n_slots, G = (int)b->groups.size(), n = B * G;
+    hipSetDevice(b->device);
+    b->fl_jobs.assign((size_t)n, lio_scan_job{});
+    b->fl_state.resize((size_t)n * 26);
+    b->fl_cov.resize((size_t)n * 529);
+    int first_err = 0, n_ready = 0;
+    std::vector<char> ready((size_t)n, 0);
+    for (int j = 0; j < n; j++) {
+        lio_engine* e = b->groups[j / B].eng[j % B];
+        lio_scan_job& job = b->fl_jobs[j];
+        job.flags = LIO_JOB_IDLE;
+        const void* d_raw = nullptr;
+        uint32_t n_raw = 0;
+        double beg = 0;
+        const int fr = engine_fastlio_front(e, &d_raw, &n_raw, &beg, &b->fl_state[(size_t)j * 26], &b->fl_cov[(size_t)j * 529]);
+        rc_out[j] = fr;
+        if (fr < 0 && !first_err) first_err = fr;
+        if (fr != 1000) continue;
+        job.flags = 0;
+        job.d_raw = d_raw;
+        job.n_raw = n_raw;
+        job.lidar_beg_time = beg;
+        job.state_in = &b->fl_state[(size_t)j * 26];
+        job.cov_in = &b->fl_cov[(size_t)j * 529];
+        job.state_out = nullptr;  // (the posterior goes into the session's engine, where the reference's accessors read it)
+        ready[j] = 1;
+        n_ready++;
+    }
+    if (n_ready) {
+        const int rc = lio_batch_sequences_step(b, b->fl_jobs.data(), n, nullptr);
+        if (rc < 0 && !first_err) first_err = rc;
+        for (int j = 0; j < n; j++) {
+            if (!ready[j]) continue;
+            rc_out[j] = b->fl_jobs[j].rc;
+            engine_fastlio_back(b->groups[j / B].eng[j % B]);
+        }
+    }
+    return first_err;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The same device-resident loop for ONE engine (lio_engine_update, the filter update inside lio_engine_process_scan / lio_fastlio_main):

@@ -37,6 +37,7 @@ struct PendingScan {
     const uint32_t* d_stamp = nullptr;
     int pinned = -1;                  // index into Frontend::pool for host input
 };
+struct lio_held_scan { PendingScan sc; };  // sequence batch: the scan between the two halves of fastlio_main
 struct Frontend {
     std::mutex mtx;  // mtx_buffer: the enqueue calls come from sensor threads
     std::deque<ImuSample> imu_buffer;
@@ -111,6 +112,7 @@ struct lio_engine {
     lio_reduce_fn reduce = nullptr;  // cross-GPU reduction of the normal equations (joint registration)
     void* reduce_ctx = nullptr;
     JointCtx* joint = nullptr;       // native joint registration (lio_engine_set_joint) behind `reduce`
+    struct lio_held_scan* held = nullptr;  // sequence batch: the scan between the two halves of fastlio_main (engine_fastlio_front / _back)
 };
 
 int engine_resume_update_impl(lio_engine* e, const double* x_now26, const double* x_prop26, const double* P_prop, int i, int converge, int t, bool keep_log);
@@ -537,6 +539,7 @@ void lio_engine_destroy(lio_engine* e) {
     delete e->joint;  // (the other sub-maps' engines may be gone already: their scans are not touched here -- lio_engine_set_joint(e, NULL, 0, NULL)
                       // before destroying the driver hands them their own degeneracy evaluation back)
     if (e->ev[0]) { hipEventDestroy(e->ev[0]); hipEventDestroy(e->ev[1]); }
+    delete e->held;
     lio_scan_destroy(e->scan);
     if (e->own_map) lio_map_destroy(e->map);
     delete e;
@@ -1390,11 +1393,13 @@ int lio_fastlio_pcl_enqueue_device(lio_engine* e, const void* d_xyzi, const void
     return fe_enqueue(e, static_cast<const float*>(d_xyzi), static_cast<const uint32_t*>(d_stamp_us), n, header_stamp, true);
 }
 
-int lio_fastlio_main(lio_engine* e) {
-    if (!e || !e->fe) return LIO_E_INVALID;
+// fastlio_main in two halves around process_core, so that the batched sequence mode (batch.hip: lio_batch_fastlio_main) can run the middle of
+// many sessions as one round.  The front half: sync_packages, the first-scan / IMU-initialisation returns, forward propagation + undistortion
+// (enqueued on the scan's stream).  kFrontReady: the scan in `sc` is ready for process_core(e, sc.beg).
+constexpr int kFrontReady = 1000;
+static int fastlio_front(lio_engine* e, PendingScan& sc) {
     Frontend* f = e->fe;
     lio_scan* s = e->scan;
-    PendingScan sc;
     std::vector<ImuSample> meas_imu;
     double lidar_end;
     double ins_vel[3] = {0, 0, 0};
@@ -1427,15 +1432,13 @@ int lio_fastlio_main(lio_engine* e) {
         fe_release(f, sc);
         return LIO_MAIN_FIRST_SCAN;
     }
-    int rc;
     if (meas_imu.empty()) {
         // ImuProcess::Process returns at once: feats_undistort still holds the PREVIOUS scan's cloud, which fastlio_main
         // then registers again (IMU_Processing.hpp:413, laserMapping.cpp:1189-1197)
         fe_release(f, sc);
+        sc.pinned = -1;  // (released: the back half has nothing to give back)
         if (!f->have_undistorted) return LIO_MAIN_IMU_INIT;
-        rc = process_core(e, sc.beg);
-        f->end_state = e->kf.x;
-        return rc;
+        return kFrontReady;
     }
     if (f->imu_need_init) {  // IMU_Processing.hpp:416-441
         fe_imu_init(e, meas_imu, lidar_end, have_ins ? ins_vel : nullptr);
@@ -1449,13 +1452,47 @@ int lio_fastlio_main(lio_engine* e) {
         return LIO_MAIN_IMU_INIT;
     }
     f->state_init_done = true;  // IMU_Processing.hpp:443: set by the first scan that is undistorted, one scan after imu_need_init_ clears
-    rc = fe_undistort(e, sc, meas_imu, lidar_end);
+    const int rc = fe_undistort(e, sc, meas_imu, lidar_end);
     if (rc != LIO_OK) { fe_release(f, sc); return rc; }
-    rc = process_core(e, sc.beg);
-    if (sc.pinned >= 0) hipStreamSynchronize(s->stream);  // the staging buffer goes back to the pool only after its copy ran
+    return kFrontReady;
+}
+// ... and what follows process_core
+static void fastlio_back(lio_engine* e, const PendingScan& sc) {
+    Frontend* f = e->fe;
+    if (sc.pinned >= 0) hipStreamSynchronize(e->scan->stream);  // the staging buffer goes back to the pool only after its copy ran
     fe_release(f, sc);
     f->end_state = e->kf.x;
+}
+
+int lio_fastlio_main(lio_engine* e) {
+    if (!e || !e->fe) return LIO_E_INVALID;
+    PendingScan sc;
+    const int fr = fastlio_front(e, sc);
+    if (fr != kFrontReady) return fr;
+    const int rc = process_core(e, sc.beg);
+    fastlio_back(e, sc);
     return rc;
+}
+
+// the two halves for the sequence batch (internal; batch.hip).  engine_fastlio_front: LIO_MAIN_* / an error for a scan that ends in the front
+// half, else 1000 with the scan ready in the engine's own buffers -- the undistortion has been WAITED for (the round reads the cloud from
+// another stream) -- and its registration inputs in the out arguments; the held scan is remembered in the engine until engine_fastlio_back.
+int engine_fastlio_front(lio_engine* e, const void** d_raw, uint32_t* n_raw, double* beg, double state26[26], double cov529[529]) {
+    if (!e || !e->fe) return LIO_E_INVALID;
+    if (!e->held) e->held = new lio_held_scan();
+    const int fr = fastlio_front(e, e->held->sc);
+    if (fr != kFrontReady) return fr;
+    lio_scan* s = e->scan;
+    if (hipStreamSynchronize(s->stream) != hipSuccess) { set_error("fastlio front half: %s", hipGetErrorString(hipGetLastError())); fe_release(e->fe, e->held->sc); return LIO_E_DEVICE; }
+    *d_raw = s->raw;
+    *n_raw = s->n_raw;
+    *beg = e->held->sc.beg;
+    state_to_array(e->kf.x, state26);
+    memcpy(cov529, e->kf.P, sizeof(double) * 529);
+    return kFrontReady;
+}
+void engine_fastlio_back(lio_engine* e) {
+    if (e && e->fe && e->held) fastlio_back(e, e->held->sc);
 }
 
 static void odom_matrix(const LioState& x, double T[16]) {  // pos + Quaterniond(rot).normalized().toRotationMatrix()

@@ -872,6 +872,14 @@ class SequenceBatch:
         check(lib().lio_batch_kernel_times(self.h, C.byref(t), int(reset)))
         return {k: getattr(t, k) for k, _ in t._fields_}
 
+    def fastlio_main(self):
+        """lio_batch_fastlio_main: one fastlio_main per session (their engines carry the front half: engine(s).fastlio_init, fastlio_imu_enqueue,
+        fastlio_pcl_enqueue...), the registrations of all sessions as one round; returns (rc, per-session return codes)"""
+        if not hasattr(self, "_fl_rc"):
+            self._fl_rc = (C.c_int * self.n)()
+        rc = lib().lio_batch_fastlio_main(self.h, self._fl_rc)
+        return rc, list(self._fl_rc)
+
     def load(self, jobs):
         """jobs: one entry per session -- None (idle this round) or a dict {dptr, n, t, state (26,), cov (23,23)}"""
         assert len(jobs) == self.n

@@ -149,3 +149,93 @@ def test_sequence_batch_rejects_what_it_cannot_run(scene):
     rc, res = b.step([None, None])
     assert rc == 0 and res == [None, None]
     b.close()
+
+
+def test_fastlio_main_for_all_sessions_at_once(scene):
+    """lio_batch_fastlio_main: the reference's entry points (fastlio_init / imu_enqueue / pcl_enqueue / main) for three recorded drives in lock
+    step -- IMU initialisation, forward propagation and undistortion per session, the registrations + map_incremental as one round -- against
+    lio_fastlio_main on a per-session engine with the device loop on: same return codes, same states, same maps, bit for bit.  The sessions are
+    out of phase (one starts two calls later, one loses the IMU for a scan)."""
+    from lsd_amd import capi, lio, synth
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device")
+    n_sess, n_scans = 3, 26
+    kw = dict(resolution=0.5, stencil=75, max_points=800_000, max_voxels=150_000, max_raw=1 << 17, max_ds=60000)
+    trajs = [synth.Trajectory(p0=(-30.0 + 25.0 * s, 10.0 * s - 10.0, 1.8), heading=0.3 + 1.1 * s, speed=5.0 + s, t_static=1.2) for s in range(n_sess)]
+    start_call = [0, 2, 0]
+    sweeps = []
+    for s, tr in enumerate(trajs):
+        imu = synth.imu_stream(tr, 0.0, 0.1 * n_scans + 0.2, rate=200.0)
+        sw = []
+        for k in range(n_scans):
+            pts, st = synth.make_sweep(scene, tr, 0.1 * k, n_beams=64, n_az=400, seed=50 * s + k, fov_deg=(-24.8, 2.0), max_range=60.0)
+            sw.append((pts, st))
+        sweeps.append((imu, sw))
+
+    def feed(e, s, k, ii):
+        """what arrives for session s before its k-th fastlio_main: the IMU samples up to the scan's end (none for scan 20 of session 2), the scan"""
+        imu, sw = sweeps[s]
+        tb = 0.1 * k
+        drop = s == 2 and k == 20
+        while ii < len(imu) and imu[ii][0] <= tb + 0.1:
+            if not drop:
+                e.fastlio_imu_enqueue(*imu[ii])
+            ii += 1
+        if drop:
+            e.fastlio_imu_enqueue(imu[ii][0] + 0.2, imu[ii][1], imu[ii][2])
+        pts, st = sw[k]
+        e.fastlio_pcl_enqueue(pts, st, tb)
+        return ii
+
+    # ---- per-session engines ----
+    solo = []
+    for s in range(n_sess):
+        e = lio.Engine(**kw)
+        e.set_device_loop(True)
+        e.fastlio_init(scan_period=0.1, filter_num=2)
+        ii, out = 0, []
+        for k in range(n_scans):
+            ii = feed(e, s, k, ii)
+            rc = e.fastlio_main()
+            out.append((rc, e.get_state(), e.get_cov()))
+        assert e.fastlio_main() == capi.MAIN_IDLE
+        e.flush()
+        solo.append(dict(out=out, stats=e.map.stats(), dump=_rows(e.map.dump()), odom=e.fastlio_odometry()))
+        e.close()
+    assert all(sum(1 for o in x["out"] if o[0] == capi.MAIN_UPDATED) >= 8 for x in solo)
+
+    # ---- the same drives as sessions of one sequence batch ----
+    b = lio.SequenceBatch(n_slots=n_sess, n_groups=1, **kw)
+    eng = [b.engine(s) for s in range(n_sess)]
+    for e in eng:
+        e.fastlio_init(scan_period=0.1, filter_num=2)
+    iis, ks = [0] * n_sess, [0] * n_sess
+    got = [[] for _ in range(n_sess)]
+    call = 0
+    while any(k < n_scans for k in ks):
+        fed = []
+        for s in range(n_sess):
+            if call >= start_call[s] and ks[s] < n_scans:
+                iis[s] = feed(eng[s], s, ks[s], iis[s])
+                ks[s] += 1
+                fed.append(s)
+        rc, rcs = b.fastlio_main()
+        assert rc == 0, capi.lib().lio_last_error().decode()
+        for s in range(n_sess):
+            if s in fed:
+                got[s].append((rcs[s], eng[s].get_state(), eng[s].get_cov()))
+            else:
+                assert rcs[s] == capi.MAIN_IDLE
+        call += 1
+    rc, rcs = b.fastlio_main()
+    assert rc == 0 and all(r == capi.MAIN_IDLE for r in rcs)
+    for s in range(n_sess):
+        assert [g[0] for g in got[s]] == [o[0] for o in solo[s]["out"]], s
+        for k, (g, o) in enumerate(zip(got[s], solo[s]["out"])):
+            assert np.array_equal(g[1], o[1]) and np.array_equal(g[2], o[2]), (s, k, np.abs(g[1] - o[1]).max())
+        assert tuple(eng[s].map.stats()) == tuple(solo[s]["stats"]), s
+        assert np.array_equal(_rows(eng[s].map.dump()), solo[s]["dump"]), s
+        oa, ob = eng[s].fastlio_odometry(), solo[s]["odom"]
+        assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1]), s
+    b.close()
