@@ -874,14 +874,18 @@ def bench_sequences(args, torch, local_rank, dev):
     step_len = 1.0  # 10 m/s at 10 Hz
     t_gen = time.perf_counter()
     plans = []
+    def clear_of_boxes(xy):
+        return not np.any((scene.lo[:, 0] - 1.5 < xy[0]) & (xy[0] < scene.hi[:, 0] + 1.5) & (scene.lo[:, 1] - 1.5 < xy[1]) & (xy[1] < scene.hi[:, 1] + 1.5))
+
     for s in range(n_sess):
-        while True:
+        while True:  # a straight drive that stays 1.5 m clear of every box over all K sweeps (and inside the scene)
             xy = rng.uniform(-70, 70, 2)
-            if not np.any((scene.lo[:, 0] - 1.5 < xy[0]) & (xy[0] < scene.hi[:, 0] + 1.5) & (scene.lo[:, 1] - 1.5 < xy[1]) & (xy[1] < scene.hi[:, 1] + 1.5)):
+            yaw = rng.uniform(-np.pi, np.pi)
+            step = step_len * np.array([np.cos(yaw), np.sin(yaw), 0.0])
+            end = xy + (K - 1) * step[:2]
+            if np.all(np.abs(end) < 90.0) and all(clear_of_boxes(xy + k * step[:2]) for k in range(K)):
                 break
-        yaw = rng.uniform(-np.pi, np.pi)
         q = synth.quat_from_rotvec([0, 0, yaw])
-        step = step_len * np.array([np.cos(yaw), np.sin(yaw), 0.0])
         scans = []
         for k in range(K):
             pos = np.array([xy[0], xy[1], 1.8]) + k * step
@@ -997,6 +1001,41 @@ def bench_sequences(args, torch, local_rank, dev):
             identical = False
     out1, ts1, _ = solo(0, False, K)
     solo_ms = 1e3 * float(np.mean([ts1[i] for i in timed]))
+    # same-run CPU baseline: session 0's sweeps through the oracle's restatement of fastlio_main after IMU processing (VoxelGrid, iVox kNN on 8
+    # threads, esekfom update, map_incremental) -- the engine-level port that tests/test_lru_gpu.py holds the engines against -- with the same priors
+    cpu = None
+    if args.cpu_scans > 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle  # test infrastructure; used here only as the timed CPU baseline / checker
+
+            threads = min(8, usable_cpus())
+            o = oracle.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=threads)
+            st, P = plans[0]["s0"].copy(), P0.copy()
+            t_o, pts_o, worst = 0.0, 0, 0.0
+            for k in range(K):
+                raw = plans[0]["scans"][k]["d"].cpu().numpy()
+                o.set_state(st)
+                o.set_cov(P)
+                c0 = time.perf_counter()
+                rc_o = o.process_scan(raw, plans[0]["scans"][k]["t"])
+                dt_o = time.perf_counter() - c0
+                if rc_o != states[0][k][0]:
+                    worst = float("inf")
+                if rc_o == 3:
+                    so = o.get_state()
+                    worst = max(worst, float(np.linalg.norm(so[:3] - states[0][k][1][:3])))
+                    st, P = next_prior(so, o.get_cov(), plans[0]["step"])
+                    if k in timed:
+                        t_o += dt_o
+                        pts_o += len(raw)
+            cpu = dict(value=round(pts_o / t_o, 1), unit="points/s", cores=threads, host_cpus=usable_cpus(), kind="port",
+                       sample=f"session 0's {len(timed)} timed sweeps through the oracle's engine-level restatement (oracle.Lio.process_scan: VoxelGrid, iVox kNN on "
+                              f"{threads} threads, esekfom update, map_incremental into its own iVox), same priors rule, {t_o:.1f} s; the reference's own code on "
+                              f"streaming sweeps is configs.config3_*.cpu_baseline",
+                       ms_per_sweep=round(1e3 * t_o / max(len(timed), 1), 2), gpu_vs_oracle_pose_max_dpos_m=worst)
+        except Exception as ex:
+            cpu = {"error": repr(ex)[-300:]}
     # SURVEY 8d per sweep, map insert included: B_ds + n_knn B_knn + n_pass B_lin + B_ins
     cand = None
     add_per_sweep = float(np.mean([(map_pts[s][0]) for s in range(n_sess)])) / max(K - 1, 1)
@@ -1023,7 +1062,7 @@ def bench_sequences(args, torch, local_rank, dev):
                      "achieved": round((b_ds + npass * b_lin + b_ins) / (ms_per_sweep * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round((b_ds + npass * b_lin + b_ins) / (ms_per_sweep * 1e-3) / 8e12, 4), "traffic": None,
                      "terms": {"B_ds": int(b_ds), "B_lin": int(b_lin), "n_pass": round(npass, 2), "B_ins": int(b_ins), "B_knn": "not counted"}},
-        "cpu_baseline": None,
+        "cpu_baseline": cpu,
         "device_us_per_round": dev_us,
         "one_session_at_a_time": {"ms_per_sweep": round(solo_ms, 4), "what": "session 0's sweeps through lio_engine_process_scan_device + flush on its own engine (host-driven loop, "
                                                                              "resident clouds): the single-scan path incl. map_incremental", "speedup_of_the_batch": round(solo_ms / ms_per_sweep, 2)},

@@ -583,6 +583,7 @@ lio_batch* lio_batch_create_sequences(int device, float resolution, int stencil,
     b->max_raw = max_raw;
     b->max_ds = max_ds;
     b->sequences = true;
+    { const char* k = getenv("LIO_BATCH_GRAPH"); b->use_graph = (k && k[0] == '0') ? 0 : 1; }
     b->groups.resize(n_groups);
     bool ok = true;
     for (Group& g : b->groups) ok = ok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess;
@@ -716,17 +717,48 @@ int lio_batch_sequences_step(lio_batch* b, lio_scan_job* jobs, int n_jobs, doubl
         }
         if (g.n_active == 0) continue;
         const bool timed = g.bt && g.bt->on;
-        BatchTimer* bt = timed ? g.bt : nullptr;
-        LIO_HIP_TRY(hipMemcpyAsync(g.d_block, g.h_block, g.block_bytes, hipMemcpyHostToDevice, g.stream));
-        if (bt) bt->begin(0);
-        int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes);
-        if (bt) bt->end(0);
-        if (rc == LIO_OK) rc = p2plane_seq_update(g.stream, g.d_maps, g.d_desc, B, ds_bound, 5, stencils, stencil_ids, n_st, bt);
-        if (bt) bt->begin(4);
-        if (rc == LIO_OK) rc = p2plane_seq_insert(g.stream, g.d_maps, g.d_desc, g.d_seq, B, ds_bound, g.any_lru);
-        if (bt) bt->end(4);
+        // the round: upload, chain, update, insert, read-back -- every argument is fixed per group (pointers into the group's blocks; what changes
+        // travels in the block) except the stencils, which the neighbour search takes by value: captured once per (radix passes, stencil set, LRU
+        // or not) into a graph and replayed with one hipGraphLaunch (~45 API calls otherwise)
+        auto enqueue = [&](BatchTimer* bt) -> int {
+            LIO_HIP_TRY(hipMemcpyAsync(g.d_block, g.h_block, g.block_bytes, hipMemcpyHostToDevice, g.stream));
+            if (bt) bt->begin(0);
+            int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes);
+            if (bt) bt->end(0);
+            if (rc == LIO_OK) rc = p2plane_seq_update(g.stream, g.d_maps, g.d_desc, B, ds_bound, 5, stencils, stencil_ids, n_st, bt);
+            if (bt) bt->begin(4);
+            if (rc == LIO_OK) rc = p2plane_seq_insert(g.stream, g.d_maps, g.d_desc, g.d_seq, B, ds_bound, g.any_lru);
+            if (bt) bt->end(4);
+            if (rc != LIO_OK) return rc;
+            LIO_HIP_TRY(hipMemcpyAsync(g.h_seq, g.d_seq, sizeof(SeqDev) * (size_t)B, hipMemcpyDeviceToHost, g.stream));
+            return LIO_OK;
+        };
+        int rc = LIO_OK;
+        if (!b->use_graph || timed) {
+            rc = enqueue(timed ? g.bt : nullptr);
+        } else {
+            int sig = g.any_lru ? 1 : 0;  // what the captured launches hold by value
+            for (int k = 0; k < n_st; k++) sig = sig * 131 + stencil_ids[k] + 1;
+            if (g.graph_stencil != sig) {
+                for (int k = 0; k < 5; k++)
+                    if (g.exec[k]) { hipGraphExecDestroy(g.exec[k]); g.exec[k] = nullptr; }
+                g.graph_stencil = sig;
+            }
+            if (!g.exec[passes]) {
+                hipGraph_t graph = nullptr;
+                rc = hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal) == hipSuccess ? LIO_OK : LIO_E_DEVICE;
+                if (rc == LIO_OK) {
+                    rc = enqueue(nullptr);
+                    const hipError_t e2 = hipStreamEndCapture(g.stream, &graph);
+                    if (rc == LIO_OK && e2 != hipSuccess) rc = LIO_E_DEVICE;
+                    if (rc == LIO_OK && hipGraphInstantiate(&g.exec[passes], graph, nullptr, nullptr, 0) != hipSuccess) rc = LIO_E_DEVICE;
+                    if (graph) hipGraphDestroy(graph);
+                }
+                if (rc == LIO_E_DEVICE) set_error("sequence batch: capturing the round failed: %s", hipGetErrorString(hipGetLastError()));
+            }
+            if (rc == LIO_OK && hipGraphLaunch(g.exec[passes], g.stream) != hipSuccess) { set_error("sequence batch: hipGraphLaunch: %s", hipGetErrorString(hipGetLastError())); rc = LIO_E_DEVICE; }
+        }
         if (rc != LIO_OK) { for (int k = 0; k <= gi; k++) hipStreamSynchronize(b->groups[k].stream); return rc; }
-        LIO_HIP_TRY(hipMemcpyAsync(g.h_seq, g.d_seq, sizeof(SeqDev) * (size_t)B, hipMemcpyDeviceToHost, g.stream));
         b->n_rounds++;
     }
     // ---- collect ----
