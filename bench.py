@@ -928,6 +928,8 @@ def bench_sequences(args, torch, local_rank, dev):
             if a.rc == 3:
                 priors[s] = next_prior(sb.states_out[s], sb.covs_out[s], plans[s]["step"])
                 reg += 1
+            else:  # nothing registered (time origin, map seed): the sensor moved on all the same
+                priors[s] = (priors[s][0] + np.r_[plans[s]["step"], np.zeros(23)], priors[s][1])
         t_round.append(dt)
         n_reg.append(reg)
     full = [i for i in range(K) if n_reg[i] == n_sess]  # rounds in which every session registered + inserted a scan (from the third on)
@@ -959,7 +961,7 @@ def bench_sequences(args, torch, local_rank, dev):
                   "linearize_per_launch": round(kt["linearize_us"] / max(kt["linearize_launches"], 1), 1),
                   "filter_pass_per_launch": round(kt["step_us"] / max(kt["step_launches"], 1), 1),
                   "map_incremental": round(kt["insert_us"] / max(kt["insert_launches"], 1), 1), "slots_per_round": B,
-                  "note": "HIP events on the round's stream, plain launches (no graph in this mode yet), one round per group in flight"}
+                  "note": "HIP events on the round's stream (timed rounds run as plain launches; untimed ones as one graph per group), one round per group in flight"}
     except Exception as ex:
         dev_us = {"error": repr(ex)[-200:]}
 
@@ -981,6 +983,8 @@ def bench_sequences(args, torch, local_rank, dev):
             out.append((rc, e.get_state(), e.get_cov().reshape(-1)))
             if rc == 3:
                 st, P = next_prior(out[-1][1], out[-1][2], plans[s]["step"])
+            else:
+                st = st + np.r_[plans[s]["step"], np.zeros(23)]
         stats = e.map.stats()
         e.close()
         return out, ts, stats
@@ -1029,6 +1033,8 @@ def bench_sequences(args, torch, local_rank, dev):
                     if k in timed:
                         t_o += dt_o
                         pts_o += len(raw)
+                else:
+                    st = st + np.r_[plans[0]["step"], np.zeros(23)]
             cpu = dict(value=round(pts_o / t_o, 1), unit="points/s", cores=threads, host_cpus=usable_cpus(), kind="port",
                        sample=f"session 0's {len(timed)} timed sweeps through the oracle's engine-level restatement (oracle.Lio.process_scan: VoxelGrid, iVox kNN on "
                               f"{threads} threads, esekfom update, map_incremental into its own iVox), same priors rule, {t_o:.1f} s; the reference's own code on "

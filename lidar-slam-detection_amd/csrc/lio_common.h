@@ -94,6 +94,7 @@ struct ScanDev {
     int32_t minb[3];
     int32_t mul1, mul2;
     uint32_t total_cells;
+    uint32_t n_monster;    // voxels with thousands of points, queued from the top of longlist for the wave-per-coordinate sums
 };
 
 struct StencilArgs {

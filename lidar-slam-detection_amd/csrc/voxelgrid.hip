@@ -500,16 +500,34 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
 // close to the sensor: a few hundred voxels holding half of the points) are queued for the wave-per-voxel
 // kernel below, so that their latency is spread over the chip instead of serialising one wave.
 constexpr uint32_t kLongRun = 32;
+// ... and the few runs of thousands of points (a wall a metre from the sensor, the ground ring under it) go to a second queue, filled from the
+// top of the same array, whose runs are summed one COMPONENT per wave by integer arithmetic inside the running sum's binade (monster_sum below)
+constexpr uint32_t kMonsterRun = 2048;
+constexpr uint32_t kMonsterBlocks = 16;       // workgroups of the long-run launch that serve the monster queue (one scan)
+constexpr uint32_t kMonsterBlocksBatch = 4;   // ... per slot of a batched launch
 
 __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                ScanDev* __restrict__ sd, float4* __restrict__ out,
-                                                               uint32_t* __restrict__ longlist) {
+                                                               uint32_t* __restrict__ longlist, uint32_t max_ds) {
     if (sd->passthrough) return;
     const uint32_t nv = sd->n_ds;
     const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
     if (v >= nv) return;
     const uint32_t a = hpos[v];
     const uint32_t b = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;  // invalid (non-finite) points sort behind every voxel
+    const bool is_monster = b - a >= kMonsterRun;
+    const unsigned long long mm = __ballot(is_monster);
+    if (mm) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mm) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&sd->n_monster, (uint32_t)__popcll(mm));
+        base = __shfl(base, leader);
+        if (is_monster) {
+            longlist[max_ds - 1u - (base + __popcll(mm & ((1ull << lane) - 1ull)))] = v;
+            return;
+        }
+    }
     // queue the long runs: one atomic per wave (ballot + popcount), not one per voxel
     const bool is_long = b - a >= kLongRun;
     const unsigned long long lm = __ballot(is_long);
@@ -543,14 +561,122 @@ __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sort
 // end is not requested, so a 40-point run costs one load).  Until round 4 one batch was in flight: ~0.15 us of adds behind every ~0.8 us load for
 // the voxels that hold thousands of points (a wall a metre from the sensor).  (Also measured in round 4 and not kept: 512 points parked per
 // step -- 32 KB of LDS per workgroup and eight loads per lane even for a 40-point run: 31 -> 83 us per batched round.)
+// The sequential f32 sum  s <- fl(s + x_i)  of ONE coordinate over a run of thousands of points, exactly, 256 points per step of one wave.
+// While the running sum stays inside one binade [2^k, 2^(k+1)) every addition rounds to a multiple of q = 2^(k-23); s = S q with an integer
+// S, and fl(s + x) = (S + rne(x / q)) q unless x / q lies exactly half way between two integers (then the tie goes to the even RESULT, which
+// depends on S).  Integer additions associate: the 256 addends of a step become integers R_i = rne(x_i / q) (lane l holds points 4l .. 4l + 3
+// of the step), a wave prefix sum gives every partial sum T_i = S + R_1 + ... + R_i, and the step is accepted if no x_i / q is a tie, every
+// |R_i| < 2^22 (no integer overflow) and every T_i lies strictly inside (2^23, 2^24) with the sign of S -- i.e. every intermediate sum the
+// sequential loop would have formed stayed in the binade: then those sums ARE T_i q, bit for bit.  Otherwise (the sum crosses into the next binade
+// ~log2(n) times per run; a tie about once per 2^12 points; the first step, from s = 0) the step is redone by the plain loop on one lane.
+// tests/test_seqsum_math.py holds the rule against the plain loop on adversarial data on the CPU; tests/test_voxelgrid_monster_gpu.py this code.
+__device__ __forceinline__ float monster_component_sum(const float4* __restrict__ sorted, uint32_t ra, uint32_t rb, int c, float* __restrict__ park /* [256] */,
+                                                       int lane) {
+    auto comp = [c](const float4& p) { return c == 0 ? p.x : (c == 1 ? p.y : (c == 2 ? p.z : p.w)); };
+    float s = 0.f;
+    float nx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = ra + (uint32_t)j * 64u + lane;
+        nx[j] = i < rb ? comp(sorted[i]) : 0.f;
+    }
+    for (uint32_t pos = ra; pos < rb; pos += 256u) {
+        const uint32_t n_here = rb - pos < 256u ? rb - pos : 256u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) park[j * 64 + lane] = nx[j];
+        if (pos + 256u < rb) {  // the next step's points are requested before this one is summed
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = pos + 256u + (uint32_t)j * 64u + lane;
+                nx[j] = i < rb ? comp(sorted[i]) : 0.f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 mine = *reinterpret_cast<const float4*>(park + lane * 4);  // points 4 lane .. 4 lane + 3 of the step, in order
+        const float xs[4] = {mine.x, mine.y, mine.z, mine.w};
+        bool fast = false;
+        const uint32_t sb = __float_as_uint(s);
+        const int be = (int)((sb >> 23) & 0xFFu);
+        if (be >= 1 && be <= 254) {  // a normal, non-zero running sum (uniform over the wave)
+            const int e = be - 127 - 23;
+            const int S0 = (int)ldexpf(s, -e);  // the mantissa with its sign: 2^23 <= |S0| < 2^24
+            bool viol = false;
+            int pre[4];
+            int loc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if ((uint32_t)(lane * 4 + j) < n_here) {
+                    const float r = ldexpf(xs[j], -e);
+                    const bool ok = fabsf(r) < 4194304.f;
+                    const float rn = rintf(r);
+                    viol |= !ok || fabsf(r - rn) == 0.5f;
+                    loc += ok ? (int)rn : 0;
+                }
+                pre[j] = loc;
+            }
+            int inc = loc;  // inclusive scan of the lanes' totals
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off);
+                if (lane >= off) inc += t;
+            }
+            const int before = S0 + (inc - loc);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if ((uint32_t)(lane * 4 + j) < n_here) {
+                    const int T = before + pre[j];
+                    const int aT = S0 > 0 ? T : -T;
+                    viol |= !(aT > 8388608 && aT < 16777216);
+                }
+            }
+            if (!__ballot(viol)) {
+                const int total = __shfl(inc, 63);
+                s = ldexpf((float)(S0 + total), e);
+                fast = true;
+            }
+        }
+        if (!fast) {  // the plain loop over the parked step, one lane
+            float t = s;
+            if (lane == 0) {
+                uint32_t j = 0;
+                for (; j + 4 <= n_here; j += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(park + j);
+                    t = t + a.x; t = t + a.y; t = t + a.z; t = t + a.w;
+                }
+                for (; j < n_here; j++) t = t + park[j];
+            }
+            s = __shfl(t, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    return s;
+}
+
+// workgroups [0, n_long_blocks) serve the long-run queue one run per wave; the workgroups beyond serve the monster queue one run per
+// workgroup, wave c summing coordinate c
 __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
-                                                                    const uint32_t* __restrict__ longlist) {
+                                                                    const uint32_t* __restrict__ longlist, uint32_t max_ds, uint32_t n_long_blocks) {
     if (sd->passthrough) return;
     const uint32_t nv = sd->n_ds, nl = sd->n_long;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t nwaves = gridDim.x * kWaves;
     __shared__ __attribute__((aligned(16))) float park[kWaves][4][64];
+    if (blockIdx.x >= n_long_blocks) {
+        const uint32_t nm = sd->n_monster;
+        for (uint32_t m = blockIdx.x - n_long_blocks; m < nm; m += gridDim.x - n_long_blocks) {
+            const uint32_t v = longlist[max_ds - 1u - m];
+            const uint32_t ra = hpos[v];
+            const uint32_t rb = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;
+            const float t = monster_component_sum(sorted, ra, rb, wv, &park[wv][0][0], lane);
+            if (lane == 0) reinterpret_cast<float*>(&out[v])[wv] = t / (float)(rb - ra);
+        }
+        return;
+    }
+    const uint32_t nwaves = n_long_blocks * kWaves;
     constexpr int kAhead = 4;
     for (uint32_t w = blockIdx.x * kWaves + wv; w < nl; w += nwaves) {
         const uint32_t v = longlist[w];
@@ -616,7 +742,7 @@ __device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict
     if (blockIdx.x == 0 && threadIdx.x < 3) {
         sd->bbox_min[threadIdx.x] = 0xFFFFFFFFu;
         sd->bbox_max[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) { sd->n_valid = 0; sd->n_long = 0; }
+        if (threadIdx.x == 0) { sd->n_valid = 0; sd->n_long = 0; sd->n_monster = 0; }
     }
 }
 
@@ -684,24 +810,24 @@ __global__ void __launch_bounds__(kThreads) vg_heads_batch(const SlotDesc* __res
 }
 __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                ScanDev* __restrict__ sd, float4* __restrict__ out,
-                                                               uint32_t* __restrict__ longlist) {
-    vg_centroid_body(sorted, hpos, sd, out, longlist);
+                                                               uint32_t* __restrict__ longlist, uint32_t max_ds) {
+    vg_centroid_body(sorted, hpos, sd, out, longlist, max_ds);
 }
 __global__ void __launch_bounds__(kThreads) vg_centroid_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    vg_centroid_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist);
+    vg_centroid_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist, d.max_ds);
 }
 __global__ void __launch_bounds__(kThreads) vg_centroid_long_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
-                                                                    const uint32_t* __restrict__ longlist) {
-    vg_centroid_long_body(sorted, hpos, sd, out, longlist);
+                                                                    const uint32_t* __restrict__ longlist, uint32_t max_ds, uint32_t n_long_blocks) {
+    vg_centroid_long_body(sorted, hpos, sd, out, longlist, max_ds, n_long_blocks);
 }
 // + the scan-begin duties (Nearest_Points.resize, re-arming the bbox) of the batch: the long-run kernel is the last of the chain
 __global__ void __launch_bounds__(kThreads) vg_centroid_long_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    vg_centroid_long_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist);
+    vg_centroid_long_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist, d.max_ds, gridDim.x - kMonsterBlocksBatch);
 }
 __global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt, uint32_t min_ds) { scan_begin_body(sd, nn_cnt, min_ds, 0u); }
 __global__ void scan_begin_batch(const SlotDesc* __restrict__ slots) {
@@ -736,8 +862,8 @@ int vg_downsample(lio_scan* s, float leaf, int passes) {
                        s->hpos, s->sorted, s->ds_body, s->max_ds, s->host_nds_dev, (uint32_t)passes);
     const uint32_t vbound = n < s->max_ds ? n : s->max_ds;
     hipLaunchKernelGGL(vg_centroid_kernel, (vbound + kThreads - 1) / kThreads, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body,
-                       s->longlist);
-    hipLaunchKernelGGL(vg_centroid_long_kernel, 256, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body, s->longlist);
+                       s->longlist, s->max_ds);
+    hipLaunchKernelGGL(vg_centroid_long_kernel, 256 + kMonsterBlocks, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body, s->longlist, s->max_ds, 256u);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }
@@ -758,7 +884,7 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
     hipLaunchKernelGGL(vg_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, (uint32_t)passes);
     const uint32_t vbound = max_raw < max_ds ? max_raw : max_ds;
     hipLaunchKernelGGL(vg_centroid_batch, dim3((vbound + kThreads - 1) / kThreads, B), kThreads, 0, st, d_slots);
-    hipLaunchKernelGGL(vg_centroid_long_batch, dim3(64, B), kThreads, 0, st, d_slots);
+    hipLaunchKernelGGL(vg_centroid_long_batch, dim3(64 + kMonsterBlocksBatch, B), kThreads, 0, st, d_slots);
     hipLaunchKernelGGL(scan_begin_batch, dim3(16, B), 256, 0, st, d_slots);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
