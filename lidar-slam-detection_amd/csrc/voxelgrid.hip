@@ -570,88 +570,103 @@ __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sort
 // sequential loop would have formed stayed in the binade: then those sums ARE T_i q, bit for bit.  Otherwise (the sum crosses into the next binade
 // ~log2(n) times per run; a tie about once per 2^12 points; the first step, from s = 0) the step is redone by the plain loop on one lane.
 // tests/test_seqsum_math.py holds the rule against the plain loop on adversarial data on the CPU; tests/test_voxelgrid_monster_gpu.py this code.
+// inclusive prefix sum over the 64 lanes of a wave by DPP (row shifts inside the rows of 16, then the row totals broadcast down): ~6 VALU
+// instructions instead of six ds_bpermute round trips
+__device__ __forceinline__ int wave_inclusive_scan_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1 (lanes without a source keep `old` = 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 __device__ __forceinline__ float monster_component_sum(const float4* __restrict__ sorted, uint32_t ra, uint32_t rb, int c, float* __restrict__ park /* [256] */,
                                                        int lane) {
     auto comp = [c](const float4& p) { return c == 0 ? p.x : (c == 1 ? p.y : (c == 2 ? p.z : p.w)); };
     float s = 0.f;
-    float nx[4];
+    constexpr int kRing = 4;  // steps requested ahead of the one being summed (a step's loads take longer than its arithmetic)
+    float nx[kRing][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t i = ra + (uint32_t)j * 64u + lane;
-        nx[j] = i < rb ? comp(sorted[i]) : 0.f;
-    }
-    for (uint32_t pos = ra; pos < rb; pos += 256u) {
-        const uint32_t n_here = rb - pos < 256u ? rb - pos : 256u;
+    for (int r = 0; r < kRing; r++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) park[j * 64 + lane] = nx[j];
-        if (pos + 256u < rb) {  // the next step's points are requested before this one is summed
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t i = pos + 256u + (uint32_t)j * 64u + lane;
-                nx[j] = i < rb ? comp(sorted[i]) : 0.f;
-            }
+        for (int j = 0; j < 4; j++) {
+            const uint32_t i = ra + (uint32_t)r * 256u + (uint32_t)j * 64u + lane;
+            nx[r][j] = i < rb ? comp(sorted[i]) : 0.f;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float4 mine = *reinterpret_cast<const float4*>(park + lane * 4);  // points 4 lane .. 4 lane + 3 of the step, in order
-        const float xs[4] = {mine.x, mine.y, mine.z, mine.w};
-        bool fast = false;
-        const uint32_t sb = __float_as_uint(s);
-        const int be = (int)((sb >> 23) & 0xFFu);
-        if (be >= 1 && be <= 254) {  // a normal, non-zero running sum (uniform over the wave)
-            const int e = be - 127 - 23;
-            const int S0 = (int)ldexpf(s, -e);  // the mantissa with its sign: 2^23 <= |S0| < 2^24
-            bool viol = false;
-            int pre[4];
-            int loc = 0;
+    for (uint32_t base = ra; base < rb; base += 256u * kRing) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if ((uint32_t)(lane * 4 + j) < n_here) {
-                    const float r = ldexpf(xs[j], -e);
-                    const bool ok = fabsf(r) < 4194304.f;
-                    const float rn = rintf(r);
-                    viol |= !ok || fabsf(r - rn) == 0.5f;
-                    loc += ok ? (int)rn : 0;
-                }
-                pre[j] = loc;
-            }
-            int inc = loc;  // inclusive scan of the lanes' totals
+        for (int r = 0; r < kRing; r++) {
+            const uint32_t pos = base + (uint32_t)r * 256u;
+            if (pos >= rb) break;  // (uniform over the wave)
+            const uint32_t n_here = rb - pos < 256u ? rb - pos : 256u;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(inc, off);
-                if (lane >= off) inc += t;
-            }
-            const int before = S0 + (inc - loc);
+            for (int j = 0; j < 4; j++) park[j * 64 + lane] = nx[r][j];
+            if (pos + 256u * kRing < rb) {  // this register set's next step: kRing steps ahead
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if ((uint32_t)(lane * 4 + j) < n_here) {
-                    const int T = before + pre[j];
-                    const int aT = S0 > 0 ? T : -T;
-                    viol |= !(aT > 8388608 && aT < 16777216);
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t i = pos + 256u * kRing + (uint32_t)j * 64u + lane;
+                    nx[r][j] = i < rb ? comp(sorted[i]) : 0.f;
                 }
             }
-            if (!__ballot(viol)) {
-                const int total = __shfl(inc, 63);
-                s = ldexpf((float)(S0 + total), e);
-                fast = true;
-            }
-        }
-        if (!fast) {  // the plain loop over the parked step, one lane
-            float t = s;
-            if (lane == 0) {
-                uint32_t j = 0;
-                for (; j + 4 <= n_here; j += 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(park + j);
-                    t = t + a.x; t = t + a.y; t = t + a.z; t = t + a.w;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float4 mine = *reinterpret_cast<const float4*>(park + lane * 4);  // points 4 lane .. 4 lane + 3 of the step, in order
+            const float xs[4] = {mine.x, mine.y, mine.z, mine.w};
+            bool fast = false;
+            const uint32_t sb = __float_as_uint(s);
+            const int be = (int)((sb >> 23) & 0xFFu);
+            if (be >= 1 && be <= 254) {  // a normal, non-zero running sum (uniform over the wave)
+                const int e = be - 127 - 23;
+                const int S0 = (int)ldexpf(s, -e);  // the mantissa with its sign: 2^23 <= |S0| < 2^24
+                bool viol = false;
+                int pre[4];
+                int loc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if ((uint32_t)(lane * 4 + j) < n_here) {
+                        const float rr = ldexpf(xs[j], -e);
+                        const bool ok = fabsf(rr) < 4194304.f;
+                        const float rn = rintf(rr);
+                        viol |= !ok || fabsf(rr - rn) == 0.5f;
+                        loc += ok ? (int)rn : 0;
+                    }
+                    pre[j] = loc;
                 }
-                for (; j < n_here; j++) t = t + park[j];
+                const int inc = wave_inclusive_scan_i32(loc);
+                const int before = S0 + (inc - loc);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if ((uint32_t)(lane * 4 + j) < n_here) {
+                        const int T = before + pre[j];
+                        const int aT = S0 > 0 ? T : -T;
+                        viol |= !(aT > 8388608 && aT < 16777216);
+                    }
+                }
+                if (!__ballot(viol)) {
+                    const int total = __builtin_amdgcn_readlane(inc, 63);
+                    s = ldexpf((float)(S0 + total), e);
+                    fast = true;
+                }
             }
-            s = __shfl(t, 0);
+            if (!fast) {  // the plain loop over the parked step, one lane
+                float t = s;
+                if (lane == 0) {
+                    uint32_t j = 0;
+                    for (; j + 4 <= n_here; j += 4) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(park + j);
+                        t = t + a4.x; t = t + a4.y; t = t + a4.z; t = t + a4.w;
+                    }
+                    for (; j < n_here; j++) t = t + park[j];
+                }
+                s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t)));  // lane 0's result to the wave
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     return s;
 }
