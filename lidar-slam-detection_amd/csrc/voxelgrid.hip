@@ -564,9 +564,9 @@ __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sort
 // The sequential f32 sum  s <- fl(s + x_i)  of ONE coordinate over a run of thousands of points, exactly, 256 points per step of one wave.
 // While the running sum stays inside one binade [2^k, 2^(k+1)) every addition rounds to a multiple of q = 2^(k-23); s = S q with an integer
 // S, and fl(s + x) = (S + rne(x / q)) q unless x / q lies exactly half way between two integers (then the tie goes to the even RESULT, which
-// depends on S).  Integer additions associate: the 256 addends of a step become integers R_i = rne(x_i / q) (lane l holds points 4l .. 4l + 3
+// depends on S).  Integer additions associate: the 512 addends of a step become integers R_i = rne(x_i / q) (lane l holds points 8l .. 8l + 7
 // of the step), a wave prefix sum gives every partial sum T_i = S + R_1 + ... + R_i, and the step is accepted if no x_i / q is a tie, every
-// |R_i| < 2^22 (no integer overflow) and every T_i lies strictly inside (2^23, 2^24) with the sign of S -- i.e. every intermediate sum the
+// |R_i| < 2^21 (no integer overflow) and every T_i lies strictly inside (2^23, 2^24) with the sign of S -- i.e. every intermediate sum the
 // sequential loop would have formed stayed in the binade: then those sums ARE T_i q, bit for bit.  Otherwise (the sum crosses into the next binade
 // ~log2(n) times per run; a tie about once per 2^12 points; the first step, from s = 0) the step is redone by the plain loop on one lane.
 // tests/test_seqsum_math.py holds the rule against the plain loop on adversarial data on the CPU; tests/test_voxelgrid_monster_gpu.py this code.
@@ -582,72 +582,74 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int x) {
     return x;
 }
 
-__device__ __forceinline__ float monster_component_sum(const float4* __restrict__ sorted, uint32_t ra, uint32_t rb, int c, float* __restrict__ park /* [256] */,
+constexpr int kMonsterPer = 8;                       // points per lane and step
+constexpr int kMonsterStep = 64 * kMonsterPer;       // 512 points per step of one wave
+__device__ __forceinline__ float monster_component_sum(const float4* __restrict__ sorted, uint32_t ra, uint32_t rb, int c, float* __restrict__ park /* [kMonsterStep] */,
                                                        int lane) {
     auto comp = [c](const float4& p) { return c == 0 ? p.x : (c == 1 ? p.y : (c == 2 ? p.z : p.w)); };
     float s = 0.f;
-    constexpr int kRing = 4;  // steps requested ahead of the one being summed (a step's loads take longer than its arithmetic)
-    float nx[kRing][4];
+    constexpr int kRing = 3;  // steps requested ahead of the one being summed (a step's loads take longer than its arithmetic)
+    constexpr int P = kMonsterPer;
+    float nx[kRing][P];
 #pragma unroll
     for (int r = 0; r < kRing; r++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t i = ra + (uint32_t)r * 256u + (uint32_t)j * 64u + lane;
+        for (int j = 0; j < P; j++) {
+            const uint32_t i = ra + (uint32_t)r * kMonsterStep + (uint32_t)j * 64u + lane;
             nx[r][j] = i < rb ? comp(sorted[i]) : 0.f;
         }
-    for (uint32_t base = ra; base < rb; base += 256u * kRing) {
+    for (uint32_t base = ra; base < rb; base += (uint32_t)kMonsterStep * kRing) {
 #pragma unroll
         for (int r = 0; r < kRing; r++) {
-            const uint32_t pos = base + (uint32_t)r * 256u;
+            const uint32_t pos = base + (uint32_t)r * kMonsterStep;
             if (pos >= rb) break;  // (uniform over the wave)
-            const uint32_t n_here = rb - pos < 256u ? rb - pos : 256u;
+            const uint32_t n_here = rb - pos < (uint32_t)kMonsterStep ? rb - pos : (uint32_t)kMonsterStep;
 #pragma unroll
-            for (int j = 0; j < 4; j++) park[j * 64 + lane] = nx[r][j];
-            if (pos + 256u * kRing < rb) {  // this register set's next step: kRing steps ahead
+            for (int j = 0; j < P; j++) park[j * 64 + lane] = nx[r][j];  // (beyond the run's end: zeros -- adding 0 changes no sum)
+            if (pos + (uint32_t)kMonsterStep * kRing < rb) {  // this register set's next step: kRing steps ahead
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t i = pos + 256u * kRing + (uint32_t)j * 64u + lane;
+                for (int j = 0; j < P; j++) {
+                    const uint32_t i = pos + (uint32_t)kMonsterStep * kRing + (uint32_t)j * 64u + lane;
                     nx[r][j] = i < rb ? comp(sorted[i]) : 0.f;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const float4 mine = *reinterpret_cast<const float4*>(park + lane * 4);  // points 4 lane .. 4 lane + 3 of the step, in order
-            const float xs[4] = {mine.x, mine.y, mine.z, mine.w};
+            float xs[P];  // points P lane .. P lane + P - 1 of the step, in order
+#pragma unroll
+            for (int j = 0; j < P; j += 4) {
+                const float4 m4 = *reinterpret_cast<const float4*>(park + lane * P + j);
+                xs[j] = m4.x; xs[j + 1] = m4.y; xs[j + 2] = m4.z; xs[j + 3] = m4.w;
+            }
             bool fast = false;
             const uint32_t sb = __float_as_uint(s);
             const int be = (int)((sb >> 23) & 0xFFu);
             if (be >= 1 && be <= 254) {  // a normal, non-zero running sum (uniform over the wave)
+                // sign-normalised: with s < 0 every addend is negated, so that the integer sums below are those of |s|
+                const uint32_t flip = sb & 0x80000000u;
                 const int e = be - 127 - 23;
-                const int S0 = (int)ldexpf(s, -e);  // the mantissa with its sign: 2^23 <= |S0| < 2^24
-                bool viol = false;
-                int pre[4];
-                int loc = 0;
+                const int S0 = (int)ldexpf(__uint_as_float(sb & 0x7FFFFFFFu), -e);  // the mantissa: 2^23 <= S0 < 2^24
+                float worst = 0.f;   // max |x / q| of this lane's points
+                bool tie = false;
+                int loc = 0, lmin = 0x7FFFFFFF, lmax = (int)0x80000000;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if ((uint32_t)(lane * 4 + j) < n_here) {
-                        const float rr = ldexpf(xs[j], -e);
-                        const bool ok = fabsf(rr) < 4194304.f;
-                        const float rn = rintf(rr);
-                        viol |= !ok || fabsf(rr - rn) == 0.5f;
-                        loc += ok ? (int)rn : 0;
-                    }
-                    pre[j] = loc;
+                for (int j = 0; j < P; j++) {  // (the zeros beyond the run's end take part: R = 0, harmless)
+                    const float rr = ldexpf(__uint_as_float(__float_as_uint(xs[j]) ^ flip), -e);
+                    const float rn = rintf(rr);
+                    worst = fmaxf(worst, fabsf(rr));
+                    tie |= fabsf(rr - rn) == 0.5f;
+                    loc += (int)fminf(fmaxf(rn, -2097152.f), 2097152.f);  // (clamped: a step with such an addend is rejected below; 512 x 2^21 + 2^24 < 2^31)
+                    lmin = min(lmin, loc);
+                    lmax = max(lmax, loc);
                 }
                 const int inc = wave_inclusive_scan_i32(loc);
                 const int before = S0 + (inc - loc);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if ((uint32_t)(lane * 4 + j) < n_here) {
-                        const int T = before + pre[j];
-                        const int aT = S0 > 0 ? T : -T;
-                        viol |= !(aT > 8388608 && aT < 16777216);
-                    }
-                }
+                // every partial sum strictly inside (2^23, 2^24): the smallest and the largest of this lane's are enough
+                const bool viol = tie || !(worst < 2097152.f) || !(before + lmin > 8388608) || !(before + lmax < 16777216);
                 if (!__ballot(viol)) {
                     const int total = __builtin_amdgcn_readlane(inc, 63);
-                    s = ldexpf((float)(S0 + total), e);
+                    s = __uint_as_float(__float_as_uint(ldexpf((float)(S0 + total), e)) | flip);
                     fast = true;
                 }
             }
@@ -679,19 +681,20 @@ __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__
     if (sd->passthrough) return;
     const uint32_t nv = sd->n_ds, nl = sd->n_long;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ __attribute__((aligned(16))) float park[kWaves][4][64];
+    __shared__ __attribute__((aligned(16))) float park[kWaves][kMonsterStep > 256 ? kMonsterStep : 256];
     if (blockIdx.x >= n_long_blocks) {
         const uint32_t nm = sd->n_monster;
         for (uint32_t m = blockIdx.x - n_long_blocks; m < nm; m += gridDim.x - n_long_blocks) {
             const uint32_t v = longlist[max_ds - 1u - m];
             const uint32_t ra = hpos[v];
             const uint32_t rb = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;
-            const float t = monster_component_sum(sorted, ra, rb, wv, &park[wv][0][0], lane);
+            const float t = monster_component_sum(sorted, ra, rb, wv, &park[wv][0], lane);
             if (lane == 0) reinterpret_cast<float*>(&out[v])[wv] = t / (float)(rb - ra);
         }
         return;
     }
     const uint32_t nwaves = n_long_blocks * kWaves;
+    float (*pk)[64] = reinterpret_cast<float (*)[64]>(&park[wv][0]);  // this wave's four coordinate rows of 64
     constexpr int kAhead = 4;
     for (uint32_t w = blockIdx.x * kWaves + wv; w < nl; w += nwaves) {
         const uint32_t v = longlist[w];
@@ -709,7 +712,7 @@ __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__
             for (int k = 0; k < kAhead; k++) {
                 const uint32_t c0 = c + (uint32_t)k * 64u;
                 if (c0 >= rb) break;  // (uniform over the wave)
-                park[wv][0][lane] = p[k].x; park[wv][1][lane] = p[k].y; park[wv][2][lane] = p[k].z; park[wv][3][lane] = p[k].w;
+                pk[0][lane] = p[k].x; pk[1][lane] = p[k].y; pk[2][lane] = p[k].z; pk[3][lane] = p[k].w;
                 const uint32_t cn = c0 + 64u * kAhead;  // this register's next batch: four batches ahead
                 if (cn < rb) p[k] = sorted[(cn + lane) < rb ? cn + lane : rb - 1];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -717,7 +720,7 @@ __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int m = (rb - c0) < 64u ? (int)(rb - c0) : 64;
                 if (lane < 4) {
-                    const float* q = park[wv][lane];
+                    const float* q = pk[lane];
                     int j = 0;
                     for (; j + 4 <= m; j += 4) {
                         const float4 a = *reinterpret_cast<const float4*>(q + j);

@@ -1,4 +1,4 @@
-"""The rule behind csrc/voxelgrid.hip::monster_component_sum -- the SEQUENTIAL f32 sum s <- fl(s + x_i) of a run of thousands of points computed 256
+"""The rule behind csrc/voxelgrid.hip::monster_component_sum -- the SEQUENTIAL f32 sum s <- fl(s + x_i) of a run of thousands of points computed 512
 points per step by integer arithmetic inside the running sum's binade -- restated with numpy and held against the plain loop on adversarial data
 (CPU; the device code itself is held against the oracle in tests/test_voxelgrid_monster_gpu.py)."""
 import numpy as np
@@ -15,7 +15,7 @@ def seq_sum(s, xs):
 
 def fast_step(s, xs):
     """(accepted, s_new): while the running sum stays in one binade [2^k, 2^(k+1)) every addition rounds to a multiple of q = 2^(k-23), so with
-    s = S q:  fl(s + x) = (S + rne(x / q)) q  unless x / q is an exact tie; accepted iff no tie, every |rne(x_i / q)| < 2^22 and every partial
+    s = S q:  fl(s + x) = (S + rne(x / q)) q  unless x / q is an exact tie; accepted iff no tie, every |x_i / q| < 2^21 and every partial
     integer sum strictly inside (2^23, 2^24) with the sign of S"""
     s = f32(s)
     be = int((np.array([s], f32).view(np.uint32)[0] >> 23) & 0xFF)
@@ -26,7 +26,7 @@ def fast_step(s, xs):
     xs = np.asarray(xs, f32)
     with np.errstate(over="ignore", under="ignore"):
         r = np.ldexp(xs, np.int32(-e)).astype(f32)
-    ok = np.abs(r) < f32(4194304.0)
+    ok = np.abs(r) < f32(2097152.0)
     rn = np.rint(r).astype(f32)
     if not ok.all() or (np.abs(r - rn) == f32(0.5)).any():
         return False, s
@@ -37,7 +37,7 @@ def fast_step(s, xs):
     return True, f32(np.ldexp(np.float64(T[-1]), e))
 
 
-def monster_sum(xs, step=256):
+def monster_sum(xs, step=512):
     s, fast, slow = f32(0), 0, 0
     for p in range(0, len(xs), step):
         ok, s2 = fast_step(s, xs[p:p + step])
@@ -78,4 +78,4 @@ def test_integer_sums_inside_the_binade_equal_the_sequential_f32_sum():
             accepted[name] = accepted.get(name, 0) + fast / (fast + slow)
     # the runs the kernel is for -- one voxel's coordinates, intensities -- go through the integer path almost always
     for name in ("positive coordinates of one voxel", "negative coordinates of one voxel", "intensity"):
-        assert accepted[name] / 6 > 0.6, (name, accepted[name] / 6)
+        assert accepted[name] / 6 > 0.4, (name, accepted[name] / 6)  # (runs of 2-9 k points: ~log2(n / 512) + 1 steps cross a binade; the share grows with the run)
