@@ -588,7 +588,7 @@ __device__ __forceinline__ float monster_component_sum(const float4* __restrict_
                                                        int lane) {
     auto comp = [c](const float4& p) { return c == 0 ? p.x : (c == 1 ? p.y : (c == 2 ? p.z : p.w)); };
     float s = 0.f;
-    constexpr int kRing = 3;  // steps requested ahead of the one being summed (a step's loads take longer than its arithmetic)
+    constexpr int kRing = 5;  // steps requested ahead of the one being summed: 2560 points, 10 KB of dword loads in flight per wave (eight steps: 103 VGPRs, which halves the occupancy of the long-run waves sharing the launch) -- a run is streamed by ONE workgroup, so its rate is (bytes in flight) / (memory latency); three steps ahead left the wave waiting ~1 us per step
     constexpr int P = kMonsterPer;
     float nx[kRing][P];
 #pragma unroll
@@ -652,6 +652,12 @@ __device__ __forceinline__ float monster_component_sum(const float4* __restrict_
                     s = __uint_as_float(__float_as_uint(ldexpf((float)(S0 + total), e)) | flip);
                     fast = true;
                 }
+            }
+            if (!fast && (sb << 1) == 0u) {  // s = +-0 (the start of a run; a coordinate that is zero throughout, e.g. an unused intensity):
+                bool nz = false;             // 0 + 0 + ... stays what it is -- a step of zeros needs no loop
+#pragma unroll
+                for (int j = 0; j < P; j++) nz |= (__float_as_uint(xs[j]) << 1) != 0u;
+                if (sb == 0u && !__ballot(nz)) fast = true;  // (+0 + -0 = +0 too; a -0 sum is left to the loop)
             }
             if (!fast) {  // the plain loop over the parked step, one lane
                 float t = s;
