@@ -586,9 +586,14 @@ constexpr int kMonsterPer = 8;                       // points per lane and step
 constexpr int kMonsterStep = 64 * kMonsterPer;       // 512 points per step of one wave
 __device__ __forceinline__ float monster_component_sum(const float4* __restrict__ sorted, uint32_t ra, uint32_t rb, int c, float* __restrict__ park /* [kMonsterStep] */,
                                                        int lane) {
-    auto comp = [c](const float4& p) { return c == 0 ? p.x : (c == 1 ? p.y : (c == 2 ? p.z : p.w)); };
+    // coordinate c of point i as ONE dword load at a computed address: a float4 load followed by a select on the (run-time) coordinate number made
+    // the wave wait for every request on the spot -- nothing was in flight ahead, 2 400 cycles per step instead of ~800
+    const float* __restrict__ flat = reinterpret_cast<const float*>(sorted) + c;
+    auto comp_at = [flat](uint32_t i) { return flat[(size_t)i * 4u]; };
     float s = 0.f;
-    constexpr int kRing = 5;  // steps requested ahead of the one being summed: 2560 points, 10 KB of dword loads in flight per wave (eight steps: 103 VGPRs, which halves the occupancy of the long-run waves sharing the launch) -- a run is streamed by ONE workgroup, so its rate is (bytes in flight) / (memory latency); three steps ahead left the wave waiting ~1 us per step
+    // steps requested ahead of the one being summed: 1536 points, 6 KB of dword loads in flight per wave.  (Five steps: 81-94 VGPRs, which cost the
+    // long-run waves sharing the launch three of their eight waves per SIMD -- the batched kernel went 69 -> 87 us per round of 64.)
+    constexpr int kRing = 3;
     constexpr int P = kMonsterPer;
     float nx[kRing][P];
 #pragma unroll
@@ -596,7 +601,7 @@ __device__ __forceinline__ float monster_component_sum(const float4* __restrict_
 #pragma unroll
         for (int j = 0; j < P; j++) {
             const uint32_t i = ra + (uint32_t)r * kMonsterStep + (uint32_t)j * 64u + lane;
-            nx[r][j] = i < rb ? comp(sorted[i]) : 0.f;
+            nx[r][j] = i < rb ? comp_at(i) : 0.f;
         }
     for (uint32_t base = ra; base < rb; base += (uint32_t)kMonsterStep * kRing) {
 #pragma unroll
@@ -610,7 +615,7 @@ __device__ __forceinline__ float monster_component_sum(const float4* __restrict_
 #pragma unroll
                 for (int j = 0; j < P; j++) {
                     const uint32_t i = pos + (uint32_t)kMonsterStep * kRing + (uint32_t)j * 64u + lane;
-                    nx[r][j] = i < rb ? comp(sorted[i]) : 0.f;
+                    nx[r][j] = i < rb ? comp_at(i) : 0.f;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
