@@ -123,6 +123,10 @@ struct __attribute__((aligned(16))) GroupLds {
     uint32_t v_dmin[LIO_KNN_LIST_CAP + kU + 1];  // bits of a lower bound of the squared distance from the query to any point of the voxel
 };
 
+// The optimiser sinks a load into the (conditional) block that consumes it -- i.e. behind the probe loop of the cell before it; an empty asm
+// statement that claims to rewrite the loaded registers pins the load above it, so that a group of loads really is in flight together
+__device__ inline void pin_loaded(uint4& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
+
 // probe_stencil for stencils of at most 2 * kG cells (NEARBY6 / 18 / 26) with the hits BUCKETED by that lower bound: bucket 0 below
 // (res / 4)^2, bucket 1 below (res / 2)^2, bucket 2 the rest.  On return the list in g is bucket 0, then 1, then 2 (order inside a
 // bucket = stencil order), n0 / n01 are the list positions where buckets 1 and 2 start.
@@ -135,23 +139,33 @@ __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table
     BrickProbe bp[KM];
     unsigned long long want[KM];
     uint32_t dmin[KM];
+    // Three groups of UNCONDITIONAL loads, each issued together and waited for once: the lane's stencil offsets (a lane-indexed read of the
+    // kernel argument: vector memory), then the home slots at clamped indices (a lane without a cell, or whose cell cannot reach `limit`,
+    // reads slot 0 and ignores it).  Written as `if (active && s < st.n) { ... raw[k] = table[...]; }` the compiler emitted offset load, wait,
+    // hash, slot load, WAIT for every k in turn (round 4, read off the ISA): 2 KM dependent memory round trips per query instead of two.
+    int ox[KM], oy[KM], oz[KM];
+    bool inb[KM];
 #pragma unroll
     for (int k = 0; k < KM; k++) {
         const int s = k * kG + gl;
-        want[k] = kEmptyKey;
-        raw[k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-        bp[k] = BrickProbe{0u, 1u, 0u};
-        dmin[k] = 0xFFFFFFFFu;
-        if (active && s < st.n) {
-            const int cx = kx + st.off[s][0], cy = ky + st.off[s][1], cz = kz + st.off[s][2];
-            dmin[k] = cell_min_d2_bits(pw.x, pw.y, pw.z, cx, cy, cz, res);
-            if (dmin[k] <= limit) {  // `limit`: a known upper bound of the fifth-nearest distance -- a voxel that cannot reach it is not even probed
-                want[k] = pack_key(cx, cy, cz);
-                bp[k] = brick_probe(cx, cy, cz);
-                raw[k] = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[k], mask)]);
-            }
-        }
+        inb[k] = active && s < st.n;
+        const int sc = s < st.n ? s : 0;
+        ox[k] = st.off[sc][0]; oy[k] = st.off[sc][1]; oz[k] = st.off[sc][2];
     }
+    uint32_t slot[KM];
+#pragma unroll
+    for (int k = 0; k < KM; k++) {
+        const int cx = kx + ox[k], cy = ky + oy[k], cz = kz + oz[k];
+        dmin[k] = inb[k] ? cell_min_d2_bits(pw.x, pw.y, pw.z, cx, cy, cz, res) : 0xFFFFFFFFu;
+        const bool go = inb[k] && dmin[k] <= limit;  // `limit`: a known upper bound of the fifth-nearest distance -- a voxel that cannot reach it is not even probed
+        want[k] = go ? pack_key(cx, cy, cz) : kEmptyKey;
+        bp[k] = brick_probe(cx, cy, cz);
+        slot[k] = go ? brick_slot(bp[k], mask) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < KM; k++) raw[k] = *reinterpret_cast<const uint4*>(&table[slot[k]]);
+#pragma unroll
+    for (int k = 0; k < KM; k++) pin_loaded(raw[k]);
     const uint32_t b1 = __float_as_uint(0.0625f * res * res), b2 = __float_as_uint(0.25f * res * res);
     const uint32_t below = (1u << gl) - 1u;
     uint32_t ptr[KM], cnt[KM], total = 0;
@@ -210,19 +224,28 @@ __device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_
     uint4 raw[KM];
     BrickProbe bp[KM];
     unsigned long long want[KM];
+    // (unconditional loads at clamped indices, issued together: see probe_stencil_bucketed)
+    int ox[KM], oy[KM], oz[KM];
+    bool inb[KM];
 #pragma unroll
-    for (int k = 0; k < KM; k++) {  // all home-slot loads first: independent, in flight together
+    for (int k = 0; k < KM; k++) {
         const int s = k * kG + gl;
-        want[k] = kEmptyKey;
-        raw[k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-        bp[k] = BrickProbe{0u, 1u, 0u};
-        if (active && s < st.n) {
-            const int cx = kx + st.off[s][0], cy = ky + st.off[s][1], cz = kz + st.off[s][2];
-            want[k] = pack_key(cx, cy, cz);
-            bp[k] = brick_probe(cx, cy, cz);
-            raw[k] = *reinterpret_cast<const uint4*>(&table[brick_slot(bp[k], mask)]);
-        }
+        inb[k] = active && s < st.n;
+        const int sc = s < st.n ? s : 0;
+        ox[k] = st.off[sc][0]; oy[k] = st.off[sc][1]; oz[k] = st.off[sc][2];
     }
+    uint32_t slot[KM];
+#pragma unroll
+    for (int k = 0; k < KM; k++) {
+        const int cx = kx + ox[k], cy = ky + oy[k], cz = kz + oz[k];
+        want[k] = inb[k] ? pack_key(cx, cy, cz) : kEmptyKey;
+        bp[k] = brick_probe(cx, cy, cz);
+        slot[k] = inb[k] ? brick_slot(bp[k], mask) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < KM; k++) raw[k] = *reinterpret_cast<const uint4*>(&table[slot[k]]);
+#pragma unroll
+    for (int k = 0; k < KM; k++) pin_loaded(raw[k]);
     uint32_t nhit = 0, total = 0;
     const uint32_t below = (1u << gl) - 1u;
 #pragma unroll
@@ -389,6 +412,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         // voxel-major sweep: kU voxel descriptors per batch come back from LDS as ds_read_b128 pairs, lane l takes point l
         // (l+32, ...) of each -- addresses are base + lane (no per-candidate search), kU 16-B loads in flight per lane
         uint32_t bound5 = 0xFFFFFFFFu;
+        const uint32_t ptr_first = g.v_ptr[0];  // (0 when nothing is listed: the pool's first record -- the sweep does not run then)
         bool need_bound = true;  // group-uniform: a lane of the group has taken a candidate since the bound was last computed
         for (uint32_t s0 = 0; s0 < nhit; s0 += kU) {
             uint32_t ptr4[kU], cnt4[kU];
@@ -427,10 +451,12 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                 if constexpr (COUNT) { if (gl == 0) touched += (vc.x + vc.y) + (vc.z + vc.w); }
             }
             for (uint32_t i0 = gl; i0 < cmax + gl; i0 += kG) {
+                // UNCONDITIONAL loads at clamped addresses (a lane beyond a voxel's count re-reads the first listed voxel's first point -- a line the
+                // group holds anyway -- and ignores it): a load inside `if (i0 < cnt)` comes out of the compiler as load + s_waitcnt vmcnt(0) + moves
+                // per voxel (round 4, read off the ISA: the kU loads "in flight" were four memory round trips one after the other)
                 float4 p[kU];
 #pragma unroll
-                for (int u = 0; u < kU; u++)
-                    if (i0 < cnt4[u]) p[u] = pool[ptr4[u] + i0];
+                for (int u = 0; u < kU; u++) p[u] = pool[i0 < cnt4[u] ? ptr4[u] + i0 : ptr_first];
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     if (i0 >= cnt4[u]) continue;
