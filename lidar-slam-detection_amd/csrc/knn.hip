@@ -123,10 +123,6 @@ struct __attribute__((aligned(16))) GroupLds {
     uint32_t v_dmin[LIO_KNN_LIST_CAP + kU + 1];  // bits of a lower bound of the squared distance from the query to any point of the voxel
 };
 
-// The optimiser sinks a load into the (conditional) block that consumes it -- i.e. behind the probe loop of the cell before it; an empty asm
-// statement that claims to rewrite the loaded registers pins the load above it, so that a group of loads really is in flight together
-__device__ inline void pin_loaded(uint4& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
-
 // probe_stencil for stencils of at most 2 * kG cells (NEARBY6 / 18 / 26) with the hits BUCKETED by that lower bound: bucket 0 below
 // (res / 4)^2, bucket 1 below (res / 2)^2, bucket 2 the rest.  On return the list in g is bucket 0, then 1, then 2 (order inside a
 // bucket = stencil order), n0 / n01 are the list positions where buckets 1 and 2 start.

@@ -13,6 +13,22 @@ struct LruEntry;
 
 namespace lio {
 
+// Loads that are meant to be in flight together: the optimiser sinks a load into the conditional block that consumes its value (and resolves the
+// PHI of a conditionally loaded value by moves at the end of the predicated block), which turns `load a, load b, ... use` into load / s_waitcnt
+// vmcnt(0) / use, one memory round trip after the other (tools/isa_load_chains.py shows where).  An empty asm statement that claims to rewrite
+// the loaded registers pins the loads above it: written after a GROUP of unconditional loads it keeps the group together.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LIO_PIN4(r) asm volatile("" : "+v"((r).x), "+v"((r).y), "+v"((r).z), "+v"((r).w))
+#define LIO_PIN1(r) asm volatile("" : "+v"(r))
+#else
+#define LIO_PIN4(r) ((void)(r))
+#define LIO_PIN1(r) ((void)(r))
+#endif
+__host__ __device__ __forceinline__ void pin_loaded(float4& r) { LIO_PIN4(r); }
+__host__ __device__ __forceinline__ void pin_loaded(uint4& r) { LIO_PIN4(r); }
+__host__ __device__ __forceinline__ void pin_loaded(uint32_t& r) { LIO_PIN1(r); }
+__host__ __device__ __forceinline__ void pin_loaded(float& r) { LIO_PIN1(r); }
+
 // a double moved across lanes by one DPP control word (two 32-bit halves): quad_perm 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1] give the quad sums
 // (v0 + v1) + (v2 + v3) in every lane of a quad without LDS -- the first stage of the fixed-order workgroup reductions (p2plane.hip, ndt.hip)
 template <int CTRL>

@@ -40,13 +40,24 @@ __device__ inline float ord2f(uint32_t u) { return __uint_as_float((u & 0x800000
 __device__ __forceinline__ void vg_bbox_atomic_body(const float4* __restrict__ in, uint32_t n, ScanDev* sd) {
     float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
     uint32_t cnt = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 p = in[i];
-        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-            mn0 = fminf(mn0, p.x); mx0 = fmaxf(mx0, p.x);
-            mn1 = fminf(mn1, p.y); mx1 = fmaxf(mx1, p.y);
-            mn2 = fminf(mn2, p.z); mx2 = fmaxf(mx2, p.z);
-            cnt++;
+    // four points of the stride loop per step, requested together (clamped, unconditional: one load per step was one memory round trip per step)
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4u * stride) {
+        float4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t j = i + (uint32_t)k * stride;
+            q[k] = in[j < n ? j : i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 p = q[k];
+            if (i + (uint32_t)k * stride < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+                mn0 = fminf(mn0, p.x); mx0 = fmaxf(mx0, p.x);
+                mn1 = fminf(mn1, p.y); mx1 = fmaxf(mx1, p.y);
+                mn2 = fminf(mn2, p.z); mx2 = fmaxf(mx2, p.z);
+                cnt++;
+            }
         }
     }
 #pragma unroll
@@ -266,10 +277,18 @@ __device__ __forceinline__ void radix_hist_body(const uint32_t* __restrict__ ka,
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * kTile;
+    // the tile's keys as kItems UNCONDITIONAL loads at clamped indices, all in flight before the first is used (`if (i < n) ... keys[i]` comes out of
+    // the compiler as load + s_waitcnt vmcnt(0) per item: eight memory round trips one after the other -- tools/isa_load_chains.py)
+    uint32_t kk[kItems];
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
         const uint32_t i = base + r * kThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        kk[r] = keys[i < n ? i : (n ? n - 1u : 0u)];
+    }
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        const uint32_t i = base + r * kThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(kk[r] >> shift) & 255u], 1u);
     }
     __syncthreads();
     hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];  // [tile][digit]: one coalesced 1-KiB row per workgroup
@@ -400,14 +419,19 @@ __device__ __forceinline__ void vg_count_heads_body(const uint32_t* __restrict__
     const uint32_t total = sd->total_cells;
     const uint32_t base = blockIdx.x * kTile;
     uint32_t mine = 0;
+    // (2 x kItems unconditional loads at clamped indices, in flight together: see radix_hist_body)
+    uint32_t kc[kItems], kp[kItems];
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
         const uint32_t i = base + r * kThreads + threadIdx.x;
-        bool head = false;
-        if (i < n) {
-            const uint32_t key = keys[i];
-            head = key < total && (i == 0 || keys[i - 1] != key);
-        }
+        const uint32_t ic = i < n ? i : (n ? n - 1u : 0u);
+        kc[r] = keys[ic];
+        kp[r] = keys[ic ? ic - 1u : 0u];
+    }
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        const uint32_t i = base + r * kThreads + threadIdx.x;
+        const bool head = i < n && kc[r] < total && (i == 0 || kp[r] != kc[r]);
         mine += __popcll(__ballot(head));
     }
     if ((threadIdx.x & 63) == 0) atomicAdd(&c, mine);
@@ -443,7 +467,6 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
     const uint32_t* keys = odd ? kb : ka;
     const uint32_t* vals = odd ? vb : va;
     __shared__ uint32_t red[kWaves];
-    __shared__ uint32_t wtot[kWaves];
     // exclusive prefix of the tiles before this one (fixed order -> deterministic output slots)
     uint32_t pre = 0;
     for (uint32_t b = tid; b < blockIdx.x; b += kThreads) pre += blockcnt[b];
@@ -458,29 +481,57 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
     const uint32_t total = sd->total_cells;
     const uint32_t base = blockIdx.x * kTile;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // Round 4, second form.  Until then: per item { key, previous key, index, the gather through the index, two workgroup barriers } -- four dependent
+    // memory round trips and two barriers eight times over (every load sat inside `if (i < n)`: load, s_waitcnt vmcnt(0), next load;
+    // tools/isa_load_chains.py).  Now: the 2 x kItems key loads and the kItems indices in flight together (clamped, unconditional), the head
+    // ballots of all items on registers with ONE barrier for the waves' counts, then the gathers four at a time.  (The first attempt at an
+    // up-front form held all eight gathered points at once -- 32 more registers -- and was slower; four at a time keeps the occupancy.)
+    uint32_t kc[kItems], kp[kItems], vv[kItems];
+#pragma unroll
     for (int r = 0; r < kItems; r++) {
         const uint32_t i = base + r * kThreads + tid;
-        bool head = false;
-        if (i < n) {
-            const uint32_t key = keys[i];
-            head = key < total && (i == 0 || keys[i - 1] != key);
-            sorted[i] = in[vals[i]];
-        }
-        const unsigned long long m = __ballot(head);
-        if (lane == 0) wtot[wave] = __popcll(m);
-        __syncthreads();
+        const uint32_t ic = i < n ? i : (n ? n - 1u : 0u);
+        kc[r] = keys[ic];
+        kp[r] = keys[ic ? ic - 1u : 0u];
+        vv[r] = vals[ic];
+    }
+    __shared__ uint32_t wcnt[kItems][kWaves];
+    unsigned long long hm[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        const uint32_t i = base + r * kThreads + tid;
+        const bool head = i < n && kc[r] < total && (i == 0 || kp[r] != kc[r]);
+        hm[r] = __ballot(head);
+        if (lane == 0) wcnt[r][wave] = (uint32_t)__popcll(hm[r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
         uint32_t woff = 0, rtot = 0;
+#pragma unroll
         for (int w = 0; w < kWaves; w++) {
-            const uint32_t t = wtot[w];
+            const uint32_t t = wcnt[r][w];
             if (w < wave) woff += t;
             rtot += t;
         }
-        if (head) {
-            const uint32_t slot = run + woff + __popcll(m & lt);
-            if (slot < max_ds) hpos[slot] = i;
+        if ((hm[r] >> lane) & 1ull) {
+            const uint32_t slot = run + woff + (uint32_t)__popcll(hm[r] & lt);
+            if (slot < max_ds) hpos[slot] = base + r * kThreads + tid;
         }
         run += rtot;
-        __syncthreads();
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < kItems; r0 += 4) {
+        float4 pt[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) pt[k] = in[vv[r0 + k]];  // (a thread beyond the scan's end gathers the last point again and drops it)
+#pragma unroll
+        for (int k = 0; k < 4; k++) pin_loaded(pt[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = base + (r0 + k) * kThreads + tid;
+            if (i < n) sorted[i] = pt[k];
+        }
     }
     if (blockIdx.x == last_block && tid == 0) {
         uint32_t err = 0;
