@@ -304,7 +304,11 @@ struct NdtReport {  // mapped pinned host memory
 
 // one cost evaluation.  UPDATE: look the neighbour voxels up at x_lin and cache them (find_voxel_correspondences);
 // DERIV: accumulate H and b besides the error (linearize) -- otherwise the error only (LM trial, compute_error)
-template <bool UPDATE, bool DERIV, int NO>
+// AHEAD (one alignment at a time, NO <= 7): the records of all NO offsets are requested together before the first is used.  A single alignment is
+// ~800 one-wave workgroups on 1 024 SIMDs -- less than a wave per SIMD, nothing hides a load -- and `if (slot[o] == kNoIdx) continue; ... rec[0..3]`
+// made the kernel NO memory round trips one after the other (tools/isa_load_chains.py); registers are free there (112 for the records of seven
+// offsets).  The batched kernels (tens of thousands of waves: occupancy is what hides their loads) keep the one-record-at-a-time form.
+template <bool UPDATE, bool DERIV, int NO, bool AHEAD = false>
 __device__ __forceinline__ void ndt_cost_body(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox,
                                               float res, const NdtOffsets& offs, const NdtXform& x_lin, const NdtXform& x,
                                               const float4* __restrict__ src, uint32_t n,
@@ -355,12 +359,27 @@ __device__ __forceinline__ void ndt_cost_body(const Slot* __restrict__ table, ui
         }
         float tp[3];
         xform_dev(x, p, tp);
+        constexpr bool kAhead = AHEAD && NO <= 7;
+        float4 recs[kAhead ? NO : 1][4];
+        if (kAhead) {
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                const float4* rec = reinterpret_cast<const float4*>(&vox[slot[o] != kNoIdx ? slot[o] : 0u]);  // (no pair: slot 0's record, ignored)
+#pragma unroll
+                for (int k = 0; k < 4; k++) recs[o][k] = rec[k];
+            }
+#pragma unroll
+            for (int o = 0; o < NO; o++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) pin_loaded(recs[o][k]);
+        }
 #pragma unroll
         for (int o = 0; o < NO; o++) {
             if (slot[o] == kNoIdx) continue;
             // one 64-byte record: mean, count, inverse covariance
             const float4* rec = reinterpret_cast<const float4*>(&vox[slot[o]]);
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            const float4 r0 = kAhead ? recs[kAhead ? o : 0][0] : rec[0], r1 = kAhead ? recs[kAhead ? o : 0][1] : rec[1],
+                         r2 = kAhead ? recs[kAhead ? o : 0][2] : rec[2], r3 = kAhead ? recs[kAhead ? o : 0][3] : rec[3];
             const int cnt = __float_as_int(r0.w);
             if (cnt <= 6) continue;  // ndt_compute_derivatives.cu:61
             const float ci[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
@@ -452,7 +471,7 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_kernel(const Slot* __res
                                                                const float4* __restrict__ src, const ScanDev* __restrict__ sd,
                                                                uint32_t* __restrict__ corr, uint32_t corr_stride, double* __restrict__ partial,
                                                                uint32_t pstride, NdtDev* nd) {
-    ndt_cost_body<UPDATE, DERIV, NO>(table, mask, vox, res, offs, x_lin, x, src, sd->n_ds, corr, corr_stride, partial, pstride, &nd->n_corr);
+    ndt_cost_body<UPDATE, DERIV, NO, true>(table, mask, vox, res, offs, x_lin, x, src, sd->n_ds, corr, corr_stride, partial, pstride, &nd->n_corr);
 }
 
 // ---- speculative evaluation (lio_ndt_align, one alignment at a time) -----------------------------------------------------------------------------
@@ -462,7 +481,7 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_kernel(const Slot* __res
 // correspondence buffer, the pairs at xi with their cost / H / b (acc[0..27]).  An accepted step finds its next linearisation already reported -- one
 // kernel, one report and one host hand-over per LM iteration instead of two; a rejected step discards it (the pairs of x0 were not touched).  Same
 // statements, same per-lane accumulation order, same reduction as the two separate kernels: the results are the same bits.
-template <int NO>
+template <int NO, bool AHEAD = false>
 __device__ __forceinline__ void ndt_spec_body(const Slot* __restrict__ table, uint32_t mask, const NdtVoxel* __restrict__ vox, float res,
                                               const NdtOffsets& offs, const NdtXform& x, const float4* __restrict__ src, uint32_t n,
                                               const uint32_t* __restrict__ corr_old, uint32_t* __restrict__ corr_new, uint32_t corr_stride,
@@ -509,6 +528,20 @@ __device__ __forceinline__ void ndt_spec_body(const Slot* __restrict__ table, ui
             }
         }
         const float ksq = res * res;
+        constexpr bool kAhead = AHEAD && NO <= 7;  // (see ndt_cost_body)
+        float4 recs[kAhead ? NO : 1][4];
+        if (kAhead) {
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                const float4* rec = reinterpret_cast<const float4*>(&vox[slot[o] != kNoIdx ? slot[o] : 0u]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) recs[o][k] = rec[k];
+            }
+#pragma unroll
+            for (int o = 0; o < NO; o++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) pin_loaded(recs[o][k]);
+        }
 #pragma unroll
         for (int o = 0; o < NO; o++) {
             // the pair of the new correspondences: cost + H + b (the DERIV branch of ndt_cost_body, statement for statement)
@@ -516,7 +549,8 @@ __device__ __forceinline__ void ndt_spec_body(const Slot* __restrict__ table, ui
             bool have_new = false;
             if (slot[o] != kNoIdx) {
                 const float4* rec = reinterpret_cast<const float4*>(&vox[slot[o]]);
-                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                const float4 r0 = kAhead ? recs[kAhead ? o : 0][0] : rec[0], r1 = kAhead ? recs[kAhead ? o : 0][1] : rec[1],
+                             r2 = kAhead ? recs[kAhead ? o : 0][2] : rec[2], r3 = kAhead ? recs[kAhead ? o : 0][3] : rec[3];
                 if (__float_as_int(r0.w) > 6) {
                     const float ci[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
                     const float e[3] = {r0.x - tp[0], r0.y - tp[1], r0.z - tp[2]};
@@ -613,7 +647,7 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_spec_kernel(const Slot* 
                                                                     NdtOffsets offs, NdtXform x, const float4* __restrict__ src, const ScanDev* __restrict__ sd,
                                                                     const uint32_t* __restrict__ corr_old, uint32_t* __restrict__ corr_new, uint32_t corr_stride,
                                                                     double* __restrict__ partial, uint32_t pstride, NdtDev* nd) {
-    ndt_spec_body<NO>(table, mask, vox, res, offs, x, src, sd->n_ds, corr_old, corr_new, corr_stride, partial, pstride, &nd->n_corr);
+    ndt_spec_body<NO, true>(table, mask, vox, res, offs, x, src, sd->n_ds, corr_old, corr_new, corr_stride, partial, pstride, &nd->n_corr);
 }
 
 // (Measured in round 4 and not kept: EIGHT LANES PER SOURCE POINT for the single alignment -- lane (point, offset), the sums re-formed in this kernel's

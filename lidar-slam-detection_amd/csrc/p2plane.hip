@@ -202,34 +202,57 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
     // the point's addends are formed at reduction time from its Jacobian row, residual and |residual| (8 doubles live instead of 29)
     double row[6] = {0, 0, 0, 0, 0, 0};
     double h = 0.0, ares = 0.0, one = 0.0;
+    // Everything this point needs from memory has an address that depends on i alone: requested up front, together (clamped, unconditional; which
+    // set is wanted depends on redo_knn, uniform over the workgroup).  Written as it reads -- point, then its neighbour count inside `if (i < n)`,
+    // then the cached plane or the five neighbours inside `if (sel)` -- the kernel made three to four memory round trips one after the other.
+    const uint32_t ic = i < n ? i : n - 1u;
+    float4 pb = ds_body[ic];
+    float* plane_d = reinterpret_cast<float*>(normvec + nn_stride);
+    int32_t cnt_i = 0;
+    uint32_t sel_i = 0;
+    float4 nv_c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pd_c = 0.f;
+    float4 near[5];
+    if (redo_knn) {
+        cnt_i = nn_cnt[ic];
+#pragma unroll
+        for (int k = 0; k < 5; k++) near[k] = nn_pts[(size_t)k * nn_stride + ic];
+#pragma unroll
+        for (int k = 0; k < 5; k++) pin_loaded(near[k]);
+    } else {
+        sel_i = selected[ic];
+        nv_c = normvec[ic];
+        pd_c = plane_d[ic];
+        pin_loaded(nv_c);
+        pin_loaded(pd_c);
+    }
+    pin_loaded(pb);
     if (i < n) {
-        const float4 pb = ds_body[i];
         double pi[3];
         float4 pw;
         body_to_world_d(pose, pb, pi, pw);
         ds_world[i] = pw;
         // point_selected_surf is re-armed only by a neighbour search (laserMapping.cpp:842-854)
-        bool sel = redo_knn ? (nn_cnt[i] >= 5) : (selected[i] != 0);
+        bool sel = redo_knn ? (cnt_i >= 5) : (sel_i != 0);
         if (sel) {
             // The plane is a function of the five neighbours alone: a pass that does not search (ES:1646-1650 leaves `converge` false) would
             // fit the plane it fitted last pass -- same inputs, same bits.  It is kept from the pass that searched: (a, b, c) in normvec,
             // d behind it (plane_d); a point is only evaluated again while it stayed selected, and it stays selected only through passes
             // that wrote both.  Skips the 80-byte neighbour load and the QR (most of this kernel's instructions) in 2.6 of 4.6 passes.
             // (An all-zero normal = nothing cached: a bare lio_p2plane_linearize(redo_knn = 0) on a fresh scan takes the long way.)
-            float* plane_d = reinterpret_cast<float*>(normvec + nn_stride);
             float pabcd[4];
             bool have = false;
             if (!redo_knn) {
-                const float4 nv = normvec[i];
-                if (nv.x != 0.f || nv.y != 0.f || nv.z != 0.f) {
-                    pabcd[0] = nv.x; pabcd[1] = nv.y; pabcd[2] = nv.z; pabcd[3] = plane_d[i];
+                if (nv_c.x != 0.f || nv_c.y != 0.f || nv_c.z != 0.f) {
+                    pabcd[0] = nv_c.x; pabcd[1] = nv_c.y; pabcd[2] = nv_c.z; pabcd[3] = pd_c;
                     have = true;
                 }
             }
             if (!have) {
-                float4 near[5];
+                if (!redo_knn) {  // (rare: nothing cached)
 #pragma unroll
-                for (int k = 0; k < 5; k++) near[k] = nn_pts[(size_t)k * nn_stride + i];
+                    for (int k = 0; k < 5; k++) near[k] = nn_pts[(size_t)k * nn_stride + i];
+                }
                 have = esti_plane_dev(near, 0.1f, pabcd);
                 if (have) plane_d[i] = pabcd[3];
             }
