@@ -706,18 +706,42 @@ __global__ void __launch_bounds__(kNdtThreads) ndt_cost_batch(float res, NdtOffs
 // the fold of the workgroup partials by a 1024-thread workgroup: wave w takes components w, w + 16, w + 32; lane l adds workgroups l, l + 64, ...
 // (coalesced: the layout is [component][workgroup]), then a fixed xor tree over the wave -- one order, run-to-run identical
 // with_count: also component kNdtCnt (the pair count: integers, exact in any order) into acc[kNdtCnt]
+// row[lane], row[lane + 64], ... < nb added in that order, the loads of eight steps in flight (the plain loop is one memory round trip per step:
+// thirteen for the 782 workgroups of a 50 000-point scan, twice per wave -- most of the report kernel's 10 us).  Same additions, same order.
+__device__ __forceinline__ double ndt_fold_row(const double* __restrict__ row, uint32_t lane, uint32_t nb) {
+    double v = 0.0;
+    uint32_t b = lane;
+    for (; b + 7u * 64u < nb; b += 8u * 64u) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = row[b + 64u * k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v += t[k];
+    }
+    if (b < nb) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t bb = b + 64u * k;
+            t[k] = row[bb < nb ? bb : b];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (b + 64u * k < nb) v += t[k];
+    }
+    return v;
+}
+
 __device__ __forceinline__ void ndt_fold(const double* __restrict__ partial, uint32_t pstride, uint32_t nb, int na, double* acc /* LDS, kNdtComps */, bool with_count) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (with_count && wave == 15) {
-        double v = 0.0;
-        for (uint32_t b = lane; b < nb; b += 64) v += partial[(size_t)kNdtCnt * pstride + b];
+        double v = ndt_fold_row(partial + (size_t)kNdtCnt * pstride, (uint32_t)lane, nb);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0) acc[kNdtCnt] = v;
     }
     for (int c = wave; c < na; c += 16) {
-        double v = 0.0;
-        for (uint32_t b = lane; b < nb; b += 64) v += partial[(size_t)c * pstride + b];
+        double v = ndt_fold_row(partial + (size_t)c * pstride, (uint32_t)lane, nb);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0) acc[c] = v;

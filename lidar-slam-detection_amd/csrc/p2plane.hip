@@ -345,6 +345,33 @@ __global__ void __launch_bounds__(kLinThreads) linearize_batch(const SlotDesc* _
     linearize_body(pose, c->converge, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, d.selected, d.normvec, d.partial);
 }
 
+// component `comp` of the workgroups' partial records b = l, l + 32, l + 64, ... < nb, added in that order -- with the loads of eight steps in flight
+// (the plain loop `s += partial[b * kAcc + comp]` is one memory round trip per step: six of them for a scan of 12 000 points, the larger
+// part of the filter-pass kernel's "copy-in + fold" phase).  Same additions, same order: the same bits.
+__device__ __forceinline__ double fold_partials(const double* __restrict__ partial, uint32_t l, uint32_t nb, int comp) {
+    double s = 0.0;
+    uint32_t b = l;
+    for (; b + 7u * 32u < nb; b += 8u * 32u) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = partial[(size_t)(b + 32u * k) * kAcc + comp];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += v[k];
+    }
+    if (b < nb) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t bb = b + 32u * k;
+            v[k] = partial[(size_t)(bb < nb ? bb : b) * kAcc + comp];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (b + 32u * k < nb) s += v[k];
+    }
+    return s;
+}
+
 // One workgroup folds the per-workgroup partials in a fixed order and writes the 29-number record straight into
 // mapped pinned host memory; the host spins on the record's sequence word (no copy launch, no stream-sync call).
 // (Folding inside linearize_kernel by the last workgroup to arrive -- agent-scope ticket, write-through payload --
@@ -363,8 +390,7 @@ __global__ void __launch_bounds__(kFinThreads) finalize_kernel(ScanDev* __restri
     {
         const int c = tid >> 5, l = tid & 31;
         double s = 0.0;
-        if (c < kAcc)
-            for (uint32_t b = l; b < nb; b += 32) s += partial[(size_t)b * kAcc + c];
+        if (c < kAcc) s = fold_partials(partial, (uint32_t)l, nb, c);
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
         if (c < kAcc && l == 0) acc[c] = s;
@@ -498,8 +524,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
                 for (int r = 1; r < world; r++) s += gathered[((size_t)r * n_slots + blockIdx.x) * 32 + tid];
             }
         } else {
-            if (!skip && comp < kAcc)
-                for (uint32_t b = l; b < nb; b += 32) s += d.partial[(size_t)b * kAcc + comp];
+            if (!skip && comp < kAcc) s = fold_partials(d.partial, (uint32_t)l, nb, comp);
         }
         if (k0 < kCoreWords) dst[k0] = v0;
         if (k1 < kCoreWords) dst[k1] = v1;
@@ -650,8 +675,7 @@ __global__ void __launch_bounds__(1024) joint_fold_batch(const SlotDesc* __restr
             for (int m = 0; m < n_maps; m++) {
                 const SlotDesc& d = descs[(size_t)m * n_slots + slot];
                 double s = 0.0;
-                if (comp < kAcc)
-                    for (uint32_t b = l; b < nb; b += 32) s += d.partial[(size_t)b * kAcc + comp];
+                if (comp < kAcc) s = fold_partials(d.partial, (uint32_t)l, nb, comp);
 #pragma unroll
                 for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
                 total = m == 0 ? s : total + s;

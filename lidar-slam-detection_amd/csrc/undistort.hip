@@ -119,24 +119,31 @@ __global__ __launch_bounds__(kThreads) void undistort_kernel(const float4* __res
                                                              float4* __restrict__ out, const ImuPoseDev* __restrict__ g_poses, UndistortArgs A,
                                                              unsigned long long* __restrict__ block_min) {
     __shared__ ImuPoseDev poses[kMaxImuPoses];
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    // the point and its time stamp are requested before the pose table is staged (their addresses depend on i alone): one memory round trip for
+    // the three instead of three in a row
+    const uint32_t ic = i < n ? i : (n ? n - 1u : 0u);
+    float4 p_in = in[ic];
+    uint32_t stamp_i = A.undistort ? stamp_us[ic] : 0u;
     {
         const double* src = reinterpret_cast<const double*>(g_poses);
         double* dst = reinterpret_cast<double*>(poses);
         const int words = A.n_poses * (int)(sizeof(ImuPoseDev) / sizeof(double));
         for (int i = threadIdx.x; i < words; i += kThreads) dst[i] = src[i];
     }
+    pin_loaded(p_in);
+    pin_loaded(stamp_i);
     __syncthreads();
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     unsigned long long key = ~0ull;  // (time bits, index) of a kept point: the minimum is the sorted cloud's begin()
     if (i < n) {
-        float4 p = in[i];
+        float4 p = p_in;
         const float nanv = __int_as_float(0x7fc00000);
         bool keep = (A.filter_num <= 1) || (i % (uint32_t)A.filter_num == 0);
         keep = keep && ((double)(p.x * p.x + p.y * p.y + p.z * p.z) > A.blind2);
         if (!keep) {
             p = make_float4(nanv, nanv, nanv, p.w);
         } else if (A.undistort) {
-            const float t_ms = (float)stamp_us[i] / 1000.0f;  // added_pt.curvature = attr.stamp / 1000.0f (ms)
+            const float t_ms = (float)stamp_i / 1000.0f;  // added_pt.curvature = attr.stamp / 1000.0f (ms)
             const double t = (double)t_ms / double(1000);
             const int h = find_segment(poses, A.n_poses, t);
             if (h >= 0) compensate(A, poses, h, t, p.x, p.y, p.z);
