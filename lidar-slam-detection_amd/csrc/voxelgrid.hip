@@ -555,7 +555,7 @@ constexpr uint32_t kLongRun = 32;
 // top of the same array, whose runs are summed one COMPONENT per wave by integer arithmetic inside the running sum's binade (monster_sum below)
 constexpr uint32_t kMonsterRun = 2048;
 constexpr uint32_t kMonsterBlocks = 16;       // workgroups of the long-run launch that serve the monster queue (one scan)
-constexpr uint32_t kMonsterBlocksBatch = 4;   // ... per slot of a batched launch
+constexpr uint32_t kMonsterBlocksBatch = 16;  // ... per slot of the batched chain (its own launch there)
 
 __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                ScanDev* __restrict__ sd, float4* __restrict__ out,
@@ -564,8 +564,13 @@ __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sort
     const uint32_t nv = sd->n_ds;
     const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
     if (v >= nv) return;
-    const uint32_t a = hpos[v];
-    const uint32_t b = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;  // invalid (non-finite) points sort behind every voxel
+    // (both run bounds and the scan's valid count requested together: the conditional form was two memory round trips one after the other)
+    uint32_t a = hpos[v];
+    uint32_t b_next = hpos[v + 1 < nv ? v + 1 : v];
+    const uint32_t n_valid = sd->n_valid;
+    pin_loaded(a);
+    pin_loaded(b_next);
+    const uint32_t b = (v + 1 < nv) ? b_next : n_valid;  // invalid (non-finite) points sort behind every voxel
     const bool is_monster = b - a >= kMonsterRun;
     const unsigned long long mm = __ballot(is_monster);
     if (mm) {
@@ -594,7 +599,16 @@ __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sort
         }
     }
     float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-    for (uint32_t j = a; j < b; j += 4) {
+    // the first eight points of the run in one request (most runs end there: one memory round trip instead of two), then four at a time
+    {
+        float4 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) p[k] = sorted[(a + k < b) ? (a + k) : (b - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (a + k < b) { sx = sx + p[k].x; sy = sy + p[k].y; sz = sz + p[k].z; sw = sw + p[k].w; }
+    }
+    for (uint32_t j = a + 8; j < b; j += 4) {
         float4 p[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) p[k] = sorted[(j + k < b) ? (j + k) : (b - 1)];
@@ -635,6 +649,7 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int x) {
 
 constexpr int kMonsterPer = 8;                       // points per lane and step
 constexpr int kMonsterStep = 64 * kMonsterPer;       // 512 points per step of one wave
+template <int kRing>
 __device__ __forceinline__ float monster_component_sum(const float4* __restrict__ sorted, uint32_t ra, uint32_t rb, int c, float* __restrict__ park /* [kMonsterStep] */,
                                                        int lane) {
     // coordinate c of point i as ONE dword load at a computed address: a float4 load followed by a select on the (run-time) coordinate number made
@@ -642,9 +657,9 @@ __device__ __forceinline__ float monster_component_sum(const float4* __restrict_
     const float* __restrict__ flat = reinterpret_cast<const float*>(sorted) + c;
     auto comp_at = [flat](uint32_t i) { return flat[(size_t)i * 4u]; };
     float s = 0.f;
-    // steps requested ahead of the one being summed: 1536 points, 6 KB of dword loads in flight per wave.  (Five steps: 81-94 VGPRs, which cost the
-    // long-run waves sharing the launch three of their eight waves per SIMD -- the batched kernel went 69 -> 87 us per round of 64.)
-    constexpr int kRing = 3;
+    // kRing steps requested ahead of the one being summed.  Three (1536 points, 6 KB of dword loads in flight per wave) where the long-run waves
+    // share the launch (one scan at a time: five steps meant 81-94 VGPRs and cost those waves three of their eight per SIMD); eight in the
+    // batched chain's own monster launch, where a step waits for its loads (~0.8 us per step of a 30 000-point run) and registers are free.
     constexpr int P = kMonsterPer;
     float nx[kRing][P];
 #pragma unroll
@@ -737,6 +752,10 @@ __device__ __forceinline__ float monster_component_sum(const float4* __restrict_
 
 // workgroups [0, n_long_blocks) serve the long-run queue one run per wave; the workgroups beyond serve the monster queue one run per
 // workgroup, wave c summing coordinate c
+// WHICH: 0 = both queues in one launch (one scan at a time: a launch less), 1 = the long-run queue only, 2 = the monster queue only (the batched
+// chain: the monster code's registers cost the long-run waves two of their eight waves per SIMD -- 69 -> 85 us per round of 64 when both shared a
+// launch -- so there the monster queue gets a small launch of its own)
+template <int WHICH>
 __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
                                                                     const uint32_t* __restrict__ longlist, uint32_t max_ds, uint32_t n_long_blocks) {
@@ -744,17 +763,18 @@ __device__ __forceinline__ void vg_centroid_long_body(const float4* __restrict__
     const uint32_t nv = sd->n_ds, nl = sd->n_long;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) float park[kWaves][kMonsterStep > 256 ? kMonsterStep : 256];
-    if (blockIdx.x >= n_long_blocks) {
+    if (WHICH == 2 || (WHICH == 0 && blockIdx.x >= n_long_blocks)) {
         const uint32_t nm = sd->n_monster;
         for (uint32_t m = blockIdx.x - n_long_blocks; m < nm; m += gridDim.x - n_long_blocks) {
             const uint32_t v = longlist[max_ds - 1u - m];
             const uint32_t ra = hpos[v];
             const uint32_t rb = (v + 1 < nv) ? hpos[v + 1] : sd->n_valid;
-            const float t = monster_component_sum(sorted, ra, rb, wv, &park[wv][0], lane);
+            const float t = monster_component_sum<WHICH == 2 ? 8 : 3>(sorted, ra, rb, wv, &park[wv][0], lane);
             if (lane == 0) reinterpret_cast<float*>(&out[v])[wv] = t / (float)(rb - ra);
         }
         return;
     }
+    if (WHICH == 2) return;
     const uint32_t nwaves = n_long_blocks * kWaves;
     float (*pk)[64] = reinterpret_cast<float (*)[64]>(&park[wv][0]);  // this wave's four coordinate rows of 64
     constexpr int kAhead = 4;
@@ -901,13 +921,23 @@ __global__ void __launch_bounds__(kThreads) vg_centroid_batch(const SlotDesc* __
 __global__ void __launch_bounds__(kThreads) vg_centroid_long_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
                                                                     const uint32_t* __restrict__ longlist, uint32_t max_ds, uint32_t n_long_blocks) {
-    vg_centroid_long_body(sorted, hpos, sd, out, longlist, max_ds, n_long_blocks);
+    vg_centroid_long_body<0>(sorted, hpos, sd, out, longlist, max_ds, n_long_blocks);
 }
 // + the scan-begin duties (Nearest_Points.resize, re-arming the bbox) of the batch: the long-run kernel is the last of the chain
 __global__ void __launch_bounds__(kThreads) vg_centroid_long_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    vg_centroid_long_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist, d.max_ds, gridDim.x - kMonsterBlocksBatch);
+    vg_centroid_long_body<1>(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist, d.max_ds, gridDim.x);
+}
+__global__ void __launch_bounds__(kThreads) vg_centroid_both_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;
+    vg_centroid_long_body<0>(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist, d.max_ds, gridDim.x - kMonsterBlocksBatch);
+}
+__global__ void __launch_bounds__(kThreads) vg_centroid_monster_batch(const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || d.sd->n_monster == 0) return;
+    vg_centroid_long_body<2>(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist, d.max_ds, 0u);
 }
 __global__ void scan_begin_kernel(ScanDev* sd, int32_t* __restrict__ nn_cnt, uint32_t min_ds) { scan_begin_body(sd, nn_cnt, min_ds, 0u); }
 __global__ void scan_begin_batch(const SlotDesc* __restrict__ slots) {
@@ -964,7 +994,13 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
     hipLaunchKernelGGL(vg_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, (uint32_t)passes);
     const uint32_t vbound = max_raw < max_ds ? max_raw : max_ds;
     hipLaunchKernelGGL(vg_centroid_batch, dim3((vbound + kThreads - 1) / kThreads, B), kThreads, 0, st, d_slots);
-    hipLaunchKernelGGL(vg_centroid_long_batch, dim3(64 + kMonsterBlocksBatch, B), kThreads, 0, st, d_slots);
+    static const bool split = []() { const char* e = getenv("LIO_VG_MONSTER_SPLIT"); return e && e[0] == '1'; }();
+    if (split) {
+        hipLaunchKernelGGL(vg_centroid_long_batch, dim3(64, B), kThreads, 0, st, d_slots);
+        hipLaunchKernelGGL(vg_centroid_monster_batch, dim3(kMonsterBlocksBatch, B), kThreads, 0, st, d_slots);
+    } else {
+        hipLaunchKernelGGL(vg_centroid_both_batch, dim3(64 + kMonsterBlocksBatch, B), kThreads, 0, st, d_slots);
+    }
     hipLaunchKernelGGL(scan_begin_batch, dim3(16, B), 256, 0, st, d_slots);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
