@@ -559,10 +559,10 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slo
                                                                        float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    const EskfDev* c = d.ctrl;
-    if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
-    const PoseArgs pose = pose_from_state(c->x);
-    knn_body<KM, 0, COUNT>(table, mask, pool, inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
+    const SlotGate sg = slot_gate(d);
+    if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
+    const PoseArgs& pose = sg.pose;
+    knn_body<KM, 0, COUNT>(table, mask, pool, inv_res, st, pose, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
 }
 
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
@@ -647,9 +647,9 @@ __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __rest
                                                               float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || d.sd->n_tie == 0) return;
-    const EskfDev* c = d.ctrl;
-    if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
-    const PoseArgs pose = pose_from_state(c->x);
+    const SlotGate sg = slot_gate(d);
+    if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
+    const PoseArgs& pose = sg.pose;
     knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list);
 }
 
@@ -695,10 +695,10 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_seq_kernel(const MapRe
     if (!d.active) return;
     const MapRef& r = maps[blockIdx.y];
     if (r.stencil_id != stencil_id) return;
-    const EskfDev* c = d.ctrl;
-    if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
-    const PoseArgs pose = pose_from_state(c->x);
-    knn_body<KM, 0, false>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, 0u, d.sd, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, r.md, &d.sd->n_tie, d.tie_list);
+    const SlotGate sg = slot_gate(d);
+    if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
+    const PoseArgs& pose = sg.pose;
+    knn_body<KM, 0, false>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, r.md, &d.sd->n_tie, d.tie_list);
 }
 template <int KM>
 __global__ void __launch_bounds__(256) knn_exact_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id, const SlotDesc* __restrict__ slots) {
@@ -706,9 +706,9 @@ __global__ void __launch_bounds__(256) knn_exact_seq_kernel(const MapRef* __rest
     if (!d.active || d.sd->n_tie == 0) return;
     const MapRef& r = maps[blockIdx.y];
     if (r.stencil_id != stencil_id) return;
-    const EskfDev* c = d.ctrl;
-    if (c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds) return;
-    const PoseArgs pose = pose_from_state(c->x);
+    const SlotGate sg = slot_gate(d);
+    if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
+    const PoseArgs& pose = sg.pose;
     knn_exact_body<KM, 0>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list);
 }
 

@@ -59,4 +59,32 @@ __device__ inline PoseArgs pose_from_state(const double* __restrict__ x) {
     return p;
 }
 
+// What a kernel of the batched loop decides on -- the slot's filter status, its "search again" flag, the scan's size -- and the pose it then works
+// with, requested TOGETHER.  The short-circuit form `c->status != EK_RUNNING || !c->converge || d.sd->n_ds < d.min_ds` followed by
+// pose_from_state(c->x) is four dependent memory round trips at the head of every workgroup (~4 us of a workgroup that lives ~15); a slot that
+// turns out to be idle has asked for 14 doubles it does not use.
+struct SlotGate {
+    int status, converge;
+    uint32_t n_ds;
+    PoseArgs pose;
+};
+__device__ __forceinline__ SlotGate slot_gate(const SlotDesc& d) {
+    const EskfDev* c = d.ctrl;
+    SlotGate g;
+    uint32_t st = (uint32_t)c->status, cv = (uint32_t)c->converge, n = d.sd->n_ds;
+    double x[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) x[i] = c->x[i];
+    pin_loaded(st);
+    pin_loaded(cv);
+    pin_loaded(n);
+#pragma unroll
+    for (int i = 0; i < 14; i++) asm volatile("" : "+v"(x[i]));
+    g.status = (int)st;
+    g.converge = (int)cv;
+    g.n_ds = n;
+    g.pose = pose_from_state(x);
+    return g;
+}
+
 }  // namespace lio

@@ -195,8 +195,8 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
                                                const float4* __restrict__ ds_body, float4* __restrict__ ds_world,
                                                const float4* __restrict__ nn_pts, uint32_t nn_stride,
                                                const int32_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
-                                               float4* __restrict__ normvec, double* __restrict__ partial) {
-    const uint32_t n = sd->n_ds;
+                                               float4* __restrict__ normvec, double* __restrict__ partial, uint32_t n_known = 0xFFFFFFFFu) {
+    const uint32_t n = n_known != 0xFFFFFFFFu ? n_known : sd->n_ds;  // (the batched kernels have read it with the slot's filter words)
     if (blockIdx.x * kLinThreads >= n) return;  // finalize only reads the first ceil(n / kLinThreads) partials
     const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
     // the point's addends are formed at reduction time from its Jacobian row, residual and |residual| (8 doubles live instead of 29)
@@ -339,10 +339,10 @@ __global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, i
 __global__ void __launch_bounds__(kLinThreads) linearize_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    const EskfDev* c = d.ctrl;
-    if (c->status != EK_RUNNING || d.sd->n_ds < d.min_ds) return;
-    const PoseArgs pose = pose_from_state(c->x);
-    linearize_body(pose, c->converge, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, d.selected, d.normvec, d.partial);
+    const SlotGate sg = slot_gate(d);
+    if ((sg.status != EK_RUNNING) | (sg.n_ds < d.min_ds)) return;
+    const PoseArgs& pose = sg.pose;
+    linearize_body(pose, sg.converge, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, d.selected, d.normvec, d.partial, sg.n_ds);
 }
 
 // component `comp` of the workgroups' partial records b = l, l + 32, l + 64, ... < nb, added in that order -- with the loads of eight steps in flight
