@@ -406,7 +406,7 @@ lio_scan* lio_scan_create(int device, uint32_t max_raw, uint32_t max_ds) {
     ok = ok && dev_alloc(&s->raw_own, max_raw, &s->bytes) && dev_alloc(&s->ds_body, max_ds, &s->bytes) && dev_alloc(&s->ds_world, max_ds, &s->bytes) &&
          dev_alloc(&s->nn_pts, (uint64_t)max_ds * 5, &s->bytes) && dev_alloc(&s->nn_cnt, max_ds, &s->bytes) && dev_alloc(&s->selected, max_ds, &s->bytes) &&
          dev_alloc(&s->normvec, (uint64_t)max_ds + (max_ds + 3) / 4, &s->bytes) && dev_alloc(&s->keys_a, max_raw, &s->bytes) && dev_alloc(&s->keys_b, max_raw, &s->bytes) &&
-         dev_alloc(&s->vals_a, max_raw, &s->bytes) && dev_alloc(&s->vals_b, max_raw, &s->bytes) && dev_alloc(&s->hist, std::max<uint64_t>((uint64_t)256 * nblocks, 2 * (((uint64_t)max_ds + 255) / 256) + 2), &s->bytes) &&
+         dev_alloc(&s->vals_a, max_raw, &s->bytes) && dev_alloc(&s->vals_b, max_raw, &s->bytes) && dev_alloc(&s->hist, std::max<uint64_t>((uint64_t)256 * (nblocks + 1) /* + the digit totals' row of the batched chain */, 2 * (((uint64_t)max_ds + 255) / 256) + 2), &s->bytes) &&
          dev_alloc(&s->blockcnt, nblocks, &s->bytes) && dev_alloc(&s->hpos, (uint64_t)max_ds + 1, &s->bytes) && dev_alloc(&s->longlist, max_ds, &s->bytes) && dev_alloc(&s->tie_list, max_ds, &s->bytes) && dev_alloc(&s->sorted, max_raw, &s->bytes) && dev_alloc(&s->partial, (uint64_t)s->partial_blocks * kAcc, &s->bytes) &&
          dev_alloc(&s->dev, 1, &s->bytes) && dev_alloc(&s->d_result, 1, &s->bytes);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&s->host_dev), sizeof(ScanDev)) == hipSuccess &&

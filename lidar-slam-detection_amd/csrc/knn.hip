@@ -596,21 +596,45 @@ __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, u
         Cand e[5];
         for (int k = 0; k < 5; k++) e[k] = {INFINITY, kNoIdx};
         (void)total;
-        for (uint32_t sv = 0; sv < nhit; sv++) {
-            const uint32_t vptr = g.v_ptr[sv], vcnt = g.v_cnt[sv];
-            for (uint32_t i = gl; i < vcnt; i += kG) {
-                const uint32_t id = vptr + i;
-                const float4 p = pool[id];
-                const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
-                const float d2 = dx * dx + (dy * dy + dz * dz);
-                if (d2 < 5.0f) {
-                    Cand cd = {d2, id};
-                    if (cand_less(cd, e[4], pool)) {
-                        e[4] = cd;
-                        for (int k = 4; k > 0; k--)
-                            if (cand_less(e[k], e[k - 1], pool)) { const Cand t = e[k - 1]; e[k - 1] = e[k]; e[k] = t; }
+        // two voxels x four points per lane and step, the eight loads requested together (clamped, unconditional; the list is zero-filled behind
+        // its end).  One load per step made a tied query ~24 memory round trips one after the other, and this kernel sits on the round's critical
+        // path five times (12 us per launch for a handful of queries).  The lists are kept in the strict total order: the order of arrival
+        // does not matter.
+        const uint32_t ptr_first = g.v_ptr[0];
+        for (uint32_t sv = 0; sv < nhit; sv += 2) {
+            const uint32_t vptr[2] = {g.v_ptr[sv], g.v_ptr[sv + 1]}, vcnt[2] = {g.v_cnt[sv], g.v_cnt[sv + 1]};
+            const uint32_t cmax = max(vcnt[0], vcnt[1]);
+            for (uint32_t i0 = 0; i0 < cmax; i0 += 4 * kG) {
+                float4 p[2][4];
+#pragma unroll
+                for (int v = 0; v < 2; v++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t i = i0 + (uint32_t)k * kG + (uint32_t)gl;
+                        p[v][k] = pool[i < vcnt[v] ? vptr[v] + i : ptr_first];
                     }
-                }
+#pragma unroll
+                for (int v = 0; v < 2; v++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pin_loaded(p[v][k]);
+#pragma unroll
+                for (int v = 0; v < 2; v++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t i = i0 + (uint32_t)k * kG + (uint32_t)gl;
+                        if (i >= vcnt[v]) continue;
+                        const uint32_t id = vptr[v] + i;
+                        const float dx = p[v][k].x - pw.x, dy = p[v][k].y - pw.y, dz = p[v][k].z - pw.z;
+                        const float d2 = dx * dx + (dy * dy + dz * dz);
+                        if (d2 < 5.0f) {
+                            Cand cd = {d2, id};
+                            if (cand_less(cd, e[4], pool)) {
+                                e[4] = cd;
+                                for (int kk = 4; kk > 0; kk--)
+                                    if (cand_less(e[kk], e[kk - 1], pool)) { const Cand t = e[kk - 1]; e[kk - 1] = e[kk]; e[kk] = t; }
+                            }
+                        }
+                    }
             }
         }
         uint32_t win = kNoIdx;

@@ -308,6 +308,11 @@ __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
 // (Measured in round 4 and not kept: this pass also building the NEXT pass's per-tile histogram -- one global atomic per key into the row of the
 // tile the key lands in -- so that a scan registered alone would need no histogram launch between its scatters: 120 000 scattered atomics cost
 // 17 us per pass, 8.5 -> 25.3 us for this kernel, against the 4.8 + 1.5 us of the launch they replace.)
+// PREFIXED (the batched chain): radix_prefix_batch has turned the tiles' histogram rows into exclusive prefixes over the tiles (in place) and
+// left the digit totals in row `nblocks`: a scatter workgroup reads its own row and the totals -- 2 KB.  Without it every workgroup folds ALL
+// rows itself (59 KB for a 120 000-point scan: 223 MB of L2 reads per launch of 64 scans, 4 TB/s -- what the batched scatter spent its 51 us on);
+// one scan at a time keeps that form, where a launch costs more than the fold.
+template <bool PREFIXED>
 __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
                                                                  const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
@@ -334,7 +339,10 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
     // this workgroup's global bases, from the raw per-tile histograms: thread d owns digit d.
     //   base[d] = sum_{d' < d} total[d'] + sum_{b' < b} hist[d][b']      (digit-major, then tile order = stable)
     uint32_t tot = 0, pre = 0;
-    {
+    if (PREFIXED) {
+        pre = hist[(size_t)blockIdx.x * 256u + tid];
+        tot = hist[(size_t)nblocks * 256u + tid];
+    } else {
         // [tile][digit] layout: for a given tile the 256 threads read one contiguous 1-KiB row (it used to be [digit][tile]: every lane
         // of a load in a different cache line, 64 transactions per instruction)
         const uint32_t* col = hist + tid;
@@ -878,12 +886,34 @@ __global__ void __launch_bounds__(kThreads) radix_hist_batch(const SlotDesc* __r
 __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
                                                                  const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
-    radix_scatter_body(ka, va, kb, vb, n, pass, hist, nblocks, sd);
+    radix_scatter_body<false>(ka, va, kb, vb, n, pass, hist, nblocks, sd);
 }
 __global__ void __launch_bounds__(kThreads) radix_scatter_batch(const SlotDesc* __restrict__ slots, int pass) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || blockIdx.x >= d.nblocks) return;
-    radix_scatter_body(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd);
+    radix_scatter_body<true>(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd);
+}
+// one workgroup per scan: digit column d (thread d) of the tiles' histogram rows becomes its exclusive prefix over the tiles, the column's total
+// goes to row `nblocks` (sixteen rows in flight; integer sums: the scatter's positions are what the all-rows fold gave)
+__global__ void __launch_bounds__(256) radix_prefix_batch(const SlotDesc* __restrict__ slots, int pass) {
+    const SlotDesc& d = slots[blockIdx.x];
+    if (!d.active) return;
+    if ((uint32_t)pass >= active_passes(d.sd)) return;
+    const uint32_t nb = d.nblocks;
+    uint32_t* col = d.hist + threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < nb; b += 16) {
+        uint32_t hv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) hv[k] = col[(size_t)(b + k < nb ? b + k : b) * 256u];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (b + k < nb) {
+                col[(size_t)(b + k) * 256u] = run;
+                run += hv[k];
+            }
+    }
+    col[(size_t)nb * 256u] = run;
 }
 __global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                                   const ScanDev* sd, uint32_t* __restrict__ blockcnt) {
@@ -988,6 +1018,7 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
     hipLaunchKernelGGL(vg_keys_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, inv);
     for (int pass = 0; pass < passes; pass++) {
         if (pass > 0) hipLaunchKernelGGL(radix_hist_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass);
+        hipLaunchKernelGGL(radix_prefix_batch, dim3(B), 256, 0, st, d_slots, pass);
         hipLaunchKernelGGL(radix_scatter_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass);
     }
     hipLaunchKernelGGL(vg_count_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots);
