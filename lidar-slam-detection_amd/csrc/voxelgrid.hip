@@ -270,25 +270,41 @@ __device__ inline uint32_t active_passes(const ScanDev* sd) { return (sd->nbits 
 
 __device__ __forceinline__ void radix_hist_body(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                               int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
-    if ((uint32_t)pass >= active_passes(sd)) return;
+    // (the pass count is requested with the keys, not before them: one memory round trip instead of two; a pass above the significant bits has
+    // loaded a tile it does not use)
+    uint32_t nbits_w = sd->nbits;
     const uint32_t* keys = (pass & 1) ? kb : ka;
     const int shift = pass * 8;
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
     const uint32_t base = blockIdx.x * kTile;
     // the tile's keys as kItems UNCONDITIONAL loads at clamped indices, all in flight before the first is used (`if (i < n) ... keys[i]` comes out of
     // the compiler as load + s_waitcnt vmcnt(0) per item: eight memory round trips one after the other -- tools/isa_load_chains.py)
-    uint32_t kk[kItems];
+    // (a histogram does not care which thread counts which key: every thread takes 2 x 4 CONSECUTIVE keys as two 16-byte loads -- a quarter of the
+    // memory requests of eight strided dword loads)
+    uint4 kq[kItems / 4];
 #pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        const uint32_t i = base + r * kThreads + threadIdx.x;
-        kk[r] = keys[i < n ? i : (n ? n - 1u : 0u)];
+    for (int r = 0; r < kItems / 4; r++) {
+        const uint32_t i = base + 4u * (uint32_t)(r * kThreads + threadIdx.x);
+        kq[r] = *reinterpret_cast<const uint4*>(keys + (i + 3u < n ? i : 0u));  // (unconditional; a thread at or beyond the scan's end reads the head and ignores it)
     }
+    pin_loaded(nbits_w);
 #pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        const uint32_t i = base + r * kThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[(kk[r] >> shift) & 255u], 1u);
+    for (int r = 0; r < kItems / 4; r++) pin_loaded(kq[r]);
+    if ((uint32_t)pass >= ((nbits_w + 7u) >> 3)) return;
+    h[threadIdx.x] = 0;
+    __syncthreads();  // (behind the loads: a workgroup barrier waits for every load in flight)
+#pragma unroll
+    for (int r = 0; r < kItems / 4; r++) {
+        const uint32_t i = base + 4u * (uint32_t)(r * kThreads + threadIdx.x);
+        if (i + 3u < n) {
+            atomicAdd(&h[(kq[r].x >> shift) & 255u], 1u);
+            atomicAdd(&h[(kq[r].y >> shift) & 255u], 1u);
+            atomicAdd(&h[(kq[r].z >> shift) & 255u], 1u);
+            atomicAdd(&h[(kq[r].w >> shift) & 255u], 1u);
+        } else {  // the scan's last one to three keys (one thread of one workgroup)
+            for (uint32_t e = 0; e < 3u; e++)
+                if (i + e < n) atomicAdd(&h[(keys[i + e] >> shift) & 255u], 1u);
+        }
     }
     __syncthreads();
     hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];  // [tile][digit]: one coalesced 1-KiB row per workgroup
@@ -316,7 +332,7 @@ template <bool PREFIXED>
 __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
                                                                  const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
-    if ((uint32_t)pass >= active_passes(sd)) return;
+    uint32_t nbits_w = sd->nbits;  // (requested with the keys: see radix_hist_body)
     const uint32_t* kin = (pass & 1) ? kb : ka;
     const uint32_t* vin = (pass & 1) ? vb : va;
     uint32_t* kout = (pass & 1) ? ka : kb;
@@ -333,9 +349,17 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
     for (int r = 0; r < kItems; r++) {
         const uint32_t i = base + r * 64 + lane;
         ok[r] = i < n;
-        k[r] = ok[r] ? kin[i] : 0u;
-        v[r] = ok[r] ? vin[i] : 0u;
+        const uint32_t ic = ok[r] ? i : 0u;  // (unconditional loads at clamped indices, in flight together)
+        k[r] = kin[ic];
+        v[r] = vin[ic];
     }
+    pin_loaded(nbits_w);
+#pragma unroll
+    for (int r = 0; r < kItems; r++) { pin_loaded(k[r]); pin_loaded(v[r]); }
+    if ((uint32_t)pass >= ((nbits_w + 7u) >> 3)) return;
+#pragma unroll
+    for (int r = 0; r < kItems; r++)
+        if (!ok[r]) { k[r] = 0u; v[r] = 0u; }
     // this workgroup's global bases, from the raw per-tile histograms: thread d owns digit d.
     //   base[d] = sum_{d' < d} total[d'] + sum_{b' < b} hist[d][b']      (digit-major, then tile order = stable)
     uint32_t tot = 0, pre = 0;
