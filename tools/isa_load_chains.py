@@ -46,8 +46,10 @@ def analyse(body):
                 runs.append(run)
             run = 0
             pending = False
-        elif t.startswith("s_endpgm"):
-            break
+        elif t.startswith(".section") or t.startswith(".amdhsa_kernel"):
+            break  # (the kernel's code is over; an s_endpgm is not the end -- early exits have their own)
+    if run:
+        runs.append(run)
     return loads, waits0, serial, runs
 
 
