@@ -81,7 +81,7 @@ def main():
                     help="batch: B scans per launch, filter loop on the device, one host thread (lio_batch_*); threads: round 1's one engine + thread per scan")
     ap.add_argument("--slots", type=int, default=64, help="--engine batch: scans per launch")
     ap.add_argument("--groups", type=int, default=4, help="--engine batch: rounds in flight (one HIP stream each)")
-    ap.add_argument("--config", choices=["metric", "merge", "stream", "localize", "sequences", "refparity"], default="metric",
+    ap.add_argument("--config", choices=["metric", "merge", "stream", "localize", "sequences", "refparity", "rcclprobe"], default="metric",
                     help="metric: BASELINE.json's headline (independent 120k-pt scans vs a 1e7-pt map); merge: BASELINE config 5, multi-map merge -- 8 sub-maps "
                          "spread over the GPUs, every key-frame scan registered JOINTLY against all of them (RCCL all-gather of the per-rank J^T J / J^T r); "
                          "stream: BASELINE config 3 (streaming front half, incremental map); localize: BASELINE config 4 (NDT scan-to-map vs a 5e7-pt resident map)")
@@ -102,11 +102,14 @@ def main():
     ap.add_argument("--parity-scans", type=int, default=32, help="scans of the pool registered by the PINNED build of the reference (scalar Eigen, oracle/_ref/libref_fastlio.so) in a "
                                                                   "child process for cpu_baseline.gpu_vs_reference_pose.pinned_build")
     ap.add_argument("--parity-dir", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)  # --config rcclprobe: the child process of rccl_probe (its job as JSON, or "uid")
     ap.add_argument("--min-seconds", type=float, default=5.0, help="the job list of --steps scans is repeated until the timed region lasts at least this long")
     args = ap.parse_args()
 
     if args.config == "refparity":  # child process of the metric config's parity leg: CPU only
         return ref_parity_leg(args.parity_dir)
+    if args.config == "rcclprobe":  # child process of rccl_probe: one rank of the C ABI's communicator, nothing of torch.distributed in it
+        return rccl_probe_child(args.probe)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher -- one process per GPU under torch.distributed.run (RCCL / gloo
         # rendezvous on 127.0.0.1), this process only waits for them and hands their exit code back
@@ -698,7 +701,12 @@ def main():
     # N > 1: the metric's ranks are replicas (no data-path collective); the native communicator of the C ABI (lio_comm_*: RCCL over xGMI, what
     # config 5's joint registration runs on) is brought up once OUTSIDE the timed region and its small-message all-gather timed, so that a
     # multi-GPU run leaves a measured collective latency and the communicator's own rank count in the line
-    collective = rccl_probe(torch, dist, lio, rank, world, local_rank, dev) if dist is not None else None
+    collective = None
+    if dist is not None:
+        try:
+            collective = rccl_probe(dist, rank, world, local_rank)
+        except Exception as ex:  # the probe must never cost the run its line
+            collective = {"error": repr(ex)[-300:]}
     if rank == 0:
         value = total_pts / t_max
         out = {
@@ -811,49 +819,78 @@ def ref_parity_leg(td):
     print(json.dumps(out))
 
 
-def rccl_probe(torch, dist, lio, rank, world, local_rank, dev, n_records=64, iters=200, timeout_s=90.0):
+def rccl_probe(dist, rank, world, local_rank, n_records=64, iters=200, timeout_s=75.0):
     """bring up lio_comm (ncclCommInitRank through the C ABI) on all ranks and time lio_allgather_records of [n_records x 32] doubles per rank -- the
-    per-round, per-pass collective of the batched joint registration (config 5).  Runs in a worker thread with a deadline: a communicator that
-    cannot be built must not cost the run its headline."""
-    import threading
+    per-round, per-pass collective of the batched joint registration (config 5).  Every rank does it in a CHILD process (`--config rcclprobe`: its
+    own HIP context on the rank's GPU, nothing of torch.distributed inside): the process that holds the headline never loads a second RCCL beside
+    torch's, and a communicator that crashes or hangs -- this path has never met more than one GPU -- costs the run a minute, not its line.  The
+    unique id comes from a child of rank 0 and travels through torch.distributed."""
+    import subprocess
 
-    from lsd_amd import capi
-
-    out = {}
-
-    def work():
+    me = os.path.abspath(__file__)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    box = [None]
+    if rank == 0:
         try:
-            box = [lio.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            comm = lio.Comm(rank=rank, world=world, device=local_rank, uid=box[0])
-            lib = capi.lib()
-            loc = torch.full((n_records * 32,), float(rank), dtype=torch.float64, device=dev)
-            gat = torch.zeros((world * n_records * 32,), dtype=torch.float64, device=dev)
-            st = torch.cuda.current_stream().cuda_stream
-            for _ in range(20):
-                if lib.lio_allgather_records(comm.h, loc.data_ptr(), gat.data_ptr(), n_records, st) != 0:
-                    raise RuntimeError(lib.lio_last_error().decode())
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                lib.lio_allgather_records(comm.h, loc.data_ptr(), gat.data_ptr(), n_records, st)
-            e1.record()
-            torch.cuda.synchronize()
-            heads = gat.view(world, -1)[:, 0].cpu().numpy()
-            out.update(rccl_ranks=int(lib.lio_comm_world(comm.h)), backend="RCCL all-gather through lio_allgather_records (librccl loaded by liblio_hip.so)",
-                       bytes_per_rank=n_records * 256, avg_us=round(e0.elapsed_time(e1) * 1e3 / iters, 2), iterations=iters,
-                       gathered_in_rank_order=bool(np.array_equal(heads, np.arange(world, dtype=np.float64))))
-            comm.close()
-        except Exception as ex:
-            out["error"] = repr(ex)[-300:]
-
-    th = threading.Thread(target=work, daemon=True)
-    th.start()
-    th.join(timeout_s)
-    if th.is_alive():
-        out["error"] = f"the communicator did not come up within {timeout_s:.0f} s"
+            r = subprocess.run([sys.executable, me, "--config", "rcclprobe", "--probe", "uid"], capture_output=True, text=True, timeout=60, env=env)
+            line = (r.stdout.strip().splitlines() or [""])[-1]
+            box = [line if len(line) == 256 else None]
+        except Exception:
+            box = [None]
+    dist.broadcast_object_list(box, src=0)
+    if not box[0]:
+        return {"error": "no RCCL unique id (librccl could not be loaded by liblio_hip.so?)"}
+    job = json.dumps(dict(rank=rank, world=world, device=local_rank, uid=box[0], n_records=n_records, iters=iters))
+    try:
+        r = subprocess.run([sys.executable, me, "--config", "rcclprobe", "--probe", job], capture_output=True, text=True, timeout=timeout_s, env=env)
+        line = (r.stdout.strip().splitlines() or [""])[-1]
+        out = json.loads(line) if line.startswith("{") else {"error": ("rc %d: " % r.returncode) + (r.stderr or "")[-300:]}
+    except subprocess.TimeoutExpired:
+        out = {"error": f"the communicator did not come up within {timeout_s:.0f} s"}
+    except Exception as ex:
+        out = {"error": repr(ex)[-300:]}
     return out
+
+
+def rccl_probe_child(spec):
+    """--config rcclprobe: "uid" prints a fresh ncclUniqueId as hex; otherwise one rank of the communicator (see rccl_probe), one JSON line"""
+    import torch  # (first: liblio_hip.so's lazily loaded librccl then resolves to the copy torch ships and has loaded -- the build this image's RCCL tests ran with)
+
+    from lsd_amd import capi, lio
+
+    if spec == "uid":
+        print(lio.Comm.unique_id().hex())
+        return
+    a = json.loads(spec)
+    out = {}
+    try:
+        torch.cuda.set_device(a["device"])
+        dev = torch.device("cuda", a["device"])
+        rank, world, n_records, iters = a["rank"], a["world"], a["n_records"], a["iters"]
+        comm = lio.Comm(rank=rank, world=world, device=a["device"], uid=bytes.fromhex(a["uid"]))
+        lib = capi.lib()
+        loc = torch.full((n_records * 32,), float(rank), dtype=torch.float64, device=dev)
+        gat = torch.zeros((world * n_records * 32,), dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(20):
+            if lib.lio_allgather_records(comm.h, loc.data_ptr(), gat.data_ptr(), n_records, st) != 0:
+                raise RuntimeError(lib.lio_last_error().decode())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            lib.lio_allgather_records(comm.h, loc.data_ptr(), gat.data_ptr(), n_records, st)
+        e1.record()
+        torch.cuda.synchronize()
+        heads = gat.view(world, -1)[:, 0].cpu().numpy()
+        out.update(rccl_ranks=int(lib.lio_comm_world(comm.h)), backend="RCCL all-gather through lio_allgather_records (librccl loaded by liblio_hip.so), in a child process per rank",
+                   bytes_per_rank=n_records * 256, avg_us=round(e0.elapsed_time(e1) * 1e3 / iters, 2), iterations=iters,
+                   gathered_in_rank_order=bool(np.array_equal(heads, np.arange(world, dtype=np.float64))))
+        comm.close()
+    except Exception as ex:
+        out["error"] = repr(ex)[-300:]
+    print(json.dumps(out))
 
 
 def bench_sequences(args, torch, local_rank, dev):

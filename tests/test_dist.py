@@ -295,3 +295,34 @@ def test_bench_spawns_its_own_ranks(config):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)
+
+
+def test_rccl_probe_runs_in_child_processes_and_never_raises():
+    """bench.py's RCCL probe (N > 1 only: the communicator of the C ABI brought up beside the headline) lives in child processes: `--config rcclprobe
+    --probe uid` hands out a fresh unique id, and the parent's helper turns every failure of a child -- here: no GPU for the communicator itself --
+    into an `error` entry of the line instead of an exception or a hang"""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "rcclprobe", "--probe", "uid"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    uid = r.stdout.strip().splitlines()[-1]
+    assert len(uid) == 256 and int(uid, 16) >= 0
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class OneRank:  # torch.distributed's broadcast_object_list for a world of one
+        @staticmethod
+        def broadcast_object_list(box, src=0):
+            return None
+
+    out = bench.rccl_probe(OneRank, rank=0, world=1, local_rank=0, iters=2, timeout_s=240.0)
+    assert isinstance(out, dict)
+    if "error" in out:  # (no GPU in this container: the child reports, the parent carries it on)
+        assert isinstance(out["error"], str) and out["error"]
+    else:
+        assert out["rccl_ranks"] == 1 and out["gathered_in_rank_order"]
+    json.dumps(out)
