@@ -5,7 +5,11 @@ were written to be in flight together but come out of the compiler as one memory
 work)`: the PHI of the loaded value is resolved by moves at the end of the predicated block, which need the data; or a load sunk into the
 conditional block that consumes it).  Round 4 found the kNN kernel's four candidate loads and its two home-slot probes serialised this way.
 
-    python tools/isa_load_chains.py <file.s> [kernel-substring]
+    python tools/isa_load_chains.py <file.s> [kernel-substring] [--min-serial N]
+
+<file.s>: `hipcc --offload-arch=gfx950 --cuda-device-only -S -O3 ... x.hip -o x.s` (or the *-hip-amdgcn-*.s that -save-temps leaves).  --min-serial N
+lists only kernels with at least N single-load-then-wait sequences (pointer chases through descriptors account for two or three in every batched
+kernel).  tests/test_isa_loads.py holds the groups the hot kernels must keep.
 """
 import re
 import sys
@@ -54,15 +58,21 @@ def analyse(body):
 
 
 def main():
-    path = sys.argv[1]
-    pat = sys.argv[2] if len(sys.argv) > 2 else ""
+    argv = list(sys.argv[1:])
+    min_serial = 0
+    if "--min-serial" in argv:
+        k = argv.index("--min-serial")
+        min_serial = int(argv[k + 1])
+        del argv[k:k + 2]
+    path = argv[0]
+    pat = argv[1] if len(argv) > 1 else ""
     for name, body in kernels(path):
         if pat and pat not in name:
             continue
         if not any(".amdhsa_kernel" in b or "s_endpgm" in b for b in body):
             continue
         loads, waits0, serial, runs = analyse(body)
-        if loads == 0:
+        if loads == 0 or serial < min_serial:
             continue
         short = re.sub(r"^_ZN3lio\d+", "", name)[:70]
         print(f"{short:72s} loads {loads:3d}  vmcnt(0) waits {waits0:3d}  single-load-then-wait {serial:3d}  groups {runs}")
