@@ -29,9 +29,58 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "lidar-slam-detection_amd", "python"))
 
+import bench_line  # the compact stdout line (bench_line.py, beside this file)
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, peak engine clock
 KNN_VALU_PER_WAVE_STATIC = 1630.0  # VALU instructions of one wave (four queries) of knn_batch_kernel at the metric map's trip counts
+FULL_LINE = False  # --full-line (the children of the metric config's secondary legs): the whole record on stdout instead of the compact line
+
+
+def emit(out, tag="metric"):
+    """rank 0's output: the whole record to bench_full[_<tag>].json beside this file and to stderr, the compact line (<= bench_line.LIMIT bytes: the
+    driver's parser did not take round 4's 30 KB line) as the ONE stdout line"""
+    if FULL_LINE:
+        print(json.dumps(out))
+        return
+    name = "bench_full.json" if tag == "metric" else f"bench_full_{tag}.json"
+    try:
+        with open(os.path.join(ROOT, name), "w") as f:
+            json.dump(out, f, indent=1)
+        out = dict(out, full_record=name)
+    except OSError:
+        pass
+    print("bench.py full record: " + json.dumps(out), file=sys.stderr)
+    sys.stderr.flush()
+    print(bench_line.line(out))
+    sys.stdout.flush()
+
+
+_VALU_PEAK = {}
+
+
+def measured_valu_peak(device=0, waves_per_simd=6, mix=1):
+    """the chip's VALU issue rate in wave-instructions per second, MEASURED by tools/valu_peak (every SIMD holding `waves_per_simd` waves of
+    independent v_add_u32 / v_min_u32 / DPP work -- the kNN merge's diet); None when the tool's library is not built"""
+    key = (device, waves_per_simd, mix)
+    if key not in _VALU_PEAK:
+        _VALU_PEAK[key] = None
+        try:
+            import ctypes as C
+
+            L = C.CDLL(os.path.join(ROOT, "tools", "valu_peak", "libvalu_peak.so"))
+            L.valu_peak_wave_insts_per_s.restype = C.c_double
+            L.valu_peak_wave_insts_per_s.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            cus, mhz = C.c_int(0), C.c_int(0)
+            best = max(L.valu_peak_wave_insts_per_s(device, waves_per_simd, mix, C.byref(cus), C.byref(mhz)) for _ in range(3))
+            if best > 0:
+                _VALU_PEAK[key] = {"wave_insts_per_s": best, "cus": cus.value, "clock_mhz": mhz.value,
+                                   "cycles_per_wave_inst_at_reported_clock": (cus.value * 4 * mhz.value * 1e6 / best) if mhz.value else None,
+                                   "mix": {0: "v_add_u32", 1: "v_add_u32 / v_min_u32 / v_add_u32_dpp row_ror", 2: "v_fma_f32", 3: "v_add_f64"}[mix],
+                                   "waves_per_simd": waves_per_simd}
+        except Exception:
+            _VALU_PEAK[key] = None
+    return _VALU_PEAK[key]
 
 
 def usable_cpus():
@@ -103,8 +152,13 @@ def main():
                                                                   "child process for cpu_baseline.gpu_vs_reference_pose.pinned_build")
     ap.add_argument("--parity-dir", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)  # --config rcclprobe: the child process of rccl_probe (its job as JSON, or "uid")
+    ap.add_argument("--full-line", action="store_true", help=argparse.SUPPRESS)  # the whole record on stdout (the metric config's children of the secondary legs)
+    ap.add_argument("--upload-scans", type=int, default=-1, help="--config metric: scans of the upload-included leg (the pool from pinned host memory, copy overlapped "
+                                                                  "with the rounds in flight); -1 = as many as the timed region, 0 = skip")
     ap.add_argument("--min-seconds", type=float, default=5.0, help="the job list of --steps scans is repeated until the timed region lasts at least this long")
     args = ap.parse_args()
+    global FULL_LINE
+    FULL_LINE = bool(args.full_line)
 
     if args.config == "refparity":  # child process of the metric config's parity leg: CPU only
         return ref_parity_leg(args.parity_dir)
@@ -303,6 +357,41 @@ def main():
 
     cand = the_map.knn_candidates - cand0
     S = 19
+    # ---- the same workload with the upload INCLUDED (t_scan upload excluded and included, both reported): the pool's clouds in
+    # page-locked HOST memory, every job LIO_JOB_HOST_RAW -- the library copies a round's clouds to HBM on the round's stream, beside the kernels of the
+    # other rounds in flight (the reference's path starts with this copy: slam/src/py_utils.cpp:149-181, slam_wrapper.cpp:64-84).  Same C call, same jobs.
+    upload = None
+    if batch is not None and args.upload_scans != 0:
+        try:
+            pinned = [lio.PinnedCloud(sc["raw"]) for sc in scans]
+
+            def job_host(i):
+                sc, pc = scans[i % len(scans)], pinned[i % len(scans)]
+                return dict(dptr=pc.ptr, n=pc.n, t=1.0 + 0.1 * i, state=sc["guess"], cov=P0, flags=lio.JOB_HOST_RAW)
+
+            n_up = args.upload_scans if args.upload_scans > 0 else int(min(n_timed, max(4 * args.slots * args.groups, np.ceil(2.5 / max(t_local / n_timed, 3.5e-5)))))
+            lio.run_prepared(lio.PreparedJobs([job_host(i) for i in range(2 * args.slots * args.groups)]), batch=batch)  # (raw rings allocated, untimed)
+            prep_up = lio.PreparedJobs([job_host(i) for i in range(n_up)])
+            barrier()
+            u0 = time.perf_counter()
+            rc_up = lio.run_prepared(prep_up, batch=batch)
+            torch.cuda.synchronize()
+            t_up = time.perf_counter() - u0
+            res_up = prep_up.results()
+            same_up = rc_up == 0 and all(r["rc"] == 3 and np.array_equal(r["state"], results[i % len(scans)]["state"]) for i, r in enumerate(res_up))
+            bytes_up = float(sum(16 * len(scans[i % len(scans)]["raw"]) for i in range(n_up)))
+            if dist is not None:
+                tu = torch.tensor([t_up], device=dev, dtype=torch.float64)
+                dist.all_reduce(tu, op=dist.ReduceOp.MAX)
+                t_up = float(tu.item())
+            upload = {"ms_per_step": round(1e3 * t_up / n_up, 4), "value": round(world * bytes_up / 16.0 / t_up, 1), "unit": "points/s", "timed_scans": n_up,
+                      "timed_seconds": round(t_up, 4), "host_bytes_per_scan": int(bytes_up / n_up), "pcie_GBps": round(bytes_up / t_up / 1e9, 2),
+                      "parity_ok": bool(same_up),
+                      "what": "the timed region's jobs with the clouds in pinned host memory (lio_pinned_alloc) and LIO_JOB_HOST_RAW: hipMemcpyAsync of a round's "
+                              "clouds on the round's stream, overlapped with the other rounds in flight; results bit-identical to the resident run's (parity_ok)"}
+            del prep_up, pinned
+        except Exception as ex:  # the headline must not depend on this leg
+            upload = {"error": repr(ex)[-300:]}
     n_ds_avg = acc["n_ds"] / n_timed
     # ---- roofline of the dominant kernel (stencil kNN) ------------------------------------------------------------------------------
     # algorithmic bytes [SURVEY.md 8d]: B_knn = N_ds * (16 query + 16 * S slot probes) + 16 * (points resident in the probed voxels), per
@@ -346,10 +435,16 @@ def main():
         return leg
 
     def knn_roofline(leg, traffic_file):
-        """the roofline object of the batched kNN kernel from a solo_leg: the kernel is VALU-issue bound, so `bound` says
-        so and the VALU roofline (wave instructions over the chip's issue rate) stands beside the three byte fractions SURVEY 8d asks for"""
+        """the roofline object of the batched kNN kernel from a solo_leg.  `frac` is a UTILISATION: bytes that reach the memory side (PMC FETCH_SIZE x 2 +
+        WRITE_SIZE per launch, profiles/<traffic_file>, collected in their own rocprofv3 --pmc passes of this workload) over the kernel's live HIP-event
+        time over the 8 TB/s peak; without a PMC file of this workload, the bytes the kernel's loads REQUEST (its counting variant on the same jobs), an
+        upper bound of what reaches HBM.  The reference algorithm's bytes (every point of the 19 stencil voxels of every query) are credit
+        for work the exactly pruned sweep does not do: they stand beside it as frac_algorithmic and may exceed 1.  frac_valu = the kernel's VALU
+        wave-instructions per launch over the chip's MEASURED issue rate (tools/valu_peak) over the same time."""
         us = leg["us"]
-        ach = leg["bytes"] / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        per_s = 1.0 / (us * 1e-6) if us > 0 else 0.0
+        alg = leg["bytes"] * per_s / 1e9
+        touched = leg["touched_bytes"] * per_s / 1e9
         traffic, valu_per_wave, valu_src = None, KNN_VALU_PER_WAVE_STATIC, "static ISA count (llvm-objdump of knn.o, loop body at the average trip counts)"
         valu_per_launch = None
         tpath = os.path.join(ROOT, "profiles", traffic_file)
@@ -364,28 +459,37 @@ def main():
             except Exception:
                 traffic = None
         waves = leg["queries_per_launch"] / 4.0  # sixteen lanes per query: four queries per wave-pass (a launched wave takes several in turn)
+        measured = valu_src.startswith("PMC")
         if valu_per_launch is None:
             valu_per_launch = waves * valu_per_wave
-        issue_us = valu_per_launch / (N_SIMD * CLOCK_GHZ * 1e3 / 4.0)  # a SIMD issues one wave64 VALU instruction per four cycles
-        measured = valu_src.startswith("PMC")
-        return dict(bound="valu", kernel="knn_batch_kernel<2, false> (16 lanes per query, %d scans per launch)" % args.slots,
-                    achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                    touched_bytes_per_launch=int(leg["touched_bytes"]),
-                    frac_touched=round(leg["touched_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
-                    frac_hbm_traffic=(round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic and us > 0 else None),
+        vp = measured_valu_peak(local_rank)
+        peak_rate = vp["wave_insts_per_s"] if vp else None
+        # (the static count is the metric map's: ~300 candidates per query; a sparser map sweeps fewer voxels per query, so without a PMC count of THIS
+        # workload the figure is an upper bound and no fraction is formed from it)
+        valu_ok = us > 0 and peak_rate and (measured or abs(leg["candidates_per_query"] - 300.0) < 60.0)
+        frac_valu = round(valu_per_launch / peak_rate / (us * 1e-6), 4) if valu_ok else None
+        mem = traffic * per_s / 1e9 if traffic else touched
+        return dict(bound="hbm", limited_by="latency / VALU issue (no MFMA on this path): frac_valu beside the byte fractions",
+                    kernel="knn_batch_kernel<2, false> (16 lanes per query, %d scans per launch)" % args.slots,
+                    achieved=round(mem, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(mem / HBM_PEAK_GBS, 4),
+                    frac_basis=("pmc: FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/%s) over the live HIP-event time" % traffic_file) if traffic
+                               else "bytes the kernel's loads request (counting variant, same jobs): no PMC pass of this workload",
+                    traffic=traffic,
+                    achieved_algorithmic=round(alg, 1), frac_algorithmic=round(alg / HBM_PEAK_GBS, 4),
+                    touched_bytes_per_launch=int(leg["touched_bytes"]), frac_touched=round(touched / HBM_PEAK_GBS, 4),
+                    frac_hbm_traffic=(round(traffic * per_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                    frac_valu=frac_valu, valu_peak_wave_insts_per_s=(round(peak_rate, 0) if peak_rate else None),
+                    valu_wave_insts_per_launch=round(valu_per_launch, 0),
                     valu={"wave_instructions_per_launch": round(valu_per_launch, 0), "per_four_queries": round(valu_per_launch / max(waves, 1.0), 1),
-                          "source": valu_src, "four_query_units_per_launch": round(waves, 1),
-                          "issue_bound_us": round(issue_us, 2),
-                          # (the static count is the metric map's: ~300 candidates per query; a sparser map sweeps fewer voxels per query, so without a
-                          # PMC count of THIS workload the figure is an upper bound and no fraction is formed from it)
-                          "frac_of_valu_issue_peak": (round(issue_us / us, 4) if us > 0 and (measured or abs(leg["candidates_per_query"] - 300.0) < 60.0) else None),
-                          "peak": "%d SIMDs x %.1f GHz / 4 cycles per wave64 instruction" % (N_SIMD, CLOCK_GHZ)},
+                          "source": valu_src, "four_query_units_per_launch": round(waves, 1), "peak_measured": vp,
+                          "issue_bound_us": (round(1e6 * valu_per_launch / peak_rate, 2) if peak_rate else None),
+                          "frac_of_valu_issue_peak": frac_valu},
                     algorithmic_bytes_per_launch=int(leg["bytes"]), avg_launch_us=round(us, 2), launches=leg["launches"],
                     candidates_per_query=round(leg["candidates_per_query"], 1),
-                    note="the kernel is VALU-issue bound: valu.frac_of_valu_issue_peak is its quality figure.  The three byte fractions of the 8 TB/s peak "
-                         "stand beside it as SURVEY 8d asks: frac = the reference algorithm's bytes (every point of the 19 stencil voxels of every query) over the "
-                         "kernel's time -- credit for bytes the pruned sweep does not read, NOT a bandwidth utilisation; frac_touched = the bytes the exactly "
-                         "pruned sweep asks for (counted by the kernel's counting variant on the same jobs); frac_hbm_traffic = what reaches HBM (PMC)")
+                    note="frac = memory-side bytes (PMC) or requested bytes over the kernel's time over 8 TB/s: a utilisation.  frac_algorithmic = the reference "
+                         "algorithm's bytes (every point of the 19 stencil voxels of every query) over the same time: credit for bytes the pruned sweep does "
+                         "not read, may exceed 1.  frac_touched = the bytes the exactly pruned sweep asks for.  frac_valu = VALU wave-instructions per launch "
+                         "over the measured issue rate (tools/valu_peak/valu_peak.hip, run in this process)")
 
     if batch is not None:
         leg = solo_leg(the_map, [job_of(i) for i in range(max(args.slots * 8, len(scans)))])
@@ -452,9 +556,9 @@ def main():
     if batch is not None:
         roofline = knn_roofline(leg, "knn_batch_traffic.json")
     else:
-        roofline = dict(bound="valu", kernel=kernel_name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+        roofline = dict(bound="hbm", kernel=kernel_name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=None, algorithmic_bytes_per_launch=int(iso_bytes), avg_launch_us=round(iso_us, 2), launches=iso_launches, per_stream=timed_region)
-    roofline.update(measured_copy_peak=copy_peak, frac_of_measured_copy_peak=(round(achieved / copy_peak, 4) if copy_peak else None),
+    roofline.update(measured_copy_peak=copy_peak, frac_of_measured_copy_peak=(round(roofline["achieved"] / copy_peak, 4) if copy_peak else None),
                     timed_region=round(t_max, 4), timed_region_s=round(t_max, 4), other_kernels_us=others,
                     whole_scan={"algorithmic_bytes_per_scan": int(b_scan), "seconds_per_scan": t_scan, "achieved": round(b_scan / t_scan / 1e9, 1),
                                 "frac": round(b_scan / t_scan / 1e9 / HBM_PEAK_GBS, 4),
@@ -656,7 +760,7 @@ def main():
                     R2.map_add(map2_pts)
                     R2.set_nearby(18)
                     m2 = min(40, args.ref_scans)
-                    t_r2, p_r2, e_r2 = 0.0, 0, 0.0
+                    t_r2, p_r2, e_r2, dps2, das2 = 0.0, 0, 0.0, [], []
                     for i in range(m2):
                         sc2 = scans[i % len(scans)]
                         R2.reset_cache()
@@ -665,11 +769,16 @@ def main():
                         t_r2 += time.perf_counter() - c0
                         p_r2 += len(sc2["raw"])
                         if rc_r2 == 3:
-                            e_r2 = max(e_r2, float(np.linalg.norm(r2[i]["state"][:3] - sr2[:3])))
+                            dps2.append(float(np.linalg.norm(r2[i]["state"][:3] - sr2[:3])))
+                            das2.append(float(synth.quat_angle(r2[i]["state"][3:7], sr2[3:7])))
+                    e_r2 = max(dps2) if dps2 else 0.0
+                    gvr2 = {"build": "the reference's own flags (-O3 -DNDEBUG, vectorised Eigen)", "scans": len(dps2), "max_dpos_m": e_r2,
+                            "max_drot_rad": max(das2) if das2 else 0.0, "median_dpos_m": float(np.median(dps2)) if dps2 else None,
+                            "scans_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((np.array(dps2) > 1e-4) | (np.array(das2) > 1e-5)))}
                     c2["cpu_baseline"] = dict(value=round(p_r2 / t_r2, 1), unit="points/s", cores=min(8, usable_cpus()), host_cpus=usable_cpus(), kind="reference",
                                               sample=f"{m2} scans of the same workload through the reference's own laserMapping.cpp h_share_model + iVox + esekfom update "
                                                      f"(oracle/_ref/libref_fastlio_release.so, MP_PROC_NUM=8) against the same 1e6 map points, {t_r2:.1f} s",
-                                              ms_per_scan=round(1e3 * t_r2 / m2, 2), gpu_vs_reference_pose_max_dpos_m=e_r2)
+                                              ms_per_scan=round(1e3 * t_r2 / m2, 2), gpu_vs_reference_pose_max_dpos_m=e_r2, gpu_vs_reference_pose=gvr2)
                     del R2
             configs["config2_1e6_map"] = c2
         except Exception as ex:  # the headline must not depend on the secondary legs
@@ -685,7 +794,7 @@ def main():
                            ("config5_merge_8_submaps_1_gpu", ["--config", "merge", "--steps", "256", "--warmup", "64", "--scan-pool", "64", "--min-seconds", "2"]),
                            ("sequence_batch", ["--config", "sequences", "--steps", "24", "--slots", "64", "--groups", "2"])):
             try:
-                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--seed", str(args.seed)] + extra, capture_output=True, text=True, timeout=900)
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--full-line", "--seed", str(args.seed)] + extra, capture_output=True, text=True, timeout=900)
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
                 if pr.returncode != 0 or not line:
                     raise RuntimeError((pr.stderr or pr.stdout)[-400:])
@@ -730,9 +839,9 @@ def main():
             "pose_error_vs_truth": {"max_dpos_m": pose_err, "max_drot_rad": ang_err,
                                     "note": "the reference's algorithm itself: at most four ESKF iterations from a prior 0.3 m / 2 deg off; the GPU pose "
                                             "equals the oracle's and the reference's own (cpu_baseline.gpu_vs_*_pose)"},
-            "batch_vs_oracle_pose": batch_vs_oracle, "roofline": roofline, "cpu_baseline": cpu, "configs": configs,
+            "batch_vs_oracle_pose": batch_vs_oracle, "upload_included": upload, "roofline": roofline, "cpu_baseline": cpu, "configs": configs,
         }
-        print(json.dumps(out))
+        emit(out, "metric")
     if dist is not None:
         if collective and "did not come up" in str(collective.get("error", "")):  # a worker thread is stuck inside ncclCommInitRank: leave without the teardown
             sys.stdout.flush()
@@ -1113,11 +1222,11 @@ def bench_sequences(args, torch, local_rank, dev):
                    "what": "state, covariance and return code of every sweep, map point / voxel counts at the end, against the same scans pushed one by one through "
                            "lio_engine_process_scan_device on an engine with the device loop on"},
     }
-    print(json.dumps(out))
+    emit(out, "sequences")
 
 
 def bench_stream(args, torch, local_rank):
-    print(json.dumps(stream_run(args, torch, local_rank)))
+    emit(stream_run(args, torch, local_rank), "stream")
 
 
 def load_bin_dir(path, scan_period=0.1):
@@ -1187,7 +1296,7 @@ def stream_run(args, torch, local_rank):
     if not evict:
         e.map.set_lru(((1 << 23) if big else 6_000_000) - 100_000, 1e9)  # a capacity the drive never reaches: nothing is evicted
     e.fastlio_init(scan_period=0.1)  # turns on the reference's 100000-voxel / 100 m LRU list unless one was set above
-    ii, t_main, t_enq, rows, pts = 0, [], [], [], 0
+    ii, t_main, t_enq, t_fl, rows, pts = 0, [], [], [], [], 0
     by_size = []  # (map points at the time, main seconds) for the curve "ms per scan against map size"
     map_points = 0
     k_done = 0
@@ -1217,7 +1326,11 @@ def stream_run(args, torch, local_rank):
             driven = float(tr._d(tk)) if hasattr(tr, "_d") else None
             dk = sk[0:3] - tr.R(0.0).T @ (tr.pos(tk) - tr.pos(0.0))
             err_curve.append([None if driven is None else round(driven, 1), round(float(np.linalg.norm(dk)), 3), round(float(dk[2]), 3)])
-        e.flush()  # after the clock: the scan's map_incremental was enqueued, not waited for (its count, and an overflow, are read here)
+        # the scan's map_incremental was enqueued by fastlio_main, not waited for; the wait (its count, and an overflow, are read here) is TIMED:
+        # this loop feeds the next sweep only after the insert is done, like the reference, whose fastlio_main inserts synchronously -- so the part of
+        # the insert that fastlio_main's return did not cover belongs to the sweep's cost (it used to fall between the clocks)
+        e.flush()
+        t3 = time.perf_counter()
         last_states.append((k, e.get_state()))  # (the engine's own poses of the last sweeps: the priors of the kNN leg on the grown map)
         if len(last_states) > 32:
             last_states.pop(0)
@@ -1236,6 +1349,7 @@ def stream_run(args, torch, local_rank):
         if rc == capi.MAIN_UPDATED and k >= 20:
             t_enq.append(t1 - t0)
             t_main.append(t2 - t1)
+            t_fl.append(t3 - t2)
             pts += len(p)
             tm = e.timings()
             rows.append((tm["n_ds"], tm["n_pass"], tm["n_knn_pass"], tm["n_added"]))
@@ -1303,7 +1417,7 @@ def stream_run(args, torch, local_rank):
     map_points, map_voxels = e.map.stats()
     evicted = e.map.lru_stats()[0]
     rows = np.array(rows, dtype=np.float64)
-    tot = float(np.sum(t_main) + np.sum(t_enq))
+    tot = float(np.sum(t_main) + np.sum(t_enq) + np.sum(t_fl))  # enqueue + fastlio_main + the wait for its map_incremental
     curve = []
     if by_size:
         bs = np.array(by_size)
@@ -1357,7 +1471,7 @@ def stream_run(args, torch, local_rank):
                         if R.map_voxels() >= 100000:
                             t_full += c1 - c0
                             n_full += 1
-                gpu_same = float(np.mean((np.array(t_main) + np.array(t_enq))[: max(n_ref, 1)]))
+                gpu_same = float(np.mean((np.array(t_main) + np.array(t_enq) + np.array(t_fl))[: max(n_ref, 1)]))
                 ref_err = None
                 if tr is not None and m_ref > 0:
                     ref_err = float(np.linalg.norm(R.get_state()[0:3] - tr.R(0.0).T @ (tr.pos(m_ref * 0.1) - tr.pos(0.0))))
@@ -1383,6 +1497,10 @@ def stream_run(args, torch, local_rank):
                       "map_points_end": int(map_points), "map_voxels_end": int(map_voxels), "voxels_evicted": int(evicted),
                       "main_ms_median": round(1e3 * float(np.median(t_main)), 4), "enqueue_ms_median": round(1e3 * float(np.median(t_enq)), 4),
                       "main_ms_p99": round(1e3 * float(np.percentile(t_main, 99)), 4), "main_ms_median_by_map_size_Mpts": curve,
+                      "insert_wait_ms_median": round(1e3 * float(np.median(t_fl)), 4),
+                      "ms_per_scan_without_the_insert_wait": round(1e3 * float(np.sum(t_main) + np.sum(t_enq)) / len(t_main), 4),
+                      "timing": "ms_per_step = enqueue + lio_fastlio_main + the wait for the map_incremental it enqueued (lio_engine_flush), per sweep: the "
+                                "synchronous cost, comparable with the reference's fastlio_main; main_ms_* are lio_fastlio_main alone (state final, insert in flight)",
                       "sweep_generation_s": round(t_gen, 1)},
            "roofline": roofline, "knn_on_this_map": knn_grown, "cpu_baseline": cpu, "pose_error_vs_truth_m": err,
            "drift": {"metres_driven__position_error_m__its_vertical_part_m": err_curve,
@@ -1695,7 +1813,7 @@ def bench_localize(args, torch, local_rank):
                       "resident_map_one_spot_pool": cases["resident_one_spot"],
                       "local_200k_map": cases["local_200k"], "local_map_key_frames_used": nk_used, "merge_candidates_batched": merge},
            "roofline": head["roofline"], "cpu_baseline": cpu, "pose_error_vs_truth_m": head["pos_err_m_max"]}
-    print(json.dumps(out))
+    emit(out, "localize")
 
 
 def dry_run(args, dist, world, rank, local_rank):
@@ -1878,8 +1996,10 @@ def bench_merge(args, torch, dist, world, rank, local_rank, dev):
             waves = n_query / L / 4.0
             issue_us = waves * KNN_VALU_PER_WAVE_STATIC / (N_SIMD * CLOCK_GHZ * 1e3 / 4.0)
             dev_us = (kt["downsample_us"] + kt["knn_us"] + kt["linearize_us"] + kt["step_us"]) / len(sj)
-            roofline = {"bound": "valu", "kernel": "knn_batch_kernel<2, false> (one launch per local sub-map and pass, %d scans per launch)" % args.slots,
+            roofline = {"bound": "hbm", "limited_by": "latency / VALU issue", "kernel": "knn_batch_kernel<2, false> (one launch per local sub-map and pass, %d scans per launch)" % args.slots,
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac_basis": "algorithmic bytes (SURVEY 8d; ~36 candidates per query here, so close to what the sweep requests): no counting / PMC pass in this leg",
+                        "frac_algorithmic": round(ach / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": int(b_alg), "avg_launch_us": round(us, 2), "launches": L,
                         "candidates_per_query": round(cand_pts / max(n_query, 1), 1),
                         "valu": {"wave_instructions_per_wave": KNN_VALU_PER_WAVE_STATIC, "source": "static ISA count at the metric map's trip counts (an upper bound here: "
@@ -1943,7 +2063,7 @@ def bench_merge(args, torch, dist, world, rank, local_rank, dev):
                "latency": {"one_scan_at_a_time_ms": round(1e3 * float(np.median(lat)), 4),
                            "host_synchronised_collectives": coll[0], "collective_avg_us": round(coll[1] / coll[0], 2) if coll[0] else None},
                "roofline": roofline, "cpu_baseline": cpu, "pose_error_vs_truth_m": err}
-        print(json.dumps(out))
+        emit(out, "merge")
     if dist is not None:
         dist.destroy_process_group()
 

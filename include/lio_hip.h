@@ -48,6 +48,18 @@ const char* lio_last_error(void);
  * leaves its rounds in flight sharing hardware queues */
 const char* lio_last_warning(void);
 int lio_device_count(void);
+/* The ABI revision this header describes; lio_abi_version() returns the revision the loaded library was built from.  A caller built against an
+ * older header can keep running as long as it checks that the library's revision is >= its own: revisions only APPEND (struct tails, flag bits,
+ * entry points).  History: 4 = round 4 (lio_batch_times grew by insert_us / insert_launches / pad: a caller that allocates the round-3 struct and
+ * calls a revision-4 library is written past -- rebuild, or check the revision and allocate sizeof(lio_batch_times) of THIS header;
+ * lio_timings.n_added may be -1 = "insert still in flight, not read back"; lio_engine_timings may return a deferred LIO_E_CAPACITY);
+ * 5 = round 5 (LIO_JOB_HOST_RAW, lio_pinned_alloc / lio_pinned_free, lio_abi_version itself). */
+#define LIO_ABI_VERSION 5
+int lio_abi_version(void);
+/* page-locked host memory for clouds handed over with LIO_JOB_HOST_RAW (or lio_scan_upload): copies from it run at the link's rate and
+ * overlap with kernels; NULL on failure.  Any hipHostMalloc'ed / hipHostRegister'ed range serves as well. */
+void* lio_pinned_alloc(uint64_t bytes);
+void lio_pinned_free(void* p);
 /* bytes of HBM currently held by a map / scan handle (capacity planning on the 288 GB part) */
 uint64_t lio_map_bytes(const lio_map*);
 
@@ -378,7 +390,10 @@ int lio_engine_joint_register_device(lio_engine* e, const void* d_raw_body_xyzi,
  * sensors / sequences, relocalisation candidates, map-merge alignments). */
 #define LIO_JOB_KEEP_CACHE 1u
 #define LIO_JOB_IDLE 2u         /* lio_batch_sequences_step: the session of this job has no scan this round (rc = 0, nothing else is looked at) */
-#define LIO_JOB_FLAGS_KNOWN 3u  /* every other bit must be zero: a job with unknown bits is rejected (rc = LIO_E_INVALID), so that an uninitialised
+#define LIO_JOB_HOST_RAW 4u     /* lio_batch_process / lio_engines_process_batch: d_raw points to HOST memory (pinned for full PCIe rate: lio_pinned_alloc);
+                                   the library copies the cloud to HBM on the round's stream, overlapped with the other rounds in flight -- the copy
+                                   the reference's boundary starts with (slam/src/py_utils.cpp:149-181, slam_wrapper.cpp:64-84).  Appended in round 5 */
+#define LIO_JOB_FLAGS_KNOWN 7u  /* every other bit must be zero: a job with unknown bits is rejected (rc = LIO_E_INVALID), so that an uninitialised
                                    word cannot silently pick a behaviour */
 typedef struct lio_scan_job {
     const void* d_raw;          /* device pointer, XYZI float4 */

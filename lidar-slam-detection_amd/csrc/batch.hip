@@ -55,6 +55,7 @@ struct Group {
     lio_batch_result* h_res = nullptr;   // pinned, mapped
     lio_batch_result* h_res_dev = nullptr;
     std::vector<int> job_of_slot;
+    float4* d_rawbuf = nullptr;          // LIO_JOB_HOST_RAW: the round's clouds copied from host memory, [slot][max_raw]; allocated with the first such job
     // sequence mode: the slots' own maps as the kernels see them (part of the uploaded block), the insert half's records (device + pinned copy)
     MapRef* d_maps = nullptr;
     MapRef* h_maps = nullptr;
@@ -131,6 +132,7 @@ void group_free(Group& g) {
     for (int k = 0; k < 5; k++)
         if (g.exec[k]) hipGraphExecDestroy(g.exec[k]);
     if (g.d_block) hipFree(g.d_block);
+    if (g.d_rawbuf) hipFree(g.d_rawbuf);
     if (g.h_block) hipHostFree(g.h_block);
     if (g.d_seq) hipFree(g.d_seq);
     if (g.h_seq) hipHostFree(g.h_seq);
@@ -142,6 +144,28 @@ void group_free(Group& g) {
                 for (int i = 0; i < BatchTimer::kPool; i++) { hipEventDestroy(g.bt->ev[c][i][0]); hipEventDestroy(g.bt->ev[c][i][1]); }
         delete g.bt;
     }
+}
+
+// LIO_JOB_HOST_RAW: the job's cloud lives in HOST memory (pinned: lio_pinned_alloc, or any hipHostMalloc / hipHostRegister'ed range; pageable memory
+// works through the runtime's staging, slower).  It is copied into the slot's row of the group's raw ring on the round's stream, ahead of the
+// round's kernels: with several rounds in flight the copy of one round runs beside the kernels of the others (the copy engine and the CUs are
+// separate; py_utils.cpp:149-181 + slam_wrapper.cpp:64-84 are this copy in the reference).  Returns the device address the chain reads.
+const float4* stage_host_raw(lio_batch* b, Group& g, int slot, const lio_scan_job& job, int* rc) {
+    *rc = LIO_OK;
+    if (!g.d_rawbuf) {
+        if (hipMalloc(reinterpret_cast<void**>(&g.d_rawbuf), sizeof(float4) * (size_t)b->max_raw * (size_t)b->n_slots) != hipSuccess) {
+            set_error("lio_batch: no memory for the raw ring of LIO_JOB_HOST_RAW jobs (%d x %u points)", b->n_slots, b->max_raw);
+            *rc = LIO_E_DEVICE;
+            return nullptr;
+        }
+    }
+    float4* dst = g.d_rawbuf + (size_t)slot * b->max_raw;
+    if (hipMemcpyAsync(dst, job.d_raw, sizeof(float4) * (size_t)job.n_raw, hipMemcpyHostToDevice, g.stream) != hipSuccess) {
+        set_error("lio_batch: copy of a LIO_JOB_HOST_RAW cloud failed: %s", hipGetErrorString(hipGetLastError()));
+        *rc = LIO_E_DEVICE;
+        return nullptr;
+    }
+    return dst;
 }
 
 // one round: jobs[first .. first + n) into the slots of g, everything enqueued on g.stream
@@ -160,12 +184,18 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
         g.job_of_slot[s] = first + s;
         job.rc = LIO_E_INVALID;
         job.n_ds = job.n_pass = job.n_knn_pass = 0;
+        // (unknown bits first: a garbage flags word must be rejected, not read as IDLE)
+        if (job.flags & ~LIO_JOB_FLAGS_KNOWN) { set_error("lio_scan_job.flags = 0x%x: unknown bits (a job array that was not zero-initialised?)", job.flags); continue; }
         if (job.flags & LIO_JOB_IDLE) { job.rc = 0; g.job_of_slot[s] = -1; continue; }  // (a session without a scan, sequence mode's marker: nothing to do here either)
         if (!job.state_in || !job.cov_in || (!job.d_raw && job.n_raw)) continue;
-        if (job.flags & ~LIO_JOB_FLAGS_KNOWN) { set_error("lio_scan_job.flags = 0x%x: unknown bits (a job array that was not zero-initialised?)", job.flags); continue; }
         if (job.n_raw > b->max_raw) { set_error("scan of %u points exceeds max_raw %u", job.n_raw, b->max_raw); job.rc = LIO_E_CAPACITY; continue; }
         if (job.n_raw == 0) { job.rc = 2; continue; }  // "FastLio undistort points is empty"
         d.raw = static_cast<const float4*>(job.d_raw);
+        if (job.flags & LIO_JOB_HOST_RAW) {
+            int src = LIO_OK;
+            d.raw = stage_host_raw(b, g, s, job, &src);
+            if (src != LIO_OK) { job.rc = src; continue; }
+        }
         d.n_raw = job.n_raw;
         d.nblocks = (job.n_raw + 2047u) / 2048u;
         d.active = 1;
@@ -653,10 +683,11 @@ int lio_batch_sequences_step(lio_batch* b, lio_scan_job* jobs, int n_jobs, doubl
             g.seq_path[s] = -1000;
             lio_scan_job& job = jobs[gi * B + s];
             job.n_ds = job.n_pass = job.n_knn_pass = 0;
-            if (job.flags & LIO_JOB_IDLE) { job.rc = 0; g.job_of_slot[s] = -1; continue; }
             job.rc = LIO_E_INVALID;
-            if (!job.state_in || !job.cov_in || (!job.d_raw && job.n_raw)) { note(job.rc); continue; }
             if (job.flags & ~LIO_JOB_FLAGS_KNOWN) { set_error("lio_scan_job.flags = 0x%x: unknown bits (a job array that was not zero-initialised?)", job.flags); note(job.rc); continue; }
+            if (job.flags & LIO_JOB_IDLE) { job.rc = 0; g.job_of_slot[s] = -1; continue; }
+            if (!job.state_in || !job.cov_in || (!job.d_raw && job.n_raw)) { note(job.rc); continue; }
+            if (job.flags & LIO_JOB_HOST_RAW) { set_error("lio_batch_sequences_step: LIO_JOB_HOST_RAW is a static-batch flag (a session's sweeps arrive through lio_fastlio_pcl_stage / _commit)"); note(job.rc); continue; }
             if (job.n_raw > b->max_raw) { set_error("scan of %u points exceeds max_raw %u", job.n_raw, b->max_raw); job.rc = LIO_E_CAPACITY; note(job.rc); continue; }
             lio_engine* e = g.eng[s];
             int ekf_inited = 0;
@@ -758,7 +789,18 @@ int lio_batch_sequences_step(lio_batch* b, lio_scan_job* jobs, int n_jobs, doubl
             }
             if (rc == LIO_OK && hipGraphLaunch(g.exec[passes], g.stream) != hipSuccess) { set_error("sequence batch: hipGraphLaunch: %s", hipGetErrorString(hipGetLastError())); rc = LIO_E_DEVICE; }
         }
-        if (rc != LIO_OK) { for (int k = 0; k <= gi; k++) hipStreamSynchronize(b->groups[k].stream); return rc; }
+        if (rc != LIO_OK) {
+            // nothing of this call is collected: every job that was waiting for a round (this group's and the earlier groups' slots) and every job of
+            // the groups not visited yet reports the failure -- a caller (lio_batch_fastlio_main) must not read a stale or value-initialised rc as success
+            for (int k = 0; k <= gi; k++) (void)hipStreamSynchronize(b->groups[k].stream);
+            for (int k = 0; k < G; k++)
+                for (int s2 = 0; s2 < B; s2++) {
+                    lio_scan_job& j2 = jobs[k * B + s2];
+                    const bool in_round = k <= gi && b->groups[k].seq_path[s2] == 11;
+                    if (k > gi || in_round) j2.rc = (j2.flags & LIO_JOB_IDLE) && !(j2.flags & ~LIO_JOB_FLAGS_KNOWN) ? 0 : LIO_E_DEVICE;
+                }
+            return rc;
+        }
         b->n_rounds++;
     }
     // ---- collect ----

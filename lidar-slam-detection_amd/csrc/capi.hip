@@ -145,6 +145,18 @@ int lio_device_count(void) {
     return n;
 }
 
+int lio_abi_version(void) { return LIO_ABI_VERSION; }
+
+void* lio_pinned_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { set_error("lio_pinned_alloc: %llu bytes of page-locked memory not available", (unsigned long long)bytes); return nullptr; }
+    return p;
+}
+
+void lio_pinned_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 uint64_t lio_map_bytes(const lio_map* m) { return m ? m->bytes : 0; }
 
 lio_map* lio_map_create(int device, float resolution, uint64_t max_points, uint64_t max_voxels, int stencil) {

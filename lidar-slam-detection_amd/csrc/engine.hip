@@ -970,7 +970,9 @@ int lio_engines_process_batch(lio_engine** engines, int n_engines, lio_scan_job*
                 state_from_array(job.state_in, e->kf.x);
                 memcpy(e->kf.P, job.cov_in, sizeof(double) * 529);
                 rc = (job.flags & LIO_JOB_KEEP_CACHE) ? LIO_OK : scan_forget_cache(e->scan);  // an independent scan: no neighbours of the engine's previous job
-                if (rc == LIO_OK) rc = lio_engine_process_scan_device(e, job.d_raw, job.n_raw, job.lidar_beg_time);
+                if (rc == LIO_OK)
+                    rc = (job.flags & LIO_JOB_HOST_RAW) ? lio_engine_process_scan(e, static_cast<const float*>(job.d_raw), job.n_raw, job.lidar_beg_time)
+                                                        : lio_engine_process_scan_device(e, job.d_raw, job.n_raw, job.lidar_beg_time);
             }
             job.rc = rc;
             job.n_ds = e->tm.n_ds;

@@ -742,6 +742,7 @@ __device__ __forceinline__ float monster_component_sum(const float4* __restrict_
                     const float rn = rintf(rr);
                     worst = fmaxf(worst, fabsf(rr));
                     tie |= fabsf(rr - rn) == 0.5f;
+                    tie |= !(rr == rr);  // a NaN addend (fmaxf keeps `worst`, the clamp would read it as -2^21): the step takes the plain loop, which yields PCL's NaN
                     loc += (int)fminf(fmaxf(rn, -2097152.f), 2097152.f);  // (clamped: a step with such an addend is rejected below; 512 x 2^21 + 2^24 < 2^31)
                     lmin = min(lmin, loc);
                     lmax = max(lmax, loc);

@@ -22,6 +22,7 @@ SYMBOLS = [
     "lio_last_warning",
     "lio_last_error", "lio_device_count", "lio_map_bytes",
     "lio_map_create", "lio_map_destroy", "lio_map_set_lru", "lio_map_lru_stats", "lio_map_pool_stats", "lio_map_set_stencil", "lio_map_insert", "lio_map_insert_device", "lio_map_stats",
+    "lio_abi_version", "lio_pinned_alloc", "lio_pinned_free",
     "lio_map_dump", "lio_map_knn", "lio_map_knn_candidates", "lio_map_knn_touched",
     "lio_scan_create", "lio_scan_destroy", "lio_scan_reset", "lio_scan_upload", "lio_scan_set_device", "lio_scan_undistort_delta", "lio_scan_undistort_poses", "lio_scan_download_raw", "lio_scan_voxel_downsample", "lio_scan_voxel_downsample_batch", "lio_scan_set_ds",
     "lio_scan_num_ds", "lio_scan_download_ds", "lio_scan_download_world", "lio_scan_download_match",
@@ -129,6 +130,9 @@ def lib():
     sig("lio_last_error", C.c_char_p)
     sig("lio_last_warning", C.c_char_p)
     sig("lio_device_count", cint)
+    sig("lio_abi_version", cint)
+    sig("lio_pinned_alloc", vp, u64)
+    sig("lio_pinned_free", None, vp)
     sig("lio_map_bytes", u64, vp)
     sig("lio_map_create", vp, cint, flt, u64, u64, cint)
     sig("lio_map_destroy", None, vp)

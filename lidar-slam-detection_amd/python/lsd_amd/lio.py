@@ -822,6 +822,30 @@ class Batch:
 
 JOB_KEEP_CACHE = 1  # LIO_JOB_KEEP_CACHE of include/lio_hip.h
 JOB_IDLE = 2        # LIO_JOB_IDLE: the session has no scan this round (lio_batch_sequences_step)
+JOB_HOST_RAW = 4    # LIO_JOB_HOST_RAW: "dptr" is a HOST address (pinned: PinnedCloud); the library copies it to HBM on the round's stream
+
+
+class PinnedCloud:
+    """a cloud in page-locked host memory (lio_pinned_alloc): .array is an (n, 4) float32 view to fill, .ptr the address for a JOB_HOST_RAW job"""
+
+    def __init__(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 4)
+        self.n = len(pts)
+        self.nbytes = max(pts.nbytes, 16)
+        self.ptr = lib().lio_pinned_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError((lib().lio_last_error() or b'').decode())
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_float)), shape=(max(self.n, 1), 4))[: self.n]
+        self.array[...] = pts
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self.array = None
+                lib().lio_pinned_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
 
 
 class SequenceBatch:

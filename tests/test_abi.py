@@ -30,6 +30,16 @@ def test_every_declared_symbol_is_exported():
     assert sorted(capi.SYMBOLS) == names, set(names) ^ set(capi.SYMBOLS)
 
 
+def test_abi_revision_of_the_library_is_the_headers():
+    """revisions only append (include/lio_hip.h: LIO_ABI_VERSION); a library older than the header a caller was built with must be detectable"""
+    from lsd_amd import capi
+
+    hdr = int(re.search(r"#define LIO_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert capi.lib().lio_abi_version() == hdr >= 5
+    known = int(re.search(r"#define LIO_JOB_FLAGS_KNOWN (\d+)u", open(HEADER).read()).group(1))
+    assert known == 1 | 2 | 4  # KEEP_CACHE | IDLE | HOST_RAW: every bit of the mask is a documented flag
+
+
 def test_struct_layouts_match_header():
     from lsd_amd import capi
 

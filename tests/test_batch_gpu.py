@@ -198,3 +198,41 @@ def test_batch_sparse_scans_hand_over_to_the_host_filter(oracle_mod):
         assert res[0]["n_pass"] == len(lo) and res[0]["n_knn_pass"] == sum(p["knn"] for p in lo), (n_az, n_beams, res[0], len(lo))
         assert np.abs(res[0]["state"] - o.get_state()).max() < 1e-8
         del b
+
+
+def test_host_raw_jobs_give_the_bits_of_resident_clouds():
+    """LIO_JOB_HOST_RAW (round 5, the upload-included leg of bench.py): the same jobs with their clouds in pinned host memory -- the library copies a
+    round's clouds to HBM on the round's stream -- return the states of the jobs whose clouds were resident, bit for bit, through the batched engine
+    and through lio_engines_process_batch; a garbage flags word is rejected (never read as IDLE)"""
+    _dev()
+    from lsd_amd import capi, lio
+
+    assert capi.lib().lio_abi_version() >= 5
+    scene = scenes.config_scene()
+    mp = scene.sample_surface(400_000, seed=2, sigma=0.01)
+    the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=1_000_000)
+    the_map.add(mp)
+    jobs, meta = _jobs(scene, range(3100, 3111), [])
+    jobs[4]["n"] = 0
+    pinned = [lio.PinnedCloud(sc["raw"]) for sc in meta]
+    hjobs = [dict(j, dptr=pc.ptr, flags=lio.JOB_HOST_RAW) for j, pc in zip(jobs, pinned)]
+    b = lio.Batch(the_map, n_slots=4, n_groups=2)
+    rc0, res0 = b.process(jobs)
+    rc1, res1 = b.process(hjobs)
+    rc2, res2 = b.process(hjobs)  # (the raw rings exist now: the steady state)
+    assert rc0 == rc1 == rc2 == 0
+    for k, (a, c, d) in enumerate(zip(res0, res1, res2)):
+        assert (a["rc"], a["n_ds"], a["n_pass"], a["n_knn_pass"]) == (c["rc"], c["n_ds"], c["n_pass"], c["n_knn_pass"]) == (d["rc"], d["n_ds"], d["n_pass"], d["n_knn_pass"]), k
+        if a["rc"] == 3:
+            assert np.array_equal(a["state"], c["state"]) and np.array_equal(a["state"], d["state"]), k
+    assert sum(r["rc"] == 3 for r in res0) == 10 and res0[4]["rc"] == 2
+    eng = lio.Engine(max_raw=1 << 18, max_ds=100000, shared_map=the_map)
+    eng.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+    rc3, res3 = lio.process_batch([eng], hjobs)
+    assert rc3 == 0
+    for k, (a, c) in enumerate(zip(res0, res3)):
+        assert a["rc"] == c["rc"] and (a["rc"] != 3 or np.array_equal(a["state"], c["state"])), k
+    # a flags word with an unknown bit AND the idle bit: rejected, not skipped
+    bad = [dict(jobs[0], flags=0x42)]
+    rc4, res4 = b.process(bad)
+    assert res4[0]["rc"] == capi.LIO_E_INVALID

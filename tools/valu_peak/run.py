@@ -1,0 +1,19 @@
+#!/usr/bin/env python
+"""Print the chip's measured VALU issue rate (tools/valu_peak/valu_peak.hip) for every instruction mix at 1..8 waves per SIMD, as JSON."""
+import ctypes as C
+import json
+import os
+
+L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvalu_peak.so"))
+L.valu_peak_wave_insts_per_s.restype = C.c_double
+L.valu_peak_wave_insts_per_s.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+cus, mhz = C.c_int(0), C.c_int(0)
+names = {0: "v_add_u32", 1: "add/min/add/add_dpp", 2: "v_fma_f32", 3: "v_add_f64"}
+out = {}
+for mix in range(4):
+    row = {}
+    for w in (1, 2, 4, 6, 8):
+        r = max(L.valu_peak_wave_insts_per_s(0, w, mix, C.byref(cus), C.byref(mhz)) for _ in range(2))
+        row[str(w)] = {"wave_insts_per_s": r, "cycles_per_wave_inst_per_simd_at_reported_clock": cus.value * 4 * mhz.value * 1e6 / r if r > 0 else None}
+    out[names[mix]] = row
+print(json.dumps({"cus": cus.value, "clock_mhz": mhz.value, "rates": out}, indent=1))
