@@ -1823,7 +1823,10 @@ def dry_run(args, dist, world, rank, local_rank):
 
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    info = {"rank": rank, "local_rank": local_rank}
+    # what the real run binds and runs: cuda:<LOCAL_RANK> (torch.cuda.set_device(local_rank) in main), the secondary legs / CPU baselines / parity child on
+    # a single-GPU run's rank 0 only (with N > 1 ranks no rank waits for them: nothing to time out at a barrier), one stdout line from rank 0
+    info = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}", "prints_the_line": rank == 0,
+            "runs_secondary_legs": bool(rank == 0 and world == 1 and args.secondary and args.config == "metric")}
     if args.config == "merge":
         plan = merge_plan(world, rank, seed=args.seed, n_keyframes=max(args.scan_pool, 16))
         info["sub_maps"] = plan["mine"]

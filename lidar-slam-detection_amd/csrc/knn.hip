@@ -455,29 +455,31 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                 for (int u = 0; u < kU; u++) p[u] = pool[i0 < cnt4[u] ? ptr4[u] + i0 : ptr_first];
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
-                    if (i0 >= cnt4[u]) continue;
+                    // branch-lean form: a lane without a candidate (beyond the voxel's count, or out of range) offers d2 = +inf bits, which every
+                    // comparison below rejects; ONE wave-uniform branch (no lane of the wave takes its candidate) skips the insertion network --
+                    // instead of three nested divergent branches per candidate (each an s_and_saveexec / s_cbranch_execz / s_or triple)
+                    const bool have = i0 < cnt4[u];
                     const float dx = p[u].x - pw.x, dy = p[u].y - pw.y, dz = p[u].z - pw.z;
                     const float d2 = dx * dx + (dy * dy + dz * dz);  // ivox3d_node.hpp:12-15: Vector3f::squaredNorm() = Eigen's unrolled tree x0 + (x1 + x2)
-                    if (d2 < 5.0f) {
-                        inrange++;
-                        const uint32_t kd = __float_as_uint(d2);  // d2 >= 0: float order == unsigned order of the bits
-                        if (kd < d4) {
-                            ins = true;
-                            const uint32_t id = ptr4[u] + i0;
-                            const bool c0 = kd < d0, c1 = kd < d1, c2 = kd < dd2, c3 = kd < d3;
-                            i4d = c3 ? i3d : id;
-                            i3d = c2 ? i2d : (c3 ? id : i3d);
-                            i2d = c1 ? i1d : (c2 ? id : i2d);
-                            i1d = c0 ? i0d : (c1 ? id : i1d);
-                            i0d = c0 ? id : i0d;
-                            d4 = med3_u32(d3, d4, kd);  // the list is sorted, so slot i becomes the median of (e_{i-1}, e_i, new)
-                            d3 = med3_u32(dd2, d3, kd);
-                            dd2 = med3_u32(d1, dd2, kd);
-                            d1 = med3_u32(d0, d1, kd);
-                            d0 = min(d0, kd);
-                        } else {
-                            drop_tie |= kd == d4;  // a candidate as far as this lane's fifth is not kept: see the merge
-                        }
+                    const bool in = have && d2 < 5.0f;
+                    inrange += in ? 1u : 0u;
+                    const uint32_t kd = in ? __float_as_uint(d2) : 0xFFFFFFFFu;  // d2 >= 0: float order == unsigned order of the bits
+                    const bool take = kd < d4;
+                    drop_tie |= in && !take && kd == d4;  // a candidate as far as this lane's fifth is not kept: see the merge
+                    if (__ballot(take)) {
+                        ins |= take;
+                        const uint32_t id = ptr4[u] + i0;
+                        const bool c0 = kd < d0, c1 = kd < d1, c2 = kd < dd2, c3 = kd < d3;
+                        i4d = c3 ? i3d : (take ? id : i4d);
+                        i3d = c2 ? i2d : (c3 ? id : i3d);
+                        i2d = c1 ? i1d : (c2 ? id : i2d);
+                        i1d = c0 ? i0d : (c1 ? id : i1d);
+                        i0d = c0 ? id : i0d;
+                        d4 = med3_u32(d3, d4, kd);  // the list is sorted, so slot i becomes the median of (e_{i-1}, e_i, new); kd >= d4 leaves it as it is
+                        d3 = med3_u32(dd2, d3, kd);
+                        dd2 = med3_u32(d1, dd2, kd);
+                        d1 = med3_u32(d0, d1, kd);
+                        d0 = min(d0, kd);
                     }
                 }
             }

@@ -250,7 +250,7 @@ def test_batched_joint_registration_degenerate_scene_falls_back_to_the_host_path
         assert r["rc"] == 3 and np.array_equal(r["state"], s)
 
 
-@pytest.mark.parametrize("config,world", [("merge", 2), ("merge", 4), ("metric", 2)])
+@pytest.mark.parametrize("config,world", [("merge", 2), ("merge", 4), ("metric", 2), ("metric", 8), ("merge", 8)])
 def test_bench_multi_gpu_launch_dry_run(config, world):
     """`bench.py --gpus N [--config merge] --dry-run` under torch.distributed.run, as the driver launches it, on the CPU: rendezvous, the sharding
     of sub-maps / scans over the ranks, the RCCL unique id made by rank 0 (librccl loaded lazily, no device needed) and shipped to the others"""
@@ -266,6 +266,10 @@ def test_bench_multi_gpu_launch_dry_run(config, world):
     assert len(line) == 1  # rank 0 alone prints
     j = json.loads(line[0])
     assert j["dry_run"] and j["n_gpus"] == world and j["rccl_unique_id_exchanged"] is True and len(j["ranks"]) == world
+    # the first 8-GPU lease cannot be rehearsed: one process per GPU, rank r of the node on cuda:r, rank 0 alone prints, no rank runs the single-GPU
+    # secondary legs (nobody waits at a barrier for a CPU baseline)
+    assert [rk["rank"] for rk in j["ranks"]] == list(range(world)) and all(rk["device"] == f"cuda:{rk['local_rank']}" == f"cuda:{rk['rank']}" for rk in j["ranks"])
+    assert [rk["prints_the_line"] for rk in j["ranks"]] == [True] + [False] * (world - 1) and not any(rk["runs_secondary_legs"] for rk in j["ranks"])
     if config == "merge":
         owned = sorted(k for rk in j["ranks"] for k in rk["sub_maps"])
         assert owned == list(range(8)) and all(len(rk["sub_maps"]) == 8 // world for rk in j["ranks"])

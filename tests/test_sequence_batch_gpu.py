@@ -45,8 +45,8 @@ def _next_prior(res, P_add=1e-2):
 
 
 @pytest.mark.parametrize("lru", [False, True])
-def test_sessions_in_a_batch_equal_sessions_on_their_own(scene, lru):
-    from lsd_amd import capi, lio
+def test_sessions_in_a_batch_equal_sessions_on_their_own(scene, lru, oracle_mod):
+    from lsd_amd import capi, lio, synth
 
     if capi.lib().lio_device_count() < 1:
         pytest.fail("no HIP device")
@@ -136,6 +136,27 @@ def test_sessions_in_a_batch_equal_sessions_on_their_own(scene, lru):
         assert sum(x["evicted"] for x in solo) > 500
     # the sessions really moved and mapped
     assert all(x["npts"] > 5000 for x in solo)
+    # ---- the ORACLE on the same sessions (the batched rounds were held against per-session HIP engines only): oracle.Lio.process_scan --
+    # VoxelGrid, iVox kNN, esti_plane, iterated ESKF, map_incremental with the LRU list, the stencil switch -- fed the scans and the priors the batch
+    # was fed.  Return codes and downsampled sizes equal; poses inside the float tolerance the engine-level oracle tests use (tests/test_lru_gpu.py:
+    # the reductions' order differs in the last bits); the maps hold the same points
+    for s in range(3):
+        o = oracle_mod.Lio(res=0.5, stencil=75, capacity=cap_lru if lru else (1 << 40), max_distance=maxd_lru if lru else 100.0, threads=8)
+        st, P = plans[s][1].copy(), P0.copy()
+        worst_p, worst_r = 0.0, 0.0
+        for k, sc in enumerate(plans[s][0]):
+            o.set_state(st)
+            o.set_cov(P)
+            rc_o = o.process_scan(sc["raw"][: 0 if k == 9 else sc["n"]], sc["t"])
+            c = got[s][k]
+            assert rc_o == c["rc"], (s, k, rc_o, c["rc"])
+            if rc_o == 3:
+                so = o.get_state()
+                worst_p = max(worst_p, float(np.linalg.norm(so[:3] - c["state"][:3])))
+                worst_r = max(worst_r, float(synth.quat_angle(so[3:7], c["state"][3:7])))
+                st, P = _next_prior(dict(state=c["state"], cov=c["cov"]))  # (the batch's own posterior: both sides start every scan from the same prior)
+        assert worst_p < 1e-9 and worst_r < 1e-9, (s, worst_p, worst_r)
+        assert o.map_num_points == solo[s]["npts"], (s, o.map_num_points, solo[s]["npts"])
     b.close()
 
 
