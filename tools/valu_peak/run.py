@@ -8,11 +8,13 @@ L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvalu_pea
 L.valu_peak_wave_insts_per_s.restype = C.c_double
 L.valu_peak_wave_insts_per_s.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 cus, mhz = C.c_int(0), C.c_int(0)
-names = {0: "v_add_u32", 1: "add/min/add/add_dpp", 2: "v_fma_f32", 3: "v_add_f64"}
+names = {0: "v_add_u32", 1: "add/min/add/add_dpp", 2: "v_fma_f32", 3: "v_add_f64", 4: "v_add_u32_dpp row_ror", 5: "v_min_u32", 6: "v_min_u32_dpp row_ror",
+         7: "v_cndmask_b32 vcc", 8: "v_mov_b32_dpp quad_perm", 9: "v_med3_u32", 10: "v_mov_b32", 11: "v_cmp_lt_u32 vcc", 12: "v_mul_f32", 13: "v_add_u32_dpp row_shr",
+         14: "v_add_u32_dpp quad_perm", 15: "v_add_u32_dpp row_bcast15", 16: "v_add3_u32"}
 out = {}
-for mix in range(4):
+for mix in sorted(names):
     row = {}
-    for w in (1, 2, 4, 6, 8):
+    for w in ((1, 2, 4, 6, 8) if mix < 4 else (1, 6)):
         r = max(L.valu_peak_wave_insts_per_s(0, w, mix, C.byref(cus), C.byref(mhz)) for _ in range(2))
         row[str(w)] = {"wave_insts_per_s": r, "cycles_per_wave_inst_per_simd_at_reported_clock": cus.value * 4 * mhz.value * 1e6 / r if r > 0 else None}
     out[names[mix]] = row

@@ -7,6 +7,8 @@
 // mix 1: v_add_u32 / v_min_u32 / v_add_u32 / v_add_u32_dpp row_ror:1   (the kNN merge's diet: integer compares + DPP row rotations)
 // mix 2: v_fma_f32 only            (the guide's 2-cycle row)
 // mix 3: v_add_f64 only            (the transforms' type)
+// mix 4..16: ONE instruction form each (valu_one below): add_dpp row_ror, min, min_dpp, cndmask, mov_dpp quad_perm, med3, mov, cmp, mul_f32,
+//            add_dpp row_shr / quad_perm / row_bcast, add3 -- what the kNN merge network's instructions cost one by one
 // Eight independent register chains per wave, 256 instructions per loop body (the loop's scalar bookkeeping is < 2 % of the issue slots).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,6 +16,46 @@
 #define REP4(x) x x x x
 #define REP16(x) REP4(REP4(x))
 #define REP32(x) REP16(x) REP16(x)
+
+// one instruction form repeated over eight independent chains: T(d, o) is the text with d = the chain's register, o = another chain's, %8 = a constant
+#define CHAINS8(OPA, OPB, OPC, OPD, OPE, OPF, OPG, OPH) OPA "\n" OPB "\n" OPC "\n" OPD "\n" OPE "\n" OPF "\n" OPG "\n" OPH "\n"
+template <int KIND>
+__global__ __launch_bounds__(256) void valu_one(uint32_t* sink, uint32_t iters, uint32_t seed) {
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3u, a2 = a0 * 5u, a3 = a0 * 7u, a4 = a0 * 11u, a5 = a0 * 13u, a6 = a0 * 17u, a7 = a0 * 19u;
+    const uint32_t k = seed | 1u;
+#define BODY(T) REP32(asm volatile(CHAINS8(T("%0", "%4"), T("%1", "%5"), T("%2", "%6"), T("%3", "%7"), T("%4", "%0"), T("%5", "%1"), T("%6", "%2"), T("%7", "%3")) \
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");)
+#define T4(d, o) "v_add_u32_dpp " d ", " d ", " o " row_ror:1 row_mask:0xf bank_mask:0xf"
+#define T5(d, o) "v_min_u32 " d ", " d ", " o
+#define T6(d, o) "v_min_u32_dpp " d ", " d ", " o " row_ror:1 row_mask:0xf bank_mask:0xf"
+#define T7(d, o) "v_cndmask_b32 " d ", " d ", " o ", vcc"
+#define T8(d, o) "v_mov_b32_dpp " d ", " o " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define T9(d, o) "v_med3_u32 " d ", " d ", " o ", %8"
+#define T10(d, o) "v_mov_b32 " d ", " o
+#define T11(d, o) "v_cmp_lt_u32 vcc, " d ", " o
+#define T12(d, o) "v_mul_f32 " d ", " d ", " o
+#define T13(d, o) "v_add_u32_dpp " d ", " d ", " o " row_shr:1 row_mask:0xf bank_mask:0xf"
+#define T14(d, o) "v_add_u32_dpp " d ", " d ", " o " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define T15(d, o) "v_add_u32_dpp " d ", " d ", " o " row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define T16(d, o) "v_add3_u32 " d ", " d ", " o ", %8"
+    for (uint32_t i = 0; i < iters; i++) {
+        if (KIND == 4) { BODY(T4) }
+        if (KIND == 5) { BODY(T5) }
+        if (KIND == 6) { BODY(T6) }
+        if (KIND == 7) { BODY(T7) }
+        if (KIND == 8) { BODY(T8) }
+        if (KIND == 9) { BODY(T9) }
+        if (KIND == 10) { BODY(T10) }
+        if (KIND == 11) { BODY(T11) }
+        if (KIND == 12) { BODY(T12) }
+        if (KIND == 13) { BODY(T13) }
+        if (KIND == 14) { BODY(T14) }
+        if (KIND == 15) { BODY(T15) }
+        if (KIND == 16) { BODY(T16) }
+    }
+    a0 += a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (a0 == 0x12345678u) sink[0] = a0;
+}
 
 template <int MIX>
 __global__ __launch_bounds__(256) void valu_spin(uint32_t* sink, uint32_t iters, uint32_t seed) {
@@ -80,6 +122,19 @@ double valu_peak_wave_insts_per_s(int device, int waves_per_simd, int mix, int* 
             case 1: valu_spin<1><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
             case 2: valu_spin<2><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
             case 3: valu_spin<3><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 4: valu_one<4><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 5: valu_one<5><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 6: valu_one<6><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 7: valu_one<7><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 8: valu_one<8><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 9: valu_one<9><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 10: valu_one<10><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 11: valu_one<11><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 12: valu_one<12><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 13: valu_one<13><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 14: valu_one<14><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 15: valu_one<15><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 16: valu_one<16><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
             default: valu_spin<0><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
         }
     };
