@@ -1599,6 +1599,7 @@ def bench_localize(args, torch, local_rank):
             s.voxel_downsample(leaf)
             n.align(s, guesses[w])
         errs, angs, its, nds, conv = [], [], [], [], 0
+        not_conv = []  # (job, LM iterations, |pose - truth|) of alignments that ended at max_iterations
         poses_single = []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -1610,6 +1611,8 @@ def bench_localize(args, torch, local_rank):
             poses_single.append(Ta)
             its.append(it + 1)
             conv += bool(cv)
+            if not cv and len(not_conv) < 8 and (i % len(pool), ) not in [(q[0] % len(pool), ) for q in not_conv]:
+                not_conv.append((i, it + 1, float(np.linalg.norm(Ta[:3, 3] - sc["T"][:3, 3]))))
             errs.append(float(np.linalg.norm(Ta[:3, 3] - sc["T"][:3, 3])))
             angs.append(float(np.arccos(np.clip((np.trace(Ta[:3, :3].T @ sc["T"][:3, :3]) - 1) / 2, -1, 1))))
         torch.cuda.synchronize()
@@ -1685,6 +1688,32 @@ def bench_localize(args, torch, local_rank):
                                     "evaluations_per_alignment": round(L / min(args.steps, 64), 2), "pairs_per_launch": round(kt["pairs"] / L, 1)}}
         if name == "local_200k":
             ref_inputs["target"] = cloud.cpu().numpy()
+        if not_conv and args.ref_scans > 0:
+            # whose failures are the alignments that end at max_iterations -- the reference's own NDT_CUDA (its kernels compiled for
+            # gfx950, oracle/_ref/libref_ndt_cuda.so) on the SAME target cloud, the same downsampled scans and the same guesses
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle as orc_nc
+                import ref_ndt_cuda as refn_nc
+
+                if refn_nc.available():
+                    reg_nc = refn_nc.NdtCudaRegistration(1.0, 7)
+                    reg_nc.set_target(cloud.cpu().numpy())
+                    rows_nc = []
+                    for (i_nc, it_nc, e_nc) in not_conv:
+                        sc_nc = pool[i_nc % len(pool)]
+                        reg_nc.set_source(orc_nc.voxel_downsample(sc_nc["raw"], leaf))
+                        Tr_nc, cv_nc, itr_nc = reg_nc.align(guesses[i_nc])
+                        rows_nc.append({"job": int(i_nc), "ours": {"lm_iterations": int(it_nc), "pos_err_m": round(e_nc, 4)},
+                                        "reference": {"converged": bool(cv_nc), "lm_iterations": int(itr_nc + 1),
+                                                      "pos_err_m": round(float(np.linalg.norm(Tr_nc[:3, 3] - sc_nc["T"][:3, 3])), 4)}})
+                    reg_nc.close()
+                    cases[name]["not_converged"] = {"alignments": rows_nc, "reference_converged": int(sum(r["reference"]["converged"] for r in rows_nc)),
+                                                    "checked": len(rows_nc),
+                                                    "what": "alignments of this case that ended at max_iterations (distinct scans, at most 8), and the reference's own "
+                                                            "fast_gicp::NDTCuda on the same target cloud, downsampled scan and guess"}
+            except Exception as ex:
+                cases[name]["not_converged"] = {"error": repr(ex)[-300:]}
         n.close()
     del dense
     # ---- the map-merge shape (overlap_merge.hpp:46-48,158-179): 64 new key frames x <= 3 candidate frames, every pair an independent alignment of the

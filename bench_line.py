@@ -100,6 +100,10 @@ def leg(c):
         s = c.get(name)
         if isinstance(s, dict):
             o[name] = _pick(s, ("ms_per_scan", "converged", "lm_iterations_avg", "target_points"))
+            nc = s.get("not_converged")
+            if isinstance(nc, dict) and "checked" in nc:
+                o[name]["not_converged_checked"] = nc["checked"]
+                o[name]["reference_converged_on_them"] = nc.get("reference_converged")
     p = c.get("parity")
     if isinstance(p, dict):
         o["parity"] = _pick(p, ("sessions_checked", "bit_identical_to_the_per_session_engine", "max_abs_state_difference"), 3)

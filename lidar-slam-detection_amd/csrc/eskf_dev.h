@@ -21,7 +21,7 @@
 #endif
 #if defined(__HIP__) && defined(LIO_STEP_TRACE)
 static __device__ unsigned long long g_ek_trace[64];
-static __device__ unsigned long long g_ek_last;
+static __device__ unsigned long long g_ek_last[2];  // per stamping wave of the step kernel (wave 0: the pass; wave 1: ek_step_prep beside the measurement head)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 // on the device a phase of the filter pass is run by ONE wave of the step kernel's workgroup (any one): loops stride over its 64 lanes, a phase
@@ -37,11 +37,12 @@ static __device__ unsigned long long g_ek_last;
 #ifdef LIO_STEP_TRACE  // diagnostic build only: cycle stamps of the filter pass's phases (workgroup 0, lane 0), see tools/experiments/step_trace.py
 #define EK_STAMP(k)                                                                          \
     do {                                                                                     \
-        if (threadIdx.x == 0 && blockIdx.x == 0) {                                           \
+        if ((threadIdx.x & 63u) == 0 && threadIdx.x < 128 && blockIdx.x == 0) {              \
             const unsigned long long now_ = __builtin_readcyclecounter();                    \
-            if ((k) > 0) g_ek_trace[(k)] += now_ - g_ek_last;                                \
-            else g_ek_trace[0] += 1;                                                         \
-            g_ek_last = now_;                                                                \
+            const int w_ = (int)(threadIdx.x >> 6);                                          \
+            if ((k) == 0) g_ek_trace[0] += 1;                                                \
+            else if ((k) != 10) g_ek_trace[(k)] += now_ - g_ek_last[w_];  /* (10: wave 1 enters the prep -- only sets its clock) */ \
+            g_ek_last[w_] = now_;                                                            \
         }                                                                                    \
     } while (0)
 #else
@@ -676,6 +677,7 @@ EK_FN void ek_step_prep(const EskfDev& c, EkWork& w) {
     EK_STAMP(13);
     EK_FOR(e, N * 6) { const int a = e / 6, col = e % 6; w.G[e] = w.P[a * N + col] / R; }
     EK_SYNC();
+    EK_STAMP(22);
 }
 
 EK_FN void ek_step_solve(EskfDev& c, EkWork& w) {

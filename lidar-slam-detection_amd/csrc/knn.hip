@@ -184,7 +184,7 @@ __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table
         bucket[k] = dmin[k] < b1 ? 0 : (dmin[k] < b2 ? 1 : 2);
 #pragma unroll
         for (int b = 0; b < 3; b++) mb[k][b] = group_ballot(hit && bucket[k] == b, lane);
-        total += group_sum32(cnt[k]);
+        total += cnt[k];  // (this LANE's share of the candidate statistic: the lanes' shares are summed once per workgroup at the end -- a group sum here was eight DPP adds per four queries for a diagnostic counter)
     }
     uint32_t nb[3] = {0, 0, 0};
 #pragma unroll
@@ -213,7 +213,7 @@ __device__ inline uint32_t probe_stencil_bucketed(const Slot* __restrict__ table
 }
 
 // probe the stencil of the group's query; on return the hit voxels are compacted in g (ptr, cnt) and
-// the total candidate count is returned.  All lanes of the wave must call this (ballots inside).
+// this lane's share of the candidate count is returned.  All lanes of the wave must call this (ballots inside).
 template <int KM>
 __device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_t mask, const StencilArgs& st, bool active, int kx, int ky,
                                          int kz, int gl, int lane, unsigned long long gmask, GroupLds& g, uint32_t& nhit_out) {
@@ -265,10 +265,7 @@ __device__ inline uint32_t probe_stencil(const Slot* __restrict__ table, uint32_
             g.v_cnt[at] = cnt;
         }
         nhit += __popc(m);
-        uint32_t sum = cnt;
-#pragma unroll
-        for (int off = kG / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kG);
-        total += sum;
+        total += cnt;  // (this lane's share: see probe_stencil_bucketed)
     }
     if (gl < kU) { g.v_ptr[nhit + gl] = 0; g.v_cnt[nhit + gl] = 0; }
     nhit_out = nhit;
@@ -292,8 +289,19 @@ __device__ inline uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
 // An upper bound of the squared distance of the query's fifth nearest candidate, from what the lanes hold so far: any lane's own fifth
 // (its five entries are five candidates at most that far), and the fifth smallest of the lanes' nearest (five candidates in five
 // lanes; equal values are counted once, which can only loosen the bound).  0xFFFFFFFF while fewer than five candidates are known.
-__device__ inline uint32_t fifth_bound(uint32_t d0, uint32_t d4) {
+#ifndef LIO_KNN_BOUND
+#define LIO_KNN_BOUND 5
+#endif
+__device__ inline uint32_t fifth_bound(uint32_t d0, uint32_t d2, uint32_t d4) {
     uint32_t t = group_min32(d4);
+#if LIO_KNN_BOUND == 2
+    // a cheaper (looser, equally valid) form: two lanes whose THIRD entries are both <= X hold six candidates <= X -- the second smallest of the
+    // lanes' thirds (equal values counted once) -- three group reductions instead of six
+    (void)d0;
+    const uint32_t m1 = group_min32(d2);
+    return min(t, group_min32(d2 == m1 ? 0xFFFFFFFFu : d2));
+#endif
+    (void)d2;
     uint32_t v = d0, m = 0xFFFFFFFFu;
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -421,7 +429,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                 // the voxels still listed can reach the bound the sweep ends here (the usual case after the first batch: one bound
                 // computation per query instead of one per batch of four listed voxels)
                 if (s0 > 0) {
-                    if (need_bound) bound5 = fifth_bound(d0, d4);
+                    if (need_bound) bound5 = fifth_bound(d0, dd2, d4);
                     const uint32_t floor_bits = s0 < n0 ? 0u : (s0 < n01 ? b1_bits : b2_bits);
                     if (bound5 < floor_bits) break;
                     const uint32_t r0 = s0 + gl, r1 = r0 + kG, r2 = r1 + kG, r3 = r2 + kG;  // a pruned stencil has at most 32 cells
@@ -485,7 +493,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
             }
             if constexpr (kPrune) need_bound = group_ballot(ins, lane) != 0;
         }
-        if (gl == 0) visited += total;
+        visited += total;  // (every lane its own share of the stencil's residents)
         inrange = group_sum32(inrange);
         // merge: six rounds pop the group's smallest (d2, index) head -- the global top-5 (lane r keeps winner r) and the best loser
         uint32_t win = 0xFFFFFFFFu, prev_d = 0xFFFFFFFFu;

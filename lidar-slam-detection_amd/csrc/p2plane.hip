@@ -546,6 +546,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
         if (tid == 0) c.status = EK_SKIPPED;
     } else if (tid < 64) {
         ek_measure_head(c, w, acc, c.converge);
+        EK_STAMP(20);
         if constexpr (JOINT) {
             // the six degeneracy sums of a joint registration live on several sub-maps and ranks: such a pass (rare: the eigenvalue bound of the
             // GLOBAL sum n n^T did not decide) is left to the host-driven joint path -- every rank reaches this decision from the same bits
@@ -557,6 +558,7 @@ __global__ void __launch_bounds__(kStepThreads) step_batch(const SlotDesc* __res
             }
         } else {
             if (!w.flag[1]) ek_measure_tail(c, w);  // the usual case: no degeneracy sums needed, everything about the measurement is settled here
+            EK_STAMP(21);
         }
     } else if (tid < 128) {
         ek_step_prep(c, w);

@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import scenes  # noqa: E402
 from lsd_amd import capi, lio, synth  # noqa: E402
 
-NAMES = {1: "copy-in + fold partials", 2: "measure_head", 3: "degeneracy sums / barrier", 4: "measure_tail", 5: "ek_step total (or nothing)", 6: "write back",
-         7: "publish", 10: "(enter step: tail->step)", 11: "boxminus", 12: "jacobians + copy P", 13: "P <- J P J^T (6 phases)", 14: "G, M6", 15: "inverse6",
+NAMES = {1: "copy-in + fold partials", 20: "  wave 0: measure_head", 21: "  wave 0: measure_tail", 2: "wave 0: wait for wave 1 (barrier)", 3: "degeneracy sums / barrier", 4: "measure_tail", 5: "ek_step total (or nothing)", 6: "write back",
+         7: "publish", 11: "  wave 1: boxminus", 12: "  wave 1: jacobians + copy P", 13: "  wave 1: P <- J P J^T (6 phases)", 22: "  wave 1: G", 14: "G, M6", 15: "inverse6",
          16: "Pi6, Kx/Kh, dx_out", 17: "boxplus", 18: "log + convergence", 19: "final covariance"}
 
 

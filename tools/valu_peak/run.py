@@ -10,7 +10,10 @@ L.valu_peak_wave_insts_per_s.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.
 cus, mhz = C.c_int(0), C.c_int(0)
 names = {0: "v_add_u32", 1: "add/min/add/add_dpp", 2: "v_fma_f32", 3: "v_add_f64", 4: "v_add_u32_dpp row_ror", 5: "v_min_u32", 6: "v_min_u32_dpp row_ror",
          7: "v_cndmask_b32 vcc", 8: "v_mov_b32_dpp quad_perm", 9: "v_med3_u32", 10: "v_mov_b32", 11: "v_cmp_lt_u32 vcc", 12: "v_mul_f32", 13: "v_add_u32_dpp row_shr",
-         14: "v_add_u32_dpp quad_perm", 15: "v_add_u32_dpp row_bcast15", 16: "v_add3_u32"}
+         14: "v_add_u32_dpp quad_perm", 15: "v_add_u32_dpp row_bcast15", 16: "v_add3_u32", 17: "v_sub_f32", 18: "v_add_f32", 19: "v_max_f32", 20: "v_min_f32",
+         21: "v_and_b32", 22: "v_xor_b32", 23: "v_lshlrev_b32", 24: "v_cndmask_b32 sgpr pair", 25: "v_cmp_lt_u32 sgpr pair", 26: "v_sub_u32", 27: "v_max_u32",
+         28: "v_bfe_u32", 29: "v_lshl_add_u32", 30: "v_mad_u32_u24", 31: "v_fma_f32 (3 src)", 32: "v_fmac_f32", 33: "v_min_i32", 34: "v_or_b32", 35: "v_cmp_lt_f32 vcc",
+         36: "v_med3_f32", 37: "v_bcnt_u32_b32"}
 out = {}
 for mix in sorted(names):
     row = {}

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void valu_one(uint32_t* sink, uint32_t iters, 
     uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3u, a2 = a0 * 5u, a3 = a0 * 7u, a4 = a0 * 11u, a5 = a0 * 13u, a6 = a0 * 17u, a7 = a0 * 19u;
     const uint32_t k = seed | 1u;
 #define BODY(T) REP32(asm volatile(CHAINS8(T("%0", "%4"), T("%1", "%5"), T("%2", "%6"), T("%3", "%7"), T("%4", "%0"), T("%5", "%1"), T("%6", "%2"), T("%7", "%3")) \
-                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");)
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc", "s20", "s21");)
 #define T4(d, o) "v_add_u32_dpp " d ", " d ", " o " row_ror:1 row_mask:0xf bank_mask:0xf"
 #define T5(d, o) "v_min_u32 " d ", " d ", " o
 #define T6(d, o) "v_min_u32_dpp " d ", " d ", " o " row_ror:1 row_mask:0xf bank_mask:0xf"
@@ -38,6 +38,27 @@ __global__ __launch_bounds__(256) void valu_one(uint32_t* sink, uint32_t iters, 
 #define T14(d, o) "v_add_u32_dpp " d ", " d ", " o " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
 #define T15(d, o) "v_add_u32_dpp " d ", " d ", " o " row_bcast:15 row_mask:0xa bank_mask:0xf"
 #define T16(d, o) "v_add3_u32 " d ", " d ", " o ", %8"
+#define T17(d, o) "v_sub_f32 " d ", " d ", " o
+#define T18(d, o) "v_add_f32 " d ", " d ", " o
+#define T19(d, o) "v_max_f32 " d ", " d ", " o
+#define T20(d, o) "v_min_f32 " d ", " d ", " o
+#define T21(d, o) "v_and_b32 " d ", " d ", " o
+#define T22(d, o) "v_xor_b32 " d ", " d ", " o
+#define T23(d, o) "v_lshlrev_b32 " d ", 1, " o
+#define T24(d, o) "v_cndmask_b32 " d ", " d ", " o ", s[20:21]"
+#define T25(d, o) "v_cmp_lt_u32 s[20:21], " d ", " o
+#define T26(d, o) "v_sub_u32 " d ", " d ", " o
+#define T27(d, o) "v_max_u32 " d ", " d ", " o
+#define T28(d, o) "v_bfe_u32 " d ", " o ", 3, 7"
+#define T29(d, o) "v_lshl_add_u32 " d ", " d ", 1, " o
+#define T30(d, o) "v_mad_u32_u24 " d ", " d ", " o ", %8"
+#define T31(d, o) "v_fma_f32 " d ", " d ", " o ", %8"
+#define T32(d, o) "v_fmac_f32 " d ", " o ", %8"
+#define T33(d, o) "v_min_i32 " d ", " d ", " o
+#define T34(d, o) "v_or_b32 " d ", " d ", " o
+#define T35(d, o) "v_cmp_lt_f32 vcc, " d ", " o
+#define T36(d, o) "v_med3_f32 " d ", " d ", " o ", %8"
+#define T37(d, o) "v_bcnt_u32_b32 " d ", " o ", " d
     for (uint32_t i = 0; i < iters; i++) {
         if (KIND == 4) { BODY(T4) }
         if (KIND == 5) { BODY(T5) }
@@ -52,6 +73,27 @@ __global__ __launch_bounds__(256) void valu_one(uint32_t* sink, uint32_t iters, 
         if (KIND == 14) { BODY(T14) }
         if (KIND == 15) { BODY(T15) }
         if (KIND == 16) { BODY(T16) }
+        if (KIND == 17) { BODY(T17) }
+        if (KIND == 18) { BODY(T18) }
+        if (KIND == 19) { BODY(T19) }
+        if (KIND == 20) { BODY(T20) }
+        if (KIND == 21) { BODY(T21) }
+        if (KIND == 22) { BODY(T22) }
+        if (KIND == 23) { BODY(T23) }
+        if (KIND == 24) { BODY(T24) }
+        if (KIND == 25) { BODY(T25) }
+        if (KIND == 26) { BODY(T26) }
+        if (KIND == 27) { BODY(T27) }
+        if (KIND == 28) { BODY(T28) }
+        if (KIND == 29) { BODY(T29) }
+        if (KIND == 30) { BODY(T30) }
+        if (KIND == 31) { BODY(T31) }
+        if (KIND == 32) { BODY(T32) }
+        if (KIND == 33) { BODY(T33) }
+        if (KIND == 34) { BODY(T34) }
+        if (KIND == 35) { BODY(T35) }
+        if (KIND == 36) { BODY(T36) }
+        if (KIND == 37) { BODY(T37) }
     }
     a0 += a1 + a2 + a3 + a4 + a5 + a6 + a7;
     if (a0 == 0x12345678u) sink[0] = a0;
@@ -135,6 +177,27 @@ double valu_peak_wave_insts_per_s(int device, int waves_per_simd, int mix, int* 
             case 14: valu_one<14><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
             case 15: valu_one<15><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
             case 16: valu_one<16><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 17: valu_one<17><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 18: valu_one<18><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 19: valu_one<19><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 20: valu_one<20><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 21: valu_one<21><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 22: valu_one<22><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 23: valu_one<23><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 24: valu_one<24><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 25: valu_one<25><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 26: valu_one<26><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 27: valu_one<27><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 28: valu_one<28><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 29: valu_one<29><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 30: valu_one<30><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 31: valu_one<31><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 32: valu_one<32><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 33: valu_one<33><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 34: valu_one<34><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 35: valu_one<35><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 36: valu_one<36><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
+            case 37: valu_one<37><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
             default: valu_spin<0><<<blocks, 256, 0, st>>>(sink, iters, 12345u); break;
         }
     };
