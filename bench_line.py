@@ -38,9 +38,9 @@ def _pick(d, keys, sig=5, text=110):
 def roofline(r, text=90):
     if not isinstance(r, dict):
         return None
-    o = _pick(r, _ROOF_NUM, 6)
+    o = _pick(r, _ROOF_NUM, 6, 64)
     if "kernel" in r:
-        o["kernel"] = _short(r["kernel"], text)
+        o["kernel"] = _short(r["kernel"], 48)
     ws = r.get("whole_scan")
     if isinstance(ws, dict):
         o["whole_scan"] = _pick(ws, ("algorithmic_bytes_per_scan", "achieved", "frac"))
@@ -60,7 +60,7 @@ def _beyond(g):
     return None
 
 
-def cpu_baseline(c, text=150):
+def cpu_baseline(c, text=110):
     if not isinstance(c, dict):
         return None
     o = _pick(c, _CPU_NUM)
@@ -85,14 +85,15 @@ def leg(c):
         return None
     if "error" in c and "ms_per_scan" not in c:
         return {"error": _short(c["error"], 160)}
-    o = _pick(c, ("ms_per_scan", "points_per_s", "n_ds_avg", "passes_avg", "main_ms_median", "map_points_end", "voxels_evicted", "pose_error_vs_truth_m",
-                  "sessions", "sub_maps_per_gpu", "upload"))
+    o = _pick(c, ("ms_per_scan", "points_per_s", "main_ms_median", "map_points_end", "voxels_evicted", "pose_error_vs_truth_m", "sessions", "sub_maps_per_gpu"))
     r = c.get("roofline")
     if isinstance(r, dict):
-        o["roofline"] = _pick(r, ("bound", "frac", "frac_basis", "frac_algorithmic", "frac_valu", "avg_launch_us", "candidates_per_query"), 4)
+        o["roofline"] = _pick(r, ("frac", "avg_launch_us"), 4)
+        basis = str(r.get("frac_basis", ""))
+        o["roofline"]["basis"] = "pmc" if basis.startswith("pmc") else ("requested" if basis.startswith("bytes the kernel") else "algorithmic")
     b = c.get("cpu_baseline")
     if isinstance(b, dict):
-        o["cpu_baseline"] = _pick(b, ("kind", "cores", "ms_per_scan", "ms_per_sweep", "value"))
+        o["cpu_baseline"] = _pick(b, ("kind", "cores", "ms_per_scan", "ms_per_sweep"))
         g = _beyond(b.get("gpu_vs_reference_pose"))
         if g:
             o["cpu_baseline"]["gpu_vs_reference_pose"] = g
@@ -116,7 +117,7 @@ def leg(c):
 def compact(out):
     o = {k: _num(out[k], 8) for k in _TOP if k in out}
     cfg = out.get("config") or {}
-    o["config"] = {k: (_short(v, 330) if isinstance(v, str) else _num(v)) for k, v in cfg.items() if not isinstance(v, dict)}
+    o["config"] = {k: (_short(v, 230 if k == "workload" else 96) if isinstance(v, str) else _num(v)) for k, v in cfg.items() if not isinstance(v, dict)}
     o["roofline"] = roofline(out.get("roofline"))
     o["cpu_baseline"] = cpu_baseline(out.get("cpu_baseline"))
     b = out.get("batch_vs_oracle_pose")

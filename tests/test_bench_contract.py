@@ -99,6 +99,48 @@ def test_round4_line_is_measured_on_varied_inputs_and_says_what_bounds_the_kerne
     assert c4["scan_pool"] >= 32 and c4["local_200k_map"]["ms_per_scan"] < 0.3
 
 
+def test_round5_line_is_the_compact_one_and_its_roofline_is_a_utilisation():
+    """the committed line of the driver's command is the compact one (<= 6 KB, one line), carries every contract field, a
+    roofline.frac that is a utilisation (PMC traffic over the live kernel time: never above 1) with the algorithmic credit figure and a MEASURED VALU
+    fraction beside it, the reference as cpu_baseline with the count of scans beyond the north_star tolerance, the upload-included leg, and one short
+    record per BASELINE configuration"""
+    raw = open(os.path.join(ROOT, "profiles", "r05_bench.json")).read()
+    assert len(raw) <= 6144 and raw.count("\n") <= 1
+    j = json.loads(raw)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "configs", "upload_included", "batch_vs_oracle_pose"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5 and j["unit"] == "points/s" and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert abs(j["value"] - j["config"]["n_raw"] / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"] and j["ms_per_step"] < 0.021
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] and r["frac_basis"].startswith("pmc") and 0.2 < r["frac"] < r["frac_touched"] < 1.0 < r["frac_algorithmic"]
+    assert abs(r["frac"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9 / 8000.0) < 2e-3
+    assert 0.3 < r["frac_valu"] < 1.0 and 5e11 < r["valu_peak_wave_insts_per_s"] < 1.3e12  # measured in the same process (tools/valu_peak)
+    assert abs(r["frac_valu"] - r["valu_wave_insts_per_launch"] / r["valu_peak_wave_insts_per_s"] / (r["avg_launch_us"] * 1e-6)) < 2e-3
+    c = j["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] == 8 and c["unit"] == "points/s" and c["ms_per_scan"] > 1000 * j["ms_per_step"]
+    assert c["gpu_vs_reference_pose"]["scans"] == 128 and c["gpu_vs_reference_pose"]["beyond_1e-4m_or_1e-5rad"] <= 1
+    b = j["batch_vs_oracle_pose"]
+    assert b["parity_ok"] and b["scans_checked"] == 128 and b["max_dpos_m"] < 1e-9
+    u = j["upload_included"]
+    assert u["parity_ok"] and j["ms_per_step"] < u["ms_per_step"] < 0.08 and 20 < u["pcie_GBps"] < 64
+    legs = j["configs"]
+    assert set(legs) == {"pool8_one_spot", "config2_1e6_map", "config3_stream_to_1e7_points", "config3_stream_lru_1e5_300_sweeps", "config4_localize_5e7_map",
+                         "config5_merge_8_submaps_1_gpu", "sequence_batch"}
+    for k, v in legs.items():
+        assert "error" not in v and v["ms_per_scan"] > 0 and 0 < v["roofline"]["frac"] < 1.0, k
+    assert legs["config2_1e6_map"]["cpu_baseline"]["gpu_vs_reference_pose"]["beyond_1e-4m_or_1e-5rad"] <= 1
+    c4 = legs["config4_localize_5e7_map"]
+    assert c4["resident_map"]["not_converged_checked"] >= 1 and c4["local_200k_map"]["converged"] == 200
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_full.json")).read())
+    assert full["value"] == pytest.approx(j["value"], rel=1e-6) and len(json.dumps(full)) > 20000
+    nc = full["configs"]["config4_localize_5e7_map"]["resident_map"]["not_converged"]
+    # the alignments that end at max_iterations: the reference's own NDT_CUDA ends there too on most of them, at the same poses
+    assert nc["checked"] - nc["reference_converged"] >= nc["checked"] - 2
+    assert all(abs(a["ours"]["pos_err_m"] - a["reference"]["pos_err_m"]) < 5e-3 for a in nc["alignments"])
+
+
 def test_compact_stdout_line_fits_the_drivers_parser():
     """round 4's 30 KB line was not parsed.  bench.py prints bench_line.line(record): at most bench_line.LIMIT (< 8 KB) bytes with the
     contract fields, roofline and cpu_baseline numbers, and one short record per secondary leg -- checked on the largest record there is (round 4's)
