@@ -39,6 +39,11 @@ namespace lio {
 #ifndef LIO_KNN_PRUNE
 #define LIO_KNN_PRUNE 1  // distance-ordered sweep with exact pruning of stencil voxels that cannot hold one of the five nearest
 #endif
+#ifdef LIO_KNN_MAXWAVES  // experiment: CAP the kernel's occupancy (leaves registers / issue slots of every SIMD to the kernels of the other rounds in flight)
+#define LIO_KNN_OCC __attribute__((amdgpu_waves_per_eu(LIO_KNN_MAXWAVES, LIO_KNN_MAXWAVES)))
+#else
+#define LIO_KNN_OCC
+#endif
 constexpr int kG = LIO_KNN_G;          // lanes per query
 constexpr int kU = LIO_KNN_U;          // voxels swept together (loads in flight per lane), multiple of 4
 constexpr int kGPB = 256 / kG;         // queries per workgroup
@@ -565,7 +570,7 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
 // the scans of a batch (lio_batch_*): blockIdx.y = slot; pose from the slot's device-resident filter; a slot whose update has finished,
 // or whose filter did not ask for a neighbour search this pass, exits at once
 template <int KM, bool COUNT>
-__global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+__global__ void LIO_KNN_OCC __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                                        float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;

@@ -195,10 +195,15 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
                                                const float4* __restrict__ ds_body, float4* __restrict__ ds_world,
                                                const float4* __restrict__ nn_pts, uint32_t nn_stride,
                                                const int32_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
-                                               float4* __restrict__ normvec, double* __restrict__ partial, uint32_t n_known = 0xFFFFFFFFu) {
+                                               float4* __restrict__ normvec, double* __restrict__ partial, uint32_t n_known = 0xFFFFFFFFu,
+                                               uint32_t vb = 0xFFFFFFFFu) {
+    // vb: the block of kLinThreads points this call works on (the batched kernel strides over a slot's blocks: its grid is sized for the largest cloud
+    // a slot may hold -- 1 563 blocks at max_ds 100 000 -- and a 12 000-point scan left 1 380 of them per slot and launch to start, wait for the
+    // slot's filter words and exit: 100 000 one-wave workgroups per launch of 64 scans, most of the kernel's 39 us); default: the launch's own block
+    if (vb == 0xFFFFFFFFu) vb = blockIdx.x;
     const uint32_t n = n_known != 0xFFFFFFFFu ? n_known : sd->n_ds;  // (the batched kernels have read it with the slot's filter words)
-    if (blockIdx.x * kLinThreads >= n) return;  // finalize only reads the first ceil(n / kLinThreads) partials
-    const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
+    if (vb * kLinThreads >= n) return;  // finalize only reads the first ceil(n / kLinThreads) partials
+    const uint32_t i = vb * kLinThreads + threadIdx.x;
     // the point's addends are formed at reduction time from its Jacobian row, residual and |residual| (8 doubles live instead of 29)
     double row[6] = {0, 0, 0, 0, 0, 0};
     double h = 0.0, ares = 0.0, one = 0.0;
@@ -324,7 +329,7 @@ __device__ __forceinline__ void linearize_body(const PoseArgs& pose, int redo_kn
             s += v.x;
             s += v.y;
         }
-        partial[(size_t)blockIdx.x * kAcc + threadIdx.x] = s;
+        partial[(size_t)vb * kAcc + threadIdx.x] = s;
     }
 }
 
@@ -336,13 +341,21 @@ __global__ void __launch_bounds__(kLinThreads) linearize_kernel(PoseArgs pose, i
     linearize_body(pose, redo_knn, sd, ds_body, ds_world, nn_pts, nn_stride, nn_cnt, selected, normvec, partial);
 }
 // the scans of a batch: pose and the "redo the neighbour search" flag come from the slot's device-resident filter
+// workgroups per slot of linearize_batch: 256 x 64 = 16 384 points per sweep of the grid (a 0.5 m-leaf scan is 7 000 - 18 000 points)
+#ifndef LIO_LIN_GRID
+#define LIO_LIN_GRID 256
+#endif
+constexpr uint32_t kLinGridCap = LIO_LIN_GRID;
 __global__ void __launch_bounds__(kLinThreads) linearize_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
     const SlotGate sg = slot_gate(d);
     if ((sg.status != EK_RUNNING) | (sg.n_ds < d.min_ds)) return;
     const PoseArgs& pose = sg.pose;
-    linearize_body(pose, sg.converge, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, d.selected, d.normvec, d.partial, sg.n_ds);
+    for (uint32_t vb = blockIdx.x; vb * kLinThreads < sg.n_ds; vb += gridDim.x) {
+        linearize_body(pose, sg.converge, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, d.selected, d.normvec, d.partial, sg.n_ds, vb);
+        __syncthreads();  // (the reduction's LDS staging is reused by this workgroup's next block)
+    }
 }
 
 // component `comp` of the workgroups' partial records b = l, l + 32, l + 64, ... < nb, added in that order -- with the loads of eight steps in flight
@@ -706,6 +719,7 @@ int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int
                                void* gather_ctx, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
                                int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt) {
     uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
+    if (lin_blocks > kLinGridCap) lin_blocks = kLinGridCap;  // (linearize_batch strides over a slot's blocks)
     if (lin_blocks == 0) lin_blocks = 1;
     for (int p = 0; p < n_passes; p++) {
         for (int m = 0; m < n_maps; m++) {
@@ -742,6 +756,7 @@ int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int
 // (maximum_iter + 1); slots that converge early skip the rest of the launches
 int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, BatchTimer* bt, int count_touched) {
     uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
+    if (lin_blocks > kLinGridCap) lin_blocks = kLinGridCap;  // (linearize_batch strides over a slot's blocks)
     if (lin_blocks == 0) lin_blocks = 1;
     for (int p = 0; p < n_passes; p++) {
         if (bt) bt->begin(1);
@@ -763,6 +778,7 @@ int p2plane_batch_update(lio_map* m, hipStream_t st, const SlotDesc* d_slots, in
 int p2plane_seq_update(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, int n_slots, uint32_t ds_bound, int n_passes, const StencilArgs* stencils,
                        const int* stencil_ids, int n_stencils, BatchTimer* bt) {
     uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
+    if (lin_blocks > kLinGridCap) lin_blocks = kLinGridCap;  // (linearize_batch strides over a slot's blocks)
     if (lin_blocks == 0) lin_blocks = 1;
     for (int p = 0; p < n_passes; p++) {
         if (bt) bt->begin(1);

@@ -583,6 +583,7 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
 // close to the sensor: a few hundred voxels holding half of the points) are queued for the wave-per-voxel
 // kernel below, so that their latency is spread over the chip instead of serialising one wave.
 constexpr uint32_t kLongRun = 32;
+constexpr uint32_t kCentroidGridCap = 96;  // workgroups per scan of vg_centroid_*: 96 x 256 = 24 576 voxels per sweep of the grid
 // ... and the few runs of thousands of points (a wall a metre from the sensor, the ground ring under it) go to a second queue, filled from the
 // top of the same array, whose runs are summed one COMPONENT per wave by integer arithmetic inside the running sum's binade (monster_sum below)
 constexpr uint32_t kMonsterRun = 2048;
@@ -591,10 +592,12 @@ constexpr uint32_t kMonsterBlocksBatch = 16;  // ... per slot of the batched cha
 
 __device__ __forceinline__ void vg_centroid_body(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                ScanDev* __restrict__ sd, float4* __restrict__ out,
-                                                               uint32_t* __restrict__ longlist, uint32_t max_ds) {
+                                                               uint32_t* __restrict__ longlist, uint32_t max_ds, uint32_t vb) {
+    // vb: the block of kThreads voxels this call works on -- the kernels stride over the scan's blocks (a grid sized for max_ds = 100 000 voxels left
+    // 345 of 391 workgroups per slot to start, wait for the scan's size and exit)
     if (sd->passthrough) return;
     const uint32_t nv = sd->n_ds;
-    const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t v = vb * kThreads + threadIdx.x;
     if (v >= nv) return;
     // (both run bounds and the scan's valid count requested together: the conditional form was two memory round trips one after the other)
     uint32_t a = hpos[v];
@@ -966,12 +969,14 @@ __global__ void __launch_bounds__(kThreads) vg_heads_batch(const SlotDesc* __res
 __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                ScanDev* __restrict__ sd, float4* __restrict__ out,
                                                                uint32_t* __restrict__ longlist, uint32_t max_ds) {
-    vg_centroid_body(sorted, hpos, sd, out, longlist, max_ds);
+    const uint32_t nv = sd->passthrough ? 0u : sd->n_ds;
+    for (uint32_t vb = blockIdx.x; vb * kThreads < nv; vb += gridDim.x) vg_centroid_body(sorted, hpos, sd, out, longlist, max_ds, vb);
 }
 __global__ void __launch_bounds__(kThreads) vg_centroid_batch(const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    vg_centroid_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist, d.max_ds);
+    const uint32_t nv = d.sd->passthrough ? 0u : d.sd->n_ds;
+    for (uint32_t vb = blockIdx.x; vb * kThreads < nv; vb += gridDim.x) vg_centroid_body(d.sorted, d.hpos, d.sd, d.ds_body, d.longlist, d.max_ds, vb);
 }
 __global__ void __launch_bounds__(kThreads) vg_centroid_long_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                     const ScanDev* __restrict__ sd, float4* __restrict__ out,
@@ -1026,8 +1031,9 @@ int vg_downsample(lio_scan* s, float leaf, int passes) {
     hipLaunchKernelGGL(vg_heads_kernel, nblocks, kThreads, 0, st, s->raw, s->keys_a, s->keys_b, s->vals_a, s->vals_b, n, s->dev, s->blockcnt,
                        s->hpos, s->sorted, s->ds_body, s->max_ds, s->host_nds_dev, (uint32_t)passes);
     const uint32_t vbound = n < s->max_ds ? n : s->max_ds;
-    hipLaunchKernelGGL(vg_centroid_kernel, (vbound + kThreads - 1) / kThreads, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body,
-                       s->longlist, s->max_ds);
+    const uint32_t cblocks1 = (vbound + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(vg_centroid_kernel, cblocks1 < 2u * kCentroidGridCap ? cblocks1 : 2u * kCentroidGridCap, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body,
+                       s->longlist, s->max_ds);  // (strides over the scan's blocks)
     hipLaunchKernelGGL(vg_centroid_long_kernel, 256 + kMonsterBlocks, kThreads, 0, st, s->sorted, s->hpos, s->dev, s->ds_body, s->longlist, s->max_ds, 256u);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
@@ -1049,7 +1055,8 @@ int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, ui
     hipLaunchKernelGGL(vg_count_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots);
     hipLaunchKernelGGL(vg_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, (uint32_t)passes);
     const uint32_t vbound = max_raw < max_ds ? max_raw : max_ds;
-    hipLaunchKernelGGL(vg_centroid_batch, dim3((vbound + kThreads - 1) / kThreads, B), kThreads, 0, st, d_slots);
+    const uint32_t cblocks = (vbound + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(vg_centroid_batch, dim3(cblocks < kCentroidGridCap ? cblocks : kCentroidGridCap, B), kThreads, 0, st, d_slots);  // (strides over the scan's blocks)
     static const bool split = []() { const char* e = getenv("LIO_VG_MONSTER_SPLIT"); return e && e[0] == '1'; }();
     if (split) {
         hipLaunchKernelGGL(vg_centroid_long_batch, dim3(64, B), kThreads, 0, st, d_slots);

@@ -11,13 +11,13 @@ rm -rf $T && mkdir -p $T/lidar-slam-detection_amd/python/lsd_amd
 cp -r $R/include $T/include
 cp -r $R/lidar-slam-detection_amd/csrc $T/lidar-slam-detection_amd/csrc
 rm -f $T/lidar-slam-detection_amd/csrc/*.o
-extra=""
 while [ $# -gt 0 ]; do
-    if [ "$1" = "--" ]; then shift; extra="$*"; break; fi
+    if [ "$1" = "--" ]; then shift; break; fi
     (cd $T && patch -p1 -s < "$R/$1")
     shift
 done
-make -C $T/lidar-slam-detection_amd/csrc -j8 ../python/lsd_amd/liblio_hip.so $extra > $T/build.log 2>&1 || { tail -30 $T/build.log; exit 1; }
+# (what follows `--` goes to make as it is: quote an EXTRA with several flags, EXTRA="-DA=1 -DB=2")
+make -C $T/lidar-slam-detection_amd/csrc -j8 ../python/lsd_amd/liblio_hip.so "$@" > $T/build.log 2>&1 || { tail -30 $T/build.log; exit 1; }
 mkdir -p $R/tools/experiments/variants
 cp $T/lidar-slam-detection_amd/python/lsd_amd/liblio_hip.so $R/tools/experiments/variants/liblio_hip_$name.so
 echo "built tools/experiments/variants/liblio_hip_$name.so"
