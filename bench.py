@@ -128,7 +128,9 @@ def main():
                                                               "each, all reading the one resident map)")
     ap.add_argument("--engine", choices=["batch", "threads"], default="batch",
                     help="batch: B scans per launch, filter loop on the device, one host thread (lio_batch_*); threads: round 1's one engine + thread per scan")
-    ap.add_argument("--slots", type=int, default=64, help="--engine batch: scans per launch")
+    ap.add_argument("--slots", type=int, default=128, help="--engine batch: scans per launch (round 5 sweep, tools/experiments/README.md: 64 x 4 0.0182, 96 x 4 0.0176, "
+                                                             "128 x 4 0.0176, 160 x 4 0.0175, 256 x 3 0.0177 ms per scan; the kNN kernel's cost per search falls from 7.1 to "
+                                                             "6.0 us between 64 and 256 scans per launch)")
     ap.add_argument("--groups", type=int, default=4, help="--engine batch: rounds in flight (one HIP stream each)")
     ap.add_argument("--config", choices=["metric", "merge", "stream", "localize", "sequences", "refparity", "rcclprobe"], default="metric",
                     help="metric: BASELINE.json's headline (independent 120k-pt scans vs a 1e7-pt map); merge: BASELINE config 5, multi-map merge -- 8 sub-maps "

@@ -14,7 +14,10 @@ cd $R
 python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*_results.db" | head -1) $(find $O/pmc_write -name "*_results.db" | head -1) "$K" $(find $O/pmc_valu -name "*_results.db" | head -1) > $O/knn_batch_traffic.json
 python - <<PY
 import json
-p = "$O/knn_batch_traffic.json"; j = json.load(open(p)); j.update(slots_per_launch=64, scan_pool=128); json.dump(j, open(p, "w"), indent=1); print(j)
+import re
+src = open("$R/bench.py").read()
+slots = int(re.search(r'"--slots", type=int, default=(\d+)', src).group(1)); pool = int(re.search(r'"--scan-pool", type=int, default=(\d+)', src).group(1))
+p = "$O/knn_batch_traffic.json"; j = json.load(open(p)); j.update(slots_per_launch=slots, scan_pool=pool); json.dump(j, open(p, "w"), indent=1); print(j)
 PY
 cp $O/knn_batch_traffic.json $R/profiles/knn_batch_traffic.json   # (the bench runs below read it)
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_valu
