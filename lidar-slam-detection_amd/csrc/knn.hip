@@ -423,7 +423,14 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         uint32_t bound5 = 0xFFFFFFFFu;
         const uint32_t ptr_first = g.v_ptr[0];  // (0 when nothing is listed: the pool's first record -- the sweep does not run then)
         bool need_bound = true;  // group-uniform: a lane of the group has taken a candidate since the bound was last computed
-        for (uint32_t s0 = 0; s0 < nhit; s0 += kU) {
+#ifndef LIO_KNN_HOME_FIRST
+#define LIO_KNN_HOME_FIRST 0
+#endif
+        // LIO_KNN_HOME_FIRST (experiment): the first listed voxel -- the query's own, when it exists -- is swept ALONE, the bound is formed from it, and
+        // the other three of the first batch go through the pruning test like every later batch: the first batch of four voxels is otherwise
+        // swept unpruned (~156 of the ~162 candidates a query touches on the metric map)
+        int phase = (kPrune && LIO_KNN_HOME_FIRST) ? 0 : 2;  // 0: the first voxel alone; 1: the rest of batch 0; 2: batches as listed
+        for (uint32_t s0 = 0; s0 < nhit; s0 += (phase >= 1 ? kU : 0u), phase = (phase < 2 ? phase + 1 : 2)) {
             uint32_t ptr4[kU], cnt4[kU];
             uint32_t cmax = 0;
             bool ins = false;
@@ -433,7 +440,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                 // is below the floor of the bucket the next batch starts in, nothing that follows can matter either -- and if none of
                 // the voxels still listed can reach the bound the sweep ends here (the usual case after the first batch: one bound
                 // computation per query instead of one per batch of four listed voxels)
-                if (s0 > 0) {
+                if (s0 > 0 || phase == 1) {
                     if (need_bound) bound5 = fifth_bound(d0, dd2, d4);
                     const uint32_t floor_bits = s0 < n0 ? 0u : (s0 < n01 ? b1_bits : b2_bits);
                     if (bound5 < floor_bits) break;
@@ -453,6 +460,10 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                     if (vd.y > bound5) vc.y = 0;
                     if (vd.z > bound5) vc.z = 0;
                     if (vd.w > bound5) vc.w = 0;
+                    if (LIO_KNN_HOME_FIRST && u == 0) {
+                        if (phase == 0) { vc.y = 0; vc.z = 0; vc.w = 0; }
+                        else if (phase == 1) vc.x = 0;
+                    }
                 }
                 ptr4[u] = vp.x; ptr4[u + 1] = vp.y; ptr4[u + 2] = vp.z; ptr4[u + 3] = vp.w;
                 cnt4[u] = vc.x; cnt4[u + 1] = vc.y; cnt4[u + 2] = vc.z; cnt4[u + 3] = vc.w;
