@@ -50,13 +50,21 @@ def roofline(r, text=90):
     return o
 
 
+def _own(g):
+    r = g.get("reference_run_to_run") if isinstance(g, dict) else None
+    return _num(r.get("max_dpos_m"), 3) if isinstance(r, dict) else None
+
+
 def _beyond(g):
     """scans beyond the north_star tolerance (1e-4 m / 1e-5 rad) against the reference's build, wherever a leg recorded it"""
     if not isinstance(g, dict):
         return None
     for k in ("scans_beyond_1e_4_m_or_1e_5_rad", "scans_beyond_tolerance"):
         if k in g:
-            return {"scans": g.get("scans"), "beyond_1e-4m_or_1e-5rad": g[k], "max_dpos_m": _num(g.get("max_dpos_m"), 3), "max_drot_rad": _num(g.get("max_drot_rad"), 3)}
+            o = {"scans": g.get("scans"), "beyond_1e-4m_or_1e-5rad": g[k], "max_dpos_m": _num(g.get("max_dpos_m"), 3), "max_drot_rad": _num(g.get("max_drot_rad"), 3)}
+            if _own(g) is not None:
+                o["reference_run_to_run_max_dpos_m"] = _own(g)
+            return o
     return None
 
 
@@ -97,6 +105,9 @@ def leg(c):
         g = _beyond(b.get("gpu_vs_reference_pose"))
         if g:
             o["cpu_baseline"]["gpu_vs_reference_pose"] = g
+        gd = b.get("gpu_vs_reference_drive")
+        if isinstance(gd, dict):  # config 3: a trajectory-level figure (two filters on the same drive)
+            o["cpu_baseline"]["gpu_vs_reference_drive"] = {k: _num(v, 3) for k, v in gd.items() if k.startswith("dpos_m_after")}
     for name in ("resident_map", "local_200k_map"):  # config 4's two cases
         s = c.get(name)
         if isinstance(s, dict):
