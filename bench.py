@@ -794,7 +794,7 @@ def main():
                            ("config3_stream_lru_1e5_300_sweeps", ["--config", "stream", "--steps", "300", "--lru", "100000", "--ref-scans", "300"]),
                            ("config4_localize_5e7_map", ["--config", "localize", "--steps", "200", "--scan-pool", "32"]),
                            ("config5_merge_8_submaps_1_gpu", ["--config", "merge", "--steps", "256", "--warmup", "64", "--scan-pool", "64", "--min-seconds", "2"]),
-                           ("sequence_batch", ["--config", "sequences", "--steps", "24", "--slots", "64", "--groups", "2"])):
+                           ("sequence_batch", ["--config", "sequences", "--steps", "24", "--slots", "128", "--groups", "2"])):
             try:
                 pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--full-line", "--seed", str(args.seed)] + extra, capture_output=True, text=True, timeout=900)
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]

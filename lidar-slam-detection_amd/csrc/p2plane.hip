@@ -820,9 +820,14 @@ constexpr int kClsThreads = 256;
 __device__ __forceinline__ void classify_body(const PoseArgs& pose, const ScanDev* __restrict__ sd, const float4* __restrict__ ds_body,
                                               float4* __restrict__ ds_world, const float4* __restrict__ nn_pts, uint32_t nn_stride,
                                               const int32_t* __restrict__ nn_cnt, float map_leaf, int ekf_inited, int seed_all,
-                                              uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt /* [2][gridDim.x] */) {
+                                              uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt /* [2][stride] */,
+                                              uint32_t vb = 0xFFFFFFFFu, uint32_t stride = 0u) {
+    // vb / stride: the block of kClsThreads points this call classifies and the row length of blk_cnt -- the launch's own block and grid by default
+    // (one scan at a time: the host knows the cloud's size); the sequence batch strides over a slot's blocks with a grid sized for the typical cloud
+    // (its capacity-sized grid -- 391 workgroups per slot for max_ds = 100 000 -- left six of seven workgroups to start, wait and leave)
+    if (vb == 0xFFFFFFFFu) { vb = blockIdx.x; stride = gridDim.x; }
     const uint32_t n = sd->n_ds;
-    const uint32_t i = blockIdx.x * kClsThreads + threadIdx.x;
+    const uint32_t i = vb * kClsThreads + threadIdx.x;
     int c = 0;  // 0 not added, 1 PointToAdd, 2 PointNoNeedDownsample
     if (i < n) {
         double pi[3];
@@ -860,23 +865,25 @@ __device__ __forceinline__ void classify_body(const PoseArgs& pose, const ScanDe
     if (threadIdx.x < 2) {
         uint32_t t = 0;
         for (int w = 0; w < kClsThreads / 64; w++) t += wc[w][threadIdx.x];
-        blk_cnt[threadIdx.x * gridDim.x + blockIdx.x] = t;
+        blk_cnt[threadIdx.x * stride + vb] = t;
     }
 }
 
 __device__ __forceinline__ void classify_scatter_body(const ScanDev* __restrict__ sd, const float4* __restrict__ ds_world,
                                                       const uint8_t* __restrict__ cls, const uint32_t* __restrict__ blk_cnt,
-                                                      float4* __restrict__ stage, MapDev* md) {
+                                                      float4* __restrict__ stage, MapDev* md, uint32_t vb = 0xFFFFFFFFu, uint32_t nb = 0u,
+                                                      uint32_t stride = 0u) {
+    // vb / nb / stride: this call's block, the number of blocks that hold points, the row length of blk_cnt (defaults: the launch's block and grid)
+    if (vb == 0xFFFFFFFFu) { vb = blockIdx.x; nb = gridDim.x; stride = gridDim.x; }
     const uint32_t n = sd->n_ds;
-    const uint32_t nb = gridDim.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // exclusive prefix of this workgroup in each list, and the size of the first list (fixed order: deterministic slots)
     __shared__ uint32_t red[kClsThreads / 64][3];
     uint32_t preA = 0, preB = 0, totA = 0;
     for (uint32_t b = tid; b < nb; b += kClsThreads) {
-        const uint32_t a = blk_cnt[b], bb = blk_cnt[nb + b];
+        const uint32_t a = blk_cnt[b], bb = blk_cnt[stride + b];
         totA += a;
-        if (b < blockIdx.x) { preA += a; preB += bb; }
+        if (b < vb) { preA += a; preB += bb; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { preA += __shfl_xor(preA, off); preB += __shfl_xor(preB, off); totA += __shfl_xor(totA, off); }
@@ -885,7 +892,7 @@ __device__ __forceinline__ void classify_scatter_body(const ScanDev* __restrict_
     preA = preB = totA = 0;
     for (int w = 0; w < kClsThreads / 64; w++) { preA += red[w][0]; preB += red[w][1]; totA += red[w][2]; }
     __syncthreads();
-    const uint32_t i = blockIdx.x * kClsThreads + tid;
+    const uint32_t i = vb * kClsThreads + tid;
     const int c = i < n ? (int)cls[i] : 0;
     const unsigned long long m1 = __ballot(c == 1), m2 = __ballot(c == 2);
     __shared__ uint32_t wc[kClsThreads / 64][2];
@@ -899,7 +906,7 @@ __device__ __forceinline__ void classify_scatter_body(const ScanDev* __restrict_
     const unsigned long long below = (1ull << lane) - 1ull;
     if (c == 1) stage[offA + __popcll(m1 & below)] = ds_world[i];
     else if (c == 2) stage[offB + __popcll(m2 & below)] = ds_world[i];
-    if (blockIdx.x == nb - 1 && tid == 0) md->n_add = totA + preB + tb;  // (the last workgroup's exclusive prefix + its own count = the total)
+    if (vb == nb - 1 && tid == 0) md->n_add = totA + preB + tb;  // (the last block's exclusive prefix + its own count = the total)
 }
 
 __global__ void __launch_bounds__(kClsThreads) classify_kernel(PoseArgs pose, const ScanDev* __restrict__ sd, const float4* __restrict__ ds_body,
@@ -949,14 +956,26 @@ __global__ void __launch_bounds__(kClsThreads) classify_seq(const MapRef* __rest
     const SlotDesc& d = slots[blockIdx.y];
     const MapRef& r = maps[blockIdx.y];
     const PoseArgs pose = pose_from_state(d.ctrl->x);
-    classify_body(pose, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, r.map_leaf, (int)r.ekf_inited, 0, reinterpret_cast<uint8_t*>(d.keys_a), d.hist);
+    const uint32_t n = d.sd->n_ds, stride = (d.max_ds + kClsThreads - 1) / kClsThreads;
+    for (uint32_t vb = blockIdx.x; vb * kClsThreads < n; vb += gridDim.x) {
+        classify_body(pose, d.sd, d.ds_body, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, r.map_leaf, (int)r.ekf_inited, 0, reinterpret_cast<uint8_t*>(d.keys_a), d.hist, vb, stride);
+        __syncthreads();  // (the workgroup's LDS staging is reused by its next block)
+    }
 }
 __global__ void __launch_bounds__(kClsThreads) classify_scatter_seq(const MapRef* __restrict__ maps, const SlotDesc* __restrict__ slots,
                                                                     const SeqDev* __restrict__ seq) {
     if (!seq[blockIdx.y].go) return;
     const SlotDesc& d = slots[blockIdx.y];
     const MapRef& r = maps[blockIdx.y];
-    classify_scatter_body(d.sd, d.ds_world, reinterpret_cast<const uint8_t*>(d.keys_a), d.hist, r.stage, r.md);
+    const uint32_t n = d.sd->n_ds, stride = (d.max_ds + kClsThreads - 1) / kClsThreads, nb = (n + kClsThreads - 1) / kClsThreads;
+    if (nb == 0) {  // an empty cloud: nothing is staged
+        if (blockIdx.x == 0 && threadIdx.x == 0) r.md->n_add = 0;
+        return;
+    }
+    for (uint32_t vb = blockIdx.x; vb < nb; vb += gridDim.x) {
+        classify_scatter_body(d.sd, d.ds_world, reinterpret_cast<const uint8_t*>(d.keys_a), d.hist, r.stage, r.md, vb, nb, stride);
+        __syncthreads();
+    }
 }
 // the read-back record of every slot: the posterior covariance and what the insert left in the map's counters
 __global__ void __launch_bounds__(256) seq_finish_kernel(const MapRef* __restrict__ maps, const SlotDesc* __restrict__ slots, SeqDev* __restrict__ seq) {
@@ -996,6 +1015,7 @@ int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float ma
 // map_incremental (laserMapping.cpp:523-576) of every slot whose update finished, against its own map, then the read-back records
 int p2plane_seq_insert(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, SeqDev* d_seq, int n_slots, uint32_t ds_bound, int any_lru) {
     uint32_t blocks = (ds_bound + kClsThreads - 1) / kClsThreads;
+    if (blocks > 96u) blocks = 96u;  // (classify_seq / classify_scatter_seq stride over a slot's blocks: 96 x 256 = 24 576 points per sweep of the grid)
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(seq_begin_insert_kernel, dim3((uint32_t)n_slots), 64, 0, st, d_maps, d_slots, d_seq);
     hipLaunchKernelGGL(classify_seq, dim3(blocks, (uint32_t)n_slots), kClsThreads, 0, st, d_maps, d_slots, d_seq);
