@@ -11,8 +11,8 @@ LIMIT = 6000  # bytes of the stdout line (the driver keeps an 8 KB tail)
 
 _TOP = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "repeats", "timed_scans", "timed_seconds", "ms_per_step", "higher_is_better",
         "scaling", "vs_baseline", "dtype", "data")
-_ROOF_NUM = ("bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_basis", "traffic", "frac_algorithmic", "frac_touched", "frac_hbm_traffic", "frac_valu",
-             "valu_peak_wave_insts_per_s", "valu_wave_insts_per_launch", "algorithmic_bytes_per_launch", "touched_bytes_per_launch", "avg_launch_us", "launches",
+_ROOF_NUM = ("bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_basis", "traffic", "frac_algorithmic", "frac_touched", "frac_valu",
+             "valu_peak_wave_insts_per_s", "valu_wave_insts_per_launch", "algorithmic_bytes_per_launch", "avg_launch_us",
              "candidates_per_query", "measured_copy_peak", "timed_region")
 _CPU_NUM = ("value", "unit", "cores", "host_cpus", "kind", "ms_per_scan", "ms_per_sweep")
 
@@ -38,7 +38,7 @@ def _pick(d, keys, sig=5, text=110):
 def roofline(r, text=90):
     if not isinstance(r, dict):
         return None
-    o = _pick(r, _ROOF_NUM, 6, 64)
+    o = _pick(r, _ROOF_NUM, 6, 40)
     if "kernel" in r:
         o["kernel"] = _short(r["kernel"], 48)
     ws = r.get("whole_scan")
@@ -68,7 +68,7 @@ def _beyond(g):
     return None
 
 
-def cpu_baseline(c, text=110):
+def cpu_baseline(c, text=90):
     if not isinstance(c, dict):
         return None
     o = _pick(c, _CPU_NUM)
@@ -93,7 +93,7 @@ def leg(c):
         return None
     if "error" in c and "ms_per_scan" not in c:
         return {"error": _short(c["error"], 160)}
-    o = _pick(c, ("ms_per_scan", "points_per_s", "main_ms_median", "map_points_end", "voxels_evicted", "pose_error_vs_truth_m", "sessions", "sub_maps_per_gpu"))
+    o = _pick(c, ("ms_per_scan", "points_per_s", "main_ms_median", "sessions", "sub_maps_per_gpu"))
     r = c.get("roofline")
     if isinstance(r, dict):
         o["roofline"] = _pick(r, ("frac", "avg_launch_us"), 4)
@@ -111,7 +111,7 @@ def leg(c):
     for name in ("resident_map", "local_200k_map"):  # config 4's two cases
         s = c.get(name)
         if isinstance(s, dict):
-            o[name] = _pick(s, ("ms_per_scan", "converged", "lm_iterations_avg", "target_points"))
+            o[name] = _pick(s, ("ms_per_scan", "converged"))
             nc = s.get("not_converged")
             if isinstance(nc, dict) and "checked" in nc:
                 o[name]["not_converged_checked"] = nc["checked"]
