@@ -236,3 +236,62 @@ def test_host_raw_jobs_give_the_bits_of_resident_clouds():
     bad = [dict(jobs[0], flags=0x42)]
     rc4, res4 = b.process(bad)
     assert res4[0]["rc"] == capi.LIO_E_INVALID
+
+
+def test_large_clouds_take_the_strided_kernels_round_their_grids(oracle_mod):
+    """Round 5: linearize_batch / vg_centroid_* / classify_seq stride over a slot's blocks with grids sized for the typical cloud (256 x 64 points,
+    96 x 256 voxels) instead of the slot's capacity.  Clouds LARGER than one sweep of those grids must give the oracle's results too: a scan whose
+    0.5 m grid holds more than 16 384 points through the batched engine (poses, pass structure), and a 0.1 m grid of more than 50 000 voxels through the
+    single and the batched downsample (bit-exact centroids, in order)."""
+    _dev()
+    from lsd_amd import lio, synth
+
+    scene = scenes.config_scene()
+    mp = scene.sample_surface(1_000_000, seed=2, sigma=0.01)
+    the_map = lio.Map(resolution=0.5, stencil=19, max_points=1_000_000, max_voxels=1_000_000)
+    the_map.add(mp)
+    P0 = lio.init_cov()
+    # dense scans (every ray hits: the metric config's field of view, 2 040 azimuth steps): n_ds ~ 18 000 > 256 x 64
+    rng = np.random.default_rng(77)
+    jobs, meta = [], []
+    for k in range(3):
+        pos = np.array([rng.uniform(-4, 4), rng.uniform(-4, 4), 1.8])
+        q = synth.quat_from_rotvec([0, 0, rng.uniform(-np.pi, np.pi)])
+        raw, _ = synth.make_scan(scene, pos, q, seed=4100 + k, n_az=2040, fov_deg=(-24.8, 2.0), max_range=150.0)  # 130 560 points, ~18 000 voxels of 0.5 m
+        gp, gq = synth.perturb_pose(pos, q, seed=9100 + k, max_t=0.2, max_deg=1.0)
+        meta.append(dict(raw=raw, guess=synth.state_from_pose(gp, gq)))
+        jobs.append(dict(dptr=scenes.to_device(raw), n=len(raw), t=1.0 + 0.1 * k, state=meta[-1]["guess"], cov=P0))
+    b = lio.Batch(the_map, n_slots=2, n_groups=2, max_raw=1 << 17, max_ds=100000)
+    rc, res = b.process(jobs)
+    assert rc == 0
+    o = oracle_mod.Lio(res=0.5, stencil=19, capacity=1 << 40, threads=8)
+    o.map_add(mp)
+    o.set_flags(ekf_inited=True, first_scan=False, travel=0.0, first_lidar_time=-10.0)
+    big = 0
+    for k, r in enumerate(res):
+        assert r["rc"] == 3, (k, r["rc"])
+        big += r["n_ds"] > 16384
+        o.reset_cache()
+        o.set_state(meta[k]["guess"])
+        o.set_cov(P0)
+        ds = oracle_mod.voxel_downsample(meta[k]["raw"], 0.5)
+        assert len(ds) == r["n_ds"], (k, len(ds), r["n_ds"])
+        o.set_ds(ds)
+        lo = o.update()
+        assert (len(lo), sum(p["knn"] for p in lo)) == (r["n_pass"], r["n_knn_pass"]), k
+        assert np.abs(r["state"] - o.get_state()).max() < 1e-9, k
+    assert big >= 2, [r["n_ds"] for r in res]  # (the point of the test: more than one sweep of linearize_batch's grid)
+    # the voxel grid at a 0.1 m leaf: more voxels than one sweep of the centroid kernels' grids, single and batched
+    raw = meta[0]["raw"]
+    ref = oracle_mod.voxel_downsample(raw, 0.1)
+    assert len(ref) > 50_000
+    s1 = lio.Scan(max_raw=1 << 17, max_ds=120000)
+    s1.upload(raw)
+    assert s1.voxel_downsample(0.1) == len(ref) and np.array_equal(s1.get_ds().view(np.uint32), ref.view(np.uint32))
+    ss = [lio.Scan(max_raw=1 << 17, max_ds=120000) for _ in range(2)]
+    for s_, m_ in zip(ss, meta[:2]):
+        s_.upload(m_["raw"])
+    ns = lio.Scan.voxel_downsample_batch(ss, 0.1)
+    for s_, m_, n_ in zip(ss, meta[:2], ns):
+        r_ = oracle_mod.voxel_downsample(m_["raw"], 0.1)
+        assert n_ == len(r_) and np.array_equal(s_.get_ds().view(np.uint32), r_.view(np.uint32))
