@@ -1015,7 +1015,7 @@ int incremental_classify(lio_map* m, lio_scan* s, const PoseArgs& pose, float ma
 // map_incremental (laserMapping.cpp:523-576) of every slot whose update finished, against its own map, then the read-back records
 int p2plane_seq_insert(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, SeqDev* d_seq, int n_slots, uint32_t ds_bound, int any_lru) {
     uint32_t blocks = (ds_bound + kClsThreads - 1) / kClsThreads;
-    if (blocks > 96u) blocks = 96u;  // (classify_seq / classify_scatter_seq stride over a slot's blocks: 96 x 256 = 24 576 points per sweep of the grid)
+    if (blocks > 64u) blocks = 64u;  // (classify_seq / classify_scatter_seq stride over a slot's blocks: 64 x 256 = 16 384 points per sweep of the grid)
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(seq_begin_insert_kernel, dim3((uint32_t)n_slots), 64, 0, st, d_maps, d_slots, d_seq);
     hipLaunchKernelGGL(classify_seq, dim3(blocks, (uint32_t)n_slots), kClsThreads, 0, st, d_maps, d_slots, d_seq);

@@ -163,6 +163,56 @@ def test_sessions_in_a_batch_equal_sessions_on_their_own(scene, lru, oracle_mod)
     b.close()
 
 
+def test_dense_sweeps_take_the_strided_insert_kernels_round_their_grid(scene):
+    """Round 5: classify_seq / classify_scatter_seq stride over a slot's blocks with a grid of 64 x 256 points.  Sweeps whose 0.5 m grid holds more points
+    than one sweep of that grid (~18 000) must leave the map a per-session engine leaves -- whose classify kernels are sized by the host -- bit for bit."""
+    from lsd_amd import capi, lio, synth
+
+    if capi.lib().lio_device_count() < 1:
+        pytest.fail("no HIP device")
+    P0 = lio.init_cov()
+    kw = dict(resolution=0.5, stencil=75, max_points=1_500_000, max_voxels=300_000, max_raw=1 << 17, max_ds=100000)
+    plans = []
+    for sidx in range(2):
+        start = np.array([3.0 * sidx, -2.0 * sidx, 1.8])
+        scans = []
+        for k in range(5):
+            pos = start + k * np.array([0.5, 0.1, 0.0])
+            q = synth.quat_from_rotvec([0, 0, 0.3 * sidx + 0.01 * k])
+            raw, _ = synth.make_scan(scene, pos, q, seed=7000 + 10 * sidx + k, n_az=2040, fov_deg=(-24.8, 2.0), max_range=150.0)
+            scans.append(dict(dptr=scenes.to_device(raw), n=len(raw), t=0.1 * k))
+        plans.append((scans, synth.state_from_pose(start, synth.quat_from_rotvec([0, 0, 0.3 * sidx]))))
+    solo = []
+    for scans, s0 in plans:
+        e = lio.Engine(**kw)
+        e.set_device_loop(True)
+        st, P = s0.copy(), P0.copy()
+        nds = []
+        for sc in scans:
+            e.set_state(st)
+            e.set_cov(P)
+            rc = e.process_scan_device(sc["dptr"], sc["n"], sc["t"])
+            if rc == 3:
+                st, P = _next_prior(dict(state=e.get_state(), cov=e.get_cov()))
+                nds.append(e.timings()["n_ds"])
+        e.flush()
+        solo.append(dict(stats=e.map.stats(), dump=_rows(e.map.dump()), state=e.get_state(), nds=nds))
+        e.close()
+    assert all(max(x["nds"]) > 16384 for x in solo), [x["nds"] for x in solo]  # (the point of the test)
+    b = lio.SequenceBatch(n_slots=2, n_groups=1, **kw)
+    priors = [(p[1].copy(), P0.copy()) for p in plans]
+    for k in range(5):
+        rc, res = b.step([dict(dptr=plans[s][0][k]["dptr"], n=plans[s][0][k]["n"], t=plans[s][0][k]["t"], state=priors[s][0], cov=priors[s][1]) for s in range(2)])
+        assert rc == 0
+        for s in range(2):
+            if res[s]["rc"] == 3:
+                priors[s] = _next_prior(res[s])
+    for s in range(2):
+        e = b.engine(s)
+        assert e.map.stats() == solo[s]["stats"] and np.array_equal(_rows(e.map.dump()), solo[s]["dump"]), s
+    b.close()
+
+
 def test_sequence_batch_rejects_what_it_cannot_run(scene):
     from lsd_amd import capi, lio
 
