@@ -392,7 +392,9 @@ int lio_engine_joint_register_device(lio_engine* e, const void* d_raw_body_xyzi,
 #define LIO_JOB_IDLE 2u         /* lio_batch_sequences_step: the session of this job has no scan this round (rc = 0, nothing else is looked at) */
 #define LIO_JOB_HOST_RAW 4u     /* lio_batch_process / lio_engines_process_batch: d_raw points to HOST memory (pinned for full PCIe rate: lio_pinned_alloc);
                                    the library copies the cloud to HBM on the round's stream, overlapped with the other rounds in flight -- the copy
-                                   the reference's boundary starts with (slam/src/py_utils.cpp:149-181, slam_wrapper.cpp:64-84).  Appended in round 5 */
+                                   the reference's boundary starts with (slam/src/py_utils.cpp:149-181, slam_wrapper.cpp:64-84).  The host buffer must
+                                   stay valid and unchanged until the call that took the job returns (the copy is asynchronous).  Not accepted by
+                                   lio_batch_sequences_step (rc = LIO_E_INVALID).  Appended in round 5 */
 #define LIO_JOB_FLAGS_KNOWN 7u  /* every other bit must be zero: a job with unknown bits is rejected (rc = LIO_E_INVALID), so that an uninitialised
                                    word cannot silently pick a behaviour */
 typedef struct lio_scan_job {
