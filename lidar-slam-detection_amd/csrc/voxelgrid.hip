@@ -184,9 +184,10 @@ __device__ inline VgGrid vg_derive(const uint32_t bmin[3], const uint32_t bmax[3
 template <bool FOLD>
 __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint32_t n, float inv, ScanDev* sd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
-                                                           uint32_t nblocks, const uint32_t* __restrict__ parts) {
+                                                           uint32_t nblocks, const uint32_t* __restrict__ parts, uint32_t bx = 0xFFFFFFFFu) {
+    if (bx == 0xFFFFFFFFu) bx = blockIdx.x;  // (the tile this call works on: the launch's own block unless the caller maps blocks to tiles itself)
     // the cloud's points first (they do not depend on the box), then the fold of the tiles' box records: every workgroup forms the same box
-    const uint32_t base = blockIdx.x * kTile;
+    const uint32_t base = bx * kTile;
     float4 p[kItems];
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
@@ -232,7 +233,7 @@ __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint
     }
     }
     const VgGrid g = vg_derive(bmin, bmax, n_valid, inv);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bx == 0 && threadIdx.x == 0) {
         if (FOLD) {
             for (int a = 0; a < 3; a++) { sd->bbox_min[a] = bmin[a]; sd->bbox_max[a] = bmax[a]; }
             sd->n_valid = n_valid;
@@ -260,7 +261,7 @@ __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint
         atomicAdd(&h[key & 255u], 1u);
     }
     __syncthreads();
-    hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];  // [tile][digit]: one coalesced 1-KiB row per workgroup
+    hist[bx * 256u + threadIdx.x] = h[threadIdx.x];  // [tile][digit]: one coalesced 1-KiB row per workgroup
 }
 
 // ---- stable LSD radix sort, 8 bits per pass, ping-pong a -> b -> a ... ------------------------------------
@@ -269,14 +270,15 @@ __device__ __forceinline__ void vg_keys_body(const float4* __restrict__ in, uint
 __device__ inline uint32_t active_passes(const ScanDev* sd) { return (sd->nbits + 7u) >> 3; }
 
 __device__ __forceinline__ void radix_hist_body(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
-                                                              int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
+                                                              int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd, uint32_t bx = 0xFFFFFFFFu) {
+    if (bx == 0xFFFFFFFFu) bx = blockIdx.x;  // (the tile this call works on: the launch's own block unless the caller maps blocks to tiles itself)
     // (the pass count is requested with the keys, not before them: one memory round trip instead of two; a pass above the significant bits has
     // loaded a tile it does not use)
     uint32_t nbits_w = sd->nbits;
     const uint32_t* keys = (pass & 1) ? kb : ka;
     const int shift = pass * 8;
     __shared__ uint32_t h[256];
-    const uint32_t base = blockIdx.x * kTile;
+    const uint32_t base = bx * kTile;
     // the tile's keys as kItems UNCONDITIONAL loads at clamped indices, all in flight before the first is used (`if (i < n) ... keys[i]` comes out of
     // the compiler as load + s_waitcnt vmcnt(0) per item: eight memory round trips one after the other -- tools/isa_load_chains.py)
     // (a histogram does not care which thread counts which key: every thread takes 2 x 4 CONSECUTIVE keys as two 16-byte loads -- a quarter of the
@@ -307,7 +309,7 @@ __device__ __forceinline__ void radix_hist_body(const uint32_t* __restrict__ ka,
         }
     }
     __syncthreads();
-    hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];  // [tile][digit]: one coalesced 1-KiB row per workgroup
+    hist[bx * 256u + threadIdx.x] = h[threadIdx.x];  // [tile][digit]: one coalesced 1-KiB row per workgroup
 }
 
 __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
@@ -331,7 +333,8 @@ __device__ inline unsigned long long match_digit(uint32_t d, bool valid) {
 template <bool PREFIXED>
 __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
-                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
+                                                                 const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd, uint32_t bx = 0xFFFFFFFFu) {
+    if (bx == 0xFFFFFFFFu) bx = blockIdx.x;  // (the tile this call works on: the launch's own block unless the caller maps blocks to tiles itself)
     uint32_t nbits_w = sd->nbits;  // (requested with the keys: see radix_hist_body)
     const uint32_t* kin = (pass & 1) ? kb : ka;
     const uint32_t* vin = (pass & 1) ? vb : va;
@@ -342,7 +345,7 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
     __shared__ uint32_t wcnt[kWaves][256];
     __shared__ uint32_t wsum[kWaves];
     // each wave owns a contiguous run of 64*kItems keys so that (round, lane) order == input order
-    const uint32_t base = blockIdx.x * kTile + wave * (64 * kItems);
+    const uint32_t base = bx * kTile + wave * (64 * kItems);
     uint32_t k[kItems], v[kItems];
     bool ok[kItems];
 #pragma unroll
@@ -364,7 +367,7 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
     //   base[d] = sum_{d' < d} total[d'] + sum_{b' < b} hist[d][b']      (digit-major, then tile order = stable)
     uint32_t tot = 0, pre = 0;
     if (PREFIXED) {
-        pre = hist[(size_t)blockIdx.x * 256u + tid];
+        pre = hist[(size_t)bx * 256u + tid];
         tot = hist[(size_t)nblocks * 256u + tid];
     } else {
         // [tile][digit] layout: for a given tile the 256 threads read one contiguous 1-KiB row (it used to be [digit][tile]: every lane
@@ -380,18 +383,18 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 tot += hv[k];
-                pre += (b + k < blockIdx.x) ? hv[k] : 0u;
+                pre += (b + k < bx) ? hv[k] : 0u;
             }
         }
         for (; b + 4 <= nblocks; b += 4) {
             const uint32_t h0 = col[(size_t)b * 256u], h1 = col[(size_t)(b + 1) * 256u], h2 = col[(size_t)(b + 2) * 256u], h3 = col[(size_t)(b + 3) * 256u];
             tot += (h0 + h1) + (h2 + h3);
-            pre += (b < blockIdx.x ? h0 : 0u) + (b + 1 < blockIdx.x ? h1 : 0u) + (b + 2 < blockIdx.x ? h2 : 0u) + (b + 3 < blockIdx.x ? h3 : 0u);
+            pre += (b < bx ? h0 : 0u) + (b + 1 < bx ? h1 : 0u) + (b + 2 < bx ? h2 : 0u) + (b + 3 < bx ? h3 : 0u);
         }
         for (; b < nblocks; b++) {
             const uint32_t h0 = col[(size_t)b * 256u];
             tot += h0;
-            pre += b < blockIdx.x ? h0 : 0u;
+            pre += b < bx ? h0 : 0u;
         }
     }
     uint32_t inc = tot;  // inclusive scan of the digit totals across the 256 threads
@@ -443,13 +446,14 @@ __device__ __forceinline__ void radix_scatter_body(uint32_t* __restrict__ ka, ui
 
 // ---- voxel heads: occupancy flags -> ballot + prefix-sum compaction -> centroid ------------------------
 __device__ __forceinline__ void vg_count_heads_body(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
-                                                                  const ScanDev* sd, uint32_t* __restrict__ blockcnt) {
+                                                                  const ScanDev* sd, uint32_t* __restrict__ blockcnt, uint32_t bx = 0xFFFFFFFFu) {
+    if (bx == 0xFFFFFFFFu) bx = blockIdx.x;  // (the tile this call works on: the launch's own block unless the caller maps blocks to tiles itself)
     const uint32_t* keys = (active_passes(sd) & 1) ? kb : ka;
     __shared__ uint32_t c;
     if (threadIdx.x == 0) c = 0;
     __syncthreads();
     const uint32_t total = sd->total_cells;
-    const uint32_t base = blockIdx.x * kTile;
+    const uint32_t base = bx * kTile;
     uint32_t mine = 0;
     // (2 x kItems unconditional loads at clamped indices, in flight together: see radix_hist_body)
     uint32_t kc[kItems], kp[kItems];
@@ -468,7 +472,7 @@ __device__ __forceinline__ void vg_count_heads_body(const uint32_t* __restrict__
     }
     if ((threadIdx.x & 63) == 0) atomicAdd(&c, mine);
     __syncthreads();
-    if (threadIdx.x == 0) blockcnt[blockIdx.x] = c;
+    if (threadIdx.x == 0) blockcnt[bx] = c;
 }
 
 // compaction of the voxel heads (ballot + prefix sum, fixed order) and the gather of the points into sorted order.
@@ -479,20 +483,21 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
                                                             const uint32_t* __restrict__ vb, uint32_t n, ScanDev* sd,
                                                             const uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ hpos,
                                                             float4* __restrict__ sorted, float4* __restrict__ out, uint32_t max_ds, uint32_t* __restrict__ host_nds,
-                                                            uint32_t launched_passes, uint32_t last_block) {
+                                                            uint32_t launched_passes, uint32_t last_block, uint32_t bx = 0xFFFFFFFFu) {
+    if (bx == 0xFFFFFFFFu) bx = blockIdx.x;  // (the tile this call works on: the launch's own block unless the caller maps blocks to tiles itself)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (sd->passthrough) {  // PCL overflow guard: output = input
-        if (blockIdx.x == 0 && tid == 0) host_nds[2] = 0u;
+        if (bx == 0 && tid == 0) host_nds[2] = 0u;
         if (n > max_ds) {
-            if (blockIdx.x == 0 && tid == 0) { sd->err |= 1u; sd->n_ds = 0; host_nds[0] = 0; host_nds[1] = 1u; }
+            if (bx == 0 && tid == 0) { sd->err |= 1u; sd->n_ds = 0; host_nds[0] = 0; host_nds[1] = 1u; }
             return;
         }
-        const uint32_t base = blockIdx.x * kTile;
+        const uint32_t base = bx * kTile;
         for (int r = 0; r < kItems; r++) {
             const uint32_t i = base + r * kThreads + tid;
             if (i < n) out[i] = in[i];
         }
-        if (blockIdx.x == 0 && tid == 0) { sd->n_ds = n; host_nds[0] = n; host_nds[1] = 0u; }
+        if (bx == 0 && tid == 0) { sd->n_ds = n; host_nds[0] = n; host_nds[1] = 0u; }
         return;
     }
     const bool odd = active_passes(sd) & 1;
@@ -501,7 +506,7 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
     __shared__ uint32_t red[kWaves];
     // exclusive prefix of the tiles before this one (fixed order -> deterministic output slots)
     uint32_t pre = 0;
-    for (uint32_t b = tid; b < blockIdx.x; b += kThreads) pre += blockcnt[b];
+    for (uint32_t b = tid; b < bx; b += kThreads) pre += blockcnt[b];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off);
     if (lane == 0) red[wave] = pre;
@@ -511,7 +516,7 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
     __syncthreads();
 
     const uint32_t total = sd->total_cells;
-    const uint32_t base = blockIdx.x * kTile;
+    const uint32_t base = bx * kTile;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // Round 4, second form.  Until then: per item { key, previous key, index, the gather through the index, two workgroup barriers } -- four dependent
     // memory round trips and two barriers eight times over (every load sat inside `if (i < n)`: load, s_waitcnt vmcnt(0), next load;
@@ -565,7 +570,7 @@ __device__ __forceinline__ void vg_heads_body(const float4* __restrict__ in, con
             if (i < n) sorted[i] = pt[k];
         }
     }
-    if (blockIdx.x == last_block && tid == 0) {
+    if (bx == last_block && tid == 0) {
         uint32_t err = 0;
         if (run > max_ds) { sd->err |= 1u; run = 0; err = 1u; }
         // the host launched as many radix passes as the previous scan needed; if this scan's bounding box needs more, the keys
@@ -883,6 +888,27 @@ __device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict
 }
 
 
+// XCD-aware workgroup -> (slot, tile) mapping for the tile kernels of the batched chain (LIO_VG_XCD=0 restores the plain mapping).  The dispatcher deals the
+// workgroups of a launch round-robin to the 8 XCDs in dispatch order (x fastest), each XCD with its own L2: with the plain mapping the 59-64 tiles of
+// ONE scan are spread over all eight L2s -- the scatter's partial-line writes into a scan's 256 digit regions, and the gather of its cloud, are
+// then merged / cached in eight places.  Here workgroup L (= blockIdx.x + gridDim.x * blockIdx.y) takes tile (L / 8) % T of slot
+// ((L / 8) / T) * 8 + L % 8: all tiles of a slot on one XCD.  Slots beyond the last whole group of eight keep the plain mapping.
+#ifndef LIO_VG_XCD
+#define LIO_VG_XCD 1  // (measured, round 5: vg_heads_batch 167 -> 124 us, radix_scatter_batch 79 -> 70 us per launch of 128 scans, chain 810 -> 757 us per round)
+#endif
+__device__ __forceinline__ void vg_slot_tile(uint32_t n_slots, uint32_t& slot, uint32_t& bx) {
+    slot = blockIdx.y;
+    bx = blockIdx.x;
+#if LIO_VG_XCD
+    const uint32_t T = gridDim.x, L = blockIdx.x + T * blockIdx.y, full = n_slots & ~7u;
+    if (L < full * T) {
+        const uint32_t j = L >> 3;
+        slot = (j / T) * 8u + (L & 7u);
+        bx = j % T;
+    }
+#endif
+}
+
 // ---- launchable forms: one scan (arguments by value), or the scans of a batch (blockIdx.y = slot, arguments from the slot's
 // descriptor in device memory; a workgroup beyond the slot's own tile count, or of an idle slot, exits at once) ----------------
 // the tiles' box records live in the head of the `sorted` buffer (free until vg_heads fills it): 32 bytes per tile
@@ -898,18 +924,22 @@ __global__ void __launch_bounds__(kThreads) vg_keys_kernel(const float4* __restr
     vg_keys_body<true>(in, n, inv, sd, keys, vals, hist, nblocks, parts);
 }
 __global__ void __launch_bounds__(kThreads) vg_keys_batch(const SlotDesc* __restrict__ slots, float inv) {
-    const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || blockIdx.x >= d.nblocks) return;
-    vg_keys_body<false>(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, nullptr);
+    uint32_t slot, bx;
+    vg_slot_tile(gridDim.y, slot, bx);
+    const SlotDesc& d = slots[slot];
+    if (!d.active || bx >= d.nblocks) return;
+    vg_keys_body<false>(d.raw, d.n_raw, inv, d.sd, d.keys_a, d.vals_a, d.hist, d.nblocks, nullptr, bx);
 }
 __global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ kb, uint32_t n,
                                                               int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
     radix_hist_body(ka, kb, n, pass, hist, nblocks, sd);
 }
 __global__ void __launch_bounds__(kThreads) radix_hist_batch(const SlotDesc* __restrict__ slots, int pass) {
-    const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || blockIdx.x >= d.nblocks) return;
-    radix_hist_body(d.keys_a, d.keys_b, d.n_raw, pass, d.hist, d.nblocks, d.sd);
+    uint32_t slot, bx;
+    vg_slot_tile(gridDim.y, slot, bx);
+    const SlotDesc& d = slots[slot];
+    if (!d.active || bx >= d.nblocks) return;
+    radix_hist_body(d.keys_a, d.keys_b, d.n_raw, pass, d.hist, d.nblocks, d.sd, bx);
 }
 __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
@@ -917,9 +947,11 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __res
     radix_scatter_body<false>(ka, va, kb, vb, n, pass, hist, nblocks, sd);
 }
 __global__ void __launch_bounds__(kThreads) radix_scatter_batch(const SlotDesc* __restrict__ slots, int pass) {
-    const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || blockIdx.x >= d.nblocks) return;
-    radix_scatter_body<true>(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd);
+    uint32_t slot, bx;
+    vg_slot_tile(gridDim.y, slot, bx);
+    const SlotDesc& d = slots[slot];
+    if (!d.active || bx >= d.nblocks) return;
+    radix_scatter_body<true>(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd, bx);
 }
 // one workgroup per scan: digit column d (thread d) of the tiles' histogram rows becomes its exclusive prefix over the tiles, the column's total
 // goes to row `nblocks` (sixteen rows in flight; integer sums: the scatter's positions are what the all-rows fold gave)
@@ -948,9 +980,11 @@ __global__ void __launch_bounds__(kThreads) vg_count_heads_kernel(const uint32_t
     vg_count_heads_body(ka, kb, n, sd, blockcnt);
 }
 __global__ void __launch_bounds__(kThreads) vg_count_heads_batch(const SlotDesc* __restrict__ slots) {
-    const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || blockIdx.x >= d.nblocks) return;
-    vg_count_heads_body(d.keys_a, d.keys_b, d.n_raw, d.sd, d.blockcnt);
+    uint32_t slot, bx;
+    vg_slot_tile(gridDim.y, slot, bx);
+    const SlotDesc& d = slots[slot];
+    if (!d.active || bx >= d.nblocks) return;
+    vg_count_heads_body(d.keys_a, d.keys_b, d.n_raw, d.sd, d.blockcnt, bx);
 }
 __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ ka,
                                                             const uint32_t* __restrict__ kb, const uint32_t* __restrict__ va,
@@ -961,10 +995,12 @@ __global__ void __launch_bounds__(kThreads) vg_heads_kernel(const float4* __rest
     vg_heads_body(in, ka, kb, va, vb, n, sd, blockcnt, hpos, sorted, out, max_ds, host_nds, launched_passes, gridDim.x - 1);
 }
 __global__ void __launch_bounds__(kThreads) vg_heads_batch(const SlotDesc* __restrict__ slots, uint32_t launched_passes) {
-    const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || blockIdx.x >= d.nblocks) return;
+    uint32_t slot, bx;
+    vg_slot_tile(gridDim.y, slot, bx);
+    const SlotDesc& d = slots[slot];
+    if (!d.active || bx >= d.nblocks) return;
     vg_heads_body(d.raw, d.keys_a, d.keys_b, d.vals_a, d.vals_b, d.n_raw, d.sd, d.blockcnt, d.hpos, d.sorted, d.ds_body, d.max_ds, d.host_nds,
-                  launched_passes, d.nblocks - 1);
+                  launched_passes, d.nblocks - 1, bx);
 }
 __global__ void __launch_bounds__(kThreads) vg_centroid_kernel(const float4* __restrict__ sorted, const uint32_t* __restrict__ hpos,
                                                                ScanDev* __restrict__ sd, float4* __restrict__ out,
