@@ -1979,7 +1979,7 @@ def bench_merge(args, torch, dist, world, rank, local_rank, dev):
         box = [lio.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm = lio.Comm(rank=rank, world=world, device=local_rank, uid=box[0])
-    args.slots, args.groups = min(args.slots, 32), min(args.groups, 3)  # every slot carries one scan buffer set PER LOCAL SUB-MAP: 8 x 32 x 3 of them at N = 1
+    args.slots, args.groups = min(args.slots, int(os.environ.get("LIO_MERGE_SLOTS", "32"))), min(args.groups, 3)  # every slot carries one scan buffer set PER LOCAL SUB-MAP: 8 x 32 x 3 of them at N = 1
     batch = lio.Batch(maps[0], n_slots=args.slots, n_groups=args.groups, max_raw=1 << 17, max_ds=100000, sub_maps=maps[1:], comm=comm)
     P0 = lio.init_cov()
     scans = []

@@ -42,6 +42,8 @@ struct Group {
     std::vector<lio_engine*> sub_eng;    // joint mode: the scan buffer sets of the further local sub-maps, [(m - 1) * B + slot]
     double* d_local32 = nullptr;         // joint mode: this rank's record per slot (B x 32), and every rank's (world x B x 32)
     double* d_gathered = nullptr;
+    MapRef* d_rowmaps = nullptr;         // joint mode: the sub-map behind every descriptor row [m * B + slot] -- ONE neighbour-search launch per pass
+    std::vector<const void*> rowmap_tables;  // ... as uploaded (refreshed when a sub-map's table moved)
     char* d_block = nullptr;             // [SlotDesc x B (x sub-maps)][EskfDev x B]: one upload per round
     char* h_block = nullptr;             // pinned staging, same layout
     size_t block_bytes = 0;
@@ -96,8 +98,36 @@ struct lio_batch {
     uint64_t n_rounds = 0;
 };
 
+static void fill_mapref(MapRef& r, const lio_map* m);
+
 namespace {
 
+// joint mode: the MapRef of every descriptor row (sub-map m, slot s) on the device, so that ONE launch of the neighbour search serves all local
+// sub-maps of a pass (knn_seq_kernel, the kernel of the sequence batch: table / pool / counters from the row's MapRef).  Null when the sub-maps do
+// not share one stencil (the per-sub-map launches stay then).
+const MapRef* joint_rowmaps(lio_batch* b, Group& g) {
+    const int M = (int)b->maps.size(), B = b->n_slots;
+    if (M < 2) return nullptr;
+    for (int m = 1; m < M; m++)
+        if (b->maps[m]->stencil_id != b->maps[0]->stencil_id || b->maps[m]->stencil.n != b->maps[0]->stencil.n) return nullptr;
+    bool fresh = g.d_rowmaps != nullptr && (int)g.rowmap_tables.size() == M;
+    for (int m = 0; m < M && fresh; m++) fresh = g.rowmap_tables[m] == (const void*)b->maps[m]->table;
+    if (fresh) return g.d_rowmaps;
+    std::vector<MapRef> rows((size_t)M * B);
+    for (int m = 0; m < M; m++) {
+        MapRef r;
+        memset(&r, 0, sizeof(r));
+        fill_mapref(r, b->maps[m]);
+        for (int s = 0; s < B; s++) rows[(size_t)m * B + s] = r;
+    }
+    if (!g.d_rowmaps && hipMalloc(reinterpret_cast<void**>(&g.d_rowmaps), sizeof(MapRef) * rows.size()) != hipSuccess) { g.d_rowmaps = nullptr; return nullptr; }
+    // (stream-ordered behind the round before it, which may still read the old table)
+    if (hipMemcpyAsync(g.d_rowmaps, rows.data(), sizeof(MapRef) * rows.size(), hipMemcpyHostToDevice, g.stream) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return nullptr;  // (rows is a local: rare -- creation, or a sub-map whose table was rebuilt)
+    g.rowmap_tables.assign(M, nullptr);
+    for (int m = 0; m < M; m++) g.rowmap_tables[m] = b->maps[m]->table;
+    return g.d_rowmaps;
+}
 
 void fill_desc(SlotDesc& d, lio_scan* sc, EskfDev* d_ctrl, lio_batch_result* d_res) {
     d.max_ds = sc->max_ds;
@@ -129,6 +159,7 @@ void group_free(Group& g) {
     for (lio_engine* e : g.sub_eng) lio_engine_destroy(e);
     if (g.d_local32) hipFree(g.d_local32);
     if (g.d_gathered) hipFree(g.d_gathered);
+    if (g.d_rowmaps) hipFree(g.d_rowmaps);
     for (int k = 0; k < 5; k++)
         if (g.exec[k]) hipGraphExecDestroy(g.exec[k]);
     if (g.d_block) hipFree(g.d_block);
@@ -220,6 +251,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
     // the sequence is captured once into a graph and replayed with a single hipGraphLaunch -- ~35 API calls of 5-15 us each otherwise,
     // which made the one submitting host thread the bottleneck.  Grids are sized for the batch's max_raw (surplus workgroups exit at once).
     const bool timed = g.bt && g.bt->on;
+    const MapRef* rowmaps = b->joint ? joint_rowmaps(b, g) : nullptr;
     auto enqueue = [&](BatchTimer* bt) -> int {
         LIO_HIP_TRY(hipMemcpyAsync(g.d_block, g.h_block, g.block_bytes, hipMemcpyHostToDevice, g.stream));
         if (bt) bt->begin(0);
@@ -232,7 +264,8 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
             rc = p2plane_batch_share(g.stream, g.d_desc, B, M, ds_bound);
             if (rc == LIO_OK) rc = scan_begin_rows(g.stream, g.d_desc + B, B * (M - 1));
             if (rc != LIO_OK) return rc;
-            return p2plane_batch_update_joint(b->maps.data(), M, b->comm, b->world, b->gather_hook, b->gather_ctx, g.stream, g.d_desc, B, ds_bound, 5, g.d_local32, g.d_gathered, bt);
+            return p2plane_batch_update_joint(b->maps.data(), M, b->comm, b->world, b->gather_hook, b->gather_ctx, g.stream, g.d_desc, B, ds_bound, 5, g.d_local32, g.d_gathered, bt,
+                                              rowmaps);
         }
         return p2plane_batch_update(b->map, g.stream, g.d_desc, B, ds_bound, 5, bt, bt ? b->count_touched : 0);
     };

@@ -355,7 +355,7 @@ struct lio_comm;
 namespace lio {
 int p2plane_batch_share(hipStream_t st, const SlotDesc* d_descs, int n_slots, int n_maps, uint32_t ds_bound);
 int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, int (*gather_hook)(void*, const double*, double*, uint32_t, void*), void* gather_ctx, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
-                               int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt);
+                               int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt, const MapRef* d_rowmaps = nullptr);
 int scan_begin_rows(hipStream_t st, const SlotDesc* d_descs, int n_rows);
 int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);

@@ -717,12 +717,27 @@ int p2plane_batch_share(hipStream_t st, const SlotDesc* d_descs, int n_slots, in
 int lio_allgather_records_internal(::lio_comm* c, const double* d_local, double* d_gathered, uint32_t n_records, hipStream_t st);  // comm.hip
 int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, int (*gather_hook)(void*, const double*, double*, uint32_t, void*),
                                void* gather_ctx, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
-                               int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt) {
+                               int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt, const MapRef* d_rowmaps) {
     uint32_t lin_blocks = (ds_bound + kLinThreads - 1) / kLinThreads;
     if (lin_blocks > kLinGridCap) lin_blocks = kLinGridCap;  // (linearize_batch strides over a slot's blocks)
     if (lin_blocks == 0) lin_blocks = 1;
     for (int p = 0; p < n_passes; p++) {
-        for (int m = 0; m < n_maps; m++) {
+        if (d_rowmaps) {
+            // round 5: ONE neighbour search (+ its tie redo) and ONE linearisation over all [sub-map x slot] rows of the pass -- the rows are independent;
+            // a launch per local sub-map was 3 M launches per pass (24 with eight sub-maps on one GPU), each filling a fraction of the chip.  The search
+            // kernel is the sequence batch's (table / pool / counters from the row's MapRef instead of kernel arguments): the same body, the same bits
+            const int rows = n_maps * n_slots;
+            const StencilArgs& sa = maps[0]->stencil;
+            const int sid = maps[0]->stencil_id;
+            if (bt) bt->begin(1);
+            const int rc = knn_seq_launch(st, d_rowmaps, d_descs, rows, (ds_bound + 15) / 16, &sa, &sid, 1);
+            if (bt) bt->end(1);
+            if (rc != LIO_OK) return rc;
+            if (bt) bt->begin(2);
+            hipLaunchKernelGGL(linearize_batch, dim3(lin_blocks, (uint32_t)rows), kLinThreads, 0, st, d_descs);
+            if (bt) bt->end(2);
+        }
+        for (int m = 0; m < n_maps && !d_rowmaps; m++) {
             const SlotDesc* row = d_descs + (size_t)m * n_slots;
             if (bt) bt->begin(1);
             const int rc = knn_batch_launch(maps[m], st, row, n_slots, (ds_bound + 15) / 16, 0);
