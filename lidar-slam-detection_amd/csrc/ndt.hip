@@ -1416,8 +1416,11 @@ int lio_ndt_align_batch(lio_ndt* n, lio_align_job* jobs, int n_jobs, const lio_n
             for (int k = 0; k < 6 && r < max_rounds; k++, r++) {
 #define NDTB_LAUNCH(NO)                                                                                                                          \
     do {                                                                                                                                         \
-        hipLaunchKernelGGL((ndt_cost_batch<true, NO>), grid, kNdtThreads, 0, st, n->res, n->offs, n->d_slots);  \
-        hipLaunchKernelGGL((ndt_cost_batch<false, NO>), grid, kNdtThreads, 0, st, n->res, n->offs, n->d_slots); \
+        /* phase 0 (the linearisation at the guess) exists in the first round of a chunk only: later rounds launched this kernel for every slot to   \
+           find, one memory round trip per workgroup, that it had nothing to do -- and the trial kernel likewise in round 0 (782 x 64 one-wave     \
+           workgroups per launch; round 5) */               \
+        if (r == 0) hipLaunchKernelGGL((ndt_cost_batch<true, NO>), grid, kNdtThreads, 0, st, n->res, n->offs, n->d_slots);  \
+        else hipLaunchKernelGGL((ndt_cost_batch<false, NO>), grid, kNdtThreads, 0, st, n->res, n->offs, n->d_slots); \
     } while (0)
                 if (n->offs.n == 1) NDTB_LAUNCH(1);
                 else if (n->offs.n == 7) NDTB_LAUNCH(7);
