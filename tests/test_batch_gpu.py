@@ -295,3 +295,31 @@ def test_large_clouds_take_the_strided_kernels_round_their_grids(oracle_mod):
     for s_, m_, n_ in zip(ss, meta[:2], ns):
         r_ = oracle_mod.voxel_downsample(m_["raw"], 0.1)
         assert n_ == len(r_) and np.array_equal(s_.get_ds().view(np.uint32), r_.view(np.uint32))
+
+
+def test_xcd_aware_tile_mapping_with_a_ragged_slot_count(oracle_mod):
+    """Round 5: the batched chain maps workgroup L to tile (L / 8) % T of slot ((L / 8) / T) * 8 + L % 8 for the slots of whole groups of eight and keeps
+    blockIdx for the rest.  Twelve and nineteen scans per launch (one / two whole groups + a remainder), of different sizes incl. an empty one: every
+    scan's downsampled cloud equals the oracle's bit for bit, in order."""
+    _dev()
+    from lsd_amd import lio, synth
+
+    scene = scenes.config_scene()
+    rng = np.random.default_rng(5)
+    clouds = []
+    for k in range(19):
+        pos = np.array([rng.uniform(-20, 20), rng.uniform(-20, 20), 1.8])
+        q = synth.quat_from_rotvec([0, 0, rng.uniform(-np.pi, np.pi)])
+        raw, _ = synth.make_scan(scene, pos, q, seed=8200 + k, n_az=120 + 40 * (k % 5), fov_deg=(-24.8, 2.0), max_range=120.0)
+        clouds.append(raw if k != 7 else raw[:0])
+    refs = [oracle_mod.voxel_downsample(c, 0.5) if len(c) else np.zeros((0, 4), np.float32) for c in clouds]
+    scans = [lio.Scan(max_raw=1 << 15, max_ds=20000) for _ in range(19)]
+    for s_, c in zip(scans, clouds):
+        if len(c):
+            s_.upload(c)
+    for count in (12, 19):
+        live = [(s_, r_) for s_, c, r_ in zip(scans[:count], clouds[:count], refs[:count]) if len(c)]
+        ns = lio.Scan.voxel_downsample_batch([s_ for s_, _ in live], 0.5)
+        assert len(live) in (11, 18)
+        for (s_, r_), n_ in zip(live, ns):
+            assert n_ == len(r_) and np.array_equal(s_.get_ds().view(np.uint32), r_.view(np.uint32))
