@@ -53,8 +53,9 @@ int lio_device_count(void);
  * entry points).  History: 4 = round 4 (lio_batch_times grew by insert_us / insert_launches / pad: a caller that allocates the round-3 struct and
  * calls a revision-4 library is written past -- rebuild, or check the revision and allocate sizeof(lio_batch_times) of THIS header;
  * lio_timings.n_added may be -1 = "insert still in flight, not read back"; lio_engine_timings may return a deferred LIO_E_CAPACITY);
- * 5 = round 5 (LIO_JOB_HOST_RAW, lio_pinned_alloc / lio_pinned_free, lio_abi_version itself). */
-#define LIO_ABI_VERSION 5
+ * 5 = round 5 (LIO_JOB_HOST_RAW, lio_pinned_alloc / lio_pinned_free, lio_abi_version itself);
+ * 6 = round 6 (lio_map_set_tie_mode / lio_map_tie_stats: candidates exactly as far as the fifth nearest are now kept as the reference keeps them). */
+#define LIO_ABI_VERSION 6
 int lio_abi_version(void);
 /* page-locked host memory for clouds handed over with LIO_JOB_HOST_RAW (or lio_scan_upload): copies from it run at the link's rate and
  * overlap with kernels; NULL on failure.  Any hipHostMalloc'ed / hipHostRegister'ed range serves as well. */
@@ -91,6 +92,16 @@ int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double
  * point order drops and re-creates it; here it keeps its points -- the one case where the maps can differ). */
 int lio_map_set_lru(lio_map*, uint64_t capacity_voxels, double max_distance);
 int lio_map_lru_stats(lio_map*, uint64_t* n_evicted, uint64_t* n_interleaved);
+/* Which five, when the fifth and the sixth nearest candidate of a query are EXACTLY equally far (f32 d2).  IVox::GetClosestPoint cuts every stencil
+ * voxel's in-range points to five and then the whole list to five with std::nth_element on the distance alone (ivox3d_node.hpp:107-127,
+ * ivox3d.h:156-164): which of the equally distant candidates survives is what libstdc++'s introselect does to that particular sequence (stencil
+ * order, push_back order inside a voxel).  mode 1 (default): the same survivor -- the map keeps every point's push_back rank, and the exact redo
+ * of tied queries runs the same selection on the same sequence (csrc/refsel.h); mode 0: the five smallest in (d2, x, y, z), the definition of
+ * rounds 1-5.  The two differ only on such ties (about one query in 1e6 on sensor data); the returned lists are in the canonical order either way.
+ * lio_map_tie_stats: queries whose set the selection decided so far, and how many of those could not be resolved (a stencil voxel with more than
+ * 2048 in-range points: the canonical set was kept) -- 0 unless a map holds voxels of thousands of points. */
+int lio_map_set_tie_mode(lio_map*, int mode);
+int lio_map_tie_stats(lio_map*, uint64_t* n_boundary_ties, uint64_t* n_unresolved);
 /* capacity planning: slots of the point pool handed out so far by the bump allocator (recycled regions of evicted / outgrown
  * voxels are re-used first and do not move it) and the pool's size, both in points of 16 B */
 int lio_map_pool_stats(lio_map*, uint64_t* pool_top, uint64_t* pool_cap);
@@ -104,7 +115,7 @@ uint64_t lio_map_knn_touched(lio_map*);
 /* all stored points, voxel by voxel in unspecified order; returns the count or -(needed) */
 int64_t lio_map_dump(lio_map*, float* out_xyzi, uint64_t cap_points);
 /* IVox::GetClosestPoint(pt, out, 5, 5.0) for a batch of world-frame queries (ivox3d.h:139-171):
- * out_pts is n x 5 x 4 floats in the canonical order (d2, x, y, z) ascending, out_cnt[n] the number
+ * out_pts is n x 5 x 4 floats -- the reference's five (lio_map_set_tie_mode) in the canonical order (d2, x, y, z) ascending, out_cnt[n] the number
  * found (0..5).  Test/diagnostic entry; the per-scan path uses lio_p2plane_linearize. */
 int lio_map_knn(lio_map*, const float* world_xyzi, uint32_t n, float* out_pts, int32_t* out_cnt);
 

@@ -622,7 +622,7 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
 // go through the slot's engine, i.e. through lio_engine_process_scan_device's own code: a session driven here and one driven scan by scan
 // through an engine with the device loop on (lio_engine_set_device_loop) run the same kernels on the same data.
 static void fill_mapref(MapRef& r, const lio_map* m) {
-    r.table = m->table; r.cap = m->cap; r.pending = m->pending; r.created = m->created; r.pool = m->pool; r.md = m->dev;
+    r.table = m->table; r.cap = m->cap; r.pending = m->pending; r.created = m->created; r.pool = m->pool; r.pool_seq = m->pool_seq; r.tie_mode = m->tie_mode; r.md = m->dev;
     r.slot_of_point = m->slot_of_point; r.stage = m->stage; r.pool_cap = m->pool_cap;
     r.touch = m->touch; r.prev_touch = m->prev_touch; r.lru_log = m->lru_log; r.log_mask = m->lru_log_cap ? m->lru_log_cap - 1 : 0;
     r.free_items = m->free_items; r.free_in = m->free_in; r.free_cap = m->free_cap;

@@ -134,6 +134,58 @@ int wait_report(lio_scan* s) {
 
 using namespace lio;
 
+// key_mode 0: an iVox map (with the per-point insertion sequence numbers the tie-exact neighbour redo reads); 1 / 2: the Gaussian-voxel grids of
+// the NDT / VGICP matchers, which have no neighbour lists to break ties in
+lio_map* lio::map_create_mode(int device, float resolution, uint64_t max_points, uint64_t max_voxels, int stencil, int key_mode) {
+    if (!(resolution > 0.f) || max_points == 0 || max_voxels == 0) { set_error("lio_map_create: bad argument"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("lio_map_create: no HIP device %d (this library has no CPU fallback)", device); return nullptr; }
+    lio_map* m = new lio_map();
+    memset(m, 0, sizeof(*m));
+    m->device = device;
+    m->res = resolution;
+    m->inv_res = 1.0f / resolution;
+    m->max_points = max_points;
+    m->max_voxels = max_voxels;
+    m->key_mode = key_mode;
+    m->tie_mode = 1;
+    if (fill_stencil(m->stencil, stencil) != LIO_OK) { set_error("lio_map_create: stencil must be 1, 7, 19, 27 or 75"); delete m; return nullptr; }
+    m->stencil_id = stencil;
+    uint64_t cap = 1024;
+    while (cap < max_voxels * 2) cap <<= 1;  // load factor <= 0.5
+    if (cap > 0x40000000ull) { set_error("lio_map_create: max_voxels too large"); delete m; return nullptr; }
+    m->table_cap = (uint32_t)cap;
+    m->table_mask = (uint32_t)cap - 1;
+    // voxel regions double when they fill up and the old region is not recycled: <= 2 x (2 x points + 8 x voxels)
+    m->pool_cap = 4 * max_points + 16 * max_voxels;
+    if (m->pool_cap > 0xFFFFFFF0ull) m->pool_cap = 0xFFFFFFF0ull;
+    m->slot_of_point_cap = max_points;
+    m->stage_cap = 1u << 20;
+    bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
+    m->own_stream = ok;
+    ok = ok && dev_alloc(&m->table, cap, &m->bytes) && dev_alloc(&m->cap, cap, &m->bytes) && dev_alloc(&m->pending, cap, &m->bytes) &&
+         dev_alloc(&m->created, cap, &m->bytes) && dev_alloc(&m->pool, m->pool_cap, &m->bytes) && dev_alloc(&m->dev, 1, &m->bytes) &&
+         dev_alloc(&m->slot_of_point, m->slot_of_point_cap, &m->bytes) && dev_alloc(&m->tile_sum, cap / 2048 + 1, &m->bytes) && dev_alloc(&m->stage, m->stage_cap, &m->bytes);
+    if (key_mode == 0) ok = ok && dev_alloc(&m->pool_seq, m->pool_cap, &m->bytes);
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&m->host_dev), sizeof(MapDev)) == hipSuccess;
+    if (ok) {
+        ok = hipMemsetAsync(m->table, 0xFF, cap * sizeof(Slot), m->stream) == hipSuccess &&  // key = empty; ptr/cnt fixed below
+             hipMemsetAsync(m->cap, 0, cap * 4, m->stream) == hipSuccess && hipMemsetAsync(m->pending, 0, cap * 4, m->stream) == hipSuccess &&
+             hipMemsetAsync(m->dev, 0, sizeof(MapDev), m->stream) == hipSuccess;
+    }
+    if (ok) {
+        // cnt must start at 0: clear the (ptr, cnt) halves with a strided 2D memset
+        ok = hipMemset2DAsync(reinterpret_cast<char*>(m->table) + 8, sizeof(Slot), 0, 8, cap, m->stream) == hipSuccess &&
+             hipStreamSynchronize(m->stream) == hipSuccess;
+    }
+    if (!ok) {
+        if (!g_err[0]) set_error("lio_map_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
+        lio_map_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+
 extern "C" {
 
 const char* lio_last_error(void) { return g_err; }
@@ -160,49 +212,7 @@ void lio_pinned_free(void* p) {
 uint64_t lio_map_bytes(const lio_map* m) { return m ? m->bytes : 0; }
 
 lio_map* lio_map_create(int device, float resolution, uint64_t max_points, uint64_t max_voxels, int stencil) {
-    if (!(resolution > 0.f) || max_points == 0 || max_voxels == 0) { set_error("lio_map_create: bad argument"); return nullptr; }
-    if (hipSetDevice(device) != hipSuccess) { set_error("lio_map_create: no HIP device %d (this library has no CPU fallback)", device); return nullptr; }
-    lio_map* m = new lio_map();
-    memset(m, 0, sizeof(*m));
-    m->device = device;
-    m->res = resolution;
-    m->inv_res = 1.0f / resolution;
-    m->max_points = max_points;
-    m->max_voxels = max_voxels;
-    if (fill_stencil(m->stencil, stencil) != LIO_OK) { set_error("lio_map_create: stencil must be 1, 7, 19, 27 or 75"); delete m; return nullptr; }
-    m->stencil_id = stencil;
-    uint64_t cap = 1024;
-    while (cap < max_voxels * 2) cap <<= 1;  // load factor <= 0.5
-    if (cap > 0x40000000ull) { set_error("lio_map_create: max_voxels too large"); delete m; return nullptr; }
-    m->table_cap = (uint32_t)cap;
-    m->table_mask = (uint32_t)cap - 1;
-    // voxel regions double when they fill up and the old region is not recycled: <= 2 x (2 x points + 8 x voxels)
-    m->pool_cap = 4 * max_points + 16 * max_voxels;
-    if (m->pool_cap > 0xFFFFFFF0ull) m->pool_cap = 0xFFFFFFF0ull;
-    m->slot_of_point_cap = max_points;
-    m->stage_cap = 1u << 20;
-    bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
-    m->own_stream = ok;
-    ok = ok && dev_alloc(&m->table, cap, &m->bytes) && dev_alloc(&m->cap, cap, &m->bytes) && dev_alloc(&m->pending, cap, &m->bytes) &&
-         dev_alloc(&m->created, cap, &m->bytes) && dev_alloc(&m->pool, m->pool_cap, &m->bytes) && dev_alloc(&m->dev, 1, &m->bytes) &&
-         dev_alloc(&m->slot_of_point, m->slot_of_point_cap, &m->bytes) && dev_alloc(&m->tile_sum, cap / 2048 + 1, &m->bytes) && dev_alloc(&m->stage, m->stage_cap, &m->bytes);
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&m->host_dev), sizeof(MapDev)) == hipSuccess;
-    if (ok) {
-        ok = hipMemsetAsync(m->table, 0xFF, cap * sizeof(Slot), m->stream) == hipSuccess &&  // key = empty; ptr/cnt fixed below
-             hipMemsetAsync(m->cap, 0, cap * 4, m->stream) == hipSuccess && hipMemsetAsync(m->pending, 0, cap * 4, m->stream) == hipSuccess &&
-             hipMemsetAsync(m->dev, 0, sizeof(MapDev), m->stream) == hipSuccess;
-    }
-    if (ok) {
-        // cnt must start at 0: clear the (ptr, cnt) halves with a strided 2D memset
-        ok = hipMemset2DAsync(reinterpret_cast<char*>(m->table) + 8, sizeof(Slot), 0, 8, cap, m->stream) == hipSuccess &&
-             hipStreamSynchronize(m->stream) == hipSuccess;
-    }
-    if (!ok) {
-        if (!g_err[0]) set_error("lio_map_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
-        lio_map_destroy(m);
-        return nullptr;
-    }
-    return m;
+    return map_create_mode(device, resolution, max_points, max_voxels, stencil, 0);
 }
 
 // back to an empty map without giving the memory back (a matcher's setInputTarget replaces its target: hipFree + hipMalloc of the pool and the
@@ -224,7 +234,7 @@ void lio_map_destroy(lio_map* m) {
     if (!m) return;
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
-    hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->dev);
+    hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->pool_seq); hipFree(m->dev);
     hipFree(m->slot_of_point); hipFree(m->tile_sum); hipFree(m->stage);
     hipFree(m->touch); hipFree(m->prev_touch); hipFree(m->touch2); hipFree(m->prev_touch2); hipFree(m->lru_log); hipFree(m->free_items); hipFree(m->free_in);
     hipFree(m->table2); hipFree(m->cap2); hipFree(m->pending2); hipFree(m->created2); hipFree(m->remap);
@@ -266,6 +276,22 @@ int lio_map_lru_stats(lio_map* m, uint64_t* n_evicted, uint64_t* n_interleaved) 
     const int rc = map_check(m, m->stream);
     if (n_evicted) *n_evicted = m->host_dev->n_evicted;
     if (n_interleaved) *n_interleaved = m->host_dev->n_lru_interleaved;
+    return rc;
+}
+
+int lio_map_set_tie_mode(lio_map* m, int mode) {
+    if (!m || (mode != 0 && mode != 1)) return LIO_E_INVALID;
+    if (mode == 1 && !m->pool_seq) { set_error("lio_map_set_tie_mode: not an iVox map"); return LIO_E_STATE; }
+    m->tie_mode = mode;
+    return LIO_OK;
+}
+
+int lio_map_tie_stats(lio_map* m, uint64_t* n_boundary, uint64_t* n_unresolved) {
+    if (!m) return LIO_E_INVALID;
+    hipSetDevice(m->device);
+    const int rc = map_check(m, m->stream);
+    if (n_boundary) *n_boundary = m->host_dev->n_tie_boundary;
+    if (n_unresolved) *n_unresolved = m->host_dev->n_tie_unresolved;
     return rc;
 }
 

@@ -477,9 +477,8 @@ int gicp_set_cloud(lio_gicp* g, int which, const float* xyzi, uint32_t n) {
     // The grid object is made once and emptied in place afterwards (map_clear: memsets; a fresh lio_map_create per call was 5-65 ms of
     // hipMalloc / hipFree, more than the covariances)
     if (!g->grid[which]) {
-        g->grid[which] = lio_map_create(g->device, g->res, g->max_points, g->max_points, 1);
+        g->grid[which] = map_create_mode(g->device, g->res, g->max_points, g->max_points, 1, 1);
         if (!g->grid[which]) return LIO_E_DEVICE;
-        g->grid[which]->key_mode = 1;
     } else {
         const int rc0 = map_clear(g->grid[which]);
         if (rc0 != LIO_OK) return rc0;
@@ -507,9 +506,8 @@ int vgicp_build(lio_gicp* g) {
         hipFree(g->vvox); g->vvox = nullptr;
     }
     if (!g->vmap) {
-        g->vmap = lio_map_create(g->device, (float)g->voxel_res, g->max_points, g->max_points, 1);
+        g->vmap = map_create_mode(g->device, (float)g->voxel_res, g->max_points, g->max_points, 1, 2);
         if (!g->vmap) return LIO_E_DEVICE;
-        g->vmap->key_mode = 2;
         LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->vvox), (size_t)g->vmap->table_cap * sizeof(VgicpVoxel)));
     } else {
         const int rc0 = map_clear(g->vmap);

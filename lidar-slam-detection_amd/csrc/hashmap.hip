@@ -33,6 +33,11 @@ __device__ __forceinline__ void map_insert_claim_body(Slot* table, uint32_t mask
                                                                unsigned long long* __restrict__ touch, unsigned long long* __restrict__ prev_touch,
                                                                unsigned long long stamp_base) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the batch's sequence numbers (read by the write kernel, a later launch): seq_acc .. seq_acc + n
+        const uint32_t base = md->seq_acc;
+        md->seq_cur = base;
+        md->seq_acc = base + (uint32_t)n;
+    }
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const float4 p = pts[i];
@@ -84,7 +89,7 @@ __device__ __forceinline__ void map_insert_claim_body(Slot* table, uint32_t mask
 }
 
 __device__ __forceinline__ void map_insert_grow_body(Slot* table, uint32_t* __restrict__ cap, uint32_t* __restrict__ pending,
-                                                              float4* pool, unsigned long long pool_cap, unsigned long long n_host,
+                                                              float4* pool, uint32_t* seq, unsigned long long pool_cap, unsigned long long n_host,
                                                               const uint32_t* __restrict__ n_dev, MapDev* md,
                                                               const uint32_t* __restrict__ slot_of_point, const uint32_t* __restrict__ free_items,
                                                               uint32_t free_cap, uint32_t* __restrict__ free_in) {
@@ -129,6 +134,7 @@ __device__ __forceinline__ void map_insert_grow_body(Slot* table, uint32_t* __re
         }
         const uint32_t old = table[h].ptr, old_cap = cap[h];
         for (uint32_t j = 0; j < have; j++) pool[at + j] = pool[old + j];
+        if (seq) for (uint32_t j = 0; j < have; j++) seq[at + j] = seq[old + j];
         table[h].ptr = (uint32_t)at;
         cap[h] = ncap;
         if (free_in && old_cap >= 8) {  // the outgrown region is recycled (without this an LRU map leaks ~one slot per inserted point)
@@ -227,19 +233,25 @@ __global__ void __launch_bounds__(256) map_layout_assign_kernel(Slot* table, uin
     }
 }
 
-__device__ __forceinline__ void map_insert_write_body(Slot* table, const uint32_t* __restrict__ cap, float4* pool,
-                                                               const float4* __restrict__ pts, unsigned long long n_host,
+__device__ __forceinline__ void map_insert_write_body(Slot* table, const uint32_t* __restrict__ cap, float4* pool, uint32_t* __restrict__ seq,
+                                                               const MapDev* __restrict__ md, const float4* __restrict__ pts, unsigned long long n_host,
                                                                const uint32_t* __restrict__ n_dev,
                                                                const uint32_t* __restrict__ slot_of_point) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
+    // A point's place inside its voxel's region is its arrival rank at the slot's counter -- any order; its push_back rank (the batch's first
+    // sequence number + its index in the batch) is written beside it
+    const uint32_t seq0 = seq ? md->seq_cur : 0u;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t sp = slot_of_point[i];
         if (sp == kNoIdx) continue;
         const uint32_t h = sp & 0x7FFFFFFFu;
         const uint32_t idx = atomicAdd(&table[h].cnt, 1u);
-        if (idx < cap[h]) pool[(unsigned long long)table[h].ptr + idx] = pts[i];
-        else atomicSub(&table[h].cnt, 1u);  // only after a pool overflow (err bit 2): cnt never exceeds cap, readers stay in bounds
+        if (idx < cap[h]) {
+            const unsigned long long at = (unsigned long long)table[h].ptr + idx;
+            pool[at] = pts[i];
+            if (seq) seq[at] = seq0 + (uint32_t)i;
+        } else atomicSub(&table[h].cnt, 1u);  // only after a pool overflow (err bit 2): cnt never exceeds cap, readers stay in bounds
     }
 }
 
@@ -455,27 +467,28 @@ __global__ void __launch_bounds__(256) map_insert_claim_seq(const MapRef* __rest
     map_insert_claim_body(r.table, r.mask, r.pending, r.created, r.stage, 0ull, &r.md->n_add, r.inv_res, r.res, r.key_mode, (float)seq[blockIdx.y].travel,
                           r.max_voxels, r.md, r.slot_of_point, r.lru_capacity ? r.touch : nullptr, r.prev_touch, r.stamp_base);
 }
-__global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint32_t* __restrict__ cap, uint32_t* __restrict__ pending, float4* pool,
+__global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint32_t* __restrict__ cap, uint32_t* __restrict__ pending, float4* pool, uint32_t* seq,
                                                               unsigned long long pool_cap, unsigned long long n_host, const uint32_t* __restrict__ n_dev,
                                                               MapDev* md, const uint32_t* __restrict__ slot_of_point, const uint32_t* __restrict__ free_items,
                                                               uint32_t free_cap, uint32_t* __restrict__ free_in) {
-    map_insert_grow_body(table, cap, pending, pool, pool_cap, n_host, n_dev, md, slot_of_point, free_items, free_cap, free_in);
+    map_insert_grow_body(table, cap, pending, pool, seq, pool_cap, n_host, n_dev, md, slot_of_point, free_items, free_cap, free_in);
 }
 __global__ void __launch_bounds__(256) map_insert_grow_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
     if (!seq[blockIdx.y].go) return;
     const MapRef& r = maps[blockIdx.y];
-    map_insert_grow_body(r.table, r.cap, r.pending, r.pool, r.pool_cap, 0ull, &r.md->n_add, r.md, r.slot_of_point, r.lru_capacity ? r.free_items : nullptr,
+    map_insert_grow_body(r.table, r.cap, r.pending, r.pool, r.pool_seq, r.pool_cap, 0ull, &r.md->n_add, r.md, r.slot_of_point, r.lru_capacity ? r.free_items : nullptr,
                          r.free_cap, r.lru_capacity ? r.free_in : nullptr);
 }
-__global__ void __launch_bounds__(256) map_insert_write_kernel(Slot* table, const uint32_t* __restrict__ cap, float4* pool, const float4* __restrict__ pts,
+__global__ void __launch_bounds__(256) map_insert_write_kernel(Slot* table, const uint32_t* __restrict__ cap, float4* pool, uint32_t* __restrict__ seq,
+                                                               const MapDev* __restrict__ md, const float4* __restrict__ pts,
                                                                unsigned long long n_host, const uint32_t* __restrict__ n_dev,
                                                                const uint32_t* __restrict__ slot_of_point) {
-    map_insert_write_body(table, cap, pool, pts, n_host, n_dev, slot_of_point);
+    map_insert_write_body(table, cap, pool, seq, md, pts, n_host, n_dev, slot_of_point);
 }
 __global__ void __launch_bounds__(256) map_insert_write_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
     if (!seq[blockIdx.y].go) return;
     const MapRef& r = maps[blockIdx.y];
-    map_insert_write_body(r.table, r.cap, r.pool, r.stage, 0ull, &r.md->n_add, r.slot_of_point);
+    map_insert_write_body(r.table, r.cap, r.pool, r.pool_seq, r.md, r.stage, 0ull, &r.md->n_add, r.slot_of_point);
 }
 __global__ void __launch_bounds__(1024) lru_append_kernel(const uint32_t* __restrict__ slot_of_point, const unsigned long long* __restrict__ touch,
                                                           unsigned long long n_host, const uint32_t* __restrict__ n_dev, unsigned long long stamp_base,
@@ -594,11 +607,11 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
         hipLaunchKernelGGL(map_layout_scan_kernel, 1, 1024, 0, stream, m->tile_sum, ntiles, m->dev, (unsigned long long)m->pool_cap);
         hipLaunchKernelGGL(map_layout_assign_kernel, ntiles, 256, 0, stream, m->table, m->cap, m->pending, m->table_cap, m->tile_sum);
     } else {
-        hipLaunchKernelGGL(map_insert_grow_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->cap, m->pending, m->pool,
+        hipLaunchKernelGGL(map_insert_grow_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->cap, m->pending, m->pool, m->pool_seq,
                            (unsigned long long)m->pool_cap, (unsigned long long)n, d_n, m->dev, m->slot_of_point, lru ? m->free_items : nullptr,
                            m->free_cap, lru ? m->free_in : nullptr);
     }
-    hipLaunchKernelGGL(map_insert_write_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->cap, m->pool, d_pts,
+    hipLaunchKernelGGL(map_insert_write_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->cap, m->pool, m->pool_seq, m->dev, d_pts,
                        (unsigned long long)n, d_n, m->slot_of_point);
     if (lru) {
         hipLaunchKernelGGL(lru_append_kernel, 1, 1024, 0, stream, m->slot_of_point, m->touch, (unsigned long long)n, d_n, stamp_base, m->lru_log,

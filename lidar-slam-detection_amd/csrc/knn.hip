@@ -24,6 +24,7 @@
 #include "hashgrid.h"
 #include "knn_dev.h"
 #include "lio_common.h"
+#include "refsel.h"
 
 namespace lio {
 
@@ -592,18 +593,123 @@ __global__ void LIO_KNN_OCC __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kern
 }
 
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
+// Two steps.  (1) The canonical list: the five smallest in the strict total order (d2, x, y, z), sixteen lanes per query.  It is the answer
+// unless the fifth and the sixth of that order are equally far -- then WHICH of the equally distant candidates belong to the five is the
+// reference's to say (ivox3d_node.hpp:107-127, ivox3d.h:156-164: std::nth_element on the distance alone, whatever it leaves in front).
+// (2) Such a query is redone by the whole workgroup the way the reference does it: stencil voxels in nearby_grids_ order, a voxel's in-range
+// points in push_back order (the pool keeps arrival order; MapDev's sequence numbers restore the push_back order), each voxel cut to five,
+// the list cut to five -- refsel.h restates libstdc++'s introselect, one lane runs it on the list in LDS.  The survivors are written in the
+// canonical order.  About one query in a million on sensor data; a map of lattice points sends every query here (tests).
+constexpr int kSelCap = 2048;  // in-range points of ONE stencil voxel the staging area holds
+struct SelLds {
+    uint32_t a_d[kSelCap], a_id[kSelCap], a_seq[kSelCap];  // one voxel's in-range candidates in pool order
+    refsel::Rec list[kSelCap + 5 * kMaxStencil + 8];        // the reference's candidate list: five per voxel done + the voxel in hand
+    uint32_t v_ptr[kMaxStencil], v_cnt[kMaxStencil];        // the stencil's voxels in nearby_grids_ order
+    uint32_t wsum[4];
+    int size;
+    uint32_t queue[kGPB], n_queue;
+};
+
+template <int MODE>
+__device__ __noinline__ void refsel_query(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, const uint32_t* __restrict__ seq,
+                                          float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries, uint32_t q,
+                                          float4* __restrict__ nn_pts, uint32_t nn_stride, MapDev* md, SelLds& S) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 pw;
+    {
+        const float4 pq = queries[q];
+        if (MODE == 0) body_to_world(pose, pq, pw);
+        else pw = pq;
+    }
+    int kx = 0, ky = 0, kz = 0;
+    pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
+    if (tid < st.n) {
+        uint32_t ptr = 0, cnt = 0;
+        grid_find(table, mask, kx + st.off[tid][0], ky + st.off[tid][1], kz + st.off[tid][2], ptr, cnt);
+        S.v_ptr[tid] = ptr;
+        S.v_cnt[tid] = cnt;
+    }
+    if (tid == 0) S.size = 0;
+    __syncthreads();
+    bool overflow = false;
+    for (int sv = 0; sv < st.n && !overflow; sv++) {
+        const uint32_t cnt = S.v_cnt[sv], ptr = S.v_ptr[sv];
+        if (cnt == 0) continue;  // (workgroup-uniform)
+        uint32_t m = 0;
+        for (uint32_t base = 0; base < cnt; base += 256) {  // ivox3d_node.hpp:111-116, pool order
+            const uint32_t i = base + (uint32_t)tid;
+            const bool have = i < cnt;
+            const float4 p = pool[have ? ptr + i : ptr];
+            const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
+            const float d2 = dx * dx + (dy * dy + dz * dz);
+            const bool in = have && d2 < 5.0f;
+            const unsigned long long bal = __ballot(in);
+            if (lane == 0) S.wsum[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t at = m + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; w++) at += S.wsum[w];
+            const uint32_t tot = (S.wsum[0] + S.wsum[1]) + (S.wsum[2] + S.wsum[3]);
+            if (in && at < (uint32_t)kSelCap) {
+                S.a_d[at] = __float_as_uint(d2);
+                S.a_id[at] = ptr + i;
+                S.a_seq[at] = seq[ptr + i];
+            }
+            m += tot;
+            __syncthreads();
+        }
+        if (m > (uint32_t)kSelCap) { overflow = true; break; }
+        // push_back order: rank by sequence number (signed difference: the counter wraps), equal numbers -- never inside one voxel short of a
+        // wrap -- by pool position
+        const int size = S.size;
+        for (uint32_t e = (uint32_t)tid; e < m; e += 256) {
+            const uint32_t se = S.a_seq[e];
+            uint32_t r = 0;
+            for (uint32_t f = 0; f < m; f++) {
+                const uint32_t sf = S.a_seq[f];
+                r += ((int32_t)(sf - se) < 0 || (sf == se && f < e)) ? 1u : 0u;
+            }
+            refsel::Rec rec;
+            rec.d = S.a_d[e];
+            rec.id = S.a_id[e];
+            S.list[size + (int)r] = rec;
+        }
+        __syncthreads();
+        if (tid == 0) S.size = refsel::voxel_cut(S.list, size, size + (int)m, 5);  // ivox3d_node.hpp:119-124
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (overflow) {
+            atomicAdd(&md->n_tie_unresolved, 1ull);  // (the canonical list written by step 1 stays)
+        } else {
+            const int n = refsel::final_cut(S.list, S.size, 5);  // ivox3d.h:156-162
+            Cand c[5];
+            for (int k = 0; k < n; k++) {  // the survivors in the canonical order
+                Cand x = {__uint_as_float(S.list[k].d), S.list[k].id};
+                int at = k;
+                while (at > 0 && cand_less(x, c[at - 1], pool)) { c[at] = c[at - 1]; at--; }
+                c[at] = x;
+            }
+            for (int k = 0; k < n; k++) nn_pts[(size_t)k * nn_stride + q] = pool[c[k].id];
+        }
+        atomicAdd(&md->n_tie_boundary, 1ull);
+    }
+    __syncthreads();
+}
+
 template <int KM, int MODE>
 __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
                                                float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
-                                               const uint32_t* __restrict__ tie_list) {
+                                               const uint32_t* __restrict__ tie_list, const uint32_t* __restrict__ seq, MapDev* md, int tie_mode) {
     __shared__ GroupLds lds[kGPB];
+    __shared__ SelLds sel;
     const int tid = threadIdx.x;
     const int grp = tid / kG, gl = tid % kG;
     const int lane = tid & 63;
     GroupLds& g = lds[grp];
     const uint32_t n = *n_tie;
     const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
+    const bool as_reference = tie_mode != 0 && seq != nullptr;
     for (uint32_t w0 = blockIdx.x * kGPB; w0 < n; w0 += gridDim.x * kGPB) {
         const uint32_t w = w0 + grp;
         const bool active = w < n;
@@ -618,9 +724,11 @@ __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, u
         pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
         uint32_t nhit = 0;
         const uint32_t total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
+        if (tid == 0) sel.n_queue = 0;
         __syncthreads();
-        Cand e[5];
-        for (int k = 0; k < 5; k++) e[k] = {INFINITY, kNoIdx};
+        // every lane keeps its SIX smallest: the sixth of the whole query decides whether the fifth place is contested
+        Cand e[6];
+        for (int k = 0; k < 6; k++) e[k] = {INFINITY, kNoIdx};
         (void)total;
         // two voxels x four points per lane and step, the eight loads requested together (clamped, unconditional; the list is zero-filled behind
         // its end).  One load per step made a tied query ~24 memory round trips one after the other, and this kernel sits on the round's critical
@@ -654,9 +762,9 @@ __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, u
                         const float d2 = dx * dx + (dy * dy + dz * dz);
                         if (d2 < 5.0f) {
                             Cand cd = {d2, id};
-                            if (cand_less(cd, e[4], pool)) {
-                                e[4] = cd;
-                                for (int kk = 4; kk > 0; kk--)
+                            if (cand_less(cd, e[5], pool)) {
+                                e[5] = cd;
+                                for (int kk = 5; kk > 0; kk--)
                                     if (cand_less(e[kk], e[kk - 1], pool)) { const Cand t = e[kk - 1]; e[kk - 1] = e[kk]; e[kk] = t; }
                             }
                         }
@@ -664,7 +772,8 @@ __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, u
             }
         }
         uint32_t win = kNoIdx;
-        for (int r = 0; r < 5; r++) {
+        float d_fifth = -1.f, d_sixth = -2.f;
+        for (int r = 0; r < 6; r++) {
             Cand best = e[0];
             for (int off = kG / 2; off > 0; off >>= 1) {
                 Cand o;
@@ -672,13 +781,21 @@ __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, u
                 o.id = __shfl_xor(best.id, off, kG);
                 if (cand_less(o, best, pool)) best = o;
             }
-            if (gl == r) win = best.id;
+            if (r < 5 && gl == r) win = best.id;
+            if (best.id != kNoIdx) {
+                if (r == 4) d_fifth = best.d2;
+                if (r == 5) d_sixth = best.d2;
+            }
             if (best.id != kNoIdx && e[0].id == best.id) {
-                for (int k = 0; k < 4; k++) e[k] = e[k + 1];
-                e[4] = {INFINITY, kNoIdx};
+                for (int k = 0; k < 5; k++) e[k] = e[k + 1];
+                e[5] = {INFINITY, kNoIdx};
             }
         }
         if (active && gl < 5 && win != kNoIdx) nn_pts[(size_t)gl * nn_stride + q] = pool[win];
+        if (as_reference && active && gl == 0 && d_fifth == d_sixth) sel.queue[atomicAdd(&sel.n_queue, 1u)] = q;
+        __syncthreads();
+        const uint32_t nq = sel.n_queue;
+        for (uint32_t k = 0; k < nq; k++) refsel_query<MODE>(table, mask, pool, seq, inv_res, st, pose, queries, sel.queue[k], nn_pts, nn_stride, md, sel);
         __syncthreads();
     }
 }
@@ -687,20 +804,21 @@ template <int KM, int MODE>
 __global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                         float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
                                                         float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
-                                                        const uint32_t* __restrict__ tie_list) {
-    knn_exact_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, nn_pts, nn_stride, n_tie, tie_list);
+                                                        const uint32_t* __restrict__ tie_list, const uint32_t* __restrict__ seq, MapDev* md, int tie_mode) {
+    knn_exact_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, nn_pts, nn_stride, n_tie, tie_list, seq, md, tie_mode);
 }
 // batch form: the queries the search of this pass queued (usually none: the kernel then ends at once); the queue is re-armed by the
 // filter-pass kernel that follows the linearisation
 template <int KM>
 __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
-                                                              float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots) {
+                                                              float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots,
+                                                              const uint32_t* __restrict__ seq, MapDev* md, int tie_mode) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active || d.sd->n_tie == 0) return;
     const SlotGate sg = slot_gate(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
     const PoseArgs& pose = sg.pose;
-    knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list);
+    knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, seq, md, tie_mode);
 }
 
 // Tied queries are queued and redone by a second (usually empty) launch.  (Measured and dropped in round 3: redoing them in place -- one
@@ -725,7 +843,7 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
     do {                                                                                                                                             \
         if (count_touched) hipLaunchKernelGGL((knn_batch_kernel<KM, true>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
         else hipLaunchKernelGGL((knn_batch_kernel<KM, false>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
-        hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots);       \
+        hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->pool_seq, m->dev, m->tie_mode); \
     } while (0)
     if (km <= 1) KNNB_LAUNCH(1);
     else if (km <= 2) KNNB_LAUNCH(2);
@@ -759,7 +877,7 @@ __global__ void __launch_bounds__(256) knn_exact_seq_kernel(const MapRef* __rest
     const SlotGate sg = slot_gate(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
     const PoseArgs& pose = sg.pose;
-    knn_exact_body<KM, 0>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list);
+    knn_exact_body<KM, 0>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, r.pool_seq, r.md, r.tie_mode);
 }
 
 int knn_seq_launch(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, const StencilArgs* stencils, const int* stencil_ids,
@@ -819,7 +937,7 @@ static int launch_knn_exact(lio_map* m, hipStream_t st, const PoseArgs& pose, co
     if (blocks > 4096) blocks = 4096;
 #define KNNX_LAUNCH(KM)                                                                                                                      \
     hipLaunchKernelGGL((knn_exact_kernel<KM, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q, nn_pts, \
-                       nn_stride, n_tie, tie_list)
+                       nn_stride, n_tie, tie_list, m->pool_seq, m->dev, m->tie_mode)
     const int km = (m->stencil.n + kG - 1) / kG;
     if (km <= 1) KNNX_LAUNCH(1);
     else if (km <= 2) KNNX_LAUNCH(2);

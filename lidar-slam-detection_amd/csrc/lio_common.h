@@ -79,6 +79,12 @@ struct MapDev {
     unsigned long long n_lru_interleaved;  // LRU-back voxels that the batch evicting around them also touched (see hashmap.hip)
     int free_top[24];                // recycled pool regions by size class (floor(log2(capacity)))
     int free_in_top[24];             // regions freed by the grow kernel of the current batch (folded into free_top by lru_evict_kernel)
+    // push_back order inside a voxel (ivox3d_node.hpp:87-90): every inserted point gets the running count of points offered to AddPoints before it
+    // (mod 2^32, compared by signed difference); the tie-exact neighbour redo sorts a voxel's candidates by it (knn.hip, refsel.h)
+    uint32_t seq_cur;                // first sequence number of the batch being inserted (set by its claim kernel)
+    uint32_t seq_acc;                // ... of the next batch
+    unsigned long long n_tie_boundary;    // queries whose fifth and sixth nearest were equally far: the set came from the reference's selection
+    unsigned long long n_tie_unresolved;  // ... of those, the ones whose voxel lists did not fit the redo's staging area: canonical set kept
     unsigned long long knn_cand[64 * 16];  // 64 shards, one 128-B line each (same-line atomics serialise in one L2 channel): word 0 = points resident in
                                            // the probed stencil voxels, word 1 = points the sweep loaded (diagnostic kernel variant only)
 };
@@ -149,6 +155,7 @@ struct MapRef {
     uint32_t* pending;
     float* created;
     float4* pool;
+    uint32_t* pool_seq;              // per pool entry: insertion sequence number (null for maps that are not iVox maps)
     MapDev* md;
     uint32_t* slot_of_point;
     float4* stage;
@@ -168,6 +175,7 @@ struct MapRef {
     float inv_res, res;
     int key_mode;
     uint32_t max_voxels;
+    int tie_mode;                    // lio_map_set_tie_mode
     int stencil_id;                  // the map's stencil this round (a launch of the neighbour search serves the slots of one stencil)
     uint32_t do_insert;              // the round's scan enters the map when its update finishes on the device (map_incremental, laserMapping.cpp:1304)
     uint32_t ekf_inited;             // flg_EKF_inited of this scan (laserMapping.cpp:1201)
@@ -223,6 +231,8 @@ struct lio_map {
     uint32_t* pending;   // per-slot staging counter of a batch insert
     float* created;      // per-slot travel distance at creation (ivox3d.h:240)
     float4* pool;
+    uint32_t* pool_seq;  // insertion sequence number of every pool entry (iVox maps only: key_mode 0)
+    int tie_mode;        // 1 (default): equally distant candidates at the fifth place are kept as the reference keeps them; 0: smallest (d2, x, y, z)
     lio::MapDev* dev;
     lio::MapDev* host_dev;  // pinned mirror
     // map_incremental enqueued on the map's own stream and not yet looked at by the host (map_incremental_async / map_settle)
@@ -361,6 +371,7 @@ int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);
 void kt_begin(lio_scan* s, int which);
 void kt_end(lio_scan* s, int which);
+lio_map* map_create_mode(int device, float resolution, uint64_t max_points, uint64_t max_voxels, int stencil, int key_mode);
 int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t n, const uint32_t* d_n, double travel);
 int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);
 int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt, uint32_t* d_tie);

@@ -1112,9 +1112,8 @@ lio_ndt* lio_ndt_create(int device, float resolution, int search_method, uint64_
     memset(n, 0, sizeof(*n));
     if (fill_offsets(n->offs, search_method) != LIO_OK) { set_error("lio_ndt_create: search method must be 1, 7 or 27"); delete n; return nullptr; }
     n->method = search_method;
-    n->map = lio_map_create(device, resolution, max_points, max_voxels, 1);
+    n->map = map_create_mode(device, resolution, max_points, max_voxels, 1, 1);
     if (!n->map) { delete n; return nullptr; }
-    n->map->key_mode = 1;
     n->device = device;
     n->res = resolution;
     n->max_src = max_source_points;

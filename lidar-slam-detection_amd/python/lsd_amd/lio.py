@@ -62,6 +62,16 @@ class Map:
         check(lib().lio_map_lru_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_tie_mode(self, mode):
+        """1 (default): candidates exactly as far as the fifth nearest are kept as the reference's std::nth_element keeps them; 0: smallest (d2, x, y, z)"""
+        check(lib().lio_map_set_tie_mode(self.h, int(mode)), "set_tie_mode")
+
+    def tie_stats(self):
+        """(queries whose neighbour set the reference's selection decided, those of them left unresolved)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().lio_map_tie_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def pool_stats(self):
         top, cap = C.c_uint64(), C.c_uint64()
         check(lib().lio_map_pool_stats(self.h, C.byref(top), C.byref(cap)), "pool stats")

@@ -47,9 +47,11 @@
 // results can be compared bit-for-bit): all per-point f32 arithmetic is written
 // as explicit, sequential IEEE operations and this file is compiled with
 // -ffp-contract=off (no FMA fusion); sqrt and division are correctly rounded.
-// Neighbour sets are put in a canonical total order (d2, x, y, z): the
-// reference only guarantees "element 0 is the nearest, the rest unordered"
-// (ivox3d.h:160-165), of which the canonical order is one valid instance.
+// Neighbour SETS are the reference's, exact ties at the fifth-nearest distance
+// included (IVox::closest); the five are then put in a canonical total order
+// (d2, x, y, z): the reference only guarantees "element 0 is the nearest, the
+// rest unordered" (ivox3d.h:160-165), of which the canonical order is one
+// valid instance.
 // =============================================================================
 #include <algorithm>
 #include <cmath>
@@ -230,22 +232,94 @@ class IVox {
     // ivox3d.h:139-171.  Returns false and leaves `closest` UNTOUCHED when no
     // candidate lies inside the stencil within the range (ivox3d.h:152-154):
     // the caller's stale content survives, as in the reference.
-    bool closest(const P4& q, std::vector<P4>& closest_pt, int max_num, double max_sq, std::vector<Cand>& scratch) const {
-        scratch.clear();
+    //
+    // WHICH five: the reference's.  Every stencil voxel, in nearby_grids_ order,
+    // appends its in-range points in push_back order and is cut to max_num by
+    // std::nth_element on `dist` alone (ivox3d_node.hpp:107-127); the whole list
+    // is cut to max_num the same way (ivox3d.h:156-164).  Candidates exactly as
+    // far as the max_num-th nearest are kept or dropped by what libstdc++'s
+    // introselect does to that sequence -- this file is compiled against the
+    // same libstdc++ as oracle/_ref, so the calls are made literally.
+    // ORDER of the five: the canonical total order (the reference leaves the
+    // nearest in front and the rest as introselect happened to leave them; no
+    // caller depends on it, common_lib.h:236-268 fits a plane to the set).
+    // tie_mode 0 restores the earlier definition (the five smallest in
+    // (d2, x, y, z)), which differs only when the fifth and sixth distances are
+    // equal.
+    int tie_mode = 1;
+    struct DistPoint {  // ivox3d_node.hpp:71-84: ordered by dist alone
+        double dist;
+        P4 p;
+        bool operator<(const DistPoint& o) const { return dist < o.dist; }
+    };
+    // the reference's selection, literally: fills `cand` with the list GetClosestPoint ends with; returns the number of in-range candidates seen
+    size_t select_as_reference(const P4& q, int max_num, double max_sq, std::vector<DistPoint>& cand) const {
+        cand.clear();
+        cand.reserve((size_t)max_num * nearby.size());
         Key3 key = pos2grid(q);
+        size_t seen = 0;
         for (const Key3& d : nearby) {
             auto it = grids.find(Key3{key.x + d.x, key.y + d.y, key.z + d.z});
             if (it == grids.end()) continue;
-            for (const P4& p : it->second->second.pts) {
-                float d2 = dist2(p, q);
-                if ((double)d2 < max_sq) scratch.push_back({d2, p});
+            const size_t old_size = cand.size();
+            for (const P4& p : it->second->second.pts) {  // ivox3d_node.hpp:111-116
+                double dd = (double)dist2(p, q);
+                if (dd < max_sq) cand.push_back({dd, p});
+            }
+            seen += cand.size() - old_size;
+            if (old_size + (size_t)max_num >= cand.size()) {  // ivox3d_node.hpp:119-124
+            } else {
+                std::nth_element(cand.begin() + old_size, cand.begin() + old_size + max_num - 1, cand.end());
+                cand.resize(old_size + max_num);
             }
         }
-        if (scratch.empty()) return false;
-        size_t k = std::min((size_t)max_num, scratch.size());
-        std::partial_sort(scratch.begin(), scratch.begin() + k, scratch.end(), cand_less);
+        if (cand.empty()) return 0;
+        if (cand.size() <= (size_t)max_num) {  // ivox3d.h:156-161
+        } else {
+            std::nth_element(cand.begin(), cand.begin() + max_num - 1, cand.end());
+            cand.resize(max_num);
+        }
+        std::nth_element(cand.begin(), cand.begin(), cand.end());  // ivox3d.h:162
+        return seen;
+    }
+    // (on return scratch.size() == the in-range candidates seen: callers read the count off it)
+    bool closest(const P4& q, std::vector<P4>& closest_pt, int max_num, double max_sq, std::vector<Cand>& scratch) const {
+        scratch.clear();
+        if (tie_mode == 0) {
+            Key3 key = pos2grid(q);
+            for (const Key3& d : nearby) {
+                auto it = grids.find(Key3{key.x + d.x, key.y + d.y, key.z + d.z});
+                if (it == grids.end()) continue;
+                for (const P4& p : it->second->second.pts) {
+                    float d2 = dist2(p, q);
+                    if ((double)d2 < max_sq) scratch.push_back({d2, p});
+                }
+            }
+            if (scratch.empty()) return false;
+            size_t k = std::min((size_t)max_num, scratch.size());
+            std::partial_sort(scratch.begin(), scratch.begin() + k, scratch.end(), cand_less);
+            closest_pt.clear();
+            for (size_t i = 0; i < k; i++) closest_pt.push_back(scratch[i].p);
+            return true;
+        }
+        std::vector<DistPoint> cand;
+        const size_t seen = select_as_reference(q, max_num, max_sq, cand);
+        if (cand.empty()) return false;
+        for (const DistPoint& c : cand) scratch.push_back({(float)c.dist, c.p});
+        std::sort(scratch.begin(), scratch.end(), cand_less);
         closest_pt.clear();
-        for (size_t i = 0; i < k; i++) closest_pt.push_back(scratch[i].p);
+        for (const Cand& c : scratch) closest_pt.push_back(c.p);
+        scratch.resize(seen);  // (callers read the number of candidates off the scratch list)
+        return true;
+    }
+    // the same query with the list exactly as the reference returns it (nearest first, the rest as introselect leaves them): pinned against
+    // the compiled ivox3d.h element by element (tests/test_oracle_vs_ref.py)
+    bool closest_as_reference(const P4& q, std::vector<P4>& closest_pt, int max_num, double max_sq) const {
+        std::vector<DistPoint> cand;
+        select_as_reference(q, max_num, max_sq, cand);
+        if (cand.empty()) return false;
+        closest_pt.clear();
+        for (const DistPoint& c : cand) closest_pt.push_back(c.p);
         return true;
     }
     size_t num_points() const {
@@ -1575,6 +1649,22 @@ void* orc_ivox_create(float res, int stencil, uint64_t capacity, double max_dist
 void orc_ivox_destroy(void* h) { delete static_cast<IVox*>(h); }
 void orc_ivox_set_stencil(void* h, int stencil) { static_cast<IVox*>(h)->set_stencil(stencil); }
 void orc_ivox_add(void* h, const float* pts, int n, double travel) { static_cast<IVox*>(h)->add_points(reinterpret_cast<const P4*>(pts), n, travel); }
+void orc_ivox_set_tie_mode(void* h, int mode) { static_cast<IVox*>(h)->tie_mode = mode; }
+// GetClosestPoint(pt, out, 5, 5.0) with the list as the reference returns it; out_pts n x 5 x 4
+void orc_ivox_knn_as_reference(void* h, const float* q_xyzi, int n, float* out_pts, int* out_cnt) {
+    IVox* iv = static_cast<IVox*>(h);
+    const P4* q = reinterpret_cast<const P4*>(q_xyzi);
+    std::vector<P4> near;
+    for (int i = 0; i < n; i++) {
+        near.clear();
+        iv->closest_as_reference(q[i], near, 5, 5.0);
+        out_cnt[i] = (int)near.size();
+        for (int k = 0; k < 5; k++) {
+            P4 o = k < (int)near.size() ? near[k] : P4{0.f, 0.f, 0.f, 0.f};
+            memcpy(out_pts + ((size_t)i * 5 + k) * 4, &o, 16);
+        }
+    }
+}
 uint64_t orc_ivox_num_voxels(void* h) { return static_cast<IVox*>(h)->grids.size(); }
 uint64_t orc_ivox_num_points(void* h) { return static_cast<IVox*>(h)->num_points(); }
 int64_t orc_ivox_dump(void* h, float* out, uint64_t cap) {  // all stored points, list order (most recently touched voxel first)
@@ -1646,6 +1736,7 @@ void orc_lio_set_flags(void* h, int ekf_inited, int first_scan, double travel, d
     l->travel = travel;
     l->first_lidar_time = first_lidar_time;
 }
+void orc_lio_set_tie_mode(void* h, int mode) { static_cast<Lio*>(h)->ivox.tie_mode = mode; }
 void orc_lio_set_stencil(void* h, int s) { static_cast<Lio*>(h)->ivox.set_stencil(s); }
 void orc_lio_map_add(void* h, const float* pts, int n, double travel) { static_cast<Lio*>(h)->ivox.add_points(reinterpret_cast<const P4*>(pts), n, travel); }
 uint64_t orc_lio_map_num_points(void* h) { return static_cast<Lio*>(h)->ivox.num_points(); }

@@ -45,6 +45,9 @@ def lib():
     L.orc_ivox_create.restype = C.c_void_p
     L.orc_ivox_destroy.argtypes = [C.c_void_p]
     L.orc_ivox_set_stencil.argtypes = [C.c_void_p, C.c_int]
+    L.orc_ivox_set_tie_mode.argtypes = [C.c_void_p, C.c_int]
+    L.orc_lio_set_tie_mode.argtypes = [C.c_void_p, C.c_int]
+    L.orc_ivox_knn_as_reference.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.orc_ivox_add.argtypes = [C.c_void_p, f32p, C.c_int, C.c_double]
     L.orc_ivox_num_voxels.argtypes = [C.c_void_p]
     L.orc_ivox_num_voxels.restype = C.c_uint64
@@ -188,6 +191,18 @@ class IVox:
         visited = lib().orc_ivox_knn(self.h, _p(q, C.c_float), len(q), _p(out, C.c_float), _p(cnt, C.c_int), threads)
         return out, cnt, int(visited)
 
+    def set_tie_mode(self, mode):
+        """1 (default): the reference's own choice among candidates exactly as far as the fifth nearest; 0: the five smallest in (d2, x, y, z)"""
+        lib().orc_ivox_set_tie_mode(self.h, int(mode))
+
+    def knn_as_reference(self, q):
+        """the list exactly as GetClosestPoint returns it (nearest first, the rest as std::nth_element leaves them)"""
+        q = _f32(q).reshape(-1, 4)
+        out = np.zeros((len(q), 5, 4), np.float32)
+        cnt = np.zeros(len(q), np.int32)
+        lib().orc_ivox_knn_as_reference(self.h, _p(q, C.c_float), len(q), _p(out, C.c_float), _p(cnt, C.c_int))
+        return out, cnt
+
     def stencil_points(self, q):
         q = _f32(q).reshape(-1, 4)
         return int(lib().orc_ivox_stencil_points(self.h, _p(q, C.c_float), len(q)))
@@ -249,6 +264,9 @@ class Lio:
 
     def set_stencil(self, s):
         lib().orc_lio_set_stencil(self.h, s)
+
+    def set_tie_mode(self, mode):
+        lib().orc_lio_set_tie_mode(self.h, int(mode))
 
     def map_add(self, pts, travel=0.0):
         p = _f32(pts).reshape(-1, 4)

@@ -133,6 +133,88 @@ def test_knn_exact_ties_and_duplicates(oracle_mod):
         assert np.array_equal(ref_pts[..., :3].view(np.uint32), got_pts[..., :3].view(np.uint32))
 
 
+def _tie_lattice(rng, n, step=0.0625, half=1.5, first_id=1):
+    """points on a dyadic lattice (exact f32 distances: ties everywhere), each with its own intensity so that WHICH of two equally distant
+    points was kept can be read off the result"""
+    ijk = rng.integers(-int(half / step), int(half / step) + 1, (n, 3))
+    return np.concatenate([ijk * step, np.arange(n)[:, None] + float(first_id)], 1).astype(np.float32)
+
+
+def test_knn_boundary_ties_are_the_references(oracle_mod):
+    """Candidates EXACTLY as far as the fifth nearest: the kernels keep the ones the reference keeps -- std::nth_element over the stencil's
+    candidates in nearby_grids_ / push_back order, every voxel cut to five first (ivox3d_node.hpp:107-127, ivox3d.h:156-164; csrc/refsel.h on
+    the device, the push_back rank of every map point kept beside it).  Lattice map, inserted in several batches (voxels grow and move: the ranks
+    move with them), intensities identify the points: all four components of all five neighbours must equal the oracle's, which is pinned
+    element for element to the compiled ivox3d.h (tests/test_oracle_vs_ref.py) -- and, where that library is present, the reference's own."""
+    _dev()
+    from lsd_amd import lio
+
+    import ref as refmod
+
+    rng = np.random.default_rng(21)
+    decided = 0
+    for trial in range(3):
+        pts = _tie_lattice(rng, 20000 + 10000 * trial)
+        q = _tie_lattice(rng, 4000)
+        q[:, :3] += np.float32(0.03125) * (trial % 2)
+        cuts = sorted(rng.choice(len(pts), 4, replace=False).tolist())
+        for st in (19, 7, 27, 75, 1):
+            iv = oracle_mod.IVox(res=0.5, stencil=st)
+            canon = oracle_mod.IVox(res=0.5, stencil=st)
+            canon.set_tie_mode(0)
+            m = lio.Map(resolution=0.5, stencil=st, max_points=200_000, max_voxels=100_000)
+            r = refmod.IVox(stencil=st) if refmod.available() else None
+            for lo, hi in zip([0] + cuts, cuts + [len(pts)]):
+                iv.add(pts[lo:hi], float(lo))
+                canon.add(pts[lo:hi], float(lo))
+                m.add(pts[lo:hi], float(lo))
+                if r is not None:
+                    r.add(pts[lo:hi], float(lo))
+            ref_pts, ref_cnt, _ = iv.knn(q)
+            got_pts, got_cnt = m.knn(q)
+            assert np.array_equal(ref_cnt, got_cnt), (trial, st)
+            # positions in the canonical order; WHICH points: by their intensities (points at one and the same position have no order in (d2, x, y, z))
+            assert np.array_equal(ref_pts[..., :3].view(np.uint32), got_pts[..., :3].view(np.uint32)), (trial, st)
+            bad = np.flatnonzero(np.any(np.sort(ref_pts[..., 3], axis=1) != np.sort(got_pts[..., 3], axis=1), axis=1))
+            assert len(bad) == 0, (trial, st, len(bad), bad[:5], ref_pts[bad[:2]], got_pts[bad[:2]])
+            if r is not None:
+                nn_r, cnt_r = r.knn(q)
+                assert np.array_equal(cnt_r, got_cnt)
+                assert np.array_equal(np.sort(nn_r[..., 3], axis=1), np.sort(got_pts[..., 3], axis=1)), (trial, st)
+            n_b, n_un = m.tie_stats()
+            can_pts, _, _ = canon.knn(q)
+            differ = int(np.any(np.sort(can_pts[..., 3], axis=1) != np.sort(ref_pts[..., 3], axis=1), axis=1).sum())
+            assert n_un == 0 and n_b >= differ
+            decided += differ
+            # the earlier definition is still there: the five smallest in (d2, x, y, z) -- duplicates of one position apart (their order is
+            # not defined by that key), so positions only
+            m.set_tie_mode(0)
+            got0, cnt0 = m.knn(q)
+            assert np.array_equal(cnt0, got_cnt)
+            assert np.array_equal(can_pts[..., :3].view(np.uint32), got0[..., :3].view(np.uint32)), (trial, st)
+            m.close()
+    assert decided > 200, "the lattice did not produce boundary ties whose resolution differs between the two definitions"
+
+
+def test_knn_boundary_ties_in_a_voxel_too_large_for_the_staging_area():
+    """a stencil voxel with more in-range points than the redo's staging area holds: counted (lio_map_tie_stats), the canonical five kept"""
+    _dev()
+    from lsd_amd import lio
+
+    rng = np.random.default_rng(3)
+    big = np.concatenate([rng.integers(-3, 4, (3000, 3)) * 0.0625, np.arange(3000)[:, None] + 1.0], 1).astype(np.float32)  # one voxel, 3000 lattice points
+    m = lio.Map(resolution=0.5, stencil=19, max_points=50_000, max_voxels=10_000)
+    m.add(big)
+    q = np.array([[0.03125, 0.03125, 0.03125, 0.0]], np.float32)
+    got, cnt = m.knn(q)
+    assert cnt[0] == 5
+    n_b, n_un = m.tie_stats()
+    assert n_b == 1 and n_un == 1
+    d2 = np.sum((got[0, :, :3] - q[0, :3]) ** 2, axis=1)
+    assert np.all(d2 == d2[0])  # eight corners of the cell around the query are equally near: any five of them
+    m.close()
+
+
 def test_knn_pruned_sweep_adversarial(oracle_mod):
     """the sweep visits the stencil voxels nearest-first and skips those that cannot beat five known candidates: maps and queries built
     to make that decision as hard as possible -- queries on voxel faces / edges / corners (+- one f32 ulp), nearest neighbours living in

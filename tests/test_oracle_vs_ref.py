@@ -126,29 +126,41 @@ def test_undistort_point_and_Exp_bit_exact(oracle_mod):
     assert np.array_equal(oracle_mod.so3_Exp([1e-9, 0, 0], 0.1), np.eye(3)) and np.array_equal(ref.so3_Exp([1e-9, 0, 0], 0.1), np.eye(3))
 
 
-def test_tie_at_the_fifth_nearest_boundary_is_the_references_to_break(oracle_mod):
-    """Two candidates at EXACTLY the same f32 squared distance compete for the fifth place of a query's neighbour list.  The reference keeps
-    whichever std::nth_element leaves in front (ivox3d_node.hpp:107-127, ivox3d.h:159-164: implementation-defined -- another libstdc++, another
-    candidate order, another answer); the oracle and the HIP kernels break the tie by the total order (d2, x, y, z).  Either is a valid 5-NN set
-    (same multiset of distances) -- but it is another SET, which no ordering of the lists repairs: this is what is left between the GPU path
-    and the reference's own code once the neighbour lists are compared in canonical order (bench.py: cpu_baseline.gpu_vs_reference_pose
-    .pinned_build.what_is_left_in_canonical_order; found in round 4 on 1 scan in ~100 of 12 000 queries each)."""
-    q = np.array([[0.25, 0.25, 0.25, 0.0]], np.float32)
-    near = np.array([[0.25, 0.3125, 0.25, 1.0], [0.25, 0.1875, 0.25, 2.0], [0.25, 0.25, 0.3125, 3.0], [0.25, 0.25, 0.1875, 4.0]], np.float32)  # d2 = 2^-8, all four
-    a = np.array([[0.375, 0.25, 0.25, 5.0]], np.float32)  # d2 = 2^-6 exactly
-    b = np.array([[0.125, 0.25, 0.25, 6.0]], np.float32)  # d2 = 2^-6 exactly: the tie
-    far = np.array([[0.25, 0.25, 0.75, 7.0]], np.float32)
-    for order in ((a, b), (b, a)):  # whichever the map saw first
-        pts = np.concatenate([near, order[0], order[1], far])
-        r, o = refmod.IVox(stencil=19), oracle_mod.IVox(stencil=19)
-        r.add(pts, 0.0)
-        o.add(pts, 0.0)
-        nn_r, cnt_r = r.knn(q)
-        nn_o, cnt_o, _ = o.knn(q)
-        assert cnt_r[0] == 5 and cnt_o[0] == 5
-        d2 = lambda p: np.sum((p[:, :3] - q[0, :3]) ** 2, axis=1)
-        assert np.array_equal(np.sort(d2(nn_r[0])), np.sort(d2(nn_o[0])))          # the same distances ...
-        fifth_r = {tuple(p) for p in nn_r[0, :, :3].tolist()} - {tuple(p) for p in near[:, :3].tolist()}
-        fifth_o = {tuple(p) for p in nn_o[0, :, :3].tolist()} - {tuple(p) for p in near[:, :3].tolist()}
-        assert fifth_o == {tuple(b[0, :3].tolist())}                                  # ... the oracle's fifth: the smaller x, whatever the insertion order
-        assert fifth_r in ({tuple(a[0, :3].tolist())}, {tuple(b[0, :3].tolist())})   # the reference's: one of the two, by its sort's whim
+def _tie_lattice(rng, n, step=0.0625, half=1.5):
+    """points on a dyadic lattice (every coordinate a multiple of 2^-4): squared distances between them are exact in f32, so equal distances
+    are everywhere -- with a distinct intensity per point so that WHICH of two equally distant points was kept can be read off the result"""
+    ijk = rng.integers(-int(half / step), int(half / step) + 1, (n, 3))
+    return np.concatenate([ijk * step, np.arange(n)[:, None] + 1.0], 1).astype(np.float32)
+
+
+def test_tie_at_the_fifth_nearest_boundary_is_resolved_as_the_reference_resolves_it(oracle_mod):
+    """Candidates at EXACTLY the same f32 squared distance compete for the fifth place of a query's neighbour list.  The reference keeps
+    whichever std::nth_element leaves in front (ivox3d_node.hpp:107-127, ivox3d.h:156-164) given ITS candidate sequence: stencil order, push_back
+    order inside a voxel, every voxel cut to five first.  The oracle makes the same calls on the same sequence (same libstdc++): its list must
+    equal the compiled ivox3d.h's element for element, intensity included, in the reference's own order -- and its canonical-order list must be
+    that same set.  (Until round 6 the oracle and the kernels took the five smallest in (d2, x, y, z): another valid 5-NN set, but another set.)"""
+    rng = np.random.default_rng(5)
+    n_boundary = 0
+    for trial in range(6):
+        pts = _tie_lattice(rng, 6000 + 3000 * trial)
+        q = _tie_lattice(rng, 1500)
+        q[:, :3] += np.float32(0.03125) * (trial % 2)  # half of the trials: queries between the lattice planes
+        for stencil in (19, 7, 27, 75, 1):
+            r, o, c = refmod.IVox(stencil=stencil), oracle_mod.IVox(stencil=stencil), oracle_mod.IVox(stencil=stencil)
+            c.set_tie_mode(0)
+            cuts = sorted(rng.choice(len(pts), 3, replace=False).tolist())  # the map arrives in four batches: push_back order spans batches
+            for lo, hi in zip([0] + cuts, cuts + [len(pts)]):
+                for m in (r, o, c):
+                    m.add(pts[lo:hi], float(lo))
+            nn_r, cnt_r = r.knn(q)
+            nn_a, cnt_a = o.knn_as_reference(q)
+            assert np.array_equal(cnt_r, cnt_a)
+            assert np.array_equal(nn_r.view(np.uint32), nn_a.view(np.uint32)), (trial, stencil)
+            nn_o, cnt_o, _ = o.knn(q)
+            assert np.array_equal(cnt_o, cnt_r)
+            # the same SET (intensities identify the points), in the canonical order
+            assert np.array_equal(np.sort(nn_o[..., 3], axis=1), np.sort(nn_r[..., 3], axis=1)), (trial, stencil)
+            assert np.array_equal(refmod.canonical(nn_r, cnt_r, q)[..., :3].view(np.uint32), nn_o[..., :3].view(np.uint32))
+            nn_c, _, _ = c.knn(q)
+            n_boundary += int(np.any(np.sort(nn_c[..., 3], axis=1) != np.sort(nn_r[..., 3], axis=1), axis=1).sum())
+    assert n_boundary > 100, "the lattice did not produce boundary ties: the test would not distinguish the two definitions"
