@@ -1459,16 +1459,38 @@ def stream_run(args, torch, local_rank):
                 m_ref = min(args.ref_scans, k_done)
                 jj, t_ref, n_ref, pts_ref = 0, 0.0, 0, 0
                 t_full, n_full = 0.0, 0  # ... of those, the sweeps registered while the reference's iVox holds its full 100000 voxels (LRU evicting)
+                # TEACHER-FORCED parity: a second HIP engine runs the same sweeps in step with the reference and is put back on the reference's posterior
+                # (state and covariance) after every sweep, so that each figure is ONE sweep's difference -- IMU propagation, undistortion, downsample,
+                # iterated update -- from the same prior against maps grown by the same inserts, not a drive's amplification of it.  The maps are not
+                # copied over: they start identical and part only where a map_incremental decision flips (voxel counts compared at the end).
+                e_tf = lio.Engine(resolution=0.5, stencil=75, max_points=2_000_000 + 14_000 * m_ref, max_voxels=(1 << 21), max_raw=1 << 18, max_ds=100000, device=local_rank)
+                if not evict:
+                    e_tf.map.set_lru((1 << 21) - 100_000, 1e9)
+                e_tf.fastlio_init(scan_period=0.1)
+                tf_dp, tf_dr, tf_first_bad = [], [], None
                 for k in range(m_ref):
                     p, st = get_sweep(k)
                     tb = k * 0.1
                     while jj < len(imu_t) and imu_t[jj] <= tb + 0.12:
                         R.imu_enqueue(imu_t[jj], imu_g[jj], imu_a[jj])
+                        e_tf.fastlio_imu_enqueue(imu_t[jj], imu_g[jj], imu_a[jj])
                         jj += 1
                     c0 = time.perf_counter()
                     R.pcl_enqueue(p, st, int(round(tb * 1e6)))
-                    R.main()
+                    updated = R.main()
                     c1 = time.perf_counter()
+                    e_tf.fastlio_pcl_enqueue(p, st, tb)
+                    rc_tf = e_tf.fastlio_main()
+                    e_tf.flush()
+                    s_ref, _, P_ref = R.state()
+                    if rc_tf == capi.MAIN_UPDATED and updated:
+                        s_tf = e_tf.get_state()
+                        tf_dp.append(float(np.linalg.norm(s_tf[0:3] - s_ref[0:3])))
+                        tf_dr.append(float(synth.quat_angle(s_tf[3:7], s_ref[3:7])))
+                        if tf_first_bad is None and (tf_dp[-1] > 1e-4 or tf_dr[-1] > 1e-5):
+                            tf_first_bad = k
+                        e_tf.set_state(s_ref)
+                        e_tf.set_cov(P_ref)
                     if k + 1 == m_ref // 2:
                         ref_half = R.get_state().copy()
                     if k >= 20:
@@ -1502,6 +1524,16 @@ def stream_run(args, torch, local_rank):
                         gv[f"dpos_m_after_{at}_sweeps"] = float(np.linalg.norm(gpu_state_at[at][0:3] - sr[0:3]))
                         gv[f"drot_rad_after_{at}_sweeps"] = float(synth.quat_angle(gpu_state_at[at][3:7], sr[3:7]))
                 cpu["gpu_vs_reference_drive"] = gv
+                if tf_dp:
+                    a_dp, a_dr = np.array(tf_dp), np.array(tf_dr)
+                    cpu["gpu_vs_reference_per_sweep"] = {
+                        "what": "teacher-forced: a HIP engine fed the same sweeps in step with the reference and reset to the reference's posterior (state, covariance) "
+                                "after every sweep -- |GPU pose - reference pose| after ONE sweep from the same prior; the reference build is the one that is timed "
+                                "(its own flags, vectorised Eigen)",
+                        "sweeps": int(len(a_dp)), "max_dpos_m": float(a_dp.max()), "max_drot_rad": float(a_dr.max()), "median_dpos_m": float(np.median(a_dp)),
+                        "p99_dpos_m": float(np.percentile(a_dp, 99)), "sweeps_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((a_dp > 1e-4) | (a_dr > 1e-5))),
+                        "first_sweep_beyond": tf_first_bad, "map_voxels_end": {"gpu": int(e_tf.map.stats()[1]), "reference": int(R.map_voxels())}}
+                e_tf.close()
         except Exception as ex:
             cpu = {"error": repr(ex)[-300:]}
     out = {"metric": "registered points/sec (streaming LIO front half, incremental map)", "value": round(pts / tot, 1), "unit": "points/s", "n_gpus": 1,

@@ -98,6 +98,9 @@ int lio_map_lru_stats(lio_map*, uint64_t* n_evicted, uint64_t* n_interleaved);
  * order, push_back order inside a voxel).  mode 1 (default): the same survivor -- the map keeps every point's push_back rank, and the exact redo
  * of tied queries runs the same selection on the same sequence (csrc/refsel.h); mode 0: the five smallest in (d2, x, y, z), the definition of
  * rounds 1-5.  The two differ only on such ties (about one query in 1e6 on sensor data); the returned lists are in the canonical order either way.
+ * mode 2: the lists exactly as the reference returns them, ORDER included (nearest first, the rest as introselect leaves them) -- every query of
+ * every search is redone by the reference's selection, tens of times slower than the search itself: a parity mode (the plane fit's QR sees its rows
+ * in the reference's order, so the whole path follows the reference's build to the rounding of the f64 sums), not a production mode.
  * lio_map_tie_stats: queries whose set the selection decided so far, and how many of those could not be resolved (a stencil voxel with more than
  * 2048 in-range points: the canonical set was kept) -- 0 unless a map holds voxels of thousands of points. */
 int lio_map_set_tie_mode(lio_map*, int mode);

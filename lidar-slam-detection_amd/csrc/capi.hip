@@ -280,8 +280,8 @@ int lio_map_lru_stats(lio_map* m, uint64_t* n_evicted, uint64_t* n_interleaved) 
 }
 
 int lio_map_set_tie_mode(lio_map* m, int mode) {
-    if (!m || (mode != 0 && mode != 1)) return LIO_E_INVALID;
-    if (mode == 1 && !m->pool_seq) { set_error("lio_map_set_tie_mode: not an iVox map"); return LIO_E_STATE; }
+    if (!m || mode < 0 || mode > 2) return LIO_E_INVALID;
+    if (mode != 0 && !m->pool_seq) { set_error("lio_map_set_tie_mode: not an iVox map"); return LIO_E_STATE; }
     m->tie_mode = mode;
     return LIO_OK;
 }
@@ -902,8 +902,8 @@ int p2plane_linearize_end(lio_map* m, lio_scan* s, const double pose_wi[7], cons
     // the reporting workgroup stores the record straight into mapped pinned host memory: no copy launch, no sync call
     int rc = wait_report(s);
     if (rc != LIO_OK) return rc;
-    if (s->h_result->n_tie) {  // exact d2 ties among some top-6: redo those queries with the canonical comparison
-        const uint32_t nt = s->h_result->n_tie;
+    if (s->h_result->n_tie || (redo_knn && m->tie_mode == 2 && s->h_result->n_ds)) {  // exact d2 ties among some top-6: redo those queries exactly (tie mode 2: all of them)
+        const uint32_t nt = m->tie_mode == 2 ? s->h_result->n_ds : s->h_result->n_tie;
         rc = map_knn_exact(m, s, pose, nt);
         if (rc != LIO_OK) return rc;
         rc = p2plane_reduce(m, s, pose, redo_knn);

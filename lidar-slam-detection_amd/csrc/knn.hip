@@ -613,7 +613,7 @@ struct SelLds {
 template <int MODE>
 __device__ __noinline__ void refsel_query(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, const uint32_t* __restrict__ seq,
                                           float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries, uint32_t q,
-                                          float4* __restrict__ nn_pts, uint32_t nn_stride, MapDev* md, SelLds& S) {
+                                          float4* __restrict__ nn_pts, uint32_t nn_stride, MapDev* md, SelLds& S, bool keep_order) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float4 pw;
     {
@@ -683,15 +683,15 @@ __device__ __noinline__ void refsel_query(const Slot* __restrict__ table, uint32
         } else {
             const int n = refsel::final_cut(S.list, S.size, 5);  // ivox3d.h:156-162
             Cand c[5];
-            for (int k = 0; k < n; k++) {  // the survivors in the canonical order
+            for (int k = 0; k < n; k++) {  // the survivors in the canonical order -- or, tie mode 2, as the reference returns them
                 Cand x = {__uint_as_float(S.list[k].d), S.list[k].id};
                 int at = k;
-                while (at > 0 && cand_less(x, c[at - 1], pool)) { c[at] = c[at - 1]; at--; }
+                while (!keep_order && at > 0 && cand_less(x, c[at - 1], pool)) { c[at] = c[at - 1]; at--; }
                 c[at] = x;
             }
             for (int k = 0; k < n; k++) nn_pts[(size_t)k * nn_stride + q] = pool[c[k].id];
         }
-        atomicAdd(&md->n_tie_boundary, 1ull);
+        if (!keep_order) atomicAdd(&md->n_tie_boundary, 1ull);
     }
     __syncthreads();
 }
@@ -700,20 +700,24 @@ template <int KM, int MODE>
 __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
                                                float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
-                                               const uint32_t* __restrict__ tie_list, const uint32_t* __restrict__ seq, MapDev* md, int tie_mode) {
+                                               const uint32_t* __restrict__ tie_list, const uint32_t* __restrict__ seq, MapDev* md, int tie_mode,
+                                               uint32_t n_all) {
     __shared__ GroupLds lds[kGPB];
     __shared__ SelLds sel;
     const int tid = threadIdx.x;
     const int grp = tid / kG, gl = tid % kG;
     const int lane = tid & 63;
     GroupLds& g = lds[grp];
-    const uint32_t n = *n_tie;
-    const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
     const bool as_reference = tie_mode != 0 && seq != nullptr;
+    // tie mode 2 (lio_map_set_tie_mode: the lists exactly as the reference returns them, order included -- a parity mode, slow): EVERY query of the
+    // scan goes through the reference's selection, not only the queued ones
+    const bool all = tie_mode == 2 && seq != nullptr;
+    const uint32_t n = all ? n_all : *n_tie;
+    const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
     for (uint32_t w0 = blockIdx.x * kGPB; w0 < n; w0 += gridDim.x * kGPB) {
         const uint32_t w = w0 + grp;
         const bool active = w < n;
-        const uint32_t q = active ? tie_list[w] : 0u;
+        const uint32_t q = active ? (all ? w : tie_list[w]) : 0u;
         float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) {
             const float4 pq = queries[q];
@@ -792,10 +796,10 @@ __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, u
             }
         }
         if (active && gl < 5 && win != kNoIdx) nn_pts[(size_t)gl * nn_stride + q] = pool[win];
-        if (as_reference && active && gl == 0 && d_fifth == d_sixth) sel.queue[atomicAdd(&sel.n_queue, 1u)] = q;
+        if (as_reference && active && gl == 0 && (all || d_fifth == d_sixth)) sel.queue[atomicAdd(&sel.n_queue, 1u)] = q;
         __syncthreads();
         const uint32_t nq = sel.n_queue;
-        for (uint32_t k = 0; k < nq; k++) refsel_query<MODE>(table, mask, pool, seq, inv_res, st, pose, queries, sel.queue[k], nn_pts, nn_stride, md, sel);
+        for (uint32_t k = 0; k < nq; k++) refsel_query<MODE>(table, mask, pool, seq, inv_res, st, pose, queries, sel.queue[k], nn_pts, nn_stride, md, sel, all);
         __syncthreads();
     }
 }
@@ -804,8 +808,9 @@ template <int KM, int MODE>
 __global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                         float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
                                                         float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
-                                                        const uint32_t* __restrict__ tie_list, const uint32_t* __restrict__ seq, MapDev* md, int tie_mode) {
-    knn_exact_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, nn_pts, nn_stride, n_tie, tie_list, seq, md, tie_mode);
+                                                        const uint32_t* __restrict__ tie_list, const uint32_t* __restrict__ seq, MapDev* md, int tie_mode,
+                                                        uint32_t n_all) {
+    knn_exact_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, nn_pts, nn_stride, n_tie, tie_list, seq, md, tie_mode, n_all);
 }
 // batch form: the queries the search of this pass queued (usually none: the kernel then ends at once); the queue is re-armed by the
 // filter-pass kernel that follows the linearisation
@@ -814,11 +819,11 @@ __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __rest
                                                               float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots,
                                                               const uint32_t* __restrict__ seq, MapDev* md, int tie_mode) {
     const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || d.sd->n_tie == 0) return;
+    if (!d.active || (d.sd->n_tie == 0 && tie_mode != 2)) return;
     const SlotGate sg = slot_gate(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
     const PoseArgs& pose = sg.pose;
-    knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, seq, md, tie_mode);
+    knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, seq, md, tie_mode, sg.n_ds);
 }
 
 // Tied queries are queued and redone by a second (usually empty) launch.  (Measured and dropped in round 3: redoing them in place -- one
@@ -837,7 +842,7 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
     if (grid_x > cap) grid_x = cap;  // grid-stride loop inside: 16 queries per workgroup and round
     if (grid_x == 0) grid_x = 8;
     const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
-    const dim3 gridx(n_slots > 8 ? 8 : 64, (uint32_t)n_slots);  // the tie queue of a scan holds a handful of queries at most: a few workgroups per slot (grid-stride inside)
+    const dim3 gridx(m->tie_mode == 2 ? 64 : (n_slots > 8 ? 8 : 64), (uint32_t)n_slots);  // the tie queue of a scan holds a handful of queries at most: a few workgroups per slot (grid-stride inside)
     const int km = (m->stencil.n + kG - 1) / kG;
 #define KNNB_LAUNCH(KM)                                                                                                                              \
     do {                                                                                                                                             \
@@ -871,13 +876,13 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_seq_kernel(const MapRe
 template <int KM>
 __global__ void __launch_bounds__(256) knn_exact_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id, const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || d.sd->n_tie == 0) return;
+    if (!d.active) return;
     const MapRef& r = maps[blockIdx.y];
-    if (r.stencil_id != stencil_id) return;
+    if (r.stencil_id != stencil_id || (d.sd->n_tie == 0 && r.tie_mode != 2)) return;
     const SlotGate sg = slot_gate(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
     const PoseArgs& pose = sg.pose;
-    knn_exact_body<KM, 0>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, r.pool_seq, r.md, r.tie_mode);
+    knn_exact_body<KM, 0>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, r.pool_seq, r.md, r.tie_mode, sg.n_ds);
 }
 
 int knn_seq_launch(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, const StencilArgs* stencils, const int* stencil_ids,
@@ -931,13 +936,13 @@ static int launch_knn(lio_map* m, hipStream_t st, const PoseArgs& pose, const fl
 
 template <int MODE>
 static int launch_knn_exact(lio_map* m, hipStream_t st, const PoseArgs& pose, const float4* q, float4* nn_pts, uint32_t nn_stride,
-                            uint32_t n_tie_host, const uint32_t* n_tie, const uint32_t* tie_list) {
+                            uint32_t n_tie_host, const uint32_t* n_tie, const uint32_t* tie_list, uint32_t n_all = 0) {
     uint32_t blocks = (n_tie_host + kGPB - 1) / kGPB;
     if (blocks == 0) return LIO_OK;
     if (blocks > 4096) blocks = 4096;
 #define KNNX_LAUNCH(KM)                                                                                                                      \
     hipLaunchKernelGGL((knn_exact_kernel<KM, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q, nn_pts, \
-                       nn_stride, n_tie, tie_list, m->pool_seq, m->dev, m->tie_mode)
+                       nn_stride, n_tie, tie_list, m->pool_seq, m->dev, m->tie_mode, n_all)
     const int km = (m->stencil.n + kG - 1) / kG;
     if (km <= 1) KNNX_LAUNCH(1);
     else if (km <= 2) KNNX_LAUNCH(2);
@@ -966,7 +971,8 @@ int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn) {
 // redo the queued tie queries of the last map_knn_plane exactly (n_tie_host = count read back by the caller)
 int map_knn_exact(lio_map* m, lio_scan* s, const PoseArgs& pose, uint32_t n_tie_host) {
     { const int rc_settle = map_settle(m); if (rc_settle != LIO_OK) return rc_settle; }  // an insert still running on the map's stream
-    return launch_knn_exact<0>(m, s->stream, pose, s->ds_body, s->nn_pts, s->max_ds, n_tie_host, &s->dev->n_tie_done, s->tie_list);
+    // (tie mode 2: n_tie_host is the number of queries of the scan -- all of them are redone)
+    return launch_knn_exact<0>(m, s->stream, pose, s->ds_body, s->nn_pts, s->max_ds, n_tie_host, &s->dev->n_tie_done, s->tie_list, m->tie_mode == 2 ? n_tie_host : 0u);
 }
 
 int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t* d_cnt, uint32_t* d_tie /* [0] = count, [1..] = list */) {
@@ -977,7 +983,8 @@ int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t*
     uint32_t nt = 0;
     LIO_HIP_TRY(hipMemcpyAsync(&nt, d_tie, 4, hipMemcpyDeviceToHost, m->stream));
     LIO_HIP_TRY(hipStreamSynchronize(m->stream));
-    if (nt) rc = launch_knn_exact<1>(m, m->stream, pose, d_q, d_out, n, nt, d_tie, d_tie + 1);
+    if (m->tie_mode == 2 && m->pool_seq) rc = launch_knn_exact<1>(m, m->stream, pose, d_q, d_out, n, n, d_tie, d_tie + 1, n);
+    else if (nt) rc = launch_knn_exact<1>(m, m->stream, pose, d_q, d_out, n, nt, d_tie, d_tie + 1);
     return rc;
 }
 

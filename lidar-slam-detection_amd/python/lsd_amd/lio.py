@@ -63,7 +63,8 @@ class Map:
         return a.value, b.value
 
     def set_tie_mode(self, mode):
-        """1 (default): candidates exactly as far as the fifth nearest are kept as the reference's std::nth_element keeps them; 0: smallest (d2, x, y, z)"""
+        """1 (default): candidates exactly as far as the fifth nearest are kept as the reference's std::nth_element keeps them; 0: smallest (d2, x, y, z);
+        2: the lists exactly as the reference returns them, order included (every query redone by the reference's selection: slow, a parity mode)"""
         check(lib().lio_map_set_tie_mode(self.h, int(mode)), "set_tie_mode")
 
     def tie_stats(self):

@@ -245,7 +245,10 @@ class IVox {
     // caller depends on it, common_lib.h:236-268 fits a plane to the set).
     // tie_mode 0 restores the earlier definition (the five smallest in
     // (d2, x, y, z)), which differs only when the fifth and sixth distances are
-    // equal.
+    // equal; tie_mode 2 keeps the reference's ORDER as well (nearest first, the
+    // rest as introselect leaves them): esti_plane's QR then sees the rows in
+    // the reference's order and the whole path follows the reference's own
+    // build to rounding of the f64 sums.
     int tie_mode = 1;
     struct DistPoint {  // ivox3d_node.hpp:71-84: ordered by dist alone
         double dist;
@@ -306,7 +309,7 @@ class IVox {
         const size_t seen = select_as_reference(q, max_num, max_sq, cand);
         if (cand.empty()) return false;
         for (const DistPoint& c : cand) scratch.push_back({(float)c.dist, c.p});
-        std::sort(scratch.begin(), scratch.end(), cand_less);
+        if (tie_mode != 2) std::sort(scratch.begin(), scratch.end(), cand_less);  // (tie_mode 2: the list as the reference returns it, order included)
         closest_pt.clear();
         for (const Cand& c : scratch) closest_pt.push_back(c.p);
         scratch.resize(seen);  // (callers read the number of candidates off the scratch list)
