@@ -101,8 +101,8 @@ int lio_map_lru_stats(lio_map*, uint64_t* n_evicted, uint64_t* n_interleaved);
  * mode 2: the lists exactly as the reference returns them, ORDER included (nearest first, the rest as introselect leaves them) -- every query of
  * every search is redone by the reference's selection, tens of times slower than the search itself: a parity mode (the plane fit's QR sees its rows
  * in the reference's order, so the whole path follows the reference's build to the rounding of the f64 sums), not a production mode.
- * lio_map_tie_stats: queries whose set the selection decided so far, and how many of those could not be resolved (a stencil voxel with more than
- * 2048 in-range points: the canonical set was kept) -- 0 unless a map holds voxels of thousands of points. */
+ * lio_map_tie_stats: queries whose set the selection decided so far, and how many of those could not be resolved (a stencil voxel of more
+ * than 2560 points: the canonical set was kept) -- 0 unless a map holds voxels of thousands of points. */
 int lio_map_set_tie_mode(lio_map*, int mode);
 int lio_map_tie_stats(lio_map*, uint64_t* n_boundary_ties, uint64_t* n_unresolved);
 /* capacity planning: slots of the point pool handed out so far by the bump allocator (recycled regions of evicted / outgrown
@@ -475,7 +475,9 @@ int lio_batch_set_gather_hook(lio_batch*, lio_gather_fn fn, void* ctx, int rank,
  * radix passes than were launched -- so a session driven here and the same scans pushed one by one through lio_engine_set_state / set_cov /
  * lio_engine_process_scan_device on an engine with lio_engine_set_device_loop(e, 1) give the same bits (tests/test_sequence_batch_gpu.py).
  * rc per job as lio_engine_process_scan; state_out and cov_out[j * 529 ..] (may be NULL) receive the posterior (the prior where nothing was
- * registered).  The pass logs of a scan registered inside a round stay on the device (lio_engine_pass_log of the slot's engine is empty). */
+ * registered).  The pass logs of a scan registered inside a round stay on the device (lio_engine_pass_log of the slot's engine is empty).
+ * A step that returns a device error after some of its groups' rounds already ran leaves those sessions' maps one sweep ahead of their engines: the
+ * batch then refuses further steps (LIO_E_STATE) -- destroy it; a step that fails before any round ran can be repeated. */
 lio_batch* lio_batch_create_sequences(int device, float resolution, int stencil, uint64_t max_points, uint64_t max_voxels, int n_slots, int n_groups,
                                       uint32_t max_raw, uint32_t max_ds);
 int lio_batch_sequences_step(lio_batch*, lio_scan_job* jobs, int n_jobs, double* cov_out);

@@ -43,7 +43,7 @@ struct Group {
     double* d_local32 = nullptr;         // joint mode: this rank's record per slot (B x 32), and every rank's (world x B x 32)
     double* d_gathered = nullptr;
     MapRef* d_rowmaps = nullptr;         // joint mode: the sub-map behind every descriptor row [m * B + slot] -- ONE neighbour-search launch per pass
-    std::vector<const void*> rowmap_tables;  // ... as uploaded (refreshed when a sub-map's table moved)
+    std::vector<MapRef> rowmap_rows;  // ... one row per sub-map as uploaded (refreshed when any word of a sub-map's row changed)
     char* d_block = nullptr;             // [SlotDesc x B (x sub-maps)][EskfDev x B]: one upload per round
     char* h_block = nullptr;             // pinned staging, same layout
     size_t block_bytes = 0;
@@ -80,6 +80,7 @@ struct lio_batch {
     int n_slots = 0;
     uint32_t max_raw = 0, max_ds = 0;
     int pred_passes = 4;  // radix passes the last rounds needed
+    bool broken = false;  // sequence mode: a step failed after some of its rounds had run on the device (lio_batch_sequences_step refuses further steps)
     int use_graph = 1;    // LIO_BATCH_GRAPH=0: plain launches instead of one hipGraphLaunch per round
     int count_touched = 0;  // lio_batch_enable_kernel_timing(b, 2): the kNN kernel's diagnostic variant that also counts the points it loads
     // joint mode (lio_batch_create_joint): every job is registered against all of `maps` (sub-maps on this GPU; maps[0] == map) and, through
@@ -110,22 +111,24 @@ const MapRef* joint_rowmaps(lio_batch* b, Group& g) {
     if (M < 2) return nullptr;
     for (int m = 1; m < M; m++)
         if (b->maps[m]->stencil_id != b->maps[0]->stencil_id || b->maps[m]->stencil.n != b->maps[0]->stencil.n) return nullptr;
-    bool fresh = g.d_rowmaps != nullptr && (int)g.rowmap_tables.size() == M;
-    for (int m = 0; m < M && fresh; m++) fresh = g.rowmap_tables[m] == (const void*)b->maps[m]->table;
+    // the cached device rows are fresh only if EVERY word of every sub-map's row is what it would be now (table, mask, pool, counters, stencil id,
+    // tie mode ...: lio_map_set_stencil and a table rebuild both change a row without changing the other's key)
+    std::vector<MapRef> now((size_t)M);
+    for (int m = 0; m < M; m++) {
+        memset(&now[m], 0, sizeof(MapRef));
+        fill_mapref(now[m], b->maps[m]);
+    }
+    bool fresh = g.d_rowmaps != nullptr && (int)g.rowmap_rows.size() == M;
+    for (int m = 0; m < M && fresh; m++) fresh = memcmp(&g.rowmap_rows[m], &now[m], sizeof(MapRef)) == 0;
     if (fresh) return g.d_rowmaps;
     std::vector<MapRef> rows((size_t)M * B);
-    for (int m = 0; m < M; m++) {
-        MapRef r;
-        memset(&r, 0, sizeof(r));
-        fill_mapref(r, b->maps[m]);
-        for (int s = 0; s < B; s++) rows[(size_t)m * B + s] = r;
-    }
+    for (int m = 0; m < M; m++)
+        for (int s = 0; s < B; s++) rows[(size_t)m * B + s] = now[m];
     if (!g.d_rowmaps && hipMalloc(reinterpret_cast<void**>(&g.d_rowmaps), sizeof(MapRef) * rows.size()) != hipSuccess) { g.d_rowmaps = nullptr; return nullptr; }
     // (stream-ordered behind the round before it, which may still read the old table)
     if (hipMemcpyAsync(g.d_rowmaps, rows.data(), sizeof(MapRef) * rows.size(), hipMemcpyHostToDevice, g.stream) != hipSuccess) return nullptr;
-    if (hipStreamSynchronize(g.stream) != hipSuccess) return nullptr;  // (rows is a local: rare -- creation, or a sub-map whose table was rebuilt)
-    g.rowmap_tables.assign(M, nullptr);
-    for (int m = 0; m < M; m++) g.rowmap_tables[m] = b->maps[m]->table;
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return nullptr;  // (rows is a local: rare -- creation, a rebuilt table, another stencil)
+    g.rowmap_rows = now;
     return g.d_rowmaps;
 }
 
@@ -528,7 +531,9 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
                 double st26[26], cov[529];
                 memcpy(st26, job.state_in, sizeof(st26));
                 memcpy(cov, job.cov_in, sizeof(cov));
-                const int rc = engine_joint_register_device(e, job.d_raw, job.n_raw, job.lidar_beg_time, st26, cov);
+                // (a LIO_JOB_HOST_RAW job's d_raw is a HOST address: its staged copy in the group's raw ring is still intact for this slot)
+                const void* d_cloud = (job.flags & LIO_JOB_HOST_RAW) ? static_cast<const void*>(g.d_rawbuf + (size_t)s * b->max_raw) : job.d_raw;
+                const int rc = engine_joint_register_device(e, d_cloud, job.n_raw, job.lidar_beg_time, st26, cov);
                 if (rc < 0) { job.rc = rc; note(rc); continue; }
                 engine_count_passes(e, &job.n_pass, &job.n_knn_pass);
                 if (job.state_out) memcpy(job.state_out, st26, sizeof(st26));
@@ -559,7 +564,9 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
     // a failed submission / wait: the rounds of the other groups are still in flight and own their pinned blocks and result records --
     // wait for them before handing the error back (their jobs keep LIO_E_INVALID), so that the next call starts from idle groups
     auto bail = [&](int rc) {
-        for (const int gi : inflight) hipStreamSynchronize(b->groups[gi].stream);
+        // every group's stream, not only the rounds in flight: the group whose submission failed may have queued copies out of the caller's
+        // LIO_JOB_HOST_RAW buffers, which only have to stay valid until this call returns
+        for (auto& gg : b->groups) hipStreamSynchronize(gg.stream);
         inflight.clear();
         return rc;
     };
@@ -605,7 +612,7 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
         Group& g = b->groups[0];
         int rc = submit(b, g, jobs, j, 1, 4);
         if (rc == LIO_OK && g.n_active) rc = wait_group(g, B);
-        if (rc != LIO_OK) return rc;
+        if (rc != LIO_OK) return bail(rc);
         collect(g);
     }
     for (const int j : retry) { jobs[j].rc = LIO_E_DEVICE; note(LIO_E_DEVICE); }
@@ -692,6 +699,7 @@ lio_batch* lio_batch_create_sequences(int device, float resolution, int stencil,
 int lio_batch_sequences_step(lio_batch* b, lio_scan_job* jobs, int n_jobs, double* cov_out) {
     if (!b || !jobs) return LIO_E_INVALID;
     if (!b->sequences) { set_error("lio_batch_sequences_step: for a batch made by lio_batch_create_sequences"); return LIO_E_STATE; }
+    if (b->broken) { set_error("lio_batch_sequences_step: an earlier step failed after part of it had run on the device; the sessions' maps hold that sweep, their engines do not -- destroy the batch"); return LIO_E_STATE; }
     const int B = b->n_slots, G = (int)b->groups.size();
     if (n_jobs != B * G) { set_error("lio_batch_sequences_step: %d jobs for %d sessions (job j is the next scan of session j; LIO_JOB_IDLE marks a session without one)", n_jobs, B * G); return LIO_E_INVALID; }
     hipSetDevice(b->device);
@@ -832,6 +840,10 @@ int lio_batch_sequences_step(lio_batch* b, lio_scan_job* jobs, int n_jobs, doubl
                     const bool in_round = k <= gi && b->groups[k].seq_path[s2] == 11;
                     if (k > gi || in_round) j2.rc = (j2.flags & LIO_JOB_IDLE) && !(j2.flags & ~LIO_JOB_FLAGS_KNOWN) ? 0 : LIO_E_DEVICE;
                 }
+            // the rounds of the groups before this one have already run on the device -- their sessions' maps and filters hold this sweep, the engines'
+            // host side (neighbour cache bookkeeping, travel, the deferred insert's accounting) does not: the batch cannot be stepped again (a retried
+            // sweep would enter those maps twice)
+            if (gi > 0) b->broken = true;
             return rc;
         }
         b->n_rounds++;

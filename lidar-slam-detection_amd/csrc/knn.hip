@@ -342,9 +342,12 @@ __device__ inline bool cand_less(const Cand& a, const Cand& b, const float4* __r
 // MODE 1: queries are world-frame points (diagnostic lio_map_knn).
 // COUNT: a diagnostic build of the same kernel that also counts the candidate points the sweep really loads (`touched`, the second word
 // of a shard of MapDev::knn_cand) beside the stencil's residents -- bench.py's roofline leg wants both; never the timed variant.
-template <int KM, int MODE, bool COUNT = false>
+// The body -> world transform's fourteen doubles live in LDS (pose_s), not in scalar registers: held there for the whole kernel they were 28 of its
+// 106 SGPRs -- 19 spilled into lanes of a VGPR, two VGPRs to scratch, re-read in every query's epilogue (round 5's -Rpass-analysis) -- and they are
+// used by one wave in four, once per 64 queries.  `fill(pose_s)` is called by every thread once, before the first barrier.
+template <int KM, int MODE, bool COUNT = false, class PoseFill>
 __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
-                                         float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
+                                         float inv_res, const StencilArgs& st, PoseFill fill, const float4* __restrict__ queries,
                                          uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
                                          float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
                                          MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
@@ -375,6 +378,8 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     // points in LDS (and in world_out, coalesced).
     constexpr uint32_t kAhead = 64 / kGPB;
     __shared__ float4 pw_s[64];
+    __shared__ PoseArgs pose_s;
+    if constexpr (MODE == 0) fill(pose_s);
     uint32_t ahead = kAhead;  // workgroup-uniform: query blocks already taken from the staged chunk
     for (uint32_t j = blockIdx.x >> 3; j < per_xcd; j += wg_per_xcd) {
         const uint32_t q0 = ((blockIdx.x & 7u) * per_xcd + j) * kGPB;
@@ -389,7 +394,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                     const uint32_t q2 = ((blockIdx.x & 7u) * per_xcd + j2) * kGPB + (uint32_t)(tid % kGPB);
                     if (j2 < per_xcd && q2 < n) {
                         float4 w2;
-                        body_to_world(pose, queries[q2], w2);
+                        body_to_world(pose_s, queries[q2], w2);
                         world_out[q2] = w2;
                         pw_s[tid] = w2;
                     }
@@ -537,7 +542,8 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         // results.  No in-range candidate at all: GetClosestPoint returns before touching the output
         // (ivox3d.h:152-154), the cached neighbours of an earlier scan survive.
         if (active && inrange > 0) {
-            if (gl < 5) nn_pts[(size_t)gl * nn_stride + q] = (win != 0xFFFFFFFFu) ? pool[win] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // (32-bit index: five planes of max_ds points; the 64-bit per-lane plane address, hoisted out of the query loop, was the one value the batched kernel spilled to scratch)
+            if (gl < 5) nn_pts[(uint32_t)gl * nn_stride + q] = (win != 0xFFFFFFFFu) ? pool[win] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (gl == 0) {
                 nn_cnt[q] = inrange < 5 ? (int32_t)inrange : 5;
                 if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
@@ -577,7 +583,8 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
                                                   uint32_t n_host, const ScanDev* __restrict__ sd, float4* __restrict__ world_out,
                                                   float4* __restrict__ nn_pts, uint32_t nn_stride, int32_t* __restrict__ nn_cnt,
                                                   MapDev* md, uint32_t* __restrict__ n_tie, uint32_t* __restrict__ tie_list) {
-    knn_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, md, n_tie, tie_list);
+    knn_body<KM, MODE>(table, mask, pool, inv_res, st, [&](PoseArgs& P) { if (threadIdx.x == 0) P = pose; }, queries, n_host, sd, world_out, nn_pts, nn_stride, nn_cnt, md,
+                       n_tie, tie_list);
 }
 // the scans of a batch (lio_batch_*): blockIdx.y = slot; pose from the slot's device-resident filter; a slot whose update has finished,
 // or whose filter did not ask for a neighbour search this pass, exits at once
@@ -586,10 +593,11 @@ __global__ void LIO_KNN_OCC __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kern
                                                                        float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
-    const SlotGate sg = slot_gate(d);
+    const SlotGateLite sg = slot_gate_lite(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
-    const PoseArgs& pose = sg.pose;
-    knn_body<KM, 0, COUNT>(table, mask, pool, inv_res, st, pose, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
+    const double* __restrict__ x = d.ctrl->x;
+    knn_body<KM, 0, COUNT>(table, mask, pool, inv_res, st, [x](PoseArgs& P) { pose_fill_from_state(P, x); }, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts, d.max_ds,
+                           d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
 }
 
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
@@ -600,18 +608,26 @@ __global__ void LIO_KNN_OCC __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kern
 // points in push_back order (the pool keeps arrival order; MapDev's sequence numbers restore the push_back order), each voxel cut to five,
 // the list cut to five -- refsel.h restates libstdc++'s introselect, one lane runs it on the list in LDS.  The survivors are written in the
 // canonical order.  About one query in a million on sensor data; a map of lattice points sends every query here (tests).
-constexpr int kSelCap = 2048;  // in-range points of ONE stencil voxel the staging area holds
+constexpr int kSelCap = 2560;  // points of one RUN of stencil voxels the staging area holds (a run = as many consecutive voxels as fit; one voxel must)
 struct SelLds {
-    uint32_t a_d[kSelCap], a_id[kSelCap], a_seq[kSelCap];  // one voxel's in-range candidates in pool order
-    refsel::Rec list[kSelCap + 5 * kMaxStencil + 8];        // the reference's candidate list: five per voxel done + the voxel in hand
+    uint32_t a_d[kSelCap], a_id[kSelCap], a_seq[kSelCap];  // the in-range candidates in stencil order, inside a voxel in pool order
+    refsel::Rec list[kSelCap];                              // ... inside a voxel in push_back order: the reference's candidate list before any cut
+    refsel::Rec fin[5 * kMaxStencil + 8];                   // ... after every voxel's cut to five
     uint32_t v_ptr[kMaxStencil], v_cnt[kMaxStencil];        // the stencil's voxels in nearby_grids_ order
+    uint32_t v_first[kMaxStencil + 1];                      // exclusive prefix of v_cnt (flat index of a voxel's first point)
+    uint32_t seg_m[kMaxStencil], seg_base[kMaxStencil + 1], seg_keep[kMaxStencil];  // in-range candidates per voxel, their prefix, what the cut keeps
     uint32_t wsum[4];
+    uint32_t out_d[8], out_id[8];
     int size;
-    uint32_t queue[kGPB], n_queue;
 };
 
+// One query, the whole workgroup.  (1) thread t < stencil size looks its voxel up; (2) the points of all stencil voxels, flattened in stencil / pool
+// order, are loaded 256 at a time, the in-range ones compacted in that order (ballot + prefix sums) with their sequence numbers; (3) every candidate
+// ranks itself inside its voxel's segment by sequence number: push_back order; (4) lane v cuts voxel v's segment to five (ivox3d_node.hpp:119-124) --
+// the voxels' selections are independent, so they run side by side; (5) one lane strings the kept candidates together and makes the two
+// nth_element calls of ivox3d.h:156-162.  The serial parts are a few hundred dependent LDS operations: ~20 us for a query of the metric map.
 template <int MODE>
-__device__ __noinline__ void refsel_query(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, const uint32_t* __restrict__ seq,
+__device__ __forceinline__ void refsel_query(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, const uint32_t* __restrict__ seq,
                                           float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries, uint32_t q,
                                           float4* __restrict__ nn_pts, uint32_t nn_stride, MapDev* md, SelLds& S, bool keep_order) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -628,68 +644,114 @@ __device__ __noinline__ void refsel_query(const Slot* __restrict__ table, uint32
         grid_find(table, mask, kx + st.off[tid][0], ky + st.off[tid][1], kz + st.off[tid][2], ptr, cnt);
         S.v_ptr[tid] = ptr;
         S.v_cnt[tid] = cnt;
+        S.seg_m[tid] = 0;
     }
-    if (tid == 0) S.size = 0;
     __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int v = 0; v < st.n; v++) { S.v_first[v] = acc; acc += S.v_cnt[v]; }
+        S.v_first[st.n] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) S.size = 0;
+    // the stencil's voxels in runs that fit the staging area (all of them at once unless the map is dense or the stencil is the 75-cell one); a single
+    // voxel with more points than the area holds cannot be staged: the query stays unresolved (counted)
     bool overflow = false;
-    for (int sv = 0; sv < st.n && !overflow; sv++) {
-        const uint32_t cnt = S.v_cnt[sv], ptr = S.v_ptr[sv];
-        if (cnt == 0) continue;  // (workgroup-uniform)
-        uint32_t m = 0;
-        for (uint32_t base = 0; base < cnt; base += 256) {  // ivox3d_node.hpp:111-116, pool order
-            const uint32_t i = base + (uint32_t)tid;
-            const bool have = i < cnt;
-            const float4 p = pool[have ? ptr + i : ptr];
+    int g0 = 0;
+    while (g0 < st.n) {
+        int g1 = g0;
+        uint32_t total = 0;
+        while (g1 < st.n && total + S.v_cnt[g1] <= (uint32_t)kSelCap) { total += S.v_cnt[g1]; g1++; }
+        if (g1 == g0) { overflow = true; break; }
+        const uint32_t f0 = S.v_first[g0];
+        uint32_t m_all = 0;  // in-range candidates of this run so far (workgroup-uniform)
+        for (uint32_t base = 0; base < total; base += 256) {  // ivox3d_node.hpp:111-116 for every voxel of the run, stencil order, pool order
+            const uint32_t f = f0 + base + (uint32_t)tid;
+            const bool have = base + (uint32_t)tid < total;
+            int v = g0;
+            if (have)
+                while (v + 1 < g1 && S.v_first[v + 1] <= f) v++;
+            const uint32_t idx = have ? S.v_ptr[v] + (f - S.v_first[v]) : 0u;
+            const float4 p = pool[idx];
             const float dx = p.x - pw.x, dy = p.y - pw.y, dz = p.z - pw.z;
             const float d2 = dx * dx + (dy * dy + dz * dz);
             const bool in = have && d2 < 5.0f;
             const unsigned long long bal = __ballot(in);
             if (lane == 0) S.wsum[wave] = (uint32_t)__popcll(bal);
             __syncthreads();
-            uint32_t at = m + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            uint32_t at = m_all + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             for (int w = 0; w < wave; w++) at += S.wsum[w];
             const uint32_t tot = (S.wsum[0] + S.wsum[1]) + (S.wsum[2] + S.wsum[3]);
-            if (in && at < (uint32_t)kSelCap) {
+            if (in) {
                 S.a_d[at] = __float_as_uint(d2);
-                S.a_id[at] = ptr + i;
-                S.a_seq[at] = seq[ptr + i];
+                S.a_id[at] = idx;
+                S.a_seq[at] = seq[idx];
+                atomicAdd(&S.seg_m[v], 1u);
             }
-            m += tot;
+            m_all += tot;
             __syncthreads();
         }
-        if (m > (uint32_t)kSelCap) { overflow = true; break; }
-        // push_back order: rank by sequence number (signed difference: the counter wraps), equal numbers -- never inside one voxel short of a
-        // wrap -- by pool position
-        const int size = S.size;
-        for (uint32_t e = (uint32_t)tid; e < m; e += 256) {
+        if (tid == 0) {
+            uint32_t acc = 0;
+            for (int v = g0; v < g1; v++) { S.seg_base[v] = acc; acc += S.seg_m[v]; }
+            S.seg_base[g1] = acc;
+        }
+        __syncthreads();
+        // push_back order inside every voxel: rank by sequence number (signed difference: the counter wraps); equal numbers -- never inside one voxel
+        // short of a wrap -- by pool position
+        for (uint32_t e = (uint32_t)tid; e < m_all; e += 256) {
+            int v = g0;
+            while (v + 1 < g1 && S.seg_base[v + 1] <= e) v++;
+            const uint32_t b0 = S.seg_base[v], b1 = S.seg_base[v + 1];
             const uint32_t se = S.a_seq[e];
             uint32_t r = 0;
-            for (uint32_t f = 0; f < m; f++) {
+            for (uint32_t f = b0; f < b1; f++) {
                 const uint32_t sf = S.a_seq[f];
                 r += ((int32_t)(sf - se) < 0 || (sf == se && f < e)) ? 1u : 0u;
             }
             refsel::Rec rec;
             rec.d = S.a_d[e];
             rec.id = S.a_id[e];
-            S.list[size + (int)r] = rec;
+            S.list[b0 + r] = rec;
         }
         __syncthreads();
-        if (tid == 0) S.size = refsel::voxel_cut(S.list, size, size + (int)m, 5);  // ivox3d_node.hpp:119-124
+        if (tid < g1 - g0) {  // ivox3d_node.hpp:119-124, every voxel of the run on its own lane
+            const int v = g0 + tid;
+            const int b0 = (int)S.seg_base[v], m = (int)S.seg_m[v];
+            S.seg_keep[v] = (uint32_t)(refsel::voxel_cut(S.list, b0, b0 + m, 5) - b0);
+        }
         __syncthreads();
+        if (tid == 0) {
+            int size = S.size;
+            for (int v = g0; v < g1; v++) {
+                const int b0 = (int)S.seg_base[v], keep = (int)S.seg_keep[v];
+                for (int k = 0; k < keep; k++) S.fin[size++] = S.list[b0 + k];
+            }
+            S.size = size;
+        }
+        __syncthreads();
+        g0 = g1;
     }
     if (tid == 0) {
         if (overflow) {
             atomicAdd(&md->n_tie_unresolved, 1ull);  // (the canonical list written by step 1 stays)
         } else {
-            const int n = refsel::final_cut(S.list, S.size, 5);  // ivox3d.h:156-162
-            Cand c[5];
-            for (int k = 0; k < n; k++) {  // the survivors in the canonical order -- or, tie mode 2, as the reference returns them
-                Cand x = {__uint_as_float(S.list[k].d), S.list[k].id};
+            const int size = S.size;
+            const int n = size ? refsel::final_cut(S.fin, size, 5) : 0;  // ivox3d.h:156-162
+            for (int k = 0; k < n; k++) {  // the survivors in the canonical order -- or, tie mode 2, as the reference returns them (the list stays in LDS: no private array)
+                const Cand x = {__uint_as_float(S.fin[k].d), S.fin[k].id};
                 int at = k;
-                while (!keep_order && at > 0 && cand_less(x, c[at - 1], pool)) { c[at] = c[at - 1]; at--; }
-                c[at] = x;
+                while (!keep_order && at > 0) {
+                    const Cand y = {__uint_as_float(S.out_d[at - 1]), S.out_id[at - 1]};
+                    if (!cand_less(x, y, pool)) break;
+                    S.out_d[at] = S.out_d[at - 1];
+                    S.out_id[at] = S.out_id[at - 1];
+                    at--;
+                }
+                S.out_d[at] = S.fin[k].d;
+                S.out_id[at] = x.id;
             }
-            for (int k = 0; k < n; k++) nn_pts[(size_t)k * nn_stride + q] = pool[c[k].id];
+            for (int k = 0; k < n; k++) nn_pts[(size_t)k * nn_stride + q] = pool[S.out_id[k]];
         }
         if (!keep_order) atomicAdd(&md->n_tie_boundary, 1ull);
     }
@@ -700,24 +762,18 @@ template <int KM, int MODE>
 __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
                                                float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
-                                               const uint32_t* __restrict__ tie_list, const uint32_t* __restrict__ seq, MapDev* md, int tie_mode,
-                                               uint32_t n_all) {
+                                               uint32_t* __restrict__ tie_list, int tie_mode) {
     __shared__ GroupLds lds[kGPB];
-    __shared__ SelLds sel;
     const int tid = threadIdx.x;
     const int grp = tid / kG, gl = tid % kG;
     const int lane = tid & 63;
     GroupLds& g = lds[grp];
-    const bool as_reference = tie_mode != 0 && seq != nullptr;
-    // tie mode 2 (lio_map_set_tie_mode: the lists exactly as the reference returns them, order included -- a parity mode, slow): EVERY query of the
-    // scan goes through the reference's selection, not only the queued ones
-    const bool all = tie_mode == 2 && seq != nullptr;
-    const uint32_t n = all ? n_all : *n_tie;
+    const uint32_t n = *n_tie;
     const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
     for (uint32_t w0 = blockIdx.x * kGPB; w0 < n; w0 += gridDim.x * kGPB) {
         const uint32_t w = w0 + grp;
         const bool active = w < n;
-        const uint32_t q = active ? (all ? w : tie_list[w]) : 0u;
+        const uint32_t q = active ? (tie_list[w] & 0x7FFFFFFFu) : 0u;
         float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) {
             const float4 pq = queries[q];
@@ -728,7 +784,6 @@ __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, u
         pos2grid(pw.x, pw.y, pw.z, inv_res, kx, ky, kz);
         uint32_t nhit = 0;
         const uint32_t total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
-        if (tid == 0) sel.n_queue = 0;
         __syncthreads();
         // every lane keeps its SIX smallest: the sixth of the whole query decides whether the fifth place is contested
         Cand e[6];
@@ -796,10 +851,8 @@ __device__ __forceinline__ void knn_exact_body(const Slot* __restrict__ table, u
             }
         }
         if (active && gl < 5 && win != kNoIdx) nn_pts[(size_t)gl * nn_stride + q] = pool[win];
-        if (as_reference && active && gl == 0 && (all || d_fifth == d_sixth)) sel.queue[atomicAdd(&sel.n_queue, 1u)] = q;
-        __syncthreads();
-        const uint32_t nq = sel.n_queue;
-        for (uint32_t k = 0; k < nq; k++) refsel_query<MODE>(table, mask, pool, seq, inv_res, st, pose, queries, sel.queue[k], nn_pts, nn_stride, md, sel, all);
+        // the fifth place is contested: the entry is marked (top bit) for the selection kernel that follows (knn_refsel_*)
+        if (tie_mode != 0 && active && gl == 0 && d_fifth == d_sixth) tie_list[w] = q | 0x80000000u;
         __syncthreads();
     }
 }
@@ -808,22 +861,60 @@ template <int KM, int MODE>
 __global__ void __launch_bounds__(256) knn_exact_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                         float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries,
                                                         float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
-                                                        const uint32_t* __restrict__ tie_list, const uint32_t* __restrict__ seq, MapDev* md, int tie_mode,
-                                                        uint32_t n_all) {
-    knn_exact_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, nn_pts, nn_stride, n_tie, tie_list, seq, md, tie_mode, n_all);
+                                                        uint32_t* __restrict__ tie_list, int tie_mode) {
+    knn_exact_body<KM, MODE>(table, mask, pool, inv_res, st, pose, queries, nn_pts, nn_stride, n_tie, tie_list, tie_mode);
+}
+// step 2: the marked entries of the tie list (tie mode 2: every query, q = 0 .. n_all - 1), one at a time by the whole workgroup
+template <int MODE>
+__device__ __forceinline__ void knn_refsel_body(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, const uint32_t* __restrict__ seq,
+                                                float inv_res, const StencilArgs& st, const PoseArgs& pose, const float4* __restrict__ queries,
+                                                float4* __restrict__ nn_pts, uint32_t nn_stride, const uint32_t* __restrict__ n_tie,
+                                                const uint32_t* __restrict__ tie_list, MapDev* md, int tie_mode, uint32_t n_all) {
+    __shared__ SelLds sel;
+    const bool all = tie_mode == 2;
+    const uint32_t n = all ? n_all : *n_tie;
+    for (uint32_t w = blockIdx.x; w < n; w += gridDim.x) {
+        const uint32_t ent = all ? (w | 0x80000000u) : tie_list[w];
+        if (!(ent >> 31)) continue;  // (workgroup-uniform)
+        refsel_query<MODE>(table, mask, pool, seq, inv_res, st, pose, queries, ent & 0x7FFFFFFFu, nn_pts, nn_stride, md, sel, all);
+    }
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) knn_refsel_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool, const uint32_t* __restrict__ seq,
+                                                         float inv_res, StencilArgs st, PoseArgs pose, const float4* __restrict__ queries, float4* __restrict__ nn_pts,
+                                                         uint32_t nn_stride, const uint32_t* __restrict__ n_tie, const uint32_t* __restrict__ tie_list, MapDev* md,
+                                                         int tie_mode, uint32_t n_all) {
+    knn_refsel_body<MODE>(table, mask, pool, seq, inv_res, st, pose, queries, nn_pts, nn_stride, n_tie, tie_list, md, tie_mode, n_all);
+}
+__global__ void __launch_bounds__(256) knn_refsel_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+                                                               const uint32_t* __restrict__ seq, float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots,
+                                                               MapDev* md, int tie_mode) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active || (d.sd->n_tie == 0 && tie_mode != 2)) return;
+    const SlotGate sg = slot_gate(d);
+    if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
+    knn_refsel_body<0>(table, mask, pool, seq, inv_res, st, sg.pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, md, tie_mode, sg.n_ds);
+}
+__global__ void __launch_bounds__(256) knn_refsel_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id, const SlotDesc* __restrict__ slots) {
+    const SlotDesc& d = slots[blockIdx.y];
+    if (!d.active) return;
+    const MapRef& r = maps[blockIdx.y];
+    if (r.stencil_id != stencil_id || r.tie_mode == 0 || !r.pool_seq || (d.sd->n_tie == 0 && r.tie_mode != 2)) return;
+    const SlotGate sg = slot_gate(d);
+    if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
+    knn_refsel_body<0>(r.table, r.mask, r.pool, r.pool_seq, r.inv_res, st, sg.pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, r.md, r.tie_mode, sg.n_ds);
 }
 // batch form: the queries the search of this pass queued (usually none: the kernel then ends at once); the queue is re-armed by the
 // filter-pass kernel that follows the linearisation
 template <int KM>
 __global__ void __launch_bounds__(256) knn_exact_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
-                                                              float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots,
-                                                              const uint32_t* __restrict__ seq, MapDev* md, int tie_mode) {
+                                                              float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, int tie_mode) {
     const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active || (d.sd->n_tie == 0 && tie_mode != 2)) return;
+    if (!d.active || d.sd->n_tie == 0) return;
     const SlotGate sg = slot_gate(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
     const PoseArgs& pose = sg.pose;
-    knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, seq, md, tie_mode, sg.n_ds);
+    knn_exact_body<KM, 0>(table, mask, pool, inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, tie_mode);
 }
 
 // Tied queries are queued and redone by a second (usually empty) launch.  (Measured and dropped in round 3: redoing them in place -- one
@@ -842,19 +933,24 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
     if (grid_x > cap) grid_x = cap;  // grid-stride loop inside: 16 queries per workgroup and round
     if (grid_x == 0) grid_x = 8;
     const dim3 grid((grid_x + 7u) & ~7u, (uint32_t)n_slots);
-    const dim3 gridx(m->tie_mode == 2 ? 64 : (n_slots > 8 ? 8 : 64), (uint32_t)n_slots);  // the tie queue of a scan holds a handful of queries at most: a few workgroups per slot (grid-stride inside)
+    const dim3 gridx(n_slots > 8 ? 8 : 64, (uint32_t)n_slots);  // the tie queue of a scan holds a handful of queries at most: a few workgroups per slot (grid-stride inside)
+    const int tmode = m->pool_seq ? m->tie_mode : 0;
     const int km = (m->stencil.n + kG - 1) / kG;
 #define KNNB_LAUNCH(KM)                                                                                                                              \
     do {                                                                                                                                             \
         if (count_touched) hipLaunchKernelGGL((knn_batch_kernel<KM, true>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
         else hipLaunchKernelGGL((knn_batch_kernel<KM, false>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \
-        hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->pool_seq, m->dev, m->tie_mode); \
+        hipLaunchKernelGGL((knn_exact_batch_kernel<KM>), gridx, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, tmode); \
     } while (0)
     if (km <= 1) KNNB_LAUNCH(1);
     else if (km <= 2) KNNB_LAUNCH(2);
     else if (km <= 3) KNNB_LAUNCH(3);
     else KNNB_LAUNCH((kMaxStencil + kG - 1) / kG);
 #undef KNNB_LAUNCH
+    // step 2 of the exact redo (the reference's selection for the queries whose fifth place is contested): usually finds nothing marked and ends at once
+    if (tmode != 0)
+        hipLaunchKernelGGL(knn_refsel_batch_kernel, dim3(tmode == 2 ? 256 : 4, (uint32_t)n_slots), 256, 0, st, m->table, m->table_mask, m->pool, m->pool_seq, m->inv_res,
+                           m->stencil, d_slots, m->dev, tmode);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }
@@ -868,21 +964,22 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_seq_kernel(const MapRe
     if (!d.active) return;
     const MapRef& r = maps[blockIdx.y];
     if (r.stencil_id != stencil_id) return;
-    const SlotGate sg = slot_gate(d);
+    const SlotGateLite sg = slot_gate_lite(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
-    const PoseArgs& pose = sg.pose;
-    knn_body<KM, 0, false>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts, d.max_ds, d.nn_cnt, r.md, &d.sd->n_tie, d.tie_list);
+    const double* __restrict__ x = d.ctrl->x;
+    knn_body<KM, 0, false>(r.table, r.mask, r.pool, r.inv_res, st, [x](PoseArgs& P) { pose_fill_from_state(P, x); }, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts, d.max_ds,
+                           d.nn_cnt, r.md, &d.sd->n_tie, d.tie_list);
 }
 template <int KM>
 __global__ void __launch_bounds__(256) knn_exact_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id, const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
     const MapRef& r = maps[blockIdx.y];
-    if (r.stencil_id != stencil_id || (d.sd->n_tie == 0 && r.tie_mode != 2)) return;
+    if (r.stencil_id != stencil_id || d.sd->n_tie == 0) return;
     const SlotGate sg = slot_gate(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
     const PoseArgs& pose = sg.pose;
-    knn_exact_body<KM, 0>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, r.pool_seq, r.md, r.tie_mode, sg.n_ds);
+    knn_exact_body<KM, 0>(r.table, r.mask, r.pool, r.inv_res, st, pose, d.ds_body, d.nn_pts, d.max_ds, &d.sd->n_tie, d.tie_list, r.pool_seq ? r.tie_mode : 0);
 }
 
 int knn_seq_launch(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, const StencilArgs* stencils, const int* stencil_ids,
@@ -908,6 +1005,7 @@ int knn_seq_launch(hipStream_t st, const MapRef* d_maps, const SlotDesc* d_slots
         else if (km <= 3) KNNS_LAUNCH(3);
         else KNNS_LAUNCH((kMaxStencil + kG - 1) / kG);
 #undef KNNS_LAUNCH
+        hipLaunchKernelGGL(knn_refsel_seq_kernel, dim3(4, (uint32_t)n_slots), 256, 0, st, d_maps, sa, stencil_ids[k], d_slots);
     }
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
@@ -936,19 +1034,29 @@ static int launch_knn(lio_map* m, hipStream_t st, const PoseArgs& pose, const fl
 
 template <int MODE>
 static int launch_knn_exact(lio_map* m, hipStream_t st, const PoseArgs& pose, const float4* q, float4* nn_pts, uint32_t nn_stride,
-                            uint32_t n_tie_host, const uint32_t* n_tie, const uint32_t* tie_list, uint32_t n_all = 0) {
+                            uint32_t n_tie_host, const uint32_t* n_tie, uint32_t* tie_list, uint32_t n_all = 0) {
+    const int tmode = m->pool_seq ? m->tie_mode : 0;
+    if (tmode == 2 && n_all) {  // every query through the reference's selection (the canonical lists of the search stay where a voxel overflows the staging area)
+        hipLaunchKernelGGL((knn_refsel_kernel<MODE>), n_all < 4096u ? n_all : 4096u, 256, 0, st, m->table, m->table_mask, m->pool, m->pool_seq, m->inv_res, m->stencil, pose,
+                           q, nn_pts, nn_stride, n_tie, tie_list, m->dev, tmode, n_all);
+        LIO_HIP_TRY(hipGetLastError());
+        return LIO_OK;
+    }
     uint32_t blocks = (n_tie_host + kGPB - 1) / kGPB;
     if (blocks == 0) return LIO_OK;
     if (blocks > 4096) blocks = 4096;
 #define KNNX_LAUNCH(KM)                                                                                                                      \
     hipLaunchKernelGGL((knn_exact_kernel<KM, MODE>), blocks, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, pose, q, nn_pts, \
-                       nn_stride, n_tie, tie_list, m->pool_seq, m->dev, m->tie_mode, n_all)
+                       nn_stride, n_tie, tie_list, tmode)
     const int km = (m->stencil.n + kG - 1) / kG;
     if (km <= 1) KNNX_LAUNCH(1);
     else if (km <= 2) KNNX_LAUNCH(2);
     else if (km <= 3) KNNX_LAUNCH(3);
     else KNNX_LAUNCH((kMaxStencil + kG - 1) / kG);
 #undef KNNX_LAUNCH
+    if (tmode != 0)
+        hipLaunchKernelGGL((knn_refsel_kernel<MODE>), n_tie_host < 1024u ? n_tie_host : 1024u, 256, 0, st, m->table, m->table_mask, m->pool, m->pool_seq, m->inv_res, m->stencil,
+                           pose, q, nn_pts, nn_stride, n_tie, tie_list, m->dev, tmode, 0u);
     LIO_HIP_TRY(hipGetLastError());
     return LIO_OK;
 }
@@ -983,7 +1091,7 @@ int knn_batch(lio_map* m, const float4* d_q, uint32_t n, float4* d_out, int32_t*
     uint32_t nt = 0;
     LIO_HIP_TRY(hipMemcpyAsync(&nt, d_tie, 4, hipMemcpyDeviceToHost, m->stream));
     LIO_HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->tie_mode == 2 && m->pool_seq) rc = launch_knn_exact<1>(m, m->stream, pose, d_q, d_out, n, n, d_tie, d_tie + 1, n);
+    if (m->tie_mode == 2 && m->pool_seq && n) rc = launch_knn_exact<1>(m, m->stream, pose, d_q, d_out, n, n, d_tie, d_tie + 1, n);
     else if (nt) rc = launch_knn_exact<1>(m, m->stream, pose, d_q, d_out, n, nt, d_tie, d_tie + 1);
     return rc;
 }

@@ -87,4 +87,32 @@ __device__ __forceinline__ SlotGate slot_gate(const SlotDesc& d) {
     return g;
 }
 
+// the gate alone (kernels that keep the pose out of their scalar registers: the neighbour search reads it into LDS, see knn.hip)
+struct SlotGateLite {
+    int status, converge;
+    uint32_t n_ds;
+};
+__device__ __forceinline__ SlotGateLite slot_gate_lite(const SlotDesc& d) {
+    const EskfDev* c = d.ctrl;
+    uint32_t st = (uint32_t)c->status, cv = (uint32_t)c->converge, n = d.sd->n_ds;
+    pin_loaded(st);
+    pin_loaded(cv);
+    pin_loaded(n);
+    SlotGateLite g;
+    g.status = (int)st;
+    g.converge = (int)cv;
+    g.n_ds = n;
+    return g;
+}
+// threads 0..13 of a workgroup copy the rigid transforms of a 26-number filter state (lio_hip.h layout: pos, rot, offset_R_L_I, offset_T_L_I) into a
+// PoseArgs in LDS; the caller's next barrier publishes it
+__device__ __forceinline__ void pose_fill_from_state(PoseArgs& P, const double* __restrict__ x) {
+    const int t = threadIdx.x;
+    if (t < 14) {
+        const double v = x[t];
+        double* dst = t < 3 ? &P.tw[t] : (t < 7 ? &P.qw[t - 3] : (t < 11 ? &P.ql[t - 7] : &P.tl[t - 11]));
+        *dst = v;
+    }
+}
+
 }  // namespace lio
