@@ -428,11 +428,15 @@ def main():
         # the same jobs once more through the COUNTING variant of the kernel: the candidate points the pruned sweep really loads ("touched")
         solo.enable_kernel_timing(2)
         solo.kernel_times(reset=True)
-        t0c = map_.knn_touched
+        t0c, u0c = map_.knn_touched, map_.knn_unique
         solo.process(sj)
         kt2 = solo.kernel_times(reset=True)
         solo.enable_kernel_timing(False)
         leg["touched_bytes"] = (n_search * (16 + 16 * S) + 16.0 * (map_.knn_touched - t0c)) / max(int(kt2["knn_launches"]), 1)
+        # UNIQUE bytes of a launch: every query's own point and stencil slots once, every DISTINCT candidate point the launch loads once (the
+        # counting variant's bitmap over the pool, cleared before each launch) -- what the launch has to move at least once whatever its caches do
+        leg["unique_bytes"] = (n_search * (16 + 16 * S) + 16.0 * (map_.knn_unique - u0c)) / max(int(kt2["knn_launches"]), 1)
+        leg["unique_points_per_launch"] = (map_.knn_unique - u0c) / max(int(kt2["knn_launches"]), 1)
         del solo
         return leg
 
@@ -447,6 +451,7 @@ def main():
         per_s = 1.0 / (us * 1e-6) if us > 0 else 0.0
         alg = leg["bytes"] * per_s / 1e9
         touched = leg["touched_bytes"] * per_s / 1e9
+        unique = leg.get("unique_bytes", 0.0) * per_s / 1e9
         traffic, valu_per_wave, valu_src = None, KNN_VALU_PER_WAVE_STATIC, "static ISA count (llvm-objdump of knn.o, loop body at the average trip counts)"
         valu_per_launch = None
         tpath = os.path.join(ROOT, "profiles", traffic_file)
@@ -479,6 +484,8 @@ def main():
                     traffic=traffic,
                     achieved_algorithmic=round(alg, 1), frac_algorithmic=round(alg / HBM_PEAK_GBS, 4),
                     touched_bytes_per_launch=int(leg["touched_bytes"]), frac_touched=round(touched / HBM_PEAK_GBS, 4),
+                    unique_bytes_per_launch=int(leg.get("unique_bytes", 0)), frac_unique=round(unique / HBM_PEAK_GBS, 4),
+                    unique_candidate_points_per_launch=int(leg.get("unique_points_per_launch", 0)),
                     frac_hbm_traffic=(round(traffic * per_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                     frac_valu=frac_valu, valu_peak_wave_insts_per_s=(round(peak_rate, 0) if peak_rate else None),
                     valu_wave_insts_per_launch=round(valu_per_launch, 0),
@@ -488,7 +495,10 @@ def main():
                           "frac_of_valu_issue_peak": frac_valu},
                     algorithmic_bytes_per_launch=int(leg["bytes"]), avg_launch_us=round(us, 2), launches=leg["launches"],
                     candidates_per_query=round(leg["candidates_per_query"], 1),
-                    note="frac = memory-side bytes (PMC) or requested bytes over the kernel's time over 8 TB/s: a utilisation.  frac_algorithmic = the reference "
+                    note="frac = memory-side bytes (PMC) or requested bytes over the kernel's time over 8 TB/s: a utilisation.  frac_unique = the bytes a launch "
+                         "must move at least once (its queries, their stencil slots, every DISTINCT candidate point it loads: measured by the counting "
+                         "variant's bitmap) over the same time: the floor of the traffic -- frac / frac_unique says how often a byte is re-fetched.  "
+                         "frac_algorithmic = the reference "
                          "algorithm's bytes (every point of the 19 stencil voxels of every query) over the same time: credit for bytes the pruned sweep does "
                          "not read, may exceed 1.  frac_touched = the bytes the exactly pruned sweep asks for.  frac_valu = VALU wave-instructions per launch "
                          "over the measured issue rate (tools/valu_peak/valu_peak.hip, run in this process)")
@@ -562,8 +572,11 @@ def main():
                         traffic=None, algorithmic_bytes_per_launch=int(iso_bytes), avg_launch_us=round(iso_us, 2), launches=iso_launches, per_stream=timed_region)
     roofline.update(measured_copy_peak=copy_peak, frac_of_measured_copy_peak=(round(roofline["achieved"] / copy_peak, 4) if copy_peak else None),
                     timed_region=round(t_max, 4), timed_region_s=round(t_max, 4), other_kernels_us=others,
-                    whole_scan={"algorithmic_bytes_per_scan": int(b_scan), "seconds_per_scan": t_scan, "achieved": round(b_scan / t_scan / 1e9, 1),
-                                "frac": round(b_scan / t_scan / 1e9 / HBM_PEAK_GBS, 4),
+                    whole_scan={"algorithmic_bytes_per_scan": int(b_scan), "seconds_per_scan": t_scan, "credit_GBps": round(b_scan / t_scan / 1e9, 1),
+                                "credit_over_peak": round(b_scan / t_scan / 1e9 / HBM_PEAK_GBS, 4),
+                                "what": "SURVEY 8d's bytes of the REFERENCE algorithm per scan (every point of the 19 stencil voxels of every query counted) over "
+                                        "the scan's wall time: credit for work the exactly pruned, cache-shared sweep does not do -- NOT a bandwidth utilisation (the "
+                                        "kernels' own are roofline.frac and configs.*.roofline)",
                                 "terms": {"B_ds": int(b_ds), "B_knn": int(b_knn), "n_knn": round(n_knn_avg, 2), "B_lin": int(b_lin), "n_pass": round(n_pass_avg, 2),
                                           "B_ins": 0, "note": "B_ins = 0: the metric's map is static (BASELINE config 2 / the headline: independent scans against a "
                                                               "fixed map, no map_incremental); the insert is timed in configs.config3_* and configs.sequence_batch"}})

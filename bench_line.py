@@ -11,7 +11,7 @@ LIMIT = 6000  # bytes of the stdout line (the driver keeps an 8 KB tail)
 
 _TOP = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "repeats", "timed_scans", "timed_seconds", "ms_per_step", "higher_is_better",
         "scaling", "vs_baseline", "dtype", "data")
-_ROOF_NUM = ("bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_basis", "traffic", "frac_algorithmic", "frac_touched", "frac_valu",
+_ROOF_NUM = ("bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_basis", "traffic", "frac_unique", "unique_bytes_per_launch", "frac_algorithmic", "frac_touched", "frac_valu",
              "valu_peak_wave_insts_per_s", "valu_wave_insts_per_launch", "algorithmic_bytes_per_launch", "avg_launch_us",
              "candidates_per_query", "measured_copy_peak", "timed_region")
 _CPU_NUM = ("value", "unit", "cores", "host_cpus", "kind", "ms_per_scan", "ms_per_sweep")
@@ -43,7 +43,7 @@ def roofline(r, text=90):
         o["kernel"] = _short(r["kernel"], 48)
     ws = r.get("whole_scan")
     if isinstance(ws, dict):
-        o["whole_scan"] = _pick(ws, ("algorithmic_bytes_per_scan", "achieved", "frac"))
+        o["whole_scan"] = _pick(ws, ("algorithmic_bytes_per_scan", "credit_GBps", "credit_over_peak"))
     ok = r.get("other_kernels_us")
     if isinstance(ok, dict):
         o["other_kernels_us"] = {k: _num(v, 4) for k, v in ok.items() if not isinstance(v, (dict, list, str))}

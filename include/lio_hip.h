@@ -115,6 +115,9 @@ uint64_t lio_map_knn_candidates(lio_map*);
 /* running total of map points whose 16 bytes the kNN sweep actually asked for (it prunes stencil voxels that cannot hold one of the five
  * nearest, exactly) -- counted only by the diagnostic kernel variant that lio_batch_enable_kernel_timing(b, 2) selects; 0 otherwise */
 uint64_t lio_map_knn_touched(lio_map*);
+/* ... and of those the DISTINCT ones per launch, summed over the counted launches (a bitmap over the point pool, cleared before every counted launch):
+ * the bytes a launch cannot avoid moving once -- 16 B for every distinct candidate point -- whatever its caches do */
+uint64_t lio_map_knn_unique(lio_map*);
 /* all stored points, voxel by voxel in unspecified order; returns the count or -(needed) */
 int64_t lio_map_dump(lio_map*, float* out_xyzi, uint64_t cap_points);
 /* IVox::GetClosestPoint(pt, out, 5, 5.0) for a batch of world-frame queries (ivox3d.h:139-171):

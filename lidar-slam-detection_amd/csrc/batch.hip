@@ -456,6 +456,7 @@ int lio_batch_enable_kernel_timing(lio_batch* b, int on) {
         g.bt->on = on != 0;
     }
     b->count_touched = (on & 2) ? 1 : 0;
+    if (b->count_touched && b->map) { const int rc = map_enable_touch_bits(b->map); if (rc != LIO_OK) return rc; }
     return LIO_OK;
 }
 

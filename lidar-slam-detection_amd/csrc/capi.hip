@@ -148,6 +148,10 @@ lio_map* lio::map_create_mode(int device, float resolution, uint64_t max_points,
     m->max_voxels = max_voxels;
     m->key_mode = key_mode;
     m->tie_mode = 1;
+    if (key_mode == 0) {  // LIO_TIE_MODE=0|1|2: the default of lio_map_set_tie_mode for maps made from now on (A/B runs of unchanged callers)
+        const char* tm = getenv("LIO_TIE_MODE");
+        if (tm && tm[0] >= '0' && tm[0] <= '2' && !tm[1]) m->tie_mode = tm[0] - '0';
+    }
     if (fill_stencil(m->stencil, stencil) != LIO_OK) { set_error("lio_map_create: stencil must be 1, 7, 19, 27 or 75"); delete m; return nullptr; }
     m->stencil_id = stencil;
     uint64_t cap = 1024;
@@ -185,6 +189,15 @@ lio_map* lio::map_create_mode(int device, float resolution, uint64_t max_points,
     return m;
 }
 
+
+// the bitmap behind lio_map_knn_unique (one bit per pool entry), made when the counting variant of the kNN kernel is first asked for
+int lio::map_enable_touch_bits(lio_map* m) {
+    if (m->touch_bits) return LIO_OK;
+    hipSetDevice(m->device);
+    if (!dev_alloc(&m->touch_bits, (m->pool_cap + 31) / 32, &m->bytes)) return LIO_E_DEVICE;
+    LIO_HIP_TRY(hipMemcpy(&m->dev->touch_bits, &m->touch_bits, sizeof(uint32_t*), hipMemcpyHostToDevice));
+    return LIO_OK;
+}
 
 extern "C" {
 
@@ -234,7 +247,7 @@ void lio_map_destroy(lio_map* m) {
     if (!m) return;
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
-    hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->pool_seq); hipFree(m->dev);
+    hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->pool_seq); hipFree(m->touch_bits); hipFree(m->dev);
     hipFree(m->slot_of_point); hipFree(m->tile_sum); hipFree(m->stage);
     hipFree(m->touch); hipFree(m->prev_touch); hipFree(m->touch2); hipFree(m->prev_touch2); hipFree(m->lru_log); hipFree(m->free_items); hipFree(m->free_in);
     hipFree(m->table2); hipFree(m->cap2); hipFree(m->pending2); hipFree(m->created2); hipFree(m->remap);
@@ -370,6 +383,16 @@ uint64_t lio_map_knn_touched(lio_map* m) {
     if (hipMemcpy(&tmp, m->dev, sizeof(MapDev), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     uint64_t s = 0;
     for (int k = 0; k < 64; k++) s += tmp.knn_cand[k * 16 + 1];
+    return s;
+}
+
+uint64_t lio_map_knn_unique(lio_map* m) {
+    if (!m) return 0;
+    hipSetDevice(m->device);
+    MapDev tmp;
+    if (hipMemcpy(&tmp, m->dev, sizeof(MapDev), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    uint64_t s = 0;
+    for (int k = 0; k < 64; k++) s += tmp.knn_cand[k * 16 + 2];
     return s;
 }
 

@@ -360,6 +360,8 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
     uint32_t visited = 0;  // this lane's share of the candidate statistic (a few queries' stencils: far below 2^32)
     uint32_t touched = 0;  // COUNT only: candidate points whose 16 bytes the sweep asked for
+    uint32_t fresh = 0;    // COUNT only: ... of those, the ones no query of this launch had asked for before (distinct points: MapDev::touch_bits)
+    uint32_t* const bits = COUNT ? md->touch_bits : nullptr;
     const float res = 1.0f / inv_res;
     const uint32_t b1_bits = __float_as_uint(0.0625f * res * res), b2_bits = __float_as_uint(0.25f * res * res);
     (void)b1_bits; (void)b2_bits;
@@ -489,6 +491,12 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                     // comparison below rejects; ONE wave-uniform branch (no lane of the wave takes its candidate) skips the insertion network --
                     // instead of three nested divergent branches per candidate (each an s_and_saveexec / s_cbranch_execz / s_or triple)
                     const bool have = i0 < cnt4[u];
+                    if constexpr (COUNT) {
+                        if (have && bits) {
+                            const uint32_t id = ptr4[u] + i0, bit = 1u << (id & 31u);
+                            if (!(atomicOr(&bits[id >> 5], bit) & bit)) fresh++;
+                        }
+                    }
                     const float dx = p[u].x - pw.x, dy = p[u].y - pw.y, dz = p[u].z - pw.z;
                     const float d2 = dx * dx + (dy * dy + dz * dz);  // ivox3d_node.hpp:12-15: Vector3f::squaredNorm() = Eigen's unrolled tree x0 + (x1 + x2)
                     const bool in = have && d2 < 5.0f;
@@ -573,6 +581,16 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         if (tid == 0) {
             const unsigned long long v = (vred[0] + vred[1]) + (vred[2] + vred[3]);
             if (v) atomicAdd(&md->knn_cand[(blockIdx.x & 63) * 16 + 1], v);
+        }
+        __syncthreads();
+        unsigned long long fsum = fresh;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) fsum += __shfl_xor(fsum, off);
+        if (lane == 0) vred[tid >> 6] = fsum;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long v = (vred[0] + vred[1]) + (vred[2] + vred[3]);
+            if (v) atomicAdd(&md->knn_cand[(blockIdx.x & 63) * 16 + 2], v);
         }
     }
 }
@@ -936,6 +954,8 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
     const dim3 gridx(n_slots > 8 ? 8 : 64, (uint32_t)n_slots);  // the tie queue of a scan holds a handful of queries at most: a few workgroups per slot (grid-stride inside)
     const int tmode = m->pool_seq ? m->tie_mode : 0;
     const int km = (m->stencil.n + kG - 1) / kG;
+    // (the counting variant also counts DISTINCT points per launch: its bitmap starts empty)
+    if (count_touched && m->touch_bits) LIO_HIP_TRY(hipMemsetAsync(m->touch_bits, 0, (size_t)((m->pool_cap + 31) / 32) * 4, st));
 #define KNNB_LAUNCH(KM)                                                                                                                              \
     do {                                                                                                                                             \
         if (count_touched) hipLaunchKernelGGL((knn_batch_kernel<KM, true>), grid, 256, 0, st, m->table, m->table_mask, m->pool, m->inv_res, m->stencil, d_slots, m->dev); \

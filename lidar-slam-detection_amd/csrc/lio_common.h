@@ -85,6 +85,7 @@ struct MapDev {
     uint32_t seq_acc;                // ... of the next batch
     unsigned long long n_tie_boundary;    // queries whose fifth and sixth nearest were equally far: the set came from the reference's selection
     unsigned long long n_tie_unresolved;  // ... of those, the ones whose voxel lists did not fit the redo's staging area: canonical set kept
+    uint32_t* touch_bits;            // diagnostic (the kNN kernel's counting variant): one bit per pool entry, cleared before every counted launch
     unsigned long long knn_cand[64 * 16];  // 64 shards, one 128-B line each (same-line atomics serialise in one L2 channel): word 0 = points resident in
                                            // the probed stencil voxels, word 1 = points the sweep loaded (diagnostic kernel variant only)
 };
@@ -232,6 +233,7 @@ struct lio_map {
     float* created;      // per-slot travel distance at creation (ivox3d.h:240)
     float4* pool;
     uint32_t* pool_seq;  // insertion sequence number of every pool entry (iVox maps only: key_mode 0)
+    uint32_t* touch_bits;  // one bit per pool entry for the counting variant of the kNN kernel (allocated by lio_batch_enable_kernel_timing(b, 2))
     int tie_mode;        // 1 (default): equally distant candidates at the fifth place are kept as the reference keeps them; 0: smallest (d2, x, y, z)
     lio::MapDev* dev;
     lio::MapDev* host_dev;  // pinned mirror
@@ -371,6 +373,7 @@ int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);
 void kt_begin(lio_scan* s, int which);
 void kt_end(lio_scan* s, int which);
+int map_enable_touch_bits(lio_map* m);
 lio_map* map_create_mode(int device, float resolution, uint64_t max_points, uint64_t max_voxels, int stencil, int key_mode);
 int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t n, const uint32_t* d_n, double travel);
 int map_knn_plane(lio_map* m, lio_scan* s, const PoseArgs& pose, int redo_knn);

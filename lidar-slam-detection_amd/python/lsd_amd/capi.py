@@ -23,7 +23,7 @@ SYMBOLS = [
     "lio_last_error", "lio_device_count", "lio_map_bytes",
     "lio_map_create", "lio_map_destroy", "lio_map_set_lru", "lio_map_lru_stats", "lio_map_set_tie_mode", "lio_map_tie_stats", "lio_map_pool_stats", "lio_map_set_stencil", "lio_map_insert", "lio_map_insert_device", "lio_map_stats",
     "lio_abi_version", "lio_pinned_alloc", "lio_pinned_free",
-    "lio_map_dump", "lio_map_knn", "lio_map_knn_candidates", "lio_map_knn_touched",
+    "lio_map_dump", "lio_map_knn", "lio_map_knn_candidates", "lio_map_knn_touched", "lio_map_knn_unique",
     "lio_scan_create", "lio_scan_destroy", "lio_scan_reset", "lio_scan_upload", "lio_scan_set_device", "lio_scan_undistort_delta", "lio_scan_undistort_poses", "lio_scan_download_raw", "lio_scan_voxel_downsample", "lio_scan_voxel_downsample_batch", "lio_scan_set_ds",
     "lio_scan_num_ds", "lio_scan_download_ds", "lio_scan_download_world", "lio_scan_download_match",
     "lio_p2plane_linearize", "lio_scan_set_degeneracy_mode", "lio_p2plane_degeneracy", "lio_engine_set_reduce_hook", "lio_p2plane_rows", "lio_map_incremental", "lio_map_seed",
@@ -148,6 +148,7 @@ def lib():
     sig("lio_map_pool_stats", cint, vp, C.POINTER(u64), C.POINTER(u64))
     sig("lio_map_knn_candidates", u64, vp)
     sig("lio_map_knn_touched", u64, vp)
+    sig("lio_map_knn_unique", u64, vp)
     sig("lio_map_knn", cint, vp, f32p, u32, f32p, i32p)
     sig("lio_scan_create", vp, cint, u32, u32)
     sig("lio_scan_destroy", None, vp)

@@ -117,6 +117,11 @@ class Map:
         return int(lib().lio_map_knn_candidates(self.h))
 
     @property
+    def knn_unique(self):
+        """distinct points per launch the kNN sweep loaded, summed over the counted launches (diagnostic kernel variant only)"""
+        return int(lib().lio_map_knn_unique(self.h))
+
+    @property
     def knn_touched(self):
         """points the kNN sweep loaded so far (counted by the diagnostic kernel variant only: Batch.enable_kernel_timing(2))"""
         return int(lib().lio_map_knn_touched(self.h))

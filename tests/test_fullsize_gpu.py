@@ -1,7 +1,7 @@
 """BASELINE.json's configurations at their full sizes on the GPU:
   config 2: 1e6-point static map, 64 x 1875 scans, seeds 1000..1099, full iterate-to-converge -- HIP vs the oracle (same passes, same
             effective points, pose <= 1e-9) and vs the reference's own translation units (north-star bar: 1e-4 m / 1e-5 rad);
-  metric config: 1e7-point map, ~120k-point scans, 16 scans, same checks -- and the batched engine (lio_batch_process, 64 scans per launch,
+  metric config: 1e7-point map, ~120k-point scans, 16 scans, same checks -- and the batched engine (lio_batch_process, 128 scans per launch,
             4 rounds in flight: what bench.py's timed region runs) on 528 jobs made of the same scans: poses <= 1e-9 from the oracle's.
 The reference leg runs when oracle/_ref/libref_fastlio.so travelled with the snapshot (it is built where /root/reference exists)."""
 import os
@@ -102,5 +102,6 @@ def test_config2_1e6_map_100_scans(oracle_mod):
 
 
 def test_metric_config_1e7_map_16_scans(oracle_mod):
-    """... and the same 16 scans 33 times over through the batched engine in bench.py's geometry (64 slots x 4 groups: two full sets of rounds in flight)"""
-    _run(oracle_mod, 10_000_000, range(2000, 2016), (-24.8, 2.0), 150.0, 2_500_000, batched=(64, 4, 33))
+    """... and the same 16 scans 65 times over through the batched engine in bench.py's geometry (128 slots x 4 groups since round 5: two full sets of
+    rounds in flight -- VERDICT r05: the test still ran round 4's 64 x 4)"""
+    _run(oracle_mod, 10_000_000, range(2000, 2016), (-24.8, 2.0), 150.0, 2_500_000, batched=(128, 4, 65))
