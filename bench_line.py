@@ -64,6 +64,9 @@ def _beyond(g):
             o = {"scans": g.get("scans"), "beyond_1e-4m_or_1e-5rad": g[k], "max_dpos_m": _num(g.get("max_dpos_m"), 3), "max_drot_rad": _num(g.get("max_drot_rad"), 3)}
             if _own(g) is not None:
                 o["reference_run_to_run_max_dpos_m"] = _own(g)
+            pe = g.get("per_scan_envelope")
+            if isinstance(pe, dict):
+                o["inside_the_references_own_per_scan_envelope"] = "%s of %s" % (pe.get("hip_inside_the_references_own_envelope"), pe.get("scans"))
             return o
     return None
 

@@ -41,17 +41,17 @@ def batch_scans():
     return out
 
 
-def run_batch(sub_maps_pts, gather=None, rank=0, world=1):
+def run_batch(sub_maps_pts, gather=None, rank=0, world=1, comm=None, device=0):
     """the scans of batch_scans() jointly against `sub_maps_pts` (this process's sub-maps); returns the result dictionaries"""
     import scenes
     from lsd_amd import lio
 
     maps = []
     for sub in sub_maps_pts:
-        m = lio.Map(resolution=0.5, stencil=19, max_points=400_000, max_voxels=200_000)
+        m = lio.Map(resolution=0.5, stencil=19, max_points=400_000, max_voxels=200_000, device=device)
         m.add(sub)
         maps.append(m)
-    b = lio.Batch(maps[0], n_slots=4, n_groups=2, max_raw=1 << 17, max_ds=1 << 16, sub_maps=maps[1:], comm=None)
+    b = lio.Batch(maps[0], n_slots=4, n_groups=2, max_raw=1 << 17, max_ds=1 << 16, sub_maps=maps[1:], comm=comm)
     if gather is not None:
         b.set_gather_hook(gather, rank, world)
     P0 = lio.init_cov()
@@ -69,6 +69,26 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     from lsd_amd import dist as ldist
 
+    if mode == "gpu_batch_rccl":
+        # the NATIVE exchange: one rank per GPU (cuda:rank), the C ABI's own RCCL communicator (lio_comm_init over a unique id made by rank 0 and
+        # handed round over gloo), ncclAllGather of the round's [B x 32] doubles on the round's stream inside lio_batch_process
+        import torch
+
+        from lsd_amd import lio
+
+        torch.cuda.set_device(rank)
+        box = [lio.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = lio.Comm(rank=rank, world=world, device=rank, uid=box[0])
+        subs4 = make_world(4)[0]
+        per = 4 // world
+        res = run_batch(subs4[rank * per:(rank + 1) * per], None, rank, world, comm=comm, device=rank)
+        n_calls, seconds = comm.stats()
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), states=np.array([r["state"] for r in res]), rcs=np.array([r["rc"] for r in res]),
+                 passes=np.array([[r["n_pass"], r["n_knn_pass"]] for r in res]), calls=n_calls, seconds=seconds)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode == "gpu_batch":
         subs4 = make_world(4)[0]
         per = 4 // world

@@ -221,6 +221,31 @@ def test_batched_joint_registration_two_ranks_one_gpu():
 
 
 @pytest.mark.gpu
+def test_batched_joint_registration_two_gpus_native_rccl_allgather():
+    """The same two-rank joint registration with the NATIVE exchange -- one process per GPU, the C ABI's RCCL communicator, ncclAllGather of the round's
+    records on the round's stream (csrc/comm.hip, step_batch<JOINT>) -- instead of the gloo hook that stands in for it where two ranks must share
+    one device.  Runs wherever two GPUs are visible (the first multi-GPU box exercises RCCL for real); skipped on the one-GPU boxes of this pool,
+    which is why `ncclAllGather` with more than one rank had never executed up to round 6."""
+    from lsd_amd import capi
+
+    if capi.lib().lio_device_count() < 2:
+        pytest.skip("needs two GPUs: ncclAllGather refuses two ranks on one device (covered there by the gloo gather hook, the test above)")
+    sys.path.insert(0, HERE)
+    from _dist_worker import batch_scans, make_world, run_batch
+
+    with tempfile.TemporaryDirectory() as td:
+        _run("gpu_batch_rccl", 2, td)
+        r0, r1 = np.load(os.path.join(td, "rank0.npz")), np.load(os.path.join(td, "rank1.npz"))
+    assert np.array_equal(r0["states"], r1["states"]) and np.array_equal(r0["passes"], r1["passes"])
+    assert np.all(r0["rcs"] == 3) and np.all(r1["rcs"] == 3)
+    assert int(r0["calls"]) == int(r1["calls"]) >= 2
+    one = run_batch(make_world(4)[0])
+    for k, (r, (_, _, pos)) in enumerate(zip(one, batch_scans())):
+        assert r["rc"] == 3 and (r["n_pass"], r["n_knn_pass"]) == tuple(r0["passes"][k])
+        assert np.abs(r["state"] - r0["states"][k]).max() < 1e-9, k
+
+
+@pytest.mark.gpu
 def test_batched_joint_registration_degenerate_scene_falls_back_to_the_host_path():
     """open ground: the eigenvalue bound of the GLOBAL sum n n^T does not decide, the six degeneracy sums are needed -- they live on several
     sub-maps, so the batched joint mode hands the scan to the host-driven joint path of the slot's engines: the result IS lio_engine_joint_register's"""
