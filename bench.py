@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--parity-scans", type=int, default=32, help="scans of the pool registered by the PINNED build of the reference (scalar Eigen, oracle/_ref/libref_fastlio.so) in a "
                                                                   "child process for cpu_baseline.gpu_vs_reference_pose.pinned_build")
     ap.add_argument("--parity-dir", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--tf-pinned", action="store_true", help=argparse.SUPPRESS)  # --config stream: the child process that runs the side-by-side legs against the pinned build
     ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)  # --config rcclprobe: the child process of rccl_probe (its job as JSON, or "uid")
     ap.add_argument("--full-line", action="store_true", help=argparse.SUPPRESS)  # the whole record on stdout (the metric config's children of the secondary legs)
     ap.add_argument("--upload-scans", type=int, default=-1, help="--config metric: scans of the upload-included leg (the pool from pinned host memory, copy overlapped "
@@ -199,6 +200,8 @@ def main():
 
     if args.config == "merge":
         return bench_merge(args, torch, dist, world, rank, local_rank, dev)
+    if args.config == "stream" and args.tf_pinned:
+        return stream_tf_pinned(args, torch, local_rank)
     if args.config == "stream":
         return bench_stream(args, torch, local_rank)
     if args.config == "localize":
@@ -293,7 +296,6 @@ def main():
     for i in range(20):
         step(i)
     latency_ms = 1e3 * (time.perf_counter() - l0) / 20
-
     if batch is None:
         for e in engines:
             e.scan.enable_kernel_timing(1)  # the dominant kernel only: two event records per kNN launch in the timed region
@@ -313,6 +315,22 @@ def main():
         return dict(dptr=s["d"].data_ptr(), n=len(s["raw"]), t=1.0 + 0.1 * i, state=s["guess"], cov=P0)
 
     jobs = [job_of(i) for i in range(args.steps)]
+    # ... and of the same scans one at a time through a ONE-slot batch: the whole registration (downsample chain, five passes of search / linearise /
+    # filter step on the device) as one captured graph and one hipGraphLaunch, against the host-driven per-pass loop above
+    latency_graph_ms = None
+    if rank == 0 and world == 1 and args.secondary:  # (not in the short forms the profiling passes run: its one-slot launches would enter their per-kernel averages)
+        try:
+            b1 = lio.Batch(the_map, n_slots=1, n_groups=1, max_raw=1 << 17, max_ds=100000)
+            for i in range(4):
+                b1.process([job_of(i)])
+            l0 = time.perf_counter()
+            for i in range(20):
+                b1.process([job_of(i)])
+            latency_graph_ms = 1e3 * (time.perf_counter() - l0) / 20
+            del b1
+        except Exception:
+            latency_graph_ms = None
+
     # calibration pass: long enough to fill every round in flight several times (a list shorter than slots x groups runs un-pipelined and
     # over-estimates the time per scan: round 4's first line had a 1.4 s region for --min-seconds 5)
     n_cal = max(8 * args.steps, 6 * args.slots * args.groups if batch is not None else 8 * n_streams)
@@ -669,7 +687,7 @@ def main():
                     sg = eng.get_state()
                     ref_dp = max(ref_dp, float(np.linalg.norm(sg[:3] - sr[:3])))
                     ref_da = max(ref_da, float(synth.quat_angle(sg[3:7], sr[3:7])))
-                    per_scan.append((float(np.linalg.norm(sg[:3] - sr[:3])), float(synth.quat_angle(sg[3:7], sr[3:7])), sg.copy()))
+                    per_scan.append((float(np.linalg.norm(sg[:3] - sr[:3])), float(synth.quat_angle(sg[3:7], sr[3:7])), sg.copy(), np.array(sr, dtype=np.float64).copy()))
             # `R` is the reference's code built with ITS flags (-O3 -DNDEBUG: Eigen vectorised, the compiler free to contract) -- the build that is
             # timed.  The build the path is PINNED to is the other one (oracle/_ref/libref_fastlio.so: scalar Eigen, no contraction -- DESIGN.md
             # section 4: Eigen's operation order depends on the build, and esti_plane's 5 x 3 QR is ill-conditioned for planes through the map
@@ -694,7 +712,8 @@ def main():
                     with tempfile.TemporaryDirectory(prefix="lio_bench_parity_") as td:
                         np.save(os.path.join(td, "map.npy"), map_pts)
                         np.savez(os.path.join(td, "scans.npz"), P0=P0, n=m_par, **{f"raw{i}": scans[i]["raw"] for i in range(m_par)},
-                                 **{f"guess{i}": scans[i]["guess"] for i in range(m_par)}, **{f"gpu{i}": per_scan[i][2] for i in range(m_par)})
+                                 **{f"guess{i}": scans[i]["guess"] for i in range(m_par)}, **{f"gpu{i}": per_scan[i][2] for i in range(m_par)},
+                                 **{f"rel{i}": per_scan[i][3] for i in range(m_par)})
                         pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "refparity", "--parity-dir", td], capture_output=True, text=True,
                                             timeout=600)
                     line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
@@ -775,7 +794,7 @@ def main():
                     R2.map_add(map2_pts)
                     R2.set_nearby(18)
                     m2 = min(40, args.ref_scans)
-                    t_r2, p_r2, e_r2, dps2, das2 = 0.0, 0, 0.0, [], []
+                    t_r2, p_r2, e_r2, dps2, das2, rel2 = 0.0, 0, 0.0, [], [], []
                     for i in range(m2):
                         sc2 = scans[i % len(scans)]
                         R2.reset_cache()
@@ -783,6 +802,7 @@ def main():
                         rc_r2, sr2, _ = R2.register(sc2["raw"], sc2["guess"], P0)
                         t_r2 += time.perf_counter() - c0
                         p_r2 += len(sc2["raw"])
+                        rel2.append(np.array(sr2, dtype=np.float64).copy())
                         if rc_r2 == 3:
                             dps2.append(float(np.linalg.norm(r2[i]["state"][:3] - sr2[:3])))
                             das2.append(float(synth.quat_angle(r2[i]["state"][3:7], sr2[3:7])))
@@ -795,6 +815,23 @@ def main():
                                                      f"(oracle/_ref/libref_fastlio_release.so, MP_PROC_NUM=8) against the same 1e6 map points, {t_r2:.1f} s",
                                               ms_per_scan=round(1e3 * t_r2 / m2, 2), gpu_vs_reference_pose_max_dpos_m=e_r2, gpu_vs_reference_pose=gvr2)
                     del R2
+                    try:  # ... and the build the path is PINNED to, in a child process (one build per process), with the release build's poses beside the GPU's
+                        import subprocess
+                        import tempfile
+
+                        with tempfile.TemporaryDirectory(prefix="lio_bench_parity2_") as td:
+                            np.save(os.path.join(td, "map.npy"), map2_pts)
+                            np.savez(os.path.join(td, "scans.npz"), P0=P0, n=m2, **{f"raw{i}": scans[i % len(scans)]["raw"] for i in range(m2)},
+                                     **{f"guess{i}": scans[i % len(scans)]["guess"] for i in range(m2)}, **{f"gpu{i}": r2[i]["state"] for i in range(m2)},
+                                     **{f"rel{i}": rel2[i] for i in range(m2)})
+                            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "refparity", "--parity-dir", td], capture_output=True, text=True,
+                                                timeout=600)
+                        line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                        if pr.returncode != 0 or not line:
+                            raise RuntimeError((pr.stderr or pr.stdout)[-300:])
+                        gvr2["pinned_build"] = json.loads(line[-1])
+                    except Exception as ex:
+                        gvr2["pinned_build"] = {"error": repr(ex)[-300:]}
             configs["config2_1e6_map"] = c2
         except Exception as ex:  # the headline must not depend on the secondary legs
             configs["config2_1e6_map"] = {"error": repr(ex)[-400:]}
@@ -850,7 +887,8 @@ def main():
                        "map_bytes_hbm": the_map.nbytes,
                        "engine": ("batched: %d scans per launch, %d rounds in flight, filter loop on the device, 1 host thread" % (args.slots, args.groups))
                                  if batch is not None else ("%d engines, one host thread + stream each" % n_streams),
-                       "single_stream_latency_ms_per_scan": round(latency_ms, 4)},
+                       "single_stream_latency_ms_per_scan": round(latency_ms, 4),
+                       "single_scan_one_graph_latency_ms": (round(latency_graph_ms, 4) if latency_graph_ms else None)},
             "pose_error_vs_truth": {"max_dpos_m": pose_err, "max_drot_rad": ang_err,
                                     "note": "the reference's algorithm itself: at most four ESKF iterations from a prior 0.3 m / 2 deg off; the GPU pose "
                                             "equals the oracle's and the reference's own (cpu_baseline.gpu_vs_*_pose)"},
@@ -885,7 +923,7 @@ def ref_parity_leg(td):
     out_dp_canonical = np.zeros(0)
     for mode in ("neighbour_lists_as_nth_element_leaves_them", "neighbour_lists_in_canonical_order"):
         R.set_canonical(mode.endswith("canonical_order"))
-        dp, da = [], []
+        dp, da, bp, ba = [], [], [], []
         for i in range(n):
             R.reset_cache()
             rc, sr, _ = R.register(d[f"raw{i}"], d[f"guess{i}"], P0)
@@ -894,7 +932,18 @@ def ref_parity_leg(td):
             g = d[f"gpu{i}"]
             dp.append(float(np.linalg.norm(g[:3] - sr[:3])))
             da.append(float(synth.quat_angle(g[3:7], sr[3:7])))
+            if f"rel{i}" in d.files and not mode.endswith("canonical_order"):  # the reference against ITSELF: its release build's pose of this scan against this (pinned) build's
+                rl = d[f"rel{i}"]
+                bp.append(float(np.linalg.norm(rl[:3] - sr[:3])))
+                ba.append(float(synth.quat_angle(rl[3:7], sr[3:7])))
         dp, da = np.array(dp), np.array(da)
+        if bp:
+            bp, ba = np.array(bp), np.array(ba)
+            out["the_references_release_build_against_its_pinned_build"] = {
+                "what": "the SAME reference sources built twice (its own CMake flags with vectorised Eigen / scalar Eigen without contraction), the same scans, priors and "
+                        "map, both untouched: what the reference moves by when only its build changes -- the resolution at which 'the reference's pose' is defined",
+                "scans": int(len(bp)), "max_dpos_m": float(bp.max()), "max_drot_rad": float(ba.max()), "median_dpos_m": float(np.median(bp)),
+                "scans_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((bp > 1e-4) | (ba > 1e-5)))}
         if mode.endswith("canonical_order"):
             out_dp_canonical = dp
         out[mode] = {"scans": int(len(dp)), "max_dpos_m": float(dp.max()), "max_drot_rad": float(da.max()), "median_dpos_m": float(np.median(dp)),
@@ -1270,6 +1319,120 @@ def load_bin_dir(path, scan_period=0.1):
     return sweeps, imu
 
 
+def stream_side_by_side(args, torch, local_rank, R, get_sweep, imu, m_ref, evict, timed, distinct=False):
+    """HIP engines beside the reference `R` on the first m_ref sweeps of a drive (bench.py --config stream): teacher-forced in the default tie mode 1 (the
+    reference's neighbour SETS, canonical list order) and in tie mode 2 (its list ORDER too: a parity mode, every query through the reference's selection),
+    and one FREE-RUNNING in tie mode 2.  Returns (record, reference seconds, sweeps timed, points timed, sweeps at capacity, seconds at capacity, state at
+    m_ref // 2).  Test infrastructure (oracle/) used as the checker / the timed CPU baseline, outside every GPU-timed region."""
+    from lsd_amd import capi, lio, synth
+
+    imu_t, imu_g, imu_a = imu
+
+    def side_engine(tie_mode):
+        e2 = lio.Engine(resolution=0.5, stencil=75, max_points=2_000_000 + 14_000 * m_ref, max_voxels=(1 << 21), max_raw=1 << 18, max_ds=100000, device=local_rank)
+        if not evict:
+            e2.map.set_lru((1 << 21) - 100_000, 1e9)
+        e2.fastlio_init(scan_period=0.1)
+        e2.map.set_tie_mode(tie_mode)
+        return e2
+
+    # (engine, state + covariance put back on the reference's after every sweep, map content too)
+    sides = {"teacher_forced": (side_engine(1), True, False), "teacher_forced_state_and_map": (side_engine(1), True, True),
+             "teacher_forced_state_and_map_tie_mode_2": (side_engine(2), True, True), "teacher_forced_tie_mode_2": (side_engine(2), True, False),
+             "free_running_tie_mode_2": (side_engine(2), False, False)}
+    tf = {name: dict(dp=[], dr=[], first_bad=None) for name in sides}
+    jj, t_ref, n_ref, pts_ref, t_full, n_full, ref_half = 0, 0.0, 0, 0, 0.0, 0, None
+    for k in range(m_ref):
+        p, st = get_sweep(k)
+        # distinct (the child process against the pinned build): both sides get the sweep in time order with pairwise DISTINCT microsecond stamps (every second / third ray where 120 000 points do not fit
+        # 100 000 microseconds): the reference sorts a sweep by time with an unstable std::sort (IMU_Processing.hpp:UndistortPcl), so points with
+        # equal stamps would reach its VoxelGrid in an order no other implementation can know -- with distinct stamps that sort has one result, and
+        # what is compared is the path, not libstdc++'s introsort (tests/test_fastlio_vs_ref.py::_sweep does the same)
+        if distinct:
+            o = np.argsort(st, kind="stable")
+            p, st = np.ascontiguousarray(p[o]), st[o].astype(np.int64)
+            thin = int(np.ceil(len(p) / 90000.0))
+            if thin > 1:
+                p, st = np.ascontiguousarray(p[::thin]), st[::thin]
+            ii = np.arange(len(st))
+            st = (np.maximum.accumulate(st - ii) + ii).astype(np.uint32)
+        tb = (k * 100000) / 1000000.0  # (the double the reference forms from its integer microsecond header stamp: k * 0.1 differs from it in the last bit for some k, and a point or an IMU sample exactly on a boundary then falls on the other side)
+        while jj < len(imu_t) and imu_t[jj] <= tb + 0.12:
+            R.imu_enqueue(imu_t[jj], imu_g[jj], imu_a[jj])
+            for e2, _, _ in sides.values():
+                e2.fastlio_imu_enqueue(imu_t[jj], imu_g[jj], imu_a[jj])
+            jj += 1
+        c0 = time.perf_counter()
+        R.pcl_enqueue(p, st, k * 100000)
+        updated = R.main()
+        c1 = time.perf_counter()
+        s_ref, _, P_ref = R.state()
+        ref_map = R.map_dump() if any(fm for _, _, fm in sides.values()) else None
+        for name, (e2, forced, forced_map) in sides.items():
+            e2.fastlio_pcl_enqueue(p, st, tb)
+            rc2 = e2.fastlio_main()
+            e2.flush()
+            if rc2 == capi.MAIN_UPDATED and updated:
+                s2 = e2.get_state()
+                rec = tf[name]
+                rec["dp"].append(float(np.linalg.norm(s2[0:3] - s_ref[0:3])))
+                rec["dr"].append(float(synth.quat_angle(s2[3:7], s_ref[3:7])))
+                if rec["first_bad"] is None and (rec["dp"][-1] > 1e-4 or rec["dr"][-1] > 1e-5):
+                    rec["first_bad"] = k
+                if forced:
+                    e2.set_state(s_ref)
+                    e2.set_cov(P_ref)
+            if forced_map and ref_map is not None and len(ref_map) and e2.map.stats()[1] > 0:
+                # the reference's map after this sweep, voxel by voxel in push_back order (IVox::GetAllPoints), in place of the engine's own
+                e2.map.clear()
+                e2.map.add(ref_map, float(R.info()["travel_distance"]))
+        if k + 1 == m_ref // 2:
+            ref_half = R.get_state().copy()
+        if timed and k >= 20:
+            t_ref += c1 - c0
+            n_ref += 1
+            pts_ref += len(p)
+            if R.map_voxels() >= 100000:
+                t_full += c1 - c0
+                n_full += 1
+    per = {}
+    for name, (e2, forced, forced_map) in sides.items():
+        rec = tf[name]
+        if rec["dp"]:
+            a_dp, a_dr = np.array(rec["dp"]), np.array(rec["dr"])
+            per[name] = {"sweeps": int(len(a_dp)), "max_dpos_m": float(a_dp.max()), "max_drot_rad": float(a_dr.max()), "median_dpos_m": float(np.median(a_dp)),
+                         "p99_dpos_m": float(np.percentile(a_dp, 99)), "last_dpos_m": float(a_dp[-1]),
+                         "sweeps_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((a_dp > 1e-4) | (a_dr > 1e-5))), "first_sweep_beyond": rec["first_bad"],
+                         "map_voxels_end": {"gpu": int(e2.map.stats()[1]), "reference": int(R.map_voxels())}}
+        e2.close()
+    return per, t_ref, n_ref, pts_ref, n_full, t_full, ref_half
+
+
+def stream_tf_pinned(args, torch, local_rank):
+    """child process of stream_run (one build of the reference per process): the same drive's first sweeps beside the PINNED build of the reference
+    (oracle/_ref/libref_fastlio.so: scalar Eigen, no contraction), whose bits tie mode 2 follows.  One JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_fastlio
+    from lsd_amd import synth, synth_gpu
+
+    if not ref_fastlio.available():
+        print(json.dumps({"error": "oracle/_ref/libref_fastlio.so is not there"}))
+        return
+    dev = torch.device("cuda", local_rank)
+    scene = synth.Scene(half=500.0, n_boxes=1500, seed=3, box_size=(4.0, 30.0), keep_clear=8.0)
+    tr = synth_gpu.Lawnmower(speed=args.speed) if args.grow_to else synth.FigureEight()
+    m_ref = args.ref_scans
+    sweeper = synth_gpu.Sweeper(scene, tr, dev, fov_deg=(-24.8, 2.0), max_range=100.0, seed=args.seed)
+    imu = synth_gpu.imu_stream(tr, 0.0, args.steps * 0.1 + 0.3, rate=100.0, seed=args.seed, gyr_sigma=1e-3, acc_sigma=1e-2)
+    R = ref_fastlio.RefFastLio(scan_period=0.1)
+    R.set_logging(False)
+    per = stream_side_by_side(args, torch, local_rank, R, sweeper.sweep, imu, m_ref, args.lru > 0, False, distinct=True)[0]
+    per["build"] = "oracle/_ref/libref_fastlio.so: the reference's translation units with scalar Eigen and no FMA contraction -- the build the path is pinned to"
+    per["sweeps_as_fed"] = ("in time order with pairwise distinct microsecond stamps, thinned to <= 90 000 points so that they fit the 100 ms: the reference's unstable "
+                            "std::sort by time (UndistortPcl) then has one result -- what is compared is the path, not libstdc++'s introsort on tied stamps")
+    print(json.dumps(per))
+
+
 def stream_run(args, torch, local_rank):
     """BASELINE.json config 3 / SURVEY.md 8d ("NCLT replay", stand-in: NCLT is not available): the streaming FastLIO front half -- IMU
     propagation, motion compensation, downsample, iterated update, map_incremental -- through lio_fastlio_* at 10 Hz, clouds from the host
@@ -1324,7 +1487,7 @@ def stream_run(args, torch, local_rank):
         g0 = time.perf_counter()
         p, st = get_sweep(k)
         t_gen += time.perf_counter() - g0
-        tb = k * 0.1
+        tb = (k * 100000) / 1000000.0  # (the double the reference forms from its integer microsecond header stamp: k * 0.1 differs from it in the last bit for some k, and a point or an IMU sample exactly on a boundary then falls on the other side)
         while ii < len(imu_t) and imu_t[ii] <= tb + 0.12:
             e.fastlio_imu_enqueue(imu_t[ii], imu_g[ii], imu_a[ii])
             ii += 1
@@ -1470,51 +1633,8 @@ def stream_run(args, torch, local_rank):
                 R = ref_fastlio.RefFastLio(scan_period=0.1)
                 R.set_logging(False)
                 m_ref = min(args.ref_scans, k_done)
-                jj, t_ref, n_ref, pts_ref = 0, 0.0, 0, 0
-                t_full, n_full = 0.0, 0  # ... of those, the sweeps registered while the reference's iVox holds its full 100000 voxels (LRU evicting)
-                # TEACHER-FORCED parity: a second HIP engine runs the same sweeps in step with the reference and is put back on the reference's posterior
-                # (state and covariance) after every sweep, so that each figure is ONE sweep's difference -- IMU propagation, undistortion, downsample,
-                # iterated update -- from the same prior against maps grown by the same inserts, not a drive's amplification of it.  The maps are not
-                # copied over: they start identical and part only where a map_incremental decision flips (voxel counts compared at the end).
-                e_tf = lio.Engine(resolution=0.5, stencil=75, max_points=2_000_000 + 14_000 * m_ref, max_voxels=(1 << 21), max_raw=1 << 18, max_ds=100000, device=local_rank)
-                if not evict:
-                    e_tf.map.set_lru((1 << 21) - 100_000, 1e9)
-                e_tf.fastlio_init(scan_period=0.1)
-                tf_dp, tf_dr, tf_first_bad = [], [], None
-                for k in range(m_ref):
-                    p, st = get_sweep(k)
-                    tb = k * 0.1
-                    while jj < len(imu_t) and imu_t[jj] <= tb + 0.12:
-                        R.imu_enqueue(imu_t[jj], imu_g[jj], imu_a[jj])
-                        e_tf.fastlio_imu_enqueue(imu_t[jj], imu_g[jj], imu_a[jj])
-                        jj += 1
-                    c0 = time.perf_counter()
-                    R.pcl_enqueue(p, st, int(round(tb * 1e6)))
-                    updated = R.main()
-                    c1 = time.perf_counter()
-                    e_tf.fastlio_pcl_enqueue(p, st, tb)
-                    rc_tf = e_tf.fastlio_main()
-                    e_tf.flush()
-                    s_ref, _, P_ref = R.state()
-                    if rc_tf == capi.MAIN_UPDATED and updated:
-                        s_tf = e_tf.get_state()
-                        tf_dp.append(float(np.linalg.norm(s_tf[0:3] - s_ref[0:3])))
-                        tf_dr.append(float(synth.quat_angle(s_tf[3:7], s_ref[3:7])))
-                        if tf_first_bad is None and (tf_dp[-1] > 1e-4 or tf_dr[-1] > 1e-5):
-                            tf_first_bad = k
-                        e_tf.set_state(s_ref)
-                        e_tf.set_cov(P_ref)
-                    if k + 1 == m_ref // 2:
-                        ref_half = R.get_state().copy()
-                    if k >= 20:
-                        t_ref += c1 - c0
-                        n_ref += 1
-                        pts_ref += len(p)
-                        if R.map_voxels() >= 100000:
-                            t_full += c1 - c0
-                            n_full += 1
+                per, t_ref, n_ref, pts_ref, n_full, t_full, ref_half = stream_side_by_side(args, torch, local_rank, R, get_sweep, (imu_t, imu_g, imu_a), m_ref, evict, True)
                 gpu_same = float(np.mean((np.array(t_main) + np.array(t_enq) + np.array(t_fl))[: max(n_ref, 1)]))
-                ref_half = None
                 ref_err = None
                 if tr is not None and m_ref > 0:
                     ref_err = float(np.linalg.norm(R.get_state()[0:3] - tr.R(0.0).T @ (tr.pos(m_ref * 0.1) - tr.pos(0.0))))
@@ -1537,16 +1657,26 @@ def stream_run(args, torch, local_rank):
                         gv[f"dpos_m_after_{at}_sweeps"] = float(np.linalg.norm(gpu_state_at[at][0:3] - sr[0:3]))
                         gv[f"drot_rad_after_{at}_sweeps"] = float(synth.quat_angle(gpu_state_at[at][3:7], sr[3:7]))
                 cpu["gpu_vs_reference_drive"] = gv
-                if tf_dp:
-                    a_dp, a_dr = np.array(tf_dp), np.array(tf_dr)
-                    cpu["gpu_vs_reference_per_sweep"] = {
-                        "what": "teacher-forced: a HIP engine fed the same sweeps in step with the reference and reset to the reference's posterior (state, covariance) "
-                                "after every sweep -- |GPU pose - reference pose| after ONE sweep from the same prior; the reference build is the one that is timed "
-                                "(its own flags, vectorised Eigen)",
-                        "sweeps": int(len(a_dp)), "max_dpos_m": float(a_dp.max()), "max_drot_rad": float(a_dr.max()), "median_dpos_m": float(np.median(a_dp)),
-                        "p99_dpos_m": float(np.percentile(a_dp, 99)), "sweeps_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((a_dp > 1e-4) | (a_dr > 1e-5))),
-                        "first_sweep_beyond": tf_first_bad, "map_voxels_end": {"gpu": int(e_tf.map.stats()[1]), "reference": int(R.map_voxels())}}
-                e_tf.close()
+                if per:
+                    per["what"] = ("HIP engines fed the same IMU stream and sweeps in step with the reference.  teacher_forced*: the engine is put back on the reference's "
+                                   "posterior (state + covariance) after every sweep, so every figure is ONE sweep's difference from the same prior -- IMU propagation, "
+                                   "undistortion, downsample, iterated update -- against maps grown by the same inserts (the maps are NOT copied over: a map_incremental "
+                                   "decision that flips leaves another point in a young map of one or two points per voxel, which the next sweeps register against; "
+                                   "voxel counts compared at the end).  tie_mode_2 = lio_map_set_tie_mode(2): the neighbour lists in the reference's own order "
+                                   "(tests/test_fastlio_golden.py holds that mode to 1e-12 m per sweep against the pinned build).  free_running_tie_mode_2: never reset.  "
+                                   "Here against the build that is timed (the reference's own flags, vectorised Eigen); `against_the_pinned_build`: the same against "
+                                   "the scalar-Eigen build, in a child process")
+                    try:
+                        import subprocess
+
+                        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "stream", "--tf-pinned", "--steps", str(max(m_ref + 5, 30)), "--ref-scans", str(m_ref),
+                                             "--lru", str(args.lru), "--grow-to", str(args.grow_to), "--speed", str(args.speed), "--seed", str(args.seed)],
+                                            capture_output=True, text=True, timeout=800)
+                        line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                        per["against_the_pinned_build"] = json.loads(line[-1]) if (pr.returncode == 0 and line) else {"error": (pr.stderr or pr.stdout)[-300:]}
+                    except Exception as ex:
+                        per["against_the_pinned_build"] = {"error": repr(ex)[-300:]}
+                    cpu["gpu_vs_reference_per_sweep"] = per
         except Exception as ex:
             cpu = {"error": repr(ex)[-300:]}
     out = {"metric": "registered points/sec (streaming LIO front half, incremental map)", "value": round(pts / tot, 1), "unit": "points/s", "n_gpus": 1,

@@ -82,6 +82,10 @@ int lio_map_set_stencil(lio_map*, int stencil);
  * nothing is ever dropped and exceeding max_points / max_voxels returns LIO_E_CAPACITY. */
 int lio_map_insert(lio_map*, const float* world_xyzi, uint64_t n, double travel);
 int lio_map_insert_device(lio_map*, const void* d_world_xyzi, uint64_t n, double travel);
+/* back to an empty map without giving its memory back: what `ivox = std::make_shared<IVoxType>(ivox_options)` does in fastlio_init (src/laserMapping.cpp:1064) when the
+ * reference starts over -- here also the way a checker puts a map of known content in place (clear, then one lio_map_insert of that content: points of a
+ * voxel keep the order of the inserted array, as IVoxNode::InsertPoint's push_back does).  The LRU list, if on, starts over with the map. */
+int lio_map_clear(lio_map*);
 /* IVox::Options capacity_ / max_distance_ (ivox3d.h:46-52; 100000 voxels / 100 m at src/laserMapping.cpp:1060-1064): turn
  * on the LRU list of IVox::AddPoints (ivox3d.h:231-256) -- after every inserted point the least recently touched voxel is
  * dropped while the map holds more than `capacity_voxels` voxels and that voxel was created more than `max_distance` of

@@ -231,14 +231,22 @@ lio_map* lio_map_create(int device, float resolution, uint64_t max_points, uint6
 // back to an empty map without giving the memory back (a matcher's setInputTarget replaces its target: hipFree + hipMalloc of the pool and the
 // table cost milliseconds, five memsets microseconds); asynchronous on the map's stream.  Not for maps with the LRU list on.
 int map_clear(lio_map* m) {
-    if (!m || m->lru_capacity) return LIO_E_INVALID;
+    if (!m) return LIO_E_INVALID;
     map_settle(m);
     hipStream_t st = m->stream;
     LIO_HIP_TRY(hipMemsetAsync(m->table, 0xFF, (size_t)m->table_cap * sizeof(Slot), st));
     LIO_HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(m->table) + 8, sizeof(Slot), 0, 8, m->table_cap, st));
     LIO_HIP_TRY(hipMemsetAsync(m->cap, 0, (size_t)m->table_cap * 4, st));
     LIO_HIP_TRY(hipMemsetAsync(m->pending, 0, (size_t)m->table_cap * 4, st));
+    uint32_t* keep_bits = m->touch_bits;
     LIO_HIP_TRY(hipMemsetAsync(m->dev, 0, sizeof(MapDev), st));
+    if (keep_bits) LIO_HIP_TRY(hipMemcpyAsync(&m->dev->touch_bits, &m->touch_bits, sizeof(uint32_t*), hipMemcpyHostToDevice, st));
+    if (m->lru_capacity) {  // the LRU list starts over too: no stamps, an empty touch log, empty free lists (their counters live in MapDev)
+        LIO_HIP_TRY(hipMemsetAsync(m->touch, 0, (size_t)m->table_cap * 8, st));
+        LIO_HIP_TRY(hipMemsetAsync(m->prev_touch, 0, (size_t)m->table_cap * 8, st));
+        LIO_HIP_TRY(hipMemsetAsync(m->lru_log, 0, (size_t)m->lru_log_cap * sizeof(LruEntry), st));
+        m->tomb_bound = 0;
+    }
     m->n_batches = 0;
     return LIO_OK;
 }
@@ -290,6 +298,15 @@ int lio_map_lru_stats(lio_map* m, uint64_t* n_evicted, uint64_t* n_interleaved) 
     if (n_evicted) *n_evicted = m->host_dev->n_evicted;
     if (n_interleaved) *n_interleaved = m->host_dev->n_lru_interleaved;
     return rc;
+}
+
+int lio_map_clear(lio_map* m) {
+    if (!m) return LIO_E_INVALID;
+    hipSetDevice(m->device);
+    const int rc = map_clear(m);
+    if (rc != LIO_OK) return rc;
+    LIO_HIP_TRY(hipStreamSynchronize(m->stream));
+    return LIO_OK;
 }
 
 int lio_map_set_tie_mode(lio_map* m, int mode) {

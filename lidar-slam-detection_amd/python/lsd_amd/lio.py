@@ -62,6 +62,10 @@ class Map:
         check(lib().lio_map_lru_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def clear(self):
+        """back to an empty map (memory kept)"""
+        check(lib().lio_map_clear(self.h), "map clear")
+
     def set_tie_mode(self, mode):
         """1 (default): candidates exactly as far as the fifth nearest are kept as the reference's std::nth_element keeps them; 0: smallest (d2, x, y, z);
         2: the lists exactly as the reference returns them, order included (every query redone by the reference's selection: slow, a parity mode)"""

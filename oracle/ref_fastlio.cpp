@@ -152,6 +152,15 @@ int ref_fl_map_add(const float* xyzi, int n) {
     ivox->AddPoints(v, travel_distance);
     return (int)ivox->NumValidGrids();
 }
+// every point the map holds, voxel by voxel (the hash map's iteration order), inside a voxel in push_back order (IVox::GetAllPoints, ivox3d.h:263-270);
+// returns the count (the first `cap` are written)
+int ref_fl_map_dump(float* xyzi, int cap) {
+    PointVector v;
+    ivox->GetAllPoints(v);
+    const int n = (int)v.size();
+    for (int i = 0; i < n && i < cap; i++) { xyzi[4 * i] = v[i].x; xyzi[4 * i + 1] = v[i].y; xyzi[4 * i + 2] = v[i].z; xyzi[4 * i + 3] = v[i].intensity; }
+    return n;
+}
 void ref_fl_set_nearby(int n) {  // 18 / 26 / 74 (fastlio_main switches NEARBY74 -> NEARBY18 one second after the first scan)
     ivox->SetNearByType(n == 18 ? IVoxType::NearbyType::NEARBY18 : n == 26 ? IVoxType::NearbyType::NEARBY26 : IVoxType::NearbyType::NEARBY74);
 }

@@ -32,6 +32,7 @@ def lib():
         _which = _which or _PATH
         L = C.CDLL(_which)
         L.ref_fl_map_add.argtypes = [C.POINTER(C.c_float), C.c_int]
+        L.ref_fl_map_dump.argtypes = [C.POINTER(C.c_float), C.c_int]
         L.ref_fl_register.argtypes = [C.POINTER(C.c_float), C.c_int] + [C.POINTER(C.c_double)] * 4
         f64p, f32p, u32p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
         L.ref_fl_init.argtypes = [f64p, f64p, C.c_int, C.c_int, C.c_double, C.c_int]
@@ -153,6 +154,13 @@ class RefFastLio:
     def map_add(self, xyzi):
         p = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
         return lib().ref_fl_map_add(_p(p, C.c_float), len(p))
+
+    def map_dump(self):
+        """every map point, voxel by voxel, inside a voxel in push_back order (IVox::GetAllPoints)"""
+        n = lib().ref_fl_map_dump(None, 0)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        n = lib().ref_fl_map_dump(_p(out, C.c_float), len(out))
+        return out[:n]
 
     def set_nearby(self, n):
         lib().ref_fl_set_nearby(int(n))

@@ -26,14 +26,14 @@ ii = jj = 0
 print("sweep  driven_m   gpu_err_m  ref_err_m  gpu_vs_ref_m   gpu_err_track(x along, y left, z up)   yaw_err_gpu_deg yaw_err_ref_deg")
 for k in range(n):
     p, st = sweeper.sweep(k)
-    tb = k * 0.1
+    tb = (k * 100000) / 1000000.0  # (the double the reference forms from its integer microsecond header stamp: k * 0.1 differs from it in the last bit for some k, and a point or an IMU sample exactly on a boundary then falls on the other side)
     while ii < len(imu_t) and imu_t[ii] <= tb + 0.12:
         e.fastlio_imu_enqueue(imu_t[ii], imu_g[ii], imu_a[ii]); ii += 1
     e.fastlio_pcl_enqueue(p, st, tb)
     e.fastlio_main()
     while jj < len(imu_t) and imu_t[jj] <= tb + 0.12:
         R.imu_enqueue(imu_t[jj], imu_g[jj], imu_a[jj]); jj += 1
-    R.pcl_enqueue(p, st, int(round(tb * 1e6)))
+    R.pcl_enqueue(p, st, k * 100000)
     R.main()
     if k % 50 == 49:
         tk = (k + 1) * 0.1
