@@ -80,7 +80,6 @@ struct lio_batch {
     int n_slots = 0;
     uint32_t max_raw = 0, max_ds = 0;
     int pred_passes = 4;  // radix passes the last rounds needed
-    int use_vg2 = 0;      // every slot's scan has the voxel-hash buffers of the downsample chain without the sort of the points (scan_enable_vg2)
     bool broken = false;  // sequence mode: a step failed after some of its rounds had run on the device (lio_batch_sequences_step refuses further steps)
     int use_graph = 1;    // LIO_BATCH_GRAPH=0: plain launches instead of one hipGraphLaunch per round
     int count_touched = 0;  // lio_batch_enable_kernel_timing(b, 2): the kNN kernel's diagnostic variant that also counts the points it loads
@@ -138,7 +137,6 @@ void fill_desc(SlotDesc& d, lio_scan* sc, EskfDev* d_ctrl, lio_batch_result* d_r
     d.partial_blocks = sc->partial_blocks;
     d.sd = sc->dev;
     d.keys_a = sc->keys_a; d.keys_b = sc->keys_b; d.vals_a = sc->vals_a; d.vals_b = sc->vals_b;
-    d.vg2_owner = sc->vg2_owner; d.vg2_idx = sc->vg2_idx; d.vg2_key = sc->vg2_key; d.vg2_cnt = sc->vg2_cnt; d.vg2_mask = sc->vg2_mask;
     d.hist = sc->hist; d.blockcnt = sc->blockcnt; d.hpos = sc->hpos; d.longlist = sc->longlist; d.tie_list = sc->tie_list;
     d.sorted = sc->sorted; d.ds_body = sc->ds_body; d.ds_world = sc->ds_world; d.nn_pts = sc->nn_pts; d.normvec = sc->normvec;
     d.nn_cnt = sc->nn_cnt; d.selected = sc->selected; d.partial = sc->partial;
@@ -260,7 +258,7 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
     auto enqueue = [&](BatchTimer* bt) -> int {
         LIO_HIP_TRY(hipMemcpyAsync(g.d_block, g.h_block, g.block_bytes, hipMemcpyHostToDevice, g.stream));
         if (bt) bt->begin(0);
-        int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes, b->use_vg2);
+        int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes);
         if (bt) bt->end(0);
         if (rc != LIO_OK) return rc;
         const uint32_t ds_bound = b->max_raw < b->max_ds ? b->max_raw : b->max_ds;
@@ -335,7 +333,6 @@ static lio_batch* batch_create_impl(lio_map** maps, int n_maps, lio_comm* comm, 
     b->device = map->device;
     b->n_slots = n_slots;
     b->max_raw = max_raw;
-    b->use_vg2 = 1;
     b->max_ds = max_ds;
     b->maps.assign(maps, maps + n_maps);
     b->comm = comm;
@@ -375,7 +372,6 @@ static lio_batch* batch_create_impl(lio_map** maps, int n_maps, lio_comm* comm, 
             if (!e) { ok = false; break; }
             lio_engine_set_flags(e, 1, 0, 0.0, -10.0);
             g.eng.push_back(e);
-            if (scan_enable_vg2(lio_engine_scan(e)) != LIO_OK) { ok = false; break; }
             fill_desc(g.h_desc[s], lio_engine_scan(e), &g.d_ctrl[s], &g.h_res_dev[s]);
         }
         for (int m = 1; m < M && ok; m++)
@@ -656,7 +652,6 @@ lio_batch* lio_batch_create_sequences(int device, float resolution, int stencil,
     b->device = device;
     b->n_slots = n_slots;
     b->max_raw = max_raw;
-    b->use_vg2 = 1;
     b->max_ds = max_ds;
     b->sequences = true;
     { const char* k = getenv("LIO_BATCH_GRAPH"); b->use_graph = (k && k[0] == '0') ? 0 : 1; }
@@ -690,7 +685,6 @@ lio_batch* lio_batch_create_sequences(int device, float resolution, int stencil,
             if (!e) { ok = false; break; }
             lio_engine_set_device_loop(e, 1);  // the scans the round cannot take run the same filter kernels
             g.eng.push_back(e);
-            if (scan_enable_vg2(lio_engine_scan(e)) != LIO_OK) { ok = false; break; }
             fill_desc(g.h_desc[s], lio_engine_scan(e), &g.d_ctrl[s], &g.h_res_dev[s]);
         }
     }
@@ -802,7 +796,7 @@ int lio_batch_sequences_step(lio_batch* b, lio_scan_job* jobs, int n_jobs, doubl
         auto enqueue = [&](BatchTimer* bt) -> int {
             LIO_HIP_TRY(hipMemcpyAsync(g.d_block, g.h_block, g.block_bytes, hipMemcpyHostToDevice, g.stream));
             if (bt) bt->begin(0);
-            int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes, b->use_vg2);
+            int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes);
             if (bt) bt->end(0);
             if (rc == LIO_OK) rc = p2plane_seq_update(g.stream, g.d_maps, g.d_desc, B, ds_bound, 5, stencils, stencil_ids, n_st, bt);
             if (bt) bt->begin(4);

@@ -199,22 +199,6 @@ int lio::map_enable_touch_bits(lio_map* m) {
     return LIO_OK;
 }
 
-// the buffers of the batched downsample chain's voxel hash (voxelgrid.hip, vg2_*): made for the scans that serve as slots of a batch
-int lio::scan_enable_vg2(lio_scan* s) {
-    if (s->vg2_key) return LIO_OK;
-    hipSetDevice(s->device);
-    uint64_t h = 1024;
-    while (h < 2ull * s->max_raw) h <<= 1;  // at most one voxel per point: load <= 0.5
-    if (!dev_alloc(&s->vg2_owner, s->max_raw, &s->bytes) || !dev_alloc(&s->vg2_idx, s->max_raw, &s->bytes) || !dev_alloc(&s->vg2_key, h, &s->bytes) ||
-        !dev_alloc(&s->vg2_cnt, h, &s->bytes))
-        return LIO_E_DEVICE;
-    s->vg2_mask = (uint32_t)(h - 1);
-    LIO_HIP_TRY(hipMemsetAsync(s->vg2_key, 0xFF, h * 4, s->stream));
-    LIO_HIP_TRY(hipMemsetAsync(s->vg2_cnt, 0, h * 4, s->stream));
-    LIO_HIP_TRY(hipStreamSynchronize(s->stream));
-    return LIO_OK;
-}
-
 extern "C" {
 
 const char* lio_last_error(void) { return g_err; }
@@ -534,7 +518,6 @@ void lio_scan_destroy(lio_scan* s) {
     if (s->stream) hipStreamSynchronize(s->stream);
     hipFree(s->raw_own); hipFree(s->ds_body); hipFree(s->ds_world); hipFree(s->nn_pts); hipFree(s->nn_cnt); hipFree(s->selected);
     hipFree(s->normvec); hipFree(s->keys_a); hipFree(s->keys_b); hipFree(s->vals_a); hipFree(s->vals_b); hipFree(s->hist);
-    hipFree(s->vg2_owner); hipFree(s->vg2_idx); hipFree(s->vg2_key); hipFree(s->vg2_cnt);
     hipFree(s->blockcnt); hipFree(s->hpos); hipFree(s->longlist); hipFree(s->tie_list); hipFree(s->sorted); hipFree(s->partial); hipFree(s->dev); hipFree(s->d_result);
     if (s->host_dev) hipHostFree(s->host_dev);
     if (s->h_result) hipHostFree(s->h_result);

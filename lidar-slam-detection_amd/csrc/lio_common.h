@@ -118,7 +118,6 @@ struct ScanDev {
     int32_t mul1, mul2;
     uint32_t total_cells;
     uint32_t n_monster;    // voxels with thousands of points, queued from the top of longlist for the wave-per-coordinate sums
-    uint32_t n_vox;        // hash-aggregating chain (vg2): occupied voxels claimed so far (the list in keys_a / vals_a)
 };
 
 struct StencilArgs {
@@ -140,9 +139,6 @@ struct SlotDesc {
     uint32_t reset_cache;    // the job is an independent scan: the slot's neighbour cache is forgotten before it (lio_scan_job.flags)
     ScanDev* sd;
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *hist, *blockcnt, *hpos, *longlist, *tie_list;
-    // the hash-aggregating downsample chain (voxelgrid.hip, vg2_*): per-point voxel slot, per-voxel point-index lists, the scan's voxel hash table
-    uint32_t *vg2_owner, *vg2_idx, *vg2_key, *vg2_cnt;
-    uint32_t vg2_mask, vg2_pad;
     float4 *sorted, *ds_body, *ds_world, *nn_pts, *normvec;
     int32_t* nn_cnt;
     uint8_t* selected;
@@ -276,8 +272,6 @@ struct lio_scan {
     uint8_t* selected;
     float4* normvec;
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b;
-    uint32_t *vg2_owner, *vg2_idx, *vg2_key, *vg2_cnt;  // the batched chain's voxel hash (scan_enable_vg2; null on scans that only run the sort chain)
-    uint32_t vg2_mask;
     uint32_t* hist;      // radix histograms [nblocks][256]
     uint32_t* blockcnt;  // head counts per tile
     uint32_t* hpos;      // first sorted position of every occupied voxel
@@ -334,8 +328,7 @@ int undistort_launch(hipStream_t stream, const float4* d_in, const uint32_t* d_s
                      const UndistortArgs& args, unsigned long long* d_block_min /* ceil(n / 256) words of scratch */);
 
 int vg_downsample(lio_scan* s, float leaf, int passes /* radix passes to launch, 1..4 */);
-int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes, int use_vg2 = 0);
-int scan_enable_vg2(lio_scan* s);
+int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes);
 int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t grid_x, int count_touched);
 // live kernel timing of the batched chain (bench.py's roofline leg): HIP events on the stream the kernels are launched on, per class
 struct BatchTimer {

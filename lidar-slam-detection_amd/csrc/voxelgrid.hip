@@ -883,7 +883,7 @@ __device__ __forceinline__ void scan_begin_body(ScanDev* sd, int32_t* __restrict
     if (blockIdx.x == 0 && threadIdx.x < 3) {
         sd->bbox_min[threadIdx.x] = 0xFFFFFFFFu;
         sd->bbox_max[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) { sd->n_valid = 0; sd->n_long = 0; sd->n_monster = 0; sd->n_vox = 0; }
+        if (threadIdx.x == 0) { sd->n_valid = 0; sd->n_long = 0; sd->n_monster = 0; }
     }
 }
 
@@ -907,398 +907,6 @@ __device__ __forceinline__ void vg_slot_tile(uint32_t n_slots, uint32_t& slot, u
         bx = j % T;
     }
 #endif
-}
-
-// =====================================================================================================================================
-// vg2: the batched chain without the sort of the points (round 6).  The three-pass radix sort of 120 000 (key, index) pairs orders the POINTS to
-// get two things: voxels in ascending key order, and inside a voxel the points in input order (the f32 sums are sequential).  Here the points are
-// never sorted:
-//   vg2_insert    every tile of 2 048 points aggregates its keys in an LDS hash (one LDS atomic per point), then inserts its <= 2 048 distinct keys
-//                 into the scan's voxel hash table in HBM / L2 (one CAS-find and one add per (tile, voxel): ~30 k global atomics per scan instead of
-//                 120 k), appends the voxels it CLAIMED to the scan's voxel list (one global atomic per tile) and leaves every point its voxel's slot;
-//   radix_*       the existing kernels sort the ~12 k (key, slot) pairs of the voxel list (n from the device: ScanDev::n_vox);
-//   vg2_scan      one workgroup per scan: exclusive scan of the voxels' counts in key order -> hpos (the run bounds the centroid kernels know) and
-//                 the voxels' write cursors; the chain's bookkeeping (n_ds, error bits, the mapped host words);
-//   vg2_scatter   every tile aggregates its points by slot in LDS again, reserves a range per (tile, voxel) at the voxel's cursor and writes the point
-//                 INDICES there -- arrival order inside a voxel;
-//   vg2_centroid  one lane per voxel: short runs (< 32 points) sort their indices in LDS (insertion sort, mostly 5-15 entries) and sum the gathered
-//                 points in ascending input order -- the same additions in the same order as the sort chain; long runs are queued as before;
-//   vg2_long_prepare / vg2_monster_prepare   the queued runs' indices are sorted (one wave, bitonic in LDS; runs of >= 2 048 points by an ordered
-//                 compaction of the points' slots) and their points gathered into `sorted` at the run's place: the long-run and monster kernels of
-//                 the sort chain then run unchanged on them.
-// Results are bit-identical to the sort chain's (same voxels, same order, same f32 additions): the single-scan engine keeps the sort chain, and the
-// tests that hold the batched engines bit-equal to it hold this chain.
-// =====================================================================================================================================
-constexpr uint32_t kVgEmpty = 0xFFFFFFFFu;   // empty hash slot / a point without a voxel (non-finite, or the overflow guard fired)
-constexpr int kVgTab = 2 * kTile;            // LDS table entries per tile (load <= 0.5)
-
-__device__ __forceinline__ uint32_t vg2_hash(uint32_t k) { return (k * 2654435761u) ^ (k >> 15); }
-
-// find or claim the slot of `key` in the scan's table (linear probing; the table holds at most max_raw keys in >= 2 max_raw slots)
-__device__ __forceinline__ uint32_t vg2_global_slot(uint32_t* __restrict__ gkey, uint32_t mask, uint32_t key, bool& claimed) {
-    uint32_t h = vg2_hash(key) & mask;
-    claimed = false;
-    for (;;) {
-        uint32_t k = *reinterpret_cast<volatile uint32_t*>(&gkey[h]);
-        if (k == kVgEmpty) {
-            k = atomicCAS(&gkey[h], kVgEmpty, key);
-            if (k == kVgEmpty) { claimed = true; return h; }
-        }
-        if (k == key) return h;
-        h = (h + 1u) & mask;
-    }
-}
-
-// LDS aggregation of a tile's items by a 32-bit id: returns the entry of `id` (after the caller's barrier tcnt[e] = items of the tile with that id)
-__device__ __forceinline__ uint32_t vg2_lds_insert(uint32_t* tkey, uint32_t* tcnt, uint32_t id, uint32_t& lrank) {
-    uint32_t e = vg2_hash(id) & (uint32_t)(kVgTab - 1);
-    for (;;) {
-        const uint32_t k = atomicCAS(&tkey[e], kVgEmpty, id);
-        if (k == kVgEmpty || k == id) break;
-        e = (e + 1u) & (uint32_t)(kVgTab - 1);
-    }
-    lrank = atomicAdd(&tcnt[e], 1u);
-    return e;
-}
-
-__global__ void __launch_bounds__(kThreads) vg2_insert_batch(const SlotDesc* __restrict__ slots, float inv) {
-    uint32_t slot, bx;
-    vg_slot_tile(gridDim.y, slot, bx);
-    const SlotDesc& d = slots[slot];
-    if (!d.active || bx >= d.nblocks) return;
-    __shared__ uint32_t tkey[kVgTab], tcnt[kVgTab], tgs[kVgTab];
-    __shared__ uint32_t wsum[kWaves], base_s;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t n = d.n_raw, base = bx * kTile;
-    float4 p[kItems];
-#pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        const uint32_t i = base + r * kThreads + tid;
-        p[r] = d.raw[i < n ? i : (n - 1u)];
-    }
-    for (int j = tid; j < kVgTab; j += kThreads) { tkey[j] = kVgEmpty; tcnt[j] = 0; }
-    ScanDev* sd = d.sd;
-    uint32_t bmin[3], bmax[3];
-    for (int a = 0; a < 3; a++) { bmin[a] = sd->bbox_min[a]; bmax[a] = sd->bbox_max[a]; }
-    const uint32_t n_valid = sd->n_valid;
-    const VgGrid g = vg_derive(bmin, bmax, n_valid, inv);
-    if (bx == 0 && tid == 0) {  // (what vg_keys leaves in the scan's record)
-        sd->n_ds_prev = sd->cache_n;
-        sd->passthrough = g.pass;
-        sd->total_cells = g.total;
-        sd->nbits = g.total ? (32 - __clz(g.total)) : 0;
-        sd->minb[0] = g.minb[0]; sd->minb[1] = g.minb[1]; sd->minb[2] = g.minb[2];
-        sd->mul1 = g.mul1; sd->mul2 = g.mul2;
-    }
-    __syncthreads();
-    uint32_t ent[kItems];
-#pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        const uint32_t i = base + r * kThreads + tid;
-        ent[r] = kVgEmpty;
-        if (i < n && g.total && isfinite(p[r].x) && isfinite(p[r].y) && isfinite(p[r].z)) {
-            const int i0 = (int)(floorf(p[r].x * inv) - (float)g.minb[0]);
-            const int i1 = (int)(floorf(p[r].y * inv) - (float)g.minb[1]);
-            const int i2 = (int)(floorf(p[r].z * inv) - (float)g.minb[2]);
-            const uint32_t key = (uint32_t)(i0 + i1 * g.mul1 + i2 * g.mul2);
-            uint32_t lr;
-            ent[r] = vg2_lds_insert(tkey, tcnt, key, lr);
-        }
-    }
-    __syncthreads();
-    // the tile's distinct keys -> the scan's table; the voxels this tile claimed are counted (bit 31 of the entry's count marks them)
-    uint32_t mine = 0;
-    for (int e = tid; e < kVgTab; e += kThreads) {
-        const uint32_t key = tkey[e];
-        if (key == kVgEmpty) continue;
-        bool claimed;
-        const uint32_t gs = vg2_global_slot(d.vg2_key, d.vg2_mask, key, claimed);
-        atomicAdd(&d.vg2_cnt[gs], tcnt[e]);
-        tgs[e] = gs;
-        if (claimed) { tcnt[e] |= 0x80000000u; mine++; }
-    }
-    uint32_t inc = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t at = inc - mine, total = 0;
-    for (int w = 0; w < kWaves; w++) {
-        if (w < wave) at += wsum[w];
-        total += wsum[w];
-    }
-    if (tid == 0) base_s = total ? atomicAdd(&sd->n_vox, total) : 0u;
-    __syncthreads();
-    at += base_s;
-    for (int e = tid; e < kVgTab; e += kThreads) {
-        if (tkey[e] != kVgEmpty && (tcnt[e] & 0x80000000u)) {
-            d.keys_a[at] = tkey[e];  // (at < max_raw: a scan claims at most one voxel per point)
-            d.vals_a[at] = tgs[e];
-            at++;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        const uint32_t i = base + r * kThreads + tid;
-        if (i < n) d.vg2_owner[i] = ent[r] == kVgEmpty ? kVgEmpty : tgs[ent[r]];
-    }
-}
-
-// one workgroup per scan: run bounds and write cursors from the voxel list in key order; the chain's bookkeeping (what vg_heads' last tile does)
-__global__ void __launch_bounds__(1024) vg2_scan_batch(const SlotDesc* __restrict__ slots, uint32_t launched_passes) {
-    const SlotDesc& d = slots[blockIdx.x];
-    if (!d.active) return;
-    ScanDev* sd = d.sd;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (sd->passthrough) {  // PCL overflow guard: output = input (vg2_scatter copies)
-        if (tid == 0) {
-            d.host_nds[2] = 0u;
-            if (d.n_raw > d.max_ds) { sd->err |= 1u; sd->n_ds = 0; d.host_nds[0] = 0; d.host_nds[1] = 1u; }
-            else { sd->n_ds = d.n_raw; d.host_nds[0] = d.n_raw; d.host_nds[1] = 0u; }
-        }
-        return;
-    }
-    const uint32_t nv = sd->n_vox;
-    const bool odd = active_passes(sd) & 1;
-    const uint32_t* vals = odd ? d.vals_b : d.vals_a;
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < nv; c0 += 1024) {
-        const uint32_t r = c0 + tid;
-        const uint32_t gs = r < nv ? vals[r] : 0u;
-        const uint32_t cnt = r < nv ? d.vg2_cnt[gs] : 0u;
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t pre = carry_s + inc - cnt;
-        for (int w = 0; w < wave; w++) pre += wsum[w];
-        if (r < nv) {
-            if (r < d.max_ds) d.hpos[r] = pre;
-            d.vg2_cnt[gs] = pre;  // the voxel's write cursor
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = pre + cnt;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        uint32_t run = nv, err = 0;
-        if (run > d.max_ds) { sd->err |= 1u; run = 0; err = 1u; }
-        if (active_passes(sd) > launched_passes) { err |= 2u; run = 0; }  // (the voxel list is not fully sorted: the host runs the chain again with all four passes)
-        sd->n_ds = run;
-        d.host_nds[0] = run;
-        d.host_nds[1] = err;
-        d.host_nds[2] = active_passes(sd);
-    }
-}
-
-__global__ void __launch_bounds__(kThreads) vg2_scatter_batch(const SlotDesc* __restrict__ slots) {
-    uint32_t slot, bx;
-    vg_slot_tile(gridDim.y, slot, bx);
-    const SlotDesc& d = slots[slot];
-    if (!d.active || bx >= d.nblocks) return;
-    const int tid = threadIdx.x;
-    const uint32_t n = d.n_raw, base = bx * kTile;
-    if (d.sd->passthrough) {
-        if (n > d.max_ds) return;
-        for (int r = 0; r < kItems; r++) {
-            const uint32_t i = base + r * kThreads + tid;
-            if (i < n) d.ds_body[i] = d.raw[i];
-        }
-        return;
-    }
-    __shared__ uint32_t tkey[kVgTab], tcnt[kVgTab];
-    uint32_t gs[kItems];
-#pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        const uint32_t i = base + r * kThreads + tid;
-        gs[r] = d.vg2_owner[i < n ? i : (n - 1u)];
-        if (i >= n) gs[r] = kVgEmpty;
-    }
-    for (int j = tid; j < kVgTab; j += kThreads) { tkey[j] = kVgEmpty; tcnt[j] = 0; }
-    __syncthreads();
-    uint32_t ent[kItems], lrank[kItems];
-#pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        ent[r] = kVgEmpty;
-        lrank[r] = 0;
-        if (gs[r] != kVgEmpty) ent[r] = vg2_lds_insert(tkey, tcnt, gs[r], lrank[r]);
-    }
-    __syncthreads();
-    for (int e = tid; e < kVgTab; e += kThreads) {
-        const uint32_t s2 = tkey[e];
-        if (s2 != kVgEmpty) tcnt[e] = atomicAdd(&d.vg2_cnt[s2], tcnt[e]);  // the tile's range in the voxel's run
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kItems; r++)
-        if (ent[r] != kVgEmpty) d.vg2_idx[tcnt[ent[r]] + lrank[r]] = base + r * kThreads + tid;
-}
-
-// one lane per voxel (strides over the scan's blocks of 256 voxels like vg_centroid_batch).  The run's point indices arrive in any order: short runs sort
-// them in LDS and gather their points in ascending input order; long runs and monsters are queued exactly as vg_centroid_body queues them.  The
-// voxel's slot of the scan's hash table is given back (the table is empty again when the chain ends).
-__global__ void __launch_bounds__(kThreads) vg2_centroid_batch(const SlotDesc* __restrict__ slots) {
-    const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active) return;
-    ScanDev* sd = d.sd;
-    if (sd->passthrough) return;
-    __shared__ uint32_t sidx[kThreads][kLongRun + 1];  // (+1: rows start in different banks)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t nv = sd->n_ds, nclaim = sd->n_vox;
-    const bool odd = active_passes(sd) & 1;
-    const uint32_t* vals = odd ? d.vals_b : d.vals_a;
-    const uint32_t n_valid = sd->n_valid;
-    const float4* __restrict__ in = d.raw;
-    for (uint32_t vb = blockIdx.x; vb * kThreads < nclaim; vb += gridDim.x) {
-        const uint32_t v = vb * kThreads + tid;
-        if (v < nclaim) {  // every claimed slot is given back, also when the scan is in error (n_ds = 0)
-            const uint32_t gs = vals[v];
-            d.vg2_key[gs] = kVgEmpty;
-            d.vg2_cnt[gs] = 0;
-        }
-        const bool have = v < nv;
-        uint32_t a = 0, b = 0;
-        if (have) {
-            a = d.hpos[v];
-            b = (v + 1 < nv) ? d.hpos[v + 1] : n_valid;
-        }
-        const bool is_monster = have && b - a >= kMonsterRun;
-        const unsigned long long mm = __ballot(is_monster);
-        if (mm) {
-            const int leader = __ffsll((long long)mm) - 1;
-            uint32_t q0 = 0;
-            if (lane == leader) q0 = atomicAdd(&sd->n_monster, (uint32_t)__popcll(mm));
-            q0 = __shfl(q0, leader);
-            if (is_monster) d.longlist[d.max_ds - 1u - (q0 + __popcll(mm & ((1ull << lane) - 1ull)))] = v;
-        }
-        const bool is_long = have && !is_monster && b - a >= kLongRun;
-        const unsigned long long lm = __ballot(is_long);
-        if (lm) {
-            const int leader = __ffsll((long long)lm) - 1;
-            uint32_t q0 = 0;
-            if (lane == leader) q0 = atomicAdd(&sd->n_long, (uint32_t)__popcll(lm));
-            q0 = __shfl(q0, leader);
-            if (is_long) d.longlist[q0 + __popcll(lm & ((1ull << lane) - 1ull))] = v;
-        }
-        if (!have || is_monster || is_long) continue;
-        // the run's indices (at most 31), eight requested together, sorted ascending by insertion into this lane's LDS row
-        const uint32_t cnt = b - a;
-        uint32_t* row = sidx[tid];
-        for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
-            uint32_t q[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) q[k] = d.vg2_idx[(j0 + k < cnt) ? (a + j0 + k) : (b - 1)];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (j0 + k >= cnt) continue;
-                int at = (int)(j0 + k);
-                while (at > 0 && row[at - 1] > q[k]) { row[at] = row[at - 1]; at--; }
-                row[at] = q[k];
-            }
-        }
-        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-        for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
-            float4 pp[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) pp[k] = in[row[(j0 + k < cnt) ? (j0 + k) : (cnt - 1)]];
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (j0 + k < cnt) { sx = sx + pp[k].x; sy = sy + pp[k].y; sz = sz + pp[k].z; sw = sw + pp[k].w; }
-        }
-        const float c = (float)cnt;
-        d.ds_body[v] = make_float4(sx / c, sy / c, sz / c, sw / c);
-    }
-}
-
-// the queued long runs (32 <= points < 2 048): one wave per run sorts the run's indices (bitonic, in LDS) and gathers the points into `sorted` at the
-// run's place, in ascending input order -- what the sort chain's vg_heads leaves there; vg_centroid_long then sums them as before
-__global__ void __launch_bounds__(kThreads) vg2_long_prepare_batch(const SlotDesc* __restrict__ slots) {
-    const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active) return;
-    const ScanDev* sd = d.sd;
-    if (sd->passthrough) return;
-    __shared__ uint32_t buf[kWaves][kMonsterRun];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t nl = sd->n_long, nv = sd->n_ds, n_valid = sd->n_valid;
-    uint32_t* w = buf[wave];
-    for (uint32_t qi = blockIdx.x * kWaves + wave; qi < nl; qi += gridDim.x * kWaves) {
-        const uint32_t v = d.longlist[qi];
-        const uint32_t a = d.hpos[v], b = (v + 1 < nv) ? d.hpos[v + 1] : n_valid, cnt = b - a;
-        uint32_t m = 64;
-        while (m < cnt) m <<= 1;
-        for (uint32_t j = lane; j < m; j += 64) w[j] = j < cnt ? d.vg2_idx[a + j] : 0xFFFFFFFFu;
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t k = 2; k <= m; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = lane; t < (m >> 1); t += 64) {
-                    const uint32_t lo = ((t / j) * (j << 1)) + (t % j), hi = lo + j;
-                    const bool up = ((lo & k) == 0);
-                    const uint32_t x = w[lo], y = w[hi];
-                    if ((x > y) == up) { w[lo] = y; w[hi] = x; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        for (uint32_t j = lane; j < cnt; j += 64) d.sorted[a + j] = d.raw[w[j]];
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// the queued monsters (>= 2 048 points in one voxel): the run's points in input order are the points whose slot is the voxel's -- an ordered compaction
-// of the scan's owner array, one workgroup per monster, gathered into `sorted` at the run's place
-__global__ void __launch_bounds__(kThreads) vg2_monster_prepare_batch(const SlotDesc* __restrict__ slots) {
-    const SlotDesc& d = slots[blockIdx.y];
-    if (!d.active) return;
-    const ScanDev* sd = d.sd;
-    if (sd->passthrough || sd->n_monster == 0) return;
-    __shared__ uint32_t wsum[kWaves];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t nm = sd->n_monster, n = d.n_raw;
-    const bool odd = active_passes(sd) & 1;
-    const uint32_t* vals = odd ? d.vals_b : d.vals_a;
-    for (uint32_t qi = blockIdx.x; qi < nm; qi += gridDim.x) {
-        const uint32_t v = d.longlist[d.max_ds - 1u - qi];
-        const uint32_t gs = vals[v];
-        uint32_t at = d.hpos[v];
-        for (uint32_t base = 0; base < n; base += kTile) {
-            // each wave owns a contiguous run of 64 x kItems points so that (round, lane) order == input order
-            const uint32_t wbase = base + wave * (64 * kItems);
-            uint32_t own[kItems];
-#pragma unroll
-            for (int r = 0; r < kItems; r++) {
-                const uint32_t i = wbase + r * 64 + lane;
-                own[r] = d.vg2_owner[i < n ? i : (n - 1u)];
-                if (i >= n) own[r] = kVgEmpty;
-            }
-            unsigned long long bal[kItems];
-            uint32_t wtot = 0;
-#pragma unroll
-            for (int r = 0; r < kItems; r++) { bal[r] = __ballot(own[r] == gs); wtot += (uint32_t)__popcll(bal[r]); }
-            if (lane == 0) wsum[wave] = wtot;
-            __syncthreads();
-            uint32_t pos = at;
-            for (int w2 = 0; w2 < wave; w2++) pos += wsum[w2];
-            const uint32_t tile_tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-#pragma unroll
-            for (int r = 0; r < kItems; r++) {
-                if ((bal[r] >> lane) & 1ull) d.sorted[pos + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull))] = d.raw[wbase + r * 64 + lane];
-                pos += (uint32_t)__popcll(bal[r]);
-            }
-            at += tile_tot;
-            __syncthreads();
-        }
-    }
 }
 
 // ---- launchable forms: one scan (arguments by value), or the scans of a batch (blockIdx.y = slot, arguments from the slot's
@@ -1326,37 +934,32 @@ __global__ void __launch_bounds__(kThreads) radix_hist_kernel(const uint32_t* __
                                                               int pass, uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
     radix_hist_body(ka, kb, n, pass, hist, nblocks, sd);
 }
-// vox: the (key, slot) pairs of the scan's voxel list are sorted instead of the (key, index) pairs of its points (vg2): n comes from the device
-__global__ void __launch_bounds__(kThreads) radix_hist_batch(const SlotDesc* __restrict__ slots, int pass, int vox) {
+__global__ void __launch_bounds__(kThreads) radix_hist_batch(const SlotDesc* __restrict__ slots, int pass) {
     uint32_t slot, bx;
     vg_slot_tile(gridDim.y, slot, bx);
     const SlotDesc& d = slots[slot];
-    if (!d.active) return;
-    const uint32_t n = vox ? d.sd->n_vox : d.n_raw, nblocks = vox ? (n + kTile - 1) / kTile : d.nblocks;
-    if (bx >= nblocks || (vox && d.sd->passthrough)) return;
-    radix_hist_body(d.keys_a, d.keys_b, n, pass, d.hist, nblocks, d.sd, bx);
+    if (!d.active || bx >= d.nblocks) return;
+    radix_hist_body(d.keys_a, d.keys_b, d.n_raw, pass, d.hist, d.nblocks, d.sd, bx);
 }
 __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(uint32_t* __restrict__ ka, uint32_t* __restrict__ va,
                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb, uint32_t n, int pass,
                                                                  const uint32_t* __restrict__ hist, uint32_t nblocks, const ScanDev* sd) {
     radix_scatter_body<false>(ka, va, kb, vb, n, pass, hist, nblocks, sd);
 }
-__global__ void __launch_bounds__(kThreads) radix_scatter_batch(const SlotDesc* __restrict__ slots, int pass, int vox) {
+__global__ void __launch_bounds__(kThreads) radix_scatter_batch(const SlotDesc* __restrict__ slots, int pass) {
     uint32_t slot, bx;
     vg_slot_tile(gridDim.y, slot, bx);
     const SlotDesc& d = slots[slot];
-    if (!d.active) return;
-    const uint32_t n = vox ? d.sd->n_vox : d.n_raw, nblocks = vox ? (n + kTile - 1) / kTile : d.nblocks;
-    if (bx >= nblocks || (vox && d.sd->passthrough)) return;
-    radix_scatter_body<true>(d.keys_a, d.vals_a, d.keys_b, d.vals_b, n, pass, d.hist, nblocks, d.sd, bx);
+    if (!d.active || bx >= d.nblocks) return;
+    radix_scatter_body<true>(d.keys_a, d.vals_a, d.keys_b, d.vals_b, d.n_raw, pass, d.hist, d.nblocks, d.sd, bx);
 }
 // one workgroup per scan: digit column d (thread d) of the tiles' histogram rows becomes its exclusive prefix over the tiles, the column's total
 // goes to row `nblocks` (sixteen rows in flight; integer sums: the scatter's positions are what the all-rows fold gave)
-__global__ void __launch_bounds__(256) radix_prefix_batch(const SlotDesc* __restrict__ slots, int pass, int vox) {
+__global__ void __launch_bounds__(256) radix_prefix_batch(const SlotDesc* __restrict__ slots, int pass) {
     const SlotDesc& d = slots[blockIdx.x];
     if (!d.active) return;
     if ((uint32_t)pass >= active_passes(d.sd)) return;
-    const uint32_t nb = vox ? (d.sd->n_vox + kTile - 1) / kTile : d.nblocks;
+    const uint32_t nb = d.nblocks;
     uint32_t* col = d.hist + threadIdx.x;
     uint32_t run = 0;
     for (uint32_t b = 0; b < nb; b += 16) {
@@ -1473,38 +1076,17 @@ int vg_downsample(lio_scan* s, float leaf, int passes) {
 }
 
 // the downsample chain for the scans of a batch: every launch serves all slots (grid.y), nothing is read back
-int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes, int use_vg2) {
+int vg_downsample_batch(hipStream_t st, const SlotDesc* d_slots, int n_slots, uint32_t max_raw, uint32_t max_ds, float leaf, int passes) {
     const float inv = 1.0f / leaf;
     const uint32_t nblocks = (max_raw + kTile - 1) / kTile;  // of the largest scan of the batch
     if (nblocks == 0 || n_slots <= 0) return LIO_OK;
     const uint32_t B = (uint32_t)n_slots;
     hipLaunchKernelGGL(vg_bbox_batch, dim3(nblocks < 48 ? nblocks : 48, B), kThreads, 0, st, d_slots);
-    static const int vg2_on = [] { const char* e = getenv("LIO_VG_CHAIN"); return (e && e[0] == '1') ? 0 : 1; }();  // LIO_VG_CHAIN=1: the sort chain of rounds 1-5
-    if (use_vg2 && vg2_on) {
-        const uint32_t vbound = max_raw < max_ds ? max_raw : max_ds;
-        const uint32_t vblocks = (vbound + kTile - 1) / kTile;  // tiles of the largest voxel list
-        hipLaunchKernelGGL(vg2_insert_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, inv);
-        for (int pass = 0; pass < passes; pass++) {
-            hipLaunchKernelGGL(radix_hist_batch, dim3(vblocks, B), kThreads, 0, st, d_slots, pass, 1);
-            hipLaunchKernelGGL(radix_prefix_batch, dim3(B), 256, 0, st, d_slots, pass, 1);
-            hipLaunchKernelGGL(radix_scatter_batch, dim3(vblocks, B), kThreads, 0, st, d_slots, pass, 1);
-        }
-        hipLaunchKernelGGL(vg2_scan_batch, dim3(B), 1024, 0, st, d_slots, (uint32_t)passes);
-        hipLaunchKernelGGL(vg2_scatter_batch, dim3(nblocks, B), kThreads, 0, st, d_slots);
-        const uint32_t cblocks = (vbound + kThreads - 1) / kThreads;
-        hipLaunchKernelGGL(vg2_centroid_batch, dim3(cblocks < kCentroidGridCap ? cblocks : kCentroidGridCap, B), kThreads, 0, st, d_slots);
-        hipLaunchKernelGGL(vg2_long_prepare_batch, dim3(64, B), kThreads, 0, st, d_slots);
-        hipLaunchKernelGGL(vg2_monster_prepare_batch, dim3(kMonsterBlocksBatch, B), kThreads, 0, st, d_slots);
-        hipLaunchKernelGGL(vg_centroid_both_batch, dim3(64 + kMonsterBlocksBatch, B), kThreads, 0, st, d_slots);
-        hipLaunchKernelGGL(scan_begin_batch, dim3(16, B), 256, 0, st, d_slots);
-        LIO_HIP_TRY(hipGetLastError());
-        return LIO_OK;
-    }
     hipLaunchKernelGGL(vg_keys_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, inv);
     for (int pass = 0; pass < passes; pass++) {
-        if (pass > 0) hipLaunchKernelGGL(radix_hist_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass, 0);
-        hipLaunchKernelGGL(radix_prefix_batch, dim3(B), 256, 0, st, d_slots, pass, 0);
-        hipLaunchKernelGGL(radix_scatter_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass, 0);
+        if (pass > 0) hipLaunchKernelGGL(radix_hist_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass);
+        hipLaunchKernelGGL(radix_prefix_batch, dim3(B), 256, 0, st, d_slots, pass);
+        hipLaunchKernelGGL(radix_scatter_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, pass);
     }
     hipLaunchKernelGGL(vg_count_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots);
     hipLaunchKernelGGL(vg_heads_batch, dim3(nblocks, B), kThreads, 0, st, d_slots, (uint32_t)passes);
