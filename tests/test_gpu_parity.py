@@ -215,6 +215,56 @@ def test_knn_boundary_ties_in_a_voxel_too_large_for_the_staging_area():
     m.close()
 
 
+def test_map_clear_and_refill(oracle_mod, small_world):
+    """lio_map_clear (fastlio_init's fresh IVox, laserMapping.cpp:1064): an emptied map takes a new content like a new map -- with and without the LRU list --
+    and a content put back voxel by voxel keeps every voxel's push_back order (what bench.py's teacher-forced legs rely on: tie mode 2 on a lattice map
+    must still return the reference's lists, order included)"""
+    _dev()
+    from lsd_amd import lio
+
+    pts = small_world["map"][:120_000]
+    rng = np.random.default_rng(12)
+    q = pts[rng.choice(len(pts), 5000, replace=False)].copy()
+    q[:, :3] += rng.normal(0, 0.2, (len(q), 3)).astype(np.float32)
+    for lru in (False, True):
+        m = lio.Map(resolution=0.5, stencil=19, max_points=600_000, max_voxels=300_000)
+        if lru:
+            m.set_lru(200_000, 100.0)
+        m.add(pts[:50_000], 1.0)
+        m.add(pts[50_000:], 2.0)
+        want = m.knn(q)
+        stats = m.stats()
+        m.clear()
+        assert m.stats() == (0, 0)
+        got0, cnt0 = m.knn(q[:100])
+        assert not cnt0.any()
+        m.add(pts[:50_000], 1.0)
+        m.add(pts[50_000:], 2.0)
+        assert m.stats() == stats
+        got = m.knn(q)
+        assert np.array_equal(want[1], got[1]) and np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32)), lru
+        m.close()
+    # push_back order survives a dump-and-refill: lattice map (ties everywhere), lists in the reference's own order (tie mode 2) before and after
+    lat = _tie_lattice(rng, 15000)
+    ql = _tie_lattice(rng, 1500)
+    iv = oracle_mod.IVox(res=0.5, stencil=19)
+    iv.set_tie_mode(2)
+    m = lio.Map(resolution=0.5, stencil=19, max_points=200_000, max_voxels=100_000)
+    m.set_tie_mode(2)
+    for lo, hi in ((0, 4000), (4000, 9000), (9000, 15000)):
+        iv.add(lat[lo:hi], 0.0)
+        m.add(lat[lo:hi], 0.0)
+    ref_pts, ref_cnt, _ = iv.knn(ql)
+    got_pts, got_cnt = m.knn(ql)
+    assert np.array_equal(ref_cnt, got_cnt) and np.array_equal(ref_pts.view(np.uint32), got_pts.view(np.uint32))
+    dump = iv.dump()  # voxel by voxel, push_back order inside a voxel
+    m.clear()
+    m.add(dump, 0.0)
+    got2, cnt2 = m.knn(ql)
+    assert np.array_equal(ref_cnt, cnt2) and np.array_equal(ref_pts.view(np.uint32), got2.view(np.uint32))
+    m.close()
+
+
 def test_knn_pruned_sweep_adversarial(oracle_mod):
     """the sweep visits the stencil voxels nearest-first and skips those that cannot beat five known candidates: maps and queries built
     to make that decision as hard as possible -- queries on voxel faces / edges / corners (+- one f32 ulp), nearest neighbours living in
