@@ -40,6 +40,9 @@ namespace lio {
 #ifndef LIO_KNN_PRUNE
 #define LIO_KNN_PRUNE 1  // distance-ordered sweep with exact pruning of stencil voxels that cannot hold one of the five nearest
 #endif
+#ifndef LIO_KNN_WAVES_BATCH
+#define LIO_KNN_WAVES_BATCH 7  // the batched / sequence kernels: 72 registers, nothing spills (round 6: the statistic in a scalar register, two cold values formed where they are used)
+#endif
 #ifdef LIO_KNN_MAXWAVES  // experiment: CAP the kernel's occupancy (leaves registers / issue slots of every SIMD to the kernels of the other rounds in flight)
 #define LIO_KNN_OCC __attribute__((amdgpu_waves_per_eu(LIO_KNN_MAXWAVES, LIO_KNN_MAXWAVES)))
 #else
@@ -358,7 +361,8 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     GroupLds& g = lds[grp];
     const uint32_t n = sd ? sd->n_ds : n_host;
     const unsigned long long gmask = ((1ull << kG) - 1ull) << (lane - gl);
-    uint32_t visited = 0;  // this lane's share of the candidate statistic (a few queries' stencils: far below 2^32)
+    __shared__ uint32_t stat_s[256 / 64];  // the waves' shares of the candidate statistic (a few hundred queries' stencils: far below 2^32)
+    if (tid < 256 / 64) stat_s[tid] = 0;
     uint32_t touched = 0;  // COUNT only: candidate points whose 16 bytes the sweep asked for
     uint32_t fresh = 0;    // COUNT only: ... of those, the ones no query of this launch had asked for before (distinct points: MapDev::touch_bits)
     uint32_t* const bits = COUNT ? md->touch_bits : nullptr;
@@ -398,7 +402,9 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                         float4 w2;
                         body_to_world(pose_s, queries[q2], w2);
                         world_out[q2] = w2;
-                        pw_s[tid] = w2;
+                        uint32_t t2 = (uint32_t)tid;
+                        asm volatile("" : "+v"(t2));  // (the LDS address is formed here, once per 64 queries: hoisted out of the query loop it was one of the two values spilled to scratch at seven waves per SIMD)
+                        pw_s[t2] = w2;
                     }
                 }
                 __syncthreads();
@@ -417,6 +423,13 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         const uint32_t limit = 0xFFFFFFFFu;  // (an upper bound of the fifth-nearest distance known before the probe: none)
         if constexpr (kPrune) total = probe_stencil_bucketed<KM>(table, mask, st, active, pw, res, kx, ky, kz, gl, lane, gmask, g, nhit, n0, n01, limit);
         else total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
+        {   // the candidate statistic, summed over the wave at once and kept in LDS: a per-lane accumulator across the query loop (and its
+            // 64-bit reduction behind it) was the register that stood between this kernel and seven waves per SIMD without a spill
+            const uint32_t gs = group_sum32(total);
+            const uint32_t ws = (uint32_t)__builtin_amdgcn_readlane((int)gs, 0) + (uint32_t)__builtin_amdgcn_readlane((int)gs, 16) +
+                                (uint32_t)__builtin_amdgcn_readlane((int)gs, 32) + (uint32_t)__builtin_amdgcn_readlane((int)gs, 48);
+            if (lane == 0) stat_s[tid >> 6] += ws;  // (this wave's own word: no other wave touches it)
+        }
         group_lds_sync();
         // every lane keeps its own ascending top-5 as (d2 bits, pool index) pairs, ordered by d2 alone: candidates with an
         // equal d2 keep their arrival order -- any such pair that reaches the global top-6 is an exact tie and the query
@@ -523,7 +536,6 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
             }
             if constexpr (kPrune) need_bound = group_ballot(ins, lane) != 0;
         }
-        visited += total;  // (every lane its own share of the stencil's residents)
         inrange = group_sum32(inrange);
         // merge: six rounds pop the group's smallest (d2, index) head -- the global top-5 (lane r keeps winner r) and the best loser
         uint32_t win = 0xFFFFFFFFu, prev_d = 0xFFFFFFFFu;
@@ -551,7 +563,11 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         // (ivox3d.h:152-154), the cached neighbours of an earlier scan survive.
         if (active && inrange > 0) {
             // (32-bit index: five planes of max_ds points; the 64-bit per-lane plane address, hoisted out of the query loop, was the one value the batched kernel spilled to scratch)
-            if (gl < 5) nn_pts[(uint32_t)gl * nn_stride + q] = (win != 0xFFFFFFFFu) ? pool[win] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gl < 5) {
+                uint32_t g2 = (uint32_t)gl;
+                asm volatile("" : "+v"(g2));  // (... and the plane offset gl * nn_stride the other: formed where it is used)
+                nn_pts[g2 * nn_stride + q] = (win != 0xFFFFFFFFu) ? pool[win] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             if (gl == 0) {
                 nn_cnt[q] = inrange < 5 ? (int32_t)inrange : 5;
                 if (tie) tie_list[atomicAdd(n_tie, 1u)] = q;
@@ -562,14 +578,16 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     // statistics: one atomic per workgroup, spread over 64 counters that each own a 128-B line (same-line
     // atomics serialise in one L2 channel at ~10 ns apiece -- 9k of them used to cost more than the kernel)
     __shared__ unsigned long long vred[256 / 64];
-    unsigned long long vsum = visited;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vsum += __shfl_xor(vsum, off);
-    if (lane == 0) vred[tid >> 6] = vsum;
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long v = (vred[0] + vred[1]) + (vred[2] + vred[3]);
-        if (v) atomicAdd(&md->knn_cand[(blockIdx.x & 63) * 16], v);
+    {
+        __syncthreads();
+        uint32_t te = threadIdx.x;
+        asm volatile("" : "+v"(te));  // (the index is formed here: kept alive from the kernel's head to this tail it was spilled)
+        if (te < 256 / 64) vred[te] = stat_s[te];
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long v = (vred[0] + vred[1]) + (vred[2] + vred[3]);
+            if (v) atomicAdd(&md->knn_cand[(blockIdx.x & 63) * 16], v);
+        }
     }
     if constexpr (COUNT) {
         __syncthreads();
@@ -607,15 +625,15 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_kernel(const Slot* __r
 // the scans of a batch (lio_batch_*): blockIdx.y = slot; pose from the slot's device-resident filter; a slot whose update has finished,
 // or whose filter did not ask for a neighbour search this pass, exits at once
 template <int KM, bool COUNT>
-__global__ void LIO_KNN_OCC __launch_bounds__(256, LIO_KNN_WAVES) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
+__global__ void LIO_KNN_OCC __launch_bounds__(256, COUNT ? LIO_KNN_WAVES : LIO_KNN_WAVES_BATCH) knn_batch_kernel(const Slot* __restrict__ table, uint32_t mask, const float4* __restrict__ pool,
                                                                        float inv_res, StencilArgs st, const SlotDesc* __restrict__ slots, MapDev* md) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
     const SlotGateLite sg = slot_gate_lite(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
     const double* __restrict__ x = d.ctrl->x;
-    knn_body<KM, 0, COUNT>(table, mask, pool, inv_res, st, [x](PoseArgs& P) { pose_fill_from_state(P, x); }, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts, d.max_ds,
-                           d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
+    knn_body<KM, 0, COUNT>(table, mask, pool, inv_res, st, [x](PoseArgs& P) { pose_fill_from_state(P, x); }, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts,
+                                  d.max_ds, d.nn_cnt, md, &d.sd->n_tie, d.tie_list);
 }
 
 // ---- exact redo of the queries whose top-6 contained an exact d2 tie ---------------------------------------
@@ -978,7 +996,7 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
 // sequence mode (lio_batch_create_sequences): every slot searches ITS OWN map -- table, pool and counters come from the slot's MapRef instead of
 // the kernel arguments.  The stencil travels by value, so one launch serves the slots whose map uses that stencil (normally all of them: 19).
 template <int KM>
-__global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id,
+__global__ void __launch_bounds__(256, LIO_KNN_WAVES_BATCH) knn_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id,
                                                                      const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
@@ -987,8 +1005,8 @@ __global__ void __launch_bounds__(256, LIO_KNN_WAVES) knn_seq_kernel(const MapRe
     const SlotGateLite sg = slot_gate_lite(d);
     if ((sg.status != EK_RUNNING) | (sg.converge == 0) | (sg.n_ds < d.min_ds)) return;
     const double* __restrict__ x = d.ctrl->x;
-    knn_body<KM, 0, false>(r.table, r.mask, r.pool, r.inv_res, st, [x](PoseArgs& P) { pose_fill_from_state(P, x); }, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts, d.max_ds,
-                           d.nn_cnt, r.md, &d.sd->n_tie, d.tie_list);
+    knn_body<KM, 0, false>(r.table, r.mask, r.pool, r.inv_res, st, [x](PoseArgs& P) { pose_fill_from_state(P, x); }, d.ds_body, sg.n_ds, nullptr, d.ds_world, d.nn_pts,
+                                  d.max_ds, d.nn_cnt, r.md, &d.sd->n_tie, d.tie_list);
 }
 template <int KM>
 __global__ void __launch_bounds__(256) knn_exact_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id, const SlotDesc* __restrict__ slots) {
