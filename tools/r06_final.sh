@@ -31,7 +31,7 @@ rm -rf $O/prof
 cp $R/bench_full.json $O/bench_full_under_rocprof.json
 cd $R
 fi
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc $? bytes $(wc -c < $O/bench.json)"
+T0=$(date +%s); timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc $? bytes $(wc -c < $O/bench.json) wall $(( $(date +%s) - T0 )) s"
 cp $R/bench_full.json $O/bench_full.json
 head -c 1200 $O/bench.json; echo
 timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu.log
