@@ -2332,7 +2332,10 @@ def bench_merge(args, torch, dist, world, rank, local_rank, dev):
                "collective": {"per_round_and_pass": 1 if comm is not None else 0,
                               "backend": "RCCL all-gather on the round's stream (lio_allgather_records), sums in rank order inside the filter-pass kernel" if comm is not None
                               else "none (one GPU: all 8 sub-maps local; the curve over 1/2/4/8 GPUs was NOT measured here -- one-GPU boxes)",
-                              "states_identical_on_all_ranks": same},
+                              "states_identical_on_all_ranks": same,
+                              "downsample": dict(batch.exchange_stats(), what="with more than one rank every scan is downsampled on ONE rank (slots dealt in contiguous "
+                                                 "shares) and the clouds reach the others in one all-gather per round of slot chunks sized 1.25 x the largest cloud seen "
+                                                 "(lio_batch_exchange_stats); zeros on one GPU: nothing to exchange")},
                "latency": {"one_scan_at_a_time_ms": round(1e3 * float(np.median(lat)), 4),
                            "host_synchronised_collectives": coll[0], "collective_avg_us": round(coll[1] / coll[0], 2) if coll[0] else None},
                "roofline": roofline, "cpu_baseline": cpu, "pose_error_vs_truth_m": err}

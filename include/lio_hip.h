@@ -469,6 +469,14 @@ lio_batch* lio_batch_create_joint(lio_map** sub_maps, int n_sub_maps, lio_comm* 
  * LIO_E_STATE in this mode. */
 typedef int (*lio_gather_fn)(void* ctx, const double* d_local, double* d_gathered, uint32_t n_records, void* stream);
 int lio_batch_set_gather_hook(lio_batch*, lio_gather_fn fn, void* ctx, int rank, int world);
+/* With more than one rank a joint round's voxel-grid chain (src/laserMapping.cpp:1206-1208, once per scan) runs on ONE rank per scan -- rank r owns the
+ * slots [r * ceil(B / world), ...) -- and the downsampled clouds reach the others in one all-gather per round of fixed-size slot chunks (the same
+ * transport as the records; with a hook, n_records = chunk bytes / 256).  The chunk holds 1.25 x the largest cloud the batch has registered so far
+ * (derived from the results, hence equal on every rank); a cloud that does not fit voids the round's result for that job on every rank and the job runs
+ * again with full-size chunks.  LIO_JOINT_SPLIT_DS=0 in the environment: every rank downsamples every scan, as up to ABI revision 5 (bit-identical
+ * results either way: tests/test_dist.py).  Statistics: points per chunk now in force (0 before the first round), jobs that ran again, bytes one rank
+ * contributes to a round's all-gather. */
+int lio_batch_exchange_stats(lio_batch*, uint32_t* chunk_points, uint64_t* jobs_rerun, uint64_t* bytes_per_rank_and_round);
 /* Sequence mode: throughput WITH map_incremental.  n_groups x n_slots independent SLAM sessions (replay of recorded drives, offline mapping of many
  * sequences), one per slot, each with ITS OWN map (lio_engine_create's arguments, per session).  lio_batch_sequences_step takes exactly one job per
  * session -- job j is the NEXT scan of session j = (group j / n_slots, slot j % n_slots): state_in / cov_in the propagated prior as for every

@@ -42,6 +42,9 @@ struct Group {
     std::vector<lio_engine*> sub_eng;    // joint mode: the scan buffer sets of the further local sub-maps, [(m - 1) * B + slot]
     double* d_local32 = nullptr;         // joint mode: this rank's record per slot (B x 32), and every rank's (world x B x 32)
     double* d_gathered = nullptr;
+    char* d_ds_send = nullptr;           // joint mode over several ranks: this rank's share of the round's downsampled clouds (slot chunks), and every rank's
+    char* d_ds_all = nullptr;
+    int ds_world = 0;                    // ... the world size the two were sized for
     MapRef* d_rowmaps = nullptr;         // joint mode: the sub-map behind every descriptor row [m * B + slot] -- ONE neighbour-search launch per pass
     std::vector<MapRef> rowmap_rows;  // ... one row per sub-map as uploaded (refreshed when any word of a sub-map's row changed)
     char* d_block = nullptr;             // [SlotDesc x B (x sub-maps)][EskfDev x B]: one upload per round
@@ -88,6 +91,12 @@ struct lio_batch {
     std::vector<lio_map*> maps;
     lio_comm* comm = nullptr;
     int world = 1;
+    int rank = 0;
+    int split_ds = 1;     // the downsample of a joint round divided among the ranks, clouds all-gathered (LIO_JOINT_SPLIT_DS=0: every rank downsamples every scan)
+    uint32_t ds_cap = 0;  // ... points per slot chunk of that all-gather: 1.25 x the largest cloud seen so far (0: not chosen yet), the same on every rank
+    uint32_t ds_seen_max = 0;
+    bool ds_cap_full = false;  // the re-run of a job whose cloud was cut: chunks of the buffers' full size
+    uint64_t n_ds_cut = 0;     // jobs re-run for that reason
     int (*gather_hook)(void*, const double*, double*, uint32_t, void*) = nullptr;  // lio_batch_set_gather_hook
     void* gather_ctx = nullptr;
     bool joint = false;
@@ -162,6 +171,8 @@ void group_free(Group& g) {
     for (lio_engine* e : g.sub_eng) lio_engine_destroy(e);
     if (g.d_local32) hipFree(g.d_local32);
     if (g.d_gathered) hipFree(g.d_gathered);
+    if (g.d_ds_send) hipFree(g.d_ds_send);
+    if (g.d_ds_all) hipFree(g.d_ds_all);
     if (g.d_rowmaps) hipFree(g.d_rowmaps);
     for (int k = 0; k < 5; k++)
         if (g.exec[k]) hipGraphExecDestroy(g.exec[k]);
@@ -257,11 +268,42 @@ int submit(lio_batch* b, Group& g, lio_scan_job* jobs, int first, int n, int pas
     const MapRef* rowmaps = b->joint ? joint_rowmaps(b, g) : nullptr;
     auto enqueue = [&](BatchTimer* bt) -> int {
         LIO_HIP_TRY(hipMemcpyAsync(g.d_block, g.h_block, g.block_bytes, hipMemcpyHostToDevice, g.stream));
-        if (bt) bt->begin(0);
-        int rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes);
-        if (bt) bt->end(0);
-        if (rc != LIO_OK) return rc;
         const uint32_t ds_bound = b->max_raw < b->max_ds ? b->max_raw : b->max_ds;
+        int rc = LIO_OK;
+        if (b->joint && b->world > 1 && b->split_ds) {
+            // this rank downsamples its share of the round's scans; one all-gather brings everybody's clouds (p2plane.hip: pack / unpack)
+            const int per = (B + b->world - 1) / b->world;
+            const int s0 = std::min(B, b->rank * per), s1 = std::min(B, s0 + per);
+            if (g.ds_world != b->world) {
+                if (g.d_ds_send) hipFree(g.d_ds_send);
+                if (g.d_ds_all) hipFree(g.d_ds_all);
+                g.d_ds_send = g.d_ds_all = nullptr;
+                g.ds_world = 0;
+                const size_t chunk = (size_t)per * ds_exchange_slot_bytes(ds_bound);
+                LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_ds_send), chunk));
+                LIO_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_ds_all), chunk * (size_t)b->world));
+                g.ds_world = b->world;
+            }
+            if (bt) bt->begin(0);
+            if (s1 > s0) rc = vg_downsample_batch(g.stream, g.d_desc + s0, s1 - s0, b->max_raw, b->max_ds, 0.5f, passes);
+            if (bt) bt->end(0);
+            if (rc != LIO_OK) return rc;
+            if (b->ds_cap == 0) {  // before any result: a quarter of the worst case, at least 4096 points (LIO_JOINT_DS_CAP: the tests' way to a cut cloud)
+                const char* k = getenv("LIO_JOINT_DS_CAP");
+                const uint32_t want = k ? (uint32_t)strtoul(k, nullptr, 10) : ((ds_bound / 4u + 1023u) & ~1023u);
+                b->ds_cap = std::min(ds_bound, std::max(k ? 1u : 4096u, want));
+            }
+            const uint32_t cap = b->ds_cap_full ? ds_bound : b->ds_cap;
+            rc = p2plane_batch_exchange_ds(b->comm, b->world, b->gather_hook, b->gather_ctx, g.stream, g.d_desc, B, per, s0, s1, cap, g.d_ds_send, g.d_ds_all);
+            if (rc == LIO_OK && s0 > 0) rc = scan_begin_rows(g.stream, g.d_desc, s0);
+            if (rc == LIO_OK && s1 < B) rc = scan_begin_rows(g.stream, g.d_desc + s1, B - s1);
+            if (rc != LIO_OK) return rc;
+        } else {
+            if (bt) bt->begin(0);
+            rc = vg_downsample_batch(g.stream, g.d_desc, B, b->max_raw, b->max_ds, 0.5f, passes);
+            if (bt) bt->end(0);
+            if (rc != LIO_OK) return rc;
+        }
         if (b->joint) {
             // the slot's downsampled cloud to the other local sub-maps' scan buffers, their neighbour caches resized / forgotten like the slot's own
             rc = p2plane_batch_share(g.stream, g.d_desc, B, M, ds_bound);
@@ -337,6 +379,8 @@ static lio_batch* batch_create_impl(lio_map** maps, int n_maps, lio_comm* comm, 
     b->maps.assign(maps, maps + n_maps);
     b->comm = comm;
     b->world = comm ? lio_comm_world(comm) : 1;
+    b->rank = comm ? lio_comm_rank(comm) : 0;
+    { const char* k = getenv("LIO_JOINT_SPLIT_DS"); b->split_ds = (k && k[0] == '0') ? 0 : 1; }
     b->joint = n_maps > 1 || comm != nullptr;
     b->groups.resize(n_groups);
     { const char* k = getenv("LIO_BATCH_GRAPH"); b->use_graph = (k && k[0] == '0') ? 0 : 1; }
@@ -424,6 +468,19 @@ int lio_batch_set_gather_hook(lio_batch* b, lio_gather_fn fn, void* ctx, int ran
     b->gather_hook = fn;
     b->gather_ctx = ctx;
     b->world = world;
+    b->rank = rank;
+    return LIO_OK;
+}
+
+int lio_batch_exchange_stats(lio_batch* b, uint32_t* chunk_points, uint64_t* jobs_rerun, uint64_t* bytes_per_rank_and_round) {
+    if (!b) return LIO_E_INVALID;
+    const bool on = b->joint && b->world > 1 && b->split_ds;
+    if (chunk_points) *chunk_points = on ? b->ds_cap : 0u;
+    if (jobs_rerun) *jobs_rerun = b->n_ds_cut;
+    if (bytes_per_rank_and_round) {
+        const int per = (b->n_slots + b->world - 1) / b->world;
+        *bytes_per_rank_and_round = on && b->ds_cap ? (uint64_t)per * ds_exchange_slot_bytes(b->ds_cap) : 0u;
+    }
     return LIO_OK;
 }
 
@@ -507,6 +564,12 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
             job.n_ds = r.n_ds;
             job.n_pass = r.n_pass;
             job.n_knn_pass = r.n_knn_pass;
+            if (r.err & 4) {  // the cloud did not fit its chunk of the round's all-gather (every rank sees the flag): again, with full-size chunks
+                hipMemsetAsync(&sc->dev->err, 0, 4, g.stream);
+                b->n_ds_cut++;
+                retry.push_back(j);
+                continue;
+            }
             if (r.err & 1) {
                 set_error("downsampled scan exceeds max_ds %u", b->max_ds);
                 hipMemsetAsync(&sc->dev->err, 0, 4, g.stream);
@@ -514,6 +577,7 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
                 note(job.rc);
                 continue;
             }
+            if ((uint32_t)r.n_ds > b->ds_seen_max) b->ds_seen_max = (uint32_t)r.n_ds;
             if (r.status == EK_SKIPPED) { job.rc = 2; continue; }  // fewer than five downsampled points
             if (r.status == EK_NEEDS_HOST && b->joint && b->gather_hook) {
                 set_error("lio_batch (gather hook mode): a scan needs the host-driven joint path, which only exists over a lio_comm");
@@ -559,6 +623,11 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
         }
         if (need_max > 4) need_max = 4;
         b->pred_passes = need_max;
+        if (b->joint && b->world > 1 && b->split_ds && b->ds_seen_max && !getenv("LIO_JOINT_DS_CAP")) {
+            const uint32_t ds_bound = b->max_raw < b->max_ds ? b->max_raw : b->max_ds;
+            const uint32_t want = (b->ds_seen_max + b->ds_seen_max / 4u + 1023u) & ~1023u;
+            b->ds_cap = std::min(ds_bound, std::max(4096u, want));
+        }
     };
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point c) { return std::chrono::duration<double>(c - a).count(); };
@@ -609,13 +678,15 @@ int lio_batch_process(lio_batch* b, lio_scan_job* jobs, int n_jobs) {
     // the rare re-runs, one by one with all four radix passes
     const std::vector<int> todo = retry;
     retry.clear();
+    b->ds_cap_full = true;
     for (const int j : todo) {
         Group& g = b->groups[0];
         int rc = submit(b, g, jobs, j, 1, 4);
         if (rc == LIO_OK && g.n_active) rc = wait_group(g, B);
-        if (rc != LIO_OK) return bail(rc);
+        if (rc != LIO_OK) { b->ds_cap_full = false; return bail(rc); }
         collect(g);
     }
+    b->ds_cap_full = false;
     for (const int j : retry) { jobs[j].rc = LIO_E_DEVICE; note(LIO_E_DEVICE); }
     return first_err;
 }

@@ -369,6 +369,9 @@ int p2plane_batch_share(hipStream_t st, const SlotDesc* d_descs, int n_slots, in
 int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, int (*gather_hook)(void*, const double*, double*, uint32_t, void*), void* gather_ctx, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
                                int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt, const MapRef* d_rowmaps = nullptr);
 int scan_begin_rows(hipStream_t st, const SlotDesc* d_descs, int n_rows);
+size_t ds_exchange_slot_bytes(uint32_t cap);
+int p2plane_batch_exchange_ds(::lio_comm* comm, int world, int (*gather_hook)(void*, const double*, double*, uint32_t, void*), void* gather_ctx, hipStream_t st,
+                              const SlotDesc* d_descs, int n_slots, int per, int s0, int s1, uint32_t cap, char* d_send, char* d_all);
 int scan_begin(lio_scan* s);
 int scan_set_nds(lio_scan* s, uint32_t n);
 void kt_begin(lio_scan* s, int which);

@@ -672,6 +672,84 @@ __global__ void __launch_bounds__(256) share_ds_batch(const SlotDesc* __restrict
     }
 }
 
+int lio_allgather_records_internal(::lio_comm* c, const double* d_local, double* d_gathered, uint32_t n_records, hipStream_t st);  // comm.hip
+// ---- the downsample of a joint round divided among the ranks ------------------------------------------------------------------------------
+// Every rank registers every scan of a round (against its own sub-maps), so every rank needs every scan's downsampled cloud -- but not its own
+// run of the voxel-grid chain over every scan: that part of a round did not shrink with the number of GPUs (12 of 99 us per scan at N = 1:
+// the ceiling of config 5's scaling).  Rank r runs the chain for the slots [r * per, (r + 1) * per) only and the clouds travel: ONE all-gather
+// per round of fixed-size slot chunks {64 header words, `cap` points}, rank-major = slot-major, on the round's stream.  The chain is
+// deterministic, so the foreign clouds are bit for bit what the rank would have computed (tests/test_dist.py compares the two forms).
+// `cap` is NOT max_ds (sized for the worst scan: 1.6 MB per slot in the bench, eight times a real cloud -- the all-gather would cost more than
+// the chain it saves): the host keeps it at 1.25 x the largest cloud the batch has seen (batch.hip), the same on every rank because every rank
+// sees every result.  A cloud that does not fit is cut, flagged in its header and in ScanDev::err (bit 2) on EVERY rank, and the job runs again
+// with cap = the buffers' full size -- the path an under-launched radix sort already takes.
+constexpr uint32_t kDsHdrBytes = 256;
+
+// blockIdx.y = my slot i (global slot s0 + i): header + cloud into the rank's send buffer
+__global__ void __launch_bounds__(256) pack_ds_batch(const SlotDesc* __restrict__ descs, uint32_t s0, char* __restrict__ send, size_t slot_bytes, uint32_t cap) {
+    const SlotDesc& d = descs[s0 + blockIdx.y];
+    char* chunk = send + (size_t)blockIdx.y * slot_bytes;
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(chunk);
+    float4* pts = reinterpret_cast<float4*>(chunk + kDsHdrBytes);
+    uint32_t n = d.active ? d.sd->n_ds : 0u;
+    const bool cut = n > cap;
+    if (cut) n = cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr[0] = n;
+        hdr[1] = d.active ? (d.sd->err | (cut ? 4u : 0u)) : 0u;
+        hdr[2] = d.active ? d.sd->nbits : 0u;
+        hdr[3] = d.active;
+        if (cut) d.sd->err |= 4u;  // (the owner's own copy is whole, but the round is void for everybody: the job runs again)
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pts[i] = d.ds_body[i];
+}
+// blockIdx.y = slot: a slot another rank downsampled receives its cloud and the words the chain leaves behind (what share_ds_batch does for the
+// further local sub-maps' rows; nbits so that every rank takes the same "sort was launched with too few passes: again" decision)
+__global__ void __launch_bounds__(256) unpack_ds_batch(const SlotDesc* __restrict__ descs, uint32_t s0, uint32_t s1, const char* __restrict__ all, size_t slot_bytes) {
+    const uint32_t slot = blockIdx.y;
+    if (slot >= s0 && slot < s1) return;
+    const SlotDesc& d = descs[slot];
+    if (!d.active) return;
+    const char* chunk = all + (size_t)slot * slot_bytes;
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(chunk);
+    const float4* pts = reinterpret_cast<const float4*>(chunk + kDsHdrBytes);
+    const uint32_t n = hdr[0];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d.ds_body[i] = pts[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.sd->n_ds_prev = d.sd->cache_n;
+        d.sd->n_ds = n;
+        d.sd->err = hdr[1];
+        d.sd->nbits = hdr[2];
+        d.sd->n_tie = 0;
+    }
+}
+
+size_t ds_exchange_slot_bytes(uint32_t cap) { return ((size_t)kDsHdrBytes + (size_t)cap * sizeof(float4) + 255u) & ~(size_t)255u; }
+
+// the chain's outputs of the slots [s0, s1) to every rank, everybody else's to this one; `per` = slots per rank (the last ranks may own fewer, or none)
+int p2plane_batch_exchange_ds(::lio_comm* comm, int world, int (*gather_hook)(void*, const double*, double*, uint32_t, void*), void* gather_ctx, hipStream_t st,
+                              const SlotDesc* d_descs, int n_slots, int per, int s0, int s1, uint32_t cap, char* d_send, char* d_all) {
+    const size_t slot_bytes = ds_exchange_slot_bytes(cap);
+    uint32_t bx = (cap + 255u) / 256u;
+    if (bx > 64u) bx = 64u;
+    if (bx == 0) bx = 1;
+    if (s1 > s0) hipLaunchKernelGGL(pack_ds_batch, dim3(bx, (uint32_t)(s1 - s0)), 256, 0, st, d_descs, (uint32_t)s0, d_send, slot_bytes, cap);
+    LIO_HIP_TRY(hipGetLastError());
+    const size_t n_records = (size_t)per * slot_bytes / 256u;  // the transports count in records of 32 doubles
+    if (n_records > 0xFFFFFFFFull) { set_error("joint batch: a rank's share of a round's downsampled clouds exceeds the transport's record count"); return LIO_E_CAPACITY; }
+    if (gather_hook) {
+        const int rc = gather_hook(gather_ctx, reinterpret_cast<const double*>(d_send), reinterpret_cast<double*>(d_all), (uint32_t)n_records, st);
+        if (rc != LIO_OK) { set_error("the gather hook returned %d", rc); return rc < 0 ? rc : LIO_E_DEVICE; }
+    } else {
+        const int rc = lio_allgather_records_internal(comm, reinterpret_cast<const double*>(d_send), reinterpret_cast<double*>(d_all), (uint32_t)n_records, st);
+        if (rc != LIO_OK) return rc;
+    }
+    hipLaunchKernelGGL(unpack_ds_batch, dim3(bx, (uint32_t)n_slots), 256, 0, st, d_descs, (uint32_t)s0, (uint32_t)s1, d_all, slot_bytes);
+    LIO_HIP_TRY(hipGetLastError());
+    (void)world;
+    return LIO_OK;
+}
+
 // per slot: the partial sums of every local sub-map's linearisation folded exactly as finalize_kernel / step_batch fold them (component c is
 // owned by 32 lanes: stride-32 chunks, fixed xor tree), then added in sub-map order -- what the host-driven joint path (engine.hip:
 // joint_reduce) forms from the sub-maps' reports -- into the rank's 32-double record of the slot; zeros for a slot that is idle or done
@@ -714,7 +792,6 @@ int p2plane_batch_share(hipStream_t st, const SlotDesc* d_descs, int n_slots, in
 // one pass per loop turn: {neighbour search where the filter asks for it, linearisation} against every local sub-map, the rank's records, the
 // all-gather across ranks (comm.hip; a world of one gathers nothing), the filter pass on the rank-ordered sums.  Enqueued blind, eagerly (no
 // graph: a collective sits in the middle of every pass).
-int lio_allgather_records_internal(::lio_comm* c, const double* d_local, double* d_gathered, uint32_t n_records, hipStream_t st);  // comm.hip
 int p2plane_batch_update_joint(lio_map** maps, int n_maps, ::lio_comm* comm, int world, int (*gather_hook)(void*, const double*, double*, uint32_t, void*),
                                void* gather_ctx, hipStream_t st, const SlotDesc* d_descs, int n_slots, uint32_t ds_bound,
                                int n_passes, double* d_local32, double* d_gathered, BatchTimer* bt, const MapRef* d_rowmaps) {

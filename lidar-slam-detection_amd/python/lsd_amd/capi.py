@@ -30,7 +30,7 @@ SYMBOLS = [
     "lio_engine_create", "lio_engine_create_shared", "lio_engine_destroy", "lio_engine_map", "lio_engine_scan", "lio_engine_set_state", "lio_engine_get_state",
     "lio_engine_set_cov", "lio_engine_get_cov", "lio_engine_set_flags", "lio_engine_travel", "lio_engine_is_degenerate",
     "lio_engine_update", "lio_engine_pass_log", "lio_engine_process_scan", "lio_engine_process_scan_device", "lio_engine_timings", "lio_engine_flush",
-    "lio_engine_enable_timing", "lio_comm_unique_id", "lio_comm_init", "lio_comm_destroy", "lio_comm_rank", "lio_comm_world", "lio_allgather_normal_eq", "lio_comm_stats", "lio_engine_set_joint", "lio_engine_joint_register", "lio_engine_joint_register_device", "lio_allgather_records", "lio_engines_process_batch", "lio_batch_create", "lio_batch_create_joint", "lio_batch_create_sequences", "lio_batch_sequences_step", "lio_batch_fastlio_main", "lio_batch_set_gather_hook", "lio_batch_destroy", "lio_batch_process", "lio_batch_engine", "lio_batch_enable_kernel_timing", "lio_batch_kernel_times", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
+    "lio_engine_enable_timing", "lio_comm_unique_id", "lio_comm_init", "lio_comm_destroy", "lio_comm_rank", "lio_comm_world", "lio_allgather_normal_eq", "lio_comm_stats", "lio_engine_set_joint", "lio_engine_joint_register", "lio_engine_joint_register_device", "lio_allgather_records", "lio_engines_process_batch", "lio_batch_create", "lio_batch_create_joint", "lio_batch_create_sequences", "lio_batch_sequences_step", "lio_batch_fastlio_main", "lio_batch_set_gather_hook", "lio_batch_exchange_stats", "lio_batch_destroy", "lio_batch_process", "lio_batch_engine", "lio_batch_enable_kernel_timing", "lio_batch_kernel_times", "lio_engine_set_static_map", "lio_scan_enable_kernel_timing", "lio_scan_kernel_times",
     "lio_state_boxplus", "lio_state_boxminus",
     "lio_localmap_create", "lio_localmap_destroy", "lio_localmap_add_keyframe", "lio_localmap_num_keyframes", "lio_localmap_update",
     "lio_localmap_download",
@@ -206,6 +206,7 @@ def lib():
     sig("lio_allgather_records", cint, vp, vp, vp, u32, vp)
     sig("lio_batch_create_joint", vp, C.POINTER(vp), cint, vp, cint, cint, u32, u32)
     sig("lio_batch_set_gather_hook", cint, vp, GATHER_FN, vp, cint, cint)
+    sig("lio_batch_exchange_stats", cint, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
     sig("lio_batch_create", vp, vp, cint, cint, u32, u32)
     sig("lio_batch_create_sequences", vp, cint, C.c_float, cint, u64, u64, cint, cint, u32, u32)
     sig("lio_batch_sequences_step", cint, vp, C.POINTER(ScanJob), cint, C.POINTER(C.c_double))

@@ -66,6 +66,7 @@ class RecordsAllGatherHost:
         self.hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         self.hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
         self.calls = 0
+        self.records = 0  # 32-double records this rank has sent
 
     def __call__(self, d_local, d_gathered, n, stream):
         torch = self.torch
@@ -79,6 +80,7 @@ class RecordsAllGatherHost:
         if self.hip.hipMemcpy(d_gathered, flat.data_ptr(), self.world * n * 32 * 8, 1) != 0:  # host -> device
             return -1
         self.calls += 1
+        self.records += n
         return 0
 
 

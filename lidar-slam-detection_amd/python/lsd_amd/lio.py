@@ -815,6 +815,13 @@ class Batch:
         self._gather = capi.GATHER_FN(_cb)  # keep the trampoline alive
         check(lib().lio_batch_set_gather_hook(self.h, self._gather, None, int(rank), int(world)), "set_gather_hook")
 
+    def exchange_stats(self):
+        """lio_batch_exchange_stats: the all-gather of a joint round's downsampled clouds -- points per slot chunk in force, jobs that ran again because
+        their cloud was cut, bytes one rank contributes per round (zeros for one rank / LIO_JOINT_SPLIT_DS=0)"""
+        cap, again, nbytes = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib().lio_batch_exchange_stats(self.h, C.byref(cap), C.byref(again), C.byref(nbytes)))
+        return {"chunk_points": cap.value, "jobs_rerun": again.value, "bytes_per_rank_and_round": nbytes.value}
+
     def enable_kernel_timing(self, on=True):
         check(lib().lio_batch_enable_kernel_timing(self.h, int(on)))
 

@@ -58,6 +58,7 @@ def run_batch(sub_maps_pts, gather=None, rank=0, world=1, comm=None, device=0):
     jobs = [dict(dptr=scenes.to_device(raw), n=len(raw), t=1.0, state=st, cov=P0) for raw, st, _ in batch_scans()]
     rc, res = b.process(jobs)
     assert rc == 0, rc
+    run_batch.exchange = b.exchange_stats()
     return res
 
 
@@ -90,12 +91,14 @@ def main():
         dist.destroy_process_group()
         return
     if mode == "gpu_batch":
-        subs4 = make_world(4)[0]
-        per = 4 // world
+        n_sub = 4 if 4 % world == 0 else 2 * world  # (at least two sub-maps per rank: a batch with one map and no communicator is not a joint batch)
+        subs4 = make_world(n_sub)[0]
+        per = n_sub // world
         gather = ldist.RecordsAllGatherHost()
         res = run_batch(subs4[rank * per:(rank + 1) * per], gather, rank, world)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), states=np.array([r["state"] for r in res]), rcs=np.array([r["rc"] for r in res]),
-                 passes=np.array([[r["n_pass"], r["n_knn_pass"]] for r in res]), calls=gather.calls)
+                 passes=np.array([[r["n_pass"], r["n_knn_pass"]] for r in res]), calls=gather.calls, records=gather.records,
+                 chunk_points=run_batch.exchange["chunk_points"], jobs_rerun=run_batch.exchange["jobs_rerun"], n_ds=np.array([r["n_ds"] for r in res]))
         dist.barrier()
         dist.destroy_process_group()
         return

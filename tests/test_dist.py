@@ -11,8 +11,8 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(mode, world, outdir, timeout=600):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+def _run(mode, world, outdir, timeout=600, **extra_env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + os.getpid() % 2000), os.path.join(HERE, "_dist_worker.py"), mode, outdir]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
@@ -218,6 +218,51 @@ def test_batched_joint_registration_two_ranks_one_gpu():
         assert r["rc"] == 3 and (r["n_pass"], r["n_knn_pass"]) == tuple(r0["passes"][k])
         assert np.abs(r["state"] - r0["states"][k]).max() < 1e-9, k
         assert not np.array_equal(r["state"], np.zeros(26)) and np.linalg.norm(r["state"][:3] - pos) < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_joint_rounds_divide_the_downsample_among_the_ranks(world):
+    """With several ranks a joint round's voxel-grid chain runs ONCE per scan, on the rank that owns the slot, and the downsampled clouds travel in one
+    all-gather per round (csrc/p2plane.hip pack_ds_batch / unpack_ds_batch) -- until round 6 every rank downsampled every scan, the part of a round that
+    did not shrink with the number of GPUs.  The chain is deterministic: states, return codes and pass counts must be BIT-identical to the form in
+    which every rank downsamples everything (LIO_JOINT_SPLIT_DS=0), on every rank.  Six jobs through four slots: the second round leaves the last
+    ranks' slots idle; world 3 leaves rank 2 with no slot of its own at all (four slots, two per rank)."""
+    outs = {}
+    for split in ("0", "1"):
+        with tempfile.TemporaryDirectory() as td:
+            _run("gpu_batch", world, td, LIO_JOINT_SPLIT_DS=split)
+            outs[split] = [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(world)]
+    for r in range(world):
+        assert np.all(outs["1"][r]["rcs"] == 3)
+        for key in ("states", "rcs", "passes"):
+            assert np.array_equal(outs["0"][r][key], outs["1"][r][key]), (r, key)
+        assert np.array_equal(outs["1"][r]["states"], outs["1"][0]["states"])
+    # the divided form makes exactly one more exchange per round (two rounds here), and that exchange carries clouds, not 32-double records
+    assert int(outs["1"][0]["calls"]) == int(outs["0"][0]["calls"]) + 2
+    assert int(outs["1"][0]["records"]) > 100 * int(outs["0"][0]["records"])
+    # the chunk follows the clouds (1.25 x the largest seen, in steps of 1024 points, at least 4096), not max_ds = 65536; nothing was cut
+    n_max = int(outs["1"][0]["n_ds"].max())
+    for r in range(world):
+        assert int(outs["1"][r]["jobs_rerun"]) == 0 and int(outs["0"][r]["chunk_points"]) == 0
+        assert int(outs["1"][r]["chunk_points"]) == max(4096, (n_max + n_max // 4 + 1023) // 1024 * 1024)
+
+
+@pytest.mark.gpu
+def test_a_cloud_that_does_not_fit_its_chunk_of_the_all_gather_is_registered_again():
+    """The slot chunks of the round's all-gather are sized from the clouds seen so far; a denser scan than any before does not fit.  Forced here with
+    chunks of 1500 points (LIO_JOINT_DS_CAP): every cloud is cut on its way to the other rank, the flag travels in the chunk's header, BOTH ranks
+    discard the round's result for the job and register it again with full-size chunks -- same states, bit for bit, as without the division."""
+    outs = {}
+    for name, env in (("whole", dict(LIO_JOINT_SPLIT_DS="0")), ("cut", dict(LIO_JOINT_DS_CAP="1500"))):
+        with tempfile.TemporaryDirectory() as td:
+            _run("gpu_batch", 2, td, **env)
+            outs[name] = [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(2)]
+    assert outs["whole"][0]["n_ds"].min() > 1500
+    for r in range(2):
+        assert int(outs["cut"][r]["jobs_rerun"]) == 6 and np.all(outs["cut"][r]["rcs"] == 3)
+        for key in ("states", "rcs", "passes", "n_ds"):
+            assert np.array_equal(outs["whole"][r][key], outs["cut"][r][key]), (r, key)
 
 
 @pytest.mark.gpu
