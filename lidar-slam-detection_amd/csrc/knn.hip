@@ -996,7 +996,7 @@ int knn_batch_launch(lio_map* m, hipStream_t st, const SlotDesc* d_slots, int n_
 // sequence mode (lio_batch_create_sequences): every slot searches ITS OWN map -- table, pool and counters come from the slot's MapRef instead of
 // the kernel arguments.  The stencil travels by value, so one launch serves the slots whose map uses that stencil (normally all of them: 19).
 template <int KM>
-__global__ void __launch_bounds__(256, LIO_KNN_WAVES_BATCH) knn_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id,
+__global__ void __launch_bounds__(256, KM <= 3 ? LIO_KNN_WAVES_BATCH : LIO_KNN_WAVES) knn_seq_kernel(const MapRef* __restrict__ maps, StencilArgs st, int stencil_id,
                                                                      const SlotDesc* __restrict__ slots) {
     const SlotDesc& d = slots[blockIdx.y];
     if (!d.active) return;
