@@ -709,11 +709,22 @@ def main():
 
                     del R
                     m_par = min(len(per_scan), args.parity_scans)
+                    # the same scans once more with the neighbour lists in the reference's own ORDER (lio_map_set_tie_mode 2: every query through the
+                    # reference's selection, a checker ~100 x the search's cost): what the pinned build is compared with AS IT IS, nothing sorted on either side
+                    mode2 = {}
+                    try:
+                        the_map.set_tie_mode(2)
+                        for i in range(m_par):
+                            eng.scan.reset()
+                            step(i)
+                            mode2[f"gpu2_{i}"] = eng.get_state().copy()
+                    finally:
+                        the_map.set_tie_mode(1)
                     with tempfile.TemporaryDirectory(prefix="lio_bench_parity_") as td:
                         np.save(os.path.join(td, "map.npy"), map_pts)
                         np.savez(os.path.join(td, "scans.npz"), P0=P0, n=m_par, **{f"raw{i}": scans[i]["raw"] for i in range(m_par)},
                                  **{f"guess{i}": scans[i]["guess"] for i in range(m_par)}, **{f"gpu{i}": per_scan[i][2] for i in range(m_par)},
-                                 **{f"rel{i}": per_scan[i][3] for i in range(m_par)})
+                                 **{f"rel{i}": per_scan[i][3] for i in range(m_par)}, **mode2)
                         pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "refparity", "--parity-dir", td], capture_output=True, text=True,
                                             timeout=600)
                     line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
@@ -923,7 +934,7 @@ def ref_parity_leg(td):
     out_dp_canonical = np.zeros(0)
     for mode in ("neighbour_lists_as_nth_element_leaves_them", "neighbour_lists_in_canonical_order"):
         R.set_canonical(mode.endswith("canonical_order"))
-        dp, da, bp, ba = [], [], [], []
+        dp, da, bp, ba, dp2, da2 = [], [], [], [], [], []
         for i in range(n):
             R.reset_cache()
             rc, sr, _ = R.register(d[f"raw{i}"], d[f"guess{i}"], P0)
@@ -932,6 +943,10 @@ def ref_parity_leg(td):
             g = d[f"gpu{i}"]
             dp.append(float(np.linalg.norm(g[:3] - sr[:3])))
             da.append(float(synth.quat_angle(g[3:7], sr[3:7])))
+            if f"gpu2_{i}" in d.files and not mode.endswith("canonical_order"):  # the HIP path with its lists in the reference's order against the untouched reference
+                g2 = d[f"gpu2_{i}"]
+                dp2.append(float(np.linalg.norm(g2[:3] - sr[:3])))
+                da2.append(float(synth.quat_angle(g2[3:7], sr[3:7])))
             if f"rel{i}" in d.files and not mode.endswith("canonical_order"):  # the reference against ITSELF: its release build's pose of this scan against this (pinned) build's
                 rl = d[f"rel{i}"]
                 bp.append(float(np.linalg.norm(rl[:3] - sr[:3])))
@@ -944,6 +959,12 @@ def ref_parity_leg(td):
                         "map, both untouched: what the reference moves by when only its build changes -- the resolution at which 'the reference's pose' is defined",
                 "scans": int(len(bp)), "max_dpos_m": float(bp.max()), "max_drot_rad": float(ba.max()), "median_dpos_m": float(np.median(bp)),
                 "scans_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((bp > 1e-4) | (ba > 1e-5)))}
+        if dp2:
+            dp2, da2 = np.array(dp2), np.array(da2)
+            out["hip_in_tie_mode_2_against_the_pinned_build_as_it_is"] = {
+                "what": "lio_map_set_tie_mode(map, 2): the neighbour lists in the reference's own order; the pinned build untouched (nothing sorted on either side)",
+                "scans": int(len(dp2)), "max_dpos_m": float(dp2.max()), "max_drot_rad": float(da2.max()), "median_dpos_m": float(np.median(dp2)),
+                "scans_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((dp2 > 1e-4) | (da2 > 1e-5)))}
         if mode.endswith("canonical_order"):
             out_dp_canonical = dp
         out[mode] = {"scans": int(len(dp)), "max_dpos_m": float(dp.max()), "max_drot_rad": float(da.max()), "median_dpos_m": float(np.median(dp)),
