@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--cpu-scans", type=int, default=320, help="scans of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--ref-scans", type=int, default=160, help="scans of the same workload timed on the reference's own code, oracle/_ref/libref_fastlio_release.so (0 = skip)")
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--frame-z", type=float, default=0.0, help="--config metric: the map frame's origin sits this far ABOVE the scene's ground (the synthetic scene has its ground at "
+                    "z = 0, i.e. the ground plane passes through the map frame's origin -- the one place where esti_plane's n.x + 1 = 0 form is ill-conditioned; a real "
+                    "drive's map frame is the first IMU pose, ~1.8 m above the ground: --frame-z 1.8 shifts map, poses and priors accordingly; parity soaks use it)")
     ap.add_argument("--streams", type=int, default=0, help="--engine threads: independent scans in flight per GPU (one engine + HIP stream + host thread "
                                                               "each, all reading the one resident map)")
     ap.add_argument("--engine", choices=["batch", "threads"], default="batch",
@@ -216,6 +219,8 @@ def main():
 
     scene = synth.Scene(half=100.0, n_boxes=40, seed=1)
     d_map = synth_gpu.sample_surface(scene, args.map_points, dev, seed=2, sigma=0.01)
+    if args.frame_z:
+        d_map[:, 2] -= float(np.float32(args.frame_z))
     scanner = synth_gpu.StaticScanner(scene, dev, n_az=args.n_az, fov_deg=(-24.8, 2.0), max_range=150.0)
 
     def make_pool(n_scans, spread, seed0):
@@ -231,6 +236,7 @@ def main():
             pos = np.array([xy[0], xy[1], 1.8])
             q = synth.quat_from_rotvec([0, 0, rng.uniform(-np.pi, np.pi)])
             d = scanner.scan(pos, q, seed=seed0 + 100000 * rank + k)
+            pos = pos - np.array([0.0, 0.0, float(np.float32(args.frame_z))])  # (the scan is body-frame data: only the pose moves with the frame)
             gp, gq = synth.perturb_pose(pos, q, seed=seed0 + 7 * k + rank, max_t=args.prior_t, max_deg=args.prior_deg)
             pool.append(dict(raw=d.cpu().numpy(), d=d, pos=pos, q=q, guess=synth.state_from_pose(gp, gq), seed=seed0 + 100000 * rank + k))
         return pool
@@ -891,7 +897,7 @@ def main():
             "config": {"workload": f"64x{args.n_az} synthetic scan (~{n_raw} pts) vs {map_points}-pt static map ({map_voxels} voxels of 0.5 m), "
                                    "voxel downsample + iterated ESKF update to convergence (map_incremental excluded: the map is static), one scan per step, "
                                    f"scans sharded across GPUs; {len(scans)} distinct scans per GPU, sensor positions uniform over +-{args.spread:.0f} m of the 200 m scene",
-                       "scan_pool": len(scans), "scan_seeds": [scans[0]["seed"], scans[-1]["seed"]], "spread_m": args.spread,
+                       "scan_pool": len(scans), "scan_seeds": [scans[0]["seed"], scans[-1]["seed"]], "spread_m": args.spread, "frame_z_m": args.frame_z,
                        "n_raw": n_raw, "n_ds_avg": round(n_ds_avg, 1), "passes_avg": round(n_pass_avg, 2),
                        "knn_passes_avg": round(n_knn_avg, 2), "stencil": 19,
                        "knn_candidates_per_query": round(cand / max(n_ds_avg * acc["n_knn"], 1), 1),
