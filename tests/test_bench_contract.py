@@ -183,9 +183,27 @@ def test_compact_stdout_line_fits_the_drivers_parser():
         r = json.loads(open(os.path.join(ROOT, "profiles", name)).read())
         c = json.loads(bench_line.line(r))
         assert c["value"] == pytest.approx(r["value"], rel=1e-6) and "roofline" in c and len(json.dumps(c)) <= bench_line.LIMIT, name
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    # every rank-0 record leaves through emit(); the two print(json.dumps(out)) left are the refparity / rcclprobe CHILD processes' hand-over lines
-    assert len(re.findall(r"^\s+emit\(", src, re.M)) >= 5 and src.split("def main")[1].count("print(json.dumps(out))") == 2
+    # every rank-0 record leaves through emit() (benchlegs/common.py); the two print(json.dumps(out)) in the legs are the refparity / rcclprobe CHILD
+    # processes' hand-over lines
+    import glob
+
+    legs = {os.path.basename(f): open(f).read() for f in glob.glob(os.path.join(ROOT, "benchlegs", "*.py"))}
+    src = "".join(v for k, v in legs.items() if k != "common.py")
+    assert len(re.findall(r"^\s+emit\(", src, re.M)) >= 5 and src.count("print(json.dumps(out))") == 2
+    assert legs["common.py"].count("print(json.dumps(out))") == 1  # (--full-line: a child of the metric leg hands its whole record over)
+
+
+def test_bench_is_an_entry_point_and_one_module_per_leg():
+    """VERDICT r05 (hygiene): bench.py was one 2 400-line file running five sub-benchmarks.  It parses the arguments, brings up the ranks and dispatches;
+    every BASELINE configuration has its own module under benchlegs/, none of them reads /root/reference, and only the checker legs import oracle/."""
+    n = len(open(os.path.join(ROOT, "bench.py")).read().splitlines())
+    assert n <= 200, n
+    for leg in ("metric", "stream", "localize", "merge", "sequences", "parity", "rccl", "common"):
+        src = open(os.path.join(ROOT, "benchlegs", leg + ".py")).read()
+        assert len(src.splitlines()) <= 800, leg
+        assert not re.search(r"[\"']/root/reference", src), leg  # (comments name where the checker libraries were compiled from; no code opens the tree)
+    for leg in ("rccl", "common"):  # nothing of the checker in the plumbing
+        assert "oracle" not in open(os.path.join(ROOT, "benchlegs", leg + ".py")).read(), leg
 
 
 def test_bench_defaults_are_the_drivers_assumptions():
