@@ -64,6 +64,11 @@ def _beyond(g):
             o = {"scans": g.get("scans"), "beyond_1e-4m_or_1e-5rad": g[k], "max_dpos_m": _num(g.get("max_dpos_m"), 3), "max_drot_rad": _num(g.get("max_drot_rad"), 3)}
             if _own(g) is not None:
                 o["reference_run_to_run_max_dpos_m"] = _own(g)
+            pb = g.get("pinned_build")
+            if isinstance(pb, dict):  # the build the path is pinned to: HIP in tie mode 2 against it as it is, the default mode against its lists in canonical order
+                for src, dst in (("hip_in_tie_mode_2_against_the_pinned_build_as_it_is", "pinned_build_as_it_is_vs_tie_mode_2"), ("neighbour_lists_in_canonical_order", "pinned_build_canonical_lists")):
+                    if isinstance(pb.get(src), dict):
+                        o[dst] = {"scans": pb[src].get("scans"), "max_dpos_m": _num(pb[src].get("max_dpos_m"), 2)}
             pe = g.get("per_scan_envelope")
             if isinstance(pe, dict):
                 o["inside_the_references_own_per_scan_envelope"] = "%s of %s" % (pe.get("hip_inside_the_references_own_envelope"), pe.get("scans"))
