@@ -53,7 +53,7 @@ def stream_side_by_side(args, torch, local_rank, R, get_sweep, imu, m_ref, evict
     sides = {"teacher_forced": (side_engine(1), True, False), "teacher_forced_state_and_map": (side_engine(1), True, True),
              "teacher_forced_state_and_map_tie_mode_2": (side_engine(2), True, True), "teacher_forced_tie_mode_2": (side_engine(2), True, False),
              "free_running_tie_mode_2": (side_engine(2), False, False)}
-    tf = {name: dict(dp=[], dr=[], first_bad=None) for name in sides}
+    tf = {name: dict(dp=[], dr=[], first_bad=None, map_cmp=0, map_same=0, map_dpts=0, map_dvox=0, ev=0, inter=0) for name in sides}
     jj, t_ref, n_ref, pts_ref, t_full, n_full, ref_half = 0, 0.0, 0, 0, 0.0, 0, None
     for k in range(m_ref):
         p, st = get_sweep(k)
@@ -96,6 +96,20 @@ def stream_side_by_side(args, torch, local_rank, R, get_sweep, imu, m_ref, evict
                     e2.set_state(s_ref)
                     e2.set_cov(P_ref)
             if forced_map and ref_map is not None and len(ref_map) and e2.map.stats()[1] > 0:
+                # both sides began this sweep with the same map content and (to the figures above) the same pose: what map_incremental + AddPoints (+ the
+                # LRU list) made of it must agree -- voxel and point counts compared before the engine's map is replaced (the one place they may not:
+                # the LRU list's point-by-point order inside a batch)
+                # (Only on a drive without evictions: the map put back below carries the reference's points in push_back order, not its LRU list -- order
+                # of last touch, distance at creation -- so with the quota in force the engine's next eviction starts from another list.)
+                pts2, vox2 = e2.map.stats() if not evict else (len(ref_map), R.map_voxels())
+                rec = tf[name]
+                rec["map_cmp"] += 0 if evict else 1
+                rec["map_same"] += int(pts2 == len(ref_map) and vox2 == R.map_voxels())
+                rec["map_dpts"] = max(rec["map_dpts"], abs(int(pts2) - len(ref_map)))
+                rec["map_dvox"] = max(rec["map_dvox"], abs(int(vox2) - int(R.map_voxels())))
+                ev, inter = e2.map.lru_stats()  # (of this sweep's insert: lio_map_clear below resets the map's counters)
+                rec["ev"] += int(ev)
+                rec["inter"] += int(inter)
                 # the reference's map after this sweep, voxel by voxel in push_back order (IVox::GetAllPoints), in place of the engine's own
                 e2.map.clear()
                 e2.map.add(ref_map, float(R.info()["travel_distance"]))
@@ -117,6 +131,10 @@ def stream_side_by_side(args, torch, local_rank, R, get_sweep, imu, m_ref, evict
                          "p99_dpos_m": float(np.percentile(a_dp, 99)), "last_dpos_m": float(a_dp[-1]),
                          "sweeps_beyond_1e_4_m_or_1e_5_rad": int(np.count_nonzero((a_dp > 1e-4) | (a_dr > 1e-5))), "first_sweep_beyond": rec["first_bad"],
                          "map_voxels_end": {"gpu": int(e2.map.stats()[1]), "reference": int(R.map_voxels())}}
+            if rec["map_cmp"]:
+                per[name]["map_after_every_sweep"] = {"sweeps_compared": rec["map_cmp"], "sweeps_with_the_references_voxel_and_point_counts": rec["map_same"],
+                                                      "max_point_count_difference": rec["map_dpts"], "max_voxel_count_difference": rec["map_dvox"],
+                                                      "voxels_evicted": rec["ev"], "lru_back_voxels_touched_by_the_evicting_batch_upper_bound": rec["inter"]}
         e2.close()
     return per, t_ref, n_ref, pts_ref, n_full, t_full, ref_half
 
