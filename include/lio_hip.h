@@ -92,10 +92,15 @@ int lio_map_clear(lio_map*);
  * travel ago.  Call before the first insert; `max_voxels` of lio_map_create stays the hard limit and must be larger (the map
  * overshoots its capacity while nothing is old enough to go).  Off by default (nothing is ever dropped).
  * lio_map_lru_stats: voxels evicted so far, and an UPPER BOUND on the back-of-list voxels that were touched by the very
- * batch that was evicting around them (if such a voxel's first point comes after its turn to go, the reference's point-by-
- * point order drops and re-creates it; here it keeps its points -- the one case where the maps can differ). */
+ * batch that was evicting around them.  If such a voxel's first point of the batch comes after its turn to go, the reference's
+ * point-by-point order drops it and creates it again holding the batch's points alone: since ABI revision 6 so does the device
+ * (the pops of a batch are replayed in order, csrc/hashmap.hip lru_exact_*; LIO_LRU_EXACT=0 in the environment when the map is
+ * made: counted only, the voxel keeps its points).  lio_map_lru_exact_stats: voxels dropped and re-created that way, and the
+ * batches in which the order could not be followed -- the map above its capacity before the batch, or a voxel younger than
+ * max_distance at the back of the list, where pops no longer coincide with creations -- and the batch was handled as a whole. */
 int lio_map_set_lru(lio_map*, uint64_t capacity_voxels, double max_distance);
 int lio_map_lru_stats(lio_map*, uint64_t* n_evicted, uint64_t* n_interleaved);
+int lio_map_lru_exact_stats(lio_map*, uint64_t* n_recreated, uint64_t* n_batches_not_followed);
 /* Which five, when the fifth and the sixth nearest candidate of a query are EXACTLY equally far (f32 d2).  IVox::GetClosestPoint cuts every stencil
  * voxel's in-range points to five and then the whole list to five with std::nth_element on the distance alone (ivox3d_node.hpp:107-127,
  * ivox3d.h:156-164): which of the equally distant candidates survives is what libstdc++'s introselect does to that particular sequence (stencil

@@ -705,6 +705,7 @@ static void fill_mapref(MapRef& r, const lio_map* m) {
     r.slot_of_point = m->slot_of_point; r.stage = m->stage; r.pool_cap = m->pool_cap;
     r.touch = m->touch; r.prev_touch = m->prev_touch; r.lru_log = m->lru_log; r.log_mask = m->lru_log_cap ? m->lru_log_cap - 1 : 0;
     r.free_items = m->free_items; r.free_in = m->free_in; r.free_cap = m->free_cap;
+    r.first_touch = m->first_touch; r.lru_g = m->lru_g; r.lru_rec = m->lru_rec;
     r.lru_capacity = (uint32_t)m->lru_capacity; r.lru_max_distance = m->lru_max_distance;
     r.mask = m->table_mask; r.inv_res = m->inv_res; r.res = m->res; r.key_mode = m->key_mode; r.max_voxels = (uint32_t)m->max_voxels;
     r.stencil_id = m->stencil_id;

@@ -258,6 +258,7 @@ void lio_map_destroy(lio_map* m) {
     hipFree(m->table); hipFree(m->cap); hipFree(m->pending); hipFree(m->created); hipFree(m->pool); hipFree(m->pool_seq); hipFree(m->touch_bits); hipFree(m->dev);
     hipFree(m->slot_of_point); hipFree(m->tile_sum); hipFree(m->stage);
     hipFree(m->touch); hipFree(m->prev_touch); hipFree(m->touch2); hipFree(m->prev_touch2); hipFree(m->lru_log); hipFree(m->free_items); hipFree(m->free_in);
+    hipFree(m->first_touch); hipFree(m->lru_g); hipFree(m->lru_rec);
     hipFree(m->table2); hipFree(m->cap2); hipFree(m->pending2); hipFree(m->created2); hipFree(m->remap);
     if (m->host_dev) hipHostFree(m->host_dev);
     if (m->ev_classified) hipEventDestroy(m->ev_classified);
@@ -282,6 +283,12 @@ int lio_map_set_lru(lio_map* m, uint64_t capacity_voxels, double max_distance) {
               dev_alloc(&m->prev_touch2, cap, &m->bytes) && dev_alloc(&m->lru_log, lc, &m->bytes) && dev_alloc(&m->free_items, (uint64_t)24 * m->free_cap, &m->bytes) && dev_alloc(&m->free_in, (uint64_t)24 * m->free_cap, &m->bytes) &&
               dev_alloc(&m->table2, cap, &m->bytes) && dev_alloc(&m->cap2, cap, &m->bytes) && dev_alloc(&m->pending2, cap, &m->bytes) &&
               dev_alloc(&m->created2, cap, &m->bytes) && dev_alloc(&m->remap, cap, &m->bytes);
+    {   // the reference's point-by-point order inside a batch (hashmap.hip lru_exact_*): LIO_LRU_EXACT=0 leaves it counted, not followed
+        const char* ex = getenv("LIO_LRU_EXACT");
+        if (!(ex && ex[0] == '0'))
+            ok = ok && dev_alloc(&m->first_touch, cap, &m->bytes) && dev_alloc(&m->lru_g, m->slot_of_point_cap, &m->bytes) && dev_alloc(&m->lru_rec, (uint64_t)kLruRecCap, &m->bytes) &&
+                 hipMemsetAsync(m->first_touch, 0, cap * 8, m->stream) == hipSuccess;
+    }
     ok = ok && hipMemsetAsync(m->touch, 0, cap * 8, m->stream) == hipSuccess && hipMemsetAsync(m->prev_touch, 0, cap * 8, m->stream) == hipSuccess &&
          hipMemsetAsync(m->prev_touch2, 0, cap * 8, m->stream) == hipSuccess && hipMemsetAsync(m->lru_log, 0, lc * sizeof(LruEntry), m->stream) == hipSuccess &&
          hipStreamSynchronize(m->stream) == hipSuccess;
@@ -297,6 +304,15 @@ int lio_map_lru_stats(lio_map* m, uint64_t* n_evicted, uint64_t* n_interleaved) 
     const int rc = map_check(m, m->stream);
     if (n_evicted) *n_evicted = m->host_dev->n_evicted;
     if (n_interleaved) *n_interleaved = m->host_dev->n_lru_interleaved;
+    return rc;
+}
+
+int lio_map_lru_exact_stats(lio_map* m, uint64_t* n_recreated, uint64_t* n_batches_not_followed) {
+    if (!m) return LIO_E_INVALID;
+    hipSetDevice(m->device);
+    const int rc = map_check(m, m->stream);
+    if (n_recreated) *n_recreated = m->host_dev->n_lru_recreated;
+    if (n_batches_not_followed) *n_batches_not_followed = m->host_dev->n_lru_inexact;
     return rc;
 }
 

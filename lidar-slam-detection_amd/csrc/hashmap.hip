@@ -31,7 +31,7 @@ __device__ __forceinline__ void map_insert_claim_body(Slot* table, uint32_t mask
                                                                float inv_res, float res, int key_mode, float travel, uint32_t max_voxels,
                                                                MapDev* md, uint32_t* __restrict__ slot_of_point,
                                                                unsigned long long* __restrict__ touch, unsigned long long* __restrict__ prev_touch,
-                                                               unsigned long long stamp_base) {
+                                                               unsigned long long stamp_base, unsigned long long* __restrict__ first_touch = nullptr) {
     const unsigned long long n = n_dev ? (unsigned long long)*n_dev : n_host;
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // the batch's sequence numbers (read by the write kernel, a later launch): seq_acc .. seq_acc + n
         const uint32_t base = md->seq_acc;
@@ -81,6 +81,9 @@ __device__ __forceinline__ void map_insert_claim_body(Slot* table, uint32_t mask
         if (touch) {  // the LAST point of the batch that lands in a voxel decides its LRU position
             const unsigned long long old = atomicMax(&touch[found], stamp_base + i);
             if (old < stamp_base) prev_touch[found] = old;  // exactly one thread per voxel and batch sees the stamp of an earlier batch
+            // ... and the FIRST point of the batch in the voxel (a later batch beats an earlier one, inside a batch the smaller index wins): when the
+            // reference's point-by-point order would have dropped the voxel before that point, it re-creates it there (lru_exact_*)
+            if (first_touch) atomicMax(&first_touch[found], stamp_base + (kStampIdxMask - i));
         }
         const uint32_t before = atomicAdd(&pending[found], 1u);
         // the first arriver of a voxel in this batch is its leader (bit 31) and sizes the region in pass 2
@@ -331,13 +334,250 @@ __device__ __forceinline__ void lru_append_body(const uint32_t* __restrict__ slo
     }
 }
 
-__device__ __forceinline__ void lru_evict_body(Slot* table, uint32_t* __restrict__ cap, const float* __restrict__ created,
+// ---- the reference's point-by-point order inside ONE batch (ivox3d.h:231-256) -------------------------------------------------------------
+// AddPoints handles a batch point by point: the point's voxel is created at the front of the list or moved there, and then, if the map holds more
+// voxels than its capacity and the voxel at the BACK is old enough, that voxel goes.  A voxel near the back that the batch touches only AFTER the
+// point at which it went is therefore dropped with all it held and created again, holding the batch's points alone, stamped with the distance of
+// now -- while the walk above, which sees the batch as a whole, skips every voxel the batch touched.  (The voxels that are dropped for good are the
+// same either way: every re-creation is one more creation, i.e. one more pop, and that pop takes the voxel the walk takes instead.)
+// Which touched voxels are dropped is decided by replaying the pops in order: pops happen at the batch's voxel-creating points (g, in point order;
+// the first capacity - size of them fill the map up and pop nothing) and at the re-creations they cause; the pop at point t takes the oldest voxel
+// of the list that has not been touched by a point before t.  One lane replays that over the list's old entries staged in LDS; the voxels found are
+// cut down to the batch's own points afterwards (the pool keeps arrival order, the sequence numbers tell the batch's points).  The replay gives up --
+// the batch is handled as before and counted in n_lru_inexact -- where pops do not coincide with creations: the map above its capacity before the
+// batch, or a voxel younger than max_distance at the back.
+struct LruExact {
+    unsigned long long* first_touch;
+    uint32_t* g;
+    uint32_t* rec;
+    const uint32_t* slot_of_point;
+    float4* pool;
+    uint32_t* seq;
+};
+constexpr int kLruRq = 8192;  // pending re-creations the replay holds (a binary min-heap in LDS)
+
+// returns the number of voxels to re-create (their slots in ex.rec); *w_pops = the untouched voxels the batch drops for good (what the walk below
+// evicts), or 0xFFFFFFFF when the replay gave up and the walk applies its own rule
+__device__ __forceinline__ uint32_t lru_exact_replay(const Slot* table, const float* __restrict__ created, const unsigned long long* __restrict__ touch,
+                                                     const unsigned long long* __restrict__ prev_touch, unsigned long long stamp_base,
+                                                     const LruEntry* __restrict__ log, unsigned long long log_mask, unsigned long long n_add, uint32_t capacity,
+                                                     float travel, float max_distance, MapDev* md, const LruExact& ex, uint32_t* w_pops) {
+    __shared__ uint32_t xw[4];
+    __shared__ uint32_t x_ng, x_gi, x_rn, x_recn, x_wp, x_excess, x_deficit;
+    __shared__ long long x_t;
+    __shared__ int x_state, x_have;  // state: 0 replaying, 1 done, 2 given up
+    __shared__ uint32_t x_rq[kLruRq];   // pending re-creation points: a binary min-heap, the next one at [0]
+    __shared__ uint8_t x_cls[256];      // 0 stale, 1 untouched, 2 touched by this batch; bit 7: younger than max_distance
+    __shared__ uint32_t x_f[256], x_slot[256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (1) the batch's voxel-creating points in point order: point i creates a voxel iff the voxel had no stamp before this batch and i is its first point
+    if (tid == 0) x_ng = 0;
+    __syncthreads();
+    for (unsigned long long base = 0; base < n_add; base += 256) {
+        const unsigned long long i = base + tid;
+        bool is_g = false;
+        if (i < n_add) {
+            const uint32_t sp = ex.slot_of_point[i];
+            if (sp != kNoIdx) {
+                const uint32_t h = sp & 0x7FFFFFFFu;
+                const unsigned long long ft = ex.first_touch[h];
+                is_g = prev_touch[h] == 0ull && ft >= stamp_base && (kStampIdxMask - (ft - stamp_base)) == i;
+            }
+        }
+        const unsigned long long m = __ballot(is_g);
+        if (lane == 0) xw[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = x_ng + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) off += xw[w];
+        if (is_g) ex.g[off] = (uint32_t)i;
+        __syncthreads();
+        if (tid == 0) x_ng += (xw[0] + xw[1]) + (xw[2] + xw[3]);
+        __syncthreads();
+    }
+    const uint32_t n_g = x_ng, n_vox = md->n_voxels;
+    const uint32_t s0 = n_vox - n_g;  // voxels before the batch
+    if (tid == 0) {
+        x_state = 0;
+        x_have = 0;
+        x_rn = 0;
+        x_recn = 0;
+        x_wp = 0;
+        x_gi = 0;
+        x_t = -1;
+        x_excess = s0 > capacity ? s0 - capacity : 0u;   // the map may already hold more than its capacity (nothing was old enough to go): a pop at every point
+        x_deficit = s0 < capacity ? capacity - s0 : 0u;  // ... or less: the first creations fill it up and pop nothing
+        if (x_excess == 0 && n_g <= x_deficit) x_state = 1;  // the batch ends at or below the capacity: no pop at all
+    }
+    __syncthreads();
+    // (2) the replay over the list's old entries, oldest first.  A pop is attempted after EVERY point while the map holds more voxels than its capacity
+    // (ivox3d.h:251): at the creation that takes it over the capacity, and at every following point until it is back.
+    const unsigned long long limit = md->log_head_prev;
+    unsigned long long tail = md->log_tail;
+    for (; x_state == 0 && tail < limit; tail += 256) {
+        const unsigned long long idx = tail + tid;
+        uint8_t cls = 0;
+        uint32_t f = 0xFFFFFFFFu, slot = 0;
+        if (idx < limit) {
+            const LruEntry e = log[idx & log_mask];
+            if (e.stamp != 0) {
+                slot = e.slot;
+                const unsigned long long now = touch[slot];
+                if (now == e.stamp) cls = 1;
+                else if (now >= stamp_base && prev_touch[slot] == e.stamp) {
+                    cls = 2;
+                    const unsigned long long ft = ex.first_touch[slot];
+                    f = (uint32_t)(kStampIdxMask - (ft - stamp_base));
+                }
+                if (cls && !((travel - created[slot]) > max_distance)) cls |= 0x80;
+            }
+        }
+        x_cls[tid] = cls;
+        x_f[tid] = f;
+        x_slot[tid] = slot;
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t len = (uint32_t)(limit - tail < 256ull ? limit - tail : 256ull);
+            uint32_t gi = x_gi, rn = x_rn, recn = x_recn, wp = x_wp, excess = x_excess, deficit = x_deficit;
+            long long t = x_t;
+            int state = 0, have = x_have;
+            // the next voxel-creating point (a new voxel's first point, or the first point of a voxel dropped earlier in the batch), 2^32 - 1 when none is left
+            auto next_creation = [&]() -> uint32_t {
+                const uint32_t tg = gi < n_g ? ex.g[gi] : 0xFFFFFFFFu, tr = rn > 0 ? x_rq[0] : 0xFFFFFFFFu;
+                return tg < tr ? tg : tr;
+            };
+            auto take_creation = [&]() {
+                const uint32_t tg = gi < n_g ? ex.g[gi] : 0xFFFFFFFFu, tr = rn > 0 ? x_rq[0] : 0xFFFFFFFFu;
+                if (tg < tr) {
+                    gi++;
+                } else {  // pop the heap's root: the last leaf sinks from the top
+                    const uint32_t v = x_rq[--rn];
+                    uint32_t at = 0;
+                    for (;;) {
+                        uint32_t ch = 2 * at + 1;
+                        if (ch >= rn) break;
+                        if (ch + 1 < rn && x_rq[ch + 1] < x_rq[ch]) ch++;
+                        if (!(x_rq[ch] < v)) break;
+                        x_rq[at] = x_rq[ch];
+                        at = ch;
+                    }
+                    if (rn) x_rq[at] = v;
+                }
+                if (deficit > 0) deficit--; else excess++;
+            };
+            for (uint32_t k = 0; k < len && state == 0; k++) {
+                const uint8_t c = x_cls[k];
+                if ((c & 0x7F) == 0) continue;  // a stale entry: the voxel was touched, or went, long ago
+                for (;;) {
+                    if (!have) {  // the point after which the next pop is attempted
+                        if (excess == 0) {
+                            const uint32_t tc = next_creation();
+                            if (tc == 0xFFFFFFFFu) { state = 1; break; }
+                            take_creation();
+                            if (excess == 0) continue;  // (it filled the map up)
+                            t = (long long)tc;
+                        } else {
+                            t = t + 1;
+                            if (t >= (long long)n_add) { state = 1; break; }
+                        }
+                        while (next_creation() != 0xFFFFFFFFu && (long long)next_creation() <= t) take_creation();
+                        have = 1;
+                    }
+                    if ((c & 0x7F) == 2 && (long long)x_f[k] <= t) break;  // touched by a point up to t: at the front of the list by then -- the next entry is the back
+                    if (c & 0x80) {  // at the back and too young to go: no pop
+                        if ((c & 0x7F) == 2) {  // ... until the batch touches it (its first point f): the map keeps growing meanwhile
+                            t = (long long)x_f[k] - 1;
+                            have = 0;
+                            continue;
+                        }
+                        state = 1;  // for the rest of the batch
+                        break;
+                    }
+                    excess--;  // the pop after point t takes this voxel
+                    have = 0;
+                    if ((c & 0x7F) == 2) {  // ... and a later point of the batch creates it again: one more creation
+                        if (recn >= kLruRecCap || rn >= (uint32_t)kLruRq) { state = 2; break; }
+                        ex.rec[recn++] = x_slot[k];
+                        const uint32_t fk = x_f[k];
+                        uint32_t at = rn++;  // heap push: the new leaf rises
+                        while (at > 0 && fk < x_rq[(at - 1) / 2]) { x_rq[at] = x_rq[(at - 1) / 2]; at = (at - 1) / 2; }
+                        x_rq[at] = fk;
+                    } else {
+                        wp++;
+                    }
+                    break;
+                }
+            }
+            x_gi = gi; x_rn = rn; x_recn = recn; x_wp = wp; x_excess = excess; x_deficit = deficit; x_t = t; x_have = have;
+            if (state) x_state = state;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // the list's old entries used up with pops still due: the back would be a voxel of this very batch -- not followed
+    if (tid == 0 && x_state == 0) {
+        bool due = x_excess > 0 && x_t + 1 < (long long)n_add;
+        if (x_excess == 0) {
+            uint32_t left = (n_g - x_gi) + x_rn;
+            due = left > x_deficit;
+        }
+        x_state = due ? 2 : 1;
+    }
+    __syncthreads();
+    const int state = x_state;
+    const uint32_t recn = x_recn;
+    if (tid == 0 && state == 2) md->n_lru_inexact++;
+    *w_pops = state == 2 ? 0xFFFFFFFFu : x_wp;
+    return state == 2 ? 0u : recn;
+}
+
+// the voxels the replay found: what they held before the batch goes, the batch's own points move to the front of the region in the order they have,
+// the voxel is as old as the batch (NodeType(distance), ivox3d.h:240).  One wave per voxel.
+__device__ __forceinline__ void lru_exact_recreate(Slot* table, float* __restrict__ created, uint32_t recn, unsigned long long n_add, float travel, MapDev* md,
+                                                   const LruExact& ex) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t seq0 = md->seq_cur;
+    for (uint32_t v = (uint32_t)wave; v < recn; v += 4u) {
+        const uint32_t h = ex.rec[v];
+        const uint32_t ptr = table[h].ptr, cnt = table[h].cnt;
+        uint32_t kept = 0;
+        for (uint32_t base = 0; base < cnt; base += 64u) {
+            const uint32_t j = base + (uint32_t)lane;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t sq = 0;
+            bool keep = false;
+            if (j < cnt) {
+                p = ex.pool[ptr + j];
+                sq = ex.seq[ptr + j];
+                keep = (unsigned long long)(uint32_t)(sq - seq0) < n_add;  // one of this batch's points
+            }
+            const unsigned long long m = __ballot(keep);
+            const uint32_t pos = kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_s_waitcnt(0);  // (every lane's load has arrived before any lane stores: the stores land at or before the places read)
+            if (keep) {
+                ex.pool[ptr + pos] = p;
+                ex.seq[ptr + pos] = sq;
+            }
+            kept += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) {
+            table[h].cnt = kept;
+            created[h] = travel;
+            atomicAdd(&md->n_points, (unsigned long long)0 - (unsigned long long)(cnt - kept));
+            atomicAdd(&md->n_lru_recreated, 1ull);
+        }
+    }
+}
+
+__device__ __forceinline__ void lru_evict_body(Slot* table, uint32_t* __restrict__ cap, float* __restrict__ created,
                                                         unsigned long long* __restrict__ touch, const unsigned long long* __restrict__ prev_touch,
                                                         unsigned long long stamp_base, const LruEntry* __restrict__ log,
                                                         unsigned long long log_mask, uint32_t* __restrict__ free_items, uint32_t free_cap,
                                                         unsigned long long n_host, const uint32_t* __restrict__ n_dev, uint32_t capacity,
-                                                        float travel, float max_distance, MapDev* md, const uint32_t* __restrict__ free_in) {
+                                                        float travel, float max_distance, MapDev* md, const uint32_t* __restrict__ free_in, const LruExact ex) {
     const unsigned long long n_add = n_dev ? (unsigned long long)*n_dev : n_host;
+    // which of the voxels this batch touched the reference dropped on the way (before the walk below changes the stamps the replay reads)
+    uint32_t w_exact = 0xFFFFFFFFu;
+    const uint32_t n_rec = ex.first_touch ? lru_exact_replay(table, created, touch, prev_touch, stamp_base, log, log_mask, n_add, capacity, travel, max_distance, md, ex, &w_exact) : 0u;
     // regions the grow kernel of this batch freed (voxels that moved to a larger one): fold them into the free lists it pops from.  The 21 size
     // classes' counters are read in one go (they used to be read class by class between two barriers: 21 dependent round trips, ~10 us of this
     // kernel's 16), the classes that received something -- usually two or three -- are then copied in turn
@@ -364,6 +604,7 @@ __device__ __forceinline__ void lru_evict_body(Slot* table, uint32_t* __restrict
     if (tid == 0) {
         unsigned long long e = n_vox > capacity ? (unsigned long long)(n_vox - capacity) : 0ull;
         want_s = (uint32_t)(e < n_add ? e : n_add);
+        if (w_exact != 0xFFFFFFFFu) want_s = w_exact;  // the replay's count: pops are one per point, and a voxel that is dropped and re-created takes one
         tail_s = md->log_tail;
         pts_s = 0;
     }
@@ -449,6 +690,8 @@ __device__ __forceinline__ void lru_evict_body(Slot* table, uint32_t* __restrict
             md->n_evicted += done;
         }
     }
+    __syncthreads();
+    if (n_rec) lru_exact_recreate(table, created, n_rec, n_add, travel, md, ex);
 }
 
 // ---- launchable forms: one map (arguments by value), or the maps of a sequence batch (blockIdx.y = slot, arguments from the slot's MapRef in
@@ -457,15 +700,16 @@ __global__ void __launch_bounds__(256) map_insert_claim_kernel(Slot* table, uint
                                                                const float4* __restrict__ pts, unsigned long long n_host, const uint32_t* __restrict__ n_dev,
                                                                float inv_res, float res, int key_mode, float travel, uint32_t max_voxels, MapDev* md,
                                                                uint32_t* __restrict__ slot_of_point, unsigned long long* __restrict__ touch,
-                                                               unsigned long long* __restrict__ prev_touch, unsigned long long stamp_base) {
+                                                               unsigned long long* __restrict__ prev_touch, unsigned long long stamp_base,
+                                                               unsigned long long* __restrict__ first_touch) {
     map_insert_claim_body(table, mask, pending, created, pts, n_host, n_dev, inv_res, res, key_mode, travel, max_voxels, md, slot_of_point, touch, prev_touch,
-                          stamp_base);
+                          stamp_base, first_touch);
 }
 __global__ void __launch_bounds__(256) map_insert_claim_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
     if (!seq[blockIdx.y].go) return;
     const MapRef& r = maps[blockIdx.y];
     map_insert_claim_body(r.table, r.mask, r.pending, r.created, r.stage, 0ull, &r.md->n_add, r.inv_res, r.res, r.key_mode, (float)seq[blockIdx.y].travel,
-                          r.max_voxels, r.md, r.slot_of_point, r.lru_capacity ? r.touch : nullptr, r.prev_touch, r.stamp_base);
+                          r.max_voxels, r.md, r.slot_of_point, r.lru_capacity ? r.touch : nullptr, r.prev_touch, r.stamp_base, r.lru_capacity ? r.first_touch : nullptr);
 }
 __global__ void __launch_bounds__(256) map_insert_grow_kernel(Slot* table, uint32_t* __restrict__ cap, uint32_t* __restrict__ pending, float4* pool, uint32_t* seq,
                                                               unsigned long long pool_cap, unsigned long long n_host, const uint32_t* __restrict__ n_dev,
@@ -500,20 +744,21 @@ __global__ void __launch_bounds__(1024) lru_append_seq(const MapRef* __restrict_
     if (!seq[blockIdx.y].go || !r.lru_capacity) return;
     lru_append_body(r.slot_of_point, r.touch, 0ull, &r.md->n_add, r.stamp_base, r.lru_log, r.log_mask, r.md);
 }
-__global__ void __launch_bounds__(256) lru_evict_kernel(Slot* table, uint32_t* __restrict__ cap, const float* __restrict__ created,
+__global__ void __launch_bounds__(256) lru_evict_kernel(Slot* table, uint32_t* __restrict__ cap, float* __restrict__ created,
                                                         unsigned long long* __restrict__ touch, const unsigned long long* __restrict__ prev_touch,
                                                         unsigned long long stamp_base, const LruEntry* __restrict__ log, unsigned long long log_mask,
                                                         uint32_t* __restrict__ free_items, uint32_t free_cap, unsigned long long n_host,
                                                         const uint32_t* __restrict__ n_dev, uint32_t capacity, float travel, float max_distance, MapDev* md,
-                                                        const uint32_t* __restrict__ free_in) {
+                                                        const uint32_t* __restrict__ free_in, const LruExact ex) {
     lru_evict_body(table, cap, created, touch, prev_touch, stamp_base, log, log_mask, free_items, free_cap, n_host, n_dev, capacity, travel, max_distance, md,
-                   free_in);
+                   free_in, ex);
 }
 __global__ void __launch_bounds__(256) lru_evict_seq(const MapRef* __restrict__ maps, const SeqDev* __restrict__ seq) {
     const MapRef& r = maps[blockIdx.y];
     if (!seq[blockIdx.y].go || !r.lru_capacity) return;
     lru_evict_body(r.table, r.cap, r.created, r.touch, r.prev_touch, r.stamp_base, r.lru_log, r.log_mask, r.free_items, r.free_cap, 0ull, &r.md->n_add,
-                   r.lru_capacity, (float)seq[blockIdx.y].travel, r.lru_max_distance, r.md, r.free_in);
+                   r.lru_capacity, (float)seq[blockIdx.y].travel, r.lru_max_distance, r.md, r.free_in,
+                   LruExact{r.first_touch, r.lru_g, r.lru_rec, r.slot_of_point, r.pool, r.pool_seq});
 }
 
 // table rebuild: live slots are re-inserted into the twin table (no tombstones), the touch log is re-pointed
@@ -600,7 +845,7 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
     }
     hipLaunchKernelGGL(map_insert_claim_kernel, (uint32_t)blocks, 256, 0, stream, m->table, m->table_mask, m->pending, m->created,
                        d_pts, (unsigned long long)n, d_n, m->inv_res, m->res, m->key_mode, (float)travel, (uint32_t)m->max_voxels, m->dev,
-                       m->slot_of_point, lru ? m->touch : nullptr, m->prev_touch, stamp_base);
+                       m->slot_of_point, lru ? m->touch : nullptr, m->prev_touch, stamp_base, lru ? m->first_touch : nullptr);
     if (layout) {
         const uint32_t ntiles = (m->table_cap + kScanTile - 1) / kScanTile;
         hipLaunchKernelGGL(map_layout_sums_kernel, ntiles, 256, 0, stream, m->pending, m->table_cap, m->tile_sum);
@@ -618,7 +863,8 @@ int map_insert_dev(lio_map* m, hipStream_t stream, const float4* d_pts, uint64_t
                            (unsigned long long)(m->lru_log_cap - 1), m->dev);
         hipLaunchKernelGGL(lru_evict_kernel, 1, 256, 0, stream, m->table, m->cap, m->created, m->touch, m->prev_touch, stamp_base, m->lru_log,
                            (unsigned long long)(m->lru_log_cap - 1), m->free_items, m->free_cap, (unsigned long long)n, d_n, (uint32_t)m->lru_capacity,
-                           (float)travel, m->lru_max_distance, m->dev, m->free_in);
+                           (float)travel, m->lru_max_distance, m->dev, m->free_in,
+                           LruExact{m->first_touch, m->lru_g, m->lru_rec, m->slot_of_point, m->pool, m->pool_seq});
         m->tomb_bound += n;
     }
     LIO_HIP_TRY(hipGetLastError());

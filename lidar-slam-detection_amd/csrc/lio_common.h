@@ -77,6 +77,8 @@ struct MapDev {
     unsigned long long log_head, log_tail, log_head_prev;  // touch log: entries appended / consumed / head before the current batch
     unsigned long long n_evicted;    // voxels evicted so far
     unsigned long long n_lru_interleaved;  // LRU-back voxels that the batch evicting around them also touched (see hashmap.hip)
+    unsigned long long n_lru_recreated;    // ... of those, the ones the reference's point-by-point order drops and re-creates: done here too (lru_exact_*)
+    unsigned long long n_lru_inexact;      // batches in which that order could not be followed (a young voxel at the back, more voxels than the quota before the batch, a full scratch list)
     int free_top[24];                // recycled pool regions by size class (floor(log2(capacity)))
     int free_in_top[24];             // regions freed by the grow kernel of the current batch (folded into free_top by lru_evict_kernel)
     // push_back order inside a voxel (ivox3d_node.hpp:87-90): every inserted point gets the running count of points offered to AddPoints before it
@@ -169,6 +171,9 @@ struct MapRef {
     unsigned long long log_mask;
     uint32_t* free_items;
     uint32_t* free_in;
+    unsigned long long* first_touch; // per slot: stamp_base + (index mask - index of the FIRST point of the batch in the voxel), atomicMax (null: the exact LRU order is off)
+    uint32_t* lru_g;                 // scratch: the batch's voxel-creating points in point order
+    uint32_t* lru_rec;               // scratch: slots of the voxels the batch drops and re-creates
     uint32_t free_cap;
     uint32_t lru_capacity;
     float lru_max_distance;
@@ -204,6 +209,8 @@ struct LruEntry {  // one entry of the touch log: the voxel in `slot` was last t
     uint32_t slot, pad;
 };
 constexpr int kStampIdxBits = 26;  // stamp = batch number << 26 | index of the point inside the batch
+constexpr unsigned long long kStampIdxMask = (1ull << kStampIdxBits) - 1ull;
+constexpr uint32_t kLruRecCap = 4096;  // voxels one batch may drop and re-create (more: the batch is counted in n_lru_inexact and handled as before)
 
 struct lio_map {
     // LRU eviction (off while lru_capacity == 0)
@@ -215,6 +222,8 @@ struct lio_map {
     uint64_t lru_log_cap;        // power of two
     uint32_t* free_items;        // [24][free_cap] recycled region offsets
     uint32_t* free_in;           // [24][free_cap] regions outgrown during the current batch
+    unsigned long long* first_touch;  // per slot: the FIRST point of the current batch in the voxel (see MapRef); lru_g / lru_rec: scratch of lru_evict_kernel's exact pass
+    uint32_t *lru_g, *lru_rec;
     uint32_t free_cap;
     uint64_t tomb_bound;         // evictions possible since the last rebuild (host-side upper bound)
     lio::Slot* table2;           // second set of per-slot arrays: target of a table rebuild, then swapped

@@ -21,7 +21,7 @@ MAIN_FIRST_SCAN, MAIN_SEEDED, MAIN_SKIPPED, MAIN_UPDATED, MAIN_IMU_INIT, MAIN_ID
 SYMBOLS = [
     "lio_last_warning",
     "lio_last_error", "lio_device_count", "lio_map_bytes",
-    "lio_map_create", "lio_map_destroy", "lio_map_set_lru", "lio_map_lru_stats", "lio_map_set_tie_mode", "lio_map_tie_stats", "lio_map_clear", "lio_map_pool_stats", "lio_map_set_stencil", "lio_map_insert", "lio_map_insert_device", "lio_map_stats",
+    "lio_map_create", "lio_map_destroy", "lio_map_set_lru", "lio_map_lru_stats", "lio_map_lru_exact_stats", "lio_map_set_tie_mode", "lio_map_tie_stats", "lio_map_clear", "lio_map_pool_stats", "lio_map_set_stencil", "lio_map_insert", "lio_map_insert_device", "lio_map_stats",
     "lio_abi_version", "lio_pinned_alloc", "lio_pinned_free",
     "lio_map_dump", "lio_map_knn", "lio_map_knn_candidates", "lio_map_knn_touched", "lio_map_knn_unique",
     "lio_scan_create", "lio_scan_destroy", "lio_scan_reset", "lio_scan_upload", "lio_scan_set_device", "lio_scan_undistort_delta", "lio_scan_undistort_poses", "lio_scan_download_raw", "lio_scan_voxel_downsample", "lio_scan_voxel_downsample_batch", "lio_scan_set_ds",
@@ -143,6 +143,7 @@ def lib():
     sig("lio_map_dump", C.c_int64, vp, f32p, u64)
     sig("lio_map_set_lru", cint, vp, u64, dbl)
     sig("lio_map_lru_stats", cint, vp, C.POINTER(u64), C.POINTER(u64))
+    sig("lio_map_lru_exact_stats", cint, vp, C.POINTER(u64), C.POINTER(u64))
     sig("lio_map_clear", cint, vp)
     sig("lio_map_set_tie_mode", cint, vp, cint)
     sig("lio_map_tie_stats", cint, vp, C.POINTER(u64), C.POINTER(u64))

@@ -62,6 +62,12 @@ class Map:
         check(lib().lio_map_lru_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def lru_exact_stats(self):
+        """(voxels dropped and re-created inside a batch as the reference's point-by-point order does, batches in which that order was not followed)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().lio_map_lru_exact_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def clear(self):
         """back to an empty map (memory kept)"""
         check(lib().lio_map_clear(self.h), "map clear")

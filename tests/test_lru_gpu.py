@@ -51,9 +51,52 @@ def test_lru_eviction_matches_oracle(oracle_mod, scene, max_voxels):
     assert evicted > 1000  # `interleaved` is an upper bound (voxels near the back that the batch touched in time count too)
 
 
-def test_revisiting_the_back_of_the_list_is_counted(oracle_mod, scene):
-    """A batch that touches the very voxels it is evicting around (tiny max_distance, overlapping windows, a return to the start):
-    the reference's point-by-point order drops and re-creates some of them, the device keeps their points and counts them"""
+def test_revisiting_the_back_of_the_list_follows_the_references_point_by_point_order(oracle_mod, scene):
+    """A batch that touches the very voxels it is evicting around (overlapping windows, returns to places left a few batches ago, a quota of a few
+    hundred voxels): the reference handles a batch point by point (ivox3d.h:231-256), so a voxel at the back of the list whose first point of the batch
+    comes after its turn to go is DROPPED with all it held and created again from the batch's points alone.  The device replays the pops of the batch
+    in order (csrc/hashmap.hip lru_exact_*) and must end every batch with the oracle's map -- the same voxels, the same points, the same neighbours
+    (the oracle's list is the reference's statements, pinned to the compiled ivox3d.h in tests/test_oracle_vs_ref.py).  Until round 6 such voxels kept
+    their old points here and were only counted."""
+    from lsd_amd import lio
+
+    rng = np.random.default_rng(8)
+    pts = scene.sample_surface(300_000, seed=11, sigma=0.01)
+    pts = pts[(np.abs(pts[:, 1]) < 25) & (pts[:, 2] < 6)]
+    n_recreated = 0
+    # three places visited in turn (the voxels of the place returned to are the back of the list), places at random, a widening zig-zag; the quota
+    # holds two to three batches' footprints (~1 900 voxels each), everything is old enough to go
+    for cap, maxd, course in ((4000, 2.0, [-30.0, 0.0, 30.0] * 6), (5000, 0.5, [float(c) for c in rng.uniform(-30, 30, 30)]),
+                              (3500, 1.0, [(-1) ** k * (5.0 + 0.7 * k) for k in range(30)])):
+        m = lio.Map(resolution=0.5, stencil=19, max_points=600_000, max_voxels=40000)
+        m.set_lru(cap, maxd)
+        o = oracle_mod.IVox(res=0.5, stencil=19, capacity=cap, max_distance=maxd)
+        travel = 0.0
+        for b, cx in enumerate(course):
+            travel += 4.0
+            batch = _batch(pts, cx, rng, 2500)
+            m.add(batch, travel=travel)
+            o.add(batch, travel=travel)
+            npts, nvox = m.stats()
+            assert (nvox, npts) == (o.num_voxels, o.num_points), (cap, b, nvox, npts, o.num_voxels, o.num_points)
+            if b % 3 == 2 or b == len(course) - 1:
+                assert np.array_equal(_rows(m.dump()), _rows(o.dump())), (cap, b)
+        q = _batch(pts, course[-1], rng, 300, half=12.0) + rng.normal(0, 0.05, (300, 4)).astype(np.float32)
+        nn_g, cnt_g = m.knn(q)
+        nn_o, cnt_o, _ = o.knn(q)
+        assert np.array_equal(cnt_g, cnt_o) and np.array_equal(nn_g.view(np.uint32), nn_o.view(np.uint32))
+        evicted, interleaved = m.lru_stats()
+        recreated, not_followed = m.lru_exact_stats()
+        assert evicted > 500 and not_followed == 0, (cap, evicted, not_followed)
+        assert recreated <= interleaved  # (the old counter is an upper bound: voxels touched in time are in it too)
+        n_recreated += recreated
+    assert n_recreated > 5000, "the courses did not make the reference drop and re-create voxels: the test would pass without the replay"
+
+
+def test_a_quota_below_one_batchs_footprint_is_counted_not_followed(scene):
+    """The replay follows the pops through the list as it was BEFORE the batch.  With a quota smaller than what one batch touches the list runs out:
+    the reference goes on dropping voxels the batch itself moved to the front a moment ago -- not followed (lio_map_lru_exact_stats counts the batch),
+    the batch is handled as a whole as it was up to round 5: its own voxels are never dropped, the map stays bounded and consistent."""
     from lsd_amd import lio
 
     rng = np.random.default_rng(8)
@@ -67,7 +110,8 @@ def test_revisiting_the_back_of_the_list_is_counted(oracle_mod, scene):
         m.add(_batch(pts, cx, rng, 2500), travel=travel)
     npts, nvox = m.stats()
     evicted, interleaved = m.lru_stats()
-    assert evicted > 1000 and interleaved > 0 and nvox <= 1500 + 2500
+    recreated, not_followed = m.lru_exact_stats()
+    assert evicted > 1000 and interleaved > 0 and nvox <= 1500 + 2500 and not_followed > 10
     assert len(m.dump()) == npts
 
 
