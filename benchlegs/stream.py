@@ -328,6 +328,7 @@ def stream_run(args, torch, local_rank):
         err = float(np.linalg.norm(s[0:3] - R0.T @ (tr.pos(k_done * 0.1) - p0)))
     map_points, map_voxels = e.map.stats()
     evicted = e.map.lru_stats()[0]
+    recreated, not_followed = e.map.lru_exact_stats()
     rows = np.array(rows, dtype=np.float64)
     tot = float(np.sum(t_main) + np.sum(t_enq) + np.sum(t_fl))  # enqueue + fastlio_main + the wait for its map_incremental
     curve = []
@@ -419,6 +420,7 @@ def stream_run(args, torch, local_rank):
                       "n_ds_avg": round(float(rows[:, 0].mean()), 1), "passes_avg": round(float(rows[:, 1].mean()), 2),
                       "knn_passes_avg": round(float(rows[:, 2].mean()), 2), "points_added_per_scan": round(float(rows[:, 3].mean()), 1),
                       "map_points_end": int(map_points), "map_voxels_end": int(map_voxels), "voxels_evicted": int(evicted),
+                      "voxels_dropped_and_recreated_inside_a_batch": int(recreated), "batches_in_which_the_lru_order_was_not_followed": int(not_followed),
                       "main_ms_median": round(1e3 * float(np.median(t_main)), 4), "enqueue_ms_median": round(1e3 * float(np.median(t_enq)), 4),
                       "main_ms_p99": round(1e3 * float(np.percentile(t_main, 99)), 4), "main_ms_median_by_map_size_Mpts": curve,
                       "insert_wait_ms_median": round(1e3 * float(np.median(t_fl)), 4),

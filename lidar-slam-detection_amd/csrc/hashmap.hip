@@ -269,9 +269,9 @@ __device__ __forceinline__ void map_insert_write_body(Slot* table, const uint32_
 //     point-by-point process performs is order independent, E = clamp(n_voxels - capacity, 0, n_points_in_batch), cut short
 //     at the first candidate younger than max_distance (the reference then keeps testing that same back voxel).
 // Evicted slots become tombstones (probes walk on), their pool regions go to per-size free lists that the grow kernel
-// pops; the table is rebuilt into its twin when tombstones pile up (map_rebuild).  A victim touched again later in the
-// SAME batch would be re-created by the reference; that needs capacity < one scan's footprint and is reported as an
-// error instead (err bit 4).
+// pops; the table is rebuilt into its twin when tombstones pile up (map_rebuild).  A voxel near the back that the SAME
+// batch touches after its turn to go is dropped and re-created by the reference's point-by-point order: lru_exact_* below
+// replays the batch's pops in order and does the same (round 6; counted only until then).
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lru_append_body(const uint32_t* __restrict__ slot_of_point, const unsigned long long* __restrict__ touch,
                                                           unsigned long long n_host, const uint32_t* __restrict__ n_dev, unsigned long long stamp_base,
@@ -362,34 +362,60 @@ __device__ __forceinline__ uint32_t lru_exact_replay(const Slot* table, const fl
                                                      const unsigned long long* __restrict__ prev_touch, unsigned long long stamp_base,
                                                      const LruEntry* __restrict__ log, unsigned long long log_mask, unsigned long long n_add, uint32_t capacity,
                                                      float travel, float max_distance, MapDev* md, const LruExact& ex, uint32_t* w_pops) {
-    __shared__ uint32_t xw[4];
+    __shared__ uint32_t xw[4], xsp[4];
+    constexpr uint32_t kGLds = 4096;    // the first creation points are kept in LDS as well: the replaying lane reads one per pop, and a global load is a microsecond to it
+    __shared__ uint32_t x_g[kGLds];
     __shared__ uint32_t x_ng, x_gi, x_rn, x_recn, x_wp, x_excess, x_deficit;
     __shared__ long long x_t;
     __shared__ int x_state, x_have;  // state: 0 replaying, 1 done, 2 given up
     __shared__ uint32_t x_rq[kLruRq];   // pending re-creation points: a binary min-heap, the next one at [0]
-    __shared__ uint8_t x_cls[256];      // 0 stale, 1 untouched, 2 touched by this batch; bit 7: younger than max_distance
-    __shared__ uint32_t x_f[256], x_slot[256];
+    constexpr int kChunk = 1024;        // list entries staged per turn: four per lane, their loads requested together
+    __shared__ uint8_t x_cls[kChunk];   // 0 stale, 1 untouched, 2 touched by this batch; bit 7: younger than max_distance
+    __shared__ uint32_t x_f[kChunk], x_slot[kChunk];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // (1) the batch's voxel-creating points in point order: point i creates a voxel iff the voxel had no stamp before this batch and i is its first point
+    // (1) the batch's voxel-creating points in point order: point i creates a voxel iff the voxel had no stamp before this batch and i is its first point.
+    // Four consecutive points per lane, their loads requested together (this kernel is one workgroup: it pays for every dependent round trip in full).
     if (tid == 0) x_ng = 0;
     __syncthreads();
-    for (unsigned long long base = 0; base < n_add; base += 256) {
-        const unsigned long long i = base + tid;
-        bool is_g = false;
-        if (i < n_add) {
-            const uint32_t sp = ex.slot_of_point[i];
-            if (sp != kNoIdx) {
-                const uint32_t h = sp & 0x7FFFFFFFu;
-                const unsigned long long ft = ex.first_touch[h];
-                is_g = prev_touch[h] == 0ull && ft >= stamp_base && (kStampIdxMask - (ft - stamp_base)) == i;
-            }
+    constexpr int kI = 4;
+    for (unsigned long long base = 0; base < n_add; base += 256ull * kI) {
+        uint32_t hs[kI];
+        bool ok[kI], fl[kI];
+#pragma unroll
+        for (int j = 0; j < kI; j++) {
+            const unsigned long long i = base + (unsigned long long)tid * kI + j;
+            const uint32_t sp = i < n_add ? ex.slot_of_point[i] : kNoIdx;
+            ok[j] = sp != kNoIdx;
+            hs[j] = ok[j] ? (sp & 0x7FFFFFFFu) : 0u;
         }
-        const unsigned long long m = __ballot(is_g);
-        if (lane == 0) xw[wave] = (uint32_t)__popcll(m);
+        unsigned long long ft[kI], pv[kI];
+#pragma unroll
+        for (int j = 0; j < kI; j++) { ft[j] = ex.first_touch[hs[j]]; pv[j] = prev_touch[hs[j]]; }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < kI; j++) {
+            const unsigned long long i = base + (unsigned long long)tid * kI + j;
+            fl[j] = ok[j] && pv[j] == 0ull && ft[j] >= stamp_base && (kStampIdxMask - (ft[j] - stamp_base)) == i;
+            mine += fl[j] ? 1u : 0u;
+        }
+        uint32_t inc = mine;  // inclusive scan of the per-lane counts: wave shuffles, then the four wave totals
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) xw[wave] = inc;
         __syncthreads();
-        uint32_t off = x_ng + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        uint32_t off = x_ng + inc - mine;
         for (int w = 0; w < wave; w++) off += xw[w];
-        if (is_g) ex.g[off] = (uint32_t)i;
+#pragma unroll
+        for (int j = 0; j < kI; j++)
+            if (fl[j]) {
+                const uint32_t gv = (uint32_t)(base + (unsigned long long)tid * kI + j);
+                ex.g[off] = gv;
+                if (off < kGLds) x_g[off] = gv;
+                off++;
+            }
         __syncthreads();
         if (tid == 0) x_ng += (xw[0] + xw[1]) + (xw[2] + xw[3]);
         __syncthreads();
@@ -413,40 +439,89 @@ __device__ __forceinline__ uint32_t lru_exact_replay(const Slot* table, const fl
     // (ivox3d.h:251): at the creation that takes it over the capacity, and at every following point until it is back.
     const unsigned long long limit = md->log_head_prev;
     unsigned long long tail = md->log_tail;
-    for (; x_state == 0 && tail < limit; tail += 256) {
-        const unsigned long long idx = tail + tid;
-        uint8_t cls = 0;
-        uint32_t f = 0xFFFFFFFFu, slot = 0;
-        if (idx < limit) {
-            const LruEntry e = log[idx & log_mask];
-            if (e.stamp != 0) {
-                slot = e.slot;
-                const unsigned long long now = touch[slot];
-                if (now == e.stamp) cls = 1;
-                else if (now >= stamp_base && prev_touch[slot] == e.stamp) {
-                    cls = 2;
-                    const unsigned long long ft = ex.first_touch[slot];
-                    f = (uint32_t)(kStampIdxMask - (ft - stamp_base));
-                }
-                if (cls && !((travel - created[slot]) > max_distance)) cls |= 0x80;
-            }
+    for (; x_state == 0 && tail < limit; tail += kChunk) {
+        LruEntry en[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long idx = tail + (unsigned long long)tid * 4ull + j;  // (four consecutive entries per lane: list order = lane order)
+            en[j].stamp = 0; en[j].slot = 0; en[j].pad = 0;
+            if (idx < limit) en[j] = log[idx & log_mask];
         }
-        x_cls[tid] = cls;
-        x_f[tid] = f;
-        x_slot[tid] = slot;
+        unsigned long long nowv[4], pvv[4], ftv[4];
+        float crv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {  // (unconditional: slot 0 for an empty entry -- four words per entry in flight instead of a chain of dependent loads)
+            nowv[j] = touch[en[j].slot];
+            pvv[j] = prev_touch[en[j].slot];
+            ftv[j] = ex.first_touch[en[j].slot];
+            crv[j] = created[en[j].slot];
+        }
+        // the entries that are a voxel's place in the list -- a few among thousands of stale ones (a voxel in view leaves an entry behind with every
+        // batch) -- are compacted in list order: the one lane that replays the pops walks over those alone
+        uint8_t cl[4];
+        uint32_t fv[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            cl[j] = 0;
+            fv[j] = 0xFFFFFFFFu;
+            if (en[j].stamp != 0) {
+                if (nowv[j] == en[j].stamp) cl[j] = 1;
+                else if (nowv[j] >= stamp_base && pvv[j] == en[j].stamp) {
+                    cl[j] = 2;
+                    fv[j] = (uint32_t)(kStampIdxMask - (ftv[j] - stamp_base));
+                }
+                if (cl[j] && !((travel - crv[j]) > max_distance)) cl[j] |= 0x80;
+            }
+            mine += cl[j] ? 1u : 0u;
+        }
+        // (anything but an untouched voxel old enough to go -- the usual content of the list's back -- makes the chunk one for the lane-by-lane replay)
+        const bool special = (cl[0] > 1) | (cl[1] > 1) | (cl[2] > 1) | (cl[3] > 1);
+        const unsigned long long spm = __ballot(special);
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) xw[wave] = inc;
+        if (lane == 0) xsp[wave] = spm != 0ull ? 1u : 0u;
+        __syncthreads();
+        uint32_t at = inc - mine;
+        for (int w = 0; w < wave; w++) at += xw[w];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (cl[j]) {
+                x_cls[at] = cl[j];
+                x_f[at] = fv[j];
+                x_slot[at] = en[j].slot;
+                at++;
+            }
         __syncthreads();
         if (tid == 0) {
-            const uint32_t len = (uint32_t)(limit - tail < 256ull ? limit - tail : 256ull);
+            const uint32_t len = (xw[0] + xw[1]) + (xw[2] + xw[3]);  // the chunk's entries that count
             uint32_t gi = x_gi, rn = x_rn, recn = x_recn, wp = x_wp, excess = x_excess, deficit = x_deficit;
             long long t = x_t;
             int state = 0, have = x_have;
             // the next voxel-creating point (a new voxel's first point, or the first point of a voxel dropped earlier in the batch), 2^32 - 1 when none is left
+            // a chunk of untouched voxels old enough to go, the map exactly at its capacity, nothing pending: every creation pops the next of them -- no
+            // decision to replay (the usual case on a drive that does not come back: ~1 000 pops per batch, which the one lane would take ~0.1 us each)
+            if (!((xsp[0] | xsp[1]) | (xsp[2] | xsp[3])) && excess == 0 && deficit == 0 && rn == 0 && !have) {
+                const uint32_t left = n_g - gi, take = len < left ? len : left;
+                if (take) {
+                    gi += take;
+                    wp += take;
+                    t = (long long)(gi - 1 < kGLds ? x_g[gi - 1] : ex.g[gi - 1]);
+                }
+                if (gi >= n_g) state = 1;
+                x_gi = gi; x_wp = wp; x_t = t;
+                if (state) x_state = state;
+            } else {
             auto next_creation = [&]() -> uint32_t {
-                const uint32_t tg = gi < n_g ? ex.g[gi] : 0xFFFFFFFFu, tr = rn > 0 ? x_rq[0] : 0xFFFFFFFFu;
+                const uint32_t tg = gi < n_g ? (gi < kGLds ? x_g[gi] : ex.g[gi]) : 0xFFFFFFFFu, tr = rn > 0 ? x_rq[0] : 0xFFFFFFFFu;
                 return tg < tr ? tg : tr;
             };
             auto take_creation = [&]() {
-                const uint32_t tg = gi < n_g ? ex.g[gi] : 0xFFFFFFFFu, tr = rn > 0 ? x_rq[0] : 0xFFFFFFFFu;
+                const uint32_t tg = gi < n_g ? (gi < kGLds ? x_g[gi] : ex.g[gi]) : 0xFFFFFFFFu, tr = rn > 0 ? x_rq[0] : 0xFFFFFFFFu;
                 if (tg < tr) {
                     gi++;
                 } else {  // pop the heap's root: the last leaf sinks from the top
@@ -466,7 +541,6 @@ __device__ __forceinline__ uint32_t lru_exact_replay(const Slot* table, const fl
             };
             for (uint32_t k = 0; k < len && state == 0; k++) {
                 const uint8_t c = x_cls[k];
-                if ((c & 0x7F) == 0) continue;  // a stale entry: the voxel was touched, or went, long ago
                 for (;;) {
                     if (!have) {  // the point after which the next pop is attempted
                         if (excess == 0) {
@@ -504,11 +578,15 @@ __device__ __forceinline__ uint32_t lru_exact_replay(const Slot* table, const fl
                     } else {
                         wp++;
                     }
+                    // nothing left that could make the map exceed its capacity again: the replay ends here (not at the next entry that counts, which
+                    // may lie thousands of stale entries further on)
+                    if (excess == 0 && next_creation() == 0xFFFFFFFFu) state = 1;
                     break;
                 }
             }
             x_gi = gi; x_rn = rn; x_recn = recn; x_wp = wp; x_excess = excess; x_deficit = deficit; x_t = t; x_have = have;
             if (state) x_state = state;
+            }
         }
         __syncthreads();
     }
