@@ -741,17 +741,19 @@ __device__ __forceinline__ void lru_evict_body(Slot* table, uint32_t* __restrict
         const uint32_t n_ev = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
         unsigned long long next = tail + 256;
         if (next > limit) next = limit;
-        if (fy != ~0ull) {
-            next = fy;
-            stop = true;
-        } else if (done + n_ev >= want_s) {
-            // the last evicted entry is the (want)-th live one of the chunk: everything up to it is consumed
+        if (done + n_ev >= want_s) {
+            // the quota is used up: the last evicted entry is the (want)-th live one of the chunk, everything up to it is consumed -- and nothing
+            // beyond it, a young voxel further on or not (until round 6 a young voxel anywhere in the chunk moved the tail to ITS place: live voxels
+            // between the last eviction and it fell off the list without being dropped, and the next batch started evicting behind them)
             __shared__ unsigned long long last_s;
             if (tid == 0) last_s = 0;
             __syncthreads();
             if (evict) atomicMax(&last_s, idx + 1);
             __syncthreads();
-            next = last_s > tail ? last_s : next;
+            next = last_s > tail ? last_s : tail;
+            stop = true;
+        } else if (fy != ~0ull) {
+            next = fy;
             stop = true;
         }
         done += n_ev;

@@ -213,3 +213,46 @@ def test_engine_map_incremental_lru_order_matches_oracle(oracle_mod, scene):
     print("evicted", a[1], "interleaved", a[2], "map sizes", a[0][-1])
     assert a[1] > 500
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3])  # run-to-run identical
+
+
+def test_random_courses_quotas_and_ages_equal_the_sequential_list(oracle_mod, scene):
+    """Forty-eight randomly drawn regimes -- quota 800 ... 6000 voxels, max_distance 0 ... 40 m, batches of 300 ... 2500 points over windows of 6 or 16 m,
+    0.5 or 4 m of travel per batch, places at random / a widening zig-zag / three places in turn: after EVERY batch that the device reports it followed
+    in the reference's point-by-point order (lio_map_lru_exact_stats) its voxel and point counts equal the oracle's sequential list, every fourth batch
+    and at the end the whole content.  (The same sweep, three times as long, in tools/experiments/lru_stress.py found the walk's resume point wrong
+    when the quota ended in a chunk that also held a young voxel: two live voxels fell off the list without being dropped.)"""
+    from lsd_amd import lio
+
+    pts = scene.sample_surface(300_000, seed=11, sigma=0.01)
+    pts = pts[(np.abs(pts[:, 1]) < 25) & (pts[:, 2] < 6)]
+    followed = cut_short = recreated = 0
+    for c in range(48):
+        rng = np.random.default_rng(1000 + c)
+        cap, maxd = int(rng.choice([800, 1500, 2500, 4000, 6000])), float(rng.choice([0.0, 0.5, 3.0, 10.0, 40.0]))
+        npts, half, step, kind = int(rng.choice([300, 1200, 2500])), float(rng.choice([3.0, 8.0])), float(rng.choice([0.5, 4.0])), int(rng.integers(0, 3))
+        regime = dict(c=c, cap=cap, maxd=maxd, npts=npts, half=half, step=step, kind=kind)
+        m = lio.Map(resolution=0.5, stencil=19, max_points=600_000, max_voxels=40000)
+        m.set_lru(cap, maxd)
+        o = oracle_mod.IVox(res=0.5, stencil=19, capacity=cap, max_distance=maxd)
+        travel, whole = 0.0, True
+        for b in range(20):
+            cx = [rng.uniform(-30, 30), (-1) ** b * (3.0 + 0.9 * b), [-25.0, 0.0, 25.0][b % 3]][kind]
+            travel += step
+            sel = np.flatnonzero(np.abs(pts[:, 0] - cx) < half)
+            batch = pts[rng.choice(sel, size=min(npts, len(sel)), replace=False)]
+            m.add(batch, travel=travel)
+            o.add(batch, travel=travel)
+            if m.lru_exact_stats()[1]:  # the quota is below what one batch touches (or the like): counted, the course ends here
+                cut_short += 1
+                whole = False
+                break
+            followed += 1
+            npo, nvo = m.stats()
+            assert (nvo, npo) == (o.num_voxels, o.num_points), (regime, b)
+            if b % 4 == 3:
+                assert np.array_equal(_rows(m.dump()), _rows(o.dump())), (regime, b)
+        if whole:
+            assert np.array_equal(_rows(m.dump()), _rows(o.dump())), regime
+        recreated += m.lru_exact_stats()[0]
+    assert followed > 600 and recreated > 5000, (followed, cut_short, recreated)
+
