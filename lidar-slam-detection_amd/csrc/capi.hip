@@ -245,6 +245,7 @@ int map_clear(lio_map* m) {
         LIO_HIP_TRY(hipMemsetAsync(m->touch, 0, (size_t)m->table_cap * 8, st));
         LIO_HIP_TRY(hipMemsetAsync(m->prev_touch, 0, (size_t)m->table_cap * 8, st));
         LIO_HIP_TRY(hipMemsetAsync(m->lru_log, 0, (size_t)m->lru_log_cap * sizeof(LruEntry), st));
+        if (m->first_touch) LIO_HIP_TRY(hipMemsetAsync(m->first_touch, 0, (size_t)m->table_cap * 8, st));  // (the batch numbers start over: an old stamp would beat every new one)
         m->tomb_bound = 0;
     }
     m->n_batches = 0;

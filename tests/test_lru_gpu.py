@@ -256,3 +256,31 @@ def test_random_courses_quotas_and_ages_equal_the_sequential_list(oracle_mod, sc
         recreated += m.lru_exact_stats()[0]
     assert followed > 600 and recreated > 5000, (followed, cut_short, recreated)
 
+
+def test_the_list_starts_over_after_lio_map_clear(oracle_mod, scene):
+    """lio_map_clear restarts the batch numbers: every per-slot stamp of the LRU bookkeeping -- last touch, the touch before, the FIRST point of a batch in
+    the voxel -- has to start over with them (a stale first-point stamp of a higher batch number would beat every new one, and the replay of the next
+    batches' pops would re-create the wrong voxels)."""
+    from lsd_amd import lio
+
+    rng = np.random.default_rng(21)
+    pts = scene.sample_surface(300_000, seed=11, sigma=0.01)
+    pts = pts[(np.abs(pts[:, 1]) < 25) & (pts[:, 2] < 6)]
+    m = lio.Map(resolution=0.5, stencil=19, max_points=600_000, max_voxels=40000)
+    m.set_lru(3500, 1.0)
+    recreated = []
+    for lap in range(2):
+        o = oracle_mod.IVox(res=0.5, stencil=19, capacity=3500, max_distance=1.0)
+        travel = 0.0
+        for b in range(14 if lap == 0 else 10):
+            travel += 4.0
+            batch = _batch(pts, (-1) ** b * (5.0 + 0.7 * b), rng, 2500)
+            m.add(batch, travel=travel)
+            o.add(batch, travel=travel)
+            npts, nvox = m.stats()
+            assert (nvox, npts) == (o.num_voxels, o.num_points), (lap, b)
+        assert np.array_equal(_rows(m.dump()), _rows(o.dump())), lap
+        recreated.append(m.lru_exact_stats())
+        m.clear()
+    assert recreated[0][0] > 1000 and recreated[1][0] > 500 and recreated[0][1] == 0 and recreated[1][1] == 0, recreated
+
