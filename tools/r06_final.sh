@@ -35,6 +35,7 @@ T0=$(date +%s); timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.jso
 cp $R/bench_full.json $O/bench_full.json
 head -c 1200 $O/bench.json; echo
 timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu.log
+timeout 600 python tools/experiments/lru_stress.py 160 > $O/lru_stress.txt 2>&1; echo "lru stress rc $?"; tail -2 $O/lru_stress.txt
 python - <<PY
 import csv, os
 f = "$O/kernel_stats_one_round_in_flight.csv"
