@@ -94,6 +94,30 @@ def test_ivox_lru_eviction_bookkeeping(oracle_mod):
     assert np.array_equal(refmod.canonical(nn_r, cnt_r, q)[..., :3].view(np.uint32), nn_o[..., :3].view(np.uint32))
 
 
+def test_ivox_lru_revisits_drop_and_recreate_like_the_reference(oracle_mod):
+    """The point-by-point order of AddPoints (ivox3d.h:231-256) where it shows: a course that keeps coming back, so that voxels at the back of the list are
+    touched by the very batch that is evicting around them -- the compiled ivox3d.h drops such a voxel with all it held and re-creates it from the
+    batch's points; the oracle's list (the statements the HIP map is held to, tests/test_lru_gpu.py) must do the same: voxel counts after every batch,
+    and the neighbours of queries all over the visited ground -- which are the voxels' CONTENT -- every third batch."""
+    rng = np.random.default_rng(4)
+    for cap, maxd, course in ((900, 1.0, [(-1) ** k * (2.0 + 0.6 * k) for k in range(30)]), (1200, 3.0, [-12.0, 0.0, 12.0] * 8), (500, 0.0, list(rng.uniform(-10, 10, 24)))):
+        r = refmod.IVox(stencil=19, capacity=cap, max_distance=maxd)
+        o = oracle_mod.IVox(stencil=19, capacity=cap, max_distance=maxd)
+        travel = 0.0
+        for b, cx in enumerate(course):
+            travel += 1.5
+            pts = np.concatenate([np.array([cx, 0.0, 0.0]) + rng.uniform(-4, 4, (500, 3)) * [1, 1, 0.1], rng.uniform(0, 255, (500, 1))], 1).astype(np.float32)
+            r.add(pts, travel)
+            o.add(pts, travel)
+            assert r.num_voxels == o.num_voxels, (cap, b)
+            if b % 3 == 2:
+                q = np.concatenate([np.array([[cx, 0.0, 0.0]]) + rng.uniform(-8, 8, (300, 3)) * [1, 1, 0.05], np.zeros((300, 1))], 1).astype(np.float32)
+                nn_r, cnt_r = r.knn(q)
+                nn_o, cnt_o, _ = o.knn(q)
+                assert np.array_equal(cnt_r, cnt_o), (cap, b)
+                assert np.array_equal(refmod.canonical(nn_r, cnt_r, q).view(np.uint32), nn_o.view(np.uint32)), (cap, b)
+
+
 def test_calc_dist(oracle_mod):
     rng = np.random.default_rng(3)
     for _ in range(200):
