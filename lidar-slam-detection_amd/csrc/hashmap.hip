@@ -505,7 +505,13 @@ __device__ __forceinline__ uint32_t lru_exact_replay(const Slot* table, const fl
             // the next voxel-creating point (a new voxel's first point, or the first point of a voxel dropped earlier in the batch), 2^32 - 1 when none is left
             // a chunk of untouched voxels old enough to go, the map exactly at its capacity, nothing pending: every creation pops the next of them -- no
             // decision to replay (the usual case on a drive that does not come back: ~1 000 pops per batch, which the one lane would take ~0.1 us each)
-            if (!((xsp[0] | xsp[1]) | (xsp[2] | xsp[3])) && excess == 0 && deficit == 0 && rn == 0 && !have) {
+            if (!((xsp[0] | xsp[1]) | (xsp[2] | xsp[3])) && excess == 0 && rn == 0 && !have) {
+                if (deficit) {  // (the creations that fill the map up to its capacity pop nothing)
+                    const uint32_t fill = deficit < n_g - gi ? deficit : n_g - gi;
+                    gi += fill;
+                    deficit -= fill;
+                    x_deficit = deficit;
+                }
                 const uint32_t left = n_g - gi, take = len < left ? len : left;
                 if (take) {
                     gi += take;
