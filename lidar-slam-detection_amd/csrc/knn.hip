@@ -519,6 +519,13 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
                     drop_tie |= in && !take && kd == d4;  // a candidate as far as this lane's fifth is not kept: see the merge
                     if (__ballot(take)) {
                         ins |= take;
+                        // ... nor is the entry this insertion pushes OUT of a full list, if it is exactly as far as the entry that becomes the lane's fifth
+                        // (d3 == d4 before: two equally distant candidates, the later one leaves) -- the other way a tie at the fifth place can go unseen.
+                        // (Remembering the last value pushed out in a register and comparing once after the sweep is one instruction less here and two
+                        // registers spilled at seven waves per SIMD.)
+                        // (until round 6 only candidates refused on arrival were remembered; found by tools/experiments/lru_tie_stress.py: one query in
+                        // ~3 000 on sparse lattice stencils kept the lower pool index instead of the reference's choice)
+                        drop_tie |= take && d3 == d4 && d4 != 0xFFFFFFFFu;
                         const uint32_t id = ptr4[u] + i0;
                         const bool c0 = kd < d0, c1 = kd < d1, c2 = kd < dd2, c3 = kd < d3;
                         i4d = c3 ? i3d : (take ? id : i4d);
