@@ -18,6 +18,10 @@ def dry_run(args, dist, world, rank, local_rank):
         info["sub_maps"] = plan["mine"]
         info["key_frames"] = len(plan["frames"])
         info["first_guess_digest"] = float(np.sum(plan["frames"][0]["guess"]))
+        # the voxel-grid chain of a round runs once per scan, on the rank that owns the slot (lio_batch_create_joint over a communicator: csrc/batch.hip)
+        slots = min(args.slots, 32)
+        per = (slots + world - 1) // world
+        info["downsamples_slots"] = [min(slots, rank * per), min(slots, rank * per + per)]
     else:
         info["scan_seeds"] = [args.seed + 100000 * rank, args.seed + 100000 * rank + args.scan_pool - 1]  # first .. last: every rank registers its own scans against its replica
     uid_ok = None
