@@ -40,6 +40,9 @@ namespace lio {
 #ifndef LIO_KNN_PRUNE
 #define LIO_KNN_PRUNE 1  // distance-ordered sweep with exact pruning of stencil voxels that cannot hold one of the five nearest
 #endif
+#ifndef LIO_KNN_STAT
+#define LIO_KNN_STAT 1  // 0: the timed kernels do not keep the candidate statistic (MapDev::knn_cand word 0; the counting variant always does): 6.82 -> 6.75 us per scan and search, not taken -- bench.py's legs read the statistic of their timed launches
+#endif
 #ifndef LIO_KNN_WAVES_BATCH
 #define LIO_KNN_WAVES_BATCH 7  // the batched / sequence kernels: 72 registers, nothing spills (round 6: the statistic in a scalar register, two cold values formed where they are used)
 #endif
@@ -423,7 +426,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
         const uint32_t limit = 0xFFFFFFFFu;  // (an upper bound of the fifth-nearest distance known before the probe: none)
         if constexpr (kPrune) total = probe_stencil_bucketed<KM>(table, mask, st, active, pw, res, kx, ky, kz, gl, lane, gmask, g, nhit, n0, n01, limit);
         else total = probe_stencil<KM>(table, mask, st, active, kx, ky, kz, gl, lane, gmask, g, nhit);
-        {   // the candidate statistic, summed over the wave at once and kept in LDS: a per-lane accumulator across the query loop (and its
+        if constexpr (LIO_KNN_STAT || COUNT) {   // the candidate statistic, summed over the wave at once and kept in LDS: a per-lane accumulator across the query loop (and its
             // 64-bit reduction behind it) was the register that stood between this kernel and seven waves per SIMD without a spill
             const uint32_t gs = group_sum32(total);
             const uint32_t ws = (uint32_t)__builtin_amdgcn_readlane((int)gs, 0) + (uint32_t)__builtin_amdgcn_readlane((int)gs, 16) +
@@ -585,7 +588,7 @@ __device__ __forceinline__ void knn_body(const Slot* __restrict__ table, uint32_
     // statistics: one atomic per workgroup, spread over 64 counters that each own a 128-B line (same-line
     // atomics serialise in one L2 channel at ~10 ns apiece -- 9k of them used to cost more than the kernel)
     __shared__ unsigned long long vred[256 / 64];
-    {
+    if constexpr (LIO_KNN_STAT || COUNT) {
         __syncthreads();
         uint32_t te = threadIdx.x;
         asm volatile("" : "+v"(te));  // (the index is formed here: kept alive from the kernel's head to this tail it was spilled)
