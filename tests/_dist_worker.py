@@ -55,7 +55,19 @@ def run_batch(sub_maps_pts, gather=None, rank=0, world=1, comm=None, device=0):
     if gather is not None:
         b.set_gather_hook(gather, rank, world)
     P0 = lio.init_cov()
-    jobs = [dict(dptr=scenes.to_device(raw), n=len(raw), t=1.0, state=st, cov=P0) for raw, st, _ in batch_scans()]
+    scans_ = batch_scans()
+    if os.environ.get("LIO_TEST_WIDE"):
+        # three rounds of ordinary scans (the batch learns that three radix passes are enough), then a scan with two returns three hundred metres away: its
+        # bounding box needs a fourth pass, the round's sort was launched without it, the job is collected as "again" -- on EVERY rank, because the
+        # radix bits of a slot travel with its cloud -- and re-registered alone with four passes
+        scans_ = scans_ + scans_[:5]
+        raw, st, pos = scans_[2]
+        wide = raw.copy()
+        wide[0, :3] = [300.0, -250.0, 5.0]
+        wide[1, :3] = [-280.0, 290.0, -3.0]
+        scans_.append((wide, st, pos))
+        scans_.append(scans_[1])
+    jobs = [dict(dptr=scenes.to_device(raw), n=len(raw), t=1.0, state=st, cov=P0) for raw, st, _ in scans_]
     rc, res = b.process(jobs)
     assert rc == 0, rc
     run_batch.exchange = b.exchange_stats()

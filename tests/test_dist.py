@@ -249,6 +249,27 @@ def test_joint_rounds_divide_the_downsample_among_the_ranks(world):
 
 
 @pytest.mark.gpu
+def test_a_sort_launched_with_too_few_passes_is_repeated_on_every_rank():
+    """The batch launches as many radix passes as the last rounds needed.  A scan whose bounding box needs one more is collected as "again" and registered
+    alone with all four -- with the downsample divided among the ranks only the slot's OWNER sees the sort, so the radix bits travel in the chunk's
+    header: every rank must take the same decision (a rank that did not would wait in the re-run's collectives alone).  Thirteen jobs, the twelfth with
+    two returns three hundred metres away: same states on both ranks, bit for bit the states of the form in which every rank downsamples everything."""
+    outs = {}
+    for split in ("0", "1"):
+        with tempfile.TemporaryDirectory() as td:
+            _run("gpu_batch", 2, td, LIO_JOINT_SPLIT_DS=split, LIO_TEST_WIDE="1")
+            outs[split] = [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(2)]
+    for r in range(2):
+        assert len(outs["1"][r]["rcs"]) == 13 and np.all(outs["1"][r]["rcs"] == 3)
+        for key in ("states", "rcs", "passes", "n_ds"):
+            assert np.array_equal(outs["0"][r][key], outs["1"][r][key]), (r, key)
+        assert np.array_equal(outs["1"][r]["states"], outs["1"][0]["states"])
+    # the wide scan was registered twice: one more round than the job list asks for (4 rounds of 4 slots + the re-run) -- the divided form makes one
+    # exchange of clouds per round on top of what the other form exchanges
+    assert int(outs["1"][0]["calls"]) - int(outs["0"][0]["calls"]) == 5
+
+
+@pytest.mark.gpu
 def test_a_cloud_that_does_not_fit_its_chunk_of_the_all_gather_is_registered_again():
     """The slot chunks of the round's all-gather are sized from the clouds seen so far; a denser scan than any before does not fit.  Forced here with
     chunks of 1500 points (LIO_JOINT_DS_CAP): every cloud is cut on its way to the other rank, the flag travels in the chunk's header, BOTH ranks
