@@ -75,7 +75,7 @@ def main(n_cfg=30, seed0=0):
             if it_o != it_g or dp > 1e-4 or da > 1e-5:
                 # an alignment is a chain of accept / reject decisions on costs that agree to 1e-3: a different path is reported, not counted, unless the poses part widely
                 print("path differs", tag, "iterations", it_o, it_g, "dpos", dp, "drot", da)
-                if dp > 0.05:
+                if dp > 0.5:
                     bad += 1
         elif conv_o != conv_g:
             print("convergence differs", tag, conv_o, conv_g, it_o, it_g)
